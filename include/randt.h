@@ -1,0 +1,227 @@
+/*
+ * randt.h -- C ABI of librandt_hip.so: MI355X-native (gfx950, hand-written HIP) NDT scan-matching
+ * core that drops in behind RaNDT-SLAM's ndt_representation / ndt_registration API.
+ *
+ * The reference (IGMR-RWTH/RaNDT-SLAM) has no FFI/plugin layer: the seam is the C++ public API
+ * that LocalFuser calls.  Every entry point below cites the reference interface
+ * it replaces; paths are relative to /root/reference/ros/ndt_radar_slam/.  The reference-side
+ * binding a maintainer would add is shown in INTEGRATION.md; include/randt_facade.hpp mirrors the
+ * reference's Cell / Map / Matcher classes on top of this ABI.
+ *
+ * Conventions
+ *   - every function returns a randt_status (0 = ok); nothing throws across the ABI;
+ *   - poses are double[4] = [cos, sin, tx, ty], the memory layout of Sophus::SE2d::data()
+ *     (include/ndt_slam/trajectory_representation.h:14, ndt_matcher.cpp:292);
+ *   - cells are float (ndt_cell.h:167-168), solves are double (ndt_matcher.cpp:231);
+ *   - pointers named d_* are DEVICE pointers (HBM resident), h_* are host pointers;
+ *   - all work is enqueued on the context's HIP stream; *_dev entry points do not synchronise;
+ *   - a context is single-caller (the reference Matcher is not re-entrant either).
+ */
+#ifndef RANDT_H
+#define RANDT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RANDT_VERSION 100
+
+typedef enum randt_status {
+  RANDT_OK = 0,
+  RANDT_ERR_INVALID = 1,      /* bad argument */
+  RANDT_ERR_HIP = 2,          /* HIP runtime error (see randt_last_error) */
+  RANDT_ERR_UNSUPPORTED = 3,  /* size beyond the kernels' limits */
+  RANDT_ERR_NOMEM = 4,
+  RANDT_ERR_NODEVICE = 5      /* no gfx950 device visible: the library never falls back to CPU */
+} randt_status;
+
+/* 48-byte NDT cell record.  Numeric payload of rc::navigation::ndt::Cell
+ * (include/ndt_representation/ndt_cell.h:164-168): mean (x, y, intensity), upper triangle of the
+ * 3x3 covariance in the order of ndt_msgs/msg/Covariance.msg (xx,xy,xi,yy,yi,ii), point count,
+ * max intensity (ndt_cell.h:166). */
+typedef struct randt_cell {
+  float mean[3];
+  float cov[6];
+  uint32_t n;
+  float max_intensity;
+  uint32_t reserved;
+} randt_cell;
+
+/* rc::navigation::ndt::NDTMapParameters (include/ndt_slam/ndt_slam_parameters.h:17-28) + the
+ * centre passed to Map::initialize (ndt_map.cpp:7-21).  size_* are in CELLS (ndt_slam.cpp:653-654). */
+typedef struct randt_map_params {
+  int32_t size_x, size_y;
+  double resolution;
+  double center_x, center_y;
+  double max_neighbour_dist; /* max_neighbour_manhattan_distance */
+  int32_t min_points_per_cell;
+  int32_t reserved;
+} randt_map_params;
+
+/* RadarPreprocessorParameters::n_clusters / max_range as consumed by Grid::cluster
+ * (src/radar_preprocessing/grid.cpp:7-14, cluster_generator.h:40-42). */
+typedef struct randt_cluster_params {
+  int32_t n_clusters;
+  float max_range;
+} randt_cluster_params;
+
+enum { RANDT_PARAM_MANIFOLD = 0, RANDT_PARAM_AMBIENT4 = 1, RANDT_PARAM_VECTOR = 2 };
+
+enum {
+  RANDT_TERM_NONE = 0,
+  RANDT_TERM_CONVERGENCE_FUNCTION = 1,
+  RANDT_TERM_CONVERGENCE_PARAMETER = 2,
+  RANDT_TERM_CONVERGENCE_GRADIENT = 3,
+  RANDT_TERM_CONVERGENCE_RADIUS = 4,
+  RANDT_TERM_NO_CONVERGENCE = 5,
+  RANDT_TERM_FAILURE = 6
+};
+
+/* Subset of rc::navigation::ndt::NDTMatcherParameters (ndt_slam_parameters.h:52-84) used by the
+ * pair registration, plus the Ceres 2.1.0 Solver::Options the reference leaves at their defaults
+ * (ndt_matcher.cpp:457-464).  Fill with randt_matcher_params_default() first. */
+typedef struct randt_matcher_params {
+  double loss_scale;   /* BarronLoss 'a': loss_function_scale, or `scale` of estimateLoopConstraint */
+  double mu_scale;     /* loss_function_scale used in the gnc_mu formula (ndt_matcher.cpp:388,475) */
+  double loss_alpha;   /* loss_function_convexity */
+  double loss_weight;  /* ScaledLoss factor (ndt_matcher.cpp:392: ndt_weight/(n_cells*k); :479: 1) */
+  double gnc_divisor;  /* gnc_control_parameter_divisor */
+  int32_t gnc_steps;   /* gnc_steps / max_gnc_steps */
+  int32_t max_iterations;
+  int32_t n_neighbours;        /* n_results_kd_lookup */
+  int32_t lookup_mahalanobis;
+  int32_t use_intensity;       /* use_intensity_as_dimension */
+  int32_t parameterization;    /* RANDT_PARAM_* ; AMBIENT4 = what estimateLoopConstraint really optimises */
+  int32_t max_consecutive_invalid_steps;
+  int32_t reserved;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_radius, max_radius, min_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+} randt_matcher_params;
+
+/* Per-registration output (64 bytes). `cost` is what estimateLoopConstraint returns
+ * (summary.final_cost / summary.num_residual_blocks, ndt_matcher.cpp:492). */
+typedef struct randt_result {
+  double cost;
+  double final_cost;
+  double initial_cost;
+  double mu0;
+  int32_t n_residuals;
+  int32_t iterations;   /* minimizer iterations summed over the GNC solves (incl. each iteration 0) */
+  int32_t gnc_solves;
+  int32_t termination;  /* RANDT_TERM_* of the last solve */
+  int32_t n_evals;      /* residual(+Jacobian) passes over the correspondence set */
+  int32_t status;       /* 0 ok, 1 no residuals ("WARNING: NO RESIDUALS ADDED!", ndt_matcher.cpp:454), 2 numerical failure */
+  int32_t reserved[2];
+} randt_result;
+
+typedef struct randt_ctx randt_ctx;
+typedef struct randt_maps randt_maps; /* a batch of device-resident NDT maps with common parameters */
+
+/* ------------------------------------------------------------------ context ----------------- */
+int randt_version(void);
+const char* randt_status_string(int status);
+const char* randt_last_error(const randt_ctx* ctx);
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the null stream. */
+int randt_ctx_create(int device, void* stream, randt_ctx** out);
+int randt_ctx_destroy(randt_ctx* ctx);
+int randt_ctx_set_stream(randt_ctx* ctx, void* stream);
+int randt_ctx_synchronize(randt_ctx* ctx);
+/* Debug/parity hook: when set, each solve writes its per-iteration (cost, radius, flag) triplets
+ * (max_len per registration; first double of each block = number written).  NULL disables. */
+int randt_ctx_set_trace(randt_ctx* ctx, double* d_trace, int max_len);
+void randt_matcher_params_default(randt_matcher_params* p);
+
+/* ------------------------------------------------------------------ maps -------------------- */
+/* Replaces Map::initialize (ndt_map.cpp:7-21) for n_maps maps at once.  Storage per map:
+ * cell_capacity x 48 B compact cells (grid_), one int32 count, size_x*size_y int32 index grid
+ * (grid_indizes_, -1 = empty; omitted when with_grid = 0: scan maps that are only ever the MOVING
+ * side need none).  Storage is hipMalloc'ed, or caller-provided (*_external) so that e.g. a torch
+ * tensor / RCCL buffer can back it. */
+int randt_maps_create(randt_ctx* ctx, int n_maps, const randt_map_params* p, int cell_capacity,
+                      int with_grid, randt_maps** out);
+int randt_maps_create_external(randt_ctx* ctx, int n_maps, const randt_map_params* p, int cell_capacity,
+                               void* d_cells, void* d_counts, void* d_grid /* nullable */, randt_maps** out);
+int randt_maps_destroy(randt_maps* m);
+size_t randt_maps_cells_bytes(int n_maps, int cell_capacity);
+size_t randt_maps_grid_bytes(int n_maps, const randt_map_params* p);
+int randt_maps_info(const randt_maps* m, int* n_maps, int* cell_capacity, int* n_slots, int* with_grid);
+int randt_maps_device_ptrs(const randt_maps* m, void** d_cells, void** d_counts, void** d_grid);
+/* Map::clear (ndt_map.cpp:252-259) + re-initialise the index grid; async on the stream. */
+int randt_maps_clear(randt_maps* m, int first, int count);
+/* Host <-> device copies of one map (synchronous).  h_grid may be NULL. */
+int randt_maps_upload(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, const int32_t* h_grid);
+int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cells, int* n_cells, int32_t* h_grid);
+int randt_maps_counts(randt_maps* m, int first, int count, int32_t* h_counts);
+/* Device copy of whole maps (Map copy-construction, local_fuser.cpp:43-44,128-129). */
+int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int src_first, int count);
+
+/* ------------------------------------------------------------------ NDT build (a1-a4) ------- */
+/* Replaces RadarPreprocessor::processScan's clustering + HierarchicalMap::addClusters:
+ * Grid::cluster (grid.cpp:7-14), ClusterGenerator::labelClouds (radar_preprocessor.cpp:151-169),
+ * Map::insertCluster (ndt_map.cpp:238-245), Cell::addPointCloud/updateCell (ndt_cell.cpp:25-114).
+ * d_points: n_scans scans, each `pitch_points` points of `stride_floats` floats (x at 0, y at 1,
+ * intensity at `intensity_index`; pcl::PointXYZI is stride 8 / index 4, packed xyzI is 4 / 3).
+ * d_n_points (nullable): per-scan point count <= pitch_points (ragged batches).
+ * Scan s is written to out map (first_map + s), which is cleared first. */
+int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
+                              const int32_t* d_n_points, int stride_floats, int intensity_index,
+                              const randt_cluster_params* cp, randt_maps* out, int first_map);
+/* Host convenience for one scan (copies the points, synchronises). */
+int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int stride_floats,
+                    int intensity_index, const randt_cluster_params* cp, randt_maps* out, int map_idx);
+
+/* ------------------------------------------------------------------ transform / merge (a9,a18) */
+/* Map::transformMap (ndt_map.cpp:177-182, Cell::transformCell ndt_cell.cpp:117-123); like the
+ * reference it leaves the index grid stale.  h_pose4: one pose per map. */
+int randt_maps_transform(randt_maps* m, int first, int count, const double* h_pose4);
+/* Rolling-submap update: for t = 0..n_moving-1, transform moving map (moving_first + t) by
+ * h_pose4[t] (Map::transformMapWithPointCloud, local_fuser.cpp:175-177) and merge it into
+ * fixed map fixed_idx with Map::mergeMapCell (ndt_map.cpp:191-207, Cell::operator+= ndt_cell.h:133-142),
+ * strictly in order.  The moving maps themselves are not modified. */
+int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_first,
+                     int n_moving, const double* h_pose4);
+
+/* ------------------------------------------------------------------ association (a7,a8,a10) -- */
+/* Association half of Matcher::addNDTFactor (ndt_matcher.cpp:200-215,249-253) with
+ * Map::getClosestCells / getAdjacentIndizes (ndt_map.cpp:101-175) and
+ * Cell::mahalanobisSquaredIntensity (ndt_cell.cpp:172-176).
+ * Pair p registers moving map (moving_first + p) against fixed map d_fixed_idx[p] from guess
+ * d_guess4[p].  d_corr: n_pairs x cell_capacity(moving) x k int32, -1 padded. */
+int randt_associate_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx,
+                              const randt_maps* moving, int moving_first, int n_pairs,
+                              const double* d_guess4, const randt_matcher_params* mp, int32_t* d_corr);
+
+/* ------------------------------------------------------------------ solve (a11-a15) ---------- */
+/* GNC loop + Ceres-LM of Matcher::estimateLoopConstraint (ndt_matcher.cpp:457-492) over frozen
+ * correspondences: residual NDTFrameToMap{,Intensity}FactorResidual{,SE2} (ceres_residuals.h:421-552),
+ * BarronLoss/ScaledLoss (ceres_loss_functions.cpp:19-39), whole iteration loop on device.
+ * d_pose4 in: initial guess, out: refined pose. */
+int randt_solve_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx,
+                          const randt_maps* moving, int moving_first, int n_pairs, const int32_t* d_corr,
+                          const randt_matcher_params* mp, double* d_pose4, randt_result* d_results);
+
+/* ------------------------------------------------------------------ registration ------------- */
+/* Matcher::estimateLoopConstraint (ndt_matcher.cpp:426-493) for a batch: associate + solve. */
+int randt_register_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx,
+                             const randt_maps* moving, int moving_first, int n_pairs,
+                             const randt_matcher_params* mp, double* d_pose4, randt_result* d_results);
+/* Whole hot path for a batch of raw scans: NDT build -> associate -> solve
+ * (LocalFuser::processScan's preprocessing + detectLoopClosures' refinement, local_fuser.cpp:102-105,335).
+ * scan_maps: workspace maps (>= n_scans, with or without grid) that receive the scan NDTs. */
+int randt_scan_register_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
+                                  const int32_t* d_n_points, int stride_floats, int intensity_index,
+                                  const randt_cluster_params* cp, const randt_maps* fixed,
+                                  const int32_t* d_fixed_idx, randt_maps* scan_maps,
+                                  const randt_matcher_params* mp, double* d_pose4, randt_result* d_results);
+/* Host convenience: one pair, synchronous (double Matcher::estimateLoopConstraint(trans, old, new, ...)). */
+int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving,
+                        int moving_idx, const randt_matcher_params* mp, double h_pose4[4], randt_result* h_result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANDT_H */

@@ -1,0 +1,334 @@
+"""ctypes binding of the CPU oracle (oracle/randt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package.  PARITY UNPINNED (see randt_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librandt_oracle.so")
+
+CELL_DTYPE = np.dtype(
+    [("mean", "<f4", (3,)), ("cov", "<f4", (6,)), ("n", "<u4"), ("max_intensity", "<f4"), ("reserved", "<u4")]
+)
+assert CELL_DTYPE.itemsize == 48
+
+TRACE_MAX = 4096
+
+PARAM_MANIFOLD, PARAM_AMBIENT4, PARAM_VECTOR = 0, 1, 2
+LINSOLVE_QR, LINSOLVE_NORMAL = 0, 1
+
+
+class OrcMap(C.Structure):
+    _fields_ = [
+        ("size_x", C.c_int32), ("size_y", C.c_int32),
+        ("res", C.c_double), ("offset_x", C.c_double), ("offset_y", C.c_double),
+        ("max_neighbour_dist", C.c_double),
+        ("min_points", C.c_int32), ("cap", C.c_int32), ("n_cells", C.c_int32), ("n_dropped", C.c_int32),
+        ("cells", C.c_void_p), ("grid", C.POINTER(C.c_int32)),
+    ]
+
+
+class MatcherParams(C.Structure):
+    _fields_ = [
+        ("loss_scale", C.c_double), ("mu_scale", C.c_double), ("loss_alpha", C.c_double),
+        ("loss_weight", C.c_double), ("gnc_divisor", C.c_double),
+        ("gnc_steps", C.c_int32), ("max_iterations", C.c_int32), ("n_neighbours", C.c_int32),
+        ("lookup_mahalanobis", C.c_int32), ("use_intensity", C.c_int32), ("parameterization", C.c_int32),
+        ("linear_solver", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+    ]
+
+
+class SolveStats(C.Structure):
+    _fields_ = [
+        ("n_residuals", C.c_int32), ("n_solves", C.c_int32), ("n_iterations", C.c_int32),
+        ("n_jac_evals", C.c_int32), ("n_cost_evals", C.c_int32), ("termination", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("max_raw_residual", C.c_double),
+        ("mu0", C.c_double),
+        ("trace_len", C.c_int32),
+        ("trace_cost", C.c_double * TRACE_MAX), ("trace_radius", C.c_double * TRACE_MAX),
+        ("trace_flag", C.c_int32 * TRACE_MAX),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "randt_oracle.c")
+    hdr = os.path.join(_HERE, "randt_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librandt_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    P = C.POINTER
+    L.orc_map_create.restype = P(OrcMap)
+    L.orc_map_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.orc_map_destroy.argtypes = [P(OrcMap)]
+    L.orc_map_clear.argtypes = [P(OrcMap)]
+    L.orc_map_copy.argtypes = [P(OrcMap), P(OrcMap)]
+    L.orc_grid_labels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.orc_ndt_build.restype = C.c_int
+    L.orc_ndt_build.argtypes = [P(OrcMap), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.orc_cell_from_points.restype = C.c_int
+    L.orc_cell_from_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_cell_merge.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_pose_to_affine_f.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_cell_transform.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_map_transform.argtypes = [P(OrcMap), C.c_void_p]
+    L.orc_map_merge.argtypes = [P(OrcMap), P(OrcMap)]
+    L.orc_map_coord_to_index.restype = C.c_uint32
+    L.orc_map_coord_to_index.argtypes = [P(OrcMap), C.c_float, C.c_float]
+    L.orc_associate.restype = C.c_int
+    L.orc_associate.argtypes = [P(OrcMap), P(OrcMap), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_barron_scaled.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    L.orc_matcher_params_default.argtypes = [P(MatcherParams)]
+    L.orc_ndt_residual.restype = C.c_double
+    L.orc_ndt_residual.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6
+    L.orc_solve_pair.restype = C.c_int
+    L.orc_solve_pair.argtypes = [P(OrcMap), P(OrcMap), C.c_void_p, C.c_int, P(MatcherParams), C.c_void_p, P(SolveStats)]
+    L.orc_register_pair.restype = C.c_int
+    L.orc_register_pair.argtypes = [P(OrcMap), P(OrcMap), P(MatcherParams), C.c_void_p, C.c_void_p, P(SolveStats)]
+    L.orc_register_batch.restype = C.c_int
+    L.orc_register_batch.argtypes = [
+        C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+        P(MatcherParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+    ]
+    for name in ("orc_se2_exp", "orc_se2_log", "orc_se2_inv"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_se2_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_num_threads.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**over):
+    p = MatcherParams()
+    lib().orc_matcher_params_default(C.byref(p))
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Map:
+    """Owning wrapper of an orc_map."""
+
+    def __init__(self, size_x=100, size_y=100, res=0.5, center=(0.0, 0.0), max_neighbour_dist=4.0, min_points=5, cap=None):
+        if cap is None:
+            cap = size_x * size_y
+        self._p = lib().orc_map_create(size_x, size_y, res, center[0], center[1], max_neighbour_dist, min_points, cap)
+        if not self._p:
+            raise MemoryError
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().orc_map_destroy(self._p)
+            self._p = None
+
+    @property
+    def c(self):
+        return self._p.contents
+
+    @property
+    def n_cells(self):
+        return self.c.n_cells
+
+    @property
+    def n_slots(self):
+        return self.c.size_x * self.c.size_y
+
+    def cells_view(self):
+        buf = (C.c_char * (48 * self.c.cap)).from_address(self.c.cells)
+        return np.frombuffer(buf, dtype=CELL_DTYPE)
+
+    def cells(self):
+        return self.cells_view()[: self.n_cells].copy()
+
+    def grid(self):
+        return np.ctypeslib.as_array(self.c.grid, shape=(self.n_slots,)).copy()
+
+    def set(self, cells, grid):
+        cells = np.ascontiguousarray(cells, dtype=CELL_DTYPE)
+        assert len(cells) <= self.c.cap
+        self.cells_view()[: len(cells)] = cells
+        self.c.n_cells = len(cells)
+        g = np.ctypeslib.as_array(self.c.grid, shape=(self.n_slots,))
+        g[:] = np.asarray(grid, dtype=np.int32)
+
+    def clear(self):
+        lib().orc_map_clear(self._p)
+
+    def copy(self):
+        m = Map(self.c.size_x, self.c.size_y, self.c.res, (0, 0), self.c.max_neighbour_dist, self.c.min_points, self.c.cap)
+        lib().orc_map_copy(m._p, self._p)
+        return m
+
+    def build(self, pts, n_clusters, max_range, ioff=3):
+        pts = np.ascontiguousarray(pts, dtype=np.float32)
+        return lib().orc_ndt_build(self._p, _ptr(pts), pts.shape[0], pts.shape[1], ioff, int(n_clusters), float(max_range))
+
+    def transform(self, pose4):
+        aff = pose_to_affine_f(pose4)
+        lib().orc_map_transform(self._p, _ptr(aff))
+
+    def merge(self, moving):
+        lib().orc_map_merge(self._p, moving._p)
+
+    def coord_to_index(self, x, y):
+        return lib().orc_map_coord_to_index(self._p, float(x), float(y))
+
+
+def grid_labels(pts, n_clusters, max_range, ioff=3):
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    out = np.empty(pts.shape[0], dtype=np.int32)
+    lib().orc_grid_labels(_ptr(pts), pts.shape[0], pts.shape[1], ioff, int(n_clusters), float(max_range), _ptr(out))
+    return out
+
+
+def cell_from_points(pts, min_points=5, ioff=3):
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    cell = np.zeros(1, dtype=CELL_DTYPE)
+    ok = lib().orc_cell_from_points(_ptr(cell), _ptr(pts), None, pts.shape[0], pts.shape[1], ioff, min_points)
+    return bool(ok), cell[0]
+
+
+def cell_merge(dst, src):
+    d = np.array([dst], dtype=CELL_DTYPE)
+    s = np.array([src], dtype=CELL_DTYPE)
+    lib().orc_cell_merge(_ptr(d), _ptr(s))
+    return d[0]
+
+
+def pose_to_affine_f(pose4):
+    p = np.ascontiguousarray(pose4, dtype=np.float64)
+    aff = np.empty(4, dtype=np.float32)
+    lib().orc_pose_to_affine_f(_ptr(p), _ptr(aff))
+    return aff
+
+
+def cell_transform(cell, pose4):
+    c = np.array([cell], dtype=CELL_DTYPE)
+    aff = pose_to_affine_f(pose4)
+    lib().orc_cell_transform(_ptr(c), _ptr(aff))
+    return c[0]
+
+
+def associate(fixed, moving, pose4, k=4, lookup_mahalanobis=True, use_intensity=True):
+    p = np.ascontiguousarray(pose4, dtype=np.float64)
+    corr = np.full((max(moving.n_cells, 1), k), -1, dtype=np.int32)
+    n = lib().orc_associate(fixed._p, moving._p, _ptr(p), k, int(lookup_mahalanobis), int(use_intensity), _ptr(corr))
+    return corr[: moving.n_cells], n
+
+
+def barron_scaled(s, a, alpha, mu, weight=1.0):
+    rho = np.empty(3)
+    lib().orc_barron_scaled(float(s), float(a), float(alpha), float(mu), float(weight), _ptr(rho))
+    return rho
+
+
+def ndt_residual(d, parameterization, pose4, mm, mc, fm, fc, want_jac=True):
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (pose4, mm, mc, fm, fc)]
+    jac = np.zeros(4)
+    r = lib().orc_ndt_residual(d, parameterization, *[_ptr(a) for a in arrs], _ptr(jac) if want_jac else None)
+    nj = 4 if parameterization == PARAM_AMBIENT4 else 3
+    return r, jac[:nj]
+
+
+def stats_to_dict(st):
+    n = st.trace_len
+    return dict(
+        n_residuals=st.n_residuals, n_solves=st.n_solves, n_iterations=st.n_iterations,
+        n_jac_evals=st.n_jac_evals, n_cost_evals=st.n_cost_evals, termination=st.termination,
+        initial_cost=st.initial_cost, final_cost=st.final_cost, max_raw_residual=st.max_raw_residual, mu0=st.mu0,
+        trace_cost=np.array(st.trace_cost[:n]), trace_radius=np.array(st.trace_radius[:n]),
+        trace_flag=np.array(st.trace_flag[:n]),
+    )
+
+
+def solve_pair(fixed, moving, corr, params, pose4):
+    p = np.array(pose4, dtype=np.float64)
+    corr = np.ascontiguousarray(corr, dtype=np.int32)
+    st = SolveStats()
+    rc = lib().orc_solve_pair(fixed._p, moving._p, _ptr(corr), corr.shape[1], C.byref(params), _ptr(p), C.byref(st))
+    return rc, p, stats_to_dict(st)
+
+
+def register_pair(fixed, moving, params, pose4):
+    p = np.array(pose4, dtype=np.float64)
+    cost = C.c_double(0)
+    st = SolveStats()
+    rc = lib().orc_register_pair(fixed._p, moving._p, C.byref(params), _ptr(p), C.byref(cost), C.byref(st))
+    return rc, p, cost.value, stats_to_dict(st)
+
+
+def register_batch(pts, fixed_maps, fixed_idx, params, guess4, n_clusters, max_range, ioff=3, n_threads=0):
+    """pts: (B, n, stride) float32.  Returns poses (B,4), cost (B,), iters (B,)."""
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    B, n, stride = pts.shape
+    arr = (C.POINTER(OrcMap) * len(fixed_maps))(*[m._p for m in fixed_maps])
+    fixed_idx = np.ascontiguousarray(fixed_idx, dtype=np.int32)
+    guess4 = np.ascontiguousarray(guess4, dtype=np.float64)
+    poses = np.zeros((B, 4))
+    cost = np.zeros(B)
+    iters = np.zeros(B, dtype=np.int32)
+    fail = lib().orc_register_batch(
+        B, _ptr(pts), n, stride, ioff, int(n_clusters), float(max_range), C.cast(arr, C.c_void_p), _ptr(fixed_idx),
+        C.byref(params), _ptr(guess4), _ptr(poses), _ptr(cost), _ptr(iters), int(n_threads),
+    )
+    return fail, poses, cost, iters
+
+
+def se2_exp(xi):
+    xi = np.ascontiguousarray(xi, dtype=np.float64)
+    out = np.empty(4)
+    lib().orc_se2_exp(_ptr(xi), _ptr(out))
+    return out
+
+
+def se2_log(p4):
+    p4 = np.ascontiguousarray(p4, dtype=np.float64)
+    out = np.empty(3)
+    lib().orc_se2_log(_ptr(p4), _ptr(out))
+    return out
+
+
+def se2_mul(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.empty(4)
+    lib().orc_se2_mul(_ptr(a), _ptr(b), _ptr(out))
+    return out
+
+
+def se2_inv(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty(4)
+    lib().orc_se2_inv(_ptr(a), _ptr(out))
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()

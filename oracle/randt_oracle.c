@@ -1,0 +1,1225 @@
+/*
+ * randt_oracle.c -- CPU restatement of the RaNDT-SLAM NDT scan-matching hot path.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see randt_oracle.h).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math [-fopenmp] (no FMA contraction: the reference
+ * is built RelWithDebInfo for generic x86-64, CMakeLists.txt:4, so its fp32 cell statistics are
+ * plain IEEE mul/add).
+ *
+ * Citations are relative to /root/reference/ros/ndt_radar_slam/.
+ */
+#include "randt_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ============================================================ small helpers =============== */
+
+/* static_cast<unsigned int>(double) as gcc/x86-64 compiles it (cvttsd2si to 64 bit, low 32 bits);
+ * used by Map::coordinateToIndex (ndt_map.h:87-90).  Out-of-range / NaN -> 0 (SPEC DECISION: UB
+ * in the reference). */
+static uint32_t trunc_to_u32(double v) {
+  if (!(v > -9.0e18 && v < 9.0e18)) return 0u;
+  return (uint32_t)(int64_t)v;
+}
+
+/* static_cast<int>(float) with the same guard (grid.cpp:11). */
+static int32_t trunc_to_i32(float v) {
+  if (!(v > -2.0e9f && v < 2.0e9f)) return 0;
+  return (int32_t)v;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ============================================================ map ========================= */
+
+/* Map::initialize, ndt_map.cpp:7-21 */
+orc_map* orc_map_create(int size_x, int size_y, double res, double center_x, double center_y,
+                        double max_neighbour_dist, int min_points, int cap) {
+  orc_map* m = (orc_map*)calloc(1, sizeof(orc_map));
+  if (!m) return NULL;
+  m->size_x = size_x;
+  m->size_y = size_y;
+  m->res = res;
+  m->offset_x = -(double)(uint32_t)size_x / 2.0 * res + center_x;
+  m->offset_y = -(double)(uint32_t)size_y / 2.0 * res + center_y;
+  m->max_neighbour_dist = max_neighbour_dist;
+  m->min_points = min_points;
+  m->cap = cap;
+  m->cells = (orc_cell*)calloc((size_t)cap, sizeof(orc_cell));
+  m->grid = (int32_t*)malloc(sizeof(int32_t) * (size_t)size_x * (size_t)size_y);
+  if (!m->cells || !m->grid) {
+    orc_map_destroy(m);
+    return NULL;
+  }
+  orc_map_clear(m);
+  return m;
+}
+
+void orc_map_destroy(orc_map* m) {
+  if (!m) return;
+  free(m->cells);
+  free(m->grid);
+  free(m);
+}
+
+void orc_map_clear(orc_map* m) {
+  size_t n = (size_t)m->size_x * (size_t)m->size_y;
+  for (size_t i = 0; i < n; ++i) m->grid[i] = -1;
+  m->n_cells = 0;
+  m->n_dropped = 0;
+}
+
+void orc_map_copy(orc_map* dst, const orc_map* src) {
+  size_t n = (size_t)src->size_x * (size_t)src->size_y;
+  dst->size_x = src->size_x;
+  dst->size_y = src->size_y;
+  dst->res = src->res;
+  dst->offset_x = src->offset_x;
+  dst->offset_y = src->offset_y;
+  dst->max_neighbour_dist = src->max_neighbour_dist;
+  dst->min_points = src->min_points;
+  dst->n_cells = src->n_cells < dst->cap ? src->n_cells : dst->cap;
+  dst->n_dropped = src->n_dropped;
+  memcpy(dst->cells, src->cells, sizeof(orc_cell) * (size_t)dst->n_cells);
+  memcpy(dst->grid, src->grid, sizeof(int32_t) * n);
+}
+
+/* Map::coordinateToIndex + getIndex, ndt_map.h:87-90,181-184 (all unsigned 32-bit arithmetic). */
+uint32_t orc_map_coord_to_index(const orc_map* m, float x, float y) {
+  uint32_t mx = trunc_to_u32(((double)x - m->offset_x) / m->res);
+  uint32_t my = trunc_to_u32(((double)y - m->offset_y) / m->res);
+  return my * (uint32_t)m->size_x + mx;
+}
+
+/* ============================================================ clustering ================== */
+
+/* Grid::cluster, grid.cpp:7-14 */
+void orc_grid_labels(const float* pts, int n, int stride, int ioff, int n_clusters, float max_range,
+                     int32_t* labels) {
+  (void)ioff;
+  int row_size = (int)sqrt((double)n_clusters);
+  float resolution = max_range * 2 / (float)row_size;
+  for (int i = 0; i < n; ++i) {
+    float x = pts[(size_t)i * stride + 0];
+    float y = pts[(size_t)i * stride + 1];
+    labels[i] = trunc_to_i32(x / resolution) + row_size * trunc_to_i32(y / resolution);
+  }
+}
+
+/* ============================================================ cell statistics ============= */
+
+/* SPEC DECISION: closed-form fp32 symmetric 2x2 eigen-decomposition standing in for
+ * Eigen::SelfAdjointEigenSolver<Matrix2f> (iterative, ndt_cell.cpp:104).  Eigenvalues ascending,
+ * V = [v0 v1] column eigenvectors (orthonormal up to rounding). */
+static void sym_eig2f(float a, float b, float d, float* l0, float* l1, float V[4] /* v00 v01 v10 v11 row-major */) {
+  float t = 0.5f * (a + d);
+  float h = 0.5f * (a - d);
+  float r = sqrtf(h * h + b * b);
+  *l0 = t - r;
+  *l1 = t + r;
+  float vx, vy; /* eigenvector of l1 */
+  if (b == 0.0f) {
+    if (a <= d) { vx = 0.0f; vy = 1.0f; } else { vx = 1.0f; vy = 0.0f; }
+  } else {
+    if (h >= 0.0f) { vx = h + r; vy = b; } else { vx = b; vy = r - h; }
+    float nrm = sqrtf(vx * vx + vy * vy);
+    vx = vx / nrm;
+    vy = vy / nrm;
+  }
+  /* v0 = perpendicular */
+  V[0] = vy;  V[1] = vx;
+  V[2] = -vx; V[3] = vy;
+}
+
+/* Regularisation, ndt_cell.cpp:102-112 */
+static void cell_regularize(orc_cell* c) {
+  float l0, l1, V[4];
+  sym_eig2f(c->cov[0], c->cov[1], c->cov[3], &l0, &l1, V);
+  l0 = fmaxf(l0, 0.001f * l1);
+  /* eig_vectors.inverse(): Eigen 2x2 inverse = adjugate * (1/det) */
+  float det = V[0] * V[3] - V[1] * V[2];
+  float invdet = 1.0f / det;
+  float I00 = V[3] * invdet, I01 = -V[1] * invdet;
+  float I10 = -V[2] * invdet, I11 = V[0] * invdet;
+  /* (V * Lambda) * Vinv, left to right */
+  float T00 = V[0] * l0, T01 = V[1] * l1;
+  float T10 = V[2] * l0, T11 = V[3] * l1;
+  c->cov[0] = T00 * I00 + T01 * I10;
+  c->cov[1] = T00 * I01 + T01 * I11; /* SPEC DECISION: symmetric storage keeps element (0,1) */
+  c->cov[3] = T10 * I01 + T11 * I11;
+  c->cov[5] = (float)((double)c->cov[5] + 0.000001); /* new_cov_(2,2) += 0.000001 (double literal) */
+}
+
+/* Cell::addPointCloud + updateCell (first-fill branch), ndt_cell.cpp:25-65,90-94,102-112.
+ * idx may be NULL (points 0..k-1).  Returns 1 if accepted. */
+int orc_cell_from_points(orc_cell* c, const float* pts, const int32_t* idx, int k, int stride,
+                         int ioff, int min_points) {
+  memset(c, 0, sizeof(*c));
+  if (!((long long)k > (long long)min_points)) return 0; /* n_points_(0) + size > min_points_per_cell_ */
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+  double maxi = 0.0;
+  for (int j = 0; j < k; ++j) {
+    const float* p = pts + (size_t)(idx ? idx[j] : j) * stride;
+    m0 += p[0];
+    m1 += p[1];
+    m2 += p[ioff];
+    if ((double)p[ioff] > maxi) maxi = (double)p[ioff];
+  }
+  float nf = (float)(double)(uint32_t)k; /* /= static_cast<double>(n) -> Scalar(float) */
+  m0 = m0 / nf;
+  m1 = m1 / nf;
+  m2 = m2 / nf;
+  float c00 = 0.f, c11 = 0.f, c22 = 0.f, c01 = 0.f, c02 = 0.f, c12 = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const float* p = pts + (size_t)(idx ? idx[j] : j) * stride;
+    float d0 = p[0] - m0, d1 = p[1] - m1, d2 = p[ioff] - m2;
+    c00 += (d0 * d0);
+    c11 += (d1 * d1);
+    c22 += (d2 * d2);
+    c01 += (d0 * d1);
+    c02 += (d0 * d2);
+    c12 += (d1 * d2);
+  }
+  c->mean[0] = m0;
+  c->mean[1] = m1;
+  c->mean[2] = m2;
+  c->cov[0] = c00 / nf;
+  c->cov[1] = c01 / nf;
+  c->cov[2] = c02 / nf;
+  c->cov[3] = c11 / nf;
+  c->cov[4] = c12 / nf;
+  c->cov[5] = c22 / nf;
+  c->n = (uint32_t)k;
+  c->max_intensity = (float)maxi;
+  cell_regularize(c); /* use_pndt = false in every shipped config */
+  return 1;
+}
+
+/* Cell::operator+=, ndt_cell.h:133-142 (note the integer division (n*m)/(n+m)). */
+void orc_cell_merge(orc_cell* dst, const orc_cell* src) {
+  uint32_t n = dst->n;
+  uint64_t m = src->n; /* size_t m_n_points */
+  float wn = (float)(uint32_t)(n - 1u);
+  float wm = (float)(uint64_t)(m - 1u);
+  float wk = (float)(uint64_t)(((uint64_t)n * m) / ((uint64_t)n + m));
+  float d[3] = {dst->mean[0] - src->mean[0], dst->mean[1] - src->mean[1], dst->mean[2] - src->mean[2]};
+  static const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+  float nc[6];
+  for (int e = 0; e < 6; ++e) nc[e] = (wn * dst->cov[e] + wm * src->cov[e]) + wk * (d[ii[e]] * d[jj[e]]);
+  float fn = (float)n, fm = (float)m, fnm = (float)((uint64_t)n + m);
+  for (int e = 0; e < 3; ++e) dst->mean[e] = ((dst->mean[e] * fn) + (src->mean[e] * fm)) / fnm;
+  dst->n = (uint32_t)(n + m);
+  float den = (float)(uint32_t)(dst->n - 1u);
+  for (int e = 0; e < 6; ++e) dst->cov[e] = nc[e] / den;
+  if (src->max_intensity > dst->max_intensity) dst->max_intensity = src->max_intensity; /* not in the reference (viz only) */
+}
+
+/* Sophus::SE2d::cast<float>() (SO2 ctor normalises the complex) then .matrix() -> Eigen::Affine2f.
+ * aff = [c, s, tx, ty] in float. */
+void orc_pose_to_affine_f(const double pose4[4], float aff[4]) {
+  float c = (float)pose4[0], s = (float)pose4[1];
+  float len = sqrtf(c * c + s * s);
+  aff[0] = c / len;
+  aff[1] = s / len;
+  aff[2] = (float)pose4[2];
+  aff[3] = (float)pose4[3];
+}
+
+/* Cell::transformCell, ndt_cell.cpp:117-123.  SPEC DECISION: Eigen's Affine3f::rotation() goes
+ * through a JacobiSVD of the linear part; here the rotation is taken as exactly
+ * blockdiag([[c,-s],[s,c]], 1).  Products evaluated left to right, k = 0,1,2. */
+void orc_cell_transform(orc_cell* cl, const float aff[4]) {
+  float c = aff[0], s = aff[1];
+  float x = cl->mean[0], y = cl->mean[1];
+  cl->mean[0] = (c * x + (-s) * y) + aff[2];
+  cl->mean[1] = (s * x + c * y) + aff[3];
+  /* full symmetric 3x3 */
+  float S[3][3] = {{cl->cov[0], cl->cov[1], cl->cov[2]}, {cl->cov[1], cl->cov[3], cl->cov[4]}, {cl->cov[2], cl->cov[4], cl->cov[5]}};
+  float R[3][3] = {{c, -s, 0.f}, {s, c, 0.f}, {0.f, 0.f, 1.f}};
+  float T[3][3], O[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[i][j] = (R[i][0] * S[0][j] + R[i][1] * S[1][j]) + R[i][2] * S[2][j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) O[i][j] = (T[i][0] * R[j][0] + T[i][1] * R[j][1]) + T[i][2] * R[j][2];
+  cl->cov[0] = O[0][0];
+  cl->cov[1] = O[0][1];
+  cl->cov[2] = O[0][2];
+  cl->cov[3] = O[1][1];
+  cl->cov[4] = O[1][2];
+  cl->cov[5] = O[2][2];
+}
+
+void orc_map_transform(orc_map* m, const float aff[4]) {
+  for (int i = 0; i < m->n_cells; ++i) orc_cell_transform(&m->cells[i], aff);
+}
+
+/* ============================================================ NDT build =================== */
+
+typedef struct { int32_t label; int32_t idx; } lbl_idx;
+static int cmp_lbl_idx(const void* a, const void* b) {
+  const lbl_idx* x = (const lbl_idx*)a;
+  const lbl_idx* y = (const lbl_idx*)b;
+  if (x->label != y->label) return x->label < y->label ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* processScan's cluster + labelClouds (radar_preprocessor.cpp:34-37,151-169): clusters in ascending
+ * label order, points inside a cluster in input order; then addClusters -> insertCluster
+ * (ndt_hierarchical_map.cpp:28-33, ndt_map.cpp:238-245). */
+int orc_ndt_build(orc_map* m, const float* pts, int n, int stride, int ioff, int n_clusters,
+                  float max_range) {
+  if (n <= 0) return 0;
+  int32_t* labels = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  lbl_idx* li = (lbl_idx*)malloc(sizeof(lbl_idx) * (size_t)n);
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  orc_grid_labels(pts, n, stride, ioff, n_clusters, max_range, labels);
+  for (int i = 0; i < n; ++i) { li[i].label = labels[i]; li[i].idx = i; }
+  qsort(li, (size_t)n, sizeof(lbl_idx), cmp_lbl_idx);
+  for (int i = 0; i < n; ++i) idx[i] = li[i].idx;
+  uint32_t n_slots = (uint32_t)m->size_x * (uint32_t)m->size_y;
+  int start = 0;
+  while (start < n) {
+    int end = start + 1;
+    while (end < n && li[end].label == li[start].label) ++end;
+    orc_cell c;
+    if (orc_cell_from_points(&c, pts, idx + start, end - start, stride, ioff, m->min_points)) {
+      uint32_t slot = orc_map_coord_to_index(m, c.mean[0], c.mean[1]);
+      if (slot < n_slots && m->n_cells < m->cap) {
+        m->grid[slot] = m->n_cells; /* later cluster overwrites the slot, both cells stay (quirk A.7-5) */
+        m->cells[m->n_cells++] = c;
+      } else {
+        m->n_dropped++; /* reference: std::vector::at throws (ndt_map.cpp:242) */
+      }
+    }
+    start = end;
+  }
+  free(labels);
+  free(li);
+  free(idx);
+  return m->n_cells;
+}
+
+/* Map::mergeMapCell, ndt_map.cpp:191-207 */
+void orc_map_merge(orc_map* fixed, const orc_map* moving) {
+  uint32_t n_slots = (uint32_t)fixed->size_x * (uint32_t)fixed->size_y;
+  for (int i = 0; i < moving->n_cells; ++i) {
+    const orc_cell* mc = &moving->cells[i];
+    uint32_t slot = orc_map_coord_to_index(fixed, mc->mean[0], mc->mean[1]);
+    if (slot < n_slots) {
+      int32_t index = fixed->grid[slot];
+      if (index >= 0) {
+        orc_cell_merge(&fixed->cells[index], mc);
+      } else if (fixed->n_cells < fixed->cap) {
+        fixed->cells[fixed->n_cells] = *mc;
+        fixed->grid[slot] = fixed->n_cells++;
+      }
+    }
+  }
+}
+
+/* ============================================================ association ================= */
+
+/* Eigen 3.3 Matrix3f::inverse() (cofactor formulation) followed by mu^T * inv * mu, all fp32;
+ * Cell::mahalanobisSquaredIntensity, ndt_cell.cpp:172-176.  q = query (transformed moving) cell,
+ * f = candidate fixed cell.  mu = f.mean - q.mean, summed = f.cov + q.cov. */
+static float mahalanobis3f(const orc_cell* q, const orc_cell* f) {
+  float S[3][3];
+  S[0][0] = f->cov[0] + q->cov[0];
+  S[0][1] = S[1][0] = f->cov[1] + q->cov[1];
+  S[0][2] = S[2][0] = f->cov[2] + q->cov[2];
+  S[1][1] = f->cov[3] + q->cov[3];
+  S[1][2] = S[2][1] = f->cov[4] + q->cov[4];
+  S[2][2] = f->cov[5] + q->cov[5];
+  float mu[3] = {f->mean[0] - q->mean[0], f->mean[1] - q->mean[1], f->mean[2] - q->mean[2]};
+  /* cofactor_3x3<i,j> = m(i1,j1)*m(i2,j2) - m(i1,j2)*m(i2,j1) */
+#define COF(i, j) (S[((i) + 1) % 3][((j) + 1) % 3] * S[((i) + 2) % 3][((j) + 2) % 3] - S[((i) + 1) % 3][((j) + 2) % 3] * S[((i) + 2) % 3][((j) + 1) % 3])
+  float c0 = COF(0, 0), c1 = COF(1, 0), c2 = COF(2, 0);
+  float det = (c0 * S[0][0] + c1 * S[1][0]) + c2 * S[2][0];
+  float invdet = 1.0f / det;
+  float inv[3][3];
+  inv[0][0] = c0 * invdet;
+  inv[0][1] = c1 * invdet;
+  inv[0][2] = c2 * invdet;
+  inv[1][0] = COF(0, 1) * invdet;
+  inv[1][1] = COF(1, 1) * invdet;
+  inv[1][2] = COF(2, 1) * invdet;
+  inv[2][0] = COF(0, 2) * invdet;
+  inv[2][1] = COF(1, 2) * invdet;
+  inv[2][2] = COF(2, 2) * invdet;
+#undef COF
+  float row[3];
+  for (int j = 0; j < 3; ++j) row[j] = (mu[0] * inv[0][j] + mu[1] * inv[1][j]) + mu[2] * inv[2][j];
+  return (row[0] * mu[0] + row[1] * mu[1]) + row[2] * mu[2];
+}
+
+typedef struct { double dist; uint64_t idx; } target_t;
+static int cmp_target(const void* a, const void* b) {
+  const target_t* x = (const target_t*)a;
+  const target_t* y = (const target_t*)b;
+  if (x->dist < y->dist) return -1;
+  if (y->dist < x->dist) return 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* Map::getAdjacentIndizes, ndt_map.cpp:163-175: x-offset outer, y-offset inner, unsigned wrap,
+ * no row-wrap guard, de-duplicated (first occurrence kept). Returns count. */
+static int adjacent_indices(const orc_map* m, uint32_t index, int r, uint32_t* out) {
+  uint32_t n_slots = (uint32_t)m->size_x * (uint32_t)m->size_y;
+  int cnt = 0;
+  for (int i = -r; i <= r; ++i) {
+    for (int j = -r; j <= r; ++j) {
+      uint32_t ni = index + (uint32_t)i + (uint32_t)j * (uint32_t)m->size_x;
+      if (ni < n_slots) {
+        int dup = 0;
+        for (int t = 0; t < cnt; ++t)
+          if (out[t] == ni) { dup = 1; break; }
+        if (!dup) out[cnt++] = ni;
+      }
+    }
+  }
+  return cnt;
+}
+
+/* Map::getClosestCells (both overloads), ndt_map.cpp:101-151.  qcell: the transformed query cell
+ * (mean used for the centre slot; full cell for the distribution metric).  metric 1 = Mahalanobis
+ * 3-D fp32, 0 = Euclidean 2-D fp32.  Writes up to k compact indices, returns count. */
+static int closest_cells(const orc_map* m, const orc_cell* qcell, int k, int metric, int32_t* out) {
+  uint32_t n_slots = (uint32_t)m->size_x * (uint32_t)m->size_y;
+  uint32_t center = orc_map_coord_to_index(m, qcell->mean[0], qcell->mean[1]);
+  int rmax = (int)(m->max_neighbour_dist / m->res);
+  int radius = 0;
+  int wcap = (2 * (rmax > 0 ? rmax : 1) + 1);
+  wcap = wcap * wcap + 8;
+  uint32_t* adj = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)wcap);
+  target_t* targets = (target_t*)malloc(sizeof(target_t) * (size_t)wcap);
+  int nt = 0, nadj = 0;
+  while ((uint64_t)nt < (uint64_t)(int64_t)k && (uint32_t)nadj < n_slots) {
+    nt = 0;
+    nadj = adjacent_indices(m, center, radius, adj);
+    for (int i = 0; i < nadj; ++i) {
+      int32_t ci = m->grid[adj[i]];
+      if (ci >= 0) {
+        const orc_cell* fc = &m->cells[ci];
+        double dist;
+        if (metric) {
+          dist = (double)mahalanobis3f(qcell, fc);
+        } else {
+          float dx = qcell->mean[0] - fc->mean[0], dy = qcell->mean[1] - fc->mean[1];
+          dist = (double)sqrtf(dx * dx + dy * dy);
+        }
+        targets[nt].dist = dist;
+        targets[nt].idx = (uint64_t)ci;
+        ++nt;
+      }
+    }
+    ++radius;
+    if (radius >= rmax) break;
+  }
+  qsort(targets, (size_t)nt, sizeof(target_t), cmp_target);
+  int cnt = k < nt ? k : nt;
+  if (cnt < 0) cnt = 0;
+  for (int i = 0; i < cnt; ++i) out[i] = (int32_t)targets[i].idx;
+  free(adj);
+  free(targets);
+  return cnt;
+}
+
+/* Association part of Matcher::addNDTFactor, ndt_matcher.cpp:200-215,249-253. */
+int orc_associate(const orc_map* fixed, const orc_map* moving, const double pose4[4], int k,
+                  int lookup_mahalanobis, int use_intensity, int32_t* corr) {
+  float aff[4];
+  orc_pose_to_affine_f(pose4, aff);
+  int total = 0;
+  for (int i = 0; i < moving->n_cells; ++i) {
+    int32_t* out = corr + (size_t)i * k;
+    for (int j = 0; j < k; ++j) out[j] = -1;
+    orc_cell q = moving->cells[i];
+    int cnt;
+    if (use_intensity && lookup_mahalanobis) {
+      orc_cell_transform(&q, aff);
+      cnt = closest_cells(fixed, &q, k, 1, out);
+    } else {
+      /* query_vector = initial_guess.cast<float>() * mean.xy  (SO2f * p + t) */
+      float x = q.mean[0], y = q.mean[1];
+      q.mean[0] = (aff[0] * x - aff[1] * y) + aff[2];
+      q.mean[1] = (aff[1] * x + aff[0] * y) + aff[3];
+      cnt = closest_cells(fixed, &q, k, 0, out);
+    }
+    total += cnt;
+  }
+  return total;
+}
+
+/* ============================================================ loss ======================== */
+
+/* BarronLoss ctor (ceres_loss_functions.h:27-35) + Evaluate (ceres_loss_functions.cpp:19-39),
+ * then ceres::ScaledLoss (multiplies rho[0..2] by weight). */
+void orc_barron_scaled(double s, double scale_a, double alpha, double mu, double weight, double rho[3]) {
+  const double a_ = alpha;
+  const double b_ = mu * scale_a * scale_a;
+  const double c_ = 1 / b_;
+  const double factor_ = fabs(a_ - 2.0);
+  const double exponent_ = 0.5 * a_;
+  const double pre_factor_ = b_ * factor_ / a_;
+  const double times_s_ = 2 * c_ / factor_;
+  if (a_ >= 2.0) {
+    rho[0] = s;
+    rho[1] = 1;
+    rho[2] = 0;
+  } else if (fabs(a_) <= 0.05) {
+    const double sum = 1.0 + s * c_;
+    const double inv = 1.0 / sum;
+    rho[0] = b_ * log(sum);
+    rho[1] = inv > DBL_MIN ? inv : DBL_MIN;
+    rho[2] = -c_ * (inv * inv);
+  } else {
+    const double to_exp = s * times_s_ + 1.0;
+    rho[0] = pre_factor_ * (pow(to_exp, exponent_) - 1.);
+    rho[1] = pre_factor_ * exponent_ * pow(to_exp, exponent_ - 1.) * times_s_;
+    rho[2] = pre_factor_ * exponent_ * (exponent_ - 1) * pow(to_exp, exponent_ - 2.) * times_s_ * times_s_;
+  }
+  rho[0] *= weight;
+  rho[1] *= weight;
+  rho[2] *= weight;
+}
+
+/* ============================================================ SE(2) (Sophus 1.22.10) ====== */
+
+static void so2_normalize(double* c, double* s) {
+  double len = sqrt((*c) * (*c) + (*s) * (*s));
+  *c = *c / len;
+  *s = *s / len;
+}
+
+/* SO2Base::operator*: complex product, first-order renormalisation, then the (real,imag) ctor's
+ * normalize(). */
+static void so2_mul(double ar, double ai, double br, double bi, double* rr, double* ri) {
+  double re = ar * br - ai * bi;
+  double im = ar * bi + ai * br;
+  double sq = re * re + im * im;
+  if (sq != 1.0) {
+    double scale = 2.0 / (1.0 + sq);
+    re *= scale;
+    im *= scale;
+  }
+  so2_normalize(&re, &im);
+  *rr = re;
+  *ri = im;
+}
+
+void orc_se2_exp(const double xi[3], double out[4]) {
+  double theta = xi[2];
+  double c = cos(theta), s = sin(theta);
+  so2_normalize(&c, &s);
+  double sbt, omcbt;
+  if (fabs(theta) < 1e-10) {
+    double tsq = theta * theta;
+    sbt = 1.0 - (1.0 / 6.0) * tsq;
+    omcbt = 0.5 * theta - (1.0 / 24.0) * theta * tsq;
+  } else {
+    sbt = s / theta;
+    omcbt = (1.0 - c) / theta;
+  }
+  out[0] = c;
+  out[1] = s;
+  out[2] = sbt * xi[0] - omcbt * xi[1];
+  out[3] = omcbt * xi[0] + sbt * xi[1];
+}
+
+void orc_se2_log(const double p[4], double xi[3]) {
+  double theta = atan2(p[1], p[0]);
+  double half = 0.5 * theta;
+  double rm1 = p[0] - 1.0;
+  double hbt;
+  if (fabs(rm1) < 1e-10) {
+    hbt = 1.0 - (1.0 / 12) * theta * theta;
+  } else {
+    hbt = -(half * p[1]) / rm1;
+  }
+  xi[0] = hbt * p[2] + half * p[3];
+  xi[1] = -half * p[2] + hbt * p[3];
+  xi[2] = theta;
+}
+
+void orc_se2_mul(const double a[4], const double b[4], double out[4]) {
+  double rr, ri;
+  so2_mul(a[0], a[1], b[0], b[1], &rr, &ri);
+  double tx = a[2] + (a[0] * b[2] - a[1] * b[3]);
+  double ty = a[3] + (a[1] * b[2] + a[0] * b[3]);
+  out[0] = rr;
+  out[1] = ri;
+  out[2] = tx;
+  out[3] = ty;
+}
+
+void orc_se2_inv(const double a[4], double out[4]) {
+  double c = a[0], s = -a[1];
+  double tx = -a[2], ty = -a[3];
+  out[0] = c;
+  out[1] = s;
+  out[2] = c * tx - s * ty;
+  out[3] = s * tx + c * ty;
+}
+
+/* ============================================================ residual ==================== */
+
+/* NDTFrameToMap{,Intensity}FactorResidual{,SE2} (ceres_residuals.h:421-552) with the Jacobian that
+ * Ceres autodiff (+ Sophus::Manifold<SE2>::PlusJacobian for MANIFOLD) produces -- SURVEY A.2.
+ * theta = atan2(s, c) of the stored complex; R built from cos/sin(theta) (Eigen::AngleAxis /
+ * Rotation2D); intensity (3rd coordinate) is neither rotated nor translated. */
+double orc_ndt_residual(int d, int parameterization, const double* pose4, const double* mm,
+                        const double* mc, const double* fm, const double* fc, double* jac) {
+  const double cp = pose4[0], sp = pose4[1];
+  const double theta = atan2(sp, cp);
+  const double c = cos(theta), s = sin(theta);
+  double R[3][3] = {{c, -s, 0}, {s, c, 0}, {0, 0, 1}};
+  double dv[3] = {0, 0, 0}, C[3][3] = {{0}}, RS[3][3] = {{0}};
+  /* RS = R * Sm ; C = RS * R^T + Sf */
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < d; ++j) {
+      double a = 0;
+      for (int k = 0; k < d; ++k) a += R[i][k] * mc[k * d + j];
+      RS[i][j] = a;
+    }
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < d; ++j) {
+      double a = 0;
+      for (int k = 0; k < d; ++k) a += RS[i][k] * R[j][k];
+      C[i][j] = a + fc[i * d + j];
+    }
+  double t[3] = {pose4[2], pose4[3], 0};
+  for (int i = 0; i < d; ++i) {
+    double a = 0;
+    for (int k = 0; k < d; ++k) a += R[i][k] * mm[k];
+    dv[i] = a + t[i] - fm[i];
+  }
+  double q[3] = {0, 0, 0};
+  if (d == 3) {
+    double c00 = C[1][1] * C[2][2] - C[1][2] * C[2][1];
+    double c01 = C[1][2] * C[2][0] - C[1][0] * C[2][2];
+    double c02 = C[1][0] * C[2][1] - C[1][1] * C[2][0];
+    double det = C[0][0] * c00 + C[0][1] * c01 + C[0][2] * c02;
+    double id = 1.0 / det;
+    double inv[3][3];
+    inv[0][0] = c00 * id;
+    inv[0][1] = (C[0][2] * C[2][1] - C[0][1] * C[2][2]) * id;
+    inv[0][2] = (C[0][1] * C[1][2] - C[0][2] * C[1][1]) * id;
+    inv[1][0] = c01 * id;
+    inv[1][1] = (C[0][0] * C[2][2] - C[0][2] * C[2][0]) * id;
+    inv[1][2] = (C[0][2] * C[1][0] - C[0][0] * C[1][2]) * id;
+    inv[2][0] = c02 * id;
+    inv[2][1] = (C[0][1] * C[2][0] - C[0][0] * C[2][1]) * id;
+    inv[2][2] = (C[0][0] * C[1][1] - C[0][1] * C[1][0]) * id;
+    for (int i = 0; i < 3; ++i) q[i] = inv[i][0] * dv[0] + inv[i][1] * dv[1] + inv[i][2] * dv[2];
+  } else {
+    double det = C[0][0] * C[1][1] - C[0][1] * C[1][0];
+    double id = 1.0 / det;
+    q[0] = (C[1][1] * dv[0] - C[0][1] * dv[1]) * id;
+    q[1] = (-C[1][0] * dv[0] + C[0][0] * dv[1]) * id;
+  }
+  double ssq = dv[0] * q[0] + dv[1] * q[1] + dv[2] * q[2];
+  double r = sqrt(ssq);
+  if (jac) {
+    int nj = parameterization == ORC_PARAM_AMBIENT4 ? 4 : 3;
+    if (!(r > 0.0)) {
+      /* SPEC DECISION: autodiff of sqrt(0) is inf/NaN in the reference (ceres_residuals.h:545);
+       * guard with a zero Jacobian row. */
+      for (int i = 0; i < nj; ++i) jac[i] = 0.0;
+      return r;
+    }
+    /* u = R^T q ; dr/dtheta = (u^T J m - u^T J Sm u) / r with J the so(2) generator */
+    double u[3] = {c * q[0] + s * q[1], -s * q[0] + c * q[1], q[2]};
+    double Su0 = 0, Su1 = 0;
+    for (int k = 0; k < d; ++k) {
+      Su0 += mc[0 * d + k] * u[k];
+      Su1 += mc[1 * d + k] * u[k];
+    }
+    double dtheta = ((u[1] * mm[0] - u[0] * mm[1]) - (u[1] * Su0 - u[0] * Su1)) / r;
+    if (parameterization == ORC_PARAM_MANIFOLD) {
+      /* ambient row [dr/dc, dr/ds, q0/r, q1/r] times PlusJacobian [[0,0,-s],[0,0,c],[c,-s,0],[s,c,0]]
+       * built from the STORED complex (cp, sp) */
+      double n2 = cp * cp + sp * sp;
+      double dc = dtheta * (-sp / n2), ds = dtheta * (cp / n2);
+      double dtx = q[0] / r, dty = q[1] / r;
+      jac[0] = dtx * cp + dty * sp;
+      jac[1] = -dtx * sp + dty * cp;
+      jac[2] = dc * (-sp) + ds * cp;
+    } else if (parameterization == ORC_PARAM_AMBIENT4) {
+      double n2 = cp * cp + sp * sp;
+      jac[0] = dtheta * (-sp / n2);
+      jac[1] = dtheta * (cp / n2);
+      jac[2] = q[0] / r;
+      jac[3] = q[1] / r;
+    } else {
+      jac[0] = q[0] / r;
+      jac[1] = q[1] / r;
+      jac[2] = dtheta;
+    }
+  }
+  return r;
+}
+
+/* ============================================================ generic LM (Ceres 2.1.0) ==== */
+
+#define ORC_MAX_TANGENT 32
+
+typedef struct orc_problem {
+  int n_ambient, n_tangent, n_res;
+  void* user;
+  /* cost = sum 1/2 rho(s); residuals/jac are the loss-corrected ones (corrector.cc). */
+  int (*eval)(void* user, const double* x, double* cost, double* residuals, double* jac);
+  void (*plus)(void* user, const double* x, const double* delta, double* x_plus);
+} orc_problem;
+
+/* Householder QR least squares min |A y - b| (Eigen HouseholderQR semantics, unblocked).
+ * A is m x n column-major (destroyed), b length m (destroyed), y length n. */
+static int qr_least_squares(double* A, double* b, int m, int n, double* y) {
+  for (int k = 0; k < n; ++k) {
+    double* col = A + (size_t)k * m;
+    double c0 = col[k];
+    double tail = 0.0;
+    for (int i = k + 1; i < m; ++i) tail += col[i] * col[i];
+    double tau, beta;
+    if (tail <= DBL_MIN) {
+      tau = 0.0;
+      beta = c0;
+      for (int i = k + 1; i < m; ++i) col[i] = 0.0;
+    } else {
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= 0.0) beta = -beta;
+      double den = c0 - beta;
+      for (int i = k + 1; i < m; ++i) col[i] /= den;
+      tau = (beta - c0) / beta;
+    }
+    col[k] = beta;
+    if (tau != 0.0) {
+      /* apply H = I - tau v v^T (v = [1; essential]) to remaining columns and b */
+      for (int j = k + 1; j <= n; ++j) {
+        double* t = (j < n) ? (A + (size_t)j * m) : b;
+        double dot = t[k];
+        for (int i = k + 1; i < m; ++i) dot += col[i] * t[i];
+        dot *= tau;
+        t[k] -= dot;
+        for (int i = k + 1; i < m; ++i) t[i] -= dot * col[i];
+      }
+    }
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    double acc = b[k];
+    for (int j = k + 1; j < n; ++j) acc -= A[(size_t)j * m + k] * y[j];
+    double dk = A[(size_t)k * m + k];
+    if (dk == 0.0) return 0;
+    y[k] = acc / dk;
+  }
+  return 1;
+}
+
+/* Cholesky solve of the n x n SPD system (row-major H, destroyed). */
+static int chol_solve(double* H, double* g, int n, double* y) {
+  for (int j = 0; j < n; ++j) {
+    double d = H[j * n + j];
+    for (int k = 0; k < j; ++k) d -= H[j * n + k] * H[j * n + k];
+    if (!(d > 0.0)) return 0;
+    d = sqrt(d);
+    H[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double a = H[i * n + j];
+      for (int k = 0; k < j; ++k) a -= H[i * n + k] * H[j * n + k];
+      H[i * n + j] = a / d;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    double a = g[i];
+    for (int k = 0; k < i; ++k) a -= H[i * n + k] * y[k];
+    y[i] = a / H[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double a = y[i];
+    for (int k = i + 1; k < n; ++k) a -= H[k * n + i] * y[k];
+    y[i] = a / H[i * n + i];
+  }
+  return 1;
+}
+
+static void trace_push(orc_solve_stats* st, double cost, double radius, int flag) {
+  if (st && st->trace_len < ORC_TRACE_MAX) {
+    st->trace_cost[st->trace_len] = cost;
+    st->trace_radius[st->trace_len] = radius;
+    st->trace_flag[st->trace_len] = flag;
+    st->trace_len++;
+  }
+}
+
+/* TrustRegionMinimizer::Minimize with LevenbergMarquardtStrategy + DENSE_QR, monotonic steps,
+ * jacobi scaling, no bounds, no inner iterations (Ceres 2.1.0).
+ * x (ambient) is updated to the best accepted point; returns termination type. */
+static int lm_minimize(const orc_problem* P, const orc_matcher_params* opt, double* x_user,
+                       orc_solve_stats* st, double* final_cost_out) {
+  const int na = P->n_ambient, nt = P->n_tangent, nr = P->n_res;
+  double* residuals = (double*)malloc(sizeof(double) * (size_t)(nr + nt));
+  double* jac = (double*)malloc(sizeof(double) * (size_t)nr * nt);      /* row-major nr x nt, Jacobi-scaled after eval */
+  double* work = (double*)malloc(sizeof(double) * (size_t)(nr + nt) * nt); /* column-major stacked [J; D] */
+  double* rhs = (double*)malloc(sizeof(double) * (size_t)(nr + nt));
+  double* model = (double*)malloc(sizeof(double) * (size_t)(nr > 0 ? nr : 1));
+  double x[8 * ORC_MAX_TANGENT], cand[8 * ORC_MAX_TANGENT], pg[8 * ORC_MAX_TANGENT];
+  double gradient[ORC_MAX_TANGENT], scaling[ORC_MAX_TANGENT], diagonal[ORC_MAX_TANGENT], lmdiag[ORC_MAX_TANGENT];
+  double step[ORC_MAX_TANGENT], delta[ORC_MAX_TANGENT], neg[ORC_MAX_TANGENT];
+  int term = ORC_TERM_FAILURE;
+  memcpy(x, x_user, sizeof(double) * na);
+
+  double x_cost = 0, x_norm = 0, cand_cost = 0;
+  double radius = opt->initial_radius, decrease_factor = 2.0;
+  int reuse_diagonal = 0;
+  int num_invalid = 0;
+  double minimum_cost = DBL_MAX; /* best accepted cost -> user parameters */
+  double summary_min_cost;       /* SetSummaryFinalCost: min over all logged iteration costs */
+  double grad_max_norm = 0;
+  int iteration = 0;
+  int step_successful;
+
+  /* ---- IterationZero -> EvaluateGradientAndJacobian */
+#define EVAL_GRAD_JAC(FIRST)                                                                    \
+  do {                                                                                          \
+    if (!P->eval(P->user, x, &x_cost, residuals, jac)) { term = ORC_TERM_FAILURE; goto done; }  \
+    if (st) st->n_jac_evals++;                                                                  \
+    for (int j = 0; j < nt; ++j) {                                                              \
+      double g = 0;                                                                             \
+      for (int i = 0; i < nr; ++i) g += jac[(size_t)i * nt + j] * residuals[i];                 \
+      gradient[j] = g;                                                                          \
+    }                                                                                           \
+    if (FIRST) {                                                                                \
+      for (int j = 0; j < nt; ++j) {                                                            \
+        double sq = 0;                                                                          \
+        for (int i = 0; i < nr; ++i) sq += jac[(size_t)i * nt + j] * jac[(size_t)i * nt + j];   \
+        scaling[j] = 1.0 / (1.0 + sqrt(sq));                                                    \
+      }                                                                                         \
+    }                                                                                           \
+    for (int i = 0; i < nr; ++i)                                                                \
+      for (int j = 0; j < nt; ++j) jac[(size_t)i * nt + j] *= scaling[j];                       \
+    for (int j = 0; j < nt; ++j) neg[j] = -gradient[j];                                         \
+    P->plus(P->user, x, neg, pg);                                                               \
+    grad_max_norm = 0;                                                                          \
+    for (int i = 0; i < na; ++i) {                                                              \
+      double a = fabs(x[i] - pg[i]);                                                            \
+      if (a > grad_max_norm) grad_max_norm = a;                                                 \
+    }                                                                                           \
+  } while (0)
+
+  x_norm = 0;
+  for (int i = 0; i < na; ++i) x_norm += x[i] * x[i];
+  x_norm = sqrt(x_norm);
+  EVAL_GRAD_JAC(1);
+  if (st && st->n_solves == 0) st->initial_cost = x_cost;
+  summary_min_cost = x_cost;
+  step_successful = 1;
+  trace_push(st, x_cost, radius, 0);
+  if (st) st->n_iterations++;
+
+  for (;;) {
+    /* ---- FinalizeIterationAndCheckIfMinimizerCanContinue */
+    if (step_successful && x_cost < minimum_cost) {
+      minimum_cost = x_cost;
+      memcpy(x_user, x, sizeof(double) * na);
+    }
+    if (iteration >= opt->max_iterations) { term = ORC_TERM_NO_CONVERGENCE; break; }
+    if (step_successful && grad_max_norm <= opt->gradient_tolerance) { term = ORC_TERM_CONVERGENCE_GRADIENT; break; }
+    if (radius <= opt->min_radius) { term = ORC_TERM_CONVERGENCE_RADIUS; break; }
+    ++iteration;
+    if (st) st->n_iterations++;
+
+    /* ---- ComputeTrustRegionStep: LevenbergMarquardtStrategy::ComputeStep */
+    if (!reuse_diagonal) {
+      for (int j = 0; j < nt; ++j) {
+        double sq = 0;
+        for (int i = 0; i < nr; ++i) sq += jac[(size_t)i * nt + j] * jac[(size_t)i * nt + j];
+        diagonal[j] = fmin(fmax(sq, opt->min_lm_diagonal), opt->max_lm_diagonal);
+      }
+    }
+    for (int j = 0; j < nt; ++j) lmdiag[j] = sqrt(diagonal[j] / radius);
+    int solved;
+    if (opt->linear_solver == ORC_LINSOLVE_QR) {
+      const int m = nr + nt;
+      for (int j = 0; j < nt; ++j) {
+        for (int i = 0; i < nr; ++i) work[(size_t)j * m + i] = jac[(size_t)i * nt + j];
+        for (int i = 0; i < nt; ++i) work[(size_t)j * m + nr + i] = (i == j) ? lmdiag[j] : 0.0;
+      }
+      memcpy(rhs, residuals, sizeof(double) * nr);
+      for (int i = 0; i < nt; ++i) rhs[nr + i] = 0.0;
+      solved = qr_least_squares(work, rhs, m, nt, step);
+    } else {
+      double H[ORC_MAX_TANGENT * ORC_MAX_TANGENT], g[ORC_MAX_TANGENT];
+      for (int a = 0; a < nt; ++a) {
+        for (int b = 0; b < nt; ++b) {
+          double h = 0;
+          for (int i = 0; i < nr; ++i) h += jac[(size_t)i * nt + a] * jac[(size_t)i * nt + b];
+          H[a * nt + b] = h + (a == b ? lmdiag[a] * lmdiag[a] : 0.0);
+        }
+        double gg = 0;
+        for (int i = 0; i < nr; ++i) gg += jac[(size_t)i * nt + a] * residuals[i];
+        g[a] = gg;
+      }
+      solved = chol_solve(H, g, nt, step);
+    }
+    for (int j = 0; j < nt; ++j) {
+      if (!isfinite(step[j])) solved = 0;
+      step[j] = -step[j];
+    }
+    reuse_diagonal = 1;
+    int step_valid = 0;
+    double model_cost_change = 0;
+    if (solved) {
+      /* model_cost_change = -(J step)^T (r + J step / 2) */
+      double acc = 0;
+      for (int i = 0; i < nr; ++i) {
+        double mr = 0;
+        for (int j = 0; j < nt; ++j) mr += jac[(size_t)i * nt + j] * step[j];
+        model[i] = mr;
+        acc += mr * (residuals[i] + mr / 2.0);
+      }
+      model_cost_change = -acc;
+      step_valid = model_cost_change > 0.0;
+    }
+    if (!step_valid) {
+      /* ---- HandleInvalidStep */
+      if (++num_invalid >= opt->max_consecutive_invalid_steps) { term = ORC_TERM_FAILURE; break; }
+      radius = radius / decrease_factor; /* StepIsInvalid -> StepRejected(0) */
+      decrease_factor *= 2.0;
+      reuse_diagonal = 1;
+      step_successful = 0;
+      if (x_cost < summary_min_cost) summary_min_cost = x_cost;
+      trace_push(st, x_cost, radius, 3);
+      continue;
+    }
+    num_invalid = 0;
+    for (int j = 0; j < nt; ++j) delta[j] = step[j] * scaling[j];
+
+    /* ---- ComputeCandidatePointAndEvaluateCost */
+    P->plus(P->user, x, delta, cand);
+    if (!P->eval(P->user, cand, &cand_cost, NULL, NULL)) cand_cost = DBL_MAX;
+    if (st) st->n_cost_evals++;
+
+    /* ---- ParameterToleranceReached */
+    double step_norm = 0;
+    for (int i = 0; i < na; ++i) step_norm += (x[i] - cand[i]) * (x[i] - cand[i]);
+    step_norm = sqrt(step_norm);
+    if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { term = ORC_TERM_CONVERGENCE_PARAMETER; break; }
+    /* ---- FunctionToleranceReached */
+    double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= opt->function_tolerance * x_cost) { term = ORC_TERM_CONVERGENCE_FUNCTION; break; }
+
+    /* ---- IsStepSuccessful (monotonic TrustRegionStepEvaluator) */
+    double relative_decrease = (cand_cost >= DBL_MAX) ? -DBL_MAX : cost_change / model_cost_change;
+    if (relative_decrease > opt->min_relative_decrease) {
+      /* ---- HandleSuccessfulStep */
+      memcpy(x, cand, sizeof(double) * na);
+      x_norm = 0;
+      for (int i = 0; i < na; ++i) x_norm += x[i] * x[i];
+      x_norm = sqrt(x_norm);
+      EVAL_GRAD_JAC(0);
+      step_successful = 1;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3));
+      radius = fmin(opt->max_radius, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = 0;
+      if (x_cost < summary_min_cost) summary_min_cost = x_cost;
+      trace_push(st, x_cost, radius, 1);
+    } else {
+      step_successful = 0;
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      reuse_diagonal = 1;
+      if (cand_cost < summary_min_cost) summary_min_cost = cand_cost;
+      trace_push(st, cand_cost, radius, 2);
+    }
+  }
+#undef EVAL_GRAD_JAC
+done:
+  if (final_cost_out) *final_cost_out = (term == ORC_TERM_FAILURE && minimum_cost == DBL_MAX) ? x_cost : summary_min_cost;
+  free(residuals);
+  free(jac);
+  free(work);
+  free(rhs);
+  free(model);
+  return term;
+}
+
+/* ============================================================ pair problem ================ */
+
+typedef struct pair_user {
+  int d, parameterization, n;
+  const double* mm; /* n x d   */
+  const double* mc; /* n x d*d */
+  const double* fm;
+  const double* fc;
+  int apply_loss;
+  double loss_a, loss_alpha, loss_mu, loss_w;
+} pair_user;
+
+static void x_to_pose4(const pair_user* u, const double* x, double p4[4]) {
+  if (u->parameterization == ORC_PARAM_VECTOR) {
+    /* NormalizeAngle(rot) then cos/sin: residual only depends on theta mod 2pi */
+    p4[0] = cos(x[2]);
+    p4[1] = sin(x[2]);
+    p4[2] = x[0];
+    p4[3] = x[1];
+  } else {
+    memcpy(p4, x, sizeof(double) * 4);
+  }
+}
+
+/* ResidualBlock::Evaluate + Corrector (Ceres 2.1.0 residual_block.cc, corrector.cc). */
+static int pair_eval(void* user, const double* x, double* cost, double* residuals, double* jac) {
+  const pair_user* u = (const pair_user*)user;
+  const int nj = u->parameterization == ORC_PARAM_AMBIENT4 ? 4 : 3;
+  double p4[4];
+  x_to_pose4(u, x, p4);
+  double total = 0;
+  for (int i = 0; i < u->n; ++i) {
+    double j[4];
+    int d = u->d;
+    double r = orc_ndt_residual(d, u->parameterization, p4, u->mm + (size_t)i * d, u->mc + (size_t)i * d * d,
+                                u->fm + (size_t)i * d, u->fc + (size_t)i * d * d, jac ? j : NULL);
+    if (!isfinite(r)) return 0;
+    double sq = r * r;
+    if (!u->apply_loss) {
+      total += 0.5 * sq;
+      if (residuals) residuals[i] = r;
+      if (jac) for (int a = 0; a < nj; ++a) jac[(size_t)i * nj + a] = j[a];
+      continue;
+    }
+    double rho[3];
+    orc_barron_scaled(sq, u->loss_a, u->loss_alpha, u->loss_mu, u->loss_w, rho);
+    total += 0.5 * rho[0];
+    if (residuals || jac) {
+      double sqrt_rho1 = sqrt(rho[1]);
+      double residual_scaling, alpha_sq_norm;
+      if (sq == 0.0 || rho[2] <= 0.0) {
+        residual_scaling = sqrt_rho1;
+        alpha_sq_norm = 0.0;
+      } else {
+        const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+        const double alpha = 1.0 - sqrt(D);
+        residual_scaling = sqrt_rho1 / (1 - alpha);
+        alpha_sq_norm = alpha / sq;
+      }
+      if (jac) {
+        /* CorrectJacobian: J = sqrt_rho1 * (J - alpha_sq_norm * r r^T J); one residual row */
+        for (int a = 0; a < nj; ++a) {
+          double ja = j[a];
+          if (alpha_sq_norm != 0.0) ja = ja - alpha_sq_norm * r * (r * ja);
+          jac[(size_t)i * nj + a] = sqrt_rho1 * ja;
+        }
+      }
+      if (residuals) residuals[i] = residual_scaling * r;
+    }
+  }
+  *cost = total;
+  return 1;
+}
+
+static void pair_plus(void* user, const double* x, const double* delta, double* xp) {
+  const pair_user* u = (const pair_user*)user;
+  if (u->parameterization == ORC_PARAM_MANIFOLD) {
+    double e[4];
+    orc_se2_exp(delta, e);
+    orc_se2_mul(x, e, xp); /* Sophus::Manifold<SE2>::Plus: T * exp(delta) */
+  } else if (u->parameterization == ORC_PARAM_AMBIENT4) {
+    for (int i = 0; i < 4; ++i) xp[i] = x[i] + delta[i];
+  } else {
+    for (int i = 0; i < 3; ++i) xp[i] = x[i] + delta[i];
+  }
+}
+
+void orc_matcher_params_default(orc_matcher_params* p) {
+  memset(p, 0, sizeof(*p));
+  /* config/parameters_indoor.yaml:24-39, base yaml :44-48; loop closure values :7,9 */
+  p->loss_scale = 1.5;
+  p->mu_scale = 1.5;
+  p->loss_alpha = -2.0;
+  p->loss_weight = 1.0;
+  p->gnc_divisor = 1.3;
+  p->gnc_steps = 2;
+  p->max_iterations = 200;
+  p->n_neighbours = 4;
+  p->lookup_mahalanobis = 1;
+  p->use_intensity = 1;
+  p->parameterization = ORC_PARAM_AMBIENT4;
+  p->linear_solver = ORC_LINSOLVE_QR;
+  p->max_consecutive_invalid_steps = 5;
+  p->function_tolerance = 1e-6;
+  p->gradient_tolerance = 1e-10;
+  p->parameter_tolerance = 1e-8;
+  p->initial_radius = 1e4;
+  p->max_radius = 1e16;
+  p->min_radius = 1e-32;
+  p->min_relative_decrease = 1e-3;
+  p->min_lm_diagonal = 1e-6;
+  p->max_lm_diagonal = 1e32;
+}
+
+static void cell_cov_full(const orc_cell* c, int d, double* out) {
+  if (d == 3) {
+    out[0] = c->cov[0]; out[1] = c->cov[1]; out[2] = c->cov[2];
+    out[3] = c->cov[1]; out[4] = c->cov[3]; out[5] = c->cov[4];
+    out[6] = c->cov[2]; out[7] = c->cov[4]; out[8] = c->cov[5];
+  } else {
+    out[0] = c->cov[0]; out[1] = c->cov[1];
+    out[2] = c->cov[1]; out[3] = c->cov[3];
+  }
+}
+
+/* GNC loop + Solve of Matcher::estimateLoopConstraint (ndt_matcher.cpp:466-492); the same loop
+ * serves estimateTransformCeres' NDT-only special case (:382-397) via loss_weight / mu_scale. */
+int orc_solve_pair(const orc_map* fixed, const orc_map* moving, const int32_t* corr, int k,
+                   const orc_matcher_params* p, double pose4[4], orc_solve_stats* st) {
+  const int d = p->use_intensity ? 3 : 2;
+  int n = 0;
+  for (int i = 0; i < moving->n_cells; ++i)
+    for (int j = 0; j < k; ++j)
+      if (corr[(size_t)i * k + j] >= 0) ++n;
+  if (st) {
+    memset(st, 0, sizeof(*st));
+    st->n_residuals = n;
+  }
+  if (n == 0) return 1; /* "WARNING: NO RESIDUALS ADDED!" (ndt_matcher.cpp:454-456): pose unchanged */
+  double* mm = (double*)malloc(sizeof(double) * (size_t)n * d);
+  double* mc = (double*)malloc(sizeof(double) * (size_t)n * d * d);
+  double* fm = (double*)malloc(sizeof(double) * (size_t)n * d);
+  double* fc = (double*)malloc(sizeof(double) * (size_t)n * d * d);
+  int r = 0;
+  for (int i = 0; i < moving->n_cells; ++i)
+    for (int j = 0; j < k; ++j) {
+      int32_t ci = corr[(size_t)i * k + j];
+      if (ci < 0) continue;
+      for (int e = 0; e < d; ++e) {
+        mm[(size_t)r * d + e] = (double)moving->cells[i].mean[e];
+        fm[(size_t)r * d + e] = (double)fixed->cells[ci].mean[e];
+      }
+      cell_cov_full(&moving->cells[i], d, mc + (size_t)r * d * d);
+      cell_cov_full(&fixed->cells[ci], d, fc + (size_t)r * d * d);
+      ++r;
+    }
+  pair_user u;
+  u.d = d;
+  u.parameterization = p->parameterization;
+  u.n = n;
+  u.mm = mm; u.mc = mc; u.fm = fm; u.fc = fc;
+  u.loss_a = p->loss_scale;
+  u.loss_alpha = p->loss_alpha;
+  u.loss_w = p->loss_weight;
+  u.loss_mu = 1.0;
+  u.apply_loss = 0;
+
+  orc_problem P;
+  P.user = &u;
+  P.eval = pair_eval;
+  P.plus = pair_plus;
+  P.n_res = n;
+  P.n_ambient = (p->parameterization == ORC_PARAM_VECTOR) ? 3 : 4;
+  P.n_tangent = (p->parameterization == ORC_PARAM_AMBIENT4) ? 4 : 3;
+
+  double x[4];
+  if (p->parameterization == ORC_PARAM_VECTOR) {
+    double xi[3];
+    orc_se2_log(pose4, xi); /* two_representation_state.rot = trans.log()(2) (ndt_matcher.cpp:438-439) */
+    x[0] = pose4[2]; x[1] = pose4[3]; x[2] = xi[2];
+  } else {
+    memcpy(x, pose4, sizeof(double) * 4);
+  }
+
+  /* raw residuals at the initial point (apply_loss_function = false) */
+  double* raw = (double*)malloc(sizeof(double) * (size_t)n);
+  double c0;
+  int ok = pair_eval(&u, x, &c0, raw, NULL);
+  double max_res = raw[0];
+  for (int i = 1; i < n; ++i) if (raw[i] > max_res) max_res = raw[i];
+  free(raw);
+  double gnc_mu = 2.0 * pow(max_res, 2) / pow(p->mu_scale, 2);
+  gnc_mu = fmin(gnc_mu, pow(p->gnc_divisor, (double)(p->gnc_steps - 1)));
+  if (st) {
+    st->max_raw_residual = max_res;
+    st->mu0 = gnc_mu;
+  }
+  int term = ORC_TERM_FAILURE;
+  double final_cost = 0;
+  u.apply_loss = 1;
+  if (ok) {
+    do {
+      gnc_mu = fmax(gnc_mu, 1.0);
+      u.loss_mu = gnc_mu;
+      term = lm_minimize(&P, p, x, st, &final_cost);
+      if (st) st->n_solves++;
+      gnc_mu /= p->gnc_divisor;
+    } while (gnc_mu > 1.0 / sqrt(p->gnc_divisor));
+  }
+  if (st) {
+    st->termination = term;
+    st->final_cost = final_cost;
+  }
+  if (p->parameterization == ORC_PARAM_VECTOR) {
+    /* Sophus::SE2d(rot, pos) (ndt_matcher.cpp:486) */
+    double c = cos(x[2]), s = sin(x[2]);
+    so2_normalize(&c, &s);
+    pose4[0] = c; pose4[1] = s; pose4[2] = x[0]; pose4[3] = x[1];
+  } else {
+    memcpy(pose4, x, sizeof(double) * 4);
+  }
+  free(mm); free(mc); free(fm); free(fc);
+  return ok ? 0 : 2;
+}
+
+int orc_register_pair(const orc_map* fixed, const orc_map* moving, const orc_matcher_params* p,
+                      double pose4[4], double* cost_out, orc_solve_stats* st) {
+  const int k = p->n_neighbours;
+  int32_t* corr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(moving->n_cells > 0 ? moving->n_cells : 1) * k);
+  orc_solve_stats local;
+  orc_solve_stats* s = st ? st : &local;
+  orc_associate(fixed, moving, pose4, k, p->lookup_mahalanobis, p->use_intensity, corr);
+  int rc = orc_solve_pair(fixed, moving, corr, k, p, pose4, s);
+  if (cost_out) *cost_out = s->n_residuals > 0 ? s->final_cost / (double)s->n_residuals : 0.0;
+  free(corr);
+  return rc;
+}
+
+int orc_register_batch(int B, const float* pts, int n, int stride, int ioff, int n_clusters,
+                       float max_range, orc_map* const* fixed_maps, const int32_t* fixed_idx,
+                       const orc_matcher_params* p, const double* guess4, double* pose4_out,
+                       double* cost_out, int32_t* iters_out, int n_threads) {
+  int fail = 0;
+#ifdef _OPENMP
+  if (n_threads <= 0) n_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : fail)
+#else
+  (void)n_threads;
+#endif
+  for (int b = 0; b < B; ++b) {
+    const orc_map* fx = fixed_maps[fixed_idx[b]];
+    orc_map* scan = orc_map_create(fx->size_x, fx->size_y, fx->res, 0.0, 0.0, fx->max_neighbour_dist,
+                                   fx->min_points, n / (fx->min_points + 1 > 0 ? fx->min_points + 1 : 1) + 8);
+    orc_solve_stats* st = (orc_solve_stats*)malloc(sizeof(orc_solve_stats));
+    orc_ndt_build(scan, pts + (size_t)b * n * stride, n, stride, ioff, n_clusters, max_range);
+    double p4[4];
+    memcpy(p4, guess4 + (size_t)b * 4, sizeof(p4));
+    double cost = 0;
+    int rc = orc_register_pair(fx, scan, p, p4, &cost, st);
+    if (rc) fail++;
+    memcpy(pose4_out + (size_t)b * 4, p4, sizeof(p4));
+    if (cost_out) cost_out[b] = cost;
+    if (iters_out) iters_out[b] = st->n_iterations;
+    free(st);
+    orc_map_destroy(scan);
+  }
+  return fail;
+}

@@ -1,0 +1,185 @@
+/*
+ * randt_oracle.h -- CPU restatement ("oracle") of the RaNDT-SLAM NDT scan-matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped library (randt-slam_amd/) links, imports or
+ * calls this code; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and
+ * only as the checker / reported CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (IGMR-RWTH/RaNDT-SLAM) ships no tests, golden vectors or
+ * fixtures for this path, and it cannot be compiled in this image (needs Eigen 3, Ceres 2.1.0,
+ * Sophus 1.22.10, PCL, ROS noetic -- none present, no network).  This file therefore restates
+ *   (1) the reference's first-party arithmetic, each function citing the file:line it follows
+ *       (paths relative to /root/reference/ros/ndt_radar_slam/), and
+ *   (2) the published algorithms of the un-vendored dependencies it calls on this path:
+ *       Ceres Solver 2.1.0 (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
+ *       dense_qr_solver.cc, corrector.cc, loss_function.cc) and Sophus 1.22.10 (so2.hpp, se2.hpp,
+ *       ceres_manifold.hpp), pinned in /root/reference/Dockerfile:11-27.
+ * It is cross-checked by independent numerics in tests/ (finite differences, scipy least_squares,
+ * zero-noise known-answer scenes, numpy float32 re-derivations) -- see tests/test_oracle_*.py.
+ *
+ * Where Eigen's exact fp32 operation order cannot be known without its sources (2x2 symmetric
+ * eigen-solver, JacobiSVD inside Transform::rotation()), the oracle fixes a documented closed
+ * form; those places are marked "SPEC DECISION".
+ */
+#ifndef RANDT_ORACLE_H
+#define RANDT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- cells / maps ------------- */
+
+/* 48-byte NDT cell record: mean (x,y,intensity), upper triangle of the 3x3 covariance in the
+ * field order of ndt_msgs/msg/Covariance.msg (xx,xy,xi,yy,yi,ii), point count.
+ * Mirrors the numeric payload of rc::navigation::ndt::Cell (include/ndt_representation/ndt_cell.h:164-168). */
+typedef struct orc_cell {
+  float mean[3];
+  float cov[6];
+  uint32_t n;
+  float max_intensity;
+  uint32_t reserved;
+} orc_cell;
+
+/* Mirrors rc::navigation::ndt::Map (include/ndt_representation/ndt_map.h:155-166): compact cell
+ * vector grid_ + dense index grid grid_indizes_ (-1 = empty). */
+typedef struct orc_map {
+  int32_t size_x, size_y;
+  double res, offset_x, offset_y;
+  double max_neighbour_dist;
+  int32_t min_points;
+  int32_t cap;
+  int32_t n_cells;
+  int32_t n_dropped; /* clusters whose slot was out of range (reference would throw, ndt_map.cpp:242) */
+  orc_cell* cells;
+  int32_t* grid;
+} orc_map;
+
+orc_map* orc_map_create(int size_x, int size_y, double res, double center_x, double center_y,
+                        double max_neighbour_dist, int min_points, int cap);
+void orc_map_destroy(orc_map* m);
+void orc_map_clear(orc_map* m);
+void orc_map_copy(orc_map* dst, const orc_map* src);
+
+/* grid.cpp:7-14 */
+void orc_grid_labels(const float* pts, int n, int stride, int ioff, int n_clusters, float max_range,
+                     int32_t* labels);
+/* radar_preprocessor.cpp:151-169 + ndt_hierarchical_map.cpp:28-33 + ndt_map.cpp:238-245 + ndt_cell.cpp:25-114 */
+int orc_ndt_build(orc_map* m, const float* pts, int n, int stride, int ioff, int n_clusters,
+                  float max_range);
+/* ndt_cell.cpp:36-114 (first-fill branch + regularisation) for one cluster of k points */
+int orc_cell_from_points(orc_cell* c, const float* pts, const int32_t* idx, int k, int stride,
+                         int ioff, int min_points);
+/* ndt_cell.h:133-142 */
+void orc_cell_merge(orc_cell* dst, const orc_cell* src);
+/* Sophus SE2d::cast<float>() -> Eigen::Affine2f, as used at ndt_matcher.cpp:208, local_fuser.cpp:175 */
+void orc_pose_to_affine_f(const double pose4[4], float aff[4]);
+/* ndt_cell.cpp:117-123 */
+void orc_cell_transform(orc_cell* c, const float aff[4]);
+/* ndt_map.cpp:177-182 (leaves the index grid stale, like the reference) */
+void orc_map_transform(orc_map* m, const float aff[4]);
+/* ndt_map.cpp:191-207 */
+void orc_map_merge(orc_map* fixed, const orc_map* moving);
+/* ndt_map.h:87-90 */
+uint32_t orc_map_coord_to_index(const orc_map* m, float x, float y);
+
+/* ndt_matcher.cpp:200-215 + ndt_map.cpp:101-175 + ndt_cell.cpp:172-176.  corr is M x k, -1 padded.
+ * returns total number of correspondences. */
+int orc_associate(const orc_map* fixed, const orc_map* moving, const double pose4[4], int k,
+                  int lookup_mahalanobis, int use_intensity, int32_t* corr);
+
+/* ---------------------------------------------------------------- loss --------------------- */
+/* ceres_loss_functions.cpp:19-39 (BarronLoss) wrapped in ceres::ScaledLoss(weight) */
+void orc_barron_scaled(double s, double scale_a, double alpha, double mu, double weight,
+                       double rho[3]);
+
+/* ---------------------------------------------------------------- registration ------------- */
+
+enum { ORC_PARAM_MANIFOLD = 0, ORC_PARAM_AMBIENT4 = 1, ORC_PARAM_VECTOR = 2 };
+enum { ORC_LINSOLVE_QR = 0, ORC_LINSOLVE_NORMAL = 1 };
+enum {
+  ORC_TERM_CONVERGENCE_FUNCTION = 1,
+  ORC_TERM_CONVERGENCE_PARAMETER = 2,
+  ORC_TERM_CONVERGENCE_GRADIENT = 3,
+  ORC_TERM_CONVERGENCE_RADIUS = 4,
+  ORC_TERM_NO_CONVERGENCE = 5,
+  ORC_TERM_FAILURE = 6
+};
+
+typedef struct orc_matcher_params {
+  double loss_scale;   /* 'a' of BarronLoss: loss_function_scale (odometry) or the `scale` arg (loop) */
+  double mu_scale;     /* parameters_.loss_function_scale used in the gnc_mu formula (ndt_matcher.cpp:388,475) */
+  double loss_alpha;   /* loss_function_convexity */
+  double loss_weight;  /* ScaledLoss factor: ndt_weight/(n_cells*k) (ndt_matcher.cpp:392) or 1 (:479) */
+  double gnc_divisor;
+  int32_t gnc_steps;
+  int32_t max_iterations;
+  int32_t n_neighbours;
+  int32_t lookup_mahalanobis;
+  int32_t use_intensity;
+  int32_t parameterization;
+  int32_t linear_solver;
+  int32_t max_consecutive_invalid_steps;
+  /* Ceres 2.1.0 Solver::Options defaults (not overridden at ndt_matcher.cpp:372-379) */
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_radius, max_radius, min_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+} orc_matcher_params;
+
+void orc_matcher_params_default(orc_matcher_params* p);
+
+#define ORC_TRACE_MAX 4096
+typedef struct orc_solve_stats {
+  int32_t n_residuals;
+  int32_t n_solves;          /* GNC solves performed */
+  int32_t n_iterations;      /* total minimizer iterations (incl. iteration 0 of each solve) */
+  int32_t n_jac_evals;       /* residual+Jacobian evaluations */
+  int32_t n_cost_evals;      /* residual-only evaluations */
+  int32_t termination;       /* of the last solve */
+  double initial_cost;       /* of the first solve */
+  double final_cost;         /* summary.final_cost of the last solve */
+  double max_raw_residual;
+  double mu0;
+  /* per-iteration trace across all solves */
+  int32_t trace_len;
+  double trace_cost[ORC_TRACE_MAX];
+  double trace_radius[ORC_TRACE_MAX];
+  int32_t trace_flag[ORC_TRACE_MAX]; /* 0 = iteration zero, 1 = accepted, 2 = rejected, 3 = invalid */
+} orc_solve_stats;
+
+/* One residual + Jacobian (ceres_residuals.h:454-552 through Ceres autodiff x Sophus manifold).
+ * d = 2 or 3.  mm/fm: means (d), mc/fc: full dxd row-major covariances.  pose4 = [c,s,tx,ty].
+ * jac (may be NULL): 3 entries for MANIFOLD / VECTOR, 4 for AMBIENT4.  Returns raw residual r. */
+double orc_ndt_residual(int d, int parameterization, const double* pose4, const double* mm,
+                        const double* mc, const double* fm, const double* fc, double* jac);
+
+/* GNC + LM for fixed correspondences (ndt_matcher.cpp:466-483 + Ceres LM).  corr M x k. */
+int orc_solve_pair(const orc_map* fixed, const orc_map* moving, const int32_t* corr, int k,
+                   const orc_matcher_params* p, double pose4[4], orc_solve_stats* st);
+
+/* Matcher::estimateLoopConstraint (ndt_matcher.cpp:426-493): associate + solve.
+ * Returns final_cost / num_residual_blocks through *cost_out. */
+int orc_register_pair(const orc_map* fixed, const orc_map* moving, const orc_matcher_params* p,
+                      double pose4[4], double* cost_out, orc_solve_stats* st);
+
+/* Batch helper for the CPU baseline: B independent registrations (OpenMP over registrations
+ * when compiled with -fopenmp).  points: B scans of n points; fixed_idx[b] selects the submap. */
+int orc_register_batch(int B, const float* pts, int n, int stride, int ioff, int n_clusters,
+                       float max_range, orc_map* const* fixed_maps, const int32_t* fixed_idx,
+                       const orc_matcher_params* p, const double* guess4, double* pose4_out,
+                       double* cost_out, int32_t* iters_out, int n_threads);
+
+/* ---------------------------------------------------------------- SE(2) helpers (Sophus) --- */
+void orc_se2_exp(const double xi[3], double out4[4]);
+void orc_se2_log(const double p4[4], double xi[3]);
+void orc_se2_mul(const double a4[4], const double b4[4], double out4[4]);
+void orc_se2_inv(const double a4[4], double out4[4]);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,19 @@
+"""randt-slam_amd -- MI355X-native NDT scan-matching core (host-side Python binding).
+
+The product is ``librandt_hip.so`` (hand-written HIP for gfx950 behind the C ABI of
+``include/randt.h``); this package binds it for the benchmark / parity harness and ships the
+synthetic-scene generator.  Nothing here computes on the CPU: every compute entry point goes
+through the shared library and fails loudly when it (or a GPU) is missing.
+"""
+from . import _capi, synth  # noqa: F401
+from ._capi import (CELL_DTYPE, RESULT_DTYPE, PARAM_AMBIENT4, PARAM_MANIFOLD, PARAM_VECTOR,  # noqa: F401
+                    ClusterParams, MapParams, MatcherParams)
+from .host import (Context, Maps, RandtError, associate_batch, default_matcher_params, indoor_cluster_params,  # noqa: F401
+                   indoor_map_params, ndt_build_batch, register_batch, scan_register_batch, solve_batch)
+
+__all__ = [
+    "Context", "Maps", "RandtError", "MapParams", "ClusterParams", "MatcherParams", "CELL_DTYPE", "RESULT_DTYPE",
+    "PARAM_MANIFOLD", "PARAM_AMBIENT4", "PARAM_VECTOR", "default_matcher_params", "indoor_map_params",
+    "indoor_cluster_params", "ndt_build_batch", "associate_batch", "solve_batch", "register_batch",
+    "scan_register_batch", "synth",
+]

@@ -1,0 +1,115 @@
+"""ctypes declarations of the C ABI in include/randt.h (librandt_hip.so).
+
+The library is the product; this file only binds it.  Loading fails loudly when the shared object
+is missing -- there is no Python / CPU fallback for any compute entry point.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librandt_hip.so")
+
+CELL_DTYPE = np.dtype(
+    [("mean", "<f4", (3,)), ("cov", "<f4", (6,)), ("n", "<u4"), ("max_intensity", "<f4"), ("reserved", "<u4")]
+)
+RESULT_DTYPE = np.dtype(
+    [("cost", "<f8"), ("final_cost", "<f8"), ("initial_cost", "<f8"), ("mu0", "<f8"),
+     ("n_residuals", "<i4"), ("iterations", "<i4"), ("gnc_solves", "<i4"), ("termination", "<i4"),
+     ("n_evals", "<i4"), ("status", "<i4"), ("reserved", "<i4", (2,))]
+)
+assert CELL_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 64
+
+PARAM_MANIFOLD, PARAM_AMBIENT4, PARAM_VECTOR = 0, 1, 2
+OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NODEVICE = range(6)
+
+
+class MapParams(C.Structure):
+    _fields_ = [
+        ("size_x", C.c_int32), ("size_y", C.c_int32), ("resolution", C.c_double),
+        ("center_x", C.c_double), ("center_y", C.c_double), ("max_neighbour_dist", C.c_double),
+        ("min_points_per_cell", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class ClusterParams(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("max_range", C.c_float)]
+
+
+class MatcherParams(C.Structure):
+    _fields_ = [
+        ("loss_scale", C.c_double), ("mu_scale", C.c_double), ("loss_alpha", C.c_double),
+        ("loss_weight", C.c_double), ("gnc_divisor", C.c_double),
+        ("gnc_steps", C.c_int32), ("max_iterations", C.c_int32), ("n_neighbours", C.c_int32),
+        ("lookup_mahalanobis", C.c_int32), ("use_intensity", C.c_int32), ("parameterization", C.c_int32),
+        ("max_consecutive_invalid_steps", C.c_int32), ("reserved", C.c_int32),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+    ]
+
+
+# every symbol include/randt.h declares: name -> (restype, argtypes)
+_V, _I, _P = C.c_void_p, C.c_int, C.POINTER
+SYMBOLS = {
+    "randt_version": (_I, []),
+    "randt_status_string": (C.c_char_p, [_I]),
+    "randt_last_error": (C.c_char_p, [_V]),
+    "randt_ctx_create": (_I, [_I, _V, _P(_V)]),
+    "randt_ctx_destroy": (_I, [_V]),
+    "randt_ctx_set_stream": (_I, [_V, _V]),
+    "randt_ctx_synchronize": (_I, [_V]),
+    "randt_ctx_set_trace": (_I, [_V, _V, _I]),
+    "randt_matcher_params_default": (None, [_P(MatcherParams)]),
+    "randt_maps_create": (_I, [_V, _I, _P(MapParams), _I, _I, _P(_V)]),
+    "randt_maps_create_external": (_I, [_V, _I, _P(MapParams), _I, _V, _V, _V, _P(_V)]),
+    "randt_maps_destroy": (_I, [_V]),
+    "randt_maps_cells_bytes": (C.c_size_t, [_I, _I]),
+    "randt_maps_grid_bytes": (C.c_size_t, [_I, _P(MapParams)]),
+    "randt_maps_info": (_I, [_V, _P(_I), _P(_I), _P(_I), _P(_I)]),
+    "randt_maps_device_ptrs": (_I, [_V, _P(_V), _P(_V), _P(_V)]),
+    "randt_maps_clear": (_I, [_V, _I, _I]),
+    "randt_maps_upload": (_I, [_V, _I, _V, _I, _V]),
+    "randt_maps_download": (_I, [_V, _I, _V, _I, _P(_I), _V]),
+    "randt_maps_counts": (_I, [_V, _I, _I, _V]),
+    "randt_maps_copy": (_I, [_V, _I, _V, _I, _I]),
+    "randt_ndt_build_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ClusterParams), _V, _I]),
+    "randt_ndt_build": (_I, [_V, _V, _I, _I, _I, _P(ClusterParams), _V, _I]),
+    "randt_maps_transform": (_I, [_V, _I, _I, _V]),
+    "randt_maps_merge": (_I, [_V, _I, _V, _I, _I, _V]),
+    "randt_associate_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _V, _P(MatcherParams), _V]),
+    "randt_solve_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _V, _P(MatcherParams), _V, _V]),
+    "randt_register_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _P(MatcherParams), _V, _V]),
+    "randt_scan_register_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ClusterParams), _V, _V, _V, _P(MatcherParams), _V, _V]),
+    "randt_register_pair": (_I, [_V, _V, _I, _V, _I, _P(MatcherParams), _V, _V]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen librandt_hip.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C randt-slam_amd/csrc).  There is no CPU fallback."
+        )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so, and a process that
+    # maps both that copy and /opt/rocm's ends up with two HSA runtimes of which only the first sees
+    # the GPU.  Importing torch first makes librandt_hip.so's DT_NEEDED libamdhip64 resolve to the
+    # copy torch already mapped (torch is the device allocator / stream provider of this harness).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pure C/C++ callers link /opt/rocm's runtime directly
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

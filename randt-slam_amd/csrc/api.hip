@@ -1,0 +1,454 @@
+// Host side of the C ABI declared in include/randt.h: contexts, device-resident map batches and
+// the entry points that enqueue the gfx950 kernels.  There is deliberately NO CPU fallback: without
+// a visible HIP device every entry point fails with RANDT_ERR_NODEVICE / RANDT_ERR_HIP.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "randt_internal.h"
+
+int randt_set_error(randt_ctx* ctx, int status, const char* what, hipError_t e) {
+  if (ctx) {
+    ctx->last_error = what ? what : "";
+    if (e != hipSuccess) {
+      ctx->last_error += ": ";
+      ctx->last_error += hipGetErrorString(e);
+    }
+  }
+  return status;
+}
+
+namespace {
+
+int ensure_ws(randt_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return RANDT_OK;
+  if (ctx->ws) {
+    RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RANDT_HIP_CHECK(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  size_t want = bytes + bytes / 4 + 4096;
+  RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->ws, want));
+  ctx->ws_bytes = want;
+  return RANDT_OK;
+}
+
+void fill_view(randt_maps* m, int n_maps, const randt_map_params* p, int cap) {
+  m->p = *p;
+  MapView& v = m->v;
+  v.n_maps = n_maps;
+  v.cap = cap;
+  v.size_x = p->size_x;
+  v.size_y = p->size_y;
+  v.n_slots = p->size_x * p->size_y;
+  v.res = p->resolution;
+  // Map::initialize (ndt_map.cpp:19-20)
+  v.offset_x = -(double)(uint32_t)p->size_x / 2.0 * p->resolution + p->center_x;
+  v.offset_y = -(double)(uint32_t)p->size_y / 2.0 * p->resolution + p->center_y;
+  v.rmax = (int)(p->max_neighbour_dist / p->resolution);  // ndt_map.cpp:117
+  v.min_points = p->min_points_per_cell;
+  v.pad_ = 0;
+}
+
+bool bad_params(const randt_map_params* p, int n_maps, int cap) {
+  return !p || n_maps <= 0 || cap <= 0 || p->size_x <= 0 || p->size_y <= 0 || !(p->resolution > 0.0) ||
+         (long long)p->size_x * p->size_y > (1ll << 30);
+}
+
+__global__ void k_clear(MapView v, int first, int count) {
+  const int map = first + blockIdx.y;
+  if (blockIdx.x == 0 && threadIdx.x == 0) v.counts[map] = 0;
+  if (v.grid) {
+    int32_t* g = v.grid + (size_t)map * v.n_slots;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n_slots; i += gridDim.x * blockDim.x) g[i] = -1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int randt_version(void) { return RANDT_VERSION; }
+
+const char* randt_status_string(int status) {
+  switch (status) {
+    case RANDT_OK: return "ok";
+    case RANDT_ERR_INVALID: return "invalid argument";
+    case RANDT_ERR_HIP: return "HIP runtime error";
+    case RANDT_ERR_UNSUPPORTED: return "size not supported by the kernels";
+    case RANDT_ERR_NOMEM: return "out of memory";
+    case RANDT_ERR_NODEVICE: return "no HIP device (this library has no CPU fallback)";
+    default: return "unknown status";
+  }
+}
+
+const char* randt_last_error(const randt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+void randt_matcher_params_default(randt_matcher_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  // config/parameters_indoor.yaml:7,9,24-39 (loop-closure refinement values) + Ceres 2.1.0 defaults
+  p->loss_scale = 1.5;
+  p->mu_scale = 1.5;
+  p->loss_alpha = -2.0;
+  p->loss_weight = 1.0;
+  p->gnc_divisor = 1.3;
+  p->gnc_steps = 2;
+  p->max_iterations = 200;
+  p->n_neighbours = 4;
+  p->lookup_mahalanobis = 1;
+  p->use_intensity = 1;
+  p->parameterization = RANDT_PARAM_AMBIENT4;
+  p->max_consecutive_invalid_steps = 5;
+  p->function_tolerance = 1e-6;
+  p->gradient_tolerance = 1e-10;
+  p->parameter_tolerance = 1e-8;
+  p->initial_radius = 1e4;
+  p->max_radius = 1e16;
+  p->min_radius = 1e-32;
+  p->min_relative_decrease = 1e-3;
+  p->min_lm_diagonal = 1e-6;
+  p->max_lm_diagonal = 1e32;
+}
+
+int randt_ctx_create(int device, void* stream, randt_ctx** out) {
+  if (!out) return RANDT_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return RANDT_ERR_NODEVICE;
+  if (device < 0 || device >= n) return RANDT_ERR_INVALID;
+  randt_ctx* ctx = new (std::nothrow) randt_ctx();
+  if (!ctx) return RANDT_ERR_NOMEM;
+  ctx->device = device;
+  ctx->stream = (hipStream_t)stream;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete ctx;
+    return RANDT_ERR_HIP;
+  }
+  int lds = 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
+    ctx->lds_limit = lds;
+  *out = ctx;
+  return RANDT_OK;
+}
+
+int randt_ctx_destroy(randt_ctx* ctx) {
+  if (!ctx) return RANDT_OK;
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  delete ctx;
+  return RANDT_OK;
+}
+
+int randt_ctx_set_stream(randt_ctx* ctx, void* stream) {
+  if (!ctx) return RANDT_ERR_INVALID;
+  ctx->stream = (hipStream_t)stream;
+  return RANDT_OK;
+}
+
+int randt_ctx_synchronize(randt_ctx* ctx) {
+  if (!ctx) return RANDT_ERR_INVALID;
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RANDT_OK;
+}
+
+int randt_ctx_set_trace(randt_ctx* ctx, double* d_trace, int max_len) {
+  if (!ctx) return RANDT_ERR_INVALID;
+  ctx->d_trace = d_trace;
+  ctx->trace_len = d_trace ? max_len : 0;
+  return RANDT_OK;
+}
+
+size_t randt_maps_cells_bytes(int n_maps, int cell_capacity) { return (size_t)n_maps * cell_capacity * sizeof(randt_cell); }
+
+size_t randt_maps_grid_bytes(int n_maps, const randt_map_params* p) {
+  return p ? (size_t)n_maps * p->size_x * p->size_y * sizeof(int32_t) : 0;
+}
+
+int randt_maps_create_external(randt_ctx* ctx, int n_maps, const randt_map_params* p, int cell_capacity, void* d_cells,
+                               void* d_counts, void* d_grid, randt_maps** out) {
+  if (!ctx || !out || bad_params(p, n_maps, cell_capacity) || !d_cells || !d_counts) return RANDT_ERR_INVALID;
+  if (((size_t)d_cells & 15) != 0) return randt_set_error(ctx, RANDT_ERR_INVALID, "cell storage must be 16-byte aligned", hipSuccess);
+  randt_maps* m = new (std::nothrow) randt_maps();
+  if (!m) return RANDT_ERR_NOMEM;
+  m->ctx = ctx;
+  fill_view(m, n_maps, p, cell_capacity);
+  m->v.cells = (randt_cell*)d_cells;
+  m->v.counts = (int32_t*)d_counts;
+  m->v.grid = (int32_t*)d_grid;
+  m->owns = false;
+  *out = m;
+  return RANDT_OK;
+}
+
+int randt_maps_create(randt_ctx* ctx, int n_maps, const randt_map_params* p, int cell_capacity, int with_grid,
+                      randt_maps** out) {
+  if (!ctx || !out || bad_params(p, n_maps, cell_capacity)) return RANDT_ERR_INVALID;
+  void *cells = nullptr, *counts = nullptr, *grid = nullptr;
+  RANDT_HIP_CHECK(ctx, hipMalloc(&cells, randt_maps_cells_bytes(n_maps, cell_capacity)));
+  RANDT_HIP_CHECK(ctx, hipMalloc(&counts, sizeof(int32_t) * n_maps));
+  if (with_grid) RANDT_HIP_CHECK(ctx, hipMalloc(&grid, randt_maps_grid_bytes(n_maps, p)));
+  int rc = randt_maps_create_external(ctx, n_maps, p, cell_capacity, cells, counts, grid, out);
+  if (rc != RANDT_OK) {
+    (void)hipFree(cells);
+    (void)hipFree(counts);
+    if (grid) (void)hipFree(grid);
+    return rc;
+  }
+  (*out)->owns = true;
+  RANDT_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, randt_maps_cells_bytes(n_maps, cell_capacity), ctx->stream));
+  return randt_maps_clear(*out, 0, n_maps);
+}
+
+int randt_maps_destroy(randt_maps* m) {
+  if (!m) return RANDT_OK;
+  if (m->owns) {
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->v.cells);
+    (void)hipFree(m->v.counts);
+    if (m->v.grid) (void)hipFree(m->v.grid);
+  }
+  delete m;
+  return RANDT_OK;
+}
+
+int randt_maps_info(const randt_maps* m, int* n_maps, int* cell_capacity, int* n_slots, int* with_grid) {
+  if (!m) return RANDT_ERR_INVALID;
+  if (n_maps) *n_maps = m->v.n_maps;
+  if (cell_capacity) *cell_capacity = m->v.cap;
+  if (n_slots) *n_slots = m->v.n_slots;
+  if (with_grid) *with_grid = m->v.grid ? 1 : 0;
+  return RANDT_OK;
+}
+
+int randt_maps_device_ptrs(const randt_maps* m, void** d_cells, void** d_counts, void** d_grid) {
+  if (!m) return RANDT_ERR_INVALID;
+  if (d_cells) *d_cells = m->v.cells;
+  if (d_counts) *d_counts = m->v.counts;
+  if (d_grid) *d_grid = m->v.grid;
+  return RANDT_OK;
+}
+
+static bool range_ok(const randt_maps* m, int first, int count) {
+  return m && first >= 0 && count >= 0 && first + count <= m->v.n_maps;
+}
+
+int randt_maps_clear(randt_maps* m, int first, int count) {
+  if (!range_ok(m, first, count)) return RANDT_ERR_INVALID;
+  if (count == 0) return RANDT_OK;
+  randt_ctx* ctx = m->ctx;
+  int bx = (m->v.n_slots + 255) / 256;
+  bx = bx > 32 ? 32 : (bx < 1 ? 1 : bx);
+  hipLaunchKernelGGL(k_clear, dim3(bx, count), dim3(256), 0, ctx->stream, m->v, first, count);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
+
+int randt_maps_upload(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, const int32_t* h_grid) {
+  if (!range_ok(m, idx, 1) || n_cells < 0 || n_cells > m->v.cap || (n_cells > 0 && !h_cells)) return RANDT_ERR_INVALID;
+  randt_ctx* ctx = m->ctx;
+  if (n_cells)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(m->v.cells + (size_t)idx * m->v.cap, h_cells, sizeof(randt_cell) * n_cells,
+                                        hipMemcpyHostToDevice, ctx->stream));
+  int32_t n = n_cells;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(m->v.counts + idx, &n, sizeof(n), hipMemcpyHostToDevice, ctx->stream));
+  if (h_grid && m->v.grid)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(m->v.grid + (size_t)idx * m->v.n_slots, h_grid, sizeof(int32_t) * m->v.n_slots,
+                                        hipMemcpyHostToDevice, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RANDT_OK;
+}
+
+int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cells, int* n_cells, int32_t* h_grid) {
+  if (!range_ok(m, idx, 1)) return RANDT_ERR_INVALID;
+  randt_ctx* ctx = m->ctx;
+  int32_t n = 0;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&n, m->v.counts + idx, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_cells) *n_cells = n;
+  int c = n < max_cells ? n : max_cells;
+  if (h_cells && c > 0)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_cells, m->v.cells + (size_t)idx * m->v.cap, sizeof(randt_cell) * c,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+  if (h_grid && m->v.grid)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_grid, m->v.grid + (size_t)idx * m->v.n_slots, sizeof(int32_t) * m->v.n_slots,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RANDT_OK;
+}
+
+int randt_maps_counts(randt_maps* m, int first, int count, int32_t* h_counts) {
+  if (!range_ok(m, first, count) || !h_counts) return RANDT_ERR_INVALID;
+  randt_ctx* ctx = m->ctx;
+  if (count)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, m->v.counts + first, sizeof(int32_t) * count, hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RANDT_OK;
+}
+
+int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int src_first, int count) {
+  if (!range_ok(dst, dst_first, count) || !range_ok(src, src_first, count)) return RANDT_ERR_INVALID;
+  if (dst->v.n_slots != src->v.n_slots || dst->v.cap < src->v.cap) return RANDT_ERR_INVALID;
+  randt_ctx* ctx = dst->ctx;
+  for (int i = 0; i < count; ++i) {
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(dst->v.cells + (size_t)(dst_first + i) * dst->v.cap,
+                                        src->v.cells + (size_t)(src_first + i) * src->v.cap,
+                                        sizeof(randt_cell) * src->v.cap, hipMemcpyDeviceToDevice, ctx->stream));
+    if (dst->v.grid && src->v.grid)
+      RANDT_HIP_CHECK(ctx, hipMemcpyAsync(dst->v.grid + (size_t)(dst_first + i) * dst->v.n_slots,
+                                          src->v.grid + (size_t)(src_first + i) * src->v.n_slots,
+                                          sizeof(int32_t) * src->v.n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (count)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(dst->v.counts + dst_first, src->v.counts + src_first, sizeof(int32_t) * count,
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+  return RANDT_OK;
+}
+
+int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
+                              const int32_t* d_n_points, int stride_floats, int intensity_index,
+                              const randt_cluster_params* cp, randt_maps* out, int first_map) {
+  if (!ctx || !cp || !range_ok(out, first_map, n_scans < 0 ? 0 : n_scans) || n_scans < 0 || pitch_points < 0 ||
+      stride_floats < 3 || intensity_index < 0 || intensity_index >= stride_floats || cp->n_clusters <= 0 ||
+      !(cp->max_range > 0.f))
+    return RANDT_ERR_INVALID;
+  if (n_scans == 0) return RANDT_OK;
+  if (!d_points && pitch_points > 0) return RANDT_ERR_INVALID;
+  if (pitch_points == 0) return randt_maps_clear(out, first_map, n_scans);
+  return launch_ndt_build(ctx, d_points, n_scans, pitch_points, d_n_points, stride_floats, intensity_index, cp, out->v, first_map);
+}
+
+int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int stride_floats, int intensity_index,
+                    const randt_cluster_params* cp, randt_maps* out, int map_idx) {
+  if (!ctx || n_points < 0 || (n_points > 0 && !h_points)) return RANDT_ERR_INVALID;
+  if (n_points == 0) {
+    int rc = randt_maps_clear(out, map_idx, 1);
+    if (rc) return rc;
+    return randt_ctx_synchronize(ctx);
+  }
+  size_t bytes = sizeof(float) * (size_t)n_points * stride_floats;
+  int rc = ensure_ws(ctx, bytes);
+  if (rc) return rc;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_points, bytes, hipMemcpyHostToDevice, ctx->stream));
+  rc = randt_ndt_build_batch_dev(ctx, (const float*)ctx->ws, 1, n_points, nullptr, stride_floats, intensity_index, cp, out, map_idx);
+  if (rc) return rc;
+  return randt_ctx_synchronize(ctx);
+}
+
+int randt_maps_transform(randt_maps* m, int first, int count, const double* h_pose4) {
+  if (!range_ok(m, first, count) || (count > 0 && !h_pose4)) return RANDT_ERR_INVALID;
+  if (count == 0) return RANDT_OK;
+  randt_ctx* ctx = m->ctx;
+  int rc = ensure_ws(ctx, sizeof(double) * 4 * count);
+  if (rc) return rc;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_pose4, sizeof(double) * 4 * count, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_maps_transform(ctx, m->v, first, count, (const double*)ctx->ws);
+  if (rc) return rc;
+  return randt_ctx_synchronize(ctx);  // ws is reused by the next call
+}
+
+int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_first, int n_moving,
+                     const double* h_pose4) {
+  if (!range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_first, n_moving) || (n_moving > 0 && !h_pose4) || !fixed->v.grid)
+    return RANDT_ERR_INVALID;
+  if (n_moving == 0) return RANDT_OK;
+  randt_ctx* ctx = fixed->ctx;
+  int rc = ensure_ws(ctx, sizeof(double) * 4 * n_moving);
+  if (rc) return rc;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_pose4, sizeof(double) * 4 * n_moving, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_maps_merge(ctx, fixed->v, fixed_idx, moving->v, moving_first, n_moving, (const double*)ctx->ws);
+  if (rc) return rc;
+  return randt_ctx_synchronize(ctx);
+}
+
+static int check_pairs(randt_ctx* ctx, const randt_maps* fixed, const randt_maps* moving, int moving_first, int n_pairs,
+                       const randt_matcher_params* mp) {
+  if (!ctx || !fixed || !mp || n_pairs < 0 || !range_ok(moving, moving_first, n_pairs)) return RANDT_ERR_INVALID;
+  if (mp->n_neighbours <= 0 || mp->n_neighbours > 64) return RANDT_ERR_INVALID;
+  return RANDT_OK;
+}
+
+int randt_associate_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx,
+                              const randt_maps* moving, int moving_first, int n_pairs, const double* d_guess4,
+                              const randt_matcher_params* mp, int32_t* d_corr) {
+  int rc = check_pairs(ctx, fixed, moving, moving_first, n_pairs, mp);
+  if (rc) return rc;
+  if (n_pairs == 0) return RANDT_OK;
+  if (!d_guess4 || !d_corr) return RANDT_ERR_INVALID;
+  return launch_associate(ctx, fixed->v, d_fixed_idx, moving->v, moving_first, n_pairs, d_guess4, mp->n_neighbours,
+                          mp->lookup_mahalanobis, mp->use_intensity, d_corr);
+}
+
+int randt_solve_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx, const randt_maps* moving,
+                          int moving_first, int n_pairs, const int32_t* d_corr, const randt_matcher_params* mp,
+                          double* d_pose4, randt_result* d_results) {
+  int rc = check_pairs(ctx, fixed, moving, moving_first, n_pairs, mp);
+  if (rc) return rc;
+  if (n_pairs == 0) return RANDT_OK;
+  if (!d_corr || !d_pose4 || !d_results) return RANDT_ERR_INVALID;
+  return launch_solve(ctx, fixed->v, d_fixed_idx, moving->v, moving_first, n_pairs, d_corr, mp, d_pose4, d_results);
+}
+
+int randt_register_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx,
+                             const randt_maps* moving, int moving_first, int n_pairs, const randt_matcher_params* mp,
+                             double* d_pose4, randt_result* d_results) {
+  int rc = check_pairs(ctx, fixed, moving, moving_first, n_pairs, mp);
+  if (rc) return rc;
+  if (n_pairs == 0) return RANDT_OK;
+  if (!d_pose4 || !d_results) return RANDT_ERR_INVALID;
+  size_t corr_bytes = sizeof(int32_t) * (size_t)n_pairs * moving->v.cap * mp->n_neighbours;
+  rc = ensure_ws(ctx, corr_bytes);
+  if (rc) return rc;
+  int32_t* d_corr = (int32_t*)ctx->ws;
+  rc = launch_associate(ctx, fixed->v, d_fixed_idx, moving->v, moving_first, n_pairs, d_pose4, mp->n_neighbours,
+                        mp->lookup_mahalanobis, mp->use_intensity, d_corr);
+  if (rc) return rc;
+  return launch_solve(ctx, fixed->v, d_fixed_idx, moving->v, moving_first, n_pairs, d_corr, mp, d_pose4, d_results);
+}
+
+int randt_scan_register_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
+                                  const int32_t* d_n_points, int stride_floats, int intensity_index,
+                                  const randt_cluster_params* cp, const randt_maps* fixed, const int32_t* d_fixed_idx,
+                                  randt_maps* scan_maps, const randt_matcher_params* mp, double* d_pose4,
+                                  randt_result* d_results) {
+  int rc = randt_ndt_build_batch_dev(ctx, d_points, n_scans, pitch_points, d_n_points, stride_floats, intensity_index, cp,
+                                     scan_maps, 0);
+  if (rc) return rc;
+  return randt_register_batch_dev(ctx, fixed, d_fixed_idx, scan_maps, 0, n_scans, mp, d_pose4, d_results);
+}
+
+int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
+                        const randt_matcher_params* mp, double h_pose4[4], randt_result* h_result) {
+  if (!ctx || !h_pose4 || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1) || !mp) return RANDT_ERR_INVALID;
+  // small staging block: [pose4 | result | fixed_idx]
+  void* stage = nullptr;
+  const size_t sz = sizeof(double) * 4 + sizeof(randt_result) + 16;
+  RANDT_HIP_CHECK(ctx, hipMalloc(&stage, sz));
+  double* d_pose = (double*)stage;
+  randt_result* d_res = (randt_result*)(d_pose + 4);
+  int32_t* d_fi = (int32_t*)(d_res + 1);
+  int32_t fi = fixed_idx;
+  hipError_t e1 = hipMemcpyAsync(d_pose, h_pose4, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e2 = hipMemcpyAsync(d_fi, &fi, sizeof(fi), hipMemcpyHostToDevice, ctx->stream);
+  int rc = (e1 != hipSuccess || e2 != hipSuccess) ? randt_set_error(ctx, RANDT_ERR_HIP, "hipMemcpyAsync", e1 != hipSuccess ? e1 : e2) : RANDT_OK;
+  if (!rc) rc = randt_register_batch_dev(ctx, fixed, d_fi, moving, moving_idx, 1, mp, d_pose, d_res);
+  randt_result r;
+  memset(&r, 0, sizeof(r));
+  if (!rc) {
+    hipError_t e3 = hipMemcpyAsync(h_pose4, d_pose, sizeof(double) * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e4 = hipMemcpyAsync(&r, d_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e5 = hipStreamSynchronize(ctx->stream);
+    if (e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
+      rc = randt_set_error(ctx, RANDT_ERR_HIP, "download", e5 != hipSuccess ? e5 : (e3 != hipSuccess ? e3 : e4));
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(stage);
+  if (h_result) *h_result = r;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Internal declarations shared by the HIP translation units of librandt_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "randt.h"
+
+#define RANDT_WAVE 64
+
+// Device-side view of a randt_maps batch (passed to kernels by value).
+struct MapView {
+  randt_cell* cells;  // [n_maps][cap]
+  int32_t* counts;    // [n_maps]
+  int32_t* grid;      // [n_maps][n_slots] or nullptr
+  int32_t n_maps, cap, n_slots, size_x, size_y;
+  int32_t rmax;       // static_cast<int>(max_neighbour_manhattan_distance / resolution), ndt_map.cpp:117
+  int32_t min_points;
+  int32_t pad_;
+  double res, offset_x, offset_y;
+};
+
+struct randt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  // scratch (grown on demand, never inside a timed region after warm-up)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  double* d_trace = nullptr;
+  int trace_len = 0;
+  int lds_limit = 160 * 1024;
+};
+
+struct randt_maps {
+  randt_ctx* ctx = nullptr;
+  randt_map_params p{};
+  MapView v{};
+  bool owns = false;
+};
+
+// Parameters of the solve kernel (POD copy of randt_matcher_params + derived values).
+struct SolveParams {
+  double loss_a, mu_scale, alpha, weight, gnc_div;
+  double ftol, gtol, ptol, r0, rmax, rmin, min_rel, dmin, dmax;
+  int32_t gnc_steps, max_it, k, max_invalid;
+};
+
+int randt_set_error(randt_ctx* ctx, int status, const char* what, hipError_t e);
+#define RANDT_HIP_CHECK(ctx, call)                                          \
+  do {                                                                       \
+    hipError_t e__ = (call);                                                 \
+    if (e__ != hipSuccess) return randt_set_error((ctx), RANDT_ERR_HIP, #call, e__); \
+  } while (0)
+
+// launchers implemented in the kernel TUs
+int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points,
+                     int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map);
+int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count, const double* d_pose4);
+int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const MapView& moving, int moving_first,
+                      int n_moving, const double* d_pose4);
+int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
+                     int moving_first, int n_pairs, const double* d_guess4, int k, int lookup_mahalanobis,
+                     int use_intensity, int32_t* d_corr);
+int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
+                 int moving_first, int n_pairs, const int32_t* d_corr, const randt_matcher_params* mp,
+                 double* d_pose4, randt_result* d_results);

@@ -1,0 +1,245 @@
+"""Host-side wrappers over the C ABI (include/randt.h).
+
+Device memory is whatever the caller hands over: any object with ``data_ptr()`` (torch CUDA
+tensors: PyTorch-ROCm is used as the device allocator / stream provider only) or a raw integer
+device address.  Batch entry points are asynchronous on the context's HIP stream, exactly like the
+``*_dev`` functions they bind.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import CELL_DTYPE, RESULT_DTYPE, ClusterParams, MapParams, MatcherParams
+
+
+class RandtError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = f"{where}: {_capi.load().randt_status_string(status).decode()} (status {status})"
+        if detail:
+            msg += f" -- {detail}"
+        super().__init__(msg)
+
+
+def _dptr(x):
+    """Device (or host) address of x: torch tensor -> data_ptr(), numpy -> ctypes address, int, None."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(x))
+
+
+def default_matcher_params(**over):
+    """randt_matcher_params_default(): indoor loop-closure refinement values + Ceres 2.1.0 defaults."""
+    p = MatcherParams()
+    _capi.load().randt_matcher_params_default(C.byref(p))
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def indoor_map_params(center=(0.0, 0.0)):
+    """config/parameters_indoor.yaml:16-18 + base yaml :59-60 through ndt_slam.cpp:653-654."""
+    from .synth import indoor_params
+
+    ip = indoor_params()
+    return MapParams(ip["size_x"], ip["size_y"], ip["resolution"], center[0], center[1], ip["max_neighbour_dist"],
+                     ip["min_points_per_cell"], 0)
+
+
+def indoor_cluster_params():
+    """ndt_slam.cpp:691: n_clusters = (2 * max_range / resolution)^2."""
+    from .synth import indoor_params
+
+    ip = indoor_params()
+    return ClusterParams(ip["n_clusters"], ip["max_range"])
+
+
+class Context:
+    """randt_ctx: one per device / caller thread.  ``stream``: a hipStream_t handle (int), e.g.
+    ``torch.cuda.current_stream().cuda_stream``; None = the null stream."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        rc = self._lib.randt_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc:
+            raise RandtError(rc, "randt_ctx_create")
+        self._h = h
+        self.device = device
+
+    def _check(self, rc, where):
+        if rc:
+            raise RandtError(rc, where, self._lib.randt_last_error(self._h).decode())
+
+    def set_stream(self, stream):
+        self._check(self._lib.randt_ctx_set_stream(self._h, C.c_void_p(stream) if stream else None), "randt_ctx_set_stream")
+
+    def synchronize(self):
+        self._check(self._lib.randt_ctx_synchronize(self._h), "randt_ctx_synchronize")
+
+    def set_trace(self, d_trace, max_len):
+        self._check(self._lib.randt_ctx_set_trace(self._h, _dptr(d_trace), int(max_len)), "randt_ctx_set_trace")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.randt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Maps:
+    """randt_maps: a batch of device-resident NDT maps (compact 48-byte cells + int32 index grid).
+
+    storage=(cells, counts, grid): externally owned device buffers (e.g. torch uint8 / int32 tensors
+    so that torch.distributed can broadcast the submap tables); otherwise hipMalloc'ed by the library.
+    """
+
+    def __init__(self, ctx, n_maps, params, capacity, with_grid=True, storage=None):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.n_maps, self.capacity, self.params = int(n_maps), int(capacity), params
+        self.n_slots = params.size_x * params.size_y
+        self.with_grid = bool(with_grid)
+        self._storage = storage
+        h = C.c_void_p()
+        if storage is None:
+            rc = self._lib.randt_maps_create(ctx._h, self.n_maps, C.byref(params), self.capacity, int(self.with_grid), C.byref(h))
+            where = "randt_maps_create"
+        else:
+            cells, counts, grid = storage
+            self.with_grid = grid is not None
+            rc = self._lib.randt_maps_create_external(ctx._h, self.n_maps, C.byref(params), self.capacity, _dptr(cells),
+                                                      _dptr(counts), _dptr(grid), C.byref(h))
+            where = "randt_maps_create_external"
+        ctx._check(rc, where)
+        self._h = h
+        if storage is not None:
+            self.clear()
+
+    @staticmethod
+    def storage_bytes(n_maps, params, capacity):
+        lib = _capi.load()
+        return lib.randt_maps_cells_bytes(n_maps, capacity), 4 * n_maps, lib.randt_maps_grid_bytes(n_maps, C.byref(params))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.randt_maps_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self, first=0, count=None):
+        count = self.n_maps - first if count is None else count
+        self.ctx._check(self._lib.randt_maps_clear(self._h, first, count), "randt_maps_clear")
+
+    def upload(self, idx, cells, grid=None):
+        cells = np.ascontiguousarray(cells, dtype=CELL_DTYPE)
+        g = None if grid is None else np.ascontiguousarray(grid, dtype=np.int32)
+        if g is not None and g.size != self.n_slots:
+            raise ValueError("grid size")
+        self.ctx._check(self._lib.randt_maps_upload(self._h, idx, _dptr(cells), len(cells), _dptr(g)), "randt_maps_upload")
+
+    def download(self, idx):
+        cells = np.zeros(self.capacity, dtype=CELL_DTYPE)
+        grid = np.empty(self.n_slots, dtype=np.int32) if self.with_grid else None
+        n = C.c_int(0)
+        self.ctx._check(self._lib.randt_maps_download(self._h, idx, _dptr(cells), self.capacity, C.byref(n), _dptr(grid)),
+                        "randt_maps_download")
+        return cells[: min(n.value, self.capacity)].copy(), grid
+
+    def counts(self, first=0, count=None):
+        count = self.n_maps - first if count is None else count
+        out = np.zeros(count, dtype=np.int32)
+        self.ctx._check(self._lib.randt_maps_counts(self._h, first, count, _dptr(out)), "randt_maps_counts")
+        return out
+
+    def copy_from(self, src, dst_first=0, src_first=0, count=None):
+        count = src.n_maps - src_first if count is None else count
+        self.ctx._check(self._lib.randt_maps_copy(self._h, dst_first, src._h, src_first, count), "randt_maps_copy")
+
+    def transform(self, first, poses4):
+        p = np.ascontiguousarray(poses4, dtype=np.float64).reshape(-1, 4)
+        self.ctx._check(self._lib.randt_maps_transform(self._h, first, len(p), _dptr(p)), "randt_maps_transform")
+
+    def merge(self, fixed_idx, moving, moving_first, poses4):
+        """Rolling-submap update: merge moving maps [moving_first, +len(poses4)) into self[fixed_idx]."""
+        p = np.ascontiguousarray(poses4, dtype=np.float64).reshape(-1, 4)
+        self.ctx._check(self._lib.randt_maps_merge(self._h, fixed_idx, moving._h, moving_first, len(p), _dptr(p)),
+                        "randt_maps_merge")
+
+    def device_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.ctx._check(self._lib.randt_maps_device_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)), "randt_maps_device_ptrs")
+        return a.value, b.value, c.value
+
+
+def _shape3(points):
+    if hasattr(points, "shape") and len(points.shape) == 3:
+        return int(points.shape[0]), int(points.shape[1]), int(points.shape[2])
+    raise ValueError("points must be a (n_scans, pitch_points, stride_floats) float32 device tensor")
+
+
+def ndt_build_batch(ctx, points, cluster, out_maps, first_map=0, n_points=None, intensity_index=None):
+    """randt_ndt_build_batch_dev.  points: (B, N, S) float32 on the device."""
+    B, N, S = _shape3(points)
+    ioff = (3 if S == 4 else 4) if intensity_index is None else intensity_index
+    ctx._check(ctx._lib.randt_ndt_build_batch_dev(ctx._h, _dptr(points), B, N, _dptr(n_points), S, ioff, C.byref(cluster),
+                                                  out_maps._h, first_map), "randt_ndt_build_batch_dev")
+
+
+def associate_batch(ctx, fixed, fixed_idx, moving, moving_first, n_pairs, guess4, mp, corr):
+    ctx._check(ctx._lib.randt_associate_batch_dev(ctx._h, fixed._h, _dptr(fixed_idx), moving._h, moving_first, n_pairs,
+                                                  _dptr(guess4), C.byref(mp), _dptr(corr)), "randt_associate_batch_dev")
+
+
+def solve_batch(ctx, fixed, fixed_idx, moving, moving_first, n_pairs, corr, mp, pose4, results):
+    ctx._check(ctx._lib.randt_solve_batch_dev(ctx._h, fixed._h, _dptr(fixed_idx), moving._h, moving_first, n_pairs,
+                                              _dptr(corr), C.byref(mp), _dptr(pose4), _dptr(results)), "randt_solve_batch_dev")
+
+
+def register_batch(ctx, fixed, fixed_idx, moving, moving_first, n_pairs, mp, pose4, results):
+    ctx._check(ctx._lib.randt_register_batch_dev(ctx._h, fixed._h, _dptr(fixed_idx), moving._h, moving_first, n_pairs,
+                                                 C.byref(mp), _dptr(pose4), _dptr(results)), "randt_register_batch_dev")
+
+
+def scan_register_batch(ctx, points, cluster, fixed, fixed_idx, scan_maps, mp, pose4, results, n_points=None,
+                        intensity_index=None):
+    """Whole hot path: NDT build -> associate -> solve for a batch of raw scans."""
+    B, N, S = _shape3(points)
+    ioff = (3 if S == 4 else 4) if intensity_index is None else intensity_index
+    ctx._check(ctx._lib.randt_scan_register_batch_dev(ctx._h, _dptr(points), B, N, _dptr(n_points), S, ioff, C.byref(cluster),
+                                                      fixed._h, _dptr(fixed_idx), scan_maps._h, C.byref(mp), _dptr(pose4),
+                                                      _dptr(results)), "randt_scan_register_batch_dev")
+
+
+def register_pair(ctx, fixed, fixed_idx, moving, moving_idx, mp, pose4):
+    """Host convenience (synchronous): Matcher::estimateLoopConstraint for one pair."""
+    p = np.array(pose4, dtype=np.float64)
+    res = np.zeros(1, dtype=RESULT_DTYPE)
+    ctx._check(ctx._lib.randt_register_pair(ctx._h, fixed._h, fixed_idx, moving._h, moving_idx, C.byref(mp), _dptr(p), _dptr(res)),
+               "randt_register_pair")
+    return p, res[0]
+
+
+def ndt_build_host(ctx, points, cluster, out_maps, map_idx, intensity_index=None):
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    S = pts.shape[1] if pts.ndim == 2 else 4
+    ioff = (3 if S == 4 else 4) if intensity_index is None else intensity_index
+    ctx._check(ctx._lib.randt_ndt_build(ctx._h, _dptr(pts) if pts.size else None, int(pts.shape[0]), S, ioff, C.byref(cluster),
+                                        out_maps._h, map_idx), "randt_ndt_build")
