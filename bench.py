@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- NDT registrations/sec on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input: BASELINE config 4's batch
+of 512 independent registrations (8 submaps x 64 scans; 2000-point radar scans vs 100x100-slot
+0.5 m submaps, indoor parameter set), each registration = NDT build from the raw points +
+association against its submap + the full GNC / Levenberg-Marquardt solve, all on the GPU through
+the C ABI of librandt_hip.so.  Inputs are resident in HBM before the timed region starts.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): independent registrations shard
+with no data-path collective -- every rank processes its own 512-registration batch per step
+("weak" scaling).  The submap tables are built once on rank 0 and broadcast over RCCL at set-up.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_SUBMAPS, SCANS_PER_SUBMAP, N_KEYFRAMES = 8, 64, 34
+N_POINTS, N_SLOTS = 2000, 100 * 100
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # vector fp64 (half the 157.3 TF fp32 vector rate)
+
+
+def algorithmic_bytes(n_points, n_slots, m_cells, k):
+    """bytes one registration must move (points in, dense submap table + index grid,
+    scan cells out + back in, correspondences, pose/stat out)."""
+    return n_points * 16 + n_slots * 48 + n_slots * 4 + m_cells * 48 * 2 + m_cells * k * 4 + 64
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock budget of the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import randt_slam_amd as R
+    from randt_slam_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+
+    stream = torch.cuda.current_stream()
+    ctx = R.Context(local_rank, stream.cuda_stream)
+    mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
+    mp = R.default_matcher_params()
+    k = mp.n_neighbours
+    B = N_SUBMAPS * SCANS_PER_SUBMAP
+    scan_cap = 512
+
+    # ---------------- set-up (untimed): synthetic world, scans, submaps ---------------------------
+    prob = synth.make_batch_problem(N_SUBMAPS, SCANS_PER_SUBMAP, N_KEYFRAMES, scan_seed0=1000 + 100000 * rank,
+                                    guess_seed0=2000 + 100000 * rank)
+    # submap tables live in torch-owned HBM so that RCCL can broadcast them
+    cb, nb, gb = R.Maps.storage_bytes(N_SUBMAPS, mapp, N_SLOTS)
+    t_cells = torch.zeros(cb, dtype=torch.uint8, device=dev)
+    t_counts = torch.zeros(N_SUBMAPS, dtype=torch.int32, device=dev)
+    t_grid = torch.zeros(gb // 4, dtype=torch.int32, device=dev)
+    submaps = R.Maps(ctx, N_SUBMAPS, mapp, N_SLOTS, storage=(t_cells, t_counts, t_grid))
+    if rank == 0:
+        for j, sm in enumerate(prob["submaps"]):
+            kf = torch.from_numpy(np.stack(sm["kf_scans"])).to(dev)
+            tmp = R.Maps(ctx, kf.shape[0], mapp, scan_cap, with_grid=False)
+            R.ndt_build_batch(ctx, kf, clu, tmp)
+            submaps.merge(j, tmp, 0, synth.pose3_to_pose4(sm["kf_rel"]))  # rolling-submap path (a9 + a18)
+            tmp.close()
+    ctx.synchronize()
+    if world > 1:
+        # the only collective: submap cell tables + index grids from the owner rank, once per submap epoch
+        for t in (t_cells, t_counts, t_grid):
+            dist.broadcast(t, src=0)
+        torch.cuda.synchronize()
+
+    points = torch.from_numpy(prob["scans"]).to(dev)                       # (B, 2000, 4) f32, 16 B / point
+    fixed_idx = torch.from_numpy(prob["submap_of"]).to(dev)
+    guess4 = torch.from_numpy(synth.pose3_to_pose4(prob["guess"])).to(dev)
+    pose = guess4.clone()
+    results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    corr = torch.full((B, scan_cap, k), -1, dtype=torch.int32, device=dev)
+    scan_maps = R.Maps(ctx, B, mapp, scan_cap, with_grid=False)
+
+    def step(events=None):
+        pose.copy_(guess4)
+        if events is not None:
+            events[0].record(stream)
+        R.ndt_build_batch(ctx, points, clu, scan_maps)
+        if events is not None:
+            events[1].record(stream)
+        R.associate_batch(ctx, submaps, fixed_idx, scan_maps, 0, B, pose, mp, corr)
+        if events is not None:
+            events[2].record(stream)
+        R.solve_batch(ctx, submaps, fixed_idx, scan_maps, 0, B, corr, mp, pose, results)
+        if events is not None:
+            events[3].record(stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # ---------------- timed region -----------------------------------------------------------------
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(ev[s])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(3)] for s in range(args.steps)]).mean(axis=0)
+
+    if rank == 0:
+        res = results.cpu().numpy().view(R.RESULT_DTYPE).reshape(-1)
+        counts = scan_maps.counts()
+        m_mean = float(counts.mean())
+        n_res_mean = float(res["n_residuals"].mean())
+        evals_mean = float(res["n_evals"].mean())
+        value = B * args.steps * world / elapsed
+        path_ms = float(stage_ms.sum())
+        b_alg = algorithmic_bytes(N_POINTS, N_SLOTS, m_mean, k)
+        achieved_gbs = b_alg * B / (path_ms * 1e-3) / 1e9
+        # fp64 work of the solve kernel: SURVEY 8(d) F_alg = C * (E_J*370 + E_c*250); every pass here is a
+        # Jacobian pass except the raw-residual one
+        flops = n_res_mean * ((evals_mean - 1) * 370 + 250) * B
+        out = {
+            "metric": "ndt_registrations_per_sec", "value": value, "unit": "registrations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 4 batch: 512 independent registrations per GPU per step "
+                            "(8 submaps x 64 scans), 2000-pt synthetic radar scan vs 100x100-slot 0.5 m NDT submap, "
+                            "indoor parameters, NDT build + association + GNC/LM solve (estimateLoopConstraint unit)",
+                "batch_per_gpu": B, "points_per_scan": N_POINTS, "submap_slots": N_SLOTS, "n_neighbours": k,
+                "parameterization": "ambient4 (reference loop-closure behaviour)", "gnc_steps": mp.gnc_steps,
+                "mean_scan_cells": m_mean, "mean_residuals": n_res_mean, "mean_lm_iterations": float(res["iterations"].mean()),
+            },
+            "stage_ms": {"ndt_build": float(stage_ms[0]), "associate": float(stage_ms[1]), "solve": float(stage_ms[2])},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_ndt_build + k_associate + k_solve (one launch each per step); k_solve dominant",
+                "algorithmic_bytes_per_registration": b_alg, "registrations_per_launch": B,
+                "avg_launch_ms": {"k_ndt_build": float(stage_ms[0]), "k_associate": float(stage_ms[1]), "k_solve": float(stage_ms[2])},
+                "note": "path is fp64-VALU / iteration-latency bound (SURVEY 8(d)); see roofline_fp64",
+            },
+            "roofline_fp64": {
+                "bound": "fp64_valu", "kernel": "k_solve", "achieved": flops / (float(stage_ms[2]) * 1e-3) / 1e12,
+                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / (float(stage_ms[2]) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out.update(cpu_baseline(prob, mp, pose.cpu().numpy(), args.cpu_seconds))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prob, mp, gpu_pose, budget_s):
+    """The CPU oracle (a restatement 'port', not Ceres) on the box's host cores, OpenMP over
+    registrations, on a bounded sample of the SAME batch; also yields the pose error GPU-vs-oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from randt_slam_amd import synth
+
+    ip = synth.indoor_params()
+    fixed = []
+    for sm in prob["submaps"]:
+        sub = po.Map(ip["size_x"], ip["size_y"], ip["resolution"], (0, 0), ip["max_neighbour_dist"], ip["min_points_per_cell"])
+        for t in range(len(sm["kf_scans"])):
+            s = po.Map(ip["size_x"], ip["size_y"], ip["resolution"], (0, 0), ip["max_neighbour_dist"], ip["min_points_per_cell"], 512)
+            s.build(sm["kf_scans"][t], ip["n_clusters"], ip["max_range"])
+            s.transform(synth.pose3_to_pose4(sm["kf_rel"][t]))
+            sub.merge(s)
+        fixed.append(sub)
+    op = po.default_params()
+    for name, _ in mp._fields_:
+        if name != "reserved":
+            setattr(op, name, getattr(mp, name))
+    g4 = synth.pose3_to_pose4(prob["guess"])
+    cores = po.num_threads()
+    B = len(prob["scans"])
+    done, t_total, poses = 0, 0.0, None
+    while t_total < budget_s:
+        t0 = time.perf_counter()
+        fail, poses, cost, iters = po.register_batch(prob["scans"], fixed, prob["submap_of"], op, g4, ip["n_clusters"],
+                                                     ip["max_range"], n_threads=cores)
+        t_total += time.perf_counter() - t0
+        done += B
+    err_t = float(np.abs(gpu_pose[:, 2:] - poses[:, 2:]).max())
+    dth = np.arctan2(gpu_pose[:, 1], gpu_pose[:, 0]) - np.arctan2(poses[:, 1], poses[:, 0])
+    err_r = float(np.abs((dth + np.pi) % (2 * np.pi) - np.pi).max())
+    return {
+        "cpu_baseline": {
+            "value": done / t_total, "unit": "registrations/s", "cores": cores, "kind": "port",
+            "sample": "%d passes of the same 512-registration batch through the OpenMP CPU oracle (%.1f s wall, %d threads)" % (done // B, t_total, cores),
+        },
+        "pose_err_vs_oracle": {"max_abs_translation_m": err_t, "max_abs_rotation_rad": err_r, "tolerance": [1e-4, 1e-4]},
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+"""Multi-GPU sharding of independent registrations.
+
+Pair registrations share nothing but the read-only submap tables, so a batch splits contiguously
+across ranks with no data-path collective.  The only exchanges are (a) a broadcast of the submap
+cell tables + index grids from the owner rank, once per submap epoch, and (b) an all-gather of the
+small per-registration results.  Both go through torch.distributed: backend "nccl" (= RCCL over
+xGMI) on the GPU box, "gloo" in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, world_size, rank):
+    """Contiguous split: rank r gets [r*B/G, (r+1)*B/G) (uneven remainders go to the low ranks)."""
+    base, rem = divmod(int(n_items), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_submap_tables(tables, src=0, group=None):
+    """tables: iterable of tensors backing a randt_maps batch (cells as uint8, counts / grid as int32).
+    520 KB per indoor submap; all maps of a batch travel in one call per tensor."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in tables:
+        dist.broadcast(t, src=src, group=group)
+
+
+def gather_results(local, group=None):
+    """All-gather per-registration outputs (poses as float64 (n,4), results as uint8 (n,64));
+    ranks may hold different counts.  Returns the concatenation in rank order."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    pad = max(counts)
+    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return torch.cat([o[:c] for o, c in zip(outs, counts)], dim=0)

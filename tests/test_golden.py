@@ -1,0 +1,89 @@
+"""Committed golden vectors (tests/golden/pair_indoor.npz, made by tests/golden/make_golden.py from
+the oracle): the oracle must keep reproducing them (CPU), and the HIP path must reproduce them
+through the C ABI without needing the oracle binary (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pair_indoor.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD))
+
+
+def test_oracle_reproduces_golden(built, gold):
+    import pyoracle as po
+    from randt_slam_amd import synth
+    from util import cells_equal, oracle_scan_map, oracle_map
+
+    sub = oracle_map()
+    for t in range(len(gold["kf_scans"])):
+        s = oracle_scan_map(gold["kf_scans"][t])
+        s.transform(synth.pose3_to_pose4(gold["kf_rel3"][t]))
+        sub.merge(s)
+    assert cells_equal(sub.cells(), gold["submap_cells"].reshape(-1).view(po.CELL_DTYPE))
+    g = sub.grid()
+    assert np.array_equal(np.nonzero(g >= 0)[0], gold["submap_grid_slots"]) and np.array_equal(g[g >= 0], gold["submap_grid_vals"])
+    for i in range(2):
+        scan = oracle_scan_map(gold["scans"][i])
+        assert cells_equal(scan.cells(), gold[f"scan{i}_cells"].reshape(-1).view(po.CELL_DTYPE))
+        g4 = synth.pose3_to_pose4(gold["guess3"][i])
+        corr, _ = po.associate(sub, scan, g4, 4, 1, 1)
+        assert np.array_equal(corr, gold[f"scan{i}_corr"])
+        for name, param in (("ambient4", po.PARAM_AMBIENT4), ("manifold", po.PARAM_MANIFOLD)):
+            rc, p4, cost, st = po.register_pair(sub, scan, po.default_params(parameterization=param), g4)
+            assert np.allclose(p4, gold[f"scan{i}_{name}_pose4"], rtol=0, atol=1e-12)
+            assert np.allclose(st["trace_cost"], gold[f"scan{i}_{name}_trace_cost"], rtol=1e-12)
+            assert np.array_equal(st["trace_flag"], gold[f"scan{i}_{name}_trace_flag"])
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_golden(gold):
+    import torch
+
+    import randt_slam_amd as R
+    from randt_slam_amd import synth
+    from util import cells_equal
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
+    sub = R.Maps(ctx, 1, mapp, 10000, with_grid=True)
+    kf = torch.from_numpy(gold["kf_scans"]).to(dev)
+    tmp = R.Maps(ctx, kf.shape[0], mapp, 512, with_grid=False)
+    R.ndt_build_batch(ctx, kf, clu, tmp)
+    sub.merge(0, tmp, 0, synth.pose3_to_pose4(gold["kf_rel3"]))
+    cells, grid = sub.download(0)
+    assert cells_equal(cells, gold["submap_cells"].reshape(-1).view(R.CELL_DTYPE))          # bit exact
+    assert np.array_equal(np.nonzero(grid >= 0)[0], gold["submap_grid_slots"]) and np.array_equal(grid[grid >= 0], gold["submap_grid_vals"])
+    pts = torch.from_numpy(gold["scans"]).to(dev)
+    scans = R.Maps(ctx, 2, mapp, 512, with_grid=False)
+    R.ndt_build_batch(ctx, pts, clu, scans)
+    fidx = torch.zeros(2, dtype=torch.int32, device=dev)
+    for name, param in (("ambient4", R.PARAM_AMBIENT4), ("manifold", R.PARAM_MANIFOLD)):
+        mp = R.default_matcher_params(parameterization=param)
+        pose = torch.from_numpy(synth.pose3_to_pose4(gold["guess3"])).to(dev)
+        corr = torch.full((2, 512, 4), -1, dtype=torch.int32, device=dev)
+        res = torch.zeros((2, 64), dtype=torch.uint8, device=dev)
+        trace = torch.zeros((2, 3 * 256 + 1), dtype=torch.float64, device=dev)
+        R.associate_batch(ctx, sub, fidx, scans, 0, 2, pose, mp, corr)
+        ctx.set_trace(trace, trace.shape[1])
+        R.solve_batch(ctx, sub, fidx, scans, 0, 2, corr, mp, pose, res)
+        ctx.synchronize()
+        ctx.set_trace(None, 0)
+        pose, corr, trace = pose.cpu().numpy(), corr.cpu().numpy(), trace.cpu().numpy()
+        for i in range(2):
+            c, _ = scans.download(i)
+            assert cells_equal(c, gold[f"scan{i}_cells"].reshape(-1).view(R.CELL_DTYPE))
+            assert np.array_equal(corr[i, : len(c)], gold[f"scan{i}_corr"])
+            gp = gold[f"scan{i}_{name}_pose4"]
+            assert np.abs(pose[i, 2:] - gp[2:]).max() <= 1e-4                             # north_star tolerance
+            assert abs(np.arctan2(pose[i, 1], pose[i, 0]) - np.arctan2(gp[1], gp[0])) <= 1e-4
+            assert np.allclose(pose[i], gp, rtol=0, atol=1e-7)
+            n = int(trace[i, 0])
+            t = trace[i, 1 : 1 + 3 * n].reshape(n, 3)
+            assert np.allclose(t[:, 0], gold[f"scan{i}_{name}_trace_cost"], rtol=1e-8)
+            assert np.array_equal(t[:, 2].astype(int), gold[f"scan{i}_{name}_trace_flag"])
