@@ -1,0 +1,277 @@
+// randt_facade.hpp -- header-only C++17 mirror of the reference's public classes on top of the C ABI.
+//
+// The reference's seam is the C++ API LocalFuser calls:
+//   rc::navigation::ndt::Cell     include/ndt_representation/ndt_cell.h:16-170
+//   rc::navigation::ndt::Map      include/ndt_representation/ndt_map.h:14-199
+//   rc::navigation::ndt::Matcher  include/ndt_registration/ndt_matcher.h:46-87
+// This header keeps their names, argument meaning and error behaviour (void/double returns, a
+// warning on std::cout, "keep the previous pose" on failure) but is free of Eigen / Sophus / PCL /
+// Ceres: vectors are std::array, poses are the 4 doubles of Sophus::SE2d::data().  A ROS node built
+// against the reference headers is re-pointed with the adapter shown in INTEGRATION.md.
+//
+// Everything numeric happens on the GPU inside librandt_hip.so; there is no CPU fallback.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "randt.h"
+
+namespace randt {
+
+using Vector2f = std::array<float, 2>;
+using Vector3f = std::array<float, 3>;
+using Matrix2f = std::array<float, 4>;  // row-major
+using Matrix3f = std::array<float, 9>;  // row-major
+
+// Sophus::SE2d stand-in: data() = [cos, sin, tx, ty] (trajectory_representation.h:14).
+struct SE2d {
+  double d[4] = {1.0, 0.0, 0.0, 0.0};
+  SE2d() = default;
+  SE2d(double theta, double tx, double ty) : d{std::cos(theta), std::sin(theta), tx, ty} {}
+  double* data() { return d; }
+  const double* data() const { return d; }
+  double angle() const { return std::atan2(d[1], d[0]); }  // so2().log()
+  std::array<double, 2> translation() const { return {d[2], d[3]}; }
+  SE2d operator*(const SE2d& o) const {
+    SE2d r;
+    r.d[0] = d[0] * o.d[0] - d[1] * o.d[1];
+    r.d[1] = d[0] * o.d[1] + d[1] * o.d[0];
+    const double n = std::sqrt(r.d[0] * r.d[0] + r.d[1] * r.d[1]);
+    r.d[0] /= n;
+    r.d[1] /= n;
+    r.d[2] = d[2] + d[0] * o.d[2] - d[1] * o.d[3];
+    r.d[3] = d[3] + d[1] * o.d[2] + d[0] * o.d[3];
+    return r;
+  }
+  SE2d inverse() const {
+    SE2d r;
+    r.d[0] = d[0];
+    r.d[1] = -d[1];
+    r.d[2] = -(d[0] * d[2] + d[1] * d[3]);
+    r.d[3] = -(-d[1] * d[2] + d[0] * d[3]);
+    return r;
+  }
+};
+
+// NDTCellParameters / NDTMapParameters / RadarPreprocessorParameters / NDTMatcherParameters
+// (include/ndt_slam/ndt_slam_parameters.h:11-84), fields used on the path only.
+struct NDTMapParameters {
+  int size_x = 100, size_y = 100;  // cells (ndt_slam.cpp:653-654)
+  double resolution = 0.5;
+  double max_neighbour_manhattan_distance = 4.0;
+  int min_points_per_cell = 5;
+};
+struct RadarPreprocessorParameters {
+  int n_clusters = 2304;  // (2*max_range/resolution)^2, ndt_slam.cpp:691
+  double max_range = 12.0;
+};
+struct NDTMatcherParameters {
+  int gnc_steps = 3;
+  double loss_function_convexity = -2.0, loss_function_scale = 1.5, gnc_control_parameter_divisor = 1.3;
+  int max_iteration = 200;
+  int n_results_kd_lookup = 4;
+  double ndt_weight = 5.0e4;
+  bool use_intensity_as_dimension = true, optimize_on_manifold = true, lookup_mahalanobis = true;
+  bool use_analytic_expressions_for_optimization = false;
+};
+
+class Context {
+ public:
+  explicit Context(int device = 0, void* stream = nullptr) {
+    int rc = randt_ctx_create(device, stream, &ctx_);
+    if (rc != RANDT_OK) throw std::runtime_error(std::string("randt_ctx_create: ") + randt_status_string(rc));
+  }
+  ~Context() { randt_ctx_destroy(ctx_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  randt_ctx* get() const { return ctx_; }
+
+ private:
+  randt_ctx* ctx_ = nullptr;
+};
+
+// Read-only host copy of one cell: the getters of rc::navigation::ndt::Cell (ndt_cell.h:39-121).
+class Cell {
+ public:
+  Cell() = default;
+  explicit Cell(const randt_cell& c) : c_(c) {}
+  Vector2f getMean() const { return {c_.mean[0], c_.mean[1]}; }
+  Vector3f getIntensityMean() const { return {c_.mean[0], c_.mean[1], c_.mean[2]}; }
+  Matrix2f getCov() const { return {c_.cov[0], c_.cov[1], c_.cov[1], c_.cov[3]}; }
+  Matrix3f getIntensityCov() const {
+    return {c_.cov[0], c_.cov[1], c_.cov[2], c_.cov[1], c_.cov[3], c_.cov[4], c_.cov[2], c_.cov[4], c_.cov[5]};
+  }
+  double getMeanIntensity() const { return c_.mean[2]; }
+  double getMaxIntensity() const { return c_.max_intensity; }
+  size_t getNumCells() const { return c_.n; }  // sic: number of POINTS (ndt_cell.cpp:178-180)
+  const randt_cell& raw() const { return c_; }
+
+ private:
+  randt_cell c_{};
+};
+
+// rc::navigation::ndt::Map: one device-resident NDT map.
+class Map {
+ public:
+  Map() = default;
+  Map(const Map& o) { *this = o; }  // the reference copies Maps by value all over (local_fuser.cpp:128-129)
+  Map& operator=(const Map& o) {
+    if (this == &o) return *this;
+    release();
+    if (o.m_) {
+      ctx_ = o.ctx_;
+      params_ = o.params_;
+      cap_ = o.cap_;
+      create();
+      check(randt_maps_copy(m_, 0, o.m_, 0, 1), "randt_maps_copy");
+    }
+    return *this;
+  }
+  ~Map() { release(); }
+
+  // Map::initialize (ndt_map.cpp:7-21)
+  void initialize(std::shared_ptr<Context> ctx, const NDTMapParameters& p, double center_x, double center_y,
+                  int cell_capacity = 0) {
+    release();
+    ctx_ = std::move(ctx);
+    params_.size_x = p.size_x;
+    params_.size_y = p.size_y;
+    params_.resolution = p.resolution;
+    params_.center_x = center_x;
+    params_.center_y = center_y;
+    params_.max_neighbour_dist = p.max_neighbour_manhattan_distance;
+    params_.min_points_per_cell = p.min_points_per_cell;
+    params_.reserved = 0;
+    cap_ = cell_capacity > 0 ? cell_capacity : p.size_x * p.size_y;
+    create();
+  }
+
+  // RadarPreprocessor::processScan's clustering + HierarchicalMap::addClusters
+  // (radar_preprocessor.cpp:34-37, ndt_hierarchical_map.cpp:28-33): the whole filtered scan at once.
+  // points: n x stride floats (pcl::PointXYZI: stride 8, intensity at 4).
+  void addScan(const float* points, int n, int stride, int intensity_index, const RadarPreprocessorParameters& rp) {
+    randt_cluster_params cp{rp.n_clusters, static_cast<float>(rp.max_range)};
+    check(randt_ndt_build(ctx_->get(), points, n, stride, intensity_index, &cp, m_, 0), "randt_ndt_build");
+  }
+
+  unsigned int get_n_cells() const {
+    int32_t n = 0;
+    check(randt_maps_counts(m_, 0, 1, &n), "randt_maps_counts");
+    return static_cast<unsigned int>(n);
+  }
+  bool isEmpty() const { return get_n_cells() == 0; }
+
+  std::vector<Cell> getCells() const {
+    std::vector<randt_cell> raw(cap_);
+    int n = 0;
+    check(randt_maps_download(m_, 0, raw.data(), cap_, &n, nullptr), "randt_maps_download");
+    std::vector<Cell> out;
+    out.reserve(n);
+    for (int i = 0; i < n && i < cap_; ++i) out.emplace_back(raw[i]);
+    return out;
+  }
+
+  std::vector<int> getGridIndizes() const {
+    std::vector<int32_t> g(static_cast<size_t>(params_.size_x) * params_.size_y);
+    int n = 0;
+    check(randt_maps_download(m_, 0, nullptr, 0, &n, g.data()), "randt_maps_download");
+    return std::vector<int>(g.begin(), g.end());
+  }
+
+  // Map::getCellMeanAndCovariance (ndt_map.cpp:33-40)
+  bool getCellMeanAndCovariance(unsigned int index, Vector3f& mean, Matrix3f& cov) const {
+    auto cells = getCells();
+    if (index < cells.size()) {
+      mean = cells[index].getIntensityMean();
+      cov = cells[index].getIntensityCov();
+      return true;
+    }
+    std::cout << "WARNING: requested cell out of range!" << "\n";
+    return false;
+  }
+
+  // Map::transformMap (ndt_map.cpp:177-182); index grid stays stale like in the reference
+  void transformMap(const SE2d& trans) { check(randt_maps_transform(m_, 0, 1, trans.data()), "randt_maps_transform"); }
+
+  // Map::mergeMapCell (ndt_map.cpp:191-207): moving_map is expected already transformed, as in
+  // local_fuser.cpp:177,190; mergeMapCellAt fuses the transform.
+  void mergeMapCell(const Map& moving_map) { mergeMapCellAt(moving_map, SE2d()); }
+  void mergeMapCellAt(const Map& moving_map, const SE2d& pose) {
+    check(randt_maps_merge(m_, 0, moving_map.m_, 0, 1, pose.data()), "randt_maps_merge");
+  }
+
+  void clear() { check(randt_maps_clear(m_, 0, 1), "randt_maps_clear"); }
+
+  randt_maps* handle() const { return m_; }
+  const std::shared_ptr<Context>& context() const { return ctx_; }
+
+ private:
+  void create() { check(randt_maps_create(ctx_->get(), 1, &params_, cap_, 1, &m_), "randt_maps_create"); }
+  void release() {
+    if (m_) randt_maps_destroy(m_);
+    m_ = nullptr;
+  }
+  void check(int rc, const char* what) const {
+    if (rc != RANDT_OK)
+      throw std::runtime_error(std::string(what) + ": " + randt_status_string(rc) + " (" +
+                               (ctx_ ? randt_last_error(ctx_->get()) : "") + ")");
+  }
+  std::shared_ptr<Context> ctx_;
+  randt_map_params params_{};
+  int cap_ = 0;
+  randt_maps* m_ = nullptr;
+};
+
+// rc::navigation::ndt::Matcher, pair-registration part.
+class Matcher {
+ public:
+  // Matcher::initialize (ndt_matcher.cpp:7-16)
+  void initialize(const NDTMatcherParameters& parameters) { parameters_ = parameters; }
+
+  // double Matcher::estimateLoopConstraint(Sophus::SE2d& trans, const Map& old_ndt, Map& new_ndt,
+  //   int max_gnc_steps, bool use_intensity_as_dimension, double scale)   (ndt_matcher.cpp:426-493)
+  // Same contract: trans is in/out, the return value is final_cost / num_residual_blocks; with no
+  // residuals it prints the reference's warning and leaves trans untouched.
+  double estimateLoopConstraint(SE2d& trans, const Map& old_ndt, Map& new_ndt, int max_gnc_steps,
+                                bool use_intensity_as_dimension, double scale, randt_result* stats = nullptr) const {
+    randt_matcher_params mp;
+    randt_matcher_params_default(&mp);
+    mp.loss_scale = scale;                              // BarronLoss(scale, ...)            (:479)
+    mp.mu_scale = parameters_.loss_function_scale;      // gnc_mu uses the odometry scale    (:475)
+    mp.loss_alpha = parameters_.loss_function_convexity;
+    mp.loss_weight = 1.0;                               // ScaledLoss(..., 1, ...)          (:479)
+    mp.gnc_divisor = parameters_.gnc_control_parameter_divisor;
+    mp.gnc_steps = max_gnc_steps;
+    mp.max_iterations = parameters_.max_iteration;
+    mp.n_neighbours = parameters_.n_results_kd_lookup;
+    mp.lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
+    mp.use_intensity = use_intensity_as_dimension ? 1 : 0;
+    // optimize_on_manifold = true: the residuals hang on an un-manifolded 4-vector
+    mp.parameterization = (parameters_.optimize_on_manifold && !parameters_.use_analytic_expressions_for_optimization)
+                              ? RANDT_PARAM_AMBIENT4
+                              : RANDT_PARAM_VECTOR;
+    randt_result r{};
+    int rc = randt_register_pair(old_ndt.context()->get(), old_ndt.handle(), 0, new_ndt.handle(), 0, &mp, trans.data(), &r);
+    if (stats) *stats = r;
+    if (rc != RANDT_OK) {
+      std::cout << "WARNING: registration failed: " << randt_status_string(rc) << std::endl;
+      return 0.0;
+    }
+    if (r.n_residuals == 0) std::cout << "WARNING: NO RESIDUALS ADDED!" << std::endl;
+    return r.cost;
+  }
+
+  void resetMatcher() {}  // imu_constraints_.clear() (ndt_matcher.cpp:18-20): no IMU state on this path
+
+ private:
+  NDTMatcherParameters parameters_;
+};
+
+}  // namespace randt

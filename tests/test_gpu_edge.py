@@ -1,0 +1,146 @@
+"""-m gpu edge cases through the C ABI: empty / ragged / tiny / maximum-size scans, PCL point
+stride, misaligned clustering grid (slot collisions), map upload/download/copy/clear round trips,
+scans with no usable cells (no residuals -> pose unchanged), run-to-run determinism."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+import randt_slam_amd as R
+from randt_slam_amd import host, synth
+from util import IP, cells_equal, oracle_map, oracle_scan_map
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    return torch, dev, ctx
+
+
+def _scan(seed):
+    w = synth.make_world()
+    tr = synth.make_trajectory(3000, 2)
+    return synth.make_scan(w, tr[0], seed)
+
+
+def test_ragged_and_empty_scans(env):
+    torch, dev, ctx = env
+    base = _scan(1000)
+    n_pts = np.array([2000, 0, 5, 6, 1234], dtype=np.int32)   # empty, below / at the min-points gate, ragged
+    pts = np.stack([base] * len(n_pts))
+    pts[3, :6, :2] = [3.2, 1.2]                                 # 6 coincident-ish points -> exactly one cell
+    pts[3, :6, 0] += np.linspace(0, 0.05, 6)
+    maps = R.Maps(ctx, len(n_pts), R.indoor_map_params(), 512, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(pts).to(dev), R.indoor_cluster_params(), maps, n_points=torch.from_numpy(n_pts).to(dev))
+    ctx.synchronize()
+    counts = maps.counts()
+    for i, n in enumerate(n_pts):
+        om = oracle_scan_map(pts[i, :n]) if n else oracle_map(512)
+        cells, grid = maps.download(i)
+        assert counts[i] == om.n_cells
+        assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+    assert counts[1] == 0 and counts[2] == 0 and counts[3] == 1
+
+
+def test_pcl_stride_and_host_entry_point(env):
+    torch, dev, ctx = env
+    base = _scan(1001)
+    pcl = np.zeros((2000, 8), dtype=F)                          # pcl::PointXYZI: x y z pad I pad pad pad
+    pcl[:, :2] = base[:, :2]
+    pcl[:, 4] = base[:, 3]
+    maps = R.Maps(ctx, 2, R.indoor_map_params(), 512, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(pcl[None]).to(dev), R.indoor_cluster_params(), maps, first_map=0)
+    host.ndt_build_host(ctx, base, R.indoor_cluster_params(), maps, 1)   # randt_ndt_build (host pointer, packed xyzI)
+    a, ga = maps.download(0)
+    b, gb = maps.download(1)
+    om = oracle_scan_map(base)
+    assert cells_equal(a, om.cells()) and cells_equal(b, om.cells()) and np.array_equal(ga, gb)
+
+
+def test_maximum_scan_size_and_too_large(env):
+    torch, dev, ctx = env
+    big = np.concatenate([_scan(1002), _scan(1003)])[:4096]
+    maps = R.Maps(ctx, 1, R.indoor_map_params(), 1024, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(big[None]).to(dev), R.indoor_cluster_params(), maps)
+    cells, grid = maps.download(0)
+    om = oracle_scan_map(big, cap=1024)
+    assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+    huge = torch.zeros((1, 5000, 4), dtype=torch.float32, device=dev)
+    with pytest.raises(R.RandtError) as e:
+        R.ndt_build_batch(ctx, huge, R.indoor_cluster_params(), maps)
+    assert e.value.status == R._capi.ERR_UNSUPPORTED           # loud, not a silent fallback
+
+
+def test_slot_collisions_misaligned_grids(env):
+    """outdoor parameter set: clustering grid 1.2308 m vs map grid 1.2 m (quirk A.7-5)."""
+    torch, dev, ctx = env
+    mapp = R.MapParams(41, 41, 1.2, 0.0, 0.0, 4.0, 3, 0)
+    clu = R.ClusterParams(int((2 * 16 / 1.2) ** 2), 16.0)
+    rng = np.random.default_rng(0)
+    pts = np.zeros((3000, 4), dtype=F)
+    pts[:, :2] = rng.uniform(-14, 14, (3000, 2))
+    pts[:, 3] = rng.uniform(20, 80, 3000)
+    maps = R.Maps(ctx, 1, mapp, 1024, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(pts[None]).to(dev), clu, maps)
+    om = po.Map(41, 41, 1.2, (0, 0), 4.0, 3, 1024)
+    om.build(pts, clu.n_clusters, clu.max_range)
+    cells, grid = maps.download(0)
+    assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+    assert (grid >= 0).sum() < len(cells)                      # collisions really happened
+
+
+def test_map_roundtrip_copy_clear(env):
+    torch, dev, ctx = env
+    om = oracle_scan_map(_scan(1004))
+    maps = R.Maps(ctx, 3, R.indoor_map_params(), 512, with_grid=True)
+    maps.upload(1, om.cells(), om.grid())
+    c, g = maps.download(1)
+    assert cells_equal(c, om.cells()) and np.array_equal(g, om.grid())
+    maps.copy_from(maps, dst_first=2, src_first=1, count=1)
+    c2, g2 = maps.download(2)
+    assert cells_equal(c2, om.cells()) and np.array_equal(g2, om.grid())
+    maps.transform(2, [[np.cos(0.3), np.sin(0.3), 1.0, -2.0]])
+    om.transform([np.cos(0.3), np.sin(0.3), 1.0, -2.0])
+    c3, g3 = maps.download(2)
+    assert cells_equal(c3, om.cells()) and np.array_equal(g3, g2)   # transformMap leaves the grid stale
+    maps.clear(1, 2)
+    assert maps.counts().tolist() == [0, 0, 0] and (maps.download(2)[1] == -1).all()
+
+
+def test_no_residuals_keeps_pose(env):
+    torch, dev, ctx = env
+    mapp = R.indoor_map_params()
+    sub = R.Maps(ctx, 1, mapp, 64, with_grid=True)             # empty submap
+    scans = R.Maps(ctx, 1, mapp, 512, with_grid=False)
+    R.ndt_build_batch(ctx, torch.from_numpy(_scan(1005)[None]).to(dev), R.indoor_cluster_params(), scans)
+    g = np.array([0.9, 0.1, 1.0, 2.0])
+    p, r = host.register_pair(ctx, sub, 0, scans, 0, R.default_matcher_params(), g)
+    assert np.array_equal(p, g) and r["n_residuals"] == 0 and r["status"] == 1 and r["cost"] == 0.0
+
+
+def test_run_to_run_bitwise_determinism(env):
+    torch, dev, ctx = env
+    prob = synth.make_batch_problem(n_submaps=1, scans_per_submap=6, n_keyframes=6)
+    mapp, clu, mp = R.indoor_map_params(), R.indoor_cluster_params(), R.default_matcher_params(parameterization=R.PARAM_MANIFOLD)
+    sub = R.Maps(ctx, 1, mapp, 10000, with_grid=True)
+    kf = torch.from_numpy(np.stack(prob["submaps"][0]["kf_scans"])).to(dev)
+    tmp = R.Maps(ctx, kf.shape[0], mapp, 512, with_grid=False)
+    R.ndt_build_batch(ctx, kf, clu, tmp)
+    sub.merge(0, tmp, 0, synth.pose3_to_pose4(prob["submaps"][0]["kf_rel"]))
+    pts = torch.from_numpy(prob["scans"]).to(dev)
+    fidx = torch.zeros(6, dtype=torch.int32, device=dev)
+    ws = R.Maps(ctx, 6, mapp, 512, with_grid=False)
+    outs = []
+    for _ in range(3):
+        pose = torch.from_numpy(synth.pose3_to_pose4(prob["guess"])).to(dev)
+        res = torch.zeros((6, 64), dtype=torch.uint8, device=dev)
+        R.scan_register_batch(ctx, pts, clu, sub, fidx, ws, mp, pose, res)
+        ctx.synchronize()
+        outs.append((pose.cpu().numpy().copy(), res.cpu().numpy().copy()))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])   # fixed reduction tree
