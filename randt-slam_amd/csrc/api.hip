@@ -3,6 +3,7 @@
 // a visible HIP device every entry point fails with RANDT_ERR_NODEVICE / RANDT_ERR_HIP.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -132,6 +133,11 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
   int lds = 0;
   if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
     ctx->lds_limit = lds;
+  if (const char* e = getenv("RANDT_SOLVE_BLOCK")) {
+    int b = atoi(e);
+    if (b == 64 || b == 128 || b == 256) ctx->solve_block = b;
+  }
+  if (const char* e = getenv("RANDT_SOLVE_STAGE")) ctx->solve_stage = atoi(e) ? 1 : 0;
   *out = ctx;
   return RANDT_OK;
 }

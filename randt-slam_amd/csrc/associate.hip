@@ -5,27 +5,32 @@
 // (src/ndt_representation/ndt_map.cpp:101-175) and Cell::mahalanobisSquaredIntensity
 // (src/ndt_representation/ndt_cell.cpp:172-176).
 //
-// One workgroup per (scan, submap) pair.  The submap's dense int32 index grid (40 KB for the
-// 100x100 indoor map) is staged once into LDS with 16-byte coalesced loads; each wavefront then
-// walks moving cells: the 64 lanes cover the (2R+1)^2 search window in the reference's x-major
-// order, ballots count occupied slots per Chebyshev ring to find the first radius that holds >= k
-// cells, candidates' 48-byte cell records are gathered from L2/HBM, the fp32 Mahalanobis (or
-// Euclidean) distance is evaluated in the reference's operation order, and k rounds of a
-// wave-level lexicographic arg-min on (distance, compact index) reproduce std::sort's order.
+// One workgroup (512 threads) per (scan, submap) pair, four phases per chunk of 64 moving cells so
+// that every global-memory round trip is taken once by all lanes together instead of once per cell:
+//   P0  the submap's dense int32 index grid (40 KB for the 100x100 indoor map) is staged into LDS
+//       with 16-byte coalesced loads; a ring-major table of the (2R+1)^2 window offsets is built;
+//   P1  one thread per moving cell: 48-byte record from HBM/L2, fp32 transform by the initial guess
+//       (reference operation order), centre slot; query cells parked in LDS;
+//   P2  one wavefront per moving cell, LDS only: lanes cover the window ring by ring, one ballot per
+//       64 slots gives the occupied / valid counts of every Chebyshev radius, the reference's
+//       termination rule picks the final radius, occupied slots are compacted into a candidate list;
+//   P3  one thread per (cell, candidate): gather the fixed cell's 48-byte record (L2), fp32
+//       Mahalanobis / Euclidean distance in Eigen's operation order;
+//   P4  one 16-lane group per cell: k rounds of lexicographic arg-min on (distance, compact index)
+//       = the order std::sort produces on std::pair<double,size_t>.
 #include "cell_math.h"
 
 using namespace randt_dev;
 
 #define ASSOC_BLOCK 512
-#define ASSOC_MAX_R 7            // window <= 15x15 = 225 slots = 4 lane passes
+#define ASSOC_WAVES (ASSOC_BLOCK / 64)
+#define ASSOC_MAX_R 7    // window <= 15x15 = 225 slots = 4 lane passes
 #define ASSOC_PASSES 4
+#define ASSOC_CH 64      // moving cells per chunk
+#define ASSOC_CAND 64    // candidates per cell: <= (k-1) + 8R = 63 for k <= 8, R <= 7
+#define ASSOC_QS 11      // LDS stride of a query record (odd => conflict-free)
 
 namespace {
-
-struct Cand {
-  float dist;
-  int32_t idx;
-};
 
 __device__ __forceinline__ bool cand_less(float da, int32_t ia, float db, int32_t ib) {
   // std::pair<double,size_t> ordering (ndt_map.cpp:122,147); idx < 0 = empty = +inf
@@ -45,24 +50,62 @@ __device__ __forceinline__ bool window_dup(int i, int j, int r, int size_x) {
   return false;
 }
 
+// ring-major enumeration of window offsets: w = 0 is the centre, ring r >= 1 occupies
+// w in [(2r-1)^2, (2r+1)^2).  Order inside a ring is irrelevant (results are sorted afterwards).
+__device__ __forceinline__ void ring_offset(int w, int& i, int& j) {
+  if (w == 0) {
+    i = j = 0;
+    return;
+  }
+  int r = 1;
+  while ((2 * r + 1) * (2 * r + 1) <= w) ++r;
+  const int o = w - (2 * r - 1) * (2 * r - 1);
+  const int side = 2 * r, edge = o / side, pos = o % side;
+  switch (edge) {
+    case 0: i = -r + pos; j = -r; break;
+    case 1: i = r; j = -r + pos; break;
+    case 2: i = r - pos; j = r; break;
+    default: i = -r; j = r - pos; break;
+  }
+}
+
+__device__ __forceinline__ unsigned long long prefix_mask(int n) {
+  return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+}
+
 template <bool STAGE_GRID>
 __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const int32_t* __restrict__ fixed_idx,
                                                            MapView moving, int moving_first,
                                                            const double* __restrict__ guess4, int k, int metric_mahal,
                                                            int transform_full, int32_t* __restrict__ corr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int32_t* lgrid = reinterpret_cast<int32_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pair = blockIdx.x;
   const int fmap = fixed_idx ? fixed_idx[pair] : 0;
   const int mmap = moving_first + pair;
-  const int32_t* ggrid = fixed.grid + (size_t)fmap * fixed.n_slots;
+  const int n_slots = fixed.n_slots;
+  const int32_t* ggrid = fixed.grid + (size_t)fmap * n_slots;
   const randt_cell* fcells = fixed.cells + (size_t)fmap * fixed.cap;
   const randt_cell* mcells = moving.cells + (size_t)mmap * moving.cap;
   int32_t* out = corr + (size_t)pair * moving.cap * k;
-  const int M = moving.counts[mmap];
-  const int n_slots = fixed.n_slots;
+  int M = moving.counts[mmap];
+  M = M > moving.cap ? moving.cap : M;
 
+  // ---- LDS carve (all 4-byte types; offsets multiples of 16 bytes)
+  int32_t* lgrid = reinterpret_cast<int32_t*>(smem);
+  const int grid_words = STAGE_GRID ? ((n_slots + 3) & ~3) : 0;
+  int32_t* wtab = lgrid + grid_words;                       // [256] packed (i+128) << 8 | (j+128)
+  float* qrec = reinterpret_cast<float*>(wtab + 256);       // [CH][QS]: mean3, cov6, centre(bits), pad
+  int32_t* clen = reinterpret_cast<int32_t*>(qrec + ASSOC_CH * ASSOC_QS + 1);  // [CH]
+  int32_t* cpref = clen + ASSOC_CH;                         // [CH + 1]
+  int32_t* cand = cpref + ASSOC_CH + 4;                     // [CH][CAND]
+  float* cdist = reinterpret_cast<float*>(cand + ASSOC_CH * ASSOC_CAND);  // [CH][CAND]
+
+  const int R = fixed.rmax - 1 > 0 ? fixed.rmax - 1 : 0;  // last radius the reference evaluates
+  const int side = 2 * R + 1, nwin = side * side;
+  const bool need_dup = fixed.size_x <= 2 * R;
+
+  // ---- P0: stage the index grid, build the window table
   if (STAGE_GRID) {
     if (((size_t)ggrid & 15) == 0) {
       const int n4 = n_slots >> 2;
@@ -73,119 +116,205 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     } else {
       for (int i = tid; i < n_slots; i += ASSOC_BLOCK) lgrid[i] = ggrid[i];
     }
-    __syncthreads();
+  }
+  if (tid < 256) {
+    int i = 0, j = 0;
+    if (tid < nwin) ring_offset(tid, i, j);
+    wtab[tid] = ((i + 128) << 8) | (j + 128);
   }
   const int32_t* grid = STAGE_GRID ? lgrid : ggrid;
 
   float aff[4];
   pose_to_affine_f(guess4 + 4 * (size_t)pair, aff);
-  const int R = fixed.rmax - 1 > 0 ? fixed.rmax - 1 : 0;  // last radius the reference evaluates
-  const int side = 2 * R + 1, nwin = side * side;
 
-  for (int ci = wave; ci < M; ci += ASSOC_BLOCK / 64) {
-    randt_cell q = load_cell(mcells + ci);
-    if (transform_full) {
-      cell_transform(q, aff);  // Cell::transformCell (ndt_matcher.cpp:207-209)
-    } else {
-      // initial_guess.cast<float>() * mean.xy (ndt_matcher.cpp:213,250)
-      float x = q.mean[0], y = q.mean[1];
-      q.mean[0] = (aff[0] * x - aff[1] * y) + aff[2];
-      q.mean[1] = (aff[1] * x + aff[0] * y) + aff[3];
-    }
-    const uint32_t center = coord_to_index(fixed, q.mean[0], q.mean[1]);
+  for (int c0 = 0; c0 < M; c0 += ASSOC_CH) {
+    const int nch = M - c0 < ASSOC_CH ? M - c0 : ASSOC_CH;
+    __syncthreads();  // previous chunk fully consumed (also orders P0 before first use)
 
-    // window scan: per-ring counts of valid (A) and occupied (T) slots
-    int32_t cidx[ASSOC_PASSES];
-    int rho[ASSOC_PASSES], wi[ASSOC_PASSES], wj[ASSOC_PASSES];
-    int T[ASSOC_MAX_R + 1], A[ASSOC_MAX_R + 1];
-#pragma unroll
-    for (int r = 0; r <= ASSOC_MAX_R; ++r) T[r] = A[r] = 0;
-#pragma unroll
-    for (int p = 0; p < ASSOC_PASSES; ++p) {
-      const int w = p * 64 + lane;
-      cidx[p] = -2;  // -2: not a valid window slot, -1: empty slot
-      rho[p] = 1 << 20;
-      wi[p] = wj[p] = 0;
-      if (w < nwin) {
-        const int i = w / side - R, j = w % side - R;  // i: x offset (outer), j: y offset (inner)
-        const uint32_t ni = center + (uint32_t)i + (uint32_t)j * (uint32_t)fixed.size_x;
-        if (ni < (uint32_t)n_slots) {
-          cidx[p] = grid[ni];
-          if (cidx[p] < -1) cidx[p] = -1;
-          rho[p] = (i < 0 ? -i : i) > (j < 0 ? -j : j) ? (i < 0 ? -i : i) : (j < 0 ? -j : j);
-          wi[p] = i;
-          wj[p] = j;
-        }
+    // ---- P1: transform the query cells of this chunk
+    if (tid < nch) {
+      randt_cell q = load_cell(mcells + c0 + tid);
+      if (transform_full) {
+        cell_transform(q, aff);  // Cell::transformCell (ndt_matcher.cpp:207-209)
+      } else {
+        // initial_guess.cast<float>() * mean.xy (ndt_matcher.cpp:213,250)
+        const float x = q.mean[0], y = q.mean[1];
+        q.mean[0] = (aff[0] * x - aff[1] * y) + aff[2];
+        q.mean[1] = (aff[1] * x + aff[0] * y) + aff[3];
       }
+      float* o = qrec + tid * ASSOC_QS;
+      o[0] = q.mean[0]; o[1] = q.mean[1]; o[2] = q.mean[2];
 #pragma unroll
-      for (int r = 0; r <= ASSOC_MAX_R; ++r) {
-        if (r <= R) {
-          const bool uniq = cidx[p] >= -1 && rho[p] <= r && !window_dup(wi[p], wj[p], r, fixed.size_x);
-          A[r] += __popcll(__ballot(uniq));
-          T[r] += __popcll(__ballot(uniq && cidx[p] >= 0));
-        }
-      }
+      for (int e = 0; e < 6; ++e) o[3 + e] = q.cov[e];
+      o[9] = __uint_as_float(coord_to_index(fixed, q.mean[0], q.mean[1]));
     }
-    // while (targets.size() < n && adjacent.size() < n_cells_) {...; r++; if (r >= rmax) break;}
-    int rstar = -1;
-    {
-      int nt = 0, nadj = 0, radius = 0;
+    __syncthreads();
+
+    // ---- P2: window scan (LDS only), one wavefront per moving cell
+    for (int c = wave; c < nch; c += ASSOC_WAVES) {
+      const uint32_t center = __float_as_uint(qrec[c * ASSOC_QS + 9]);
+      int32_t cidx[ASSOC_PASSES];
+      unsigned long long occ[ASSOC_PASSES], val[ASSOC_PASSES];
+      int wi[ASSOC_PASSES], wj[ASSOC_PASSES];
+      int loaded = 0;  // passes evaluated so far
+      int nt = 0, nadj = 0, radius = 0, rstar = -1;
+      // while (targets.size() < n && adjacent.size() < n_cells_) {...; r++; if (r >= rmax) break;}
       while (nt < k && nadj < n_slots) {
-        nt = T[radius];
-        nadj = A[radius];
+        const int need = (2 * radius + 1) * (2 * radius + 1);  // window entries of this radius
+#pragma unroll
+        for (int p = 0; p < ASSOC_PASSES; ++p) {
+          if (p == loaded && need > 64 * p) {
+            const int w = p * 64 + lane;
+            int32_t ci = -2;  // -2: not a valid window slot, -1: empty slot
+            int i = 0, j = 0;
+            if (w < nwin) {
+              const int packed = wtab[w];
+              i = (packed >> 8) - 128;
+              j = (packed & 255) - 128;
+              const uint32_t ni = center + (uint32_t)i + (uint32_t)j * (uint32_t)fixed.size_x;
+              if (ni < (uint32_t)n_slots) {
+                ci = grid[ni];
+                if (ci < -1) ci = -1;
+              }
+            }
+            cidx[p] = ci;
+            wi[p] = i;
+            wj[p] = j;
+            occ[p] = __ballot(ci >= 0);
+            val[p] = __ballot(ci >= -1);
+            loaded = p + 1;
+          }
+        }
+        nt = 0;
+        nadj = 0;
+#pragma unroll
+        for (int p = 0; p < ASSOC_PASSES; ++p) {
+          if (p < loaded) {
+            unsigned long long o = occ[p], v = val[p];
+            if (need_dup) {  // tiny maps only: drop repeated window entries (std::find in the reference)
+              const bool rep = window_dup(wi[p], wj[p], radius, fixed.size_x);
+              o = __ballot(cidx[p] >= 0 && !rep);
+              v = __ballot(cidx[p] >= -1 && !rep);
+            }
+            const unsigned long long pm = prefix_mask(need - 64 * p);
+            nt += __popcll(o & pm);
+            nadj += __popcll(v & pm);
+          }
+        }
         rstar = radius;
         ++radius;
         if (radius >= fixed.rmax) break;
       }
+      // candidates of the final window -> cand[c][0 .. nt)
+      int base = 0;
+      if (rstar >= 0) {
+        const int need = (2 * rstar + 1) * (2 * rstar + 1);
+#pragma unroll
+        for (int p = 0; p < ASSOC_PASSES; ++p) {
+          if (p < loaded) {
+            bool in = cidx[p] >= 0 && (p * 64 + lane) < need;
+            if (need_dup) in = in && !window_dup(wi[p], wj[p], rstar, fixed.size_x);
+            const unsigned long long m = __ballot(in);
+            const int pos = base + __popcll(m & prefix_mask(lane));
+            if (in && pos < ASSOC_CAND) cand[c * ASSOC_CAND + pos] = cidx[p];
+            base += __popcll(m);
+          }
+        }
+      }
+      if (lane == 0) clen[c] = base < ASSOC_CAND ? base : ASSOC_CAND;
     }
+    __syncthreads();
 
-    // candidates of the final window: distance in fp32, compared as (double)dist then index
-    Cand cand[ASSOC_PASSES];
+    // exclusive prefix of clen over the chunk (one wavefront)
+    if (wave == 0) {
+      const int v = lane < nch ? clen[lane] : 0;
+      int incl = v;
 #pragma unroll
-    for (int p = 0; p < ASSOC_PASSES; ++p) {
-      cand[p].idx = -1;
-      cand[p].dist = 0.f;
-      const bool in = rstar >= 0 && cidx[p] >= 0 && rho[p] <= rstar && !window_dup(wi[p], wj[p], rstar, fixed.size_x);
-      if (in) {
-        const int32_t fi = cidx[p] < fixed.cap ? cidx[p] : fixed.cap - 1;
-        randt_cell f = load_cell(fcells + fi);
-        float d;
-        if (metric_mahal) {
-          d = mahalanobis3f(q, f);
-        } else {
-          const float dx = q.mean[0] - f.mean[0], dy = q.mean[1] - f.mean[1];
-          d = sqrtf(dx * dx + dy * dy);
-        }
-        cand[p].dist = d;
-        cand[p].idx = cidx[p];
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
       }
+      cpref[lane] = incl - v;
+      if (lane == 63) cpref[64] = incl;
     }
-    for (int kk = 0; kk < k; ++kk) {
-      // lane-local best
-      float bd = cand[0].dist;
-      int32_t bi = cand[0].idx;
+    __syncthreads();
+    const int total = cpref[64];
+
+    // ---- P3: one thread per (cell, candidate): gather + fp32 distance
+    for (int p = tid; p < total; p += ASSOC_BLOCK) {
+      int lo = 0, hi = nch;  // largest c with cpref[c] <= p
 #pragma unroll
-      for (int p = 1; p < ASSOC_PASSES; ++p)
-        if (cand_less(cand[p].dist, cand[p].idx, bd, bi)) {
-          bd = cand[p].dist;
-          bi = cand[p].idx;
-        }
-      // wave arg-min
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float od = __shfl_xor(bd, off, 64);
-        const int32_t oi = __shfl_xor(bi, off, 64);
-        if (cand_less(od, oi, bd, bi)) {
-          bd = od;
-          bi = oi;
+      for (int s = 0; s < 7; ++s) {
+        const int mid = (lo + hi) >> 1;
+        if (hi - lo > 1) {
+          if (cpref[mid] <= p) lo = mid; else hi = mid;
         }
       }
-      if (lane == 0) out[(size_t)ci * k + kk] = bi;
+      const int c = lo, jj = p - cpref[lo];
+      const int32_t fi_raw = cand[c * ASSOC_CAND + jj];
+      const int32_t fi = fi_raw < fixed.cap ? fi_raw : fixed.cap - 1;
+      const randt_cell f = load_cell(fcells + fi);
+      const float* o = qrec + c * ASSOC_QS;
+      float d;
+      if (metric_mahal) {
+        randt_cell q;
+        q.mean[0] = o[0]; q.mean[1] = o[1]; q.mean[2] = o[2];
 #pragma unroll
-      for (int p = 0; p < ASSOC_PASSES; ++p)
-        if (bi >= 0 && cand[p].idx == bi) cand[p].idx = -1;
+        for (int e = 0; e < 6; ++e) q.cov[e] = o[3 + e];
+        d = mahalanobis3f(q, f);
+      } else {
+        const float dx = o[0] - f.mean[0], dy = o[1] - f.mean[1];
+        d = sqrtf(dx * dx + dy * dy);
+      }
+      cdist[c * ASSOC_CAND + jj] = d;
+    }
+    __syncthreads();
+
+    // ---- P4: top-k per cell by (dist, idx), one 16-lane group per cell
+    {
+      const int grp = tid >> 4, gl = tid & 15;
+      for (int c = grp; c < nch; c += ASSOC_BLOCK / 16) {
+        const int n = clen[c];
+        float cd[4];
+        int32_t ci[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int jj = gl + 16 * s;
+          ci[s] = jj < n ? cand[c * ASSOC_CAND + jj] : -1;
+          cd[s] = jj < n ? cdist[c * ASSOC_CAND + jj] : 0.f;
+        }
+        for (int kk = 0; kk < k; ++kk) {
+          float bd = cd[0];
+          int32_t bi = ci[0];
+#pragma unroll
+          for (int s = 1; s < 4; ++s)
+            if (cand_less(cd[s], ci[s], bd, bi)) {
+              bd = cd[s];
+              bi = ci[s];
+            }
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) {
+            const float od = __shfl_xor(bd, off, 16);
+            const int32_t oi = __shfl_xor(bi, off, 16);
+            if (cand_less(od, oi, bd, bi)) {
+              bd = od;
+              bi = oi;
+            }
+          }
+          if (gl == 0) out[(size_t)(c0 + c) * k + kk] = bi;
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            if (bi >= 0 && ci[s] == bi) ci[s] = -1;
+        }
+      }
     }
   }
+}
+
+size_t assoc_lds_bytes(int n_slots, bool stage) {
+  size_t words = (stage ? ((n_slots + 3) & ~3) : 0) + 256 + (ASSOC_CH * ASSOC_QS + 1) + ASSOC_CH + (ASSOC_CH + 4) +
+                 2 * ASSOC_CH * ASSOC_CAND;
+  return words * 4 + 64;
 }
 
 }  // namespace
@@ -197,15 +326,21 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   if (!fixed.grid) return randt_set_error(ctx, RANDT_ERR_INVALID, "fixed maps need an index grid", hipSuccess);
   if (fixed.rmax - 1 > ASSOC_MAX_R)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "max_neighbour_dist/resolution > 8 not supported by the association kernel", hipSuccess);
+  if (k > 8) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "n_neighbours > 8 not supported by the association kernel", hipSuccess);
+  if (fixed.n_slots <= 225)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "maps with <= 225 slots not supported by the association kernel", hipSuccess);
   const int full = (use_intensity && lookup_mahalanobis) ? 1 : 0;
-  size_t lds = (size_t)fixed.n_slots * 4;
-  if (lds + 1024 <= (size_t)ctx->lds_limit / 2) {
+  const bool stage = assoc_lds_bytes(fixed.n_slots, true) <= (size_t)ctx->lds_limit / 2;
+  const size_t lds = assoc_lds_bytes(fixed.n_slots, stage);
+  if (stage) {
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_associate<true>, dim3(n_pairs), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
                        moving, moving_first, d_guess4, k, full, full, d_corr);
   } else {
-    hipLaunchKernelGGL(k_associate<false>, dim3(n_pairs), dim3(ASSOC_BLOCK), 0, ctx->stream, fixed, d_fixed_idx,
+    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_associate<false>, dim3(n_pairs), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
                        moving, moving_first, d_guess4, k, full, full, d_corr);
   }
   RANDT_HIP_CHECK(ctx, hipGetLastError());

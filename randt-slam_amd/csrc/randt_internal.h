@@ -32,6 +32,9 @@ struct randt_ctx {
   double* d_trace = nullptr;
   int trace_len = 0;
   int lds_limit = 160 * 1024;
+  // solve-kernel geometry (tunable through RANDT_SOLVE_BLOCK / RANDT_SOLVE_STAGE for experiments)
+  int solve_block = 128;
+  int solve_stage = 0;
 };
 
 struct randt_maps {

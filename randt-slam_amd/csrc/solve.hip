@@ -21,8 +21,7 @@
 
 #include <float.h>
 
-#define SOLVE_BLOCK 256
-#define SOLVE_WAVES (SOLVE_BLOCK / 64)
+#define SOLVE_MAX_WAVES 4
 
 namespace {
 
@@ -87,7 +86,7 @@ __device__ __forceinline__ void plus(const double* x, const double* d, double* x
 
 // ---------------------------------------------------------------- loss -------------------------
 struct Loss {
-  double b, c, factor, exponent, pre, ts, alpha, weight;
+  double b, c, factor, exponent, pre, ts, alpha, weight, sqrt_w;
   int mode;  // 0: identity (alpha >= 2), 1: log (|alpha| <= 0.05), 2: alpha == -2 closed form, 3: general pow
 };
 
@@ -102,6 +101,7 @@ __device__ __forceinline__ Loss make_loss(double a, double alpha, double mu, dou
   L.pre = L.b * L.factor / alpha;
   L.ts = 2 * L.c / L.factor;
   L.weight = weight;
+  L.sqrt_w = sqrt(weight);
   L.mode = alpha >= 2.0 ? 0 : (fabs(alpha) <= 0.05 ? 1 : (alpha == -2.0 ? 2 : 3));
   return L;
 }
@@ -182,15 +182,17 @@ __device__ __forceinline__ double residual(const float* mv, const float* fv, dou
     q1 = (-C01 * d0 + C00 * d1) * id;
     ssq = d0 * q0 + d1 * q1;
   }
-  const double r = sqrt(ssq);
-  if (want_jac) {
-    if (!(r > 0.0)) {
+  if (!want_jac) return sqrt(ssq);
+  {
+    if (!(ssq > 0.0)) {
       // autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545): zero row instead
 #pragma unroll
       for (int i = 0; i < NT; ++i) J[i] = 0.0;
-      return r;
+      return sqrt(ssq);
     }
-    const double ir = 1.0 / r;
+    // r = ssq * rsqrt(ssq), 1/r = rsqrt(ssq): one transcendental instead of sqrt + divide
+    const double ir = rsqrt(ssq);
+    const double r = ssq * ir;
     const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
     double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
     if (D == 3) {
@@ -214,8 +216,8 @@ __device__ __forceinline__ double residual(const float* mv, const float* fv, dou
       J[1] = dty;
       J[2] = dth;
     }
+    return r;
   }
-  return r;
 }
 
 // ---------------------------------------------------------------- reductions -------------------
@@ -233,9 +235,12 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// Where a pass finds the frozen correspondence set.  STAGE = true: LDS copies (mov [M][9], fix
+// [M*k][9], stride 9 words => conflict-free ds_read_b32).  STAGE = false: the 48-byte cell records
+// are read in place from L1/L2 (the first 9 floats of a record are mean xyz + covariance).
 struct Stage {
-  const float* mov;    // [M][9]
-  const float* fix;    // [M*k][9]
+  const float* mov;
+  const float* fix;
   const int* valid;    // [M*k] compact fixed index or -1
   int n_slots, k;
 };
@@ -243,9 +248,10 @@ struct Stage {
 // Pass over all correspondence slots at ambient point x.  MODE 0: max raw residual; MODE 1: cost,
 // J^T r, J^T J with loss + corrector (Ceres residual_block.cc / corrector.cc).
 // Returns false if any residual was non-finite.
-template <int D, int PARAM, int NT, int MODE>
+template <int D, int PARAM, int NT, int MODE, int BLOCK, bool STAGE>
 __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const Loss& L, Sums<NT>& out, double& raw_max,
                                           double (*red)[24]) {
+  constexpr int SOLVE_WAVES = BLOCK / 64;
   double cp, sp, tx, ty, c, s, n2;
   if (PARAM == RANDT_PARAM_VECTOR) {
     c = cos(x[2]);
@@ -273,10 +279,11 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   for (int i = 0; i < NA; ++i) acc[i] = 0.0;
   double mx = -DBL_MAX;
   int bad = 0;
-  for (int slot = threadIdx.x; slot < S.n_slots; slot += SOLVE_BLOCK) {
-    if (S.valid[slot] < 0) continue;
-    const float* mv = S.mov + (slot / S.k) * 9;
-    const float* fv = S.fix + slot * 9;
+  for (int slot = threadIdx.x; slot < S.n_slots; slot += BLOCK) {
+    const int ci = S.valid[slot];
+    if (ci < 0) continue;
+    const float* mv = STAGE ? S.mov + (slot / S.k) * 9 : S.mov + (size_t)(slot / S.k) * 12;
+    const float* fv = STAGE ? S.fix + slot * 9 : S.fix + (size_t)ci * 12;
     double J[NT];
     const double r = residual<D, PARAM, NT>(mv, fv, c, s, cp, sp, n2, tx, ty, J, MODE == 1);
     if (!isfinite(r)) bad = 1;
@@ -285,10 +292,16 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     } else {
       const double sq = r * r;
       double r0, r1, r2;
+      double rs, jscale;
+      if (L.mode == 2) {
+        // alpha = -2: rho' = w / u^2 > 0, rho'' < 0 always => corrector is sqrt(rho') = sqrt(w) / u
+        const double iu = 1.0 / (sq * L.ts + 1.0);
+        acc[0] += 0.5 * (L.weight * (L.pre * (iu - 1.)));
+        rs = jscale = L.sqrt_w * iu;
+      } else {
       loss_eval(L, sq, r0, r1, r2);
       acc[0] += 0.5 * r0;
       const double sqrt_rho1 = sqrt(r1);
-      double rs, jscale;
       if (sq == 0.0 || r2 <= 0.0) {
         rs = sqrt_rho1;
         jscale = sqrt_rho1;
@@ -297,6 +310,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
         const double al = 1.0 - sqrt(Dc);
         rs = sqrt_rho1 / (1 - al);
         jscale = sqrt_rho1 * (1.0 - al);  // J - (alpha/sq) r r^T J for a scalar residual
+      }
       }
       const double wr = rs * r;
       double wJ[NT];
@@ -312,6 +326,23 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (SOLVE_WAVES == 1) {
+    // one wavefront owns the registration: pure register reduction, no LDS, no barrier
+    const double b1 = wave_max((double)bad);
+    if (MODE == 0) {
+      raw_max = wave_max(mx);
+      return b1 == 0.0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) acc[i] = wave_sum(acc[i]);
+      out.cost = acc[0];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) out.g[i] = acc[1 + i];
+#pragma unroll
+      for (int i = 0; i < NH; ++i) out.h[i] = acc[1 + NT + i];
+      return b1 == 0.0 && isfinite(acc[0]);
+    }
+  }
   __syncthreads();  // red[] reuse
   if (MODE == 0) {
     mx = wave_max(mx);
@@ -364,39 +395,44 @@ __device__ __forceinline__ constexpr int hix(int i, int j) {
   return i <= j ? (i * NT - i * (i - 1) / 2 + (j - i)) : (j * NT - j * (j - 1) / 2 + (i - j));
 }
 
-// Cholesky solve of the NT x NT SPD system A y = g (A full, row-major, destroyed).
+// Solve of the NT x NT SPD system A y = g by LDL^T (A full, row-major, destroyed): NT reciprocals,
+// no square roots.  Returns false if a pivot is not positive.
 template <int NT>
 __device__ __forceinline__ bool chol_solve(double* A, const double* g, double* y) {
   bool ok = true;
+  double inv_d[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     double d = A[j * NT + j];
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= A[j * NT + k] * A[j * NT + k];
+    for (int k = 0; k < j; ++k) d -= A[j * NT + k] * A[j * NT + k] * A[k * NT + k];
     if (!(d > 0.0)) ok = false;
-    d = sqrt(d);
     A[j * NT + j] = d;
+    inv_d[j] = 1.0 / d;
 #pragma unroll
     for (int i = j + 1; i < NT; ++i) {
       double a = A[i * NT + j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) a -= A[i * NT + k] * A[j * NT + k];
-      A[i * NT + j] = a / d;
+      for (int k = 0; k < j; ++k) a -= A[i * NT + k] * A[j * NT + k] * A[k * NT + k];
+      A[i * NT + j] = a * inv_d[j];
     }
   }
+  // L z = g ; D w = z ; L^T y = w
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     double a = g[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) a -= A[i * NT + k] * y[k];
-    y[i] = a / A[i * NT + i];
+    y[i] = a;
   }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) y[i] *= inv_d[i];
 #pragma unroll
   for (int i = NT - 1; i >= 0; --i) {
     double a = y[i];
 #pragma unroll
     for (int k = i + 1; k < NT; ++k) a -= A[k * NT + i] * y[k];
-    y[i] = a / A[i * NT + i];
+    y[i] = a;
   }
   return ok;
 }
@@ -439,14 +475,14 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
   }
 }
 
-template <int D, int PARAM>
-__global__ __launch_bounds__(SOLVE_BLOCK) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
+template <int D, int PARAM, int BLOCK, bool STAGE>
+__global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
                                                        int moving_first, const int32_t* __restrict__ corr, SolveParams P,
                                                        double* __restrict__ pose4, randt_result* __restrict__ results,
                                                        double* trace, int trace_len) {
   constexpr int NT = PARAM == RANDT_PARAM_AMBIENT4 ? 4 : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double red[SOLVE_WAVES][24];
+  __shared__ double red[BLOCK / 64][24];
   __shared__ int s_count;
 
   const int tid = threadIdx.x;
@@ -458,45 +494,67 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_solve(MapView fixed, const int3
   M = M > moving.cap ? moving.cap : M;
   const int n_slots = M * k;
 
-  float* lmov = reinterpret_cast<float*>(smem);
-  float* lfix = lmov + (size_t)moving.cap * 9;
-  int* lvalid = reinterpret_cast<int*>(lfix + (size_t)moving.cap * k * 9);
-
-  // ---- stage the frozen correspondence set (addNDTFactor, ndt_matcher.cpp:217-246)
-  if (tid == 0) s_count = 0;
-  __syncthreads();
   const randt_cell* mcells = moving.cells + (size_t)mmap * moving.cap;
   const randt_cell* fcells = fixed.cells + (size_t)fmap * fixed.cap;
   const int32_t* pc = corr + (size_t)pair * moving.cap * k;
-  for (int i = tid; i < M; i += SOLVE_BLOCK) {
-    const float4* q = reinterpret_cast<const float4*>(mcells + i);
-    const float4 a = q[0], b = q[1], c = q[2];
-    float* o = lmov + i * 9;
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; o[8] = c.x;
-  }
-  int local = 0;
-  for (int sidx = tid; sidx < n_slots; sidx += SOLVE_BLOCK) {
-    int ci = pc[sidx];
-    if (ci >= fixed.cap) ci = -1;
-    lvalid[sidx] = ci;
-    if (ci >= 0) {
-      const float4* q = reinterpret_cast<const float4*>(fcells + ci);
-      const float4 a = q[0], b = q[1], c = q[2];
-      float* o = lfix + sidx * 9;
-      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; o[8] = c.x;
-      ++local;
-    }
-  }
-  if (local) atomicAdd(&s_count, local);
-  __syncthreads();
-  const int n_res = s_count;
-
   Stage S;
-  S.mov = lmov;
-  S.fix = lfix;
-  S.valid = lvalid;
   S.n_slots = n_slots;
   S.k = k;
+  int n_res;
+  if (STAGE) {
+    // ---- stage the frozen correspondence set in LDS (addNDTFactor, ndt_matcher.cpp:217-246)
+    float* lmov = reinterpret_cast<float*>(smem);
+    float* lfix = lmov + (size_t)moving.cap * 9;
+    int* lvalid = reinterpret_cast<int*>(lfix + (size_t)moving.cap * k * 9);
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for (int i = tid; i < M; i += BLOCK) {
+      const float4* q = reinterpret_cast<const float4*>(mcells + i);
+      const float4 a = q[0], b = q[1], c = q[2];
+      float* o = lmov + i * 9;
+      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; o[8] = c.x;
+    }
+    int local = 0;
+    for (int sidx = tid; sidx < n_slots; sidx += BLOCK) {
+      int ci = pc[sidx];
+      if (ci >= fixed.cap) ci = -1;
+      lvalid[sidx] = ci;
+      if (ci >= 0) {
+        const float4* q = reinterpret_cast<const float4*>(fcells + ci);
+        const float4 a = q[0], b = q[1], c = q[2];
+        float* o = lfix + sidx * 9;
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; o[8] = c.x;
+        ++local;
+      }
+    }
+    if (local) atomicAdd(&s_count, local);
+    __syncthreads();
+    n_res = s_count;
+    S.mov = lmov;
+    S.fix = lfix;
+    S.valid = lvalid;
+  } else {
+    // ---- read the 48-byte records in place (L1/L2 resident after the first pass)
+    int local = 0;
+    for (int sidx = tid; sidx < n_slots; sidx += BLOCK) {
+      const int ci = pc[sidx];
+      local += (ci >= 0 && ci < fixed.cap) ? 1 : 0;
+    }
+    if (BLOCK == 64) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+      n_res = local;
+    } else {
+      if (tid == 0) s_count = 0;
+      __syncthreads();
+      if (local) atomicAdd(&s_count, local);
+      __syncthreads();
+      n_res = s_count;
+    }
+    S.mov = reinterpret_cast<const float*>(mcells);
+    S.fix = reinterpret_cast<const float*>(fcells);
+    S.valid = pc;
+  }
 
   double* tr = trace ? trace + (size_t)pair * trace_len : nullptr;
   if (tr && tid == 0) tr[0] = 0.0;
@@ -533,7 +591,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_solve(MapView fixed, const int3
   Loss L = make_loss(P.loss_a, P.alpha, 1.0, P.weight);
   Sums<NT> cur, cnd;
   double raw_max = 0.0;
-  bool ok = eval_pass<D, PARAM, NT, 0>(S, x, L, cur, raw_max, red);
+  bool ok = eval_pass<D, PARAM, NT, 0, BLOCK, STAGE>(S, x, L, cur, raw_max, red);
   res.n_evals++;
   double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
   gnc_mu = fmin(gnc_mu, pow(P.gnc_div, (double)(P.gnc_steps - 1)));
@@ -555,7 +613,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_solve(MapView fixed, const int3
 #pragma unroll
       for (int i = 0; i < 4; ++i) x[i] = best[i];
       double x_norm = ambient_norm<PARAM>(x);
-      bool e_ok = eval_pass<D, PARAM, NT, 1>(S, x, L, cur, raw_max, red);
+      bool e_ok = eval_pass<D, PARAM, NT, 1, BLOCK, STAGE>(S, x, L, cur, raw_max, red);
       res.n_evals++;
       res.iterations++;
       if (!e_ok) {
@@ -596,12 +654,12 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_solve(MapView fixed, const int3
 #pragma unroll
           for (int i = 0; i < NT; ++i) diag[i] = fmin(fmax(Hs[i * NT + i], P.dmin), P.dmax);
         }
+        const double inv_radius = 1.0 / radius;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) A[i * NT + j] = Hs[i * NT + j];
-          const double lm = sqrt(diag[i] / radius);
-          A[i * NT + i] += lm * lm;
+          A[i * NT + i] += diag[i] * inv_radius;  // (sqrt(D^2/radius))^2
         }
         bool solved = chol_solve<NT>(A, gs, step);
 #pragma unroll
@@ -638,7 +696,7 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_solve(MapView fixed, const int3
         plus<PARAM>(x, delta, cand);
 
         // ---- candidate cost (+ speculative gradient / J^T J)
-        bool c_ok = eval_pass<D, PARAM, NT, 1>(S, cand, L, cnd, raw_max, red);
+        bool c_ok = eval_pass<D, PARAM, NT, 1, BLOCK, STAGE>(S, cand, L, cnd, raw_max, red);
         res.n_evals++;
         const double cand_cost = c_ok ? cnd.cost : DBL_MAX;
 
@@ -700,16 +758,37 @@ __global__ __launch_bounds__(SOLVE_BLOCK) void k_solve(MapView fixed, const int3
   }
 }
 
+template <int D, int PARAM, int BLOCK, bool STAGE>
+int launch_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
+               int n_pairs, const int32_t* d_corr, const SolveParams& P, size_t lds, double* d_pose4,
+               randt_result* d_results) {
+  if (STAGE)
+    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<D, PARAM, BLOCK, STAGE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_solve<D, PARAM, BLOCK, STAGE>), dim3(n_pairs), dim3(BLOCK), STAGE ? lds : 0, ctx->stream, fixed,
+                     d_fixed_idx, moving, moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
+
+// Geometry: `block` threads cooperate on one registration (64 = one wavefront, no barriers);
+// stage = 1 copies the correspondence set into LDS first.
 template <int D, int PARAM>
 int launch_one(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
                int n_pairs, const int32_t* d_corr, const SolveParams& P, size_t lds, double* d_pose4,
-               randt_result* d_results) {
-  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<D, PARAM>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_solve<D, PARAM>), dim3(n_pairs), dim3(SOLVE_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
-                     moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len);
-  RANDT_HIP_CHECK(ctx, hipGetLastError());
-  return RANDT_OK;
+               randt_result* d_results, int block, int stage) {
+#define RANDT_CFG(B, S) \
+  return launch_cfg<D, PARAM, B, S>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, lds, d_pose4, d_results)
+  if (stage) {
+    if (block == 64) RANDT_CFG(64, true);
+    if (block == 128) RANDT_CFG(128, true);
+    RANDT_CFG(256, true);
+  } else {
+    if (block == 64) RANDT_CFG(64, false);
+    if (block == 128) RANDT_CFG(128, false);
+    RANDT_CFG(256, false);
+  }
+#undef RANDT_CFG
 }
 
 }  // namespace
@@ -739,11 +818,11 @@ int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_id
   P.max_invalid = mp->max_consecutive_invalid_steps;
   if (P.k <= 0) return randt_set_error(ctx, RANDT_ERR_INVALID, "n_neighbours must be > 0", hipSuccess);
   const size_t lds = (size_t)moving.cap * 9 * 4 + (size_t)moving.cap * P.k * 9 * 4 + (size_t)moving.cap * P.k * 4;
-  if (lds + 2048 > (size_t)ctx->lds_limit)
-    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "moving-map capacity x k too large for the LDS-resident solve kernel", hipSuccess);
+  int block = ctx->solve_block, stage = ctx->solve_stage;
+  if (stage && lds + 2048 > (size_t)ctx->lds_limit) stage = 0;  // too big for LDS: read cells in place
   const int d3 = mp->use_intensity ? 1 : 0;
 #define RANDT_DISPATCH(DD, PP) \
-  return launch_one<DD, PP>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, lds, d_pose4, d_results)
+  return launch_one<DD, PP>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, lds, d_pose4, d_results, block, stage)
   switch (mp->parameterization) {
     case RANDT_PARAM_MANIFOLD:
       if (d3) RANDT_DISPATCH(3, RANDT_PARAM_MANIFOLD); else RANDT_DISPATCH(2, RANDT_PARAM_MANIFOLD);

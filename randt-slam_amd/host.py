@@ -135,7 +135,9 @@ class Maps:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.randt_maps_destroy(self._h)
+            # at interpreter shutdown the context may already be gone: leak rather than touch it
+            if getattr(self.ctx, "_h", None):
+                self._lib.randt_maps_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -64,16 +64,31 @@ def test_pcl_stride_and_host_entry_point(env):
 
 def test_maximum_scan_size_and_too_large(env):
     torch, dev, ctx = env
-    big = np.concatenate([_scan(1002), _scan(1003)])[:4096]
-    maps = R.Maps(ctx, 1, R.indoor_map_params(), 1024, with_grid=True)
-    R.ndt_build_batch(ctx, torch.from_numpy(big[None]).to(dev), R.indoor_cluster_params(), maps)
-    cells, grid = maps.download(0)
-    om = oracle_scan_map(big, cap=1024)
-    assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
-    huge = torch.zeros((1, 5000, 4), dtype=torch.float32, device=dev)
+    maps = R.Maps(ctx, 1, R.indoor_map_params(), 2048, with_grid=True)
+    for n in (4096, 7168):                                      # 7168 = the LDS build kernel's maximum
+        big = np.concatenate([_scan(1002 + i) for i in range(4)])[:n]
+        R.ndt_build_batch(ctx, torch.from_numpy(big[None]).to(dev), R.indoor_cluster_params(), maps)
+        cells, grid = maps.download(0)
+        om = oracle_scan_map(big, cap=2048)
+        assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+    huge = torch.zeros((1, 9000, 4), dtype=torch.float32, device=dev)
     with pytest.raises(R.RandtError) as e:
         R.ndt_build_batch(ctx, huge, R.indoor_cluster_params(), maps)
     assert e.value.status == R._capi.ERR_UNSUPPORTED           # loud, not a silent fallback
+
+
+def test_out_of_range_points_take_the_fallback_sort(env):
+    """labels far outside the clustering grid (points beyond max_range) exceed the LDS label bins:
+    the kernel's rank-by-counting fallback must give the same cells."""
+    torch, dev, ctx = env
+    pts = _scan(1006).copy()
+    pts[::97, 0] += 300.0                                       # garbage returns far away
+    pts[5::101, 1] -= 450.0
+    maps = R.Maps(ctx, 1, R.indoor_map_params(), 512, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(pts[None]).to(dev), R.indoor_cluster_params(), maps)
+    cells, grid = maps.download(0)
+    om = oracle_scan_map(pts)
+    assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
 
 
 def test_slot_collisions_misaligned_grids(env):
