@@ -33,7 +33,7 @@ struct randt_ctx {
   int trace_len = 0;
   int lds_limit = 160 * 1024;
   // solve-kernel geometry (tunable through RANDT_SOLVE_BLOCK / RANDT_SOLVE_STAGE for experiments)
-  int solve_block = 128;
+  int solve_block = 64;
   int solve_stage = 0;
 };
 

@@ -8,28 +8,30 @@
 //   Ceres 2.1.0 (un-vendored): TrustRegionMinimizer, LevenbergMarquardtStrategy, DENSE_QR, Corrector
 //   Sophus 1.22.10 (un-vendored): SE2 exp / group product / Manifold<SE2>::Plus and PlusJacobian
 //
-// Layout: the frozen correspondence set is staged once into LDS as fp32 records of 9 floats
-// (mean xyz + upper-triangular covariance; stride 9 words is odd => conflict-free ds_read_b32):
-// moving cells [M][9] and, per correspondence slot, the fixed cell [M*k][9]; cast to fp64 in
-// registers like the reference does (ndt_matcher.cpp:231).  Every LM iteration is one pass of the
-// 256 lanes over the M*k slots (residual + tangent Jacobian + robust re-weighting in fp64), a
-// fixed-order reduction of {cost, J^T r, upper(J^T J)} (wave __shfl_xor tree -> 4-way LDS combine,
-// deterministic), and the 3x3 / 4x4 damped normal-equation solve + Ceres' accept/reject logic
-// executed redundantly by all lanes (uniform control flow, no broadcast).  The candidate point is
-// evaluated WITH its Jacobian so that an accepted step needs no second pass.
+// Geometry: BLOCK = 64 / 128 / 256 threads cooperate on one registration (default 128 = two
+// wavefronts on two SIMDs; 64 = a single wavefront with no barrier at all).  The frozen
+// correspondence set is read in place: the 48-byte cell records (first 9 floats = mean xyz +
+// upper-triangular covariance) stay L1/L2 resident across the ~30 passes of a registration and are
+// cast to fp64 in registers like the reference does (ndt_matcher.cpp:231).
+// Every LM iteration is one pass over the M*k correspondence slots: fp64 residual, its Jacobian
+// with respect to (tx, ty, theta), loss + Ceres corrector, and TEN accumulators {cost, J^T r (3),
+// upper J^T J (6)} reduced in a fixed order (DPP row reduction -> readlane across rows -> LDS
+// combine across wavefronts): deterministic, run-to-run bit-identical.  The Jacobian of the actual
+// parameterisation (SE(2) tangent / ambient [c,s,tx,ty] / vector) is a per-evaluation-constant
+// linear map T of that base Jacobian, so H = T G T^T and g = T g_b are formed after the reduction.
+// Jacobi scaling, LM diagonal clamp, damped normal equations (LDL^T), model-cost change, Plus,
+// both convergence tests, accept/reject and radius update run redundantly on all lanes (uniform
+// control flow, no broadcast).  The candidate is evaluated WITH its Jacobian so an accepted step
+// needs no second pass.
 #include "randt_internal.h"
 
 #include <float.h>
 
-#define SOLVE_MAX_WAVES 4
-
 namespace {
 
-template <int NT>
-struct Sums {
-  double cost;
-  double g[NT];
-  double h[NT * (NT + 1) / 2];
+// base sums of one pass: cost, g_b (tx, ty, theta), G upper (tt: 00 01 02 11 12 22)
+struct Base {
+  double v[10];
 };
 
 // ---------------------------------------------------------------- Sophus SE(2) pieces ----------
@@ -86,7 +88,7 @@ __device__ __forceinline__ void plus(const double* x, const double* d, double* x
 
 // ---------------------------------------------------------------- loss -------------------------
 struct Loss {
-  double b, c, factor, exponent, pre, ts, alpha, weight, sqrt_w;
+  double b, c, factor, exponent, pre, ts, alpha, weight, sqrt_w, half_w_pre;
   int mode;  // 0: identity (alpha >= 2), 1: log (|alpha| <= 0.05), 2: alpha == -2 closed form, 3: general pow
 };
 
@@ -102,20 +104,14 @@ __device__ __forceinline__ Loss make_loss(double a, double alpha, double mu, dou
   L.ts = 2 * L.c / L.factor;
   L.weight = weight;
   L.sqrt_w = sqrt(weight);
+  L.half_w_pre = 0.5 * weight * L.pre;
   L.mode = alpha >= 2.0 ? 0 : (fabs(alpha) <= 0.05 ? 1 : (alpha == -2.0 ? 2 : 3));
   return L;
 }
 
-// BarronLoss::Evaluate (ceres_loss_functions.cpp:19-39) x ScaledLoss
+// BarronLoss::Evaluate (ceres_loss_functions.cpp:19-39) x ScaledLoss, general branches
 __device__ __forceinline__ void loss_eval(const Loss& L, double s, double& r0, double& r1, double& r2) {
-  if (L.mode == 2) {
-    // alpha = -2: exponent -1 -> pow(u,-1) = 1/u, pow(u,-2), pow(u,-3)
-    const double u = s * L.ts + 1.0;
-    const double iu = 1.0 / u;
-    r0 = L.pre * (iu - 1.);
-    r1 = L.pre * L.exponent * (iu * iu) * L.ts;
-    r2 = L.pre * L.exponent * (L.exponent - 1) * (iu * iu * iu) * L.ts * L.ts;
-  } else if (L.mode == 0) {
+  if (L.mode == 0) {
     r0 = s;
     r1 = 1;
     r2 = 0;
@@ -137,31 +133,29 @@ __device__ __forceinline__ void loss_eval(const Loss& L, double s, double& r0, d
 }
 
 // ---------------------------------------------------------------- residual ---------------------
-// One D2D residual r = sqrt(d^T (R Sm R^T + Sf)^-1 d) and its Jacobian row in the chosen
-// parameterisation.  mv/fv: 9 floats (mean xyz, cov xx xy xi yy yi ii).
-// c, s = cos/sin of theta = atan2 of the stored complex; cp, sp = the stored complex itself.
-template <int D, int PARAM, int NT>
-__device__ __forceinline__ double residual(const float* mv, const float* fv, double c, double s, double cp, double sp,
-                                           double n2, double tx, double ty, double* J, bool want_jac) {
+// One D2D residual: ssq = d^T (R Sm R^T + Sf)^-1 d and, if WANT_JAC,
+// jb = d r / d (tx, ty, theta) with r = sqrt(ssq) (A.2 in the global frame).
+// mv/fv: first 9 floats of a cell record (mean xyz, cov xx xy xi yy yi ii); c, s = cos/sin(theta).
+template <int D, bool WANT_JAC>
+__device__ __forceinline__ double residual_sq(const float* __restrict__ mv, const float* __restrict__ fv, double c, double s,
+                                              double tx, double ty, double* jb) {
   const double m0 = mv[0], m1 = mv[1];
   const double a = mv[3], b = mv[4], dd = mv[6];
-  const double F0 = fv[3], F1 = fv[4], F3 = fv[6];
   const double RS00 = c * a - s * b, RS01 = c * b - s * dd;
   const double RS10 = s * a + c * b, RS11 = s * b + c * dd;
-  const double C00 = (RS00 * c - RS01 * s) + F0;
-  const double C01 = (RS00 * s + RS01 * c) + F1;
-  const double C11 = (RS10 * s + RS11 * c) + F3;
-  const double d0 = (c * m0 - s * m1) + tx - fv[0];
-  const double d1 = (s * m0 + c * m1) + ty - fv[1];
+  const double C00 = (RS00 * c - RS01 * s) + (double)fv[3];
+  const double C01 = (RS00 * s + RS01 * c) + (double)fv[4];
+  const double C11 = (RS10 * s + RS11 * c) + (double)fv[6];
+  const double d0 = (c * m0 - s * m1) + tx - (double)fv[0];
+  const double d1 = (s * m0 + c * m1) + ty - (double)fv[1];
   double q0, q1, q2 = 0.0, ssq;
   double cc = 0.0, e = 0.0;
   if (D == 3) {
     cc = mv[5];
     e = mv[7];
-    const double f = mv[8];
-    const double C02 = (c * cc - s * e) + fv[5];
-    const double C12 = (s * cc + c * e) + fv[7];
-    const double C22 = f + fv[8];
+    const double C02 = (c * cc - s * e) + (double)fv[5];
+    const double C12 = (s * cc + c * e) + (double)fv[7];
+    const double C22 = (double)mv[8] + (double)fv[8];
     const double d2 = (double)mv[2] - (double)fv[2];
     const double k00 = C11 * C22 - C12 * C12;
     const double k01 = C12 * C02 - C01 * C22;
@@ -182,49 +176,43 @@ __device__ __forceinline__ double residual(const float* mv, const float* fv, dou
     q1 = (-C01 * d0 + C00 * d1) * id;
     ssq = d0 * q0 + d1 * q1;
   }
-  if (!want_jac) return sqrt(ssq);
-  {
+  if (WANT_JAC) {
     if (!(ssq > 0.0)) {
       // autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545): zero row instead
-#pragma unroll
-      for (int i = 0; i < NT; ++i) J[i] = 0.0;
-      return sqrt(ssq);
-    }
-    // r = ssq * rsqrt(ssq), 1/r = rsqrt(ssq): one transcendental instead of sqrt + divide
-    const double ir = rsqrt(ssq);
-    const double r = ssq * ir;
-    const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
-    double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
-    if (D == 3) {
-      Su0 += cc * q2;
-      Su1 += e * q2;
-    }
-    const double dth = ((u1 * m0 - u0 * m1) - (u1 * Su0 - u0 * Su1)) * ir;
-    const double dtx = q0 * ir, dty = q1 * ir;
-    if (PARAM == RANDT_PARAM_MANIFOLD) {
-      const double dc = dth * (-sp / n2), ds = dth * (cp / n2);
-      J[0] = dtx * cp + dty * sp;
-      J[1] = -dtx * sp + dty * cp;
-      J[2] = dc * (-sp) + ds * cp;
-    } else if (PARAM == RANDT_PARAM_AMBIENT4) {
-      J[0] = dth * (-sp / n2);
-      J[1] = dth * (cp / n2);
-      J[2] = dtx;
-      J[3] = dty;
+      jb[0] = jb[1] = jb[2] = 0.0;
     } else {
-      J[0] = dtx;
-      J[1] = dty;
-      J[2] = dth;
+      const double ir = rsqrt(ssq);  // 1/r; r = ssq * ir
+      const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
+      double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
+      if (D == 3) {
+        Su0 += cc * q2;
+        Su1 += e * q2;
+      }
+      jb[0] = q0 * ir;
+      jb[1] = q1 * ir;
+      jb[2] = ((u1 * m0 - u0 * m1) - (u1 * Su0 - u0 * Su1)) * ir;
     }
-    return r;
   }
+  return ssq;
 }
 
 // ---------------------------------------------------------------- reductions -------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// Sum over the 64 lanes, result in every lane; fixed association order.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror -> every lane holds its row's (16-lane) sum
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -235,170 +223,172 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// Where a pass finds the frozen correspondence set.  STAGE = true: LDS copies (mov [M][9], fix
-// [M*k][9], stride 9 words => conflict-free ds_read_b32).  STAGE = false: the 48-byte cell records
-// are read in place from L1/L2 (the first 9 floats of a record are mean xyz + covariance).
 struct Stage {
-  const float* mov;
-  const float* fix;
-  const int* valid;    // [M*k] compact fixed index or -1
-  int n_slots, k;
+  const float* mov;  // moving cell records (stride 12 floats)
+  const float* fix;  // fixed cell records (stride 12 floats)
+  const int* corr;   // [M*k] compact fixed index or -1
+  int n_slots, k, fixed_cap;
 };
 
-// Pass over all correspondence slots at ambient point x.  MODE 0: max raw residual; MODE 1: cost,
-// J^T r, J^T J with loss + corrector (Ceres residual_block.cc / corrector.cc).
-// Returns false if any residual was non-finite.
-template <int D, int PARAM, int NT, int MODE, int BLOCK, bool STAGE>
-__device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const Loss& L, Sums<NT>& out, double& raw_max,
-                                          double (*red)[24]) {
-  constexpr int SOLVE_WAVES = BLOCK / 64;
-  double cp, sp, tx, ty, c, s, n2;
+// Pass over all correspondence slots at ambient point x.  MODE 0: max raw residual (out.v[0]);
+// MODE 1: the ten base sums with loss + corrector (Ceres residual_block.cc / corrector.cc).
+// Returns false if any residual was non-finite.  red: [2][BLOCK/64][12] LDS, parity alternates per call.
+template <int D, int PARAM, int MODE, int BLOCK>
+__device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const Loss& L, Base& out, double* red, int& parity) {
+  constexpr int WAVES = BLOCK / 64;
+  double c, s, tx, ty;
   if (PARAM == RANDT_PARAM_VECTOR) {
     c = cos(x[2]);
     s = sin(x[2]);
-    cp = c;
-    sp = s;
-    n2 = 1.0;
     tx = x[0];
     ty = x[1];
   } else {
-    cp = x[0];
-    sp = x[1];
+    // R = AngleAxis(atan2(sp, cp)): cos/sin of the angle == normalised stored complex
+    const double inv = rsqrt(x[0] * x[0] + x[1] * x[1]);
+    c = x[0] * inv;
+    s = x[1] * inv;
     tx = x[2];
     ty = x[3];
-    n2 = cp * cp + sp * sp;
-    // R = AngleAxis(atan2(sp, cp)): cos/sin of the angle == normalised complex
-    const double inv = 1.0 / sqrt(n2);
-    c = cp * inv;
-    s = sp * inv;
   }
-  constexpr int NH = NT * (NT + 1) / 2;
-  constexpr int NA = 1 + NT + NH;
-  double acc[NA];
+  double acc[10];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) acc[i] = 0.0;
+  for (int i = 0; i < 10; ++i) acc[i] = 0.0;
   double mx = -DBL_MAX;
   int bad = 0;
   for (int slot = threadIdx.x; slot < S.n_slots; slot += BLOCK) {
-    const int ci = S.valid[slot];
-    if (ci < 0) continue;
-    const float* mv = STAGE ? S.mov + (slot / S.k) * 9 : S.mov + (size_t)(slot / S.k) * 12;
-    const float* fv = STAGE ? S.fix + slot * 9 : S.fix + (size_t)ci * 12;
-    double J[NT];
-    const double r = residual<D, PARAM, NT>(mv, fv, c, s, cp, sp, n2, tx, ty, J, MODE == 1);
-    if (!isfinite(r)) bad = 1;
+    const int ci = S.corr[slot];
+    if (ci < 0 || ci >= S.fixed_cap) continue;
+    const float* mv = S.mov + (size_t)(slot / S.k) * 12;
+    const float* fv = S.fix + (size_t)ci * 12;
+    double jb[3];
+    const double sq = residual_sq<D, MODE == 1>(mv, fv, c, s, tx, ty, jb);
+    if (!isfinite(sq)) bad = 1;
     if (MODE == 0) {
-      mx = r > mx ? r : mx;
+      mx = sq > mx ? sq : mx;
     } else {
-      const double sq = r * r;
-      double r0, r1, r2;
-      double rs, jscale;
+      double rs;  // residual and Jacobian scale of the corrector (equal for a scalar residual when rho'' <= 0)
+      double js;
       if (L.mode == 2) {
         // alpha = -2: rho' = w / u^2 > 0, rho'' < 0 always => corrector is sqrt(rho') = sqrt(w) / u
         const double iu = 1.0 / (sq * L.ts + 1.0);
-        acc[0] += 0.5 * (L.weight * (L.pre * (iu - 1.)));
-        rs = jscale = L.sqrt_w * iu;
+        acc[0] += L.half_w_pre * (iu - 1.);
+        rs = js = L.sqrt_w * iu;
       } else {
-      loss_eval(L, sq, r0, r1, r2);
-      acc[0] += 0.5 * r0;
-      const double sqrt_rho1 = sqrt(r1);
-      if (sq == 0.0 || r2 <= 0.0) {
-        rs = sqrt_rho1;
-        jscale = sqrt_rho1;
-      } else {
-        const double Dc = 1.0 + 2.0 * sq * r2 / r1;
-        const double al = 1.0 - sqrt(Dc);
-        rs = sqrt_rho1 / (1 - al);
-        jscale = sqrt_rho1 * (1.0 - al);  // J - (alpha/sq) r r^T J for a scalar residual
+        double r0, r1, r2;
+        loss_eval(L, sq, r0, r1, r2);
+        acc[0] += 0.5 * r0;
+        const double sqrt_rho1 = sqrt(r1);
+        if (sq == 0.0 || r2 <= 0.0) {
+          rs = js = sqrt_rho1;
+        } else {
+          const double Dc = 1.0 + 2.0 * sq * r2 / r1;
+          const double al = 1.0 - sqrt(Dc);
+          rs = sqrt_rho1 / (1 - al);
+          js = sqrt_rho1 * (1.0 - al);  // J - (alpha/sq) r r^T J for a scalar residual
+        }
       }
-      }
+      const double r = sq > 0.0 ? sq * rsqrt(sq) : 0.0;
       const double wr = rs * r;
-      double wJ[NT];
-#pragma unroll
-      for (int i = 0; i < NT; ++i) wJ[i] = jscale * J[i];
-      int hidx = 0;
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        acc[1 + i] += wJ[i] * wr;
-#pragma unroll
-        for (int j = i; j < NT; ++j) acc[1 + NT + (hidx++)] += wJ[i] * wJ[j];
-      }
+      const double w0 = js * jb[0], w1 = js * jb[1], w2 = js * jb[2];
+      acc[1] += w0 * wr;
+      acc[2] += w1 * wr;
+      acc[3] += w2 * wr;
+      acc[4] += w0 * w0;
+      acc[5] += w0 * w1;
+      acc[6] += w0 * w2;
+      acc[7] += w1 * w1;
+      acc[8] += w1 * w2;
+      acc[9] += w2 * w2;
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (SOLVE_WAVES == 1) {
-    // one wavefront owns the registration: pure register reduction, no LDS, no barrier
-    const double b1 = wave_max((double)bad);
-    if (MODE == 0) {
-      raw_max = wave_max(mx);
-      return b1 == 0.0;
-    } else {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) acc[i] = wave_sum(acc[i]);
-      out.cost = acc[0];
-#pragma unroll
-      for (int i = 0; i < NT; ++i) out.g[i] = acc[1 + i];
-#pragma unroll
-      for (int i = 0; i < NH; ++i) out.h[i] = acc[1 + NT + i];
-      return b1 == 0.0 && isfinite(acc[0]);
-    }
-  }
-  __syncthreads();  // red[] reuse
+  double badf = wave_max((double)bad);
   if (MODE == 0) {
     mx = wave_max(mx);
-    const double b = wave_max((double)bad);
-    if (lane == 0) {
-      red[wave][0] = mx;
-      red[wave][1] = b;
+    if (WAVES > 1) {
+      double* r = red + parity * (WAVES * 12);
+      parity ^= 1;
+      if (lane == 0) {
+        r[wave * 12 + 0] = mx;
+        r[wave * 12 + 1] = badf;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        mx = r[w * 12] > mx ? r[w * 12] : mx;
+        badf = r[w * 12 + 1] > badf ? r[w * 12 + 1] : badf;
+      }
     }
-    __syncthreads();
-    double m = red[0][0], bb = red[0][1];
-#pragma unroll
-    for (int w = 1; w < SOLVE_WAVES; ++w) {
-      m = red[w][0] > m ? red[w][0] : m;
-      bb = red[w][1] > bb ? red[w][1] : bb;
-    }
-    raw_max = m;
-    return bb == 0.0;
-  } else {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = wave_sum(acc[i]);
-    const double b = wave_max((double)bad);
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) red[wave][i] = acc[i];
-      red[wave][NA] = b;
-    }
-    __syncthreads();
-    double tot[NA];
-    double bb = 0.0;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) tot[i] = 0.0;
-#pragma unroll
-    for (int w = 0; w < SOLVE_WAVES; ++w) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) tot[i] += red[w][i];
-      bb = red[w][NA] > bb ? red[w][NA] : bb;
-    }
-    out.cost = tot[0];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) out.g[i] = tot[1 + i];
-#pragma unroll
-    for (int i = 0; i < NH; ++i) out.h[i] = tot[1 + NT + i];
-    return bb == 0.0 && isfinite(tot[0]);
+    out.v[0] = mx > 0.0 ? sqrt(mx) : 0.0;  // max raw residual
+    return badf == 0.0;
   }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = wave_sum(acc[i]);
+  if (WAVES > 1) {
+    double* r = red + parity * (WAVES * 12);
+    parity ^= 1;
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) r[wave * 12 + i] = acc[i];
+      r[wave * 12 + 10] = badf;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) acc[i] += r[w * 12 + i];
+      badf = r[w * 12 + 10] > badf ? r[w * 12 + 10] : badf;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) out.v[i] = acc[i];
+  return badf == 0.0 && isfinite(acc[0]);
 }
 
-// upper-triangular packed index
-template <int NT>
-__device__ __forceinline__ constexpr int hix(int i, int j) {
-  return i <= j ? (i * NT - i * (i - 1) / 2 + (j - i)) : (j * NT - j * (j - 1) / 2 + (i - j));
+// g = T g_b, H = T G T^T for the parameterisation at ambient point x (T is NT x 3, see header).
+template <int PARAM, int NT>
+__device__ __forceinline__ void to_param(const Base& B, const double* x, double* g, double* H /* NT*NT full */) {
+  double T[NT][3];
+  if (PARAM == RANDT_PARAM_VECTOR) {
+    T[0][0] = 1; T[0][1] = 0; T[0][2] = 0;
+    T[1][0] = 0; T[1][1] = 1; T[1][2] = 0;
+    T[2][0] = 0; T[2][1] = 0; T[2][2] = 1;
+  } else {
+    const double cp = x[0], sp = x[1];
+    const double n2 = cp * cp + sp * sp;
+    const double a = -sp / n2, b = cp / n2;  // d theta / d c, d theta / d s  (theta = atan2(s, c))
+    if (PARAM == RANDT_PARAM_AMBIENT4) {
+      T[0][0] = 0; T[0][1] = 0; T[0][2] = a;
+      T[1][0] = 0; T[1][1] = 0; T[1][2] = b;
+      T[2][0] = 1; T[2][1] = 0; T[2][2] = 0;
+      T[NT - 1][0] = 0; T[NT - 1][1] = 1; T[NT - 1][2] = 0;
+    } else {
+      // ambient row times Sophus PlusJacobian [[0,0,-s],[0,0,c],[c,-s,0],[s,c,0]] (stored complex)
+      T[0][0] = cp;  T[0][1] = sp; T[0][2] = 0;
+      T[1][0] = -sp; T[1][1] = cp; T[1][2] = 0;
+      T[2][0] = 0;   T[2][1] = 0;  T[2][2] = a * (-sp) + b * cp;
+    }
+  }
+  const double G[3][3] = {{B.v[4], B.v[5], B.v[6]}, {B.v[5], B.v[7], B.v[8]}, {B.v[6], B.v[8], B.v[9]}};
+  double TG[NT][3];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    g[i] = T[i][0] * B.v[1] + T[i][1] * B.v[2] + T[i][2] * B.v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) TG[i][j] = T[i][0] * G[0][j] + T[i][1] * G[1][j] + T[i][2] * G[2][j];
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) H[i * NT + j] = TG[i][0] * T[j][0] + TG[i][1] * T[j][1] + TG[i][2] * T[j][2];
 }
 
 // Solve of the NT x NT SPD system A y = g by LDL^T (A full, row-major, destroyed): NT reciprocals,
 // no square roots.  Returns false if a pivot is not positive.
 template <int NT>
-__device__ __forceinline__ bool chol_solve(double* A, const double* g, double* y) {
+__device__ __forceinline__ bool ldlt_solve(double* A, const double* g, double* y) {
   bool ok = true;
   double inv_d[NT];
 #pragma unroll
@@ -417,7 +407,6 @@ __device__ __forceinline__ bool chol_solve(double* A, const double* g, double* y
       A[i * NT + j] = a * inv_d[j];
     }
   }
-  // L z = g ; D w = z ; L^T y = w
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     double a = g[i];
@@ -446,21 +435,27 @@ __device__ __forceinline__ double ambient_norm(const double* x) {
   return sqrt(n);
 }
 
-// ||x - Plus(x, -g)||_inf (TrustRegionMinimizer::EvaluateGradientAndJacobian)
+// Is ||x - Plus(x, -g)||_inf <= gtol (TrustRegionMinimizer::GradientToleranceReached)?  For the
+// manifold the displacement is >= 0.4 max|g_i| (|omega| <= pi), so the exact Plus is only
+// evaluated for tiny gradients.
 template <int PARAM, int NT>
-__device__ __forceinline__ double grad_max_norm(const double* x, const double* g) {
+__device__ __forceinline__ bool gradient_converged(const double* x, const double* g, double gtol) {
+  double gm = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) gm = fabs(g[i]) > gm ? fabs(g[i]) : gm;
+  if (PARAM != RANDT_PARAM_MANIFOLD) return gm <= gtol;
+  if (0.4 * gm > gtol && gm < 3.0) return false;
   double neg[NT], xp[4];
 #pragma unroll
   for (int i = 0; i < NT; ++i) neg[i] = -g[i];
   plus<PARAM>(x, neg, xp);
   double m = 0.0;
-  constexpr int NA = PARAM == RANDT_PARAM_VECTOR ? 3 : 4;
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const double a = fabs(x[i] - xp[i]);
     m = a > m ? a : m;
   }
-  return m;
+  return m <= gtol;
 }
 
 __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost, double radius, int flag) {
@@ -475,15 +470,15 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
   }
 }
 
-template <int D, int PARAM, int BLOCK, bool STAGE>
+template <int D, int PARAM, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
-                                                       int moving_first, const int32_t* __restrict__ corr, SolveParams P,
-                                                       double* __restrict__ pose4, randt_result* __restrict__ results,
-                                                       double* trace, int trace_len) {
+                                                 int moving_first, const int32_t* __restrict__ corr, SolveParams P,
+                                                 double* __restrict__ pose4, randt_result* __restrict__ results,
+                                                 double* trace, int trace_len) {
   constexpr int NT = PARAM == RANDT_PARAM_AMBIENT4 ? 4 : 3;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double red[BLOCK / 64][24];
-  __shared__ int s_count;
+  constexpr int WAVES = BLOCK / 64;
+  __shared__ double red[2 * WAVES * 12];
+  __shared__ int s_count[WAVES];
 
   const int tid = threadIdx.x;
   const int pair = blockIdx.x;
@@ -492,69 +487,31 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
   const int k = P.k;
   int M = moving.counts[mmap];
   M = M > moving.cap ? moving.cap : M;
-  const int n_slots = M * k;
 
-  const randt_cell* mcells = moving.cells + (size_t)mmap * moving.cap;
-  const randt_cell* fcells = fixed.cells + (size_t)fmap * fixed.cap;
-  const int32_t* pc = corr + (size_t)pair * moving.cap * k;
   Stage S;
-  S.n_slots = n_slots;
+  S.mov = reinterpret_cast<const float*>(moving.cells + (size_t)mmap * moving.cap);
+  S.fix = reinterpret_cast<const float*>(fixed.cells + (size_t)fmap * fixed.cap);
+  S.corr = corr + (size_t)pair * moving.cap * k;
+  S.n_slots = M * k;
   S.k = k;
-  int n_res;
-  if (STAGE) {
-    // ---- stage the frozen correspondence set in LDS (addNDTFactor, ndt_matcher.cpp:217-246)
-    float* lmov = reinterpret_cast<float*>(smem);
-    float* lfix = lmov + (size_t)moving.cap * 9;
-    int* lvalid = reinterpret_cast<int*>(lfix + (size_t)moving.cap * k * 9);
-    if (tid == 0) s_count = 0;
-    __syncthreads();
-    for (int i = tid; i < M; i += BLOCK) {
-      const float4* q = reinterpret_cast<const float4*>(mcells + i);
-      const float4 a = q[0], b = q[1], c = q[2];
-      float* o = lmov + i * 9;
-      o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; o[8] = c.x;
-    }
-    int local = 0;
-    for (int sidx = tid; sidx < n_slots; sidx += BLOCK) {
-      int ci = pc[sidx];
-      if (ci >= fixed.cap) ci = -1;
-      lvalid[sidx] = ci;
-      if (ci >= 0) {
-        const float4* q = reinterpret_cast<const float4*>(fcells + ci);
-        const float4 a = q[0], b = q[1], c = q[2];
-        float* o = lfix + sidx * 9;
-        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; o[8] = c.x;
-        ++local;
-      }
-    }
-    if (local) atomicAdd(&s_count, local);
-    __syncthreads();
-    n_res = s_count;
-    S.mov = lmov;
-    S.fix = lfix;
-    S.valid = lvalid;
-  } else {
-    // ---- read the 48-byte records in place (L1/L2 resident after the first pass)
-    int local = 0;
-    for (int sidx = tid; sidx < n_slots; sidx += BLOCK) {
-      const int ci = pc[sidx];
-      local += (ci >= 0 && ci < fixed.cap) ? 1 : 0;
-    }
-    if (BLOCK == 64) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
-      n_res = local;
-    } else {
-      if (tid == 0) s_count = 0;
-      __syncthreads();
-      if (local) atomicAdd(&s_count, local);
-      __syncthreads();
-      n_res = s_count;
-    }
-    S.mov = reinterpret_cast<const float*>(mcells);
-    S.fix = reinterpret_cast<const float*>(fcells);
-    S.valid = pc;
+  S.fixed_cap = fixed.cap;
+
+  // number of residual blocks (addNDTFactor, ndt_matcher.cpp:217-246)
+  int n_res = 0;
+  for (int sidx = tid; sidx < S.n_slots; sidx += BLOCK) {
+    const int ci = S.corr[sidx];
+    n_res += (ci >= 0 && ci < fixed.cap) ? 1 : 0;
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n_res += __shfl_xor(n_res, off, 64);
+  if (WAVES > 1) {
+    if ((tid & 63) == 0) s_count[tid >> 6] = n_res;
+    __syncthreads();
+    n_res = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) n_res += s_count[w];
+  }
+  int parity = 0;
 
   double* tr = trace ? trace + (size_t)pair * trace_len : nullptr;
   if (tr && tid == 0) tr[0] = 0.0;
@@ -589,9 +546,9 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
 
   // ---- raw residuals at the initial point -> gnc_mu (ndt_matcher.cpp:466-476)
   Loss L = make_loss(P.loss_a, P.alpha, 1.0, P.weight);
-  Sums<NT> cur, cnd;
-  double raw_max = 0.0;
-  bool ok = eval_pass<D, PARAM, NT, 0, BLOCK, STAGE>(S, x, L, cur, raw_max, red);
+  Base cur, cnd;
+  bool ok = eval_pass<D, PARAM, 0, BLOCK>(S, x, L, cur, red, parity);
+  const double raw_max = cur.v[0];
   res.n_evals++;
   double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
   gnc_mu = fmin(gnc_mu, pow(P.gnc_div, (double)(P.gnc_steps - 1)));
@@ -606,6 +563,8 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
       L = make_loss(P.loss_a, P.alpha, gnc_mu, P.weight);
       // ================= one ceres::Solve (TrustRegionMinimizer::Minimize) =================
       double sigma[NT], diag[NT], step[NT], delta[NT], cand[4];
+      double gs[NT], Hs[NT * NT];  // Jacobi-scaled gradient / J^T J at the current point
+      double g[NT], H[NT * NT];
       double radius = P.r0, decrease = 2.0;
       bool reuse = false, step_ok = true;
       int num_invalid = 0, iteration = 0;
@@ -613,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
 #pragma unroll
       for (int i = 0; i < 4; ++i) x[i] = best[i];
       double x_norm = ambient_norm<PARAM>(x);
-      bool e_ok = eval_pass<D, PARAM, NT, 1, BLOCK, STAGE>(S, x, L, cur, raw_max, red);
+      const bool e_ok = eval_pass<D, PARAM, 1, BLOCK>(S, x, L, cur, red, parity);
       res.n_evals++;
       res.iterations++;
       if (!e_ok) {
@@ -622,34 +581,36 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         res.gnc_solves++;
         break;
       }
-      if (res.gnc_solves == 0) res.initial_cost = cur.cost;
-      summary_min = cur.cost;
+      double cost = cur.v[0];
+      if (res.gnc_solves == 0) res.initial_cost = cost;
+      summary_min = cost;
+      to_param<PARAM, NT>(cur, x, g, H);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) sigma[i] = 1.0 / (1.0 + sqrt(cur.h[hix<NT>(i, i)]));
-      double gmax = grad_max_norm<PARAM, NT>(x, cur.g);
-      trace_push(tr, trace_len, cur.cost, radius, 0);
+      for (int i = 0; i < NT; ++i) sigma[i] = 1.0 / (1.0 + sqrt(H[i * NT + i]));  // jacobi scaling, fixed per solve
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        gs[i] = g[i] * sigma[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Hs[i * NT + j] = H[i * NT + j] * sigma[i] * sigma[j];
+      }
+      bool gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
+      trace_push(tr, trace_len, cost, radius, 0);
 
       for (;;) {
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
-        if (step_ok && cur.cost < minimum_cost) {
-          minimum_cost = cur.cost;
+        if (step_ok && cost < minimum_cost) {
+          minimum_cost = cost;
 #pragma unroll
           for (int i = 0; i < 4; ++i) best[i] = x[i];
         }
         if (iteration >= P.max_it) { term = RANDT_TERM_NO_CONVERGENCE; break; }
-        if (step_ok && gmax <= P.gtol) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
+        if (step_ok && gconv) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
         if (radius <= P.rmin) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
         ++iteration;
         res.iterations++;
 
         // ---- LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled normal equations
-        double A[NT * NT], gs[NT], Hs[NT * NT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          gs[i] = cur.g[i] * sigma[i];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) Hs[i * NT + j] = cur.h[hix<NT>(i, j)] * sigma[i] * sigma[j];
-        }
+        double A[NT * NT];
         if (!reuse) {
 #pragma unroll
           for (int i = 0; i < NT; ++i) diag[i] = fmin(fmax(Hs[i * NT + i], P.dmin), P.dmax);
@@ -659,9 +620,9 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         for (int i = 0; i < NT; ++i) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) A[i * NT + j] = Hs[i * NT + j];
-          A[i * NT + i] += diag[i] * inv_radius;  // (sqrt(D^2/radius))^2
+          A[i * NT + i] += diag[i] * inv_radius;  // (sqrt(D^2 / radius))^2
         }
-        bool solved = chol_solve<NT>(A, gs, step);
+        bool solved = ldlt_solve<NT>(A, gs, step);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
           if (!isfinite(step[i])) solved = false;
@@ -686,8 +647,8 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
           decrease *= 2.0;
           reuse = true;
           step_ok = false;
-          summary_min = fmin(summary_min, cur.cost);
-          trace_push(tr, trace_len, cur.cost, radius, 3);
+          summary_min = fmin(summary_min, cost);
+          trace_push(tr, trace_len, cost, radius, 3);
           continue;
         }
         num_invalid = 0;
@@ -696,21 +657,21 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         plus<PARAM>(x, delta, cand);
 
         // ---- candidate cost (+ speculative gradient / J^T J)
-        bool c_ok = eval_pass<D, PARAM, NT, 1, BLOCK, STAGE>(S, cand, L, cnd, raw_max, red);
+        const bool c_ok = eval_pass<D, PARAM, 1, BLOCK>(S, cand, L, cnd, red, parity);
         res.n_evals++;
-        const double cand_cost = c_ok ? cnd.cost : DBL_MAX;
+        const double cand_cost = c_ok ? cnd.v[0] : DBL_MAX;
 
         // ---- ParameterToleranceReached / FunctionToleranceReached (before accept/reject)
-        double sn = 0.0;
+        double sn2 = 0.0;
         {
           constexpr int NAmb = PARAM == RANDT_PARAM_VECTOR ? 3 : 4;
 #pragma unroll
-          for (int i = 0; i < NAmb; ++i) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
-          sn = sqrt(sn);
+          for (int i = 0; i < NAmb; ++i) sn2 += (x[i] - cand[i]) * (x[i] - cand[i]);
         }
-        if (sn <= P.ptol * (x_norm + P.ptol)) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
-        const double cost_change = cur.cost - cand_cost;
-        if (fabs(cost_change) <= P.ftol * cur.cost) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
+        const double ptol_abs = P.ptol * (x_norm + P.ptol);
+        if (sn2 <= ptol_abs * ptol_abs) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
+        const double cost_change = cost - cand_cost;
+        if (fabs(cost_change) <= P.ftol * cost) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
 
         const double rel = c_ok ? cost_change / mcc : -DBL_MAX;
         if (rel > P.min_rel) {
@@ -718,16 +679,23 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
 #pragma unroll
           for (int i = 0; i < 4; ++i) x[i] = cand[i];
           x_norm = ambient_norm<PARAM>(x);
-          cur = cnd;
-          gmax = grad_max_norm<PARAM, NT>(x, cur.g);
+          cost = cand_cost;
+          to_param<PARAM, NT>(cnd, x, g, H);
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            gs[i] = g[i] * sigma[i];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) Hs[i * NT + j] = H[i * NT + j] * sigma[i] * sigma[j];
+          }
+          gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
           step_ok = true;
           const double t = 2.0 * rel - 1.0;
           radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
           radius = fmin(P.rmax, radius);
           decrease = 2.0;
           reuse = false;
-          summary_min = fmin(summary_min, cur.cost);
-          trace_push(tr, trace_len, cur.cost, radius, 1);
+          summary_min = fmin(summary_min, cost);
+          trace_push(tr, trace_len, cost, radius, 1);
         } else {
           step_ok = false;
           radius = radius / decrease;
@@ -758,37 +726,21 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
   }
 }
 
-template <int D, int PARAM, int BLOCK, bool STAGE>
+template <int D, int PARAM, int BLOCK>
 int launch_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
-               int n_pairs, const int32_t* d_corr, const SolveParams& P, size_t lds, double* d_pose4,
-               randt_result* d_results) {
-  if (STAGE)
-    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve<D, PARAM, BLOCK, STAGE>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_solve<D, PARAM, BLOCK, STAGE>), dim3(n_pairs), dim3(BLOCK), STAGE ? lds : 0, ctx->stream, fixed,
-                     d_fixed_idx, moving, moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len);
+               int n_pairs, const int32_t* d_corr, const SolveParams& P, double* d_pose4, randt_result* d_results) {
+  hipLaunchKernelGGL((k_solve<D, PARAM, BLOCK>), dim3(n_pairs), dim3(BLOCK), 0, ctx->stream, fixed, d_fixed_idx, moving,
+                     moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
 
-// Geometry: `block` threads cooperate on one registration (64 = one wavefront, no barriers);
-// stage = 1 copies the correspondence set into LDS first.
 template <int D, int PARAM>
 int launch_one(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
-               int n_pairs, const int32_t* d_corr, const SolveParams& P, size_t lds, double* d_pose4,
-               randt_result* d_results, int block, int stage) {
-#define RANDT_CFG(B, S) \
-  return launch_cfg<D, PARAM, B, S>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, lds, d_pose4, d_results)
-  if (stage) {
-    if (block == 64) RANDT_CFG(64, true);
-    if (block == 128) RANDT_CFG(128, true);
-    RANDT_CFG(256, true);
-  } else {
-    if (block == 64) RANDT_CFG(64, false);
-    if (block == 128) RANDT_CFG(128, false);
-    RANDT_CFG(256, false);
-  }
-#undef RANDT_CFG
+               int n_pairs, const int32_t* d_corr, const SolveParams& P, double* d_pose4, randt_result* d_results, int block) {
+  if (block == 64) return launch_cfg<D, PARAM, 64>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results);
+  if (block == 256) return launch_cfg<D, PARAM, 256>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results);
+  return launch_cfg<D, PARAM, 128>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results);
 }
 
 }  // namespace
@@ -817,12 +769,10 @@ int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_id
   P.k = mp->n_neighbours;
   P.max_invalid = mp->max_consecutive_invalid_steps;
   if (P.k <= 0) return randt_set_error(ctx, RANDT_ERR_INVALID, "n_neighbours must be > 0", hipSuccess);
-  const size_t lds = (size_t)moving.cap * 9 * 4 + (size_t)moving.cap * P.k * 9 * 4 + (size_t)moving.cap * P.k * 4;
-  int block = ctx->solve_block, stage = ctx->solve_stage;
-  if (stage && lds + 2048 > (size_t)ctx->lds_limit) stage = 0;  // too big for LDS: read cells in place
+  const int block = ctx->solve_block;
   const int d3 = mp->use_intensity ? 1 : 0;
 #define RANDT_DISPATCH(DD, PP) \
-  return launch_one<DD, PP>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, lds, d_pose4, d_results, block, stage)
+  return launch_one<DD, PP>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results, block)
   switch (mp->parameterization) {
     case RANDT_PARAM_MANIFOLD:
       if (d3) RANDT_DISPATCH(3, RANDT_PARAM_MANIFOLD); else RANDT_DISPATCH(2, RANDT_PARAM_MANIFOLD);

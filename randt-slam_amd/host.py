@@ -106,7 +106,7 @@ class Maps:
     so that torch.distributed can broadcast the submap tables); otherwise hipMalloc'ed by the library.
     """
 
-    def __init__(self, ctx, n_maps, params, capacity, with_grid=True, storage=None):
+    def __init__(self, ctx, n_maps, params, capacity, with_grid=True, storage=None, clear=True):
         self.ctx = ctx
         self._lib = ctx._lib
         self.n_maps, self.capacity, self.params = int(n_maps), int(capacity), params
@@ -125,7 +125,7 @@ class Maps:
             where = "randt_maps_create_external"
         ctx._check(rc, where)
         self._h = h
-        if storage is not None:
+        if storage is not None and clear:
             self.clear()
 
     @staticmethod
