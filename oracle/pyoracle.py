@@ -58,6 +58,23 @@ class SolveStats(C.Structure):
     ]
 
 
+class State(C.Structure):
+    _fields_ = [("pose", C.c_double * 4), ("pos", C.c_double * 2), ("rot", C.c_double), ("lin_vel", C.c_double * 2),
+                ("rot_vel", C.c_double), ("lin_acc", C.c_double * 2), ("imu_bias", C.c_double), ("stamp", C.c_double)]
+
+
+class WindowParams(C.Structure):
+    _fields_ = [("motion_sqrtI", C.c_double * 64), ("ndt_weight", C.c_double), ("weight_imu", C.c_double),
+                ("weight_imu_bias", C.c_double), ("pose_reject_translation", C.c_double), ("pose_reject_rotation", C.c_double),
+                ("smoothing_steps", C.c_int32), ("use_imu", C.c_int32), ("use_constant_velocity_model", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+STATE_DTYPE = np.dtype([("pose", "<f8", (4,)), ("pos", "<f8", (2,)), ("rot", "<f8"), ("lin_vel", "<f8", (2,)), ("rot_vel", "<f8"),
+                        ("lin_acc", "<f8", (2,)), ("imu_bias", "<f8"), ("stamp", "<f8")])
+assert STATE_DTYPE.itemsize == C.sizeof(State) == 112
+
+
 def build(force=False):
     src = os.path.join(_HERE, "randt_oracle.c")
     hdr = os.path.join(_HERE, "randt_oracle.h")
@@ -115,6 +132,12 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
     L.orc_se2_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_num_threads.restype = C.c_int
+    L.orc_predict_state.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+    L.orc_motion_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_imu_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    L.orc_register_window.restype = C.c_int
+    L.orc_register_window.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, P(MatcherParams),
+                                      P(WindowParams), C.c_void_p, P(SolveStats)]
     _lib = L
     return L
 
@@ -332,3 +355,70 @@ def se2_inv(a):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+# ------------------------------------------------------------------ fixed-lag window ----------
+def make_state(pose4, lin_vel=(0.0, 0.0), rot_vel=0.0, lin_acc=(0.0, 0.0), imu_bias=0.0, stamp=0.0):
+    st = np.zeros(1, dtype=STATE_DTYPE)[0]
+    st["pose"] = pose4
+    st["pos"] = pose4[2:]
+    st["rot"] = np.arctan2(pose4[1], pose4[0])
+    st["lin_vel"] = lin_vel
+    st["rot_vel"] = rot_vel
+    st["lin_acc"] = lin_acc
+    st["imu_bias"] = imu_bias
+    st["stamp"] = stamp
+    return st
+
+
+def window_params(motion_sqrtI_diag=(1, 1, 1, 1, 3, 0.1, 20, 60), covariance_scaling_factor=25.0, ndt_weight=5.0e4,
+                  weight_imu=64.0, weight_imu_bias=6.0e5, reject_t=2.0, reject_r=2.0, smoothing_steps=3, use_imu=0,
+                  const_vel=1):
+    """indoor values: config/parameters_indoor.yaml:32-39 + base yaml :36-47."""
+    wp = WindowParams()
+    M = np.diag(np.asarray(motion_sqrtI_diag, dtype=np.float64)) * covariance_scaling_factor
+    for i, v in enumerate(M.reshape(-1)):
+        wp.motion_sqrtI[i] = v
+    wp.ndt_weight, wp.weight_imu, wp.weight_imu_bias = ndt_weight, weight_imu, weight_imu_bias
+    wp.pose_reject_translation, wp.pose_reject_rotation = reject_t, reject_r
+    wp.smoothing_steps, wp.use_imu, wp.use_constant_velocity_model = smoothing_steps, use_imu, const_vel
+    return wp
+
+
+def predict_state(last, stamp):
+    a = np.array([last], dtype=STATE_DTYPE)
+    out = np.zeros(1, dtype=STATE_DTYPE)
+    lib().orc_predict_state(_ptr(a), float(stamp), _ptr(out))
+    return out[0]
+
+
+def motion_residual(x0, x1, sqrtI, want_jac=True):
+    a = np.array([x0], dtype=STATE_DTYPE)
+    b = np.array([x1], dtype=STATE_DTYPE)
+    M = np.ascontiguousarray(sqrtI, dtype=np.float64).reshape(64)
+    r = np.zeros(8)
+    J = np.zeros((8, 16))
+    lib().orc_motion_residual(_ptr(a), _ptr(b), _ptr(M), _ptr(r), _ptr(J) if want_jac else None)
+    return r, J
+
+
+def imu_residual(x0, x1, imu_rot, weight, bias_weight, want_jac=True):
+    a = np.array([x0], dtype=STATE_DTYPE)
+    b = np.array([x1], dtype=STATE_DTYPE)
+    r = np.zeros(2)
+    J = np.zeros((2, 8))
+    lib().orc_imu_residual(_ptr(a), _ptr(b), float(imu_rot), float(weight), float(bias_weight), _ptr(r), _ptr(J) if want_jac else None)
+    return r, J
+
+
+def register_window(fixed_maps, moving_maps, states, params, wparams, trans4, imu=None):
+    """states: STATE_DTYPE array (S+1), oldest first; returns (rc, states_out, trans_out, stats)."""
+    st = np.array(states, dtype=STATE_DTYPE).copy()
+    fx = (C.POINTER(OrcMap) * len(fixed_maps))(*[m._p for m in fixed_maps])
+    mv = (C.POINTER(OrcMap) * len(moving_maps))(*[m._p for m in moving_maps])
+    t = np.array(trans4, dtype=np.float64)
+    im = None if imu is None else np.ascontiguousarray(imu, dtype=np.float64)
+    ss = SolveStats()
+    rc = lib().orc_register_window(C.cast(fx, C.c_void_p), len(fixed_maps), C.cast(mv, C.c_void_p), _ptr(st), len(st),
+                                   _ptr(im) if im is not None else None, C.byref(params), C.byref(wparams), _ptr(t), C.byref(ss))
+    return rc, st, t, stats_to_dict(ss)

@@ -673,7 +673,7 @@ double orc_ndt_residual(int d, int parameterization, const double* pose4, const 
 
 /* ============================================================ generic LM (Ceres 2.1.0) ==== */
 
-#define ORC_MAX_TANGENT 32
+#define ORC_MAX_TANGENT 72
 
 typedef struct orc_problem {
   int n_ambient, n_tangent, n_res;
@@ -1222,4 +1222,485 @@ int orc_register_batch(int B, const float* pts, int n, int stride, int ioff, int
     orc_map_destroy(scan);
   }
   return fail;
+}
+
+/* ============================================================ fixed-lag window (a16/a17) == */
+
+/* predictSE2 (ceres_residuals.h:62-83): dt clamped to >= 0.2; screw uses 0.5*dt*a (sic). */
+static void predict_se2(const double pose[4], const double v[2], double w, const double a[2], double raw_dt,
+                        double pose_out[4], double v_out[2], double* w_out, double a_out[2]) {
+  const double dt = raw_dt > 0.2 ? raw_dt : 0.2;
+  double screw[3] = {v[0] * dt + 0.5 * dt * a[0], v[1] * dt + 0.5 * dt * a[1], w * dt};
+  double e[4];
+  orc_se2_exp(screw, e);
+  orc_se2_mul(pose, e, pose_out);
+  v_out[0] = v[0] + dt * a[0];
+  v_out[1] = v[1] + dt * a[1];
+  *w_out = w;
+  a_out[0] = a[0];
+  a_out[1] = a[1];
+}
+
+/* Matcher::predictTransform (ndt_matcher.cpp:22-59), optimize_on_manifold branch */
+void orc_predict_state(const orc_state* last, double stamp, orc_state* next) {
+  const double zero[2] = {0.0, 0.0}; /* last_state.lin_acc = Zero (:26) */
+  memset(next, 0, sizeof(*next));
+  predict_se2(last->pose, last->lin_vel, last->rot_vel, zero, stamp - last->stamp, next->pose, next->lin_vel,
+              &next->rot_vel, next->lin_acc);
+  next->pos[0] = next->pose[2];
+  next->pos[1] = next->pose[3];
+  next->rot = atan2(next->pose[1], next->pose[0]); /* pose.log()(2) */
+  next->imu_bias = 0.0;                            /* X_next_.imu_bias stays at Matcher::initialize's 0 (:15) */
+  next->stamp = stamp;
+}
+
+/* V(w) = [[a,-b],[b,a]], a = sin w / w, b = (1-cos w)/w and derivatives; Sophus' small-angle branch */
+static void se2_V(double w, double* a, double* b, double* da, double* db) {
+  if (fabs(w) < 1e-10) {
+    *a = 1.0 - w * w / 6.0;
+    *b = 0.5 * w - w * w * w / 24.0;
+    *da = -w / 3.0;
+    *db = 0.5 - w * w / 8.0;
+  } else {
+    const double s = sin(w), c = cos(w);
+    *a = s / w;
+    *b = (1.0 - c) / w;
+    *da = (w * c - s) / (w * w);
+    *db = (w * s - (1.0 - c)) / (w * w);
+  }
+}
+
+/* MotionModelFactorSE2 (ceres_residuals.h:621-679) with the Jacobian Ceres autodiff x
+ * Sophus::Manifold<SE2>::PlusJacobian yields (right perturbations X <- X exp(delta)). */
+void orc_motion_residual(const orc_state* x0, const orc_state* x1, const double* sqrtI, double* r8, double* J) {
+  const double raw_dt = x1->stamp - x0->stamp;
+  const double dt = raw_dt > 0.2 ? raw_dt : 0.2;
+  double pred[4], vp[2], wp_, ap[2];
+  predict_se2(x0->pose, x0->lin_vel, x0->rot_vel, x0->lin_acc, raw_dt, pred, vp, &wp_, ap);
+  double pinv[4], E[4], lg[3];
+  orc_se2_inv(pred, pinv);
+  orc_se2_mul(pinv, x1->pose, E);
+  orc_se2_log(E, lg);
+  double r[8] = {lg[0], lg[1], lg[2], x1->lin_vel[0] - vp[0], x1->lin_vel[1] - vp[1], x1->rot_vel - wp_,
+                 x1->lin_acc[0] - ap[0], x1->lin_acc[1] - ap[1]};
+  double Jr[8][16];
+  memset(Jr, 0, sizeof(Jr));
+  if (J) {
+    /* E = (R_E, t_E), phi = angle(E); r_xy = Vinv(phi) t_E, r_phi = phi */
+    const double phi = lg[2];
+    const double cE = E[0], sE = E[1], tEx = E[2], tEy = E[3];
+    double h, dh; /* Vinv = [[h, phi/2], [-phi/2, h]] */
+    if (fabs(E[0] - 1.0) < 1e-10) {
+      h = 1.0 - phi * phi / 12.0;
+      dh = -phi / 6.0;
+    } else {
+      const double half = 0.5 * phi, sh = sin(half), ch = cos(half);
+      h = half * ch / sh;
+      dh = 0.5 * ch / sh - 0.5 * half / (sh * sh);
+    }
+    const double Vi[2][2] = {{h, 0.5 * phi}, {-0.5 * phi, h}};
+    /* d(Vinv)/dphi * t_E */
+    const double dVt[2] = {dh * tEx + 0.5 * tEy, -0.5 * tEx + dh * tEy};
+    /* ---- X1 = X1 exp(d1): dphi = dw1, dt_E = R_E dv1 */
+    {
+      const double RE[2][2] = {{cE, -sE}, {sE, cE}};
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) Jr[i][8 + j] = Vi[i][0] * RE[0][j] + Vi[i][1] * RE[1][j];
+      Jr[0][8 + 2] = dVt[0];
+      Jr[1][8 + 2] = dVt[1];
+      Jr[2][8 + 2] = 1.0;
+    }
+    /* ---- pred = X0 exp(xi): dtheta_p and dt_p in terms of (dv0', dw0') of X0 and dxi */
+    const double xi[3] = {x0->lin_vel[0] * dt + 0.5 * dt * x0->lin_acc[0], x0->lin_vel[1] * dt + 0.5 * dt * x0->lin_acc[1],
+                          x0->rot_vel * dt};
+    double a, b, da, db;
+    se2_V(xi[2], &a, &b, &da, &db);
+    const double c0 = x0->pose[0], s0 = x0->pose[1];
+    const double Vxi[2] = {a * xi[0] - b * xi[1], b * xi[0] + a * xi[1]};   /* V(xi_w) xi_v */
+    const double dVxi[2] = {da * xi[0] - db * xi[1], db * xi[0] + da * xi[1]}; /* V'(xi_w) xi_v */
+    /* columns of dt_p (world frame) and dtheta_p for the 6 generators: X0 tangent (vx, vy, w) and xi (vx, vy, w) */
+    double dtp[6][2], dth[6];
+    /* X0 vx, vy: dt_p = R0 e_k */
+    dtp[0][0] = c0;  dtp[0][1] = s0;  dth[0] = 0;
+    dtp[1][0] = -s0; dtp[1][1] = c0;  dth[1] = 0;
+    /* X0 w: dt_p = R0 J V xi_v, dtheta_p = 1 */
+    dtp[2][0] = c0 * (-Vxi[1]) - s0 * Vxi[0];
+    dtp[2][1] = s0 * (-Vxi[1]) + c0 * Vxi[0];
+    dth[2] = 1;
+    /* xi vx, vy: dt_p = R0 V e_k */
+    dtp[3][0] = c0 * a - s0 * b;     dtp[3][1] = s0 * a + c0 * b;  dth[3] = 0;
+    dtp[4][0] = c0 * (-b) - s0 * a;  dtp[4][1] = s0 * (-b) + c0 * a; dth[4] = 0;
+    /* xi w: dt_p = R0 V' xi_v, dtheta_p = 1 */
+    dtp[5][0] = c0 * dVxi[0] - s0 * dVxi[1];
+    dtp[5][1] = s0 * dVxi[0] + c0 * dVxi[1];
+    dth[5] = 1;
+    /* dphi = -dtheta_p ; dt_E = -R_p^T dt_p - J t_E dtheta_p ; dr_xy = Vinv dt_E + dVt dphi */
+    const double cp = pred[0], sp = pred[1];
+    double G[6][3];
+    for (int g = 0; g < 6; ++g) {
+      const double ex = -(cp * dtp[g][0] + sp * dtp[g][1]) - (-tEy) * dth[g];
+      const double ey = -(-sp * dtp[g][0] + cp * dtp[g][1]) - (tEx) * dth[g];
+      const double dphi = -dth[g];
+      G[g][0] = Vi[0][0] * ex + Vi[0][1] * ey + dVt[0] * dphi;
+      G[g][1] = Vi[1][0] * ex + Vi[1][1] * ey + dVt[1] * dphi;
+      G[g][2] = dphi;
+    }
+    for (int i = 0; i < 3; ++i) {
+      Jr[i][0] = G[0][i];              /* X0 vx */
+      Jr[i][1] = G[1][i];              /* X0 vy */
+      Jr[i][2] = G[2][i];              /* X0 w  */
+      Jr[i][3] = G[3][i] * dt;         /* v0x: xi_vx = dt v0x + .. */
+      Jr[i][4] = G[4][i] * dt;         /* v0y */
+      Jr[i][5] = G[5][i] * dt;         /* w0:  xi_w = dt w0 */
+      Jr[i][6] = G[3][i] * 0.5 * dt;   /* a0x */
+      Jr[i][7] = G[4][i] * 0.5 * dt;   /* a0y */
+    }
+    /* rows 3..7 */
+    Jr[3][3] = -1; Jr[3][6] = -dt; Jr[3][8 + 3] = 1;
+    Jr[4][4] = -1; Jr[4][7] = -dt; Jr[4][8 + 4] = 1;
+    Jr[5][5] = -1; Jr[5][8 + 5] = 1;
+    Jr[6][6] = -1; Jr[6][8 + 6] = 1;
+    Jr[7][7] = -1; Jr[7][8 + 7] = 1;
+  }
+  /* residuals_map.applyOnTheLeft(sqrtI_) */
+  for (int i = 0; i < 8; ++i) {
+    double acc = 0;
+    for (int k = 0; k < 8; ++k) acc += sqrtI[i * 8 + k] * r[k];
+    r8[i] = acc;
+  }
+  if (J)
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 16; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 8; ++k) acc += sqrtI[i * 8 + k] * Jr[k][j];
+        J[i * 16 + j] = acc;
+      }
+}
+
+/* RotationalResidualSE2 (ceres_residuals.h:338-370) */
+void orc_imu_residual(const orc_state* x0, const orc_state* x1, double imu_rot, double weight, double bias_weight,
+                      double* r2, double* J) {
+  const double raw_dt = x1->stamp - x0->stamp; /* dt_ is NOT clamped here (ndt_matcher.cpp:147) */
+  double screw[3] = {0.0, 0.0, x1->imu_bias * raw_dt};
+  double e[4], M1[4], inv0[4], E[4], lg[3];
+  orc_se2_exp(screw, e);
+  orc_se2_mul(x1->pose, e, M1);
+  orc_se2_inv(x0->pose, inv0);
+  orc_se2_mul(inv0, M1, E);
+  orc_se2_log(E, lg);
+  r2[0] = weight * (imu_rot - lg[2]);
+  r2[1] = bias_weight * (x1->imu_bias - x0->imu_bias);
+  if (J) {
+    memset(J, 0, sizeof(double) * 16);
+    J[0 * 8 + 2] = weight;           /* d/dw0: phi = th1 + b1 dt - th0 */
+    J[0 * 8 + 3 + 2] = -weight;      /* d/dw1 */
+    J[0 * 8 + 7] = -weight * raw_dt; /* d/db1 */
+    J[1 * 8 + 6] = -bias_weight;     /* d/db0 */
+    J[1 * 8 + 7] = bias_weight;      /* d/db1 */
+  }
+}
+
+typedef struct win_user {
+  int S, F, d, k;               /* states 0..S (0 = oldest, pose constant), fixed maps */
+  int const_vel, use_imu;
+  orc_state base[8];            /* constant parts (stamps, oldest pose, constant blocks) */
+  const double* imu;
+  const double* sqrtI;
+  double weight_imu, weight_imu_bias;
+  /* NDT residuals, grouped by state j = 1..S */
+  int n_ndt;
+  int* ndt_state;
+  double *mm, *mc, *fm, *fc;
+  int apply_loss;
+  double loss_a, loss_alpha, loss_mu, loss_w;
+  /* layout */
+  int off_amb[8][5], off_tan[8][5]; /* block offsets per state: pose, v, w, a, b ; -1 = constant */
+  int n_amb, n_tan, n_res;
+} win_user;
+
+static void win_layout(win_user* u) {
+  int a = 0, t = 0;
+  for (int j = 0; j <= u->S; ++j) {
+    /* AddParameterBlock order: pose, lin_vel, rot_vel, lin_acc, [imu_bias] (ndt_matcher.cpp:290-320,146-181) */
+    if (j == 0) { u->off_amb[j][0] = u->off_tan[j][0] = -1; } else { u->off_amb[j][0] = a; u->off_tan[j][0] = t; a += 4; t += 3; }
+    u->off_amb[j][1] = a; u->off_tan[j][1] = t; a += 2; t += 2;
+    u->off_amb[j][2] = a; u->off_tan[j][2] = t; a += 1; t += 1;
+    if (u->const_vel) { u->off_amb[j][3] = u->off_tan[j][3] = -1; } else { u->off_amb[j][3] = a; u->off_tan[j][3] = t; a += 2; t += 2; }
+    if (u->use_imu && j > 0) { u->off_amb[j][4] = a; u->off_tan[j][4] = t; a += 1; t += 1; } else { u->off_amb[j][4] = u->off_tan[j][4] = -1; }
+  }
+  u->n_amb = a;
+  u->n_tan = t;
+}
+
+static void win_unpack(const win_user* u, const double* x, orc_state* st) {
+  for (int j = 0; j <= u->S; ++j) {
+    st[j] = u->base[j];
+    if (u->off_amb[j][0] >= 0) memcpy(st[j].pose, x + u->off_amb[j][0], sizeof(double) * 4);
+    memcpy(st[j].lin_vel, x + u->off_amb[j][1], sizeof(double) * 2);
+    st[j].rot_vel = x[u->off_amb[j][2]];
+    if (u->off_amb[j][3] >= 0) memcpy(st[j].lin_acc, x + u->off_amb[j][3], sizeof(double) * 2);
+    if (u->off_amb[j][4] >= 0) st[j].imu_bias = x[u->off_amb[j][4]];
+  }
+}
+
+static void win_pack(const win_user* u, const orc_state* st, double* x) {
+  for (int j = 0; j <= u->S; ++j) {
+    if (u->off_amb[j][0] >= 0) memcpy(x + u->off_amb[j][0], st[j].pose, sizeof(double) * 4);
+    memcpy(x + u->off_amb[j][1], st[j].lin_vel, sizeof(double) * 2);
+    x[u->off_amb[j][2]] = st[j].rot_vel;
+    if (u->off_amb[j][3] >= 0) memcpy(x + u->off_amb[j][3], st[j].lin_acc, sizeof(double) * 2);
+    if (u->off_amb[j][4] >= 0) x[u->off_amb[j][4]] = st[j].imu_bias;
+  }
+}
+
+static void win_plus(void* user, const double* x, const double* delta, double* xp) {
+  const win_user* u = (const win_user*)user;
+  for (int j = 0; j <= u->S; ++j) {
+    if (u->off_amb[j][0] >= 0) {
+      double e[4];
+      orc_se2_exp(delta + u->off_tan[j][0], e);
+      orc_se2_mul(x + u->off_amb[j][0], e, xp + u->off_amb[j][0]);
+    }
+    static const int sz[5] = {0, 2, 1, 2, 1};
+    for (int b = 1; b < 5; ++b)
+      if (u->off_amb[j][b] >= 0)
+        for (int e = 0; e < sz[b]; ++e) xp[u->off_amb[j][b] + e] = x[u->off_amb[j][b] + e] + delta[u->off_tan[j][b] + e];
+  }
+}
+
+/* scatter a factor's local Jacobian columns (blocks of state j: pose3 v2 w1 a2 [b1]) into the dense row */
+static void win_scatter(const win_user* u, double* row, int j, int blk, const double* vals, int n) {
+  const int off = u->off_tan[j][blk];
+  if (off < 0) return;
+  for (int e = 0; e < n; ++e) row[off + e] += vals[e];
+}
+
+/* Residual order = AddResidualBlock order (ndt_matcher.cpp:355-368): for i = S..1 (state j = S+1-i ... ),
+ * i.e. oldest pair first: motion(j-1,j), [imu(j-1,j)], NDT(j, f = 0..F-1). */
+static int win_eval(void* user, const double* x, double* cost, double* residuals, double* jac) {
+  win_user* u = (win_user*)user;
+  orc_state st[8];
+  win_unpack(u, x, st);
+  const int nt = u->n_tan;
+  double total = 0;
+  int row = 0, ndt_at = 0;
+  if (jac) memset(jac, 0, sizeof(double) * (size_t)u->n_res * nt);
+  for (int j = 1; j <= u->S; ++j) {
+    double r8[8], J[8 * 16];
+    orc_motion_residual(&st[j - 1], &st[j], u->sqrtI, r8, jac ? J : NULL);
+    for (int i = 0; i < 8; ++i) {
+      total += 0.5 * r8[i] * r8[i];
+      if (residuals) residuals[row + i] = r8[i];
+      if (jac) {
+        double* rw = jac + (size_t)(row + i) * nt;
+        win_scatter(u, rw, j - 1, 0, J + i * 16 + 0, 3);
+        win_scatter(u, rw, j - 1, 1, J + i * 16 + 3, 2);
+        win_scatter(u, rw, j - 1, 2, J + i * 16 + 5, 1);
+        win_scatter(u, rw, j - 1, 3, J + i * 16 + 6, 2);
+        win_scatter(u, rw, j, 0, J + i * 16 + 8, 3);
+        win_scatter(u, rw, j, 1, J + i * 16 + 11, 2);
+        win_scatter(u, rw, j, 2, J + i * 16 + 13, 1);
+        win_scatter(u, rw, j, 3, J + i * 16 + 14, 2);
+      }
+    }
+    row += 8;
+    if (u->use_imu) {
+      double r2[2], J2[16];
+      orc_imu_residual(&st[j - 1], &st[j], u->imu[j - 1], u->weight_imu, u->weight_imu_bias, r2, jac ? J2 : NULL);
+      for (int i = 0; i < 2; ++i) {
+        total += 0.5 * r2[i] * r2[i];
+        if (residuals) residuals[row + i] = r2[i];
+        if (jac) {
+          double* rw = jac + (size_t)(row + i) * nt;
+          win_scatter(u, rw, j - 1, 0, J2 + i * 8 + 0, 3);
+          win_scatter(u, rw, j, 0, J2 + i * 8 + 3, 3);
+          win_scatter(u, rw, j - 1, 4, J2 + i * 8 + 6, 1);
+          win_scatter(u, rw, j, 4, J2 + i * 8 + 7, 1);
+        }
+      }
+      row += 2;
+    }
+    while (ndt_at < u->n_ndt && u->ndt_state[ndt_at] == j) {
+      const int d = u->d;
+      double jl[4];
+      double r = orc_ndt_residual(d, ORC_PARAM_MANIFOLD, st[j].pose, u->mm + (size_t)ndt_at * d, u->mc + (size_t)ndt_at * d * d,
+                                  u->fm + (size_t)ndt_at * d, u->fc + (size_t)ndt_at * d * d, jac ? jl : NULL);
+      if (!isfinite(r)) return 0;
+      const double sq = r * r;
+      double rs = 1.0, js = 1.0;
+      if (u->apply_loss) {
+        double rho[3];
+        orc_barron_scaled(sq, u->loss_a, u->loss_alpha, u->loss_mu, u->loss_w, rho);
+        total += 0.5 * rho[0];
+        const double sqrt_rho1 = sqrt(rho[1]);
+        if (sq == 0.0 || rho[2] <= 0.0) {
+          rs = js = sqrt_rho1;
+        } else {
+          const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+          const double alpha = 1.0 - sqrt(D);
+          rs = sqrt_rho1 / (1 - alpha);
+          js = sqrt_rho1 * (1.0 - alpha);
+        }
+      } else {
+        total += 0.5 * sq;
+      }
+      if (residuals) residuals[row] = rs * r;
+      if (jac) {
+        double* rw = jac + (size_t)row * nt;
+        for (int e = 0; e < 3; ++e) rw[u->off_tan[j][0] + e] = js * jl[e];
+      }
+      ++row;
+      ++ndt_at;
+    }
+  }
+  *cost = total;
+  return 1;
+}
+
+int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* moving, orc_state* states, int n_states,
+                        const double* imu, const orc_matcher_params* p, const orc_window_params* wp, double trans4[4],
+                        orc_solve_stats* st) {
+  const int S = n_states - 1;
+  if (S < 1 || S > 7 || n_fixed < 1) return -1;
+  orc_solve_stats local;
+  if (!st) st = &local;
+  memset(st, 0, sizeof(*st));
+  const int k = p->n_neighbours, d = p->use_intensity ? 3 : 2;
+  /* prior for the rejection gate (ndt_matcher.cpp:339-340) */
+  const double prior_t[2] = {trans4[2], trans4[3]};
+  const double prior_rot = atan2(trans4[1], trans4[0]);
+
+  win_user u;
+  memset(&u, 0, sizeof(u));
+  u.S = S; u.F = n_fixed; u.d = d; u.k = k;
+  u.const_vel = wp->use_constant_velocity_model;
+  u.use_imu = wp->use_imu && imu;
+  u.imu = imu;
+  u.sqrtI = wp->motion_sqrtI;
+  u.weight_imu = wp->weight_imu;
+  u.weight_imu_bias = wp->weight_imu_bias;
+  for (int j = 0; j <= S; ++j) u.base[j] = states[j];
+  win_layout(&u);
+
+  /* addNDTFactor per state and fixed map; association at the state's own pose (ndt_matcher.cpp:363-366) */
+  int n_cells = 0, cap = 0;
+  for (int j = 1; j <= S; ++j) {
+    n_cells += moving[j - 1]->n_cells;
+    cap += moving[j - 1]->n_cells * k * n_fixed;
+  }
+  u.ndt_state = (int*)malloc(sizeof(int) * (size_t)(cap > 0 ? cap : 1));
+  u.mm = (double*)malloc(sizeof(double) * (size_t)(cap > 0 ? cap : 1) * d);
+  u.mc = (double*)malloc(sizeof(double) * (size_t)(cap > 0 ? cap : 1) * d * d);
+  u.fm = (double*)malloc(sizeof(double) * (size_t)(cap > 0 ? cap : 1) * d);
+  u.fc = (double*)malloc(sizeof(double) * (size_t)(cap > 0 ? cap : 1) * d * d);
+  int n = 0;
+  for (int j = 1; j <= S; ++j) {
+    const orc_map* mv = moving[j - 1];
+    int32_t* corr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(mv->n_cells > 0 ? mv->n_cells : 1) * k);
+    for (int f = 0; f < n_fixed; ++f) {
+      orc_associate(fixed[f], mv, states[j].pose, k, p->lookup_mahalanobis, p->use_intensity, corr);
+      for (int i = 0; i < mv->n_cells; ++i)
+        for (int q = 0; q < k; ++q) {
+          const int32_t ci = corr[(size_t)i * k + q];
+          if (ci < 0) continue;
+          u.ndt_state[n] = j;
+          for (int e = 0; e < d; ++e) {
+            u.mm[(size_t)n * d + e] = (double)mv->cells[i].mean[e];
+            u.fm[(size_t)n * d + e] = (double)fixed[f]->cells[ci].mean[e];
+          }
+          cell_cov_full(&mv->cells[i], d, u.mc + (size_t)n * d * d);
+          cell_cov_full(&fixed[f]->cells[ci], d, u.fc + (size_t)n * d * d);
+          ++n;
+        }
+    }
+    free(corr);
+  }
+  u.n_ndt = n;
+  u.n_res = n + S * 8 + (u.use_imu ? S * 2 : 0);
+  st->n_residuals = n;
+  u.loss_a = p->loss_scale;
+  u.loss_alpha = p->loss_alpha;
+  u.loss_w = (n_cells > 0) ? wp->ndt_weight / (double)(n_cells * k) : 0.0; /* ndt_matcher.cpp:392 */
+  u.loss_mu = 1.0;
+
+  orc_problem P;
+  P.user = &u;
+  P.eval = win_eval;
+  P.plus = win_plus;
+  P.n_res = u.n_res;
+  P.n_ambient = u.n_amb;
+  P.n_tangent = u.n_tan;
+
+  double x[64];
+  win_pack(&u, states, x);
+
+  /* raw NDT residuals -> gnc_mu (ndt_matcher.cpp:382-389) */
+  double max_res = 0.0;
+  int ok = 1;
+  if (n > 0) {
+    double* raw = (double*)malloc(sizeof(double) * (size_t)u.n_res);
+    double c0;
+    u.apply_loss = 0;
+    ok = win_eval(&u, x, &c0, raw, NULL);
+    /* NDT rows only */
+    int row = 0, at = 0;
+    max_res = -DBL_MAX;
+    for (int j = 1; j <= S; ++j) {
+      row += 8 + (u.use_imu ? 2 : 0);
+      while (at < n && u.ndt_state[at] == j) {
+        if (raw[row] > max_res) max_res = raw[row];
+        ++row;
+        ++at;
+      }
+    }
+    free(raw);
+  }
+  double gnc_mu = 2.0 * pow(max_res, 2) / pow(p->mu_scale, 2);
+  gnc_mu = fmin(gnc_mu, pow(p->gnc_divisor, (double)(p->gnc_steps - 1)));
+  st->max_raw_residual = max_res;
+  st->mu0 = gnc_mu;
+  int term = ORC_TERM_FAILURE;
+  double final_cost = 0;
+  u.apply_loss = 1;
+  if (ok) {
+    do {
+      gnc_mu = fmax(gnc_mu, 1.0);
+      u.loss_mu = gnc_mu;
+      term = lm_minimize(&P, p, x, st, &final_cost);
+      st->n_solves++;
+      gnc_mu /= p->gnc_divisor;
+    } while (gnc_mu > 1.0 / sqrt(p->gnc_divisor));
+  }
+  st->termination = term;
+  st->final_cost = final_cost;
+  win_unpack(&u, x, states);
+  /* both representations (ndt_matcher.cpp:403-406; local_fuser.cpp:141-150 does it for the whole window) */
+  for (int j = 0; j <= S; ++j) {
+    states[j].pos[0] = states[j].pose[2];
+    states[j].pos[1] = states[j].pose[3];
+    states[j].rot = atan2(states[j].pose[1], states[j].pose[0]);
+  }
+  int rejected = 0;
+  {
+    /* rejection gate (ndt_matcher.cpp:411-422) */
+    orc_state* X = &states[S];
+    /* (pose.so2().inverse() * SO2(prior_rotation)).log() */
+    const double pc = cos(prior_rot), ps = sin(prior_rot);
+    const double re = X->pose[0] * pc + X->pose[1] * ps, im = X->pose[0] * ps - X->pose[1] * pc;
+    const double dth = atan2(im, re);
+    if (fabs(X->pose[2] - prior_t[0]) > wp->pose_reject_translation || fabs(X->pose[3] - prior_t[1]) > wp->pose_reject_translation ||
+        fabs(dth) > wp->pose_reject_rotation) {
+      rejected = 1;
+      memcpy(X->pos, states[S - 1].pos, sizeof(X->pos));
+      memcpy(X->pose, states[S - 1].pose, sizeof(X->pose));
+      X->rot = states[S - 1].rot;
+      X->lin_vel[0] = X->lin_vel[1] = 0.0;
+      X->rot_vel = 0.0;
+      X->lin_acc[0] = X->lin_acc[1] = 0.0;
+      X->imu_bias = states[S - 1].imu_bias;
+    }
+  }
+  memcpy(trans4, states[S].pose, sizeof(double) * 4);
+  free(u.ndt_state); free(u.mm); free(u.mc); free(u.fm); free(u.fc);
+  return ok ? rejected : -2;
 }

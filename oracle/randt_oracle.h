@@ -171,6 +171,44 @@ int orc_register_batch(int B, const float* pts, int n, int stride, int ioff, int
                        const orc_matcher_params* p, const double* guess4, double* pose4_out,
                        double* cost_out, int32_t* iters_out, int n_threads);
 
+/* ---------------------------------------------------------------- fixed-lag window (a16/a17) */
+
+/* rc::navigation::ndt::State (include/ndt_slam/trajectory_representation.h:12-22) as a POD. */
+typedef struct orc_state {
+  double pose[4]; /* Sophus::SE2d data: cos, sin, tx, ty */
+  double pos[2];
+  double rot;
+  double lin_vel[2];
+  double rot_vel;
+  double lin_acc[2];
+  double imu_bias;
+  double stamp;
+} orc_state;
+
+typedef struct orc_window_params {
+  double motion_sqrtI[64];  /* covariance_scaling_factor * motion_sqrtI, row-major 8x8 (ndt_matcher.cpp:99) */
+  double ndt_weight, weight_imu, weight_imu_bias;
+  double pose_reject_translation, pose_reject_rotation;
+  int32_t smoothing_steps, use_imu, use_constant_velocity_model, reserved;
+} orc_window_params;
+
+/* Matcher::predictTransform, manifold branch (ndt_matcher.cpp:22-59) -> predictSE2 (ceres_residuals.h:62-83) */
+void orc_predict_state(const orc_state* last, double stamp, orc_state* next);
+/* MotionModelFactorSE2 (ceres_residuals.h:621-679): 8 residuals (already multiplied by sqrtI) and
+ * the 8 x 16 row-major Jacobian w.r.t. tangent [X0: pose3 v2 w1 a2 | X1: pose3 v2 w1 a2]. */
+void orc_motion_residual(const orc_state* x0, const orc_state* x1, const double* sqrtI, double* r8, double* J8x16);
+/* RotationalResidualSE2 (ceres_residuals.h:338-370): 2 residuals, 2 x 8 Jacobian w.r.t.
+ * [X0 pose3, X1 pose3, b0, b1]. */
+void orc_imu_residual(const orc_state* x0, const orc_state* x1, double imu_rot, double weight, double bias_weight,
+                      double* r2, double* J2x8);
+/* Matcher::estimateTransformCeres (ndt_matcher.cpp:322-424).  states: n_states = S+1 (oldest first,
+ * its pose constant); moving: S maps for states 1..S; fixed: n_fixed maps; imu: S constraints (pair j
+ * = states j, j+1) or NULL.  trans4: in = prior pose for the rejection gate, out = newest pose.
+ * returns 1 if the estimate was rejected (ndt_matcher.cpp:411-422), 0 otherwise, <0 on failure. */
+int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* moving, orc_state* states, int n_states,
+                        const double* imu, const orc_matcher_params* p, const orc_window_params* wp, double trans4[4],
+                        orc_solve_stats* st);
+
 /* ---------------------------------------------------------------- SE(2) helpers (Sophus) --- */
 void orc_se2_exp(const double xi[3], double out4[4]);
 void orc_se2_log(const double p4[4], double xi[3]);

@@ -1,0 +1,152 @@
+"""Fixed-lag window restatement: motion-model and IMU factor Jacobians
+against finite differences on the manifold, prediction, and estimateTransformCeres behaviour."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+from randt_slam_amd import synth
+from util import IP, oracle_scan_map, oracle_submap, problem
+
+
+def rand_state(rng, stamp):
+    th = rng.uniform(-3, 3)
+    return po.make_state([np.cos(th), np.sin(th), rng.normal(0, 3), rng.normal(0, 3)], lin_vel=rng.normal(0, 1, 2),
+                         rot_vel=rng.normal(0, 0.5), lin_acc=rng.normal(0, 0.3, 2), imu_bias=rng.normal(0, 0.01), stamp=stamp)
+
+
+def perturb(st, blk, e, eps):
+    """right-perturb tangent coordinate e of block blk (0 pose3, 1 v2, 2 w1, 3 a2, 4 b1)."""
+    s = st.copy()
+    if blk == 0:
+        d = np.zeros(3); d[e] = eps
+        s["pose"] = po.se2_mul(st["pose"], po.se2_exp(d))
+    elif blk == 1:
+        s["lin_vel"][e] += eps
+    elif blk == 2:
+        s["rot_vel"] += eps
+    elif blk == 3:
+        s["lin_acc"][e] += eps
+    else:
+        s["imu_bias"] += eps
+    return s
+
+
+@pytest.mark.parametrize("dt", [0.25, 0.05, 1.0])
+def test_motion_factor_jacobian_fd(built, dt):
+    rng = np.random.default_rng(int(dt * 100))
+    sqrtI = np.diag([1, 1, 1, 1, 3, 0.1, 20, 60.0]) * 25 + rng.normal(0, 0.1, (8, 8))   # full matrix on purpose
+    for trial in range(5):
+        x0, x1 = rand_state(rng, 10.0), rand_state(rng, 10.0 + dt)
+        if trial == 4:   # near-identity relative pose: small-angle branches
+            x0["rot_vel"] = 1e-13
+            x1["pose"] = po.se2_mul(x0["pose"], po.se2_exp([x0["lin_vel"][0] * max(dt, .2), x0["lin_vel"][1] * max(dt, .2), 0.0]))
+        r, J = po.motion_residual(x0, x1, sqrtI)
+        cols = [(0, 0, 0), (0, 0, 1), (0, 0, 2), (0, 1, 0), (0, 1, 1), (0, 2, 0), (0, 3, 0), (0, 3, 1),
+                (1, 0, 0), (1, 0, 1), (1, 0, 2), (1, 1, 0), (1, 1, 1), (1, 2, 0), (1, 3, 0), (1, 3, 1)]
+        # near the identity Sophus' log loses digits in (cos(phi) - 1) for 1e-5 > |phi| > 1e-10 (restated
+        # faithfully), so the finite-difference step is kept out of that band for the small-angle trial
+        eps = 1e-6 if trial < 4 else 3e-3
+        for c, (which, blk, e) in enumerate(cols):
+            a = (perturb(x0, blk, e, eps), x1) if which == 0 else (x0, perturb(x1, blk, e, eps))
+            b = (perturb(x0, blk, e, -eps), x1) if which == 0 else (x0, perturb(x1, blk, e, -eps))
+            fd = (po.motion_residual(*a, sqrtI, False)[0] - po.motion_residual(*b, sqrtI, False)[0]) / (2 * eps)
+            tol = 2e-5 if trial < 4 else 2e-3
+            assert np.allclose(J[:, c], fd, rtol=tol, atol=tol), (trial, c, J[:, c], fd)
+    # a perfect constant-velocity pair has zero residual (dt >= 0.2, no clamp active)
+    if dt >= 0.2:
+        x0 = rand_state(rng, 0.0); x0["lin_acc"] = 0
+        x1 = po.predict_state(x0, dt)
+        r, _ = po.motion_residual(x0, x1, sqrtI)
+        assert np.allclose(r, 0, atol=1e-9)
+
+
+def test_prediction_clamps_dt_and_zeroes_acceleration(built):
+    x0 = po.make_state([1, 0, 0, 0], lin_vel=(1.0, 0.0), rot_vel=0.0, lin_acc=(5.0, 5.0), stamp=3.0)
+    x1 = po.predict_state(x0, 3.0)            # identical stamps -> dt clamped to 0.2 (ceres_residuals.h:73)
+    assert np.allclose(x1["pose"], [1, 0, 0.2, 0]) and np.allclose(x1["lin_vel"], [1, 0]) and np.allclose(x1["lin_acc"], 0)
+    x0["rot_vel"] = 0.5
+    x1 = po.predict_state(x0, 4.0)
+    xi = [1.0, 0.0, 0.5]
+    assert np.allclose(x1["pose"], po.se2_exp(xi)) and np.isclose(x1["rot"], 0.5)
+
+
+def test_imu_factor_jacobian_fd(built):
+    rng = np.random.default_rng(5)
+    x0, x1 = rand_state(rng, 1.0), rand_state(rng, 1.25)
+    r, J = po.imu_residual(x0, x1, 0.03, 64.0, 6e5)
+    eps = 1e-6
+    cols = [(0, 0, 0), (0, 0, 1), (0, 0, 2), (1, 0, 0), (1, 0, 1), (1, 0, 2), (0, 4, 0), (1, 4, 0)]
+    for c, (which, blk, e) in enumerate(cols):
+        a = (perturb(x0, blk, e, eps), x1) if which == 0 else (x0, perturb(x1, blk, e, eps))
+        b = (perturb(x0, blk, e, -eps), x1) if which == 0 else (x0, perturb(x1, blk, e, -eps))
+        fd = (po.imu_residual(*a, 0.03, 64.0, 6e5, False)[0] - po.imu_residual(*b, 0.03, 64.0, 6e5, False)[0]) / (2 * eps)
+        assert np.allclose(J[:, c], fd, rtol=1e-5, atol=1e-3), (c, J[:, c], fd)
+
+
+def _window_setup(n_scans=6, dt=0.25, seed=3100):
+    """a short drive inside one submap: truth poses, scans, submap from the first scans."""
+    world = synth.make_world()
+    traj = synth.make_trajectory(seed, n_scans + 34, step=0.25)
+    origin_inv = synth.se2_inv3(traj[0])
+    rel = np.array([synth.se2_mul3(origin_inv, p) for p in traj])
+    rel[:, 2] = synth.wrap_angle(rel[:, 2])
+    sub = po.Map(IP["size_x"], IP["size_y"], IP["resolution"], (0, 0), IP["max_neighbour_dist"], IP["min_points_per_cell"])
+    for t in range(0, 32, 4):
+        s = oracle_scan_map(synth.make_scan(world, traj[t], 7000 + t))
+        s.transform(synth.pose3_to_pose4(rel[t]))
+        sub.merge(s)
+    scans = [oracle_scan_map(synth.make_scan(world, traj[32 + i], 8000 + i)) for i in range(n_scans)]
+    return sub, scans, rel[32:32 + n_scans], dt
+
+
+def test_window_registration_tracks_truth(built):
+    sub, scans, truth, dt = _window_setup()
+    prm = po.default_params(parameterization=po.PARAM_MANIFOLD, gnc_steps=3)
+    wp = po.window_params()
+    v_true = np.array([0.25 / dt, 0.0])
+    # start from the true first pose with a wrong velocity guess
+    states = [po.make_state(synth.pose3_to_pose4(truth[0]), lin_vel=v_true * 0.8, rot_vel=0.0, stamp=0.0)]
+    window = []
+    trans = synth.pose3_to_pose4(truth[0])
+    for i in range(1, len(scans)):
+        states.append(po.predict_state(states[-1], i * dt))
+        window.append(scans[i])
+        S = min(len(states) - 1, 3)
+        rc, out, trans, st = po.register_window([sub], window[-S:], np.array(states[-S - 1:], dtype=po.STATE_DTYPE), prm, wp, trans)
+        assert rc == 0 and st["termination"] in (1, 2, 3)
+        for j in range(S + 1):
+            states[len(states) - S - 1 + j] = out[j]
+        est = synth.pose4_to_pose3(trans)
+        assert np.all(np.abs(est[:2] - truth[i][:2]) < 0.08) and abs(synth.wrap_angle(est[2] - truth[i][2])) < 0.03, (i, est, truth[i])
+        assert st["n_solves"] == 3 or st["mu0"] < 1.3 ** 2
+        if window.__len__() >= 3:
+            window.pop(0)
+    # the smoother recovered the speed (0.25 m per 0.25 s = 1 m/s in the body frame)
+    assert abs(np.hypot(*states[-1]["lin_vel"]) - 1.0) < 0.15
+
+
+def test_window_with_zero_motion_weight_equals_pair_registration(built):
+    """S = 1 and a null motion factor: the window problem reduces to the manifold pair problem."""
+    sub, scans, truth, dt = _window_setup(n_scans=2)
+    g4 = synth.pose3_to_pose4(synth.perturb_pose(truth[1], 42, dt=0.1, dtheta_deg=1.0))
+    k = 4
+    w = 5.0e4 / (scans[1].n_cells * k)
+    prm = po.default_params(parameterization=po.PARAM_MANIFOLD, gnc_steps=3, loss_weight=w, parameter_tolerance=0.0)
+    rc, p_pair, cost, st_pair = po.register_pair(sub, scans[1], prm, g4)
+    wp = po.window_params(covariance_scaling_factor=0.0)
+    states = np.array([po.make_state(synth.pose3_to_pose4(truth[0]), stamp=0.0), po.make_state(g4, stamp=dt)], dtype=po.STATE_DTYPE)
+    rc, out, trans, st_win = po.register_window([sub], [scans[1]], states, prm, wp, g4)
+    assert np.allclose(trans, p_pair, atol=1e-9)
+    assert np.allclose(st_win["trace_cost"], st_pair["trace_cost"], rtol=1e-9)
+
+
+def test_rejection_gate(built):
+    sub, scans, truth, dt = _window_setup(n_scans=2)
+    prm = po.default_params(parameterization=po.PARAM_MANIFOLD, gnc_steps=3)
+    wp = po.window_params(reject_t=0.001)      # everything deviates by more than 1 mm from the prior
+    prev = po.make_state(synth.pose3_to_pose4(truth[0]), lin_vel=(1.0, 0.0), stamp=0.0)
+    states = np.array([prev, po.predict_state(prev, dt)], dtype=po.STATE_DTYPE)
+    rc, out, trans, st = po.register_window([sub], [scans[1]], states, prm, wp, synth.pose3_to_pose4(truth[0]))
+    assert rc == 1                                           # "Rejected new estimated transform!"
+    assert np.array_equal(out[1]["pose"], out[0]["pose"]) and np.all(out[1]["lin_vel"] == 0) and out[1]["rot_vel"] == 0
+    assert np.array_equal(trans, out[0]["pose"])
