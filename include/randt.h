@@ -118,6 +118,31 @@ typedef struct randt_result {
   int32_t reserved[2];
 } randt_result;
 
+/* rc::navigation::ndt::State (include/ndt_slam/trajectory_representation.h:12-22) as a POD:
+ * both pose representations, velocities, acceleration, IMU bias, stamp. 14 doubles. */
+typedef struct randt_state {
+  double pose[4]; /* Sophus::SE2d data: cos, sin, tx, ty */
+  double pos[2];
+  double rot;
+  double lin_vel[2];
+  double rot_vel;
+  double lin_acc[2];
+  double imu_bias;
+  double stamp;
+} randt_state;
+
+/* Fixed-lag smoother part of NDTMatcherParameters (ndt_slam_parameters.h:52-84). */
+typedef struct randt_window_params {
+  double motion_sqrtI[64];  /* covariance_scaling_factor * motion_sqrtI, row-major 8x8 (ndt_matcher.cpp:99) */
+  double ndt_weight;
+  double weight_imu, weight_imu_bias;
+  double pose_reject_translation, pose_reject_rotation;
+  int32_t smoothing_steps;
+  int32_t use_imu;
+  int32_t use_constant_velocity_model;
+  int32_t reserved;
+} randt_window_params;
+
 typedef struct randt_ctx randt_ctx;
 typedef struct randt_maps randt_maps; /* a batch of device-resident NDT maps with common parameters */
 
@@ -220,6 +245,24 @@ int randt_scan_register_batch_dev(randt_ctx* ctx, const float* d_points, int n_s
 /* Host convenience: one pair, synchronous (double Matcher::estimateLoopConstraint(trans, old, new, ...)). */
 int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving,
                         int moving_idx, const randt_matcher_params* mp, double h_pose4[4], randt_result* h_result);
+
+/* ------------------------------------------------------------------ fixed-lag window (a16, a17) */
+/* Matcher::predictTransform, optimize_on_manifold branch (ndt_matcher.cpp:22-59) with predictSE2
+ * (ceres_residuals.h:62-83): constant-velocity prediction of the next state.  Host-side O(1) math. */
+int randt_predict_state(const randt_state* last, double stamp, randt_state* next);
+/* Matcher::estimateTransformCeres (ndt_matcher.cpp:322-424): fixed-lag smoother over n_states = S+1
+ * states (oldest first; its pose is held constant), S <= 3.  Per state j = 1..S: MotionModelFactorSE2 to
+ * its predecessor (ceres_residuals.h:621-679), optional RotationalResidualSE2 (:338-370, h_imu[j-1]),
+ * and NDT factors of moving map moving_idx[j-1] against every fixed map (association at the state's
+ * own pose), robustified by Scaled(Barron) with weight ndt_weight / (n_cells * k); GNC loop as in the
+ * pair registration; whole LM loop on the device.  h_states in/out (both pose representations are
+ * synchronised on return, cf. local_fuser.cpp:141-150); h_trans4 in: prior pose for the rejection
+ * gate (ndt_matcher.cpp:339-340,411-422), out: newest pose.  *rejected = 1 if the gate fired.
+ * mp->parameterization must be RANDT_PARAM_MANIFOLD (the shipped configuration). */
+int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
+                          const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
+                          const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
+                          double h_trans4[4], int* rejected, randt_result* h_result);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,17 @@ class MatcherParams(C.Structure):
     ]
 
 
+class WindowParams(C.Structure):
+    _fields_ = [("motion_sqrtI", C.c_double * 64), ("ndt_weight", C.c_double), ("weight_imu", C.c_double),
+                ("weight_imu_bias", C.c_double), ("pose_reject_translation", C.c_double), ("pose_reject_rotation", C.c_double),
+                ("smoothing_steps", C.c_int32), ("use_imu", C.c_int32), ("use_constant_velocity_model", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+STATE_DTYPE = np.dtype([("pose", "<f8", (4,)), ("pos", "<f8", (2,)), ("rot", "<f8"), ("lin_vel", "<f8", (2,)), ("rot_vel", "<f8"),
+                        ("lin_acc", "<f8", (2,)), ("imu_bias", "<f8"), ("stamp", "<f8")])
+assert STATE_DTYPE.itemsize == 112
+
 # every symbol include/randt.h declares: name -> (restype, argtypes)
 _V, _I, _P = C.c_void_p, C.c_int, C.POINTER
 SYMBOLS = {
@@ -83,6 +94,8 @@ SYMBOLS = {
     "randt_register_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _P(MatcherParams), _V, _V]),
     "randt_scan_register_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ClusterParams), _V, _V, _V, _P(MatcherParams), _V, _V]),
     "randt_register_pair": (_I, [_V, _V, _I, _V, _I, _P(MatcherParams), _V, _V]),
+    "randt_predict_state": (_I, [_V, C.c_double, _V]),
+    "randt_register_window": (_I, [_V, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _P(_I), _V]),
 }
 
 _lib = None

@@ -457,4 +457,196 @@ int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   return rc;
 }
 
+
+// ------------------------------------------------------------------ fixed-lag window (a16, a17) --
+namespace {
+void h_so2_normalize(double& c, double& s) {
+  const double len = sqrt(c * c + s * s);
+  c = c / len;
+  s = s / len;
+}
+// Sophus SE2::exp and group product (se2.hpp, so2.hpp), host copies for the O(1) prediction step
+void h_se2_exp(const double* xi, double* out) {
+  const double theta = xi[2];
+  double c = cos(theta), s = sin(theta);
+  h_so2_normalize(c, s);
+  double sbt, omcbt;
+  if (fabs(theta) < 1e-10) {
+    const double tsq = theta * theta;
+    sbt = 1.0 - (1.0 / 6.0) * tsq;
+    omcbt = 0.5 * theta - (1.0 / 24.0) * theta * tsq;
+  } else {
+    sbt = s / theta;
+    omcbt = (1.0 - c) / theta;
+  }
+  out[0] = c;
+  out[1] = s;
+  out[2] = sbt * xi[0] - omcbt * xi[1];
+  out[3] = omcbt * xi[0] + sbt * xi[1];
+}
+void h_se2_mul(const double* a, const double* b, double* out) {
+  double re = a[0] * b[0] - a[1] * b[1];
+  double im = a[0] * b[1] + a[1] * b[0];
+  const double sq = re * re + im * im;
+  if (sq != 1.0) {
+    const double scale = 2.0 / (1.0 + sq);
+    re *= scale;
+    im *= scale;
+  }
+  h_so2_normalize(re, im);
+  const double tx = a[2] + (a[0] * b[2] - a[1] * b[3]);
+  const double ty = a[3] + (a[1] * b[2] + a[0] * b[3]);
+  out[0] = re;
+  out[1] = im;
+  out[2] = tx;
+  out[3] = ty;
+}
+}  // namespace
+
+int randt_predict_state(const randt_state* last, double stamp, randt_state* next) {
+  if (!last || !next) return RANDT_ERR_INVALID;
+  // predictSE2 with last_state.lin_acc = 0 (ndt_matcher.cpp:26,44-54; ceres_residuals.h:62-83)
+  const double raw_dt = stamp - last->stamp;
+  const double dt = raw_dt > 0.2 ? raw_dt : 0.2;
+  const double screw[3] = {last->lin_vel[0] * dt, last->lin_vel[1] * dt, last->rot_vel * dt};
+  double e[4];
+  randt_state n;
+  memset(&n, 0, sizeof(n));
+  h_se2_exp(screw, e);
+  h_se2_mul(last->pose, e, n.pose);
+  n.lin_vel[0] = last->lin_vel[0];
+  n.lin_vel[1] = last->lin_vel[1];
+  n.rot_vel = last->rot_vel;
+  n.lin_acc[0] = n.lin_acc[1] = 0.0;
+  n.pos[0] = n.pose[2];
+  n.pos[1] = n.pose[3];
+  n.rot = atan2(n.pose[1], n.pose[0]);
+  n.imu_bias = 0.0;  // X_next_.imu_bias keeps Matcher::initialize's value (ndt_matcher.cpp:15)
+  n.stamp = stamp;
+  *next = n;
+  return RANDT_OK;
+}
+
+int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
+                          const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
+                          const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
+                          double h_trans4[4], int* rejected, randt_result* h_result) {
+  if (!ctx || !fixed || !moving || !h_fixed_idx || !h_moving_idx || !h_states || !mp || !wp || !h_trans4) return RANDT_ERR_INVALID;
+  const int S = n_states - 1;
+  if (S < 1 || S > 3 || n_fixed < 1 || n_fixed > 2) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..3 optimised states, 1..2 fixed maps", hipSuccess);
+  if (mp->parameterization != RANDT_PARAM_MANIFOLD) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window solve implements the manifold configuration", hipSuccess);
+  if (mp->n_neighbours <= 0 || mp->n_neighbours > 8) return RANDT_ERR_INVALID;
+  for (int f = 0; f < n_fixed; ++f)
+    if (!range_ok(fixed, h_fixed_idx[f], 1)) return RANDT_ERR_INVALID;
+  for (int j = 0; j < S; ++j)
+    if (!range_ok(moving, h_moving_idx[j], 1)) return RANDT_ERR_INVALID;
+  const int k = mp->n_neighbours;
+  const double prior_t[2] = {h_trans4[2], h_trans4[3]};
+  const double prior_rot = atan2(h_trans4[1], h_trans4[0]);
+
+  WinDesc W;
+  memset(&W, 0, sizeof(W));
+  W.S = S;
+  W.k = k;
+  W.d3 = mp->use_intensity ? 1 : 0;
+  W.const_vel = wp->use_constant_velocity_model ? 1 : 0;
+  W.use_imu = (wp->use_imu && h_imu) ? 1 : 0;
+  W.w_imu = wp->weight_imu;
+  W.w_bias = wp->weight_imu_bias;
+  W.ndt_weight = wp->ndt_weight;
+  memcpy(W.sqrtI, wp->motion_sqrtI, sizeof(W.sqrtI));
+  // tangent / ambient layout in Ceres' parameter-block order (ndt_matcher.cpp:290-320)
+  int a = 0, t = 0;
+  for (int j = 0; j <= S; ++j) {
+    if (j == 0) { W.off_amb[j][0] = W.off_tan[j][0] = -1; } else { W.off_amb[j][0] = a; W.off_tan[j][0] = t; a += 4; t += 3; }
+    W.off_amb[j][1] = a; W.off_tan[j][1] = t; a += 2; t += 2;
+    W.off_amb[j][2] = a; W.off_tan[j][2] = t; a += 1; t += 1;
+    if (W.const_vel) { W.off_amb[j][3] = W.off_tan[j][3] = -1; } else { W.off_amb[j][3] = a; W.off_tan[j][3] = t; a += 2; t += 2; }
+    if (W.use_imu && j > 0) { W.off_amb[j][4] = a; W.off_tan[j][4] = t; a += 1; t += 1; } else { W.off_amb[j][4] = W.off_tan[j][4] = -1; }
+    if (j > 0) {
+      W.raw_dt[j] = h_states[j].stamp - h_states[j - 1].stamp;
+      W.imu[j - 1] = W.use_imu ? h_imu[j - 1] : 0.0;
+    }
+  }
+  W.n_amb = a;
+  W.n_tan = t;
+  W.n_terms = 0;
+  int32_t h_idx[2 * RANDT_WIN_MAX_TERMS];
+  double h_guess[4 * RANDT_WIN_MAX_TERMS];
+  for (int j = 1; j <= S; ++j)
+    for (int f = 0; f < n_fixed; ++f) {
+      const int q = W.n_terms++;
+      W.term_state[q] = j;
+      W.term_moving[q] = h_moving_idx[j - 1];
+      W.term_fixed[q] = h_fixed_idx[f];
+      h_idx[q] = h_fixed_idx[f];
+      h_idx[RANDT_WIN_MAX_TERMS + q] = h_moving_idx[j - 1];
+      memcpy(h_guess + 4 * q, h_states[j].pose, sizeof(double) * 4);  // association at the state's own pose (:364)
+    }
+  // workspace: corr | states | guess | idx | result
+  const size_t corr_bytes = sizeof(int32_t) * (size_t)W.n_terms * moving->v.cap * k;
+  const size_t off_states = (corr_bytes + 255) & ~(size_t)255;
+  const size_t off_guess = off_states + sizeof(double) * 10 * RANDT_WIN_MAX_STATES;
+  const size_t off_idx = off_guess + sizeof(h_guess);
+  const size_t off_res = off_idx + sizeof(h_idx) + 64;
+  int rc = ensure_ws(ctx, off_res + sizeof(randt_result) + 64);
+  if (rc) return rc;
+  char* ws = (char*)ctx->ws;
+  double h_packed[10 * RANDT_WIN_MAX_STATES];
+  for (int j = 0; j <= S; ++j) {
+    double* o = h_packed + 10 * j;
+    memcpy(o, h_states[j].pose, sizeof(double) * 4);
+    o[4] = h_states[j].lin_vel[0]; o[5] = h_states[j].lin_vel[1]; o[6] = h_states[j].rot_vel;
+    o[7] = h_states[j].lin_acc[0]; o[8] = h_states[j].lin_acc[1]; o[9] = h_states[j].imu_bias;
+  }
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_states, h_packed, sizeof(double) * 10 * (S + 1), hipMemcpyHostToDevice, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_guess, h_guess, sizeof(h_guess), hipMemcpyHostToDevice, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_idx, h_idx, sizeof(h_idx), hipMemcpyHostToDevice, ctx->stream));
+  const int32_t* d_fidx = (const int32_t*)(ws + off_idx);
+  const int32_t* d_midx = d_fidx + RANDT_WIN_MAX_TERMS;
+  rc = launch_associate(ctx, fixed->v, d_fidx, moving->v, 0, W.n_terms, (const double*)(ws + off_guess), k, mp->lookup_mahalanobis,
+                        mp->use_intensity, (int32_t*)ws, d_midx);
+  if (rc) return rc;
+  rc = launch_solve_window(ctx, fixed->v, moving->v, W, (const int32_t*)ws, mp, (double*)(ws + off_states), (randt_result*)(ws + off_res));
+  if (rc) return rc;
+  randt_result r;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_packed, ws + off_states, sizeof(double) * 10 * (S + 1), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&r, ws + off_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int j = 0; j <= S; ++j) {
+    const double* o = h_packed + 10 * j;
+    memcpy(h_states[j].pose, o, sizeof(double) * 4);
+    h_states[j].lin_vel[0] = o[4]; h_states[j].lin_vel[1] = o[5]; h_states[j].rot_vel = o[6];
+    h_states[j].lin_acc[0] = o[7]; h_states[j].lin_acc[1] = o[8]; h_states[j].imu_bias = o[9];
+    // both pose representations (ndt_matcher.cpp:403-406, local_fuser.cpp:141-150)
+    h_states[j].pos[0] = o[2];
+    h_states[j].pos[1] = o[3];
+    h_states[j].rot = atan2(o[1], o[0]);
+  }
+  // rejection gate (ndt_matcher.cpp:411-422)
+  int rej = 0;
+  {
+    randt_state* X = &h_states[S];
+    const double pc = cos(prior_rot), ps = sin(prior_rot);
+    const double re = X->pose[0] * pc + X->pose[1] * ps, im = X->pose[0] * ps - X->pose[1] * pc;
+    const double dth = atan2(im, re);
+    if (fabs(X->pose[2] - prior_t[0]) > wp->pose_reject_translation || fabs(X->pose[3] - prior_t[1]) > wp->pose_reject_translation ||
+        fabs(dth) > wp->pose_reject_rotation) {
+      printf("Rejected new estimated transform!\n");
+      rej = 1;
+      memcpy(X->pos, h_states[S - 1].pos, sizeof(X->pos));
+      memcpy(X->pose, h_states[S - 1].pose, sizeof(X->pose));
+      X->rot = h_states[S - 1].rot;
+      X->lin_vel[0] = X->lin_vel[1] = 0.0;
+      X->rot_vel = 0.0;
+      X->lin_acc[0] = X->lin_acc[1] = 0.0;
+      X->imu_bias = h_states[S - 1].imu_bias;
+    }
+  }
+  memcpy(h_trans4, h_states[S].pose, sizeof(double) * 4);
+  if (rejected) *rejected = rej;
+  if (h_result) *h_result = r;
+  return RANDT_OK;
+}
+
 }  // extern "C"

@@ -76,13 +76,14 @@ __device__ __forceinline__ unsigned long long prefix_mask(int n) {
 template <bool STAGE_GRID>
 __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const int32_t* __restrict__ fixed_idx,
                                                            MapView moving, int moving_first,
+                                                           const int32_t* __restrict__ moving_idx,
                                                            const double* __restrict__ guess4, int k, int metric_mahal,
                                                            int transform_full, int32_t* __restrict__ corr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pair = blockIdx.x;
   const int fmap = fixed_idx ? fixed_idx[pair] : 0;
-  const int mmap = moving_first + pair;
+  const int mmap = moving_idx ? moving_idx[pair] : moving_first + pair;
   const int n_slots = fixed.n_slots;
   const int32_t* ggrid = fixed.grid + (size_t)fmap * n_slots;
   const randt_cell* fcells = fixed.cells + (size_t)fmap * fixed.cap;
@@ -321,7 +322,7 @@ size_t assoc_lds_bytes(int n_slots, bool stage) {
 
 int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
                      int moving_first, int n_pairs, const double* d_guess4, int k, int lookup_mahalanobis,
-                     int use_intensity, int32_t* d_corr) {
+                     int use_intensity, int32_t* d_corr, const int32_t* d_moving_idx) {
   if (n_pairs <= 0) return RANDT_OK;
   if (!fixed.grid) return randt_set_error(ctx, RANDT_ERR_INVALID, "fixed maps need an index grid", hipSuccess);
   if (fixed.rmax - 1 > ASSOC_MAX_R)
@@ -336,12 +337,12 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_associate<true>, dim3(n_pairs), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
-                       moving, moving_first, d_guess4, k, full, full, d_corr);
+                       moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr);
   } else {
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_associate<false>, dim3(n_pairs), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
-                       moving, moving_first, d_guess4, k, full, full, d_corr);
+                       moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr);
   }
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;

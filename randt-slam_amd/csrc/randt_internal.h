@@ -66,7 +66,23 @@ int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const
                       int n_moving, const double* d_pose4);
 int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
                      int moving_first, int n_pairs, const double* d_guess4, int k, int lookup_mahalanobis,
-                     int use_intensity, int32_t* d_corr);
+                     int use_intensity, int32_t* d_corr, const int32_t* d_moving_idx = nullptr);
+
+// fixed-lag window problem description (kernel argument, by value)
+#define RANDT_WIN_MAX_STATES 4
+#define RANDT_WIN_MAX_TERMS 6
+struct WinDesc {
+  int S, n_terms, n_tan, n_amb, use_imu, const_vel, k, d3;
+  int term_state[RANDT_WIN_MAX_TERMS], term_moving[RANDT_WIN_MAX_TERMS], term_fixed[RANDT_WIN_MAX_TERMS];
+  int off_tan[RANDT_WIN_MAX_STATES][5], off_amb[RANDT_WIN_MAX_STATES][5];  // pose, v, w, a, b; -1 = constant
+  double sqrtI[64];
+  double imu[RANDT_WIN_MAX_STATES];
+  double raw_dt[RANDT_WIN_MAX_STATES];  // stamp[j] - stamp[j-1], index j
+  double w_imu, w_bias, ndt_weight;
+};
+int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc,
+                        const int32_t* d_corr, const randt_matcher_params* mp, double* d_states /* (S+1) x 10 */,
+                        randt_result* d_result);
 int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
                  int moving_first, int n_pairs, const int32_t* d_corr, const randt_matcher_params* mp,
                  double* d_pose4, randt_result* d_results);

@@ -1,0 +1,998 @@
+// Fixed-lag window solve for gfx950: Matcher::estimateTransformCeres on the device.
+//
+// Replaces (paths relative to /root/reference/ros/ndt_radar_slam/):
+//   src/ndt_registration/ndt_matcher.cpp:322-424          estimateTransformCeres (problem wiring, GNC loop, ceres::Solve)
+//   include/ndt_registration/ceres_residuals.h:62-83      predictSE2
+//   include/ndt_registration/ceres_residuals.h:621-679    MotionModelFactorSE2
+//   include/ndt_registration/ceres_residuals.h:338-370    RotationalResidualSE2
+//   include/ndt_registration/ceres_residuals.h:520-552    NDTFrameToMapIntensityFactorResidualSE2 (and the 2-D form)
+//   Ceres 2.1.0 trust-region LM / Sophus 1.22.10 SE(2) manifold (un-vendored), as in solve.hip.
+//
+// One 256-thread workgroup owns one window problem (<= 3 optimised states, <= 2 fixed maps, 21-32
+// tangent dimensions) and runs the whole GNC x LM loop without host round trips:
+//   * NDT terms: all lanes stream the correspondence slots of every (state, fixed map) term, cell
+//     records read in place from L1/L2, ten fp64 base sums PER STATE, fixed-order reduction;
+//   * motion / IMU factors: one lane per factor evaluates residual + analytic Jacobian (right
+//     perturbations, verified against finite differences in tests/test_oracle_window.py), all lanes
+//     apply the 8x8 square-root information;
+//   * J^T J / J^T r: one thread per matrix entry gathers the factor blocks and the per-state
+//     3x3 NDT blocks (T G T^T with Sophus' PlusJacobian) into LDS;
+//   * Jacobi scaling, LM damping, LDL^T of the dense n x n system, model-cost change, Plus on every
+//     manifold block and the step norms run on wavefront 0 with LDS-resident matrices;
+//   * convergence tests / accept-reject / radius update are evaluated redundantly by every lane
+//     from broadcast scalars (uniform control flow).
+// The candidate point is evaluated with its Jacobians so that an accepted step costs one pass.
+#include <float.h>
+
+#include "randt_internal.h"
+
+#define WIN_BLOCK 256
+#define WIN_WAVES 4
+#define WIN_NMAX 32  // tangent dimensions
+#define WIN_SMAX 3   // optimised states
+
+namespace {
+
+// ---------------------------------------------------------------- SE(2) (Sophus 1.22.10) -------
+__device__ __forceinline__ void so2_normalize(double& c, double& s) {
+  const double len = sqrt(c * c + s * s);
+  c = c / len;
+  s = s / len;
+}
+__device__ __forceinline__ void se2_exp(const double* xi, double* out) {
+  const double theta = xi[2];
+  double c = cos(theta), s = sin(theta);
+  so2_normalize(c, s);
+  double sbt, omcbt;
+  if (fabs(theta) < 1e-10) {
+    const double tsq = theta * theta;
+    sbt = 1.0 - (1.0 / 6.0) * tsq;
+    omcbt = 0.5 * theta - (1.0 / 24.0) * theta * tsq;
+  } else {
+    sbt = s / theta;
+    omcbt = (1.0 - c) / theta;
+  }
+  out[0] = c;
+  out[1] = s;
+  out[2] = sbt * xi[0] - omcbt * xi[1];
+  out[3] = omcbt * xi[0] + sbt * xi[1];
+}
+__device__ __forceinline__ void se2_mul(const double* a, const double* b, double* out) {
+  double re = a[0] * b[0] - a[1] * b[1];
+  double im = a[0] * b[1] + a[1] * b[0];
+  const double sq = re * re + im * im;
+  if (sq != 1.0) {
+    const double scale = 2.0 / (1.0 + sq);
+    re *= scale;
+    im *= scale;
+  }
+  so2_normalize(re, im);
+  const double tx = a[2] + (a[0] * b[2] - a[1] * b[3]);
+  const double ty = a[3] + (a[1] * b[2] + a[0] * b[3]);
+  out[0] = re;
+  out[1] = im;
+  out[2] = tx;
+  out[3] = ty;
+}
+__device__ __forceinline__ void se2_inv(const double* a, double* out) {
+  const double c = a[0], s = -a[1];
+  const double tx = -a[2], ty = -a[3];
+  out[0] = c;
+  out[1] = s;
+  out[2] = c * tx - s * ty;
+  out[3] = s * tx + c * ty;
+}
+__device__ __forceinline__ void se2_log(const double* p, double* xi) {
+  const double theta = atan2(p[1], p[0]);
+  const double half = 0.5 * theta;
+  const double rm1 = p[0] - 1.0;
+  double hbt;
+  if (fabs(rm1) < 1e-10) {
+    hbt = 1.0 - (1.0 / 12) * theta * theta;
+  } else {
+    hbt = -(half * p[1]) / rm1;
+  }
+  xi[0] = hbt * p[2] + half * p[3];
+  xi[1] = -half * p[2] + hbt * p[3];
+  xi[2] = theta;
+}
+
+// state record in LDS: [0..3] pose, [4,5] lin_vel, [6] rot_vel, [7,8] lin_acc, [9] imu_bias
+#define ST_STRIDE 10
+
+// MotionModelFactorSE2 (ceres_residuals.h:621-679): UNWEIGHTED residual r[8] and Jacobian Ju[8][16]
+// w.r.t. tangent [X0: pose3 v2 w1 a2 | X1: pose3 v2 w1 a2] (right perturbations).
+__device__ void motion_factor(const double* x0, const double* x1, double raw_dt, double* r, double* Ju /* LDS 8x16 */) {
+  const double dt = raw_dt > 0.2 ? raw_dt : 0.2;  // predictSE2 clamp (:73)
+  const double xi[3] = {x0[4] * dt + 0.5 * dt * x0[7], x0[5] * dt + 0.5 * dt * x0[8], x0[6] * dt};
+  double e[4], pred[4], pinv[4], E[4], lg[3];
+  se2_exp(xi, e);
+  se2_mul(x0, e, pred);
+  se2_inv(pred, pinv);
+  se2_mul(pinv, x1, E);
+  se2_log(E, lg);
+  r[0] = lg[0];
+  r[1] = lg[1];
+  r[2] = lg[2];
+  r[3] = x1[4] - (x0[4] + dt * x0[7]);
+  r[4] = x1[5] - (x0[5] + dt * x0[8]);
+  r[5] = x1[6] - x0[6];
+  r[6] = x1[7] - x0[7];
+  r[7] = x1[8] - x0[8];
+  for (int i = 0; i < 128; ++i) Ju[i] = 0.0;
+  const double phi = lg[2];
+  const double cE = E[0], sE = E[1], tEx = E[2], tEy = E[3];
+  double h, dh;  // Vinv(phi) = [[h, phi/2], [-phi/2, h]]
+  if (fabs(E[0] - 1.0) < 1e-10) {
+    h = 1.0 - phi * phi / 12.0;
+    dh = -phi / 6.0;
+  } else {
+    const double half = 0.5 * phi, sh = sin(half), ch = cos(half);
+    h = half * ch / sh;
+    dh = 0.5 * ch / sh - 0.5 * half / (sh * sh);
+  }
+  const double Vi00 = h, Vi01 = 0.5 * phi, Vi10 = -0.5 * phi, Vi11 = h;
+  const double dVt0 = dh * tEx + 0.5 * tEy, dVt1 = -0.5 * tEx + dh * tEy;
+  // X1 <- X1 exp(d1): dphi = dw1, dt_E = R_E dv1
+  Ju[0 * 16 + 8] = Vi00 * cE + Vi01 * sE;
+  Ju[0 * 16 + 9] = Vi00 * (-sE) + Vi01 * cE;
+  Ju[1 * 16 + 8] = Vi10 * cE + Vi11 * sE;
+  Ju[1 * 16 + 9] = Vi10 * (-sE) + Vi11 * cE;
+  Ju[0 * 16 + 10] = dVt0;
+  Ju[1 * 16 + 10] = dVt1;
+  Ju[2 * 16 + 10] = 1.0;
+  // pred = X0 exp(xi)
+  double a, b, da, db;
+  if (fabs(xi[2]) < 1e-10) {
+    const double w = xi[2];
+    a = 1.0 - w * w / 6.0;
+    b = 0.5 * w - w * w * w / 24.0;
+    da = -w / 3.0;
+    db = 0.5 - w * w / 8.0;
+  } else {
+    const double w = xi[2], s = sin(w), c = cos(w);
+    a = s / w;
+    b = (1.0 - c) / w;
+    da = (w * c - s) / (w * w);
+    db = (w * s - (1.0 - c)) / (w * w);
+  }
+  const double c0 = x0[0], s0 = x0[1];
+  const double Vx = a * xi[0] - b * xi[1], Vy = b * xi[0] + a * xi[1];
+  const double dVx = da * xi[0] - db * xi[1], dVy = db * xi[0] + da * xi[1];
+  double dtp[6][2], dth[6];
+  dtp[0][0] = c0;  dtp[0][1] = s0;  dth[0] = 0;
+  dtp[1][0] = -s0; dtp[1][1] = c0;  dth[1] = 0;
+  dtp[2][0] = c0 * (-Vy) - s0 * Vx;
+  dtp[2][1] = s0 * (-Vy) + c0 * Vx;
+  dth[2] = 1;
+  dtp[3][0] = c0 * a - s0 * b;     dtp[3][1] = s0 * a + c0 * b;   dth[3] = 0;
+  dtp[4][0] = c0 * (-b) - s0 * a;  dtp[4][1] = s0 * (-b) + c0 * a; dth[4] = 0;
+  dtp[5][0] = c0 * dVx - s0 * dVy;
+  dtp[5][1] = s0 * dVx + c0 * dVy;
+  dth[5] = 1;
+  const double cp = pred[0], sp = pred[1];
+  double G[6][3];
+#pragma unroll
+  for (int g = 0; g < 6; ++g) {
+    const double ex = -(cp * dtp[g][0] + sp * dtp[g][1]) - (-tEy) * dth[g];
+    const double ey = -(-sp * dtp[g][0] + cp * dtp[g][1]) - (tEx)*dth[g];
+    const double dphi = -dth[g];
+    G[g][0] = Vi00 * ex + Vi01 * ey + dVt0 * dphi;
+    G[g][1] = Vi10 * ex + Vi11 * ey + dVt1 * dphi;
+    G[g][2] = dphi;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Ju[i * 16 + 0] = G[0][i];
+    Ju[i * 16 + 1] = G[1][i];
+    Ju[i * 16 + 2] = G[2][i];
+    Ju[i * 16 + 3] = G[3][i] * dt;
+    Ju[i * 16 + 4] = G[4][i] * dt;
+    Ju[i * 16 + 5] = G[5][i] * dt;
+    Ju[i * 16 + 6] = G[3][i] * 0.5 * dt;
+    Ju[i * 16 + 7] = G[4][i] * 0.5 * dt;
+  }
+  Ju[3 * 16 + 3] = -1; Ju[3 * 16 + 6] = -dt; Ju[3 * 16 + 11] = 1;
+  Ju[4 * 16 + 4] = -1; Ju[4 * 16 + 7] = -dt; Ju[4 * 16 + 12] = 1;
+  Ju[5 * 16 + 5] = -1; Ju[5 * 16 + 13] = 1;
+  Ju[6 * 16 + 6] = -1; Ju[6 * 16 + 14] = 1;
+  Ju[7 * 16 + 7] = -1; Ju[7 * 16 + 15] = 1;
+}
+
+// RotationalResidualSE2 (ceres_residuals.h:338-370): r[2], J[2][8] w.r.t. [X0 pose3, X1 pose3, b0, b1]
+__device__ void imu_factor(const double* x0, const double* x1, double raw_dt, double imu_rot, double w, double wb, double* r,
+                           double* J /* LDS 2x8 */) {
+  const double screw[3] = {0.0, 0.0, x1[9] * raw_dt};
+  double e[4], M1[4], inv0[4], E[4], lg[3];
+  se2_exp(screw, e);
+  se2_mul(x1, e, M1);
+  se2_inv(x0, inv0);
+  se2_mul(inv0, M1, E);
+  se2_log(E, lg);
+  r[0] = w * (imu_rot - lg[2]);
+  r[1] = wb * (x1[9] - x0[9]);
+  for (int i = 0; i < 16; ++i) J[i] = 0.0;
+  J[2] = w;
+  J[3 + 2] = -w;
+  J[7] = -w * raw_dt;
+  J[8 + 6] = -wb;
+  J[8 + 7] = wb;
+}
+
+// ---------------------------------------------------------------- loss (as in solve.hip) -------
+struct Loss {
+  double b, c, factor, exponent, pre, ts, alpha, weight, sqrt_w, half_w_pre;
+  int mode;
+};
+__device__ __forceinline__ Loss make_loss(double a, double alpha, double mu, double weight) {
+  Loss L;
+  L.alpha = alpha;
+  L.b = mu * a * a;
+  L.c = 1 / L.b;
+  L.factor = fabs(alpha - 2.0);
+  L.exponent = 0.5 * alpha;
+  L.pre = L.b * L.factor / alpha;
+  L.ts = 2 * L.c / L.factor;
+  L.weight = weight;
+  L.sqrt_w = sqrt(weight);
+  L.half_w_pre = 0.5 * weight * L.pre;
+  L.mode = alpha >= 2.0 ? 0 : (fabs(alpha) <= 0.05 ? 1 : (alpha == -2.0 ? 2 : 3));
+  return L;
+}
+__device__ __forceinline__ void loss_eval(const Loss& L, double s, double& r0, double& r1, double& r2) {
+  if (L.mode == 0) {
+    r0 = s;
+    r1 = 1;
+    r2 = 0;
+  } else if (L.mode == 1) {
+    const double sum = 1.0 + s * L.c;
+    const double inv = 1.0 / sum;
+    r0 = L.b * log(sum);
+    r1 = inv > DBL_MIN ? inv : DBL_MIN;
+    r2 = -L.c * (inv * inv);
+  } else {
+    const double u = s * L.ts + 1.0;
+    r0 = L.pre * (pow(u, L.exponent) - 1.);
+    r1 = L.pre * L.exponent * pow(u, L.exponent - 1.) * L.ts;
+    r2 = L.pre * L.exponent * (L.exponent - 1) * pow(u, L.exponent - 2.) * L.ts * L.ts;
+  }
+  r0 *= L.weight;
+  r1 *= L.weight;
+  r2 *= L.weight;
+}
+
+// D2D residual: ssq and d r / d (tx, ty, theta); same formulas as solve.hip
+template <int D, bool WANT_JAC>
+__device__ __forceinline__ double residual_sq(const float* __restrict__ mv, const float* __restrict__ fv, double c, double s,
+                                              double tx, double ty, double* jb) {
+  const double m0 = mv[0], m1 = mv[1];
+  const double a = mv[3], b = mv[4], dd = mv[6];
+  const double RS00 = c * a - s * b, RS01 = c * b - s * dd;
+  const double RS10 = s * a + c * b, RS11 = s * b + c * dd;
+  const double C00 = (RS00 * c - RS01 * s) + (double)fv[3];
+  const double C01 = (RS00 * s + RS01 * c) + (double)fv[4];
+  const double C11 = (RS10 * s + RS11 * c) + (double)fv[6];
+  const double d0 = (c * m0 - s * m1) + tx - (double)fv[0];
+  const double d1 = (s * m0 + c * m1) + ty - (double)fv[1];
+  double q0, q1, q2 = 0.0, ssq;
+  double cc = 0.0, e = 0.0;
+  if (D == 3) {
+    cc = mv[5];
+    e = mv[7];
+    const double C02 = (c * cc - s * e) + (double)fv[5];
+    const double C12 = (s * cc + c * e) + (double)fv[7];
+    const double C22 = (double)mv[8] + (double)fv[8];
+    const double d2 = (double)mv[2] - (double)fv[2];
+    const double k00 = C11 * C22 - C12 * C12;
+    const double k01 = C12 * C02 - C01 * C22;
+    const double k02 = C01 * C12 - C11 * C02;
+    const double det = C00 * k00 + C01 * k01 + C02 * k02;
+    const double id = 1.0 / det;
+    const double k11 = C00 * C22 - C02 * C02;
+    const double k12 = C02 * C01 - C00 * C12;
+    const double k22 = C00 * C11 - C01 * C01;
+    q0 = (k00 * d0 + k01 * d1 + k02 * d2) * id;
+    q1 = (k01 * d0 + k11 * d1 + k12 * d2) * id;
+    q2 = (k02 * d0 + k12 * d1 + k22 * d2) * id;
+    ssq = d0 * q0 + d1 * q1 + d2 * q2;
+  } else {
+    const double det = C00 * C11 - C01 * C01;
+    const double id = 1.0 / det;
+    q0 = (C11 * d0 - C01 * d1) * id;
+    q1 = (-C01 * d0 + C00 * d1) * id;
+    ssq = d0 * q0 + d1 * q1;
+  }
+  if (WANT_JAC) {
+    if (!(ssq > 0.0)) {
+      jb[0] = jb[1] = jb[2] = 0.0;
+    } else {
+      const double ir = rsqrt(ssq);
+      const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
+      double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
+      if (D == 3) {
+        Su0 += cc * q2;
+        Su1 += e * q2;
+      }
+      jb[0] = q0 * ir;
+      jb[1] = q1 * ir;
+      jb[2] = ((u1 * m0 - u0 * m1) - (u1 * Su0 - u0 * Su1)) * ir;
+    }
+  }
+  return ssq;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct Shared {
+  double xs[2][WIN_SMAX + 1][ST_STRIDE];  // states: buffer p = current, 1-p = candidate
+  double Ju[WIN_SMAX][128];               // unweighted motion Jacobians (scratch)
+  double ru[WIN_SMAX][8];
+  double Jf[2][WIN_SMAX][128];            // weighted motion Jacobians at current / candidate
+  double rf[2][WIN_SMAX][8];
+  double J2[2][WIN_SMAX][16];             // IMU factors
+  double r2[2][WIN_SMAX][2];
+  double H[WIN_NMAX * WIN_NMAX];
+  double A[WIN_NMAX * WIN_NMAX];
+  double Hs[WIN_NMAX * WIN_NMAX];
+  double g[WIN_NMAX], gs[WIN_NMAX], sigma[WIN_NMAX], diag[WIN_NMAX], step[WIN_NMAX], delta[WIN_NMAX], col[WIN_NMAX];
+  double red[2][WIN_WAVES][34];
+  double scal[8];  // 0 mcc, 1 sn2, 2 x_norm, 3 solved, 4 gconv
+  int lcol[WIN_SMAX][WIN_NMAX];   // tangent column -> local column of motion factor f (-1 none)
+  int lcol2[WIN_SMAX][WIN_NMAX];  // ... of IMU factor f
+  int pose_of[WIN_NMAX];          // tangent column -> state whose pose block holds it (-1 none)
+};
+
+// NDT pass over every term at the states in xs[buf].  MODE 0: max raw residual -> out[0];
+// MODE 1: ten base sums per state -> out[(j-1)*10 ..].
+template <int D, int MODE>
+__device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const int32_t* __restrict__ corr,
+                         const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw) {
+  double acc[WIN_SMAX * 10];
+#pragma unroll
+  for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] = 0.0;
+  double mx = -DBL_MAX;
+  int bad = 0;
+  for (int t = 0; t < W.n_terms; ++t) {
+    const int j = W.term_state[t];
+    const double* xp = sh.xs[buf][j];
+    const double inv = rsqrt(xp[0] * xp[0] + xp[1] * xp[1]);
+    const double c = xp[0] * inv, s = xp[1] * inv, tx = xp[2], ty = xp[3];
+    const int mmap = W.term_moving[t], fmap = W.term_fixed[t];
+    int M = moving.counts[mmap];
+    M = M > moving.cap ? moving.cap : M;
+    const float* mov = reinterpret_cast<const float*>(moving.cells + (size_t)mmap * moving.cap);
+    const float* fix = reinterpret_cast<const float*>(fixed.cells + (size_t)fmap * fixed.cap);
+    const int32_t* pc = corr + (size_t)t * moving.cap * W.k;
+    const int n_slots = M * W.k;
+    double a10[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a10[i] = 0.0;
+    for (int slot = threadIdx.x; slot < n_slots; slot += WIN_BLOCK) {
+      const int ci = pc[slot];
+      if (ci < 0 || ci >= fixed.cap) continue;
+      double jb[3];
+      const double sq = residual_sq<D, MODE == 1>(mov + (size_t)(slot / W.k) * 12, fix + (size_t)ci * 12, c, s, tx, ty, jb);
+      if (!isfinite(sq)) bad = 1;
+      if (MODE == 0) {
+        mx = sq > mx ? sq : mx;
+      } else {
+        double rs, js;
+        if (L.mode == 2) {
+          const double iu = 1.0 / (sq * L.ts + 1.0);
+          a10[0] += L.half_w_pre * (iu - 1.);
+          rs = js = L.sqrt_w * iu;
+        } else {
+          double r0, r1, r2;
+          loss_eval(L, sq, r0, r1, r2);
+          a10[0] += 0.5 * r0;
+          const double sqrt_rho1 = sqrt(r1);
+          if (sq == 0.0 || r2 <= 0.0) {
+            rs = js = sqrt_rho1;
+          } else {
+            const double Dc = 1.0 + 2.0 * sq * r2 / r1;
+            const double al = 1.0 - sqrt(Dc);
+            rs = sqrt_rho1 / (1 - al);
+            js = sqrt_rho1 * (1.0 - al);
+          }
+        }
+        const double r = sq > 0.0 ? sq * rsqrt(sq) : 0.0;
+        const double wr = rs * r;
+        const double w0 = js * jb[0], w1 = js * jb[1], w2 = js * jb[2];
+        a10[1] += w0 * wr;
+        a10[2] += w1 * wr;
+        a10[3] += w2 * wr;
+        a10[4] += w0 * w0;
+        a10[5] += w0 * w1;
+        a10[6] += w0 * w2;
+        a10[7] += w1 * w1;
+        a10[8] += w1 * w2;
+        a10[9] += w2 * w2;
+      }
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int jj = 1; jj <= WIN_SMAX; ++jj)
+        if (jj == j) {
+#pragma unroll
+          for (int i = 0; i < 10; ++i) acc[(jj - 1) * 10 + i] += a10[i];
+        }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double badf = wave_max((double)bad);
+  double* r = shw.red[parity][0];
+  parity ^= 1;
+  if (MODE == 0) {
+    mx = wave_max(mx);
+    if (lane == 0) {
+      r[wave * 34 + 0] = mx;
+      r[wave * 34 + 1] = badf;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WIN_WAVES; ++w) {
+      mx = r[w * 34] > mx ? r[w * 34] : mx;
+      badf = r[w * 34 + 1] > badf ? r[w * 34 + 1] : badf;
+    }
+    out[0] = mx > 0.0 ? sqrt(mx) : 0.0;
+    return badf == 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] = wave_sum(acc[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < WIN_SMAX * 10; ++i) r[wave * 34 + i] = acc[i];
+    r[wave * 34 + 30] = badf;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int w = 0; w < WIN_WAVES; ++w) {
+#pragma unroll
+    for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] += r[w * 34 + i];
+    badf = r[w * 34 + 30] > badf ? r[w * 34 + 30] : badf;
+  }
+#pragma unroll
+  for (int i = 0; i < WIN_SMAX * 10; ++i) out[i] = acc[i];
+  return badf == 0.0;
+}
+
+// Evaluate motion / IMU factors at xs[buf]: residuals + weighted Jacobians into Jf/rf/J2/r2[buf].
+// Returns sum of 1/2 r^2 over the factor residuals (identical in every thread).  Two barriers.
+__device__ double factor_pass(const WinDesc& W, Shared& sh, int buf) {
+  const int tid = threadIdx.x;
+  if (tid < W.S) {
+    const int f = tid;  // factor between states f and f+1
+    double r[8];
+    motion_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], r, sh.Ju[f]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sh.ru[f][i] = r[i];
+    if (W.use_imu) {
+      double r2[2];
+      imu_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], W.imu[f], W.w_imu, W.w_bias, r2, sh.J2[buf][f]);
+      sh.r2[buf][f][0] = r2[0];
+      sh.r2[buf][f][1] = r2[1];
+    }
+  }
+  __syncthreads();
+  // residuals_map.applyOnTheLeft(sqrtI_): one thread per weighted entry
+  for (int e = tid; e < W.S * 128; e += WIN_BLOCK) {
+    const int f = e >> 7, i = (e & 127) >> 4, c = e & 15;
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += W.sqrtI[i * 8 + k] * sh.Ju[f][k * 16 + c];
+    sh.Jf[buf][f][i * 16 + c] = a;
+  }
+  if (tid < W.S * 8) {
+    const int f = tid >> 3, i = tid & 7;
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += W.sqrtI[i * 8 + k] * sh.ru[f][k];
+    sh.rf[buf][f][i] = a;
+  }
+  __syncthreads();
+  double cost = 0.0;
+  for (int f = 0; f < W.S; ++f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cost += 0.5 * sh.rf[buf][f][i] * sh.rf[buf][f][i];
+    if (W.use_imu) cost += 0.5 * sh.r2[buf][f][0] * sh.r2[buf][f][0] + 0.5 * sh.r2[buf][f][1] * sh.r2[buf][f][1];
+  }
+  return cost;
+}
+
+// Entry (a, b) of T G T^T and entry a of T g_b for the manifold pose block of a state
+// (T rows: [cp, sp, 0], [-sp, cp, 0], [0, 0, kappa], see solve.hip::to_param).
+__device__ __forceinline__ void pose_T(const double* xp, double T[3][3]) {
+  const double cp = xp[0], sp = xp[1];
+  const double n2 = cp * cp + sp * sp;
+  const double a = -sp / n2, b = cp / n2;
+  T[0][0] = cp;  T[0][1] = sp; T[0][2] = 0;
+  T[1][0] = -sp; T[1][1] = cp; T[1][2] = 0;
+  T[2][0] = 0;   T[2][1] = 0;  T[2][2] = a * (-sp) + b * cp;
+}
+
+// J^T J and J^T r at xs[buf] from the factor blocks in LDS and the per-state NDT base sums.
+__device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* base /* S*10 */) {
+  const int n = W.n_tan, tid = threadIdx.x;
+  for (int e = tid; e < n * n; e += WIN_BLOCK) {
+    const int a = e / n, b = e % n;
+    double h = 0.0;
+    for (int f = 0; f < W.S; ++f) {
+      const int la = sh.lcol[f][a], lb = sh.lcol[f][b];
+      if (la >= 0 && lb >= 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h += sh.Jf[buf][f][i * 16 + la] * sh.Jf[buf][f][i * 16 + lb];
+      }
+      if (W.use_imu) {
+        const int ma = sh.lcol2[f][a], mb = sh.lcol2[f][b];
+        if (ma >= 0 && mb >= 0) h += sh.J2[buf][f][ma] * sh.J2[buf][f][mb] + sh.J2[buf][f][8 + ma] * sh.J2[buf][f][8 + mb];
+      }
+    }
+    const int j = sh.pose_of[a];
+    if (j >= 0 && sh.pose_of[b] == j) {
+      double T[3][3];
+      pose_T(sh.xs[buf][j], T);
+      const double* B = base + (j - 1) * 10;
+      const double G[3][3] = {{B[4], B[5], B[6]}, {B[5], B[7], B[8]}, {B[6], B[8], B[9]}};
+      const int ia = a - W.off_tan[j][0], ib = b - W.off_tan[j][0];
+      double v = 0.0;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v += T[ia][p] * G[p][q] * T[ib][q];
+      h += v;
+    }
+    sh.H[a * n + b] = h;
+  }
+  if (tid < n) {
+    const int a = tid;
+    double g = 0.0;
+    for (int f = 0; f < W.S; ++f) {
+      const int la = sh.lcol[f][a];
+      if (la >= 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g += sh.Jf[buf][f][i * 16 + la] * sh.rf[buf][f][i];
+      }
+      if (W.use_imu) {
+        const int ma = sh.lcol2[f][a];
+        if (ma >= 0) g += sh.J2[buf][f][ma] * sh.r2[buf][f][0] + sh.J2[buf][f][8 + ma] * sh.r2[buf][f][1];
+      }
+    }
+    const int j = sh.pose_of[a];
+    if (j >= 0) {
+      double T[3][3];
+      pose_T(sh.xs[buf][j], T);
+      const double* B = base + (j - 1) * 10;
+      const int ia = a - W.off_tan[j][0];
+      g += T[ia][0] * B[1] + T[ia][1] * B[2] + T[ia][2] * B[3];
+    }
+    sh.g[a] = g;
+  }
+  __syncthreads();
+}
+
+// Plus for every variable block: xs[dst] = Plus(xs[src], sign * vec), one lane per state.
+__device__ void plus_states(const WinDesc& W, Shared& sh, int src, int dst, const double* vec, double sign, int lane) {
+  if (lane <= W.S) {
+    const int j = lane;
+    const double* x = sh.xs[src][j];
+    double* y = sh.xs[dst][j];
+    if (W.off_tan[j][0] >= 0) {
+      const double d[3] = {sign * vec[W.off_tan[j][0]], sign * vec[W.off_tan[j][0] + 1], sign * vec[W.off_tan[j][0] + 2]};
+      double e[4];
+      se2_exp(d, e);
+      se2_mul(x, e, y);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = x[i];
+    }
+    y[4] = x[4] + (W.off_tan[j][1] >= 0 ? sign * vec[W.off_tan[j][1]] : 0.0);
+    y[5] = x[5] + (W.off_tan[j][1] >= 0 ? sign * vec[W.off_tan[j][1] + 1] : 0.0);
+    y[6] = x[6] + (W.off_tan[j][2] >= 0 ? sign * vec[W.off_tan[j][2]] : 0.0);
+    y[7] = x[7] + (W.off_tan[j][3] >= 0 ? sign * vec[W.off_tan[j][3]] : 0.0);
+    y[8] = x[8] + (W.off_tan[j][3] >= 0 ? sign * vec[W.off_tan[j][3] + 1] : 0.0);
+    y[9] = x[9] + (W.off_tan[j][4] >= 0 ? sign * vec[W.off_tan[j][4]] : 0.0);
+  }
+}
+
+// squared norm over the VARIABLE ambient blocks of (xs[a] - xs[b]) or of xs[a] (b < 0); wave 0, all lanes get it
+__device__ double ambient_sq(const WinDesc& W, const Shared& sh, int a, int b, int lane) {
+  double v = 0.0;
+  if (lane <= W.S) {
+    const int j = lane;
+    const int lo[5] = {0, 4, 6, 7, 9}, sz[5] = {4, 2, 1, 2, 1};
+#pragma unroll
+    for (int blk = 0; blk < 5; ++blk)
+      if (W.off_amb[j][blk] >= 0)
+        for (int e = 0; e < sz[blk]; ++e) {
+          const double d = sh.xs[a][j][lo[blk] + e] - (b >= 0 ? sh.xs[b][j][lo[blk] + e] : 0.0);
+          v += d * d;
+        }
+  }
+  return wave_sum(v);
+}
+
+__device__ __forceinline__ void trace_push(double* tr, int max_len, double cost, double radius, int flag) {
+  if (tr && threadIdx.x == 0) {
+    const int n = (int)tr[0];
+    if (3 * (n + 1) + 1 <= max_len) {
+      tr[1 + 3 * n + 0] = cost;
+      tr[1 + 3 * n + 1] = radius;
+      tr[1 + 3 * n + 2] = (double)flag;
+      tr[0] = (double)(n + 1);
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapView moving, WinDesc W,
+                                                            const int32_t* __restrict__ corr, SolveParams P,
+                                                            double* __restrict__ states, randt_result* __restrict__ result,
+                                                            double* trace, int trace_len) {
+  __shared__ Shared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = W.n_tan, S = W.S;
+  int parity = 0;
+
+  // ---- load states, build column maps
+  for (int e = tid; e < (S + 1) * ST_STRIDE; e += WIN_BLOCK) {
+    sh.xs[0][e / ST_STRIDE][e % ST_STRIDE] = states[e];
+    sh.xs[1][e / ST_STRIDE][e % ST_STRIDE] = states[e];
+  }
+  for (int e = tid; e < WIN_SMAX * WIN_NMAX; e += WIN_BLOCK) {
+    sh.lcol[e / WIN_NMAX][e % WIN_NMAX] = -1;
+    sh.lcol2[e / WIN_NMAX][e % WIN_NMAX] = -1;
+  }
+  if (tid < WIN_NMAX) sh.pose_of[tid] = -1;
+  __syncthreads();
+  if (tid == 0) {
+    const int sz[4] = {3, 2, 1, 2}, lbase[4] = {0, 3, 5, 6};
+    for (int f = 0; f < S; ++f)
+      for (int side = 0; side < 2; ++side) {
+        const int j = f + side;
+        for (int blk = 0; blk < 4; ++blk)
+          if (W.off_tan[j][blk] >= 0)
+            for (int e = 0; e < sz[blk]; ++e) sh.lcol[f][W.off_tan[j][blk] + e] = side * 8 + lbase[blk] + e;
+        if (W.off_tan[j][0] >= 0)
+          for (int e = 0; e < 3; ++e) sh.lcol2[f][W.off_tan[j][0] + e] = side * 3 + e;
+        if (W.off_tan[j][4] >= 0) sh.lcol2[f][W.off_tan[j][4]] = 6 + side;
+      }
+    for (int j = 1; j <= S; ++j)
+      if (W.off_tan[j][0] >= 0)
+        for (int e = 0; e < 3; ++e) sh.pose_of[W.off_tan[j][0] + e] = j;
+  }
+  __syncthreads();
+
+  // number of NDT residual blocks and of moving cells
+  int n_res = 0;
+  for (int t = 0; t < W.n_terms; ++t) {
+    int M = moving.counts[W.term_moving[t]];
+    M = M > moving.cap ? moving.cap : M;
+    const int32_t* pc = corr + (size_t)t * moving.cap * W.k;
+    for (int s = tid; s < M * W.k; s += WIN_BLOCK) {
+      const int ci = pc[s];
+      n_res += (ci >= 0 && ci < fixed.cap) ? 1 : 0;
+    }
+  }
+  {
+    double v = wave_sum((double)n_res);
+    if (lane == 0) sh.red[0][wave][33] = v;
+    __syncthreads();
+    n_res = (int)(sh.red[0][0][33] + sh.red[0][1][33] + sh.red[0][2][33] + sh.red[0][3][33]);
+    __syncthreads();
+  }
+  int n_cells = 0;  // sum over optimised states (ndt_matcher.cpp:367)
+  {
+    int last = -1;
+    for (int t = 0; t < W.n_terms; ++t)
+      if (W.term_state[t] != last) {
+        int M = moving.counts[W.term_moving[t]];
+        n_cells += M > moving.cap ? moving.cap : M;
+        last = W.term_state[t];
+      }
+  }
+
+  double* tr = trace;
+  if (tr && tid == 0) tr[0] = 0.0;
+  randt_result res;
+  res.cost = res.final_cost = res.initial_cost = res.mu0 = 0.0;
+  res.n_residuals = n_res;
+  res.iterations = res.gnc_solves = res.n_evals = 0;
+  res.termination = RANDT_TERM_NONE;
+  res.status = 0;
+  res.reserved[0] = res.reserved[1] = 0;
+
+  // ---- raw NDT residuals -> gnc_mu (ndt_matcher.cpp:382-389)
+  const double weight = n_cells > 0 ? W.ndt_weight / (double)(n_cells * W.k) : 0.0;
+  Loss L = make_loss(P.loss_a, P.alpha, 1.0, weight);
+  double base_cur[WIN_SMAX * 10], base_cnd[WIN_SMAX * 10];
+  double raw_max = 0.0;
+  bool ok = true;
+  if (n_res > 0) {
+    ok = ndt_pass<D, 0>(fixed, moving, W, corr, sh, 0, L, base_cur, parity, sh);
+    raw_max = base_cur[0];
+    res.n_evals++;
+  }
+  double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
+  gnc_mu = fmin(gnc_mu, pow(P.gnc_div, (double)(P.gnc_steps - 1)));
+  res.mu0 = gnc_mu;
+  int term = RANDT_TERM_FAILURE;
+  double summary_min = 0.0;
+  if (!ok) res.status = 2;
+  int p = 0;  // current state buffer
+
+  if (ok) {
+    do {
+      gnc_mu = fmax(gnc_mu, 1.0);
+      L = make_loss(P.loss_a, P.alpha, gnc_mu, weight);
+      // ================= one ceres::Solve =================
+      double radius = P.r0, decrease = 2.0;
+      bool reuse = false, step_ok = true;
+      int num_invalid = 0, iteration = 0;
+      double minimum_cost = DBL_MAX;
+      double fcost = factor_pass(W, sh, p);
+      bool e_ok = ndt_pass<D, 1>(fixed, moving, W, corr, sh, p, L, base_cur, parity, sh);
+      res.n_evals++;
+      res.iterations++;
+      double cost = fcost;
+#pragma unroll
+      for (int j = 0; j < WIN_SMAX; ++j) cost += base_cur[j * 10];
+      if (!e_ok || !isfinite(cost)) {
+        term = RANDT_TERM_FAILURE;
+        res.status = 2;
+        res.gnc_solves++;
+        break;
+      }
+      if (res.gnc_solves == 0) res.initial_cost = cost;
+      summary_min = cost;
+      assemble(W, sh, p, base_cur);
+      bool first = true, need_scale = true;
+      double x_norm = 0.0;
+      trace_push(tr, trace_len, cost, radius, 0);
+
+      for (;;) {
+        // ---- (wave 0) Jacobi scaling of the freshly assembled system, gradient test
+        if (need_scale) {
+          if (wave == 0) {
+            if (first) {
+              if (lane < n) sh.sigma[lane] = 1.0 / (1.0 + sqrt(sh.H[lane * n + lane]));
+              wave_fence();
+            }
+            for (int e = lane; e < n * n; e += 64) sh.Hs[e] = sh.H[e] * sh.sigma[e / n] * sh.sigma[e % n];
+            if (lane < n) sh.gs[lane] = sh.g[lane] * sh.sigma[lane];
+            // gradient tolerance: ||x - Plus(x, -g)||_inf <= gtol
+            double gm = lane < n ? fabs(sh.g[lane]) : 0.0;
+            gm = wave_max(gm);
+            double gconv = 0.0;
+            // the displacement of Plus(x, -g) is >= 0.4 max|g_i| (|omega| <= pi): exact test only for tiny gradients
+            if (!(0.4 * gm > P.gtol && gm < 3.0)) {
+              wave_fence();
+              plus_states(W, sh, p, 1 - p, sh.g, -1.0, lane);
+              wave_fence();
+              double m = 0.0;
+              if (lane <= S) {
+                for (int e = 0; e < ST_STRIDE; ++e) {
+                  const double d = fabs(sh.xs[p][lane][e] - sh.xs[1 - p][lane][e]);
+                  m = d > m ? d : m;
+                }
+              }
+              m = wave_max(m);
+              gconv = m <= P.gtol ? 1.0 : 0.0;
+            }
+            const double xn = ambient_sq(W, sh, p, -1, lane);
+            if (lane == 0) {
+              sh.scal[4] = gconv;
+              sh.scal[2] = sqrt(xn);
+            }
+          }
+          __syncthreads();
+          x_norm = sh.scal[2];
+          need_scale = false;
+          first = false;
+        }
+        const bool gconv = sh.scal[4] != 0.0;
+        // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
+        // (Ceres copies x to the user parameters after successful steps that lower the minimum cost;
+        //  accepted steps are monotone here, so the current buffer p always is that point.)
+        if (step_ok && cost < minimum_cost) minimum_cost = cost;
+        if (iteration >= P.max_it) { term = RANDT_TERM_NO_CONVERGENCE; break; }
+        if (step_ok && gconv) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
+        if (radius <= P.rmin) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
+        ++iteration;
+        res.iterations++;
+
+        // ---- (wave 0) LevenbergMarquardtStrategy::ComputeStep: damped normal equations, LDL^T in LDS
+        if (wave == 0) {
+          if (!reuse && lane < n) sh.diag[lane] = fmin(fmax(sh.Hs[lane * n + lane], P.dmin), P.dmax);
+          wave_fence();
+          const double inv_radius = 1.0 / radius;
+          for (int e = lane; e < n * n; e += 64) sh.A[e] = sh.Hs[e] + ((e / n) == (e % n) ? sh.diag[e / n] * inv_radius : 0.0);
+          wave_fence();
+          double okf = 1.0;
+          for (int j = 0; j < n; ++j) {
+            const double d = sh.A[j * n + j];
+            if (!(d > 0.0)) okf = 0.0;
+            const double invd = 1.0 / d;
+            for (int i = j + 1 + lane; i < n; i += 64) sh.col[i] = sh.A[i * n + j] * invd;  // L_ij
+            wave_fence();
+            const int m = n - j - 1;
+            for (int e = lane; e < m * m; e += 64) {
+              const int i = j + 1 + e / m, k = j + 1 + e % m;
+              if (k <= i) sh.A[i * n + k] -= sh.col[i] * d * sh.col[k];
+            }
+            for (int i = j + 1 + lane; i < n; i += 64) sh.A[i * n + j] = sh.col[i];
+            wave_fence();
+          }
+          // L z = gs ; w = z / d ; L^T y = w   (y overwrites step)
+          if (lane < n) sh.step[lane] = sh.gs[lane];
+          wave_fence();
+          for (int j = 0; j < n; ++j) {
+            const double yj = sh.step[j];
+            for (int i = j + 1 + lane; i < n; i += 64) sh.step[i] -= sh.A[i * n + j] * yj;
+            wave_fence();
+          }
+          if (lane < n) sh.step[lane] = sh.step[lane] / sh.A[lane * n + lane];
+          wave_fence();
+          for (int j = n - 1; j >= 0; --j) {
+            const double yj = sh.step[j];
+            for (int i = lane; i < j; i += 64) sh.step[i] -= sh.A[j * n + i] * yj;
+            wave_fence();
+          }
+          double fin = 1.0;
+          if (lane < n) {
+            if (!isfinite(sh.step[lane])) fin = 0.0;
+            sh.step[lane] = -sh.step[lane];
+          }
+          fin = -wave_max(-fin);
+          wave_fence();
+          // model_cost_change = -(step.gs + step^T Hs step / 2)
+          double t = 0.0;
+          if (lane < n) {
+            double hs = 0.0;
+            for (int b = 0; b < n; ++b) hs += sh.Hs[lane * n + b] * sh.step[b];
+            t = sh.step[lane] * (sh.gs[lane] + 0.5 * hs);
+            sh.delta[lane] = sh.step[lane] * sh.sigma[lane];
+          }
+          const double mcc = -wave_sum(t);
+          wave_fence();
+          plus_states(W, sh, p, 1 - p, sh.delta, 1.0, lane);
+          wave_fence();
+          const double sn2 = ambient_sq(W, sh, p, 1 - p, lane);
+          if (lane == 0) {
+            sh.scal[0] = mcc;
+            sh.scal[1] = sn2;
+            sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
+          }
+        }
+        __syncthreads();
+        reuse = true;
+        const double mcc = sh.scal[0], sn2 = sh.scal[1];
+        const bool valid = sh.scal[3] != 0.0 && mcc > 0.0;
+        if (!valid) {
+          // ---- HandleInvalidStep
+          if (++num_invalid >= P.max_invalid) { term = RANDT_TERM_FAILURE; break; }
+          radius = radius / decrease;
+          decrease *= 2.0;
+          step_ok = false;
+          summary_min = fmin(summary_min, cost);
+          trace_push(tr, trace_len, cost, radius, 3);
+          __syncthreads();
+          continue;
+        }
+        num_invalid = 0;
+
+        // ---- candidate: factors + NDT terms with Jacobians (speculative)
+        const double cf = factor_pass(W, sh, 1 - p);
+        const bool c_ok = ndt_pass<D, 1>(fixed, moving, W, corr, sh, 1 - p, L, base_cnd, parity, sh);
+        res.n_evals++;
+        double cand_cost = cf;
+#pragma unroll
+        for (int j = 0; j < WIN_SMAX; ++j) cand_cost += base_cnd[j * 10];
+        const bool cfin = c_ok && isfinite(cand_cost);
+        if (!cfin) cand_cost = DBL_MAX;
+
+        // ---- ParameterToleranceReached / FunctionToleranceReached
+        const double ptol_abs = P.ptol * (x_norm + P.ptol);
+        if (sn2 <= ptol_abs * ptol_abs) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
+        const double cost_change = cost - cand_cost;
+        if (fabs(cost_change) <= P.ftol * cost) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
+        const double rel = cfin ? cost_change / mcc : -DBL_MAX;
+        if (rel > P.min_rel) {
+          // ---- HandleSuccessfulStep: the candidate buffer becomes current
+          p = 1 - p;
+          cost = cand_cost;
+#pragma unroll
+          for (int i = 0; i < WIN_SMAX * 10; ++i) base_cur[i] = base_cnd[i];
+          assemble(W, sh, p, base_cur);
+          need_scale = true;
+          step_ok = true;
+          const double t = 2.0 * rel - 1.0;
+          radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+          radius = fmin(P.rmax, radius);
+          decrease = 2.0;
+          reuse = false;
+          summary_min = fmin(summary_min, cost);
+          trace_push(tr, trace_len, cost, radius, 1);
+        } else {
+          step_ok = false;
+          radius = radius / decrease;
+          decrease *= 2.0;
+          summary_min = fmin(summary_min, cand_cost);
+          trace_push(tr, trace_len, cand_cost, radius, 2);
+          __syncthreads();
+        }
+      }
+      res.gnc_solves++;
+      gnc_mu /= P.gnc_div;
+    } while (gnc_mu > 1.0 / sqrt(P.gnc_div));
+  }
+  __syncthreads();
+  for (int e = tid; e < (S + 1) * ST_STRIDE; e += WIN_BLOCK) states[e] = sh.xs[p][e / ST_STRIDE][e % ST_STRIDE];
+  res.termination = term;
+  res.final_cost = summary_min;
+  res.cost = n_res > 0 ? summary_min / (double)n_res : 0.0;
+  if (tid == 0) result[0] = res;
+}
+
+}  // namespace
+
+int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc,
+                        const int32_t* d_corr, const randt_matcher_params* mp, double* d_states, randt_result* d_result) {
+  SolveParams P;
+  P.loss_a = mp->loss_scale;
+  P.mu_scale = mp->mu_scale;
+  P.alpha = mp->loss_alpha;
+  P.weight = mp->loss_weight;
+  P.gnc_div = mp->gnc_divisor;
+  P.ftol = mp->function_tolerance;
+  P.gtol = mp->gradient_tolerance;
+  P.ptol = mp->parameter_tolerance;
+  P.r0 = mp->initial_radius;
+  P.rmax = mp->max_radius;
+  P.rmin = mp->min_radius;
+  P.min_rel = mp->min_relative_decrease;
+  P.dmin = mp->min_lm_diagonal;
+  P.dmax = mp->max_lm_diagonal;
+  P.gnc_steps = mp->gnc_steps;
+  P.max_it = mp->max_iterations;
+  P.k = mp->n_neighbours;
+  P.max_invalid = mp->max_consecutive_invalid_steps;
+  if (desc.n_tan > WIN_NMAX || desc.S > WIN_SMAX)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window too large for the device solver", hipSuccess);
+  if (desc.d3)
+    hipLaunchKernelGGL(k_solve_window<3>, dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, desc, d_corr, P, d_states,
+                       d_result, ctx->d_trace, ctx->trace_len);
+  else
+    hipLaunchKernelGGL(k_solve_window<2>, dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, desc, d_corr, P, d_states,
+                       d_result, ctx->d_trace, ctx->trace_len);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}

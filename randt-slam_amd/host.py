@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import CELL_DTYPE, RESULT_DTYPE, ClusterParams, MapParams, MatcherParams
+from ._capi import CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, ClusterParams, MapParams, MatcherParams, WindowParams
 
 
 class RandtError(RuntimeError):
@@ -245,3 +245,58 @@ def ndt_build_host(ctx, points, cluster, out_maps, map_idx, intensity_index=None
     ioff = (3 if S == 4 else 4) if intensity_index is None else intensity_index
     ctx._check(ctx._lib.randt_ndt_build(ctx._h, _dptr(pts) if pts.size else None, int(pts.shape[0]), S, ioff, C.byref(cluster),
                                         out_maps._h, map_idx), "randt_ndt_build")
+
+
+# ------------------------------------------------------------------ fixed-lag window (a16 / a17) ----
+def make_state(pose4, lin_vel=(0.0, 0.0), rot_vel=0.0, lin_acc=(0.0, 0.0), imu_bias=0.0, stamp=0.0):
+    """rc::navigation::ndt::State as a STATE_DTYPE scalar (both pose representations filled)."""
+    st = np.zeros(1, dtype=STATE_DTYPE)[0]
+    st["pose"] = pose4
+    st["pos"] = pose4[2:]
+    st["rot"] = np.arctan2(pose4[1], pose4[0])
+    st["lin_vel"] = lin_vel
+    st["rot_vel"] = rot_vel
+    st["lin_acc"] = lin_acc
+    st["imu_bias"] = imu_bias
+    st["stamp"] = stamp
+    return st
+
+
+def window_params(motion_sqrtI_diag=(1, 1, 1, 1, 3, 0.1, 20, 60), covariance_scaling_factor=25.0, ndt_weight=5.0e4,
+                  weight_imu=64.0, weight_imu_bias=6.0e5, reject_t=2.0, reject_r=2.0, smoothing_steps=3, use_imu=0,
+                  const_vel=1):
+    """indoor values: config/parameters_indoor.yaml:32-39 + ndt_radar_slam_base_parameters.yaml:36-47."""
+    wp = WindowParams()
+    M = np.diag(np.asarray(motion_sqrtI_diag, dtype=np.float64)) * covariance_scaling_factor
+    for i, v in enumerate(M.reshape(-1)):
+        wp.motion_sqrtI[i] = v
+    wp.ndt_weight, wp.weight_imu, wp.weight_imu_bias = ndt_weight, weight_imu, weight_imu_bias
+    wp.pose_reject_translation, wp.pose_reject_rotation = reject_t, reject_r
+    wp.smoothing_steps, wp.use_imu, wp.use_constant_velocity_model = smoothing_steps, use_imu, const_vel
+    return wp
+
+
+def predict_state(last, stamp):
+    """Matcher::predictTransform (constant-velocity prediction of the next State)."""
+    a = np.array([last], dtype=STATE_DTYPE)
+    out = np.zeros(1, dtype=STATE_DTYPE)
+    rc = _capi.load().randt_predict_state(_dptr(a), float(stamp), _dptr(out))
+    if rc:
+        raise RandtError(rc, "randt_predict_state")
+    return out[0]
+
+
+def register_window(ctx, fixed, fixed_idx, moving, moving_idx, states, mp, wp, trans4, imu=None):
+    """Matcher::estimateTransformCeres.  states: STATE_DTYPE array (S+1, oldest first).
+    Returns (states_out, trans_out, rejected, result)."""
+    st = np.array(states, dtype=STATE_DTYPE).copy()
+    fi = np.ascontiguousarray(fixed_idx, dtype=np.int32)
+    mi = np.ascontiguousarray(moving_idx, dtype=np.int32)
+    t = np.array(trans4, dtype=np.float64)
+    im = None if imu is None else np.ascontiguousarray(imu, dtype=np.float64)
+    rej = C.c_int(0)
+    res = np.zeros(1, dtype=RESULT_DTYPE)
+    ctx._check(ctx._lib.randt_register_window(ctx._h, fixed._h, _dptr(fi), len(fi), moving._h, _dptr(mi), _dptr(st), len(st),
+                                              _dptr(im), C.byref(mp), C.byref(wp), _dptr(t), C.byref(rej), _dptr(res)),
+               "randt_register_window")
+    return st, t, bool(rej.value), res[0]

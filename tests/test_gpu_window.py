@@ -1,0 +1,162 @@
+"""-m gpu parity of the fixed-lag window path: randt_predict_state and
+randt_register_window against the CPU oracle on a simulated drive, incl. the overlap case with two
+fixed maps, the IMU factor, the constant-acceleration layout and the rejection gate."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+import randt_slam_amd as R
+from randt_slam_amd import synth
+from util import IP, cells_equal, oracle_scan_map, to_oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def to_oracle_wp(wp):
+    o = po.WindowParams()
+    for name, _ in R.WindowParams._fields_:
+        v = getattr(wp, name)
+        if name == "motion_sqrtI":
+            for i in range(64):
+                o.motion_sqrtI[i] = v[i]
+        else:
+            setattr(o, name, v)
+    return o
+
+
+@pytest.fixture(scope="module")
+def drive(built):
+    import torch
+
+    world = synth.make_world()
+    n_scans, dt = 8, 0.25
+    traj = synth.make_trajectory(3100, n_scans + 34, step=0.25)
+    origin_inv = synth.se2_inv3(traj[0])
+    rel = np.array([synth.se2_mul3(origin_inv, p) for p in traj])
+    rel[:, 2] = synth.wrap_angle(rel[:, 2])
+    kf = [synth.make_scan(world, traj[t], 7000 + t) for t in range(0, 32, 4)]
+    kf_rel = rel[0:32:4]
+    scans = [synth.make_scan(world, traj[32 + i], 8000 + i) for i in range(n_scans)]
+
+    # oracle side
+    def omap(cap=None):
+        return po.Map(IP["size_x"], IP["size_y"], IP["resolution"], (0, 0), IP["max_neighbour_dist"], IP["min_points_per_cell"], cap)
+
+    osub, osub2 = omap(), omap()
+    for i, s in enumerate(kf):
+        m = oracle_scan_map(s)
+        m.transform(synth.pose3_to_pose4(kf_rel[i]))
+        osub.merge(m)
+        if i % 2 == 0:
+            osub2.merge(m)          # a sparser second "previous submap" for the overlap case
+    oscans = [oracle_scan_map(s) for s in scans]
+    # device side
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
+    sub = R.Maps(ctx, 2, mapp, 10000, with_grid=True)
+    tmp = R.Maps(ctx, len(kf), mapp, 512, with_grid=False)
+    R.ndt_build_batch(ctx, torch.from_numpy(np.stack(kf)).to(dev), clu, tmp)
+    sub.merge(0, tmp, 0, synth.pose3_to_pose4(kf_rel))
+    for i in range(0, len(kf), 2):
+        sub.merge(1, tmp, i, synth.pose3_to_pose4(kf_rel[i:i + 1]))
+    smaps = R.Maps(ctx, n_scans, mapp, 512, with_grid=False)
+    R.ndt_build_batch(ctx, torch.from_numpy(np.stack(scans)).to(dev), clu, smaps)
+    ctx.synchronize()
+    assert cells_equal(sub.download(1)[0], osub2.cells())
+    return dict(ctx=ctx, sub=sub, smaps=smaps, osub=osub, osub2=osub2, oscans=oscans, truth=rel[32:32 + n_scans], dt=dt, torch=torch)
+
+
+def test_predict_state_matches_oracle(built):
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        th = rng.uniform(-3, 3)
+        st = R.make_state([np.cos(th), np.sin(th), rng.normal(), rng.normal()], lin_vel=rng.normal(0, 1, 2), rot_vel=rng.normal(0, .5),
+                          lin_acc=rng.normal(0, 1, 2), imu_bias=0.1, stamp=5.0)
+        stamp = 5.0 + rng.choice([0.0, 0.1, 0.25, 1.0])
+        a = R.predict_state(st, stamp)
+        b = po.predict_state(st.astype(po.STATE_DTYPE), stamp)
+        for f in a.dtype.names:
+            assert np.allclose(a[f], b[f], rtol=0, atol=1e-15), f
+
+
+def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True):
+    torch, ctx = drive["torch"], drive["ctx"]
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    wp = R.window_params(use_imu=use_imu, const_vel=const_vel)
+    op, owp = to_oracle_params(mp), to_oracle_wp(wp)
+    truth, dt = drive["truth"], drive["dt"]
+    s0 = R.make_state(synth.pose3_to_pose4(truth[0]), lin_vel=(0.8, 0.0), rot_vel=0.0, stamp=0.0)
+    gs, os_ = [s0], [s0.astype(po.STATE_DTYPE)]
+    gtrans = otrans = synth.pose3_to_pose4(truth[0])
+    fixed_o = [drive["osub"], drive["osub2"]][:n_fixed]
+    imu_all = []
+    dev_trace = torch.zeros(3 * 512 + 1, dtype=torch.float64, device="cuda:0")
+    for i in range(1, len(truth)):
+        gs.append(R.predict_state(gs[-1], i * dt))
+        os_.append(po.predict_state(os_[-1], i * dt))
+        imu_all.append(synth.wrap_angle(truth[i][2] - truth[i - 1][2]) + 0.002)
+        S = min(len(gs) - 1, 3)
+        win = list(range(i - S + 1, i + 1))                       # scan indices of the optimised states
+        imu = np.array(imu_all[-S:]) if use_imu else None
+        if trace:
+            ctx.set_trace(dev_trace, dev_trace.shape[0])
+        g_states, gtrans, g_rej, g_res = R.register_window(ctx, drive["sub"], list(range(n_fixed)), drive["smaps"], win,
+                                                           np.array(gs[-S - 1:], dtype=R.STATE_DTYPE), mp, wp, gtrans, imu)
+        ctx.set_trace(None, 0)
+        rc, o_states, otrans, o_st = po.register_window(fixed_o, [drive["oscans"][w] for w in win],
+                                                        np.array(os_[-S - 1:], dtype=po.STATE_DTYPE), op, owp, otrans, imu)
+        assert rc == int(g_rej) == 0
+        # pose of every state of the window within the north_star tolerance (observed ~1e-9)
+        for j in range(S + 1):
+            assert np.abs(g_states[j]["pose"][2:] - o_states[j]["pose"][2:]).max() <= 1e-4
+            assert abs(g_states[j]["rot"] - o_states[j]["rot"]) <= 1e-4
+            assert np.allclose(g_states[j]["pose"], o_states[j]["pose"], atol=1e-7)
+            assert np.allclose(g_states[j]["lin_vel"], o_states[j]["lin_vel"], atol=1e-6)
+            assert np.isclose(g_states[j]["rot_vel"], o_states[j]["rot_vel"], atol=1e-6)
+            assert np.allclose(g_states[j]["lin_acc"], o_states[j]["lin_acc"], atol=1e-5)
+            assert np.isclose(g_states[j]["imu_bias"], o_states[j]["imu_bias"], atol=1e-7)
+        assert np.allclose(gtrans, otrans, atol=1e-7)
+        assert g_res["n_residuals"] == o_st["n_residuals"] and g_res["gnc_solves"] == o_st["n_solves"]
+        assert g_res["iterations"] == o_st["n_iterations"] and g_res["termination"] == o_st["termination"]
+        if trace:
+            tr = dev_trace.cpu().numpy()
+            n = int(tr[0])
+            t = tr[1:1 + 3 * n].reshape(n, 3)
+            assert n == len(o_st["trace_cost"])
+            assert np.allclose(t[:, 0], o_st["trace_cost"], rtol=1e-7)
+            assert np.array_equal(t[:, 2].astype(int), o_st["trace_flag"])
+        for j in range(S + 1):
+            gs[len(gs) - S - 1 + j] = g_states[j]
+            os_[len(os_) - S - 1 + j] = o_states[j]
+        est = synth.pose4_to_pose3(gtrans)
+        assert np.all(np.abs(est[:2] - truth[i][:2]) < 0.08) and abs(synth.wrap_angle(est[2] - truth[i][2])) < 0.03
+    return gs
+
+
+def test_window_drive_matches_oracle(drive):
+    gs = _run_drive(drive)
+    assert abs(np.hypot(*gs[-1]["lin_vel"]) - 1.0) < 0.15       # the smoother recovered the 1 m/s body speed
+
+
+def test_window_overlap_two_fixed_maps(drive):
+    _run_drive(drive, n_fixed=2)
+
+
+def test_window_with_imu_factor(drive):
+    _run_drive(drive, use_imu=1)
+
+
+def test_window_constant_acceleration_layout(drive):
+    _run_drive(drive, const_vel=0)
+
+
+def test_window_rejection_gate(drive):
+    ctx = drive["ctx"]
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    wp = R.window_params(reject_t=0.001)
+    truth, dt = drive["truth"], drive["dt"]
+    prev = R.make_state(synth.pose3_to_pose4(truth[0]), lin_vel=(1.0, 0.0), stamp=0.0)
+    states = np.array([prev, R.predict_state(prev, dt)], dtype=R.STATE_DTYPE)
+    out, trans, rej, res = R.register_window(ctx, drive["sub"], [0], drive["smaps"], [1], states, mp, wp, synth.pose3_to_pose4(truth[0]))
+    assert rej and np.array_equal(out[1]["pose"], out[0]["pose"]) and np.all(out[1]["lin_vel"] == 0) and np.array_equal(trans, out[0]["pose"])
