@@ -1,0 +1,207 @@
+"""Streaming-odometry harness: the call pattern of LocalFuser::processScan / initializeNewSubmap
+(src/local_fuser/local_fuser.cpp:40-63,99-300) and NDTSlam::radarCb's submap roll-over
+(src/ndt_slam/ndt_slam.cpp:211-223) on top of the C ABI -- BASELINE config 3.
+
+Only the data path is reproduced (scan NDT -> predict -> fixed-lag registration -> keyframe queue
+with insertion delay -> rolling submap merge -> new submap with overlap); pose-graph nodes,
+ScanContext, ray tracing and ROS plumbing are out of scope.
+
+The numerical work is done by a *backend*; the default one drives librandt_hip.so.  Tests inject
+a backend built on the CPU oracle to check the whole sequence for parity -- this module itself never
+imports the oracle.
+"""
+import numpy as np
+
+from . import host
+from ._capi import STATE_DTYPE
+from .synth import indoor_params
+
+
+def _se2_mul4(a, b):
+    """Sophus SE2 product on [c, s, tx, ty] (double), complex re-normalised."""
+    re, im = a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]
+    n = np.hypot(re, im)
+    return np.array([re / n, im / n, a[2] + a[0] * b[2] - a[1] * b[3], a[3] + a[1] * b[2] + a[0] * b[3]])
+
+
+def _se2_inv4(a):
+    c, s = a[0], -a[1]
+    return np.array([c, s, -(c * a[2] - s * a[3]), -(s * a[2] + c * a[3])])
+
+
+class HipBackend:
+    """Device-resident maps in two pools: scan NDTs (ring of slots) and submaps."""
+
+    def __init__(self, ctx, map_params, cluster_params, scan_capacity=512, scan_slots=24, submap_slots=4):
+        import torch
+
+        self.torch = torch
+        self.ctx, self.mapp, self.clu = ctx, map_params, cluster_params
+        self.scans = host.Maps(ctx, scan_slots, map_params, scan_capacity, with_grid=False)
+        self.subs = host.Maps(ctx, submap_slots, map_params, map_params.size_x * map_params.size_y, with_grid=True)
+        self.free_scans = list(range(scan_slots))
+        self.free_subs = list(range(submap_slots))
+        self.dev = torch.device("cuda", ctx.device)
+
+    # ---- scans
+    def build_scan(self, points):
+        idx = self.free_scans.pop(0)
+        pts = points if hasattr(points, "data_ptr") else self.torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(self.dev)
+        host.ndt_build_batch(self.ctx, pts.reshape(1, pts.shape[-2], pts.shape[-1]), self.clu, self.scans, first_map=idx)
+        return idx
+
+    def release_scan(self, idx):
+        self.free_scans.append(idx)
+
+    # ---- submaps
+    def new_submap(self):
+        idx = self.free_subs.pop(0)
+        self.subs.clear(idx, 1)
+        return idx
+
+    def release_submap(self, idx):
+        self.free_subs.append(idx)
+
+    def submap_cells(self, idx):
+        return int(self.subs.counts(idx, 1)[0])
+
+    def merge(self, sub_idx, scan_idx, pose4):
+        self.subs.merge(sub_idx, self.scans, scan_idx, np.asarray(pose4, dtype=np.float64).reshape(1, 4))
+
+    def copy_transformed(self, src_idx, pose4):
+        """_last_submap_transformed = _current_submap; .transformMap(pose) (local_fuser.cpp:44-46)."""
+        dst = self.free_subs.pop(0)
+        self.subs.copy_from(self.subs, dst_first=dst, src_first=src_idx, count=1)
+        self.subs.transform(dst, np.asarray(pose4, dtype=np.float64).reshape(1, 4))
+        return dst
+
+    # ---- matcher
+    def predict(self, state, stamp):
+        return host.predict_state(state, stamp)
+
+    def register_window(self, fixed_idx, moving_idx, states, mp, wp, trans4):
+        st, t, rej, res = host.register_window(self.ctx, self.subs, fixed_idx, self.scans, moving_idx, states, mp, wp, trans4, None)
+        return st, t, rej, res
+
+
+class Odometry:
+    """LocalFuser's front-end loop.  process_scan(points, stamp) returns the scan's pose in the global
+    frame as [c, s, tx, ty]."""
+
+    def __init__(self, backend, matcher_params, window_params, params=None):
+        p = dict(indoor_params())
+        if params:
+            p.update(params)
+        self.b, self.mp, self.wp = backend, matcher_params, window_params
+        self.insertion_step = p["insertion_step"]
+        self.insertion_delay = p["smoothing_steps"] + 1              # ndt_slam.cpp:580
+        self.smoothing_steps = p["smoothing_steps"]
+        self.submap_size_poses = p["submap_size_poses"]
+        self.submap_overlap = p["submap_overlap"]
+        self.current_submap = backend.new_submap()
+        self.last_submap_transformed = None
+        self.trajectory = []                                          # list of STATE_DTYPE scalars
+        self.map_window = []                                          # scan handles of the newest states
+        self.next_maps_to_insert = []                                 # keyframe queue (scan handles)
+        self.current_transform = np.array([1.0, 0.0, 0.0, 0.0])       # pose in the submap frame
+        self.current_global_transform = np.array([1.0, 0.0, 0.0, 0.0])
+        self.n_finished_submaps = 0
+        self.last_state = None
+        self.n_scans = 0
+        self.n_registrations = 0
+        self.n_rejected = 0
+        self.last_result = None
+
+    # LocalFuser::getTransform (local_fuser.h:113-127)
+    def get_transform(self):
+        return _se2_mul4(self.current_global_transform, self.current_transform)
+
+    def submap_complete(self):
+        return len(self.trajectory) >= self.submap_size_poses
+
+    # LocalFuser::initializeNewSubmap (local_fuser.cpp:40-63)
+    def initialize_new_submap(self, initial_transform):
+        b = self.b
+        self.last_state = self.trajectory[-1].copy()
+        if self.last_submap_transformed is not None:
+            b.release_submap(self.last_submap_transformed)
+        old_to_new = _se2_mul4(_se2_inv4(self.current_global_transform), initial_transform)
+        self.last_submap_transformed = b.copy_transformed(self.current_submap, old_to_new)
+        for h in self.next_maps_to_insert + self.map_window:
+            self._unref(h)
+        self.next_maps_to_insert, self.map_window = [], []
+        self.current_transform = np.array([1.0, 0.0, 0.0, 0.0])
+        self.current_global_transform = np.array(initial_transform, dtype=np.float64)
+        b.release_submap(self.current_submap)
+        self.current_submap = b.new_submap()
+        self.trajectory = []
+        self.n_finished_submaps += 1
+
+    # scan handles can sit in the window and in the keyframe queue at the same time
+    def _ref(self, h):
+        self._refs[h] = self._refs.get(h, 0) + 1
+
+    def _unref(self, h):
+        self._refs[h] -= 1
+        if self._refs[h] == 0:
+            del self._refs[h]
+            self.b.release_scan(h)
+
+    _refs = None
+
+    # LocalFuser::processScan (local_fuser.cpp:99-300), data path only
+    def _process(self, scan, stamp):
+        b = self.b
+        if b.submap_cells(self.current_submap) > 0:
+            self.trajectory.append(b.predict(self.trajectory[-1], stamp))                 # :125
+            self.map_window.append(scan)                                                  # :130
+            self._ref(scan)
+            fixed = [self.current_submap]
+            if len(self.trajectory) < self.submap_overlap and self.n_finished_submaps > 0:  # :133-136
+                fixed.append(self.last_submap_transformed)
+            S = min(len(self.trajectory) - 1, self.smoothing_steps)                       # ndt_matcher.cpp:343
+            states = np.array(self.trajectory[-S - 1:], dtype=STATE_DTYPE)
+            states, trans, rej, res = b.register_window(fixed, self.map_window[-S:], states, self.mp, self.wp, self.current_transform)
+            for j in range(S + 1):
+                self.trajectory[len(self.trajectory) - S - 1 + j] = states[j]
+            self.current_transform = trans
+            self.n_registrations += 1
+            self.n_rejected += int(bool(rej))
+            self.last_result = res
+            n = len(self.trajectory)
+            if len(self.map_window) >= self.smoothing_steps:                              # :152-154
+                self._unref(self.map_window.pop(0))
+            if n % self.insertion_step == 0:                                              # :155-161 keyframe
+                self.next_maps_to_insert.append(scan)
+                self._ref(scan)
+            if n >= self.insertion_delay + self.insertion_step and (n - self.insertion_delay) % self.insertion_step == 0:  # :164
+                smoothed = self.trajectory[-self.insertion_delay - 1]["pose"]             # :165-166
+                kf = self.next_maps_to_insert.pop(0)
+                b.merge(self.current_submap, kf, smoothed)                                # :177,190
+                self._unref(kf)
+        else:
+            # first scan of the submap (:225-295)
+            st = np.zeros(1, dtype=STATE_DTYPE)[0]
+            st["pose"] = self.current_transform
+            st["pos"] = self.current_transform[2:]
+            st["rot"] = np.arctan2(self.current_transform[1], self.current_transform[0])
+            if self.n_finished_submaps > 0:
+                st["lin_vel"], st["rot_vel"] = self.last_state["lin_vel"], self.last_state["rot_vel"]
+                st["lin_acc"], st["imu_bias"] = self.last_state["lin_acc"], self.last_state["imu_bias"]
+            st["stamp"] = stamp
+            self.trajectory.append(st)
+            b.merge(self.current_submap, scan, self.current_transform)                    # :281,293
+
+    def process_scan(self, points, stamp):
+        """NDTSlam::radarCb (ndt_slam.cpp:211-223): process, roll the submap over when complete."""
+        if self._refs is None:
+            self._refs = {}
+        scan = self.b.build_scan(points)                                                  # :102-105
+        self._ref(scan)
+        self._process(scan, stamp)
+        if self.submap_complete():
+            self.initialize_new_submap(self.get_transform())
+            self._process(scan, stamp)
+        self._unref(scan)
+        self.n_scans += 1
+        return self.get_transform()
