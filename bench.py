@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=4, help="in-flight batches: step i runs on HIP stream i %% streams")
+    ap.add_argument("--odometry-scans", type=int, default=200, help="BASELINE config 3 side measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock budget of the CPU baseline leg")
     args = ap.parse_args()
@@ -196,10 +197,63 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out.update(cpu_baseline(prob, mp, pose.cpu().numpy(), args.cpu_seconds))
+        if args.odometry_scans > 0 and world == 1:
+            out["config3_streaming_odometry"] = streaming_odometry(ctx, args.odometry_scans, not args.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def streaming_odometry(ctx, n_scans, with_cpu):
+    """BASELINE config 3 (side measurement, not the headline metric): sequential scans through the
+    LocalFuser::processScan call pattern -- scan NDT build, constant-velocity prediction, fixed-lag
+    window registration (3 states, motion factors), keyframe merge with insertion delay, submap
+    roll-over with overlap -- one scan after the other on one GPU (the path does not shard: scan t
+    needs pose t-1).  Inputs resident in HBM; every scan costs one device->host pose read-back."""
+    import torch
+
+    import randt_slam_amd as R
+    from randt_slam_amd import odometry, synth
+
+    world = synth.make_world()
+    dt = 0.25
+    traj = synth.make_trajectory(3300, n_scans, step=0.25)
+    scans = np.stack([synth.make_scan(world, traj[i], 20000 + i) for i in range(n_scans)])
+    d_scans = torch.from_numpy(scans).to(torch.device("cuda", ctx.device))
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    wp = R.window_params()
+    odo = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, wp)
+    for i in range(min(8, n_scans)):                       # warm-up (kernels, workspace)
+        odo.process_scan(d_scans[i], i * dt)
+    odo = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, wp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 0
+    for i in range(n_scans):
+        pose = odo.process_scan(d_scans[i], i * dt)
+        iters += int(odo.last_result["iterations"]) if odo.last_result is not None else 0
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    origin_inv = synth.se2_inv3(traj[0])
+    rel = synth.se2_mul3(origin_inv, traj[-1])
+    est = synth.pose4_to_pose3(pose)
+    out = {"scans": n_scans, "scans_per_sec": n_scans / el, "ms_per_scan": el / n_scans * 1e3,
+           "mean_lm_iterations_per_scan": iters / max(1, odo.n_registrations), "submaps_finished": odo.n_finished_submaps,
+           "end_pose_error_vs_truth_m": float(np.hypot(est[0] - rel[0], est[1] - rel[1]))}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_backend import OracleBackend
+
+        n_cpu = min(n_scans, 40)
+        cpu = odometry.Odometry(OracleBackend(), mp, wp)
+        t0 = time.perf_counter()
+        for i in range(n_cpu):
+            pc = cpu.process_scan(scans[i], i * dt)
+        out["cpu_oracle_scans_per_sec"] = n_cpu / (time.perf_counter() - t0)
+        out["cpu_oracle_sample"] = "first %d scans, 1 thread (sequential path)" % n_cpu
+    return out
 
 
 def cpu_baseline(prob, mp, gpu_pose, budget_s):

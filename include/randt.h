@@ -246,6 +246,25 @@ int randt_scan_register_batch_dev(randt_ctx* ctx, const float* d_points, int n_s
 int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving,
                         int moving_idx, const randt_matcher_params* mp, double h_pose4[4], randt_result* h_result);
 
+/* ------------------------------------------------------------------ scan filter (f-1) -------- */
+/* RadarPreprocessorParameters used by filterScan + initial_transform_radar_baselink_ as a row-major
+ * 3x4 matrix (radar_preprocessor.cpp:7-28,124). */
+typedef struct randt_filter_params {
+  float min_range, max_range, min_intensity, beam_distance_increment_threshold;
+  float sensor_to_base[12];
+} randt_filter_params;
+/* RadarPreprocessor::filterScan (src/radar_preprocessing/radar_preprocessor.cpp:45-125) for a batch of
+ * polar-organised raw scans: d_raw = n_scans x n_azimuths x n_bins points of stride_floats floats
+ * (x, y, z, .., intensity at intensity_index), azimuth after azimuth, range ascending -- the layout
+ * the reference assumes (:61).  Output per scan: up to pitch_out filtered points as packed x y z I
+ * in the base frame (feed them to randt_ndt_build_batch_dev with d_n_points = d_out_counts),
+ * optional polar (angle, range) pairs, optional per-azimuth peak detections (angle, range,
+ * intensity = max_detections).  d_status[s]: 0 ok, 1 input not azimuth-organised, 2 output overflow. */
+int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans, int n_azimuths, int n_bins,
+                                int stride_floats, int intensity_index, const randt_filter_params* fp,
+                                float* d_out_points, int pitch_out, int32_t* d_out_counts, float* d_out_polar,
+                                float* d_peaks, int32_t* d_peak_counts, int32_t* d_status);
+
 /* ------------------------------------------------------------------ fixed-lag window (a16, a17) */
 /* Matcher::predictTransform, optimize_on_manifold branch (ndt_matcher.cpp:22-59) with predictSE2
  * (ceres_residuals.h:62-83): constant-velocity prediction of the next state.  Host-side O(1) math. */

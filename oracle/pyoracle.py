@@ -58,6 +58,11 @@ class SolveStats(C.Structure):
     ]
 
 
+class FilterParams(C.Structure):
+    _fields_ = [("min_range", C.c_float), ("max_range", C.c_float), ("min_intensity", C.c_float),
+                ("beam_distance_increment_threshold", C.c_float), ("sensor_to_base", C.c_float * 12)]
+
+
 class State(C.Structure):
     _fields_ = [("pose", C.c_double * 4), ("pos", C.c_double * 2), ("rot", C.c_double), ("lin_vel", C.c_double * 2),
                 ("rot_vel", C.c_double), ("lin_acc", C.c_double * 2), ("imu_bias", C.c_double), ("stamp", C.c_double)]
@@ -132,6 +137,9 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
     L.orc_se2_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_num_threads.restype = C.c_int
+    L.orc_filter_scan.restype = C.c_int
+    L.orc_filter_scan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(FilterParams), C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int, P(C.c_int)]
     L.orc_predict_state.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
     L.orc_motion_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_imu_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
@@ -422,3 +430,25 @@ def register_window(fixed_maps, moving_maps, states, params, wparams, trans4, im
     rc = lib().orc_register_window(C.cast(fx, C.c_void_p), len(fixed_maps), C.cast(mv, C.c_void_p), _ptr(st), len(st),
                                    _ptr(im) if im is not None else None, C.byref(params), C.byref(wparams), _ptr(t), C.byref(ss))
     return rc, st, t, stats_to_dict(ss)
+
+
+# ------------------------------------------------------------------ f-1 filterScan -------------
+def filter_params(min_range=0.6, max_range=12.0, min_intensity=6.0, beam_thr=0.04, sensor_to_base=None):
+    fp = FilterParams()
+    fp.min_range, fp.max_range, fp.min_intensity, fp.beam_distance_increment_threshold = min_range, max_range, min_intensity, beam_thr
+    T = np.eye(4, dtype=np.float32)[:3] if sensor_to_base is None else np.asarray(sensor_to_base, dtype=np.float32).reshape(3, 4)
+    for i, v in enumerate(T.reshape(-1)):
+        fp.sensor_to_base[i] = v
+    return fp
+
+
+def filter_scan(raw, fp, ioff=3, capacity=None):
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    n, stride = raw.shape
+    capacity = n if capacity is None else capacity
+    pts = np.zeros((capacity, 4), dtype=np.float32)
+    polar = np.zeros((capacity, 2), dtype=np.float32)
+    peaks = np.zeros((n, 3), dtype=np.float32)
+    npk = C.c_int(0)
+    cnt = lib().orc_filter_scan(_ptr(raw), n, stride, ioff, C.byref(fp), _ptr(pts), _ptr(polar), capacity, _ptr(peaks), n, C.byref(npk))
+    return cnt, pts[:max(cnt, 0)], polar[:max(cnt, 0)], peaks[:npk.value]

@@ -8,6 +8,7 @@
  *
  * Citations are relative to /root/reference/ros/ndt_radar_slam/.
  */
+#define _GNU_SOURCE
 #include "randt_oracle.h"
 
 #include <float.h>
@@ -1703,4 +1704,107 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
   memcpy(trans4, states[S].pose, sizeof(double) * 4);
   free(u.ndt_state); free(u.mm); free(u.mc); free(u.fm); free(u.fc);
   return ok ? rejected : -2;
+}
+
+/* ============================================================ f-1: filterScan ============= */
+
+/* std::hypot(float, float): glibc evaluates hypotf in double and rounds once. */
+static float hypot_f(float x, float y) { return (float)sqrt((double)x * (double)x + (double)y * (double)y); }
+
+int orc_filter_scan(const float* raw, int n, int stride, int ioff, const orc_filter_params* p, float* out_pts,
+                    float* out_polar, int capacity, float* peaks, int peak_cap, int* n_peaks) {
+#define PX(i) raw[(size_t)(i) * stride + 0]
+#define PY(i) raw[(size_t)(i) * stride + 1]
+#define PZ(i) raw[(size_t)(i) * stride + 2]
+#define PI_(i) raw[(size_t)(i) * stride + ioff]
+  const float min_d = p->min_range, max_d = p->max_range, min_i = p->min_intensity; /* members are double in the
+      reference but hold these float-representable config values; comparisons are float vs double there */
+  float current_angle = 1000;
+  float max_intensity = 0;
+  size_t current_max_idx = 0;
+  size_t* idzs = (size_t*)malloc(sizeof(size_t) * (size_t)(n > 0 ? n : 1));
+  int n_idz = 0, np = 0;
+  /* radar_preprocessor.cpp:56-75 */
+  for (int i = 0; i < n; ++i) {
+    const float dist = hypot_f(PX(i), PY(i));
+    const float angle = atan2f(PY(i), PX(i));
+    const float intensity = PI_(i);
+    if (fabsf(angle - current_angle) > 0.0001) {
+      if ((double)current_angle < 3 * M_PI) {
+        if (n_idz == 0 || idzs[n_idz - 1] != current_max_idx) {
+          if (peaks && np < peak_cap) {
+            peaks[3 * np + 0] = current_angle;
+            peaks[3 * np + 1] = hypot_f(PX(current_max_idx), PY(current_max_idx));
+            peaks[3 * np + 2] = max_intensity;
+          }
+          ++np;
+          idzs[n_idz++] = current_max_idx;
+        }
+        max_intensity = 0;
+      }
+      current_angle = angle;
+    }
+    if ((double)dist > (double)min_d && (double)dist < (double)max_d && intensity > max_intensity) {
+      max_intensity = intensity;
+      current_max_idx = (size_t)i;
+    }
+  }
+  if (n_peaks) *n_peaks = np;
+  /* :76-119 */
+  int cnt = 0;
+  const float thr = p->beam_distance_increment_threshold;
+  for (int q = 0; q < n_idz; ++q) {
+    const long long m = (long long)idzs[q];
+    long long closer, further;
+    long long d = 0;
+    for (;;) {
+      const long long b = m - d - 1;
+      if (b < 0 || b > (long long)n - 1) { closer = m - d; break; } /* SPEC DECISION: closer_idx is left uninitialised in the reference */
+      const long long a = m - d;
+      if (((double)(hypot_f(PX(a), PY(a)) - hypot_f(PX(b), PY(b))) > (double)thr) || (PI_(a) <= PI_(b)) ||
+          ((double)hypot_f(PX(a), PY(a)) < (double)min_d)) {
+        closer = a;
+        break;
+      }
+      ++d;
+    }
+    d = 0;
+    for (;;) {
+      const long long b = m + d + 1;
+      if (b < 0 || b > (long long)n - 1) { further = m + d; break; } /* SPEC DECISION: idem */
+      const long long a = m + d;
+      if (((double)(hypot_f(PX(a), PY(a)) - hypot_f(PX(b), PY(b))) > (double)thr) || (PI_(a) <= PI_(b)) ||
+          ((double)hypot_f(PX(a), PY(a)) < (double)min_d)) {
+        further = a;
+        break;
+      }
+      ++d;
+    }
+    for (long long j = closer; j <= further; ++j) {
+      const float dist = hypot_f(PX(j), PY(j));
+      const float angle = atan2f(PY(j), PX(j));
+      const float intensity = PI_(j);
+      if ((double)dist > (double)min_d && (double)dist < (double)max_d && (double)intensity > (double)min_i) {
+        if (cnt >= capacity) { free(idzs); return -1; }
+        const float x = PX(j), y = PY(j), z = PZ(j);
+        const float* T = p->sensor_to_base;
+        /* pcl::transformPointCloud with an Affine3f */
+        out_pts[4 * cnt + 0] = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+        out_pts[4 * cnt + 1] = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+        out_pts[4 * cnt + 2] = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+        out_pts[4 * cnt + 3] = intensity;
+        if (out_polar) {
+          out_polar[2 * cnt + 0] = angle;
+          out_polar[2 * cnt + 1] = dist;
+        }
+        ++cnt;
+      }
+    }
+  }
+  free(idzs);
+  return cnt;
+#undef PX
+#undef PY
+#undef PZ
+#undef PI_
 }

@@ -209,6 +209,20 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
                         const double* imu, const orc_matcher_params* p, const orc_window_params* wp, double trans4[4],
                         orc_solve_stats* st);
 
+/* ---------------------------------------------------------------- f-1: filterScan ---------- */
+typedef struct orc_filter_params {
+  float min_range, max_range, min_intensity, beam_distance_increment_threshold;
+  float sensor_to_base[12]; /* row-major 3x4 of initial_transform_radar_baselink_ */
+} orc_filter_params;
+/* RadarPreprocessor::filterScan (src/radar_preprocessing/radar_preprocessor.cpp:45-125), sequential,
+ * exactly as written (incl. the never-flushed last azimuth and the carried-over max index).
+ * raw: n points (stride floats, intensity at ioff), azimuth after azimuth, range ascending.
+ * out_pts: capacity x 4 floats (x y z I, base frame), out_polar: capacity x 2 (angle, dist),
+ * peaks: peak_cap x 3 (angle, dist, intensity) = max_detections.  Returns #filtered points (or -1 on
+ * overflow); *n_peaks receives the number of max detections. */
+int orc_filter_scan(const float* raw, int n, int stride, int ioff, const orc_filter_params* p, float* out_pts,
+                    float* out_polar, int capacity, float* peaks, int peak_cap, int* n_peaks);
+
 /* ---------------------------------------------------------------- SE(2) helpers (Sophus) --- */
 void orc_se2_exp(const double xi[3], double out4[4]);
 void orc_se2_log(const double p4[4], double xi[3]);

@@ -50,6 +50,11 @@ class MatcherParams(C.Structure):
     ]
 
 
+class FilterParams(C.Structure):
+    _fields_ = [("min_range", C.c_float), ("max_range", C.c_float), ("min_intensity", C.c_float),
+                ("beam_distance_increment_threshold", C.c_float), ("sensor_to_base", C.c_float * 12)]
+
+
 class WindowParams(C.Structure):
     _fields_ = [("motion_sqrtI", C.c_double * 64), ("ndt_weight", C.c_double), ("weight_imu", C.c_double),
                 ("weight_imu_bias", C.c_double), ("pose_reject_translation", C.c_double), ("pose_reject_rotation", C.c_double),
@@ -94,6 +99,7 @@ SYMBOLS = {
     "randt_register_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _P(MatcherParams), _V, _V]),
     "randt_scan_register_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ClusterParams), _V, _V, _V, _P(MatcherParams), _V, _V]),
     "randt_register_pair": (_I, [_V, _V, _I, _V, _I, _P(MatcherParams), _V, _V]),
+    "randt_filter_scan_batch_dev": (_I, [_V, _V, _I, _I, _I, _I, _I, _P(FilterParams), _V, _I, _V, _V, _V, _V, _V]),
     "randt_predict_state": (_I, [_V, C.c_double, _V]),
     "randt_register_window": (_I, [_V, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _P(_I), _V]),
 }

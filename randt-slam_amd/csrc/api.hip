@@ -458,6 +458,23 @@ int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
 }
 
 
+int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans, int n_azimuths, int n_bins,
+                                int stride_floats, int intensity_index, const randt_filter_params* fp,
+                                float* d_out_points, int pitch_out, int32_t* d_out_counts, float* d_out_polar,
+                                float* d_peaks, int32_t* d_peak_counts, int32_t* d_status) {
+  if (!ctx || !fp || n_scans < 0 || n_azimuths <= 0 || n_bins <= 0 || stride_floats < 3 || intensity_index < 0 ||
+      intensity_index >= stride_floats || pitch_out <= 0)
+    return RANDT_ERR_INVALID;
+  if (n_scans == 0) return RANDT_OK;
+  if (!d_raw || !d_out_points || !d_out_counts || !d_status) return RANDT_ERR_INVALID;
+  if (stride_floats == 4 && ((size_t)d_raw & 15) != 0) return randt_set_error(ctx, RANDT_ERR_INVALID, "packed xyzI input must be 16-byte aligned", hipSuccess);
+  if ((long long)n_azimuths * n_bins > (1ll << 30)) return RANDT_ERR_UNSUPPORTED;
+  int rc = ensure_ws(ctx, (size_t)n_scans * n_azimuths * 12 + 256);
+  if (rc) return rc;
+  return launch_filter_scan(ctx, d_raw, n_scans, n_azimuths, n_bins, stride_floats, intensity_index, fp, d_out_points, pitch_out,
+                            d_out_counts, d_out_polar, d_peaks, d_peak_counts, d_status, ctx->ws);
+}
+
 // ------------------------------------------------------------------ fixed-lag window (a16, a17) --
 namespace {
 void h_so2_normalize(double& c, double& s) {

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, ClusterParams, MapParams, MatcherParams, WindowParams
+from ._capi import CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, ClusterParams, FilterParams, MapParams, MatcherParams, WindowParams
 
 
 class RandtError(RuntimeError):
@@ -300,3 +300,25 @@ def register_window(ctx, fixed, fixed_idx, moving, moving_idx, states, mp, wp, t
                                               _dptr(im), C.byref(mp), C.byref(wp), _dptr(t), C.byref(rej), _dptr(res)),
                "randt_register_window")
     return st, t, bool(rej.value), res[0]
+
+
+# ------------------------------------------------------------------ scan filter (f-1) ---------------
+def filter_params(min_range=0.6, max_range=12.0, min_intensity=6.0, beam_thr=0.04, sensor_to_base=None):
+    """indoor values: config/parameters_indoor.yaml:42-44, base yaml :33; identity sensor->base."""
+    fp = FilterParams()
+    fp.min_range, fp.max_range, fp.min_intensity, fp.beam_distance_increment_threshold = min_range, max_range, min_intensity, beam_thr
+    T = np.eye(4, dtype=np.float32)[:3] if sensor_to_base is None else np.asarray(sensor_to_base, dtype=np.float32).reshape(3, 4)
+    for i, v in enumerate(T.reshape(-1)):
+        fp.sensor_to_base[i] = v
+    return fp
+
+
+def filter_scan_batch(ctx, raw, fp, out_points, out_counts, status, out_polar=None, peaks=None, peak_counts=None,
+                      intensity_index=None):
+    """randt_filter_scan_batch_dev.  raw: (n_scans, n_azimuths, n_bins, stride) float32 device tensor;
+    out_points: (n_scans, pitch_out, 4)."""
+    n_scans, n_az, n_bins, stride = (int(v) for v in raw.shape)
+    ioff = (3 if stride == 4 else 4) if intensity_index is None else intensity_index
+    ctx._check(ctx._lib.randt_filter_scan_batch_dev(ctx._h, _dptr(raw), n_scans, n_az, n_bins, stride, ioff, C.byref(fp),
+                                                    _dptr(out_points), int(out_points.shape[1]), _dptr(out_counts), _dptr(out_polar),
+                                                    _dptr(peaks), _dptr(peak_counts), _dptr(status)), "randt_filter_scan_batch_dev")

@@ -133,6 +133,28 @@ def make_scan(world, pose, seed, n_az=400, sigma=0.02, stride=4):
     return pts
 
 
+def make_polar_scan(world, pose, seed, n_az=400, n_bins=3000, bin_size=0.0438, speckle=5.0, stride=4):
+    """Oxford-RobotCar-shaped raw radar scan (BASELINE config 5): n_az azimuths x n_bins range bins,
+    every bin a point (x, y, 0, intensity) in the SENSOR frame, azimuth after azimuth, range ascending
+    (the organisation RadarPreprocessor::filterScan assumes, radar_preprocessor.cpp:61).
+    Intensity = speckle U[0, speckle) everywhere + the 5-bin return profile of the first surface hit."""
+    rng = np.random.default_rng(seed)
+    az = -np.pi + (np.arange(n_az) + 0.5) * (2 * np.pi / n_az)
+    r_hit, I0 = raycast(world, pose[:2], az + pose[2])
+    r = (np.arange(n_bins) + 0.5) * bin_size
+    inten = rng.uniform(0.0, speckle, (n_az, n_bins))
+    hit_bin = np.floor(r_hit / bin_size).astype(np.int64)
+    for k, w in enumerate(BIN_PROFILE):
+        b = hit_bin + (k - 2)
+        ok = np.isfinite(r_hit) & (b >= 0) & (b < n_bins)
+        inten[np.nonzero(ok)[0], b[ok]] += I0[ok] * w
+    pts = np.zeros((n_az, n_bins, stride), dtype=np.float32)
+    pts[..., 0] = r[None, :] * np.cos(az)[:, None]
+    pts[..., 1] = r[None, :] * np.sin(az)[:, None]
+    pts[..., stride - 1 if stride == 4 else 4] = inten
+    return pts
+
+
 def make_trajectory(seed, n_poses, step=1.0):
     """Smooth seeded path (arc of an ellipse well inside the room); poses (n,3) in the world frame,
     heading along the tangent, arc-length spacing ~ step metres."""

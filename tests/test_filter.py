@@ -1,0 +1,116 @@
+"""SURVEY row f-1 (RadarPreprocessor::filterScan): oracle properties on CPU, HIP parity on GPU."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+import randt_slam_amd as R
+from randt_slam_amd import host, synth
+
+
+def small_polar(seed=0, n_az=12, n_bins=80, empty_rows=()):
+    rng = np.random.default_rng(seed)
+    az = -np.pi + (np.arange(n_az) + 0.5) * (2 * np.pi / n_az)
+    r = (np.arange(n_bins) + 0.5) * 0.16
+    I = rng.uniform(0, 5, (n_az, n_bins))
+    centres = rng.integers(10, 60, n_az)
+    for a in range(n_az):
+        if a in empty_rows:
+            I[a] = 0.0
+            continue
+        I[a, centres[a] - 2:centres[a] + 3] += np.array([.6, .8, 1, .8, .6]) * rng.uniform(20, 80)
+    raw = np.zeros((n_az, n_bins, 4), np.float32)
+    raw[..., 0] = r[None] * np.cos(az)[:, None]
+    raw[..., 1] = r[None] * np.sin(az)[:, None]
+    raw[..., 3] = I
+    return raw, centres
+
+
+def test_oracle_filter_semantics(built):
+    raw, centres = small_polar()
+    fp = po.filter_params()
+    cnt, pts, polar, peaks = po.filter_scan(raw.reshape(-1, 4), fp)
+    n_az, n_bins = raw.shape[:2]
+    assert len(peaks) == n_az - 1                      # the last azimuth is never flushed (:61-70)
+    flat = raw.reshape(-1, 4)
+    for a in range(n_az - 1):
+        rng_a = np.hypot(flat[a * n_bins:(a + 1) * n_bins, 0], flat[a * n_bins:(a + 1) * n_bins, 1])
+        valid = (rng_a > 0.6) & (rng_a < 12.0)
+        m = np.argmax(np.where(valid, flat[a * n_bins:(a + 1) * n_bins, 3], -1))
+        assert np.isclose(peaks[a][1], rng_a[m]) and np.isclose(peaks[a][2], flat[a * n_bins + m, 3])
+    assert cnt == len(pts) and (pts[:, 3] > 6.0).all()   # min_intensity gate
+    d = np.hypot(pts[:, 0], pts[:, 1])
+    assert (d > 0.6).all() and (d < 12.0).all() and np.allclose(polar[:, 1], d)
+    # a sensor->base offset is applied to every kept point
+    T = np.eye(4, dtype=np.float32)[:3].copy(); T[0, 3] = 0.5; T[1, 3] = -0.25
+    cnt2, pts2, _, _ = po.filter_scan(raw.reshape(-1, 4), po.filter_params(sensor_to_base=T))
+    assert cnt2 == cnt and np.allclose(pts2[:, 0], pts[:, 0] + 0.5) and np.allclose(pts2[:, 1], pts[:, 1] - 0.25)
+
+
+def test_oracle_filter_empty_azimuth_quirks(built):
+    # azimuth 0 empty: the first boundary still pushes index 0 with intensity 0; later empty azimuths re-use
+    # the previous maximum and push nothing
+    raw, _ = small_polar(1, empty_rows=(0, 4))
+    cnt, pts, polar, peaks = po.filter_scan(raw.reshape(-1, 4), po.filter_params())
+    assert len(peaks) == raw.shape[0] - 1 - 1          # rows 0..10 flushed, row 4 contributes nothing, row 0 pushes idx 0
+    assert peaks[0][2] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(12, 80), (400, 3000)])
+def test_hip_filter_matches_oracle(built, shape):
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    if shape[0] == 12:
+        scans = np.stack([small_polar(s, empty_rows=(0, 4) if s == 1 else ())[0] for s in range(3)])
+    else:
+        w = synth.make_world()
+        tr = synth.make_trajectory(3000, 2)
+        scans = np.stack([synth.make_polar_scan(w, tr[i], 50 + i) for i in range(2)])   # BASELINE config 5 shape
+    n_scans, n_az, n_bins = scans.shape[:3]
+    T = np.eye(4, dtype=np.float32)[:3].copy(); T[0, 3] = 0.3
+    fp, ofp = host.filter_params(sensor_to_base=T), po.filter_params(sensor_to_base=T)
+    pitch = 8192
+    out = torch.zeros((n_scans, pitch, 4), dtype=torch.float32, device=dev)
+    polar = torch.zeros((n_scans, pitch, 2), dtype=torch.float32, device=dev)
+    peaks = torch.zeros((n_scans, n_az, 3), dtype=torch.float32, device=dev)
+    counts = torch.zeros(n_scans, dtype=torch.int32, device=dev)
+    pcounts = torch.zeros(n_scans, dtype=torch.int32, device=dev)
+    status = torch.zeros(n_scans, dtype=torch.int32, device=dev)
+    host.filter_scan_batch(ctx, torch.from_numpy(scans).to(dev), fp, out, counts, status, polar, peaks, pcounts)
+    ctx.synchronize()
+    assert status.cpu().tolist() == [0] * n_scans
+    for s in range(n_scans):
+        cnt, pts, pol, pk = po.filter_scan(scans[s].reshape(-1, 4), ofp)
+        assert counts[s].item() == cnt and pcounts[s].item() == len(pk)
+        assert np.array_equal(out[s, :cnt].cpu().numpy().view(np.uint32), pts.view(np.uint32))        # bit exact points
+        assert np.array_equal(polar[s, :cnt, 1].cpu().numpy(), pol[:, 1])
+        assert np.allclose(polar[s, :cnt, 0].cpu().numpy(), pol[:, 0], atol=1e-6)                        # atan2f: libm vs ocml
+        g = peaks[s, :len(pk)].cpu().numpy()
+        assert np.array_equal(g[:, 1:], pk[:, 1:]) and np.allclose(g[:, 0], pk[:, 0], atol=1e-6)
+    # filtered points feed the NDT build directly (ragged counts)
+    maps = R.Maps(ctx, n_scans, R.indoor_map_params(), 1024, with_grid=True)
+    R.ndt_build_batch(ctx, out[:, :6144].contiguous(), R.indoor_cluster_params(), maps, n_points=counts)
+    ctx.synchronize()
+    from util import cells_equal, oracle_scan_map
+    for s in range(n_scans):
+        cnt, pts, _, _ = po.filter_scan(scans[s].reshape(-1, 4), ofp)
+        om = oracle_scan_map(pts, cap=1024)
+        assert cells_equal(maps.download(s)[0], om.cells())
+
+
+@pytest.mark.gpu
+def test_hip_filter_flags_unorganised_input(built):
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    raw, _ = small_polar(2)
+    raw[3, 40, :2] = raw[7, 40, :2]                       # a point of another azimuth inside row 3
+    out = torch.zeros((1, 4096, 4), dtype=torch.float32, device=dev)
+    counts = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    host.filter_scan_batch(ctx, torch.from_numpy(raw[None]).to(dev), host.filter_params(), out, counts, status)
+    ctx.synchronize()
+    assert status.item() == 1                              # loud, never a silently different result
