@@ -12,6 +12,7 @@
 // Everything numeric happens on the GPU inside librandt_hip.so; there is no CPU fallback.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -76,6 +77,7 @@ struct NDTMatcherParameters {
   int gnc_steps = 3;
   double loss_function_convexity = -2.0, loss_function_scale = 1.5, gnc_control_parameter_divisor = 1.3;
   int max_iteration = 200;
+  int smoothing_steps = 3;
   int n_results_kd_lookup = 4;
   double ndt_weight = 5.0e4;
   bool use_intensity_as_dimension = true, optimize_on_manifold = true, lookup_mahalanobis = true;
@@ -115,6 +117,18 @@ class Cell {
 
  private:
   randt_cell c_{};
+};
+
+// rc::navigation::ndt::State (include/ndt_slam/trajectory_representation.h:12-22)
+struct State {
+  SE2d pose;
+  std::array<double, 2> pos{0.0, 0.0};
+  double rot = 0.0;
+  std::array<double, 2> lin_vel{0.0, 0.0};
+  double rot_vel = 0.0;
+  std::array<double, 2> lin_acc{0.0, 0.0};
+  double imu_bias = 0.0;
+  double stamp = 0.0;
 };
 
 // rc::navigation::ndt::Map: one device-resident NDT map.
@@ -268,10 +282,78 @@ class Matcher {
     return r.cost;
   }
 
-  void resetMatcher() {}  // imu_constraints_.clear() (ndt_matcher.cpp:18-20): no IMU state on this path
+  void resetMatcher() { imu_constraints_.clear(); }  // ndt_matcher.cpp:18-20
+
+  // void Matcher::predictTransform(const double& initial_angle_guess, const double& stamp,
+  //                                std::vector<State>& trajectory)            (ndt_matcher.cpp:22-59)
+  void predictTransform(const double& initial_angle_guess, const double& stamp, std::vector<State>& trajectory) {
+    if (trajectory.empty()) return;
+    randt_state last = toAbi(trajectory.back()), next;
+    randt_predict_state(&last, stamp, &next);
+    trajectory.push_back(fromAbi(next));
+    imu_constraints_.push_back(initial_angle_guess);
+  }
+
+  // void Matcher::estimateTransformCeres(Sophus::SE2d& trans, std::vector<State>& trajectory,
+  //      const double& initial_angle_guess, const double& stamp, const std::deque<Map>& fixed_ndts,
+  //      const std::deque<Map>& moving_ndts)                                   (ndt_matcher.cpp:322-424)
+  // The maps of one call must live in the same device batch: pass the MapBatch that owns them and
+  // their slot indices (a std::deque<Map> of the reference becomes a vector of slots).
+  void estimateTransformCeres(SE2d& trans, std::vector<State>& trajectory, const double& /*initial_angle_guess*/,
+                              const double& /*stamp*/, randt_maps* fixed_batch, const std::vector<int32_t>& fixed_slots,
+                              randt_maps* moving_batch, const std::vector<int32_t>& moving_slots, randt_ctx* ctx,
+                              const randt_window_params& wp, randt_result* stats = nullptr) {
+    if (trajectory.size() < 2) return;
+    const size_t S = std::min(trajectory.size() - 1, static_cast<size_t>(parameters_.smoothing_steps));  // :343
+    randt_matcher_params mp;
+    randt_matcher_params_default(&mp);
+    mp.loss_scale = mp.mu_scale = parameters_.loss_function_scale;
+    mp.loss_alpha = parameters_.loss_function_convexity;
+    mp.gnc_divisor = parameters_.gnc_control_parameter_divisor;
+    mp.gnc_steps = parameters_.gnc_steps;
+    mp.max_iterations = parameters_.max_iteration;
+    mp.n_neighbours = parameters_.n_results_kd_lookup;
+    mp.lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
+    mp.use_intensity = parameters_.use_intensity_as_dimension ? 1 : 0;
+    mp.parameterization = RANDT_PARAM_MANIFOLD;
+    std::vector<randt_state> st(S + 1);
+    for (size_t j = 0; j <= S; ++j) st[j] = toAbi(trajectory.end()[-(long)(S + 1) + (long)j]);
+    std::vector<int32_t> mv(moving_slots.end() - (long)S, moving_slots.end());  // moving_ndts.end()[-i], i = S..1
+    std::vector<double> imu;
+    if (wp.use_imu && imu_constraints_.size() > S)
+      for (size_t i = S; i >= 1; --i) imu.push_back(imu_constraints_.end()[-(long)i - 1]);  // sic: one step older (:360)
+    int rejected = 0;
+    randt_result r{};
+    int rc = randt_register_window(ctx, fixed_batch, fixed_slots.data(), (int)fixed_slots.size(), moving_batch, mv.data(), st.data(),
+                                   (int)st.size(), imu.empty() ? nullptr : imu.data(), &mp, &wp, trans.data(), &rejected, &r);
+    if (stats) *stats = r;
+    if (rc != RANDT_OK) {
+      std::cout << "WARNING: window registration failed: " << randt_status_string(rc) << std::endl;
+      return;
+    }
+    for (size_t j = 0; j <= S; ++j) trajectory.end()[-(long)(S + 1) + (long)j] = fromAbi(st[j]);
+  }
+
+  static randt_state toAbi(const State& s) {
+    randt_state a{};
+    std::copy(s.pose.d, s.pose.d + 4, a.pose);
+    a.pos[0] = s.pos[0]; a.pos[1] = s.pos[1]; a.rot = s.rot;
+    a.lin_vel[0] = s.lin_vel[0]; a.lin_vel[1] = s.lin_vel[1]; a.rot_vel = s.rot_vel;
+    a.lin_acc[0] = s.lin_acc[0]; a.lin_acc[1] = s.lin_acc[1]; a.imu_bias = s.imu_bias; a.stamp = s.stamp;
+    return a;
+  }
+  static State fromAbi(const randt_state& a) {
+    State s;
+    std::copy(a.pose, a.pose + 4, s.pose.d);
+    s.pos = {a.pos[0], a.pos[1]}; s.rot = a.rot;
+    s.lin_vel = {a.lin_vel[0], a.lin_vel[1]}; s.rot_vel = a.rot_vel;
+    s.lin_acc = {a.lin_acc[0], a.lin_acc[1]}; s.imu_bias = a.imu_bias; s.stamp = a.stamp;
+    return s;
+  }
 
  private:
   NDTMatcherParameters parameters_;
+  std::vector<double> imu_constraints_;
 };
 
 }  // namespace randt

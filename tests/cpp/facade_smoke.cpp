@@ -62,5 +62,38 @@ int main() {
   SE2d keep(0.2, 1.0, 2.0);
   matcher.estimateLoopConstraint(keep, submap, empty, 2, true, 1.5);
   const bool kept = keep.d[2] == 1.0 && keep.d[3] == 2.0;
-  return (ok && kept) ? 0 : 2;
+  // fixed-lag odometry through the facade: predictTransform + estimateTransformCeres on a 3-scan drive
+  bool win_ok = true;
+  {
+    randt_map_params rmp{mp.size_x, mp.size_y, mp.resolution, 0.0, 0.0, mp.max_neighbour_manhattan_distance, mp.min_points_per_cell, 0};
+    randt_maps *fixed_batch = nullptr, *scan_batch = nullptr;
+    if (randt_maps_create(ctx->get(), 1, &rmp, 10000, 1, &fixed_batch) || randt_maps_create(ctx->get(), 4, &rmp, 512, 0, &scan_batch)) return 4;
+    randt_cluster_params cp{rp.n_clusters, (float)rp.max_range};
+    // submap = the blob scene at identity; scans seen from a sensor moving +0.25 m in x per step
+    randt_ndt_build(ctx->get(), fixed_pts.data(), (int)fixed_pts.size() / 4, 4, 3, &cp, scan_batch, 0);
+    const double id[4] = {1, 0, 0, 0};
+    randt_maps_merge(fixed_batch, 0, scan_batch, 0, 1, id);
+    std::vector<State> trajectory(1);
+    trajectory[0].lin_vel = {0.8, 0.0};
+    randt_window_params wp{};
+    const double diag[8] = {1, 1, 1, 1, 3, 0.1, 20, 60};
+    for (int i = 0; i < 8; ++i) wp.motion_sqrtI[i * 8 + i] = 25.0 * diag[i];
+    wp.ndt_weight = 5.0e4; wp.pose_reject_translation = 2.0; wp.pose_reject_rotation = 2.0;
+    wp.smoothing_steps = 3; wp.use_constant_velocity_model = 1;
+    SE2d cur;
+    std::vector<int32_t> window;
+    for (int step = 1; step <= 3; ++step) {
+      std::vector<float> pts;
+      for (size_t p = 0; p < fixed_pts.size(); p += 4) pts.insert(pts.end(), {fixed_pts[p] - 0.25f * step, fixed_pts[p + 1], 0.f, fixed_pts[p + 3]});
+      randt_ndt_build(ctx->get(), pts.data(), (int)pts.size() / 4, 4, 3, &cp, scan_batch, step);
+      window.push_back(step);
+      matcher.predictTransform(0.0, 0.25 * step, trajectory);
+      matcher.estimateTransformCeres(cur, trajectory, 0.0, 0.25 * step, fixed_batch, {0}, scan_batch, window, ctx->get(), wp);
+      std::printf("step %d pose %.4f %.4f %.4f vel %.3f\n", step, cur.d[2], cur.d[3], cur.angle(), trajectory.back().lin_vel[0]);
+      win_ok = win_ok && std::fabs(cur.d[2] - 0.25 * step) < 0.03 && std::fabs(cur.d[3]) < 0.03 && std::fabs(cur.angle()) < 0.01;
+    }
+    randt_maps_destroy(fixed_batch);
+    randt_maps_destroy(scan_batch);
+  }
+  return (ok && kept && win_ok) ? 0 : 2;
 }
