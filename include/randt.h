@@ -246,6 +246,17 @@ int randt_scan_register_batch_dev(randt_ctx* ctx, const float* d_points, int n_s
 int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving,
                         int moving_idx, const randt_matcher_params* mp, double h_pose4[4], randt_result* h_result);
 
+/* ------------------------------------------------------------------ CS divergence (f-2) ------ */
+/* Map::calculateCSDivergence (src/ndt_representation/ndt_map.cpp:42-99) for a batch of pairs: pair p =
+ * fixed map d_fixed_idx[p] (must lie in [fixed_first, fixed_first + fixed_count)) vs moving map
+ * (moving_first + p), the moving map first transformed by d_pose4[p] like local_fuser.cpp:338
+ * (d_pose4 may be NULL = already transformed).  The fixed maps' self terms are computed once per map.
+ * d_out[p] = -log(interaction) + 0.5 log(fixed term) + 0.5 log(moving term); d_terms (nullable):
+ * the three sums per pair. */
+int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed_first, int fixed_count,
+                                  const int32_t* d_fixed_idx, const randt_maps* moving, int moving_first, int n_pairs,
+                                  const double* d_pose4, double* d_out, double* d_terms);
+
 /* ------------------------------------------------------------------ scan filter (f-1) -------- */
 /* RadarPreprocessorParameters used by filterScan + initial_transform_radar_baselink_ as a row-major
  * 3x4 matrix (radar_preprocessor.cpp:7-28,124). */

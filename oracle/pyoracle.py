@@ -137,6 +137,8 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
     L.orc_se2_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_num_threads.restype = C.c_int
+    L.orc_cs_divergence.restype = C.c_double
+    L.orc_cs_divergence.argtypes = [P(OrcMap), P(OrcMap), C.c_void_p]
     L.orc_filter_scan.restype = C.c_int
     L.orc_filter_scan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(FilterParams), C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_int, P(C.c_int)]
@@ -452,3 +454,10 @@ def filter_scan(raw, fp, ioff=3, capacity=None):
     npk = C.c_int(0)
     cnt = lib().orc_filter_scan(_ptr(raw), n, stride, ioff, C.byref(fp), _ptr(pts), _ptr(polar), capacity, _ptr(peaks), n, C.byref(npk))
     return cnt, pts[:max(cnt, 0)], polar[:max(cnt, 0)], peaks[:npk.value]
+
+
+# ------------------------------------------------------------------ f-2 CS divergence ----------
+def cs_divergence(fixed, moving):
+    terms = np.zeros(3)
+    v = lib().orc_cs_divergence(fixed._p, moving._p, _ptr(terms))
+    return v, terms

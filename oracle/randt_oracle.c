@@ -1808,3 +1808,68 @@ int orc_filter_scan(const float* raw, int n, int stride, int ioff, const orc_fil
 #undef PZ
 #undef PI_
 }
+
+/* ============================================================ f-2: CS divergence ========== */
+
+static void cell_full3f(const orc_cell* c, float S[3][3]) {
+  S[0][0] = c->cov[0]; S[0][1] = S[1][0] = c->cov[1]; S[0][2] = S[2][0] = c->cov[2];
+  S[1][1] = c->cov[3]; S[1][2] = S[2][1] = c->cov[4]; S[2][2] = c->cov[5];
+}
+/* Eigen bruteforce_det3_helper order */
+static float det3f(float m[3][3]) {
+#define H3(a, b, c) (m[0][a] * (m[1][b] * m[2][c] - m[1][c] * m[2][b]))
+  return H3(0, 1, 2) - H3(1, 0, 2) + H3(2, 0, 1);
+#undef H3
+}
+/* Eigen 3.3 cofactor inverse (see mahalanobis3f) */
+static void inv3f(float S[3][3], float inv[3][3]) {
+#define COF(i, j) (S[((i) + 1) % 3][((j) + 1) % 3] * S[((i) + 2) % 3][((j) + 2) % 3] - S[((i) + 1) % 3][((j) + 2) % 3] * S[((i) + 2) % 3][((j) + 1) % 3])
+  float c0 = COF(0, 0), c1 = COF(1, 0), c2 = COF(2, 0);
+  float det = (c0 * S[0][0] + c1 * S[1][0]) + c2 * S[2][0];
+  float invdet = 1.0f / det;
+  inv[0][0] = c0 * invdet; inv[0][1] = c1 * invdet; inv[0][2] = c2 * invdet;
+  inv[1][0] = COF(0, 1) * invdet; inv[1][1] = COF(1, 1) * invdet; inv[1][2] = COF(2, 1) * invdet;
+  inv[2][0] = COF(0, 2) * invdet; inv[2][1] = COF(1, 2) * invdet; inv[2][2] = COF(2, 2) * invdet;
+#undef COF
+}
+/* (0.5 / sqrt(pi^2 det(Sf+Sq))) * exp(-0.5 d^T (Sf+Sq)^-1 d), ndt_map.cpp:60-64 */
+static double cs_pair(const orc_cell* f, const orc_cell* q) {
+  float Sf[3][3], Sq[3][3], M[3][3], inv[3][3];
+  cell_full3f(f, Sf);
+  cell_full3f(q, Sq);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M[i][j] = Sf[i][j] + Sq[i][j];
+  float d[3] = {f->mean[0] - q->mean[0], f->mean[1] - q->mean[1], f->mean[2] - q->mean[2]};
+  inv3f(M, inv);
+  float row[3];
+  for (int j = 0; j < 3; ++j) row[j] = (d[0] * inv[0][j] + d[1] * inv[1][j]) + d[2] * inv[2][j];
+  const double e = (double)((row[0] * d[0] + row[1] * d[1]) + row[2] * d[2]);
+  return (0.5 / sqrt(M_PI * M_PI * (double)det3f(M))) * exp(-0.5 * e);
+}
+
+double orc_cs_divergence(const orc_map* fixed, const orc_map* moving, double terms[3]) {
+  double interaction = 0.0, fixed_term = 0.0, moving_term = 0.0;
+  for (int fi = 0; fi < fixed->n_cells; ++fi) {
+    float Sf[3][3], inv[3][3];
+    cell_full3f(&fixed->cells[fi], Sf);
+    if ((double)det3f(Sf) < 0.00001) continue;
+    for (int qi = 0; qi < moving->n_cells; ++qi) interaction += cs_pair(&fixed->cells[fi], &moving->cells[qi]);
+    inv3f(Sf, inv);
+    fixed_term += (double)sqrtf(det3f(inv)) / (2 * M_PI);
+    for (int qi = 0; qi < fi; ++qi) fixed_term += 2 * cs_pair(&fixed->cells[fi], &fixed->cells[qi]);
+  }
+  for (int fi = 0; fi < moving->n_cells; ++fi) {
+    float Sf[3][3], inv[3][3];
+    cell_full3f(&moving->cells[fi], Sf);
+    if ((double)det3f(Sf) < 0.00001) continue;
+    inv3f(Sf, inv);
+    moving_term += (double)sqrtf(det3f(inv)) / (2 * M_PI);
+    for (int qi = 0; qi < fi; ++qi) moving_term += 2 * cs_pair(&moving->cells[fi], &moving->cells[qi]);
+  }
+  if (terms) {
+    terms[0] = interaction;
+    terms[1] = fixed_term;
+    terms[2] = moving_term;
+  }
+  return -log(interaction) + 0.5 * log(fixed_term) + 0.5 * log(moving_term);
+}

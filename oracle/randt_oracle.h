@@ -209,6 +209,13 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
                         const double* imu, const orc_matcher_params* p, const orc_window_params* wp, double trans4[4],
                         orc_solve_stats* st);
 
+/* ---------------------------------------------------------------- f-2: CS divergence ------- */
+/* Map::calculateCSDivergence (src/ndt_representation/ndt_map.cpp:42-99) of fixed vs moving (the
+ * moving map already transformed, local_fuser.cpp:338-339).  SPEC DECISION: the reference's three
+ * accumulators are uninitialised (:43-46); they start at 0 here.  terms (nullable): interaction,
+ * fixed, moving. */
+double orc_cs_divergence(const orc_map* fixed, const orc_map* moving, double terms[3]);
+
 /* ---------------------------------------------------------------- f-1: filterScan ---------- */
 typedef struct orc_filter_params {
   float min_range, max_range, min_intensity, beam_distance_increment_threshold;

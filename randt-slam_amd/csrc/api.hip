@@ -458,6 +458,20 @@ int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
 }
 
 
+int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed_first, int fixed_count,
+                                  const int32_t* d_fixed_idx, const randt_maps* moving, int moving_first, int n_pairs,
+                                  const double* d_pose4, double* d_out, double* d_terms) {
+  if (!ctx || !range_ok(fixed, fixed_first, fixed_count) || fixed_count < 1 || n_pairs < 0 || !range_ok(moving, moving_first, n_pairs))
+    return RANDT_ERR_INVALID;
+  if (n_pairs == 0) return RANDT_OK;
+  if (!d_out) return RANDT_ERR_INVALID;
+  const int max_tiles = (fixed->v.cap + 255) / 256;
+  int rc = ensure_ws(ctx, sizeof(double) * (size_t)fixed_count * max_tiles + 256);
+  if (rc) return rc;
+  return launch_cs_divergence(ctx, fixed->v, fixed_first, fixed_count, d_fixed_idx, moving->v, moving_first, n_pairs, d_pose4,
+                              (double*)ctx->ws, d_out, d_terms);
+}
+
 int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans, int n_azimuths, int n_bins,
                                 int stride_floats, int intensity_index, const randt_filter_params* fp,
                                 float* d_out_points, int pitch_out, int32_t* d_out_counts, float* d_out_polar,

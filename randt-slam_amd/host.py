@@ -322,3 +322,11 @@ def filter_scan_batch(ctx, raw, fp, out_points, out_counts, status, out_polar=No
     ctx._check(ctx._lib.randt_filter_scan_batch_dev(ctx._h, _dptr(raw), n_scans, n_az, n_bins, stride, ioff, C.byref(fp),
                                                     _dptr(out_points), int(out_points.shape[1]), _dptr(out_counts), _dptr(out_polar),
                                                     _dptr(peaks), _dptr(peak_counts), _dptr(status)), "randt_filter_scan_batch_dev")
+
+
+# ------------------------------------------------------------------ CS divergence (f-2) -------------
+def cs_divergence_batch(ctx, fixed, fixed_first, fixed_count, fixed_idx, moving, moving_first, n_pairs, pose4, out, terms=None):
+    """randt_cs_divergence_batch_dev (Map::calculateCSDivergence after transformMap)."""
+    ctx._check(ctx._lib.randt_cs_divergence_batch_dev(ctx._h, fixed._h, fixed_first, fixed_count, _dptr(fixed_idx), moving._h,
+                                                      moving_first, n_pairs, _dptr(pose4), _dptr(out), _dptr(terms)),
+               "randt_cs_divergence_batch_dev")
