@@ -246,6 +246,27 @@ int randt_scan_register_batch_dev(randt_ctx* ctx, const float* d_points, int n_s
 int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving,
                         int moving_idx, const randt_matcher_params* mp, double h_pose4[4], randt_result* h_result);
 
+/* ------------------------------------------------------------------ correlative search (f-3) - */
+/* csm_* members of NDTMatcherParameters (ndt_slam_parameters.h:76-83). */
+typedef struct randt_bnb_params {
+  double csm_window_linear, csm_window_angular, csm_linear_step, csm_cost_threshold, csm_max_px_accurate_range;
+  int32_t csm_n_iter, reserved;
+} randt_bnb_params;
+/* ceres::Problem::Evaluate with the loss applied (ndt_matcher.cpp:561-576) at n_poses poses for one
+ * frozen correspondence set d_corr (cell_capacity(moving) x k): d_cost[p] = sum 1/2 rho(s),
+ * rho = BarronLoss(scale, loss_alpha) (mu = 1, unscaled, :517).  d_n_res (nullable): residual count. */
+int randt_eval_cost_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
+                              const int32_t* d_corr, const randt_matcher_params* mp, double scale, const double* d_poses4,
+                              int n_poses, double* d_cost, int32_t* d_n_res);
+/* Matcher::estimateTransformGlobalBNB (ndt_matcher.cpp:495-608): association with 4 neighbours at the
+ * guess, then the breadth-first coarse-to-fine pose grid; every level is evaluated in one launch.
+ * h_trans4 in: guess, out: best pose (identity if no pose is below csm_cost_threshold, like the
+ * reference).  *min_cost_out: the reference's return value; *n_evals (nullable): poses evaluated. */
+int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
+                        const randt_matcher_params* mp, const randt_bnb_params* bp, double scale,
+                        double search_window_size_linear, double search_window_size_angular, double h_trans4[4],
+                        double* min_cost_out, int* n_evals);
+
 /* ------------------------------------------------------------------ CS divergence (f-2) ------ */
 /* Map::calculateCSDivergence (src/ndt_representation/ndt_map.cpp:42-99) for a batch of pairs: pair p =
  * fixed map d_fixed_idx[p] (must lie in [fixed_first, fixed_first + fixed_count)) vs moving map

@@ -63,6 +63,12 @@ class FilterParams(C.Structure):
                 ("beam_distance_increment_threshold", C.c_float), ("sensor_to_base", C.c_float * 12)]
 
 
+class BnbParams(C.Structure):
+    _fields_ = [("csm_window_linear", C.c_double), ("csm_window_angular", C.c_double), ("csm_linear_step", C.c_double),
+                ("csm_cost_threshold", C.c_double), ("csm_max_px_accurate_range", C.c_double), ("csm_n_iter", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class State(C.Structure):
     _fields_ = [("pose", C.c_double * 4), ("pos", C.c_double * 2), ("rot", C.c_double), ("lin_vel", C.c_double * 2),
                 ("rot_vel", C.c_double), ("lin_acc", C.c_double * 2), ("imu_bias", C.c_double), ("stamp", C.c_double)]
@@ -137,6 +143,11 @@ def lib():
         getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
     L.orc_se2_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_num_threads.restype = C.c_int
+    L.orc_eval_cost_batch.argtypes = [P(OrcMap), P(OrcMap), C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int,
+                                      C.c_void_p, P(C.c_int)]
+    L.orc_search_global_bnb.restype = C.c_double
+    L.orc_search_global_bnb.argtypes = [P(OrcMap), P(OrcMap), P(MatcherParams), P(BnbParams), C.c_double, C.c_double, C.c_double,
+                                        C.c_void_p, P(C.c_int)]
     L.orc_cs_divergence.restype = C.c_double
     L.orc_cs_divergence.argtypes = [P(OrcMap), P(OrcMap), C.c_void_p]
     L.orc_filter_scan.restype = C.c_int
@@ -461,3 +472,26 @@ def cs_divergence(fixed, moving):
     terms = np.zeros(3)
     v = lib().orc_cs_divergence(fixed._p, moving._p, _ptr(terms))
     return v, terms
+
+
+# ------------------------------------------------------------------ f-3 correlative search -----
+def bnb_params(window_linear=4.5, window_angular=0.45, linear_step=0.4, cost_threshold=0.82, max_px_accurate_range=4.0, n_iter=2):
+    """config/ndt_radar_slam_base_parameters.yaml:50-56."""
+    return BnbParams(window_linear, window_angular, linear_step, cost_threshold, max_px_accurate_range, n_iter, 0)
+
+
+def eval_cost_batch(fixed, moving, corr, poses4, scale=1.5, alpha=-2.0, use_intensity=1):
+    corr = np.ascontiguousarray(corr, dtype=np.int32)
+    poses4 = np.ascontiguousarray(poses4, dtype=np.float64).reshape(-1, 4)
+    cost = np.zeros(len(poses4))
+    n = C.c_int(0)
+    lib().orc_eval_cost_batch(fixed._p, moving._p, _ptr(corr), corr.shape[1], use_intensity, scale, alpha, _ptr(poses4), len(poses4),
+                              _ptr(cost), C.byref(n))
+    return cost, n.value
+
+
+def search_global_bnb(fixed, moving, params, bp, trans4, scale=1.5, window_linear=4.5, window_angular=0.45):
+    t = np.array(trans4, dtype=np.float64)
+    n = C.c_int(0)
+    mc = lib().orc_search_global_bnb(fixed._p, moving._p, C.byref(params), C.byref(bp), scale, window_linear, window_angular, _ptr(t), C.byref(n))
+    return mc, t, n.value

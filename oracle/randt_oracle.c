@@ -1873,3 +1873,127 @@ double orc_cs_divergence(const orc_map* fixed, const orc_map* moving, double ter
   }
   return -log(interaction) + 0.5 * log(fixed_term) + 0.5 * log(moving_term);
 }
+
+/* ============================================================ f-3: correlative search ===== */
+
+void orc_eval_cost_batch(const orc_map* fixed, const orc_map* moving, const int32_t* corr, int k, int use_intensity,
+                         double scale, double alpha, const double* poses4, int n_poses, double* cost, int* n_res) {
+  const int d = use_intensity ? 3 : 2;
+  int n = 0;
+  for (int i = 0; i < moving->n_cells * k; ++i) n += corr[i] >= 0;
+  if (n_res) *n_res = n;
+  for (int p = 0; p < n_poses; ++p) {
+    double total = 0.0;
+    for (int i = 0; i < moving->n_cells; ++i)
+      for (int j = 0; j < k; ++j) {
+        const int32_t ci = corr[(size_t)i * k + j];
+        if (ci < 0) continue;
+        double mm[3], fm[3], mc[9], fc[9];
+        for (int e = 0; e < d; ++e) {
+          mm[e] = (double)moving->cells[i].mean[e];
+          fm[e] = (double)fixed->cells[ci].mean[e];
+        }
+        cell_cov_full(&moving->cells[i], d, mc);
+        cell_cov_full(&fixed->cells[ci], d, fc);
+        const double r = orc_ndt_residual(d, ORC_PARAM_AMBIENT4, poses4 + 4 * (size_t)p, mm, mc, fm, fc, NULL);
+        double rho[3];
+        orc_barron_scaled(r * r, scale, alpha, 1.0, 1.0, rho); /* BarronLoss(scale, alpha): b = a^2 */
+        total += 0.5 * rho[0];
+      }
+    cost[p] = total;
+  }
+}
+
+typedef struct { double pose[4]; int level; } bnb_node;
+
+static void se2_from_angle(double a, double tx, double ty, double out[4]) {
+  double c = cos(a), s = sin(a);
+  so2_normalize(&c, &s);
+  out[0] = c; out[1] = s; out[2] = tx; out[3] = ty;
+}
+/* std::vector<float>(matrix.data(), ...) of the 3x3 homogeneous matrix, column-major */
+static void pose_key(const double p[4], float key[9]) {
+  key[0] = (float)p[0]; key[1] = (float)p[1]; key[2] = 0.f;
+  key[3] = (float)(-p[1]); key[4] = (float)p[0]; key[5] = 0.f;
+  key[6] = (float)p[2]; key[7] = (float)p[3]; key[8] = 1.f;
+}
+
+double orc_search_global_bnb(const orc_map* fixed, const orc_map* moving, const orc_matcher_params* p, const orc_bnb_params* bp,
+                             double scale, double swl, double swa, double trans4[4], int* n_evals) {
+  swl = fmin(swl, bp->csm_window_linear);
+  swa = fmin(swa, bp->csm_window_angular);
+  const int k = 4; /* addNDTFactor(..., 4) (ndt_matcher.cpp:520) */
+  int32_t* corr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(moving->n_cells > 0 ? moving->n_cells : 1) * k);
+  orc_associate(fixed, moving, trans4, k, p->lookup_mahalanobis, p->use_intensity, corr);
+  const double linear_step = bp->csm_linear_step, max_range = bp->csm_max_px_accurate_range;
+  const double angular_step = acos(1 - ((linear_step * linear_step) / (2 * max_range * max_range)));
+  const double cost_threshold = bp->csm_cost_threshold;
+  const size_t n_iter = (size_t)bp->csm_n_iter;
+  const double initial_linear_step = pow(2, (double)n_iter - 1) * linear_step;
+  const double initial_angular_step = angular_step;
+  double min_cost = 100000.0;
+  size_t cap = 1024, nq = 0, head = 0, nk = 0;
+  bnb_node* q = (bnb_node*)malloc(sizeof(bnb_node) * cap);
+  float* keys = (float*)malloc(sizeof(float) * 9 * cap);
+#define PUSH(P4, LVL)                                                   \
+  do {                                                                  \
+    if (nq == cap) {                                                    \
+      cap *= 2;                                                         \
+      q = (bnb_node*)realloc(q, sizeof(bnb_node) * cap);                \
+      keys = (float*)realloc(keys, sizeof(float) * 9 * cap);            \
+    }                                                                   \
+    memcpy(q[nq].pose, (P4), sizeof(double) * 4);                       \
+    q[nq].level = (LVL);                                                \
+    ++nq;                                                               \
+  } while (0)
+  for (double tx = -swl / 2.0; tx <= swl / 2.0; tx += initial_linear_step)
+    for (double ty = -swl / 2.0; ty <= swl / 2.0; ty += initial_linear_step)
+      for (double a = -swa / 2.0; a < swa / 2.0; a += initial_angular_step) {
+        double d4[4], cur[4];
+        se2_from_angle(a, tx, ty, d4);
+        orc_se2_mul(trans4, d4, cur);
+        PUSH(cur, 1);
+        pose_key(cur, keys + 9 * nk);
+        ++nk;
+      }
+  double best[4] = {1.0, 0.0, 0.0, 0.0}; /* Sophus::SE2d best_trans: identity if nothing qualifies */
+  int evals = 0, n_res = 0;
+  while (head < nq) {
+    double cost;
+    orc_eval_cost_batch(fixed, moving, corr, k, p->use_intensity, scale, p->loss_alpha, q[head].pose, 1, &cost, &n_res);
+    ++evals;
+    const double current_cost = cost / (double)n_res;
+    const size_t level = (size_t)q[head].level;
+    if (current_cost < cost_threshold) {
+      if (current_cost < min_cost) {
+        memcpy(best, q[head].pose, sizeof(best));
+        min_cost = current_cost;
+      }
+      if (level < n_iter) {
+        const double cls = pow(2.0, (double)level) * linear_step, cas = angular_step;
+        for (double tx = -cls; tx <= cls; tx += cls)
+          for (double ty = -cls; ty <= cls; ty += cls)
+            for (double a = -cas; a <= cas; a += cas) {
+              double d4[4], smp[4];
+              float key[9];
+              se2_from_angle(a, tx, ty, d4);
+              orc_se2_mul(q[head].pose, d4, smp);
+              pose_key(smp, key);
+              int found = 0;
+              for (size_t t = 0; t < nk && !found; ++t) found = memcmp(keys + 9 * t, key, sizeof(key)) == 0 ? 1 : 0;
+              if (!found) {
+                PUSH(smp, (int)level + 1); /* may realloc keys */
+                memcpy(keys + 9 * nk, key, sizeof(key));
+                ++nk;
+              }
+            }
+      }
+    }
+    ++head;
+  }
+#undef PUSH
+  memcpy(trans4, best, sizeof(best));
+  if (n_evals) *n_evals = evals;
+  free(q); free(keys); free(corr);
+  return min_cost;
+}

@@ -209,6 +209,21 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
                         const double* imu, const orc_matcher_params* p, const orc_window_params* wp, double trans4[4],
                         orc_solve_stats* st);
 
+/* ---------------------------------------------------------------- f-3: correlative search -- */
+typedef struct orc_bnb_params {
+  double csm_window_linear, csm_window_angular, csm_linear_step, csm_cost_threshold, csm_max_px_accurate_range;
+  int32_t csm_n_iter, reserved;
+} orc_bnb_params;
+/* problem.Evaluate(apply_loss_function = true) at n_poses poses for one frozen correspondence set
+ * (ndt_matcher.cpp:561-576): cost[p] = sum 1/2 rho(s) with BarronLoss(scale, alpha) (mu = 1, weight 1). */
+void orc_eval_cost_batch(const orc_map* fixed, const orc_map* moving, const int32_t* corr, int k, int use_intensity,
+                         double scale, double alpha, const double* poses4, int n_poses, double* cost, int* n_res);
+/* Matcher::estimateTransformGlobalBNB (ndt_matcher.cpp:495-608).  trans4 in/out; returns min_cost.
+ * n_evals (nullable): number of poses evaluated. */
+double orc_search_global_bnb(const orc_map* fixed, const orc_map* moving, const orc_matcher_params* p, const orc_bnb_params* bp,
+                             double scale, double search_window_linear, double search_window_angular, double trans4[4],
+                             int* n_evals);
+
 /* ---------------------------------------------------------------- f-2: CS divergence ------- */
 /* Map::calculateCSDivergence (src/ndt_representation/ndt_map.cpp:42-99) of fixed vs moving (the
  * moving map already transformed, local_fuser.cpp:338-339).  SPEC DECISION: the reference's three

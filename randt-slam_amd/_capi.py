@@ -55,6 +55,12 @@ class FilterParams(C.Structure):
                 ("beam_distance_increment_threshold", C.c_float), ("sensor_to_base", C.c_float * 12)]
 
 
+class BnbParams(C.Structure):
+    _fields_ = [("csm_window_linear", C.c_double), ("csm_window_angular", C.c_double), ("csm_linear_step", C.c_double),
+                ("csm_cost_threshold", C.c_double), ("csm_max_px_accurate_range", C.c_double), ("csm_n_iter", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class WindowParams(C.Structure):
     _fields_ = [("motion_sqrtI", C.c_double * 64), ("ndt_weight", C.c_double), ("weight_imu", C.c_double),
                 ("weight_imu_bias", C.c_double), ("pose_reject_translation", C.c_double), ("pose_reject_rotation", C.c_double),
@@ -99,6 +105,9 @@ SYMBOLS = {
     "randt_register_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _P(MatcherParams), _V, _V]),
     "randt_scan_register_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ClusterParams), _V, _V, _V, _P(MatcherParams), _V, _V]),
     "randt_register_pair": (_I, [_V, _V, _I, _V, _I, _P(MatcherParams), _V, _V]),
+    "randt_eval_cost_batch_dev": (_I, [_V, _V, _I, _V, _I, _V, _P(MatcherParams), C.c_double, _V, _I, _V, _V]),
+    "randt_search_global": (_I, [_V, _V, _I, _V, _I, _P(MatcherParams), _P(BnbParams), C.c_double, C.c_double, C.c_double, _V,
+                                 _P(C.c_double), _P(_I)]),
     "randt_cs_divergence_batch_dev": (_I, [_V, _V, _I, _I, _V, _V, _I, _I, _V, _V, _V]),
     "randt_filter_scan_batch_dev": (_I, [_V, _V, _I, _I, _I, _I, _I, _P(FilterParams), _V, _I, _V, _V, _V, _V, _V]),
     "randt_predict_state": (_I, [_V, C.c_double, _V]),

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <new>
+#include <vector>
 
 #include "randt_internal.h"
 
@@ -458,6 +459,16 @@ int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
 }
 
 
+int randt_eval_cost_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
+                              const int32_t* d_corr, const randt_matcher_params* mp, double scale, const double* d_poses4,
+                              int n_poses, double* d_cost, int32_t* d_n_res) {
+  if (!ctx || !mp || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1) || n_poses < 0) return RANDT_ERR_INVALID;
+  if (n_poses == 0) return RANDT_OK;
+  if (!d_corr || !d_poses4 || !d_cost || mp->n_neighbours <= 0) return RANDT_ERR_INVALID;
+  return launch_eval_cost(ctx, fixed->v, fixed_idx, moving->v, moving_idx, d_corr, mp->n_neighbours, mp->use_intensity, scale,
+                          mp->loss_alpha, d_poses4, n_poses, d_cost, d_n_res);
+}
+
 int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed_first, int fixed_count,
                                   const int32_t* d_fixed_idx, const randt_maps* moving, int moving_first, int n_pairs,
                                   const double* d_pose4, double* d_out, double* d_terms) {
@@ -487,6 +498,126 @@ int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans,
   if (rc) return rc;
   return launch_filter_scan(ctx, d_raw, n_scans, n_azimuths, n_bins, stride_floats, intensity_index, fp, d_out_points, pitch_out,
                             d_out_counts, d_out_polar, d_peaks, d_peak_counts, d_status, ctx->ws);
+}
+
+// ------------------------------------------------------------------ correlative search (f-3) ------
+namespace {
+struct BnbNode {
+  double pose[4];
+  int level;
+};
+void bnb_pose(double a, double tx, double ty, double* out);
+void bnb_mul(const double* a, const double* b, double* out);
+}  // namespace
+
+int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
+                        const randt_matcher_params* mp, const randt_bnb_params* bp, double scale, double swl, double swa,
+                        double h_trans4[4], double* min_cost_out, int* n_evals) {
+  if (!ctx || !mp || !bp || !h_trans4 || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1)) return RANDT_ERR_INVALID;
+  swl = fmin(swl, bp->csm_window_linear);   // ndt_matcher.cpp:505-506
+  swa = fmin(swa, bp->csm_window_angular);
+  const int k = 4;                          // addNDTFactor(..., 4), :520
+  const double linear_step = bp->csm_linear_step, max_range = bp->csm_max_px_accurate_range;
+  const double angular_step = acos(1 - ((linear_step * linear_step) / (2 * max_range * max_range)));
+  const size_t n_iter = (size_t)bp->csm_n_iter;
+  const double initial_linear_step = pow(2, (double)n_iter - 1) * linear_step;
+  std::vector<BnbNode> level_nodes, next_nodes;
+  std::vector<float> keys;  // std::vector<std::vector<float>> calculated_points, 9 floats each
+  auto key_of = [](const double* p, float* key) {
+    key[0] = (float)p[0]; key[1] = (float)p[1]; key[2] = 0.f;
+    key[3] = (float)(-p[1]); key[4] = (float)p[0]; key[5] = 0.f;
+    key[6] = (float)p[2]; key[7] = (float)p[3]; key[8] = 1.f;
+  };
+  for (double tx = -swl / 2.0; tx <= swl / 2.0; tx += initial_linear_step)
+    for (double ty = -swl / 2.0; ty <= swl / 2.0; ty += initial_linear_step)
+      for (double a = -swa / 2.0; a < swa / 2.0; a += angular_step) {
+        double d4[4];
+        BnbNode nd;
+        bnb_pose(a, tx, ty, d4);
+        bnb_mul(h_trans4, d4, nd.pose);
+        nd.level = 1;
+        level_nodes.push_back(nd);
+        float key[9];
+        key_of(nd.pose, key);
+        keys.insert(keys.end(), key, key + 9);
+      }
+  // association once at the guess (frozen for the whole search, quirk A.7-8)
+  randt_matcher_params amp = *mp;
+  amp.n_neighbours = k;
+  const size_t corr_bytes = sizeof(int32_t) * (size_t)moving->v.cap * k;
+  double min_cost = 100000.0;
+  double best[4] = {1.0, 0.0, 0.0, 0.0};
+  int evals = 0;
+  void* d_blk = nullptr;  // [guess4 | idx | n_res] + corr live in a private allocation (ws is used for poses / costs)
+  RANDT_HIP_CHECK(ctx, hipMalloc(&d_blk, 256 + corr_bytes));
+  double* d_guess = (double*)d_blk;
+  int32_t* d_idx = (int32_t*)((char*)d_blk + 64);
+  int32_t* d_nres = d_idx + 4;
+  int32_t* d_corr = (int32_t*)((char*)d_blk + 256);
+  int32_t h_idx[2] = {fixed_idx, moving_idx};
+  int rc = RANDT_OK;
+  hipError_t e = hipMemcpyAsync(d_guess, h_trans4, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_idx, h_idx, sizeof(h_idx), hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "hipMemcpyAsync", e);
+  if (!rc) rc = launch_associate(ctx, fixed->v, d_idx, moving->v, 0, 1, d_guess, k, mp->lookup_mahalanobis, mp->use_intensity, d_corr, d_idx + 1);
+  while (!rc && !level_nodes.empty()) {
+    const int P = (int)level_nodes.size();
+    rc = ensure_ws(ctx, (size_t)P * 40 + 64);
+    if (rc) break;
+    std::vector<double> h_poses((size_t)P * 4), h_cost(P);
+    for (int i = 0; i < P; ++i) memcpy(&h_poses[4 * (size_t)i], level_nodes[i].pose, sizeof(double) * 4);
+    double* d_poses = (double*)ctx->ws;
+    double* d_cost = d_poses + (size_t)P * 4;
+    int32_t n_res = 0;
+    e = hipMemcpyAsync(d_poses, h_poses.data(), sizeof(double) * 4 * P, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { rc = randt_set_error(ctx, RANDT_ERR_HIP, "hipMemcpyAsync", e); break; }
+    rc = launch_eval_cost(ctx, fixed->v, fixed_idx, moving->v, moving_idx, d_corr, k, mp->use_intensity, scale, mp->loss_alpha, d_poses, P, d_cost, d_nres);
+    if (rc) break;
+    e = hipMemcpyAsync(h_cost.data(), d_cost, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_res, d_nres, sizeof(n_res), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { rc = randt_set_error(ctx, RANDT_ERR_HIP, "cost read-back", e); break; }
+    evals += P;
+    next_nodes.clear();
+    for (int i = 0; i < P; ++i) {   // FIFO order of the reference's queue (:560-605)
+      const double current_cost = h_cost[i] / (double)n_res;
+      const size_t level = (size_t)level_nodes[i].level;
+      if (current_cost < bp->csm_cost_threshold) {
+        if (current_cost < min_cost) {
+          memcpy(best, level_nodes[i].pose, sizeof(best));
+          min_cost = current_cost;
+        }
+        if (level < n_iter) {
+          const double cls = pow(2.0, (double)level) * linear_step, cas = angular_step;
+          for (double tx = -cls; tx <= cls; tx += cls)
+            for (double ty = -cls; ty <= cls; ty += cls)
+              for (double a = -cas; a <= cas; a += cas) {
+                double d4[4];
+                BnbNode nd;
+                bnb_pose(a, tx, ty, d4);
+                bnb_mul(level_nodes[i].pose, d4, nd.pose);
+                nd.level = (int)level + 1;
+                float key[9];
+                key_of(nd.pose, key);
+                bool found = false;
+                for (size_t t = 0; t + 9 <= keys.size() && !found; t += 9) found = memcmp(&keys[t], key, sizeof(key)) == 0;
+                if (!found) {
+                  keys.insert(keys.end(), key, key + 9);
+                  next_nodes.push_back(nd);
+                }
+              }
+        }
+      }
+    }
+    level_nodes.swap(next_nodes);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_blk);
+  if (rc) return rc;
+  memcpy(h_trans4, best, sizeof(best));  // trans = best_trans (identity if nothing qualified), :606
+  if (min_cost_out) *min_cost_out = min_cost;
+  if (n_evals) *n_evals = evals;
+  return RANDT_OK;
 }
 
 // ------------------------------------------------------------------ fixed-lag window (a16, a17) --
@@ -532,6 +663,13 @@ void h_se2_mul(const double* a, const double* b, double* out) {
   out[2] = tx;
   out[3] = ty;
 }
+// Sophus::SE2d(a, {tx, ty}) and the group product for the BNB pose grid
+void bnb_pose(double a, double tx, double ty, double* out) {
+  double c = cos(a), s = sin(a);
+  h_so2_normalize(c, s);
+  out[0] = c; out[1] = s; out[2] = tx; out[3] = ty;
+}
+void bnb_mul(const double* a, const double* b, double* out) { h_se2_mul(a, b, out); }
 }  // namespace
 
 int randt_predict_state(const randt_state* last, double stamp, randt_state* next) {

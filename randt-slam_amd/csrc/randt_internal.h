@@ -94,3 +94,7 @@ int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az
 int launch_cs_divergence(randt_ctx* ctx, const MapView& fixed, int fixed_first, int fixed_count, const int32_t* d_fixed_idx,
                          const MapView& moving, int moving_first, int n_pairs, const double* d_pose4, double* d_partial,
                          double* d_out, double* d_terms);
+
+int launch_eval_cost(randt_ctx* ctx, const MapView& fixed, int fmap, const MapView& moving, int mmap, const int32_t* d_corr, int k,
+                     int use_intensity, double scale, double alpha, const double* d_poses4, int n_poses, double* d_cost,
+                     int32_t* d_n_res);

@@ -726,6 +726,46 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
   }
 }
 
+// f-3: problem.Evaluate(apply_loss_function = true) at many poses for ONE frozen correspondence set
+// (Matcher::estimateTransformGlobalBNB, ndt_matcher.cpp:561-576): one wavefront per pose, cost only.
+template <int D>
+__global__ __launch_bounds__(64) void k_eval_cost(MapView fixed, int fmap, MapView moving, int mmap, const int32_t* __restrict__ corr,
+                                                  int k, double scale, double alpha, const double* __restrict__ poses4,
+                                                  double* __restrict__ cost, int32_t* __restrict__ n_res_out) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  int M = moving.counts[mmap];
+  M = M > moving.cap ? moving.cap : M;
+  const float* mov = reinterpret_cast<const float*>(moving.cells + (size_t)mmap * moving.cap);
+  const float* fix = reinterpret_cast<const float*>(fixed.cells + (size_t)fmap * fixed.cap);
+  const Loss L = make_loss(scale, alpha, 1.0, 1.0);  // BarronLoss(scale, alpha): b = a^2, no ScaledLoss (:517)
+  const double* x = poses4 + 4 * (size_t)p;
+  const double inv = rsqrt(x[0] * x[0] + x[1] * x[1]);
+  const double c = x[0] * inv, s = x[1] * inv, tx = x[2], ty = x[3];
+  double acc = 0.0;
+  int n = 0;
+  for (int slot = lane; slot < M * k; slot += 64) {
+    const int ci = corr[slot];
+    if (ci < 0 || ci >= fixed.cap) continue;
+    double jb[3];
+    const double sq = residual_sq<D, false>(mov + (size_t)(slot / k) * 12, fix + (size_t)ci * 12, c, s, tx, ty, jb);
+    ++n;
+    if (L.mode == 2) {
+      const double iu = 1.0 / (sq * L.ts + 1.0);
+      acc += L.half_w_pre * (iu - 1.);
+    } else {
+      double r0, r1, r2;
+      loss_eval(L, sq, r0, r1, r2);
+      acc += 0.5 * r0;
+    }
+  }
+  acc = wave_sum(acc);
+  const double nn = wave_sum((double)n);
+  if (lane == 0) {
+    cost[p] = acc;
+    if (n_res_out && p == 0) n_res_out[0] = (int)nn;
+  }
+}
+
 template <int D, int PARAM, int BLOCK>
 int launch_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
                int n_pairs, const int32_t* d_corr, const SolveParams& P, double* d_pose4, randt_result* d_results) {
@@ -784,4 +824,18 @@ int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_id
       return randt_set_error(ctx, RANDT_ERR_INVALID, "unknown parameterization", hipSuccess);
   }
 #undef RANDT_DISPATCH
+}
+
+int launch_eval_cost(randt_ctx* ctx, const MapView& fixed, int fmap, const MapView& moving, int mmap, const int32_t* d_corr, int k,
+                     int use_intensity, double scale, double alpha, const double* d_poses4, int n_poses, double* d_cost,
+                     int32_t* d_n_res) {
+  if (n_poses <= 0) return RANDT_OK;
+  if (use_intensity)
+    hipLaunchKernelGGL(k_eval_cost<3>, dim3(n_poses), dim3(64), 0, ctx->stream, fixed, fmap, moving, mmap, d_corr, k, scale, alpha,
+                       d_poses4, d_cost, d_n_res);
+  else
+    hipLaunchKernelGGL(k_eval_cost<2>, dim3(n_poses), dim3(64), 0, ctx->stream, fixed, fmap, moving, mmap, d_corr, k, scale, alpha,
+                       d_poses4, d_cost, d_n_res);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
 }

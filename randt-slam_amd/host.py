@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, ClusterParams, FilterParams, MapParams, MatcherParams, WindowParams
+from ._capi import CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, BnbParams, ClusterParams, FilterParams, MapParams, MatcherParams, WindowParams
 
 
 class RandtError(RuntimeError):
@@ -330,3 +330,25 @@ def cs_divergence_batch(ctx, fixed, fixed_first, fixed_count, fixed_idx, moving,
     ctx._check(ctx._lib.randt_cs_divergence_batch_dev(ctx._h, fixed._h, fixed_first, fixed_count, _dptr(fixed_idx), moving._h,
                                                       moving_first, n_pairs, _dptr(pose4), _dptr(out), _dptr(terms)),
                "randt_cs_divergence_batch_dev")
+
+
+# ------------------------------------------------------------------ correlative search (f-3) --------
+def bnb_params(window_linear=4.5, window_angular=0.45, linear_step=0.4, cost_threshold=0.82, max_px_accurate_range=4.0, n_iter=2):
+    """config/ndt_radar_slam_base_parameters.yaml:50-56."""
+    return BnbParams(window_linear, window_angular, linear_step, cost_threshold, max_px_accurate_range, n_iter, 0)
+
+
+def eval_cost_batch(ctx, fixed, fixed_idx, moving, moving_idx, corr, mp, scale, poses4, cost, n_res=None):
+    n = int(poses4.shape[0])
+    ctx._check(ctx._lib.randt_eval_cost_batch_dev(ctx._h, fixed._h, fixed_idx, moving._h, moving_idx, _dptr(corr), C.byref(mp), float(scale),
+                                                  _dptr(poses4), n, _dptr(cost), _dptr(n_res)), "randt_eval_cost_batch_dev")
+
+
+def search_global(ctx, fixed, fixed_idx, moving, moving_idx, mp, bp, trans4, scale=1.5, window_linear=4.5, window_angular=0.45):
+    """Matcher::estimateTransformGlobalBNB.  Returns (min_cost, pose4, n_evals)."""
+    t = np.array(trans4, dtype=np.float64)
+    mc, ne = C.c_double(0), C.c_int(0)
+    ctx._check(ctx._lib.randt_search_global(ctx._h, fixed._h, fixed_idx, moving._h, moving_idx, C.byref(mp), C.byref(bp), float(scale),
+                                            float(window_linear), float(window_angular), _dptr(t), C.byref(mc), C.byref(ne)),
+               "randt_search_global")
+    return mc.value, t, ne.value
