@@ -26,6 +26,20 @@
 
 #include "randt_internal.h"
 
+#ifdef RANDT_TIMING
+__device__ long long g_randt_win_timing[16];
+extern "C" int randt_debug_win_timing(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_randt_win_timing), sizeof(long long) * 16);
+}
+#define WT_DECL long long wt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wt_last = wall_clock64();
+#define WT(slot) do { const long long now_ = wall_clock64(); wt_acc[slot] += now_ - wt_last; wt_last = now_; } while (0)
+#define WT_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) g_randt_win_timing[i_] = wt_acc[i_]; } while (0)
+#else
+#define WT_DECL
+#define WT(slot) do {} while (0)
+#define WT_FLUSH do {} while (0)
+#endif
+
 #define WIN_BLOCK 256
 #define WIN_WAVES 4
 #define WIN_NMAX 32  // tangent dimensions
@@ -345,6 +359,14 @@ __device__ __forceinline__ double wave_max(double v) {
   }
   return v;
 }
+// 1/x to ~1 ulp: hardware reciprocal seed + two Newton-Raphson steps
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -364,16 +386,41 @@ struct Shared {
   double g[WIN_NMAX], gs[WIN_NMAX], sigma[WIN_NMAX], diag[WIN_NMAX], step[WIN_NMAX], delta[WIN_NMAX], col[WIN_NMAX];
   double red[2][WIN_WAVES][34];
   double scal[8];  // 0 mcc, 1 sn2, 2 x_norm, 3 solved, 4 gconv
+  double base[2][WIN_SMAX * 10];  // NDT base sums at current / candidate point (uniform values)
   int lcol[WIN_SMAX][WIN_NMAX];   // tangent column -> local column of motion factor f (-1 none)
   int lcol2[WIN_SMAX][WIN_NMAX];  // ... of IMU factor f
   int pose_of[WIN_NMAX];          // tangent column -> state whose pose block holds it (-1 none)
 };
 
+// Unweighted motion / IMU factors at xs[buf], one lane per factor (called by ONE wavefront).
+__device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
+  const int lane = threadIdx.x & 63;
+  if (lane < W.S) {
+    const int f = lane;  // factor between states f and f+1
+    double r[8];
+    motion_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], r, sh.Ju[f]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sh.ru[f][i] = r[i];
+    if (W.use_imu) {
+      double r2[2];
+      imu_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], W.imu[f], W.w_imu, W.w_bias, r2, sh.J2[buf][f]);
+      sh.r2[buf][f][0] = r2[0];
+      sh.r2[buf][f][1] = r2[1];
+    }
+  }
+}
+
 // NDT pass over every term at the states in xs[buf].  MODE 0: max raw residual -> out[0];
 // MODE 1: ten base sums per state -> out[(j-1)*10 ..].
+// In MODE 1 wavefront 3 evaluates the motion / IMU factors of the same point while wavefronts 0-2
+// stream the NDT slots (the factors are a ~2000-instruction serial chain: hidden behind the pass).
 template <int D, int MODE>
 __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const int32_t* __restrict__ corr,
                          const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw) {
+  const bool factor_wave = MODE == 1 && (threadIdx.x >> 6) == 3;
+  if (factor_wave) factors_unweighted(W, shw, buf);
+  const int wtid = MODE == 1 ? (factor_wave ? (1 << 30) : (int)threadIdx.x) : (int)threadIdx.x;
+  const int wstride = MODE == 1 ? 192 : WIN_BLOCK;
   double acc[WIN_SMAX * 10];
 #pragma unroll
   for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] = 0.0;
@@ -394,7 +441,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
     double a10[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) a10[i] = 0.0;
-    for (int slot = threadIdx.x; slot < n_slots; slot += WIN_BLOCK) {
+    for (int slot = wtid; slot < n_slots; slot += wstride) {
       const int ci = pc[slot];
       if (ci < 0 || ci >= fixed.cap) continue;
       double jb[3];
@@ -461,7 +508,8 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
       mx = r[w * 34] > mx ? r[w * 34] : mx;
       badf = r[w * 34 + 1] > badf ? r[w * 34 + 1] : badf;
     }
-    out[0] = mx > 0.0 ? sqrt(mx) : 0.0;
+    if (threadIdx.x == 0) out[0] = mx > 0.0 ? sqrt(mx) : 0.0;
+    __syncthreads();
     return badf == 0.0;
   }
 #pragma unroll
@@ -473,37 +521,18 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] = 0.0;
-#pragma unroll
-  for (int w = 0; w < WIN_WAVES; ++w) {
-#pragma unroll
-    for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] += r[w * 34 + i];
-    badf = r[w * 34 + 30] > badf ? r[w * 34 + 30] : badf;
-  }
-#pragma unroll
-  for (int i = 0; i < WIN_SMAX * 10; ++i) out[i] = acc[i];
+  for (int w = 0; w < WIN_WAVES; ++w) badf = r[w * 34 + 30] > badf ? r[w * 34 + 30] : badf;
+  // fixed-order 4-way combine, one thread per sum; published by the caller's next barrier
+  if (threadIdx.x < WIN_SMAX * 10) out[threadIdx.x] = ((r[0 * 34 + threadIdx.x] + r[1 * 34 + threadIdx.x]) + r[2 * 34 + threadIdx.x]) + r[3 * 34 + threadIdx.x];
   return badf == 0.0;
 }
 
-// Evaluate motion / IMU factors at xs[buf]: residuals + weighted Jacobians into Jf/rf/J2/r2[buf].
-// Returns sum of 1/2 r^2 over the factor residuals (identical in every thread).  Two barriers.
-__device__ double factor_pass(const WinDesc& W, Shared& sh, int buf) {
+// Weighting half of the factor evaluation (the unweighted residuals / Jacobians were produced by
+// factors_unweighted on wavefront 3 during the NDT pass, whose barrier published them):
+// residuals_map.applyOnTheLeft(sqrtI_), one thread per entry.  Returns sum of 1/2 r^2 over the
+// factor residuals (identical in every thread).  One barrier.
+__device__ double factors_weight(const WinDesc& W, Shared& sh, int buf) {
   const int tid = threadIdx.x;
-  if (tid < W.S) {
-    const int f = tid;  // factor between states f and f+1
-    double r[8];
-    motion_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], r, sh.Ju[f]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sh.ru[f][i] = r[i];
-    if (W.use_imu) {
-      double r2[2];
-      imu_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], W.imu[f], W.w_imu, W.w_bias, r2, sh.J2[buf][f]);
-      sh.r2[buf][f][0] = r2[0];
-      sh.r2[buf][f][1] = r2[1];
-    }
-  }
-  __syncthreads();
-  // residuals_map.applyOnTheLeft(sqrtI_): one thread per weighted entry
   for (int e = tid; e < W.S * 128; e += WIN_BLOCK) {
     const int f = e >> 7, i = (e & 127) >> 4, c = e & 15;
     double a = 0.0;
@@ -733,13 +762,13 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   // ---- raw NDT residuals -> gnc_mu (ndt_matcher.cpp:382-389)
   const double weight = n_cells > 0 ? W.ndt_weight / (double)(n_cells * W.k) : 0.0;
   Loss L = make_loss(P.loss_a, P.alpha, 1.0, weight);
-  double base_cur[WIN_SMAX * 10], base_cnd[WIN_SMAX * 10];
   double raw_max = 0.0;
   bool ok = true;
   if (n_res > 0) {
-    ok = ndt_pass<D, 0>(fixed, moving, W, corr, sh, 0, L, base_cur, parity, sh);
-    raw_max = base_cur[0];
+    ok = ndt_pass<D, 0>(fixed, moving, W, corr, sh, 0, L, sh.base[0], parity, sh);
+    raw_max = sh.base[0][0];
     res.n_evals++;
+    __syncthreads();
   }
   double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
   gnc_mu = fmin(gnc_mu, pow(P.gnc_div, (double)(P.gnc_steps - 1)));
@@ -748,6 +777,8 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   double summary_min = 0.0;
   if (!ok) res.status = 2;
   int p = 0;  // current state buffer
+  WT_DECL
+  WT(0);
 
   if (ok) {
     do {
@@ -758,13 +789,15 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       bool reuse = false, step_ok = true;
       int num_invalid = 0, iteration = 0;
       double minimum_cost = DBL_MAX;
-      double fcost = factor_pass(W, sh, p);
-      bool e_ok = ndt_pass<D, 1>(fixed, moving, W, corr, sh, p, L, base_cur, parity, sh);
+      bool e_ok = ndt_pass<D, 1>(fixed, moving, W, corr, sh, p, L, sh.base[p], parity, sh);
+      WT(1);
+      double fcost = factors_weight(W, sh, p);  // its barrier also publishes sh.base[p]
+      WT(2);
       res.n_evals++;
       res.iterations++;
       double cost = fcost;
 #pragma unroll
-      for (int j = 0; j < WIN_SMAX; ++j) cost += base_cur[j * 10];
+      for (int j = 0; j < WIN_SMAX; ++j) cost += sh.base[p][j * 10];
       if (!e_ok || !isfinite(cost)) {
         term = RANDT_TERM_FAILURE;
         res.status = 2;
@@ -773,7 +806,8 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       }
       if (res.gnc_solves == 0) res.initial_cost = cost;
       summary_min = cost;
-      assemble(W, sh, p, base_cur);
+      assemble(W, sh, p, sh.base[p]);
+      WT(3);
       bool first = true, need_scale = true;
       double x_norm = 0.0;
       trace_push(tr, trace_len, cost, radius, 0);
@@ -817,6 +851,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           x_norm = sh.scal[2];
           need_scale = false;
           first = false;
+          WT(4);
         }
         const bool gconv = sh.scal[4] != 0.0;
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
@@ -836,36 +871,51 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           const double inv_radius = 1.0 / radius;
           for (int e = lane; e < n * n; e += 64) sh.A[e] = sh.Hs[e] + ((e / n) == (e % n) ? sh.diag[e / n] * inv_radius : 0.0);
           wave_fence();
+          WT(8);
+          // SPD solve A y = gs by symmetric Gaussian elimination.  Lane i keeps row i of A (and gs_i) in
+          // registers; every step broadcasts the pivot row through LDS (kept as row j of U for the back
+          // substitution).  The j loops are ROLLED and only the k dimension is unrolled, so the whole solve is
+          // a few hundred instructions that stay in the instruction cache (a fully unrolled elimination is
+          // ~70 KB of straight-line code and runs at instruction-fetch speed).  By symmetry of the trailing
+          // matrix the multiplier of lane i is U[j][i] / U[j][j]: no dynamic register indexing anywhere.
           double okf = 1.0;
-          for (int j = 0; j < n; ++j) {
-            const double d = sh.A[j * n + j];
-            if (!(d > 0.0)) okf = 0.0;
-            const double invd = 1.0 / d;
-            for (int i = j + 1 + lane; i < n; i += 64) sh.col[i] = sh.A[i * n + j] * invd;  // L_ij
+          {
+            double row[WIN_NMAX], b = lane < n ? sh.gs[lane] : 0.0;
+#pragma clang loop unroll(full)
+            for (int k = 0; k < WIN_NMAX; ++k) row[k] = (lane < n && k < n) ? sh.A[lane * n + k] : 0.0;
+            double* U = sh.A;      // reused: U[j][k], stride WIN_NMAX (all rows already copied into registers)
+            double* ub = sh.col;   // right-hand side of the pivot rows
             wave_fence();
-            const int m = n - j - 1;
-            for (int e = lane; e < m * m; e += 64) {
-              const int i = j + 1 + e / m, k = j + 1 + e % m;
-              if (k <= i) sh.A[i * n + k] -= sh.col[i] * d * sh.col[k];
+            for (int j = 0; j < n; ++j) {
+              if (lane == j) {
+#pragma clang loop unroll(full)
+                for (int k = 0; k < WIN_NMAX; ++k) U[j * WIN_NMAX + k] = row[k];
+                ub[j] = b;
+              }
+              wave_fence();
+              const double pj = U[j * WIN_NMAX + j];
+              if (!(pj > 0.0)) okf = 0.0;
+              const double f = (lane > j && lane < n) ? U[j * WIN_NMAX + lane] * fast_rcp(pj) : 0.0;
+#pragma clang loop unroll(full)
+              for (int k = 0; k < WIN_NMAX; ++k) row[k] -= f * U[j * WIN_NMAX + k];
+              b -= f * ub[j];
             }
-            for (int i = j + 1 + lane; i < n; i += 64) sh.A[i * n + j] = sh.col[i];
+            // back substitution on U y = ub
+            double y = 0.0;
             wave_fence();
+            for (int j = n - 1; j >= 0; --j) {
+              // lane j's b has received all updates from columns > j
+              if (lane == j) sh.delta[0] = b;
+              wave_fence();
+              const double yj = sh.delta[0] * fast_rcp(U[j * WIN_NMAX + j]);
+              if (lane < j) b -= U[lane * WIN_NMAX + j] * yj;
+              if (lane == j) y = yj;
+              wave_fence();
+            }
+            if (lane < n) sh.step[lane] = y;
           }
-          // L z = gs ; w = z / d ; L^T y = w   (y overwrites step)
-          if (lane < n) sh.step[lane] = sh.gs[lane];
           wave_fence();
-          for (int j = 0; j < n; ++j) {
-            const double yj = sh.step[j];
-            for (int i = j + 1 + lane; i < n; i += 64) sh.step[i] -= sh.A[i * n + j] * yj;
-            wave_fence();
-          }
-          if (lane < n) sh.step[lane] = sh.step[lane] / sh.A[lane * n + lane];
-          wave_fence();
-          for (int j = n - 1; j >= 0; --j) {
-            const double yj = sh.step[j];
-            for (int i = lane; i < j; i += 64) sh.step[i] -= sh.A[j * n + i] * yj;
-            wave_fence();
-          }
+          WT(9);
           double fin = 1.0;
           if (lane < n) {
             if (!isfinite(sh.step[lane])) fin = 0.0;
@@ -883,9 +933,12 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           }
           const double mcc = -wave_sum(t);
           wave_fence();
+          WT(10);
           plus_states(W, sh, p, 1 - p, sh.delta, 1.0, lane);
           wave_fence();
+          WT(11);
           const double sn2 = ambient_sq(W, sh, p, 1 - p, lane);
+          WT(12);
           if (lane == 0) {
             sh.scal[0] = mcc;
             sh.scal[1] = sn2;
@@ -893,6 +946,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           }
         }
         __syncthreads();
+        WT(5);
         reuse = true;
         const double mcc = sh.scal[0], sn2 = sh.scal[1];
         const bool valid = sh.scal[3] != 0.0 && mcc > 0.0;
@@ -910,12 +964,14 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         num_invalid = 0;
 
         // ---- candidate: factors + NDT terms with Jacobians (speculative)
-        const double cf = factor_pass(W, sh, 1 - p);
-        const bool c_ok = ndt_pass<D, 1>(fixed, moving, W, corr, sh, 1 - p, L, base_cnd, parity, sh);
+        const bool c_ok = ndt_pass<D, 1>(fixed, moving, W, corr, sh, 1 - p, L, sh.base[1 - p], parity, sh);
+        WT(1);
+        const double cf = factors_weight(W, sh, 1 - p);
+        WT(2);
         res.n_evals++;
         double cand_cost = cf;
 #pragma unroll
-        for (int j = 0; j < WIN_SMAX; ++j) cand_cost += base_cnd[j * 10];
+        for (int j = 0; j < WIN_SMAX; ++j) cand_cost += sh.base[1 - p][j * 10];
         const bool cfin = c_ok && isfinite(cand_cost);
         if (!cfin) cand_cost = DBL_MAX;
 
@@ -929,9 +985,9 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           // ---- HandleSuccessfulStep: the candidate buffer becomes current
           p = 1 - p;
           cost = cand_cost;
-#pragma unroll
-          for (int i = 0; i < WIN_SMAX * 10; ++i) base_cur[i] = base_cnd[i];
-          assemble(W, sh, p, base_cur);
+          WT(6);
+          assemble(W, sh, p, sh.base[p]);
+          WT(3);
           need_scale = true;
           step_ok = true;
           const double t = 2.0 * rel - 1.0;
@@ -959,6 +1015,8 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   res.termination = term;
   res.final_cost = summary_min;
   res.cost = n_res > 0 ? summary_min / (double)n_res : 0.0;
+  WT(7);
+  WT_FLUSH;
   if (tid == 0) result[0] = res;
 }
 
