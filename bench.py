@@ -62,10 +62,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and os.environ.get("RANDT_BENCH_BACKEND") != "gloo":
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, n_dev))
+    local_rank = local_rank % max(1, n_dev)   # only differs in the single-GPU gloo logic test
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        # "nccl" IS RCCL on ROCm.  RANDT_BENCH_BACKEND=gloo exists only to exercise the multi-rank control
+        # flow on a box with fewer GPUs than ranks (tests); it is never used for reported numbers.
+        backend = os.environ.get("RANDT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     # One randt context per HIP stream: consecutive steps (independent batches) alternate streams so
     # that the latency-bound tail of one batch's solve overlaps the next batch's build / association.

@@ -50,6 +50,20 @@ class HipBackend:
         host.ndt_build_batch(self.ctx, pts.reshape(1, pts.shape[-2], pts.shape[-1]), self.clu, self.scans, first_map=idx)
         return idx
 
+    def build_scan_from_polar(self, raw, filter_params, pitch_out=6144):
+        """BASELINE config 5 front end: RadarPreprocessor::filterScan on a raw polar scan
+        (n_azimuths x n_bins x stride, device tensor) followed by the NDT build of the kept points."""
+        torch = self.torch
+        if getattr(self, "_f_out", None) is None or self._f_out.shape[1] != pitch_out:
+            self._f_out = torch.zeros((1, pitch_out, 4), dtype=torch.float32, device=self.dev)
+            self._f_cnt = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self._f_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        raw = raw if hasattr(raw, "data_ptr") else torch.from_numpy(np.ascontiguousarray(raw, dtype=np.float32)).to(self.dev)
+        host.filter_scan_batch(self.ctx, raw.reshape(1, *raw.shape[-3:]), filter_params, self._f_out, self._f_cnt, self._f_status)
+        idx = self.free_scans.pop(0)
+        host.ndt_build_batch(self.ctx, self._f_out, self.clu, self.scans, first_map=idx, n_points=self._f_cnt)
+        return idx
+
     def release_scan(self, idx):
         self.free_scans.append(idx)
 
@@ -192,11 +206,15 @@ class Odometry:
             self.trajectory.append(st)
             b.merge(self.current_submap, scan, self.current_transform)                    # :281,293
 
-    def process_scan(self, points, stamp):
-        """NDTSlam::radarCb (ndt_slam.cpp:211-223): process, roll the submap over when complete."""
+    def process_scan(self, points, stamp, polar_filter=None):
+        """NDTSlam::radarCb (ndt_slam.cpp:211-223): process, roll the submap over when complete.
+        polar_filter: FilterParams -> `points` is a raw polar scan and goes through filterScan first."""
         if self._refs is None:
             self._refs = {}
-        scan = self.b.build_scan(points)                                                  # :102-105
+        if polar_filter is not None:
+            scan = self.b.build_scan_from_polar(points, polar_filter)                     # :102 filterScan + clustering
+        else:
+            scan = self.b.build_scan(points)                                              # :102-105
         self._ref(scan)
         self._process(scan, stamp)
         if self.submap_complete():

@@ -23,6 +23,20 @@ class OracleBackend:
         self.scans[self._next] = m
         return self._next
 
+    def build_scan_from_polar(self, raw, filter_params, pitch_out=6144):
+        import pyoracle as po_
+        fp = po_.FilterParams()
+        for name, _ in fp._fields_:
+            v = getattr(filter_params, name)
+            if name == "sensor_to_base":
+                for i in range(12):
+                    fp.sensor_to_base[i] = v[i]
+            else:
+                setattr(fp, name, v)
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        cnt, pts, _, _ = po_.filter_scan(raw.reshape(-1, raw.shape[-1]), fp, capacity=pitch_out)
+        return self.build_scan(pts)
+
     def release_scan(self, h):
         del self.scans[h]
 

@@ -1,0 +1,44 @@
+"""-m gpu: bench.py contract -- one JSON line with the required keys; the multi-rank control flow
+(barriers, submap broadcast, MAX over ranks, rank-0 print) exercised with two ranks on one GPU
+through gloo (RCCL itself needs >= 2 GPUs, which the driver provides at round end)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--odometry-scans", "8", "--polar-scans", "2",
+                        "--cpu-seconds", "0.5"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    d = _last_json(r.stdout)
+    for k in REQUIRED + ["cpu_baseline"]:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["value"] > 1e5 and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["traffic"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["pose_err_vs_oracle"]["max_abs_translation_m"] <= 1e-4 and d["pose_err_vs_oracle"]["max_abs_rotation_rad"] <= 1e-4
+
+
+def test_bench_two_ranks_control_flow():
+    env = dict(os.environ, RANDT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+           "--odometry-scans", "0", "--polar-scans", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 1e5
