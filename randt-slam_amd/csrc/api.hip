@@ -138,7 +138,6 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
     int b = atoi(e);
     if (b == 64 || b == 128 || b == 256) ctx->solve_block = b;
   }
-  if (const char* e = getenv("RANDT_SOLVE_STAGE")) ctx->solve_stage = atoi(e) ? 1 : 0;
   *out = ctx;
   return RANDT_OK;
 }

@@ -34,7 +34,6 @@ struct randt_ctx {
   int lds_limit = 160 * 1024;
   // solve-kernel geometry (tunable through RANDT_SOLVE_BLOCK / RANDT_SOLVE_STAGE for experiments)
   int solve_block = 64;
-  int solve_stage = 0;
 };
 
 struct randt_maps {

@@ -10,9 +10,11 @@
 //
 // Geometry: BLOCK = 64 / 128 / 256 threads cooperate on one registration (default 128 = two
 // wavefronts on two SIMDs; 64 = a single wavefront with no barrier at all).  The frozen
-// correspondence set is read in place: the 48-byte cell records (first 9 floats = mean xyz +
-// upper-triangular covariance) stay L1/L2 resident across the ~30 passes of a registration and are
-// cast to fp64 in registers like the reference does (ndt_matcher.cpp:231).
+// correspondence set is compacted once into an LDS index list and its 48-byte cell records (first
+// 9 floats = mean xyz + upper-triangular covariance) are read in place: they stay L1/L2 resident
+// across the ~30 passes of a registration and are cast to fp64 in registers like the reference
+// does (ndt_matcher.cpp:231).  (Staging the records themselves in LDS was measured slower: the LDS
+// it takes costs the co-running kernels more than the solve gains.)
 // Every LM iteration is one pass over the M*k correspondence slots: fp64 residual, its Jacobian
 // with respect to (tx, ty, theta), loss + Ceres corrector, and TEN accumulators {cost, J^T r (3),
 // upper J^T J (6)} reduced in a fixed order (DPP row reduction -> readlane across rows -> LDS
@@ -33,6 +35,23 @@ namespace {
 struct Base {
   double v[10];
 };
+
+// 1/x and 1/sqrt(x) to ~1 ulp: hardware seed (2^-23 relative) + two Newton-Raphson steps.  A correctly
+// rounded fp64 division costs ~25 instructions on gfx950, these 5 / 9.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-x * y, y, 1.0);
+  return fma(0.5 * y, e, y);
+}
 
 // ---------------------------------------------------------------- Sophus SE(2) pieces ----------
 __device__ __forceinline__ void so2_normalize(double& c, double& s) {
@@ -134,11 +153,17 @@ __device__ __forceinline__ void loss_eval(const Loss& L, double s, double& r0, d
 
 // ---------------------------------------------------------------- residual ---------------------
 // One D2D residual: ssq = d^T (R Sm R^T + Sf)^-1 d and, if WANT_JAC,
-// jb = d r / d (tx, ty, theta) with r = sqrt(ssq) (A.2 in the global frame).
+// jb = r * d r / d (tx, ty, theta) with r = sqrt(ssq) (A.2 in the global frame): the 1/r factor is
+// folded into the accumulation by the caller, so no square root is taken per residual.
 // mv/fv: first 9 floats of a cell record (mean xyz, cov xx xy xi yy yi ii); c, s = cos/sin(theta).
 template <int D, bool WANT_JAC>
-__device__ __forceinline__ double residual_sq(const float* __restrict__ mv, const float* __restrict__ fv, double c, double s,
+__device__ __forceinline__ double residual_sq(const float4* mrec, const float4* frec, double c, double s,
                                               double tx, double ty, double* jb) {
+  // 48-byte records as three 16-byte loads each (global: dwordx4, LDS: ds_read_b128, conflict-free at stride 48)
+  const float4 ma = mrec[0], mb = mrec[1], mc4 = mrec[2];
+  const float4 fa = frec[0], fb = frec[1], fc4 = frec[2];
+  const float mv[9] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w, mc4.x};
+  const float fv[9] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc4.x};
   const double m0 = mv[0], m1 = mv[1];
   const double a = mv[3], b = mv[4], dd = mv[6];
   const double RS00 = c * a - s * b, RS01 = c * b - s * dd;
@@ -161,7 +186,7 @@ __device__ __forceinline__ double residual_sq(const float* __restrict__ mv, cons
     const double k01 = C12 * C02 - C01 * C22;
     const double k02 = C01 * C12 - C11 * C02;
     const double det = C00 * k00 + C01 * k01 + C02 * k02;
-    const double id = 1.0 / det;
+    const double id = fast_rcp(det);
     const double k11 = C00 * C22 - C02 * C02;
     const double k12 = C02 * C01 - C00 * C12;
     const double k22 = C00 * C11 - C01 * C01;
@@ -171,27 +196,21 @@ __device__ __forceinline__ double residual_sq(const float* __restrict__ mv, cons
     ssq = d0 * q0 + d1 * q1 + d2 * q2;
   } else {
     const double det = C00 * C11 - C01 * C01;
-    const double id = 1.0 / det;
+    const double id = fast_rcp(det);
     q0 = (C11 * d0 - C01 * d1) * id;
     q1 = (-C01 * d0 + C00 * d1) * id;
     ssq = d0 * q0 + d1 * q1;
   }
   if (WANT_JAC) {
-    if (!(ssq > 0.0)) {
-      // autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545): zero row instead
-      jb[0] = jb[1] = jb[2] = 0.0;
-    } else {
-      const double ir = rsqrt(ssq);  // 1/r; r = ssq * ir
-      const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
-      double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
-      if (D == 3) {
-        Su0 += cc * q2;
-        Su1 += e * q2;
-      }
-      jb[0] = q0 * ir;
-      jb[1] = q1 * ir;
-      jb[2] = ((u1 * m0 - u0 * m1) - (u1 * Su0 - u0 * Su1)) * ir;
+    const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
+    double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
+    if (D == 3) {
+      Su0 += cc * q2;
+      Su1 += e * q2;
     }
+    jb[0] = q0;
+    jb[1] = q1;
+    jb[2] = (u1 * m0 - u0 * m1) - (u1 * Su0 - u0 * Su1);
   }
   return ssq;
 }
@@ -223,11 +242,19 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// valid correspondences of one registration, compacted once into LDS: (moving index << 21) | fixed index
+constexpr int PAIR_CAP = 1024;
+constexpr int PAIR_SHIFT = 21;
+constexpr unsigned PAIR_MASK = (1u << PAIR_SHIFT) - 1u;
+
 struct Stage {
-  const float* mov;  // moving cell records (stride 12 floats)
-  const float* fix;  // fixed cell records (stride 12 floats)
-  const int* corr;   // [M*k] compact fixed index or -1
+  const float4* mov;      // moving cell records (3 x float4 each)
+  const float4* fix;      // fixed cell records
+  const int* corr;        // [M*k] compact fixed index or -1
+  const unsigned* pairs;  // LDS: compacted valid correspondences, or nullptr (then the raw slots are walked)
+  int n_pairs;
   int n_slots, k, fixed_cap;
+  unsigned kmagic;        // ceil(2^32 / k): slot / k == umulhi(slot, kmagic) for slot < 2^32 / k (k >= 2)
 };
 
 // Pass over all correspondence slots at ambient point x.  MODE 0: max raw residual (out.v[0]);
@@ -244,7 +271,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     ty = x[1];
   } else {
     // R = AngleAxis(atan2(sp, cp)): cos/sin of the angle == normalised stored complex
-    const double inv = rsqrt(x[0] * x[0] + x[1] * x[1]);
+    const double inv = fast_rsqrt(x[0] * x[0] + x[1] * x[1]);
     c = x[0] * inv;
     s = x[1] * inv;
     tx = x[2];
@@ -255,11 +282,22 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   for (int i = 0; i < 10; ++i) acc[i] = 0.0;
   double mx = -DBL_MAX;
   int bad = 0;
-  for (int slot = threadIdx.x; slot < S.n_slots; slot += BLOCK) {
-    const int ci = S.corr[slot];
-    if (ci < 0 || ci >= S.fixed_cap) continue;
-    const float* mv = S.mov + (size_t)(slot / S.k) * 12;
-    const float* fv = S.fix + (size_t)ci * 12;
+  const bool compact = S.pairs != nullptr;
+  const int n_it = compact ? S.n_pairs : S.n_slots;
+  for (int slot = threadIdx.x; slot < n_it; slot += BLOCK) {
+    unsigned mi, ci;
+    if (compact) {
+      const unsigned u = S.pairs[slot];
+      mi = u >> PAIR_SHIFT;
+      ci = u & PAIR_MASK;
+    } else {
+      const int cr = S.corr[slot];
+      if (cr < 0 || cr >= S.fixed_cap) continue;
+      ci = (unsigned)cr;
+      mi = S.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, S.kmagic);  // slot / k
+    }
+    const float4* mv = S.mov + (size_t)mi * 3;
+    const float4* fv = S.fix + (size_t)ci * 3;
     double jb[3];
     const double sq = residual_sq<D, MODE == 1>(mv, fv, c, s, tx, ty, jb);
     if (!isfinite(sq)) bad = 1;
@@ -270,7 +308,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
       double js;
       if (L.mode == 2) {
         // alpha = -2: rho' = w / u^2 > 0, rho'' < 0 always => corrector is sqrt(rho') = sqrt(w) / u
-        const double iu = 1.0 / (sq * L.ts + 1.0);
+        const double iu = fast_rcp(sq * L.ts + 1.0);
         acc[0] += L.half_w_pre * (iu - 1.);
         rs = js = L.sqrt_w * iu;
       } else {
@@ -287,18 +325,23 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
           js = sqrt_rho1 * (1.0 - al);  // J - (alpha/sq) r r^T J for a scalar residual
         }
       }
-      const double r = sq > 0.0 ? sq * rsqrt(sq) : 0.0;
-      const double wr = rs * r;
-      const double w0 = js * jb[0], w1 = js * jb[1], w2 = js * jb[2];
-      acc[1] += w0 * wr;
-      acc[2] += w1 * wr;
-      acc[3] += w2 * wr;
-      acc[4] += w0 * w0;
-      acc[5] += w0 * w1;
-      acc[6] += w0 * w2;
-      acc[7] += w1 * w1;
-      acc[8] += w1 * w2;
-      acc[9] += w2 * w2;
+      // With r = sqrt(sq) and the true Jacobian row J = jb / r: the corrected residual is rs * r and the
+      // corrected row js * J, so  J^T r += (js rs) jb  and  J^T J += (js^2 / sq) jb jb^T  -- no square root.
+      // sq == 0: autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545); zero row instead.
+      if (sq > DBL_MIN) {
+        const double jr = js * rs;
+        const double h = js * js * fast_rcp(sq);
+        const double h0 = h * jb[0], h1 = h * jb[1], h2 = h * jb[2];
+        acc[1] += jr * jb[0];
+        acc[2] += jr * jb[1];
+        acc[3] += jr * jb[2];
+        acc[4] += h0 * jb[0];
+        acc[5] += h0 * jb[1];
+        acc[6] += h0 * jb[2];
+        acc[7] += h1 * jb[1];
+        acc[8] += h1 * jb[2];
+        acc[9] += h2 * jb[2];
+      }
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -357,8 +400,8 @@ __device__ __forceinline__ void to_param(const Base& B, const double* x, double*
     T[2][0] = 0; T[2][1] = 0; T[2][2] = 1;
   } else {
     const double cp = x[0], sp = x[1];
-    const double n2 = cp * cp + sp * sp;
-    const double a = -sp / n2, b = cp / n2;  // d theta / d c, d theta / d s  (theta = atan2(s, c))
+    const double in2 = fast_rcp(cp * cp + sp * sp);
+    const double a = -sp * in2, b = cp * in2;  // d theta / d c, d theta / d s  (theta = atan2(s, c))
     if (PARAM == RANDT_PARAM_AMBIENT4) {
       T[0][0] = 0; T[0][1] = 0; T[0][2] = a;
       T[1][0] = 0; T[1][1] = 0; T[1][2] = b;
@@ -398,7 +441,7 @@ __device__ __forceinline__ bool ldlt_solve(double* A, const double* g, double* y
     for (int k = 0; k < j; ++k) d -= A[j * NT + k] * A[j * NT + k] * A[k * NT + k];
     if (!(d > 0.0)) ok = false;
     A[j * NT + j] = d;
-    inv_d[j] = 1.0 / d;
+    inv_d[j] = fast_rcp(d);
 #pragma unroll
     for (int i = j + 1; i < NT; ++i) {
       double a = A[i * NT + j];
@@ -479,6 +522,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
   constexpr int WAVES = BLOCK / 64;
   __shared__ double red[2 * WAVES * 12];
   __shared__ int s_count[WAVES];
+  __shared__ unsigned s_pairs[PAIR_CAP];
 
   const int tid = threadIdx.x;
   const int pair = blockIdx.x;
@@ -489,12 +533,15 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
   M = M > moving.cap ? moving.cap : M;
 
   Stage S;
-  S.mov = reinterpret_cast<const float*>(moving.cells + (size_t)mmap * moving.cap);
-  S.fix = reinterpret_cast<const float*>(fixed.cells + (size_t)fmap * fixed.cap);
+  S.mov = reinterpret_cast<const float4*>(moving.cells + (size_t)mmap * moving.cap);
+  S.fix = reinterpret_cast<const float4*>(fixed.cells + (size_t)fmap * fixed.cap);
   S.corr = corr + (size_t)pair * moving.cap * k;
   S.n_slots = M * k;
   S.k = k;
   S.fixed_cap = fixed.cap;
+  S.pairs = nullptr;
+  S.n_pairs = 0;
+  S.kmagic = k > 1 ? (unsigned)((0x100000000ull + (unsigned)k - 1) / (unsigned)k) : 0u;
 
   // number of residual blocks (addNDTFactor, ndt_matcher.cpp:217-246)
   int n_res = 0;
@@ -512,6 +559,29 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
     for (int w = 0; w < WAVES; ++w) n_res += s_count[w];
   }
   int parity = 0;
+
+  // Compact the valid correspondences once (ascending slot order): every pass then walks a dense list,
+  // ceil(n_res / BLOCK) trips per lane instead of ceil(M k / BLOCK), with no per-pass index arithmetic.
+  if (n_res > 0 && n_res <= PAIR_CAP && fixed.cap <= (int)PAIR_MASK + 1 && M <= (1 << (32 - PAIR_SHIFT))) {
+    if (tid < 64) {
+      int n_out = 0;
+      for (int base = 0; base < S.n_slots; base += 64) {
+        const int slot = base + tid;
+        const int cr = slot < S.n_slots ? S.corr[slot] : -1;
+        const bool valid = cr >= 0 && cr < fixed.cap;
+        const unsigned long long mask = __ballot(valid);
+        if (valid) {
+          const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          const unsigned mi = k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, S.kmagic);
+          s_pairs[n_out + rank] = (mi << PAIR_SHIFT) | (unsigned)cr;
+        }
+        n_out += __popcll(mask);
+      }
+    }
+    __syncthreads();
+    S.pairs = s_pairs;
+    S.n_pairs = n_res;
+  }
 
   double* tr = trace ? trace + (size_t)pair * trace_len : nullptr;
   if (tr && tid == 0) tr[0] = 0.0;
@@ -615,7 +685,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
 #pragma unroll
           for (int i = 0; i < NT; ++i) diag[i] = fmin(fmax(Hs[i * NT + i], P.dmin), P.dmax);
         }
-        const double inv_radius = 1.0 / radius;
+        const double inv_radius = fast_rcp(radius);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
 #pragma unroll
@@ -643,7 +713,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         if (!valid) {
           // ---- HandleInvalidStep
           if (++num_invalid >= P.max_invalid) { term = RANDT_TERM_FAILURE; break; }
-          radius = radius / decrease;
+          radius = radius * fast_rcp(decrease);  // decrease is a power of two: exact
           decrease *= 2.0;
           reuse = true;
           step_ok = false;
@@ -673,7 +743,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         const double cost_change = cost - cand_cost;
         if (fabs(cost_change) <= P.ftol * cost) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
 
-        const double rel = c_ok ? cost_change / mcc : -DBL_MAX;
+        const double rel = c_ok ? cost_change * fast_rcp(mcc) : -DBL_MAX;
         if (rel > P.min_rel) {
           // ---- HandleSuccessfulStep
 #pragma unroll
@@ -690,7 +760,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
           gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
           step_ok = true;
           const double t = 2.0 * rel - 1.0;
-          radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+          radius = radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - t * t * t));
           radius = fmin(P.rmax, radius);
           decrease = 2.0;
           reuse = false;
@@ -698,7 +768,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
           trace_push(tr, trace_len, cost, radius, 1);
         } else {
           step_ok = false;
-          radius = radius / decrease;
+          radius = radius * fast_rcp(decrease);  // decrease is a power of two: exact
           decrease *= 2.0;
           reuse = true;
           summary_min = fmin(summary_min, cand_cost);
@@ -735,8 +805,8 @@ __global__ __launch_bounds__(64) void k_eval_cost(MapView fixed, int fmap, MapVi
   const int p = blockIdx.x, lane = threadIdx.x;
   int M = moving.counts[mmap];
   M = M > moving.cap ? moving.cap : M;
-  const float* mov = reinterpret_cast<const float*>(moving.cells + (size_t)mmap * moving.cap);
-  const float* fix = reinterpret_cast<const float*>(fixed.cells + (size_t)fmap * fixed.cap);
+  const float4* mov = reinterpret_cast<const float4*>(moving.cells + (size_t)mmap * moving.cap);
+  const float4* fix = reinterpret_cast<const float4*>(fixed.cells + (size_t)fmap * fixed.cap);
   const Loss L = make_loss(scale, alpha, 1.0, 1.0);  // BarronLoss(scale, alpha): b = a^2, no ScaledLoss (:517)
   const double* x = poses4 + 4 * (size_t)p;
   const double inv = rsqrt(x[0] * x[0] + x[1] * x[1]);
@@ -747,7 +817,7 @@ __global__ __launch_bounds__(64) void k_eval_cost(MapView fixed, int fmap, MapVi
     const int ci = corr[slot];
     if (ci < 0 || ci >= fixed.cap) continue;
     double jb[3];
-    const double sq = residual_sq<D, false>(mov + (size_t)(slot / k) * 12, fix + (size_t)ci * 12, c, s, tx, ty, jb);
+    const double sq = residual_sq<D, false>(mov + (size_t)(slot / k) * 3, fix + (size_t)ci * 3, c, s, tx, ty, jb);
     ++n;
     if (L.mode == 2) {
       const double iu = 1.0 / (sq * L.ts + 1.0);
