@@ -42,8 +42,12 @@ def algorithmic_bytes(n_points, n_slots, m_cells, k):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch-scale", type=int, default=1,
+                    help="diagnostic: registrations per step = 512 x this (the headline workload is 1)")
+    ap.add_argument("--only", choices=["build", "associate", "solve"], default=None,
+                    help="diagnostic: time ONE stage alone at saturation (the printed value is then not the headline metric)")
     ap.add_argument("--streams", type=int, default=4, help="in-flight batches: step i runs on HIP stream i %% streams")
     ap.add_argument("--odometry-scans", type=int, default=200, help="BASELINE config 3 side measurement (0 = skip)")
     ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
@@ -86,11 +90,12 @@ def main():
     mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
     mp = R.default_matcher_params()
     k = mp.n_neighbours
-    B = N_SUBMAPS * SCANS_PER_SUBMAP
+    scans_per_submap = SCANS_PER_SUBMAP * max(1, args.batch_scale)
+    B = N_SUBMAPS * scans_per_submap
     scan_cap = 512
 
     # ---------------- set-up (untimed): synthetic world, scans, submaps ---------------------------
-    prob = synth.make_batch_problem(N_SUBMAPS, SCANS_PER_SUBMAP, N_KEYFRAMES, scan_seed0=1000 + 100000 * rank,
+    prob = synth.make_batch_problem(N_SUBMAPS, scans_per_submap, N_KEYFRAMES, scan_seed0=1000 + 100000 * rank,
                                     guess_seed0=2000 + 100000 * rank)
     # submap tables live in torch-owned HBM so that RCCL can broadcast them
     cb, nb, gb = R.Maps.storage_bytes(N_SUBMAPS, mapp, N_SLOTS)
@@ -130,15 +135,19 @@ def main():
         st, cx = streams[j], ctxs[j]
         with torch.cuda.stream(st):
             poses[j].copy_(guess4)
+        only = args.only if events is not None else None        # warm-up always runs the full path
         if events is not None:
             events[0].record(st)
-        R.ndt_build_batch(cx, points, clu, scan_mapss[j])
+        if only in (None, "build"):
+            R.ndt_build_batch(cx, points, clu, scan_mapss[j])
         if events is not None:
             events[1].record(st)
-        R.associate_batch(cx, submaps_v[j], fixed_idx, scan_mapss[j], 0, B, poses[j], mp, corrs[j])
+        if only in (None, "associate"):
+            R.associate_batch(cx, submaps_v[j], fixed_idx, scan_mapss[j], 0, B, poses[j], mp, corrs[j])
         if events is not None:
             events[2].record(st)
-        R.solve_batch(cx, submaps_v[j], fixed_idx, scan_mapss[j], 0, B, corrs[j], mp, poses[j], resultss[j])
+        if only in (None, "solve"):
+            R.solve_batch(cx, submaps_v[j], fixed_idx, scan_mapss[j], 0, B, corrs[j], mp, poses[j], resultss[j])
         if events is not None:
             events[3].record(st)
 
@@ -181,7 +190,7 @@ def main():
         # Jacobian pass except the raw-residual one
         flops = n_res_mean * ((evals_mean - 1) * 370 + 250) * B
         out = {
-            "metric": "ndt_registrations_per_sec", "value": value, "unit": "registrations/s",
+            "metric": "ndt_registrations_per_sec" if args.only is None and args.batch_scale == 1 else "DIAGNOSTIC_only=%s_batch_scale=%d" % (args.only, args.batch_scale), "value": value, "unit": "registrations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

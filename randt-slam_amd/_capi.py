@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librandt_hip.so")
+# RANDT_LIB: developer A/B hook (an alternative build of the same library); the default is the in-tree build
+LIB_PATH = os.environ.get("RANDT_LIB") or os.path.join(_HERE, "librandt_hip.so")
 
 CELL_DTYPE = np.dtype(
     [("mean", "<f4", (3,)), ("cov", "<f4", (6,)), ("n", "<u4"), ("max_intensity", "<f4"), ("reserved", "<u4")]

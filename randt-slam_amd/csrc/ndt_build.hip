@@ -42,197 +42,12 @@ __device__ __forceinline__ int32_t point_label(float x, float y, int row_size, f
   return trunc_to_i32(x / resolution) + row_size * trunc_to_i32(y / resolution);
 }
 
-// One workgroup per scan.  labelClouds' order (ascending label, input order inside a label) is
-// produced by a STABLE counting sort: every wavefront owns a contiguous quarter of the points;
-// a 64-bit LDS word per label bin packs the four per-wave counts (4 x u16); a block scan turns the
-// counts into per-(bin, wave) start positions; each wave then walks its quarter in order and ranks
-// equal labels inside a 64-point step with ballots.  Label ranges that do not fit the LDS bins
-// (points far outside max_range) fall back to an O(N^2/256) rank-by-counting pass.
-// The placement pass re-reads each point (L2-hot) and writes it straight into label-sorted SoA
-// arrays, so the per-cluster fp32 loops stream consecutive LDS words with no index indirection.
-// Dynamic LDS: sx | sy | si | lab [npad] | cstart[npad+2] | bins[nb_cap] u64 | scratch
-__global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restrict__ pts, int pitch,
-                                                           const int32_t* __restrict__ n_pts_arr, int stride,
-                                                           int ioff, int row_size, float resolution, MapView out,
-                                                           int first_map, int npad, int nb_cap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sx = reinterpret_cast<float*>(smem);  // points in labelClouds order
-  float* sy = sx + npad;
-  float* si = sy + npad;
-  int32_t* lab = reinterpret_cast<int32_t*>(si + npad);
-  int* cstart = lab + npad;                                                  // [npad + 1] (+1 pad)
-  unsigned long long* bins = reinterpret_cast<unsigned long long*>(cstart + npad + 2);
-  int* scratch = reinterpret_cast<int*>(bins + nb_cap);                      // [16]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int scan = blockIdx.x;
-  const int map = first_map + scan;
-  int n = n_pts_arr ? n_pts_arr[scan] : pitch;
-  n = n < 0 ? 0 : (n > pitch ? pitch : n);
-  const float* sp = pts + (size_t)scan * pitch * stride;
-  int32_t* grid = out.grid ? out.grid + (size_t)map * out.n_slots : nullptr;
-  randt_cell* cells = out.cells + (size_t)map * out.cap;
-
-  RANDT_TICK(0);
-  // Map::initialize: index grid = -1 (ndt_map.cpp:13-16)
-  if (grid) {
-    int4* g4 = reinterpret_cast<int4*>(grid);
-    const int n4 = out.n_slots >> 2;
-    if (((size_t)grid & 15) == 0) {
-      for (int i = tid; i < n4; i += BUILD_BLOCK) g4[i] = make_int4(-1, -1, -1, -1);
-      for (int i = (n4 << 2) + tid; i < out.n_slots; i += BUILD_BLOCK) grid[i] = -1;
-    } else {
-      for (int i = tid; i < out.n_slots; i += BUILD_BLOCK) grid[i] = -1;
-    }
-  }
-
-  RANDT_TICK(1);
-  // ---- load points (16 B / lane coalesced for packed xyzI), labels, label range
-  const bool vec4 = (stride == 4) && (((size_t)sp & 15) == 0);
-  int lmin = 0x7fffffff, lmax = (int)0x80000000;
-#define RANDT_FETCH_POINT(i, x, y, in)                                             \
-  do {                                                                             \
-    if (vec4) {                                                                    \
-      const float4 p_ = reinterpret_cast<const float4*>(sp)[i];                    \
-      x = p_.x;                                                                    \
-      y = p_.y;                                                                    \
-      in = ioff == 3 ? p_.w : (ioff == 2 ? p_.z : (ioff == 1 ? p_.y : p_.x));      \
-    } else {                                                                       \
-      const float* p_ = sp + (size_t)(i) * stride;                                 \
-      x = p_[0];                                                                   \
-      y = p_[1];                                                                   \
-      in = p_[ioff];                                                               \
-    }                                                                              \
-  } while (0)
-  for (int i = tid; i < n; i += BUILD_BLOCK) {
-    float x, y, in;
-    RANDT_FETCH_POINT(i, x, y, in);
-    (void)in;
-    const int32_t l = point_label(x, y, row_size, resolution);
-    lab[i] = l;
-    lmin = l < lmin ? l : lmin;
-    lmax = l > lmax ? l : lmax;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int a = __shfl_xor(lmin, off, 64), b = __shfl_xor(lmax, off, 64);
-    lmin = a < lmin ? a : lmin;
-    lmax = b > lmax ? b : lmax;
-  }
-  if (lane == 0) {
-    scratch[8 + wave] = lmin;
-    scratch[12 + wave] = lmax;
-  }
-  __syncthreads();
-  lmin = scratch[8];
-  lmax = scratch[12];
-#pragma unroll
-  for (int w = 1; w < 4; ++w) {
-    lmin = scratch[8 + w] < lmin ? scratch[8 + w] : lmin;
-    lmax = scratch[12 + w] > lmax ? scratch[12 + w] : lmax;
-  }
-  RANDT_TICK(2);
-  const long long range = n > 0 ? (long long)lmax - (long long)lmin + 1 : 0;
-  const bool fast = range <= (long long)nb_cap;
-  int nc = 0;  // number of clusters (distinct labels)
-
-  if (fast) {
-    const int nb = (int)range;
-    for (int b = tid; b < nb; b += BUILD_BLOCK) bins[b] = 0ull;
-    __syncthreads();
-    // per-(bin, wave) counts: wave w owns points [w*q, (w+1)*q)
-    const int q = (n + 3) >> 2;
-    const int w_beg = wave * q, w_end = (w_beg + q) < n ? (w_beg + q) : n;
-    for (int i = w_beg + lane; i < w_end; i += 64)
-      atomicAdd(&bins[lab[i] - lmin], 1ull << (16 * wave));
-    __syncthreads();
-    RANDT_TICK(3);
-    // block scan over bins: (points << 16 | non-empty) per thread chunk
-    const int chunk = (nb + BUILD_BLOCK - 1) / BUILD_BLOCK;
-    const int b0 = tid * chunk, b1 = (b0 + chunk) < nb ? (b0 + chunk) : nb;
-    int local = 0;
-    for (int b = b0; b < b1; ++b) {
-      const unsigned long long c = bins[b];
-      const int tot = (int)(c & 0xffff) + (int)((c >> 16) & 0xffff) + (int)((c >> 32) & 0xffff) + (int)((c >> 48) & 0xffff);
-      local += (tot << 16) | (tot > 0 ? 1 : 0);
-    }
-    int total;
-    int run = block_exclusive_scan_256(local, scratch, &total);
-    nc = total & 0xffff;
-    for (int b = b0; b < b1; ++b) {
-      const unsigned long long c = bins[b];
-      const int c0 = (int)(c & 0xffff), c1 = (int)((c >> 16) & 0xffff), c2 = (int)((c >> 32) & 0xffff), c3 = (int)((c >> 48) & 0xffff);
-      const int tot = c0 + c1 + c2 + c3;
-      const int start = run >> 16;
-      if (tot > 0) cstart[run & 0xffff] = start;
-      // packed start positions of the four waves inside this bin
-      bins[b] = (unsigned long long)start | ((unsigned long long)(start + c0) << 16) |
-                ((unsigned long long)(start + c0 + c1) << 32) | ((unsigned long long)(start + c0 + c1 + c2) << 48);
-      run += (tot << 16) | (tot > 0 ? 1 : 0);
-    }
-    if (tid == 0) cstart[nc] = n;
-    __syncthreads();
-    RANDT_TICK(4);
-    // stable placement: each wave walks its quarter in input order
-    for (int base = w_beg; base < w_end; base += 64) {
-      const int i = base + lane;
-      const bool valid = i < w_end;
-      const int b = valid ? lab[i] - lmin : -1;
-      float x = 0.f, y = 0.f, in = 0.f;
-      if (valid) RANDT_FETCH_POINT(i, x, y, in);
-      unsigned long long todo = __ballot(valid);
-      int pos = 0;
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lb = __shfl(b, leader, 64);
-        const unsigned long long m = __ballot(valid && b == lb);
-        const unsigned long long word = bins[lb];
-        if (b == lb) pos = (int)((word >> (16 * wave)) & 0xffff) + __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == leader) atomicAdd(&bins[lb], (unsigned long long)__popcll(m) << (16 * wave));
-        todo &= ~m;
-      }
-      if (valid) {
-        sx[pos] = x;
-        sy[pos] = y;
-        si[pos] = in;
-      }
-    }
-    __syncthreads();
-  } else {
-    // fallback: rank of (label, index) by counting -- unique keys => a permutation
-    for (int i = tid; i < n; i += BUILD_BLOCK) {
-      const int32_t li = lab[i];
-      int rank = 0;
-      for (int j = 0; j < n; ++j) {
-        const int32_t lj = lab[j];
-        rank += (lj < li || (lj == li && j < i)) ? 1 : 0;
-      }
-      float x, y, in;
-      RANDT_FETCH_POINT(i, x, y, in);
-      sx[rank] = x;
-      sy[rank] = y;
-      si[rank] = in;
-      cstart[rank] = li;  // sorted labels, parked in cstart until the heads are known
-    }
-    __syncthreads();
-    // cluster heads from the sorted labels (cstart[] is rewritten in place: a head's cluster index
-    // never exceeds its position, and positions are consumed in ascending order per thread chunk,
-    // so first copy the labels of this chunk's range to registers-free scratch in lab[])
-    for (int p = tid; p < n; p += BUILD_BLOCK) lab[p] = cstart[p];
-    __syncthreads();
-    const int chunk = (n + BUILD_BLOCK - 1) / BUILD_BLOCK;
-    const int b0 = tid * chunk, b1 = (b0 + chunk) < n ? (b0 + chunk) : n;
-    int heads = 0;
-    for (int p = b0; p < b1; ++p) heads += (p == 0 || lab[p] != lab[p - 1]) ? 1 : 0;
-    int cbase = block_exclusive_scan_256(heads, scratch, &nc);
-    for (int p = b0; p < b1; ++p)
-      if (p == 0 || lab[p] != lab[p - 1]) cstart[cbase++] = p;
-    if (tid == 0) cstart[nc] = n;
-    __syncthreads();
-  }
-
-  RANDT_TICK(5);
-  // Map::insertCluster per cluster in label order (ndt_map.cpp:238-245)
+// Per-cluster cell statistics with one lane per cluster, strictly in cluster order: the reference
+// arithmetic spelled out once.  Used for the rare case where a cluster mean falls outside the map
+// (the compact cell index of every later cluster then shifts), after the fast path below.
+__device__ void cluster_stats_sequential(const float* sx, const float* sy, const float* si, const int* cstart, int nc,
+                                         const MapView& out, randt_cell* cells, int32_t* grid, int* scratch, int* n_cells_out) {
+  const int tid = threadIdx.x;
   int n_cells = 0;
   for (int c0 = 0; c0 < nc; c0 += BUILD_BLOCK) {
     const int c = c0 + tid;
@@ -242,10 +57,8 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     if (c < nc) {
       const int s = cstart[c], e = cstart[c + 1];
       const int k = e - s;
-      // Cell::addPointCloud: n_points_(0) + size > min_points_per_cell_ (ndt_cell.cpp:26)
       if ((long long)k > (long long)out.min_points) {
         float m0 = 0.f, m1 = 0.f, m2 = 0.f, maxi = 0.f;
-#pragma unroll 8
         for (int j = s; j < e; ++j) {
           const float in = si[j];
           m0 += sx[j];
@@ -258,7 +71,6 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
         m1 = m1 / nf;
         m2 = m2 / nf;
         float c00 = 0.f, c11 = 0.f, c22 = 0.f, c01 = 0.f, c02 = 0.f, c12 = 0.f;
-#pragma unroll 8
         for (int j = s; j < e; ++j) {
           const float d0 = sx[j] - m0, d1 = sy[j] - m1, d2 = si[j] - m2;
           c00 += (d0 * d0);
@@ -293,6 +105,349 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       if (grid) atomicMax(&grid[slot], idx);
     }
     n_cells += tot;
+  }
+  *n_cells_out = n_cells;
+}
+
+// One workgroup per scan.  labelClouds' order (ascending label, input order inside a label) is
+// produced by a STABLE counting sort: every wavefront owns a contiguous quarter of the points and
+// keeps them in registers (PPT per lane); a 64-bit LDS word per label bin packs the four per-wave
+// counts (4 x u16).  While counting, the lanes of a 64-point step that share a label find each
+// other with one ballot per label bit, so every point learns its rank inside (label, wave) right
+// there; a block scan turns the counts into per-(bin, wave) start positions and the placement is
+// then a plain scatter into label-sorted SoA arrays.  Label ranges that do not fit the LDS bins
+// (points far outside max_range) fall back to an O(N^2/256) rank-by-counting pass.
+//
+// Cell statistics: the fp32 sums must run in the reference's sequential point order to be
+// bit-identical, so a cluster cannot be split over points -- but its ten accumulator chains
+// (3 sums + max, then 6 covariance sums) are independent: a group of 8 lanes owns a cluster and
+// each lane walks ONE chain.  Clusters are handed to the 32 groups in descending size so that a
+// round's wavefronts finish together.
+// Dynamic LDS: sx | sy | si [npad] | cstart[npad+2] | aux (bins u64[nb_cap] / labels / order+prefix) | scratch
+template <int PPT, bool KEEP>
+__global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restrict__ pts, int pitch,
+                                                           const int32_t* __restrict__ n_pts_arr, int stride,
+                                                           int ioff, int row_size, float resolution, MapView out,
+                                                           int first_map, int npad, int nb_cap, int aux_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sx = reinterpret_cast<float*>(smem);  // points in labelClouds order
+  float* sy = sx + npad;
+  float* si = sy + npad;
+  int* cstart = reinterpret_cast<int*>(si + npad);                            // [npad + 1] (+1 pad)
+  unsigned long long* bins = reinterpret_cast<unsigned long long*>(cstart + npad + 2);
+  int32_t* lab = reinterpret_cast<int32_t*>(bins);                            // fallback only (aliases bins)
+  uint16_t* order = reinterpret_cast<uint16_t*>(bins);                        // after placement (aliases bins)
+  uint16_t* pre = order + npad;
+  int* scratch = reinterpret_cast<int*>(reinterpret_cast<char*>(bins) + aux_bytes);  // [16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int scan = blockIdx.x;
+  const int map = first_map + scan;
+  int n = n_pts_arr ? n_pts_arr[scan] : pitch;
+  n = n < 0 ? 0 : (n > pitch ? pitch : n);
+  const float* sp = pts + (size_t)scan * pitch * stride;
+  int32_t* grid = out.grid ? out.grid + (size_t)map * out.n_slots : nullptr;
+  randt_cell* cells = out.cells + (size_t)map * out.cap;
+
+  RANDT_TICK(0);
+  // Map::initialize: index grid = -1 (ndt_map.cpp:13-16)
+  if (grid) {
+    int4* g4 = reinterpret_cast<int4*>(grid);
+    const int n4 = out.n_slots >> 2;
+    if (((size_t)grid & 15) == 0) {
+      for (int i = tid; i < n4; i += BUILD_BLOCK) g4[i] = make_int4(-1, -1, -1, -1);
+      for (int i = (n4 << 2) + tid; i < out.n_slots; i += BUILD_BLOCK) grid[i] = -1;
+    } else {
+      for (int i = tid; i < out.n_slots; i += BUILD_BLOCK) grid[i] = -1;
+    }
+  }
+
+  RANDT_TICK(1);
+  // ---- load points (16 B / lane coalesced for packed xyzI), labels, label range.  Wave w owns the
+  // contiguous quarter [w*q, (w+1)*q) of the input; lane l holds points w*q + 64*j + l.
+  const bool vec4 = (stride == 4) && (((size_t)sp & 15) == 0);
+  int lmin = 0x7fffffff, lmax = (int)0x80000000;
+#define RANDT_FETCH_POINT(i, x, y, in)                                             \
+  do {                                                                             \
+    if (vec4) {                                                                    \
+      const float4 p_ = reinterpret_cast<const float4*>(sp)[i];                    \
+      x = p_.x;                                                                    \
+      y = p_.y;                                                                    \
+      in = ioff == 3 ? p_.w : (ioff == 2 ? p_.z : (ioff == 1 ? p_.y : p_.x));      \
+    } else {                                                                       \
+      const float* p_ = sp + (size_t)(i) * stride;                                 \
+      x = p_[0];                                                                   \
+      y = p_[1];                                                                   \
+      in = p_[ioff];                                                               \
+    }                                                                              \
+  } while (0)
+  const int q = (n + 3) >> 2;
+  const int w_beg = wave * q, w_end = (w_beg + q) < n ? (w_beg + q) : n;
+  float px[KEEP ? PPT : 1], py[KEEP ? PPT : 1], pin[KEEP ? PPT : 1];
+  int32_t pl[PPT];  // label, later: rank inside (label, wave)
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int i = w_beg + 64 * j + lane;
+    pl[j] = 0;
+    if (i < w_end) {
+      float x, y, in;
+      RANDT_FETCH_POINT(i, x, y, in);
+      if (KEEP) {
+        px[j] = x;
+        py[j] = y;
+        pin[j] = in;
+      }
+      const int32_t l = point_label(x, y, row_size, resolution);
+      pl[j] = l;
+      lmin = l < lmin ? l : lmin;
+      lmax = l > lmax ? l : lmax;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int a = __shfl_xor(lmin, off, 64), b = __shfl_xor(lmax, off, 64);
+    lmin = a < lmin ? a : lmin;
+    lmax = b > lmax ? b : lmax;
+  }
+  if (lane == 0) {
+    scratch[8 + wave] = lmin;
+    scratch[12 + wave] = lmax;
+  }
+  __syncthreads();
+  lmin = scratch[8];
+  lmax = scratch[12];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    lmin = scratch[8 + w] < lmin ? scratch[8 + w] : lmin;
+    lmax = scratch[12 + w] > lmax ? scratch[12 + w] : lmax;
+  }
+  RANDT_TICK(2);
+  const long long range = n > 0 ? (long long)lmax - (long long)lmin + 1 : 0;
+  const bool fast = range <= (long long)nb_cap;
+  int nc = 0;  // number of clusters (distinct labels)
+
+  if (fast) {
+    const int nb = (int)range;
+    for (int b = tid; b < nb; b += BUILD_BLOCK) bins[b] = 0ull;
+    __syncthreads();
+    // ---- count: per-(bin, wave) totals, and for every point its rank inside (bin, wave)
+    const int nbits = nb > 1 ? 32 - __clz(nb - 1) : 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int sh = 16 * wave;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = w_beg + 64 * j + lane;
+      const bool valid = i < w_end;
+      const int b = pl[j] - lmin;
+      unsigned long long mask = __ballot(valid);  // lanes of this step with my label
+      if (mask == 0ull) break;                    // wave-uniform: this quarter is exhausted
+      for (int bit = 0; bit < nbits; ++bit) {
+        const bool one = (b >> bit) & 1;
+        const unsigned long long m = __ballot(valid && one);
+        mask &= one ? m : ~m;
+      }
+      int field = 0;
+      const int leader = __ffsll((long long)mask) - 1;
+      if (valid && lane == leader) {
+        const unsigned long long old = atomicAdd(&bins[b], (unsigned long long)__popcll(mask) << sh);
+        field = (int)((old >> sh) & 0xffff);
+      }
+      field = __shfl(field, valid ? leader : lane, 64);
+      pl[j] = b | ((field + __popcll(mask & lt)) << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
+    }
+    __syncthreads();
+    RANDT_TICK(3);
+    // block scan over bins: (points << 16 | non-empty) per thread chunk
+    const int chunk = (nb + BUILD_BLOCK - 1) / BUILD_BLOCK;
+    const int b0 = tid * chunk, b1 = (b0 + chunk) < nb ? (b0 + chunk) : nb;
+    int local = 0;
+    for (int b = b0; b < b1; ++b) {
+      const unsigned long long c = bins[b];
+      const int tot = (int)(c & 0xffff) + (int)((c >> 16) & 0xffff) + (int)((c >> 32) & 0xffff) + (int)((c >> 48) & 0xffff);
+      local += (tot << 16) | (tot > 0 ? 1 : 0);
+    }
+    int total;
+    int run = block_exclusive_scan_256(local, scratch, &total);
+    nc = total & 0xffff;
+    for (int b = b0; b < b1; ++b) {
+      const unsigned long long c = bins[b];
+      const int c0 = (int)(c & 0xffff), c1 = (int)((c >> 16) & 0xffff), c2 = (int)((c >> 32) & 0xffff), c3 = (int)((c >> 48) & 0xffff);
+      const int tot = c0 + c1 + c2 + c3;
+      const int start = run >> 16;
+      if (tot > 0) cstart[run & 0xffff] = start;
+      // packed start positions of the four waves inside this bin
+      bins[b] = (unsigned long long)start | ((unsigned long long)(start + c0) << 16) |
+                ((unsigned long long)(start + c0 + c1) << 32) | ((unsigned long long)(start + c0 + c1 + c2) << 48);
+      run += (tot << 16) | (tot > 0 ? 1 : 0);
+    }
+    if (tid == 0) cstart[nc] = n;
+    __syncthreads();
+    RANDT_TICK(4);
+    // ---- placement: position = start of (bin, wave) + rank inside it
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = w_beg + 64 * j + lane;
+      if (i < w_end) {
+        const int b = pl[j] & 0xffff, r = (int)((unsigned)pl[j] >> 16);
+        const int pos = (int)((bins[b] >> sh) & 0xffff) + r;
+        float x, y, in;
+        if (KEEP) {
+          x = px[j];
+          y = py[j];
+          in = pin[j];
+        } else {
+          RANDT_FETCH_POINT(i, x, y, in);
+        }
+        sx[pos] = x;
+        sy[pos] = y;
+        si[pos] = in;
+      }
+    }
+    __syncthreads();
+  } else {
+    // fallback: rank of (label, index) by counting -- unique keys => a permutation
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = w_beg + 64 * j + lane;
+      if (i < w_end) lab[i] = pl[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += BUILD_BLOCK) {
+      const int32_t li = lab[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const int32_t lj = lab[j];
+        rank += (lj < li || (lj == li && j < i)) ? 1 : 0;
+      }
+      float x, y, in;
+      RANDT_FETCH_POINT(i, x, y, in);
+      sx[rank] = x;
+      sy[rank] = y;
+      si[rank] = in;
+      cstart[rank] = li;  // sorted labels, parked in cstart until the heads are known
+    }
+    __syncthreads();
+    // cluster heads from the sorted labels (cstart[] is rewritten in place, so park the sorted labels in lab[])
+    for (int p = tid; p < n; p += BUILD_BLOCK) lab[p] = cstart[p];
+    __syncthreads();
+    const int chunk = (n + BUILD_BLOCK - 1) / BUILD_BLOCK;
+    const int b0 = tid * chunk, b1 = (b0 + chunk) < n ? (b0 + chunk) : n;
+    int heads = 0;
+    for (int p = b0; p < b1; ++p) heads += (p == 0 || lab[p] != lab[p - 1]) ? 1 : 0;
+    int cbase = block_exclusive_scan_256(heads, scratch, &nc);
+    for (int p = b0; p < b1; ++p)
+      if (p == 0 || lab[p] != lab[p - 1]) cstart[cbase++] = p;
+    if (tid == 0) cstart[nc] = n;
+    __syncthreads();
+  }
+
+  RANDT_TICK(5);
+  // ---- Map::insertCluster per cluster in label order (ndt_map.cpp:238-245)
+  // compact cell index of cluster c if every accepted-by-size cluster lands inside the map (the normal case)
+  int n_cells = 0;
+  for (int c0 = 0; c0 < nc; c0 += BUILD_BLOCK) {
+    const int c = c0 + tid;
+    // Cell::addPointCloud: n_points_(0) + size > min_points_per_cell_ (ndt_cell.cpp:26)
+    const int big = (c < nc && (long long)(cstart[c + 1] - cstart[c]) > (long long)out.min_points) ? 1 : 0;
+    int tot;
+    const int idx = n_cells + block_exclusive_scan_256(big, scratch, &tot);
+    if (c < nc) pre[c] = (uint16_t)(big ? (idx < 0xffff ? idx : 0xfffe) : 0xffff);
+    n_cells += tot;
+  }
+  // hand-out order: descending size (ties by index) when one thread per cluster can rank them
+  if (nc <= BUILD_BLOCK) {
+    if (tid < nc) {
+      const int k = cstart[tid + 1] - cstart[tid];
+      int rank = 0;
+      for (int o = 0; o < nc; ++o) {
+        const int ko = cstart[o + 1] - cstart[o];
+        rank += (ko > k || (ko == k && o < tid)) ? 1 : 0;
+      }
+      order[rank] = (uint16_t)tid;
+    }
+  } else {
+    for (int c = tid; c < nc; c += BUILD_BLOCK) order[c] = (uint16_t)c;
+  }
+  if (tid == 0) scratch[4] = 0;  // "a cluster mean fell outside the map"
+  __syncthreads();
+
+  const int g = tid & 7, gbase = lane & ~7, group = tid >> 3;
+  // pass-1 chain of lane g: sum x, sum y, sum i, max i;  pass-2 chain: c00 c11 c22 c01 c02 c12
+  const float* p1 = g == 0 ? sx : (g == 1 ? sy : si);
+  const float* pa = (g == 0 || g == 3 || g == 4) ? sx : ((g == 1 || g == 5) ? sy : si);
+  const float* pb = (g == 0) ? sx : ((g == 1 || g == 3) ? sy : si);
+  const int ia = (g == 0 || g == 3 || g == 4) ? 0 : ((g == 1 || g == 5) ? 1 : 2);
+  const int ib = (g == 0) ? 0 : ((g == 1 || g == 3) ? 1 : 2);
+  for (int r0 = 0; r0 < nc; r0 += BUILD_BLOCK / 8) {
+    const int oc = r0 + group;
+    const int c = oc < nc ? (int)order[oc] : -1;
+    int s = 0, e = 0, target = 0xffff;
+    if (c >= 0) {
+      target = pre[c];
+      if (target != 0xffff) {
+        s = cstart[c];
+        e = cstart[c + 1];
+      }
+    }
+    const int k = e - s;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int j = s; j < e; ++j) {
+      const float v = p1[j];
+      const float add = acc + v;
+      const float mx = v > acc ? v : acc;
+      acc = g == 3 ? mx : add;
+    }
+    const float nf = (float)(uint32_t)k;
+    const float mean = acc / nf;  // lanes 0..2; lane 3 holds the max intensity
+    const float m0 = __shfl(mean, gbase + 0, 64), m1 = __shfl(mean, gbase + 1, 64), m2 = __shfl(mean, gbase + 2, 64);
+    const float maxi = __shfl(acc, gbase + 3, 64);
+    const float ma = ia == 0 ? m0 : (ia == 1 ? m1 : m2);
+    const float mb = ib == 0 ? m0 : (ib == 1 ? m1 : m2);
+    float cacc = 0.f;
+#pragma unroll 4
+    for (int j = s; j < e; ++j) {
+      const float da = pa[j] - ma, db = pb[j] - mb;
+      cacc += (da * db);
+    }
+    const float cv = cacc / nf;
+    const float c00 = __shfl(cv, gbase + 0, 64), c11 = __shfl(cv, gbase + 1, 64), c22 = __shfl(cv, gbase + 2, 64);
+    const float c01 = __shfl(cv, gbase + 3, 64), c02 = __shfl(cv, gbase + 4, 64), c12 = __shfl(cv, gbase + 5, 64);
+    if (g == 0 && k > 0) {
+      randt_cell cell;
+      cell.mean[0] = m0;
+      cell.mean[1] = m1;
+      cell.mean[2] = m2;
+      cell.cov[0] = c00;
+      cell.cov[1] = c01;
+      cell.cov[2] = c02;
+      cell.cov[3] = c11;
+      cell.cov[4] = c12;
+      cell.cov[5] = c22;
+      cell.n = (uint32_t)k;
+      cell.max_intensity = maxi;
+      cell.reserved = 0;
+      cell_regularize(cell);
+      const uint32_t slot = coord_to_index(out, cell.mean[0], cell.mean[1]);
+      if (slot < (uint32_t)out.n_slots && target != 0xfffe) {  // reference: vector::at throws otherwise
+        if (target < out.cap) {
+          store_cell(cells + target, cell);
+          // later cluster overwrites the slot, both cells stay in grid_ (quirk A.7-5)
+          if (grid) atomicMax(&grid[slot], target);
+        }
+      } else {
+        scratch[4] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (scratch[4]) {
+    // rare: indices shift behind a dropped cluster (or > 65534 cells) -- redo in strict cluster order
+    if (grid) {
+      for (int i = tid; i < out.n_slots; i += BUILD_BLOCK) grid[i] = -1;
+    }
+    __syncthreads();
+    cluster_stats_sequential(sx, sy, si, cstart, nc, out, cells, grid, scratch, &n_cells);
   }
   RANDT_TICK(6);
   if (tid == 0) out.counts[map] = n_cells < out.cap ? n_cells : out.cap;
@@ -402,19 +557,35 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   const int row_size = (int)sqrt((double)cp->n_clusters);
   const float resolution = cp->max_range * 2 / (float)row_size;
   // label bins: coordinates up to ~1.5 x max_range in fast mode, anything else takes the fallback
-  const size_t fixed_bytes = (size_t)npad * 16 + (size_t)(npad + 2) * 4 + 128;
+  const size_t fixed_bytes = (size_t)npad * 12 + (size_t)(npad + 2) * 4 + 128;
+  // aux region: label bins (8 B each) during the sort, then order + index prefix (2 x u16 per cluster);
+  // the fallback parks the labels there (4 B per point)
+  const size_t aux_min = (size_t)npad * 4;
   const int h = (3 * row_size) / 4 + 2;
   int nb_want = 2 * (h + row_size * h) + 1;
-  size_t budget = (size_t)ctx->lds_limit / 2;
+  if (nb_want > 65535) nb_want = 65535;  // bin index is packed into 16 bits
+  size_t budget = (size_t)ctx->lds_limit / 3;
+  if (fixed_bytes + (size_t)nb_want * 8 > budget) budget = (size_t)ctx->lds_limit / 2;
   if (fixed_bytes + (size_t)nb_want * 8 > budget) budget = (size_t)ctx->lds_limit;
-  if (fixed_bytes + 1024 > budget) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel", hipSuccess);
+  if (fixed_bytes + aux_min + 1024 > budget) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel", hipSuccess);
   const size_t room = (budget - fixed_bytes) / 8;
   const int nb_cap = (int)((size_t)nb_want < room ? (size_t)nb_want : room);
-  const size_t lds = fixed_bytes + (size_t)nb_cap * 8;
-  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_ndt_build, dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch, d_n_points,
-                     stride, ioff, row_size, resolution, out, first_map, npad, nb_cap);
+  size_t aux = (size_t)nb_cap * 8;
+  if (aux < aux_min) aux = aux_min;
+  aux = (aux + 15) & ~(size_t)15;
+  const size_t lds = fixed_bytes + aux;
+#define RANDT_BUILD_LAUNCH(PPT, KEEP)                                                                                      \
+  do {                                                                                                                     \
+    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<PPT, KEEP>),                        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+    hipLaunchKernelGGL((k_ndt_build<PPT, KEEP>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,      \
+                       d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux);            \
+  } while (0)
+  // points per lane: a wave owns a quarter of the scan
+  if (pitch <= 2048) RANDT_BUILD_LAUNCH(8, true);
+  else if (pitch <= 4096) RANDT_BUILD_LAUNCH(16, false);
+  else RANDT_BUILD_LAUNCH(28, false);
+#undef RANDT_BUILD_LAUNCH
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
