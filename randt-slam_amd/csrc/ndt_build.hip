@@ -130,9 +130,11 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
                                                            int ioff, int row_size, float resolution, MapView out,
                                                            int first_map, int npad, int nb_cap, int aux_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sx = reinterpret_cast<float*>(smem);  // points in labelClouds order
-  float* sy = sx + npad;
-  float* si = sy + npad;
+  // points in labelClouds order; the three arrays are shifted by 16 banks against each other because the
+  // lanes of a cluster group read x[j], y[j] and i[j] in the same instruction
+  float* sx = reinterpret_cast<float*>(smem);
+  float* sy = sx + npad + 16;
+  float* si = sy + npad + 16;
   int* cstart = reinterpret_cast<int*>(si + npad);                            // [npad + 1] (+1 pad)
   unsigned long long* bins = reinterpret_cast<unsigned long long*>(cstart + npad + 2);
   int32_t* lab = reinterpret_cast<int32_t*>(bins);                            // fallback only (aliases bins)
@@ -354,11 +356,13 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     if (c < nc) pre[c] = (uint16_t)(big ? (idx < 0xffff ? idx : 0xfffe) : 0xffff);
     n_cells += tot;
   }
+  RANDT_TICK(6);
   // hand-out order: descending size (ties by index) when one thread per cluster can rank them
   if (nc <= BUILD_BLOCK) {
     if (tid < nc) {
       const int k = cstart[tid + 1] - cstart[tid];
       int rank = 0;
+#pragma unroll 8
       for (int o = 0; o < nc; ++o) {
         const int ko = cstart[o + 1] - cstart[o];
         rank += (ko > k || (ko == k && o < tid)) ? 1 : 0;
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   }
   if (tid == 0) scratch[4] = 0;  // "a cluster mean fell outside the map"
   __syncthreads();
+  RANDT_TICK(7);
 
   const int g = tid & 7, gbase = lane & ~7, group = tid >> 3;
   // pass-1 chain of lane g: sum x, sum y, sum i, max i;  pass-2 chain: c00 c11 c22 c01 c02 c12
@@ -390,22 +395,21 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       }
     }
     const int k = e - s;
-    float acc = 0.f;
-#pragma unroll 4
+    float acc = 0.f, accm = 0.f;  // two independent one-op chains per point: sum (lanes 0..2) and max (lane 3)
+#pragma unroll 8
     for (int j = s; j < e; ++j) {
       const float v = p1[j];
-      const float add = acc + v;
-      const float mx = v > acc ? v : acc;
-      acc = g == 3 ? mx : add;
+      acc += v;
+      accm = v > accm ? v : accm;
     }
     const float nf = (float)(uint32_t)k;
-    const float mean = acc / nf;  // lanes 0..2; lane 3 holds the max intensity
+    const float mean = acc / nf;
     const float m0 = __shfl(mean, gbase + 0, 64), m1 = __shfl(mean, gbase + 1, 64), m2 = __shfl(mean, gbase + 2, 64);
-    const float maxi = __shfl(acc, gbase + 3, 64);
+    const float maxi = __shfl(accm, gbase + 3, 64);
     const float ma = ia == 0 ? m0 : (ia == 1 ? m1 : m2);
     const float mb = ib == 0 ? m0 : (ib == 1 ? m1 : m2);
     float cacc = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int j = s; j < e; ++j) {
       const float da = pa[j] - ma, db = pb[j] - mb;
       cacc += (da * db);
@@ -441,6 +445,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     }
   }
   __syncthreads();
+  RANDT_TICK(8);
   if (scratch[4]) {
     // rare: indices shift behind a dropped cluster (or > 65534 cells) -- redo in strict cluster order
     if (grid) {
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     __syncthreads();
     cluster_stats_sequential(sx, sy, si, cstart, nc, out, cells, grid, scratch, &n_cells);
   }
-  RANDT_TICK(6);
+  RANDT_TICK(9);
   if (tid == 0) out.counts[map] = n_cells < out.cap ? n_cells : out.cap;
 }
 
@@ -556,19 +561,21 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   // Grid::cluster (grid.cpp:8-9)
   const int row_size = (int)sqrt((double)cp->n_clusters);
   const float resolution = cp->max_range * 2 / (float)row_size;
-  // label bins: coordinates up to ~1.5 x max_range in fast mode, anything else takes the fallback
-  const size_t fixed_bytes = (size_t)npad * 12 + (size_t)(npad + 2) * 4 + 128;
+  // label bins: coordinates inside +-max_range (what RadarPreprocessor hands over) in fast mode: int(x/res) and
+  // int(y/res) in [-row/2, row/2]; anything wider takes the fallback
+  const size_t fixed_bytes = (size_t)npad * 12 + 128 + (size_t)(npad + 2) * 4 + 128;
   // aux region: label bins (8 B each) during the sort, then order + index prefix (2 x u16 per cluster);
   // the fallback parks the labels there (4 B per point)
   const size_t aux_min = (size_t)npad * 4;
-  const int h = (3 * row_size) / 4 + 2;
-  int nb_want = 2 * (h + row_size * h) + 1;
+  int nb_want = row_size * row_size + 2 * row_size + 2;
   if (nb_want > 65535) nb_want = 65535;  // bin index is packed into 16 bits
+  // smallest occupancy tier (3, 2, 1 workgroups per CU) that holds all the bins
+  const size_t want = fixed_bytes + ((size_t)nb_want * 8 > aux_min ? (size_t)nb_want * 8 : aux_min) + 16;
   size_t budget = (size_t)ctx->lds_limit / 3;
-  if (fixed_bytes + (size_t)nb_want * 8 > budget) budget = (size_t)ctx->lds_limit / 2;
-  if (fixed_bytes + (size_t)nb_want * 8 > budget) budget = (size_t)ctx->lds_limit;
+  if (want > budget) budget = (size_t)ctx->lds_limit / 2;
+  if (want > budget) budget = (size_t)ctx->lds_limit;
   if (fixed_bytes + aux_min + 1024 > budget) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel", hipSuccess);
-  const size_t room = (budget - fixed_bytes) / 8;
+  const size_t room = (budget - fixed_bytes - 16) / 8;
   const int nb_cap = (int)((size_t)nb_want < room ? (size_t)nb_want : room);
   size_t aux = (size_t)nb_cap * 8;
   if (aux < aux_min) aux = aux_min;

@@ -14,5 +14,5 @@ for _ in range(3):
 ctx.synchronize()
 out = (C.c_longlong*32)()
 lib.randt_debug_timing(out)
-t = np.array(out[:7], dtype=np.float64)
+t = np.array(out[:10], dtype=np.float64)
 print("phase us:", np.diff(t)*0.01)
