@@ -135,12 +135,12 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   float* sx = reinterpret_cast<float*>(smem);
   float* sy = sx + npad + 16;
   float* si = sy + npad + 16;
-  int* cstart = reinterpret_cast<int*>(si + npad);                            // [npad + 1] (+1 pad)
+  int* cstart = reinterpret_cast<int*>(si + npad + 16);                       // [npad + 1] (+1 pad)
   unsigned long long* bins = reinterpret_cast<unsigned long long*>(cstart + npad + 2);
   int32_t* lab = reinterpret_cast<int32_t*>(bins);                            // fallback only (aliases bins)
   uint16_t* order = reinterpret_cast<uint16_t*>(bins);                        // after placement (aliases bins)
   uint16_t* pre = order + npad;
-  int* scratch = reinterpret_cast<int*>(reinterpret_cast<char*>(bins) + aux_bytes);  // [16]
+  int* scratch = reinterpret_cast<int*>(reinterpret_cast<char*>(bins) + aux_bytes);  // [48]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scan = blockIdx.x;
@@ -357,22 +357,33 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     n_cells += tot;
   }
   RANDT_TICK(6);
-  // hand-out order: descending size (ties by index) when one thread per cluster can rank them
-  if (nc <= BUILD_BLOCK) {
-    if (tid < nc) {
-      const int k = cstart[tid + 1] - cstart[tid];
-      int rank = 0;
-#pragma unroll 8
-      for (int o = 0; o < nc; ++o) {
-        const int ko = cstart[o + 1] - cstart[o];
-        rank += (ko > k || (ko == k && o < tid)) ? 1 : 0;
-      }
-      order[rank] = (uint16_t)tid;
-    }
-  } else {
-    for (int c = tid; c < nc; c += BUILD_BLOCK) order[c] = (uint16_t)c;
-  }
+  // hand-out order: roughly descending size (32 size classes, LDS counting sort).  The order only decides
+  // which clusters share a round -- every cluster's arithmetic and output index are fixed -- so the
+  // arbitrary order inside a class does not touch the result.
+  int* bcount = scratch + 16;  // [32]
+  if (tid < 32) bcount[tid] = 0;
   if (tid == 0) scratch[4] = 0;  // "a cluster mean fell outside the map"
+  __syncthreads();
+  for (int c = tid; c < nc; c += BUILD_BLOCK) {
+    const int kc = (cstart[c + 1] - cstart[c]) >> 3;
+    atomicAdd(&bcount[31 - (kc < 31 ? kc : 31)], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int v = tid < 32 ? bcount[tid] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (tid < 32) bcount[tid] = incl - v;
+  }
+  __syncthreads();
+  for (int c = tid; c < nc; c += BUILD_BLOCK) {
+    const int kc = (cstart[c + 1] - cstart[c]) >> 3;
+    order[atomicAdd(&bcount[31 - (kc < 31 ? kc : 31)], 1)] = (uint16_t)c;
+  }
   __syncthreads();
   RANDT_TICK(7);
 
@@ -395,6 +406,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       }
     }
     const int k = e - s;
+    // per-lane trip counts: the hardware masks the lanes of finished clusters (cheaper than selecting per point)
     float acc = 0.f, accm = 0.f;  // two independent one-op chains per point: sum (lanes 0..2) and max (lane 3)
 #pragma unroll 8
     for (int j = s; j < e; ++j) {
@@ -402,6 +414,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       acc += v;
       accm = v > accm ? v : accm;
     }
+    if (r0 == 0) RANDT_TICK(10);
     const float nf = (float)(uint32_t)k;
     const float mean = acc / nf;
     const float m0 = __shfl(mean, gbase + 0, 64), m1 = __shfl(mean, gbase + 1, 64), m2 = __shfl(mean, gbase + 2, 64);
@@ -414,6 +427,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       const float da = pa[j] - ma, db = pb[j] - mb;
       cacc += (da * db);
     }
+    if (r0 == 0) RANDT_TICK(11);
     const float cv = cacc / nf;
     const float c00 = __shfl(cv, gbase + 0, 64), c11 = __shfl(cv, gbase + 1, 64), c22 = __shfl(cv, gbase + 2, 64);
     const float c01 = __shfl(cv, gbase + 3, 64), c02 = __shfl(cv, gbase + 4, 64), c12 = __shfl(cv, gbase + 5, 64);
@@ -443,6 +457,8 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
         scratch[4] = 1;
       }
     }
+    if (r0 == 0) RANDT_TICK(12);
+    if (r0 == 32) RANDT_TICK(13);
   }
   __syncthreads();
   RANDT_TICK(8);
@@ -563,7 +579,7 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   const float resolution = cp->max_range * 2 / (float)row_size;
   // label bins: coordinates inside +-max_range (what RadarPreprocessor hands over) in fast mode: int(x/res) and
   // int(y/res) in [-row/2, row/2]; anything wider takes the fallback
-  const size_t fixed_bytes = (size_t)npad * 12 + 128 + (size_t)(npad + 2) * 4 + 128;
+  const size_t fixed_bytes = (size_t)npad * 12 + 192 + (size_t)(npad + 2) * 4 + 256;
   // aux region: label bins (8 B each) during the sort, then order + index prefix (2 x u16 per cluster);
   // the fallback parks the labels there (4 B per point)
   const size_t aux_min = (size_t)npad * 4;

@@ -16,3 +16,5 @@ out = (C.c_longlong*32)()
 lib.randt_debug_timing(out)
 t = np.array(out[:10], dtype=np.float64)
 print("phase us:", np.diff(t)*0.01)
+r = np.array([out[7], out[10], out[11], out[12], out[13], out[8]], dtype=np.float64)
+print("rounds: pass1, pass2, finish(r0), round1, rest us:", np.diff(r)*0.01)
