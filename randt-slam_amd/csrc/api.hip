@@ -136,7 +136,7 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
     ctx->lds_limit = lds;
   if (const char* e = getenv("RANDT_SOLVE_BLOCK")) {
     int b = atoi(e);
-    if (b == 64 || b == 128 || b == 256) ctx->solve_block = b;
+    if (b == 64 || b == 128) ctx->solve_block = b;
   }
   *out = ctx;
   return RANDT_OK;
