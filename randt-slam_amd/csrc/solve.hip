@@ -53,6 +53,11 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   return fma(0.5 * y, e, y);
 }
 
+// The solver state is the same in every lane, but it lives in VGPRs (fp64 has no scalar unit), so the compiler
+// must treat a branch on it as divergent: exec-mask bookkeeping and select/copy merges at every join.  uni()
+// turns such a condition into a scalar one (one compare into an SGPR pair + s_cmp): real scalar branches.
+__device__ __forceinline__ bool uni(bool c) { return __ballot(c) != 0ull; }
+
 // ---------------------------------------------------------------- Sophus SE(2) pieces ----------
 __device__ __forceinline__ void so2_normalize(double& c, double& s) {
   const double len = sqrt(c * c + s * s);
@@ -66,7 +71,7 @@ __device__ __forceinline__ void se2_plus(const double* x, const double* d, doubl
   double c = cos(theta), s = sin(theta);
   so2_normalize(c, s);
   double sbt, omcbt;
-  if (fabs(theta) < 1e-10) {
+  if (uni(fabs(theta) < 1e-10)) {
     const double tsq = theta * theta;
     sbt = 1.0 - (1.0 / 6.0) * tsq;
     omcbt = 0.5 * theta - (1.0 / 24.0) * theta * tsq;
@@ -79,7 +84,7 @@ __device__ __forceinline__ void se2_plus(const double* x, const double* d, doubl
   double re = x[0] * c - x[1] * s;
   double im = x[0] * s + x[1] * c;
   const double sq = re * re + im * im;
-  if (sq != 1.0) {
+  if (uni(sq != 1.0)) {
     const double scale = 2.0 / (1.0 + sq);
     re *= scale;
     im *= scale;
@@ -402,7 +407,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
       }
     }
     out.v[0] = mx > 0.0 ? sqrt(mx) : 0.0;  // max raw residual
-    return badf == 0.0;
+    return uni(badf == 0.0);
   }
   wave_sum10(acc);
   if (WAVES > 1) {
@@ -425,7 +430,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   }
 #pragma unroll
   for (int i = 0; i < 10; ++i) out.v[i] = acc[i];
-  return badf == 0.0 && isfinite(acc[0]);
+  return uni(badf == 0.0 && isfinite(acc[0]));
 }
 
 // g = T g_b, H = T G T^T for the parameterisation at ambient point x (T is NT x 3, see header).
@@ -524,8 +529,8 @@ __device__ __forceinline__ bool gradient_converged(const double* x, const double
   double gm = 0.0;
 #pragma unroll
   for (int i = 0; i < NT; ++i) gm = fabs(g[i]) > gm ? fabs(g[i]) : gm;
-  if (PARAM != RANDT_PARAM_MANIFOLD) return gm <= gtol;
-  if (0.4 * gm > gtol && gm < 3.0) return false;
+  if (PARAM != RANDT_PARAM_MANIFOLD) return uni(gm <= gtol);
+  if (uni(0.4 * gm > gtol && gm < 3.0)) return false;
   double neg[NT], xp[4];
 #pragma unroll
   for (int i = 0; i < NT; ++i) neg[i] = -g[i];
@@ -536,7 +541,7 @@ __device__ __forceinline__ bool gradient_converged(const double* x, const double
     const double a = fabs(x[i] - xp[i]);
     m = a > m ? a : m;
   }
-  return m <= gtol;
+  return uni(m <= gtol);
 }
 
 __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost, double radius, int flag) {
@@ -708,14 +713,14 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
 
       for (;;) {
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
-        if (step_ok && cost < minimum_cost) {
+        if (step_ok && uni(cost < minimum_cost)) {
           minimum_cost = cost;
 #pragma unroll
           for (int i = 0; i < 4; ++i) best[i] = x[i];
         }
         if (iteration >= P.max_it) { term = RANDT_TERM_NO_CONVERGENCE; break; }
         if (step_ok && gconv) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
-        if (radius <= P.rmin) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
+        if (uni(radius <= P.rmin)) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
         ++iteration;
         res.iterations++;
 
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
           mcc += step[i] * (gs[i] + 0.5 * hs);
         }
         mcc = -mcc;
-        const bool valid = solved && mcc > 0.0;
+        const bool valid = uni(solved && mcc > 0.0);
         if (!valid) {
           // ---- HandleInvalidStep
           if (++num_invalid >= P.max_invalid) { term = RANDT_TERM_FAILURE; break; }
@@ -779,12 +784,12 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
           for (int i = 0; i < NAmb; ++i) sn2 += (x[i] - cand[i]) * (x[i] - cand[i]);
         }
         const double ptol_abs = P.ptol * (x_norm + P.ptol);
-        if (sn2 <= ptol_abs * ptol_abs) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
+        if (uni(sn2 <= ptol_abs * ptol_abs)) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
         const double cost_change = cost - cand_cost;
-        if (fabs(cost_change) <= P.ftol * cost) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
+        if (uni(fabs(cost_change) <= P.ftol * cost)) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
 
         const double rel = c_ok ? cost_change * fast_rcp(mcc) : -DBL_MAX;
-        if (rel > P.min_rel) {
+        if (uni(rel > P.min_rel)) {
           // ---- HandleSuccessfulStep
 #pragma unroll
           for (int i = 0; i < 4; ++i) x[i] = cand[i];
@@ -817,7 +822,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
       }
       res.gnc_solves++;
       gnc_mu /= P.gnc_div;
-    } while (gnc_mu > 1.0 / sqrt(P.gnc_div));
+    } while (uni(gnc_mu > 1.0 / sqrt(P.gnc_div)));
   }
 
   res.termination = term;
