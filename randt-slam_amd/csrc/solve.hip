@@ -433,45 +433,52 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   return uni(badf == 0.0 && isfinite(acc[0]));
 }
 
-// g = T g_b, H = T G T^T for the parameterisation at ambient point x (T is NT x 3, see header).
+// packed lower triangle: (i, j), i >= j  ->  i (i + 1) / 2 + j
+__device__ __forceinline__ constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// g = T g_b, H = T G T^T (packed lower, NT (NT + 1) / 2 entries) for the parameterisation at ambient point x.
+// T is NT x 3 (see header); its zero / one entries are spelled out so that no multiplications by zero are left
+// (the compiler may not fold 0 * x under IEEE rules).
 template <int PARAM, int NT>
-__device__ __forceinline__ void to_param(const Base& B, const double* x, double* g, double* H /* NT*NT full */) {
-  double T[NT][3];
+__device__ __forceinline__ void to_param(const Base& B, const double* x, double* g, double* H) {
+  const double gb0 = B.v[1], gb1 = B.v[2], gb2 = B.v[3];
+  const double G00 = B.v[4], G01 = B.v[5], G02 = B.v[6], G11 = B.v[7], G12 = B.v[8], G22 = B.v[9];
   if (PARAM == RANDT_PARAM_VECTOR) {
-    T[0][0] = 1; T[0][1] = 0; T[0][2] = 0;
-    T[1][0] = 0; T[1][1] = 1; T[1][2] = 0;
-    T[2][0] = 0; T[2][1] = 0; T[2][2] = 1;
+    g[0] = gb0; g[1] = gb1; g[2] = gb2;
+    H[sym(0, 0)] = G00; H[sym(1, 0)] = G01; H[sym(1, 1)] = G11;
+    H[sym(2, 0)] = G02; H[sym(2, 1)] = G12; H[sym(2, 2)] = G22;
+    return;
+  }
+  const double cp = x[0], sp = x[1];
+  const double in2 = fast_rcp(cp * cp + sp * sp);
+  const double a = -sp * in2, b = cp * in2;  // d theta / d c, d theta / d s  (theta = atan2(s, c))
+  if (PARAM == RANDT_PARAM_AMBIENT4) {
+    // rows of T: c -> (0, 0, a); s -> (0, 0, b); tx -> (1, 0, 0); ty -> (0, 1, 0)
+    const double aG = a * G22, bG = b * G22;
+    g[0] = a * gb2; g[1] = b * gb2; g[2] = gb0; g[NT - 1] = gb1;
+    H[sym(0, 0)] = aG * a;
+    H[sym(1, 0)] = bG * a; H[sym(1, 1)] = bG * b;
+    H[sym(2, 0)] = a * G02; H[sym(2, 1)] = b * G02; H[sym(2, 2)] = G00;
+    H[sym(NT - 1, 0)] = a * G12; H[sym(NT - 1, 1)] = b * G12; H[sym(NT - 1, 2)] = G01; H[sym(NT - 1, NT - 1)] = G11;
   } else {
-    const double cp = x[0], sp = x[1];
-    const double in2 = fast_rcp(cp * cp + sp * sp);
-    const double a = -sp * in2, b = cp * in2;  // d theta / d c, d theta / d s  (theta = atan2(s, c))
-    if (PARAM == RANDT_PARAM_AMBIENT4) {
-      T[0][0] = 0; T[0][1] = 0; T[0][2] = a;
-      T[1][0] = 0; T[1][1] = 0; T[1][2] = b;
-      T[2][0] = 1; T[2][1] = 0; T[2][2] = 0;
-      T[NT - 1][0] = 0; T[NT - 1][1] = 1; T[NT - 1][2] = 0;
-    } else {
-      // ambient row times Sophus PlusJacobian [[0,0,-s],[0,0,c],[c,-s,0],[s,c,0]] (stored complex)
-      T[0][0] = cp;  T[0][1] = sp; T[0][2] = 0;
-      T[1][0] = -sp; T[1][1] = cp; T[1][2] = 0;
-      T[2][0] = 0;   T[2][1] = 0;  T[2][2] = a * (-sp) + b * cp;
-    }
+    // ambient row times Sophus PlusJacobian [[0,0,-s],[0,0,c],[c,-s,0],[s,c,0]] (stored complex):
+    // T = [[cp, sp, 0], [-sp, cp, 0], [0, 0, w]], w = a (-sp) + b cp
+    const double w = a * (-sp) + b * cp;
+    g[0] = cp * gb0 + sp * gb1;
+    g[1] = cp * gb1 - sp * gb0;
+    g[2] = w * gb2;
+    const double r00 = cp * G00 + sp * G01, r01 = cp * G01 + sp * G11;   // (R G2) rows
+    const double r10 = cp * G01 - sp * G00, r11 = cp * G11 - sp * G01;
+    H[sym(0, 0)] = r00 * cp + r01 * sp;
+    H[sym(1, 0)] = r10 * cp + r11 * sp;
+    H[sym(1, 1)] = r11 * cp - r10 * sp;
+    H[sym(2, 0)] = w * (cp * G02 + sp * G12);
+    H[sym(2, 1)] = w * (cp * G12 - sp * G02);
+    H[sym(2, 2)] = (w * G22) * w;
   }
-  const double G[3][3] = {{B.v[4], B.v[5], B.v[6]}, {B.v[5], B.v[7], B.v[8]}, {B.v[6], B.v[8], B.v[9]}};
-  double TG[NT][3];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    g[i] = T[i][0] * B.v[1] + T[i][1] * B.v[2] + T[i][2] * B.v[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) TG[i][j] = T[i][0] * G[0][j] + T[i][1] * G[1][j] + T[i][2] * G[2][j];
-  }
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) H[i * NT + j] = TG[i][0] * T[j][0] + TG[i][1] * T[j][1] + TG[i][2] * T[j][2];
 }
 
-// Solve of the NT x NT SPD system A y = g by LDL^T (A full, row-major, destroyed): NT reciprocals,
+// Solve of the NT x NT SPD system A y = g by LDL^T (A packed lower, destroyed): NT reciprocals,
 // no square roots.  Returns false if a pivot is not positive.
 template <int NT>
 __device__ __forceinline__ bool ldlt_solve(double* A, const double* g, double* y) {
@@ -479,25 +486,25 @@ __device__ __forceinline__ bool ldlt_solve(double* A, const double* g, double* y
   double inv_d[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    double d = A[j * NT + j];
+    double d = A[sym(j, j)];
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= A[j * NT + k] * A[j * NT + k] * A[k * NT + k];
+    for (int k = 0; k < j; ++k) d -= A[sym(j, k)] * A[sym(j, k)] * A[sym(k, k)];
     if (!(d > 0.0)) ok = false;
-    A[j * NT + j] = d;
+    A[sym(j, j)] = d;
     inv_d[j] = fast_rcp(d);
 #pragma unroll
     for (int i = j + 1; i < NT; ++i) {
-      double a = A[i * NT + j];
+      double a = A[sym(i, j)];
 #pragma unroll
-      for (int k = 0; k < j; ++k) a -= A[i * NT + k] * A[j * NT + k] * A[k * NT + k];
-      A[i * NT + j] = a * inv_d[j];
+      for (int k = 0; k < j; ++k) a -= A[sym(i, k)] * A[sym(j, k)] * A[sym(k, k)];
+      A[sym(i, j)] = a * inv_d[j];
     }
   }
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     double a = g[i];
 #pragma unroll
-    for (int k = 0; k < i; ++k) a -= A[i * NT + k] * y[k];
+    for (int k = 0; k < i; ++k) a -= A[sym(i, k)] * y[k];
     y[i] = a;
   }
 #pragma unroll
@@ -506,7 +513,7 @@ __device__ __forceinline__ bool ldlt_solve(double* A, const double* g, double* y
   for (int i = NT - 1; i >= 0; --i) {
     double a = y[i];
 #pragma unroll
-    for (int k = i + 1; k < NT; ++k) a -= A[k * NT + i] * y[k];
+    for (int k = i + 1; k < NT; ++k) a -= A[sym(k, i)] * y[k];
     y[i] = a;
   }
   return ok;
@@ -678,8 +685,9 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
       L = make_loss(P.loss_a, P.alpha, gnc_mu, P.weight);
       // ================= one ceres::Solve (TrustRegionMinimizer::Minimize) =================
       double sigma[NT], diag[NT], step[NT], delta[NT], cand[4];
-      double gs[NT], Hs[NT * NT];  // Jacobi-scaled gradient / J^T J at the current point
-      double g[NT], H[NT * NT];
+      constexpr int NS = NT * (NT + 1) / 2;
+      double gs[NT], Hs[NS];  // Jacobi-scaled gradient / J^T J (packed lower) at the current point
+      double g[NT], H[NS], ss[NS];
       double radius = P.r0, decrease = 2.0;
       bool reuse = false, step_ok = true;
       int num_invalid = 0, iteration = 0;
@@ -701,12 +709,15 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
       summary_min = cost;
       to_param<PARAM, NT>(cur, x, g, H);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) sigma[i] = 1.0 / (1.0 + sqrt(H[i * NT + i]));  // jacobi scaling, fixed per solve
+      for (int i = 0; i < NT; ++i) sigma[i] = 1.0 / (1.0 + sqrt(H[sym(i, i)]));  // jacobi scaling, fixed per solve
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         gs[i] = g[i] * sigma[i];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) Hs[i * NT + j] = H[i * NT + j] * sigma[i] * sigma[j];
+        for (int j = 0; j <= i; ++j) {
+          ss[sym(i, j)] = sigma[i] * sigma[j];
+          Hs[sym(i, j)] = H[sym(i, j)] * ss[sym(i, j)];
+        }
       }
       bool gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
       trace_push(tr, trace_len, cost, radius, 0);
@@ -725,18 +736,16 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         res.iterations++;
 
         // ---- LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled normal equations
-        double A[NT * NT];
+        double A[NS];
         if (!reuse) {
 #pragma unroll
-          for (int i = 0; i < NT; ++i) diag[i] = fmin(fmax(Hs[i * NT + i], P.dmin), P.dmax);
+          for (int i = 0; i < NT; ++i) diag[i] = fmin(fmax(Hs[sym(i, i)], P.dmin), P.dmax);
         }
         const double inv_radius = fast_rcp(radius);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
+        for (int i = 0; i < NS; ++i) A[i] = Hs[i];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) A[i * NT + j] = Hs[i * NT + j];
-          A[i * NT + i] += diag[i] * inv_radius;  // (sqrt(D^2 / radius))^2
-        }
+        for (int i = 0; i < NT; ++i) A[sym(i, i)] += diag[i] * inv_radius;  // (sqrt(D^2 / radius))^2
         bool solved = ldlt_solve<NT>(A, gs, step);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -750,7 +759,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         for (int i = 0; i < NT; ++i) {
           double hs = 0.0;
 #pragma unroll
-          for (int j = 0; j < NT; ++j) hs += Hs[i * NT + j] * step[j];
+          for (int j = 0; j < NT; ++j) hs += Hs[sym(i, j)] * step[j];
           mcc += step[i] * (gs[i] + 0.5 * hs);
         }
         mcc = -mcc;
@@ -797,11 +806,9 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
           cost = cand_cost;
           to_param<PARAM, NT>(cnd, x, g, H);
 #pragma unroll
-          for (int i = 0; i < NT; ++i) {
-            gs[i] = g[i] * sigma[i];
+          for (int i = 0; i < NT; ++i) gs[i] = g[i] * sigma[i];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) Hs[i * NT + j] = H[i * NT + j] * sigma[i] * sigma[j];
-          }
+          for (int i = 0; i < NS; ++i) Hs[i] = H[i] * ss[i];
           gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
           step_ok = true;
           const double t = 2.0 * rel - 1.0;
