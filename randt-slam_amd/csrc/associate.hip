@@ -151,14 +151,75 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     }
     __syncthreads();
 
-    // ---- P2: window scan (LDS only), one wavefront per moving cell
+    // ---- P2: window scan (LDS only), one wavefront per moving cell.
+    // Reference loop (ndt_map.cpp:101-152): evaluate radius 0, 1, ... until enough targets (nt >= k) or
+    // enough adjacent slots (nadj >= n_slots) were seen or the radius reaches rmax.  The window is
+    // enumerated ring-major, so "everything up to radius r" is a prefix of (2r+1)^2 entries: 64 lanes
+    // fetch a pass of the window, two ballots give its occupied / in-range masks, and LANE r evaluates
+    // radius r from those masks -- the termination radius is one more ballot instead of a scalar loop.
     for (int c = wave; c < nch; c += ASSOC_WAVES) {
       const uint32_t center = __float_as_uint(qrec[c * ASSOC_QS + 9]);
       int32_t cidx[ASSOC_PASSES];
       unsigned long long occ[ASSOC_PASSES], val[ASSOC_PASSES];
+      int rstar = -1;
+      if (!need_dup) {
+        // radius of lane r: prefix length (2r+1)^2; lanes >= rmax never win
+        const int need_l = (2 * lane + 1) * (2 * lane + 1);
+        int nt_l = 0, nadj_l = 0;
+        int loaded = 0;
+#pragma unroll
+        for (int p = 0; p < ASSOC_PASSES; ++p) {
+          // passes are fetched lazily: pass 0 covers radii 0..3, pass 1 radii 4..5, pass 2 radius 6, pass 3 radius 7
+          const int r_first = p == 0 ? 0 : (p == 1 ? 4 : (p == 2 ? 6 : 7));
+          if (rstar < 0 && r_first <= R) {
+            const int w = p * 64 + lane;
+            int32_t ci = -2;  // -2: not a valid window slot, -1: empty slot
+            if (w < nwin) {
+              const int packed = wtab[w];
+              const int i = (packed >> 8) - 128, j = (packed & 255) - 128;
+              const uint32_t ni = center + (uint32_t)i + (uint32_t)j * (uint32_t)fixed.size_x;
+              if (ni < (uint32_t)n_slots) {
+                ci = grid[ni];
+                if (ci < -1) ci = -1;
+              }
+            }
+            cidx[p] = ci;
+            occ[p] = __ballot(ci >= 0);
+            val[p] = __ballot(ci >= -1);
+            loaded = p + 1;
+            const unsigned long long pm = prefix_mask(need_l - 64 * p);
+            nt_l += __popcll(occ[p] & pm);
+            nadj_l += __popcll(val[p] & pm);
+            // radii completely inside the passes fetched so far
+            const int r_last = p == 0 ? 3 : (p == 1 ? 5 : (p == 2 ? 6 : 7));
+            const int r_hi = r_last < R ? r_last : R;
+            const bool stop = lane <= r_hi && !(nt_l < k && nadj_l < n_slots);
+            const unsigned long long sm = __ballot(stop);
+            if (sm) rstar = __ffsll((long long)sm) - 1;
+            else if (r_hi == R) rstar = R;  // "if (r >= rmax) break" after the last radius
+          }
+        }
+        // candidates of the final window -> cand[c][0 .. nt)
+        int base = 0;
+        const int need = (2 * rstar + 1) * (2 * rstar + 1);
+#pragma unroll
+        for (int p = 0; p < ASSOC_PASSES; ++p) {
+          if (p < loaded) {
+            const bool in = cidx[p] >= 0 && (p * 64 + lane) < need;
+            const unsigned long long m = __ballot(in);
+            const int pos = base + __popcll(m & prefix_mask(lane));
+            if (in && pos < ASSOC_CAND) cand[c * ASSOC_CAND + pos] = cidx[p];
+            base += __popcll(m);
+          }
+        }
+        if (lane == 0) clen[c] = base < ASSOC_CAND ? base : ASSOC_CAND;
+        continue;
+      }
+      // tiny maps (size_x <= 2R): the window wraps onto itself and the reference drops repeated entries
+      // (std::find) -- radius by radius, as written there
       int wi[ASSOC_PASSES], wj[ASSOC_PASSES];
       int loaded = 0;  // passes evaluated so far
-      int nt = 0, nadj = 0, radius = 0, rstar = -1;
+      int nt = 0, nadj = 0, radius = 0;
       // while (targets.size() < n && adjacent.size() < n_cells_) {...; r++; if (r >= rmax) break;}
       while (nt < k && nadj < n_slots) {
         const int need = (2 * radius + 1) * (2 * radius + 1);  // window entries of this radius
@@ -166,7 +227,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
         for (int p = 0; p < ASSOC_PASSES; ++p) {
           if (p == loaded && need > 64 * p) {
             const int w = p * 64 + lane;
-            int32_t ci = -2;  // -2: not a valid window slot, -1: empty slot
+            int32_t ci = -2;
             int i = 0, j = 0;
             if (w < nwin) {
               const int packed = wtab[w];
@@ -181,8 +242,6 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
             cidx[p] = ci;
             wi[p] = i;
             wj[p] = j;
-            occ[p] = __ballot(ci >= 0);
-            val[p] = __ballot(ci >= -1);
             loaded = p + 1;
           }
         }
@@ -191,12 +250,9 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
 #pragma unroll
         for (int p = 0; p < ASSOC_PASSES; ++p) {
           if (p < loaded) {
-            unsigned long long o = occ[p], v = val[p];
-            if (need_dup) {  // tiny maps only: drop repeated window entries (std::find in the reference)
-              const bool rep = window_dup(wi[p], wj[p], radius, fixed.size_x);
-              o = __ballot(cidx[p] >= 0 && !rep);
-              v = __ballot(cidx[p] >= -1 && !rep);
-            }
+            const bool rep = window_dup(wi[p], wj[p], radius, fixed.size_x);
+            const unsigned long long o = __ballot(cidx[p] >= 0 && !rep);
+            const unsigned long long v = __ballot(cidx[p] >= -1 && !rep);
             const unsigned long long pm = prefix_mask(need - 64 * p);
             nt += __popcll(o & pm);
             nadj += __popcll(v & pm);
@@ -206,15 +262,13 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
         ++radius;
         if (radius >= fixed.rmax) break;
       }
-      // candidates of the final window -> cand[c][0 .. nt)
       int base = 0;
       if (rstar >= 0) {
         const int need = (2 * rstar + 1) * (2 * rstar + 1);
 #pragma unroll
         for (int p = 0; p < ASSOC_PASSES; ++p) {
           if (p < loaded) {
-            bool in = cidx[p] >= 0 && (p * 64 + lane) < need;
-            if (need_dup) in = in && !window_dup(wi[p], wj[p], rstar, fixed.size_x);
+            const bool in = cidx[p] >= 0 && (p * 64 + lane) < need && !window_dup(wi[p], wj[p], rstar, fixed.size_x);
             const unsigned long long m = __ballot(in);
             const int pos = base + __popcll(m & prefix_mask(lane));
             if (in && pos < ASSOC_CAND) cand[c * ASSOC_CAND + pos] = cidx[p];
@@ -331,7 +385,7 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   if (fixed.n_slots <= 225)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "maps with <= 225 slots not supported by the association kernel", hipSuccess);
   const int full = (use_intensity && lookup_mahalanobis) ? 1 : 0;
-  const bool stage = assoc_lds_bytes(fixed.n_slots, true) <= (size_t)ctx->lds_limit / 2;
+  const bool stage = ctx->assoc_stage_grid && assoc_lds_bytes(fixed.n_slots, true) <= (size_t)ctx->lds_limit / 2;
   const size_t lds = assoc_lds_bytes(fixed.n_slots, stage);
   if (stage) {
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<true>),
