@@ -758,7 +758,8 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   const size_t off_guess = off_states + sizeof(double) * 10 * RANDT_WIN_MAX_STATES;
   const size_t off_idx = off_guess + sizeof(h_guess);
   const size_t off_res = off_idx + sizeof(h_idx) + 64;
-  int rc = ensure_ws(ctx, off_res + sizeof(randt_result) + 64);
+  const size_t off_desc = (off_res + sizeof(randt_result) + 64 + 255) & ~(size_t)255;
+  int rc = ensure_ws(ctx, off_desc + sizeof(WinDesc) + 64);
   if (rc) return rc;
   char* ws = (char*)ctx->ws;
   double h_packed[10 * RANDT_WIN_MAX_STATES];
@@ -771,12 +772,14 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_states, h_packed, sizeof(double) * 10 * (S + 1), hipMemcpyHostToDevice, ctx->stream));
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_guess, h_guess, sizeof(h_guess), hipMemcpyHostToDevice, ctx->stream));
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_idx, h_idx, sizeof(h_idx), hipMemcpyHostToDevice, ctx->stream));
+  // the window descriptor is indexed dynamically by the kernel: it lives in device memory, not in kernel arguments
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_desc, &W, sizeof(W), hipMemcpyHostToDevice, ctx->stream));
   const int32_t* d_fidx = (const int32_t*)(ws + off_idx);
   const int32_t* d_midx = d_fidx + RANDT_WIN_MAX_TERMS;
   rc = launch_associate(ctx, fixed->v, d_fidx, moving->v, 0, W.n_terms, (const double*)(ws + off_guess), k, mp->lookup_mahalanobis,
                         mp->use_intensity, (int32_t*)ws, d_midx);
   if (rc) return rc;
-  rc = launch_solve_window(ctx, fixed->v, moving->v, W, (const int32_t*)ws, mp, (double*)(ws + off_states), (randt_result*)(ws + off_res));
+  rc = launch_solve_window(ctx, fixed->v, moving->v, W, (const WinDesc*)(ws + off_desc), (const int32_t*)ws, mp, (double*)(ws + off_states), (randt_result*)(ws + off_res));
   if (rc) return rc;
   randt_result r;
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_packed, ws + off_states, sizeof(double) * 10 * (S + 1), hipMemcpyDeviceToHost, ctx->stream));

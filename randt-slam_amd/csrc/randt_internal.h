@@ -80,7 +80,7 @@ struct WinDesc {
   double raw_dt[RANDT_WIN_MAX_STATES];  // stamp[j] - stamp[j-1], index j
   double w_imu, w_bias, ndt_weight;
 };
-int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc,
+int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
                         const int32_t* d_corr, const randt_matcher_params* mp, double* d_states /* (S+1) x 10 */,
                         randt_result* d_result);
 int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,

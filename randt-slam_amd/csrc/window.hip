@@ -359,6 +359,9 @@ __device__ __forceinline__ double wave_max(double v) {
   }
   return v;
 }
+// The solver scalars are the same in every lane but live in VGPRs (no fp64 scalar unit): a branch on them looks
+// divergent to the compiler.  uni() makes the condition scalar (compare into an SGPR pair + s_cmp).
+__device__ __forceinline__ bool uni(bool c) { return __ballot(c) != 0ull; }
 // 1/x to ~1 ulp: hardware reciprocal seed + two Newton-Raphson steps
 __device__ __forceinline__ double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
@@ -414,7 +417,7 @@ __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
 // MODE 1: ten base sums per state -> out[(j-1)*10 ..].
 // In MODE 1 wavefront 3 evaluates the motion / IMU factors of the same point while wavefronts 0-2
 // stream the NDT slots (the factors are a ~2000-instruction serial chain: hidden behind the pass).
-template <int D, int MODE>
+template <int D, int MODE, bool AM2>
 __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const int32_t* __restrict__ corr,
                          const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw) {
   const bool factor_wave = MODE == 1 && (threadIdx.x >> 6) == 3;
@@ -451,7 +454,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
         mx = sq > mx ? sq : mx;
       } else {
         double rs, js;
-        if (L.mode == 2) {
+        if (AM2) {
           const double iu = 1.0 / (sq * L.ts + 1.0);
           a10[0] += L.half_w_pre * (iu - 1.);
           rs = js = L.sqrt_w * iu;
@@ -510,7 +513,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
     }
     if (threadIdx.x == 0) out[0] = mx > 0.0 ? sqrt(mx) : 0.0;
     __syncthreads();
-    return badf == 0.0;
+    return uni(badf == 0.0);
   }
 #pragma unroll
   for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] = wave_sum(acc[i]);
@@ -524,7 +527,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
   for (int w = 0; w < WIN_WAVES; ++w) badf = r[w * 34 + 30] > badf ? r[w * 34 + 30] : badf;
   // fixed-order 4-way combine, one thread per sum; published by the caller's next barrier
   if (threadIdx.x < WIN_SMAX * 10) out[threadIdx.x] = ((r[0 * 34 + threadIdx.x] + r[1 * 34 + threadIdx.x]) + r[2 * 34 + threadIdx.x]) + r[3 * 34 + threadIdx.x];
-  return badf == 0.0;
+  return uni(badf == 0.0);
 }
 
 // Weighting half of the factor evaluation (the unweighted residuals / Jacobians were produced by
@@ -681,12 +684,15 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
   }
 }
 
-template <int D>
-__global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapView moving, WinDesc W,
+// AM2: Barron shape exactly -2 (the shipped configurations): closed-form loss, no pow() in the kernel
+template <int D, bool AM2>
+__global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapView moving, const WinDesc* __restrict__ Wp,
                                                             const int32_t* __restrict__ corr, SolveParams P,
                                                             double* __restrict__ states, randt_result* __restrict__ result,
                                                             double* trace, int trace_len) {
   __shared__ Shared sh;
+  // dynamically indexed (state j, term t): read from device memory on demand instead of pinning ~200 SGPRs
+  const WinDesc& W = *Wp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = W.n_tan, S = W.S;
   int parity = 0;
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   double raw_max = 0.0;
   bool ok = true;
   if (n_res > 0) {
-    ok = ndt_pass<D, 0>(fixed, moving, W, corr, sh, 0, L, sh.base[0], parity, sh);
+    ok = ndt_pass<D, 0, AM2>(fixed, moving, W, corr, sh, 0, L, sh.base[0], parity, sh);
     raw_max = sh.base[0][0];
     res.n_evals++;
     __syncthreads();
@@ -789,7 +795,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       bool reuse = false, step_ok = true;
       int num_invalid = 0, iteration = 0;
       double minimum_cost = DBL_MAX;
-      bool e_ok = ndt_pass<D, 1>(fixed, moving, W, corr, sh, p, L, sh.base[p], parity, sh);
+      bool e_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, corr, sh, p, L, sh.base[p], parity, sh);
       WT(1);
       double fcost = factors_weight(W, sh, p);  // its barrier also publishes sh.base[p]
       WT(2);
@@ -798,7 +804,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       double cost = fcost;
 #pragma unroll
       for (int j = 0; j < WIN_SMAX; ++j) cost += sh.base[p][j * 10];
-      if (!e_ok || !isfinite(cost)) {
+      if (uni(!e_ok || !isfinite(cost))) {
         term = RANDT_TERM_FAILURE;
         res.status = 2;
         res.gnc_solves++;
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
             gm = wave_max(gm);
             double gconv = 0.0;
             // the displacement of Plus(x, -g) is >= 0.4 max|g_i| (|omega| <= pi): exact test only for tiny gradients
-            if (!(0.4 * gm > P.gtol && gm < 3.0)) {
+            if (uni(!(0.4 * gm > P.gtol && gm < 3.0))) {
               wave_fence();
               plus_states(W, sh, p, 1 - p, sh.g, -1.0, lane);
               wave_fence();
@@ -853,14 +859,14 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           first = false;
           WT(4);
         }
-        const bool gconv = sh.scal[4] != 0.0;
+        const bool gconv = uni(sh.scal[4] != 0.0);
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
         // (Ceres copies x to the user parameters after successful steps that lower the minimum cost;
         //  accepted steps are monotone here, so the current buffer p always is that point.)
-        if (step_ok && cost < minimum_cost) minimum_cost = cost;
+        if (step_ok && uni(cost < minimum_cost)) minimum_cost = cost;
         if (iteration >= P.max_it) { term = RANDT_TERM_NO_CONVERGENCE; break; }
         if (step_ok && gconv) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
-        if (radius <= P.rmin) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
+        if (uni(radius <= P.rmin)) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
         ++iteration;
         res.iterations++;
 
@@ -872,47 +878,36 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           for (int e = lane; e < n * n; e += 64) sh.A[e] = sh.Hs[e] + ((e / n) == (e % n) ? sh.diag[e / n] * inv_radius : 0.0);
           wave_fence();
           WT(8);
-          // SPD solve A y = gs by symmetric Gaussian elimination.  Lane i keeps row i of A (and gs_i) in
-          // registers; every step broadcasts the pivot row through LDS (kept as row j of U for the back
-          // substitution).  The j loops are ROLLED and only the k dimension is unrolled, so the whole solve is
-          // a few hundred instructions that stay in the instruction cache (a fully unrolled elimination is
-          // ~70 KB of straight-line code and runs at instruction-fetch speed).  By symmetry of the trailing
-          // matrix the multiplier of lane i is U[j][i] / U[j][j]: no dynamic register indexing anywhere.
+          // SPD solve A y = gs by Gauss-Jordan elimination entirely in registers.  Lane i keeps row i of A and
+          // gs_i; after every step all rows are shifted left by one column, so the pivot column is ALWAYS register
+          // 0 and no register is indexed dynamically: step j broadcasts lane j's row with v_readlane (the lane
+          // select may be a loop variable), every other lane subtracts its multiple of it, and lane j parks its
+          // pivot.  Eliminating above the pivot as well leaves a diagonal system -- no back substitution, no LDS
+          // round trips, no barriers; the j loop stays rolled (~130 instructions per step).
           double okf = 1.0;
           {
-            double row[WIN_NMAX], b = lane < n ? sh.gs[lane] : 0.0;
+            double row[WIN_NMAX], b = lane < n ? sh.gs[lane] : 0.0, dg = 1.0;
 #pragma clang loop unroll(full)
             for (int k = 0; k < WIN_NMAX; ++k) row[k] = (lane < n && k < n) ? sh.A[lane * n + k] : 0.0;
-            double* U = sh.A;      // reused: U[j][k], stride WIN_NMAX (all rows already copied into registers)
-            double* ub = sh.col;   // right-hand side of the pivot rows
-            wave_fence();
-            for (int j = 0; j < n; ++j) {
-              if (lane == j) {
-#pragma clang loop unroll(full)
-                for (int k = 0; k < WIN_NMAX; ++k) U[j * WIN_NMAX + k] = row[k];
-                ub[j] = b;
-              }
-              wave_fence();
-              const double pj = U[j * WIN_NMAX + j];
-              if (!(pj > 0.0)) okf = 0.0;
-              const double f = (lane > j && lane < n) ? U[j * WIN_NMAX + lane] * fast_rcp(pj) : 0.0;
-#pragma clang loop unroll(full)
-              for (int k = 0; k < WIN_NMAX; ++k) row[k] -= f * U[j * WIN_NMAX + k];
-              b -= f * ub[j];
-            }
-            // back substitution on U y = ub
-            double y = 0.0;
-            wave_fence();
-            for (int j = n - 1; j >= 0; --j) {
-              // lane j's b has received all updates from columns > j
-              if (lane == j) sh.delta[0] = b;
-              wave_fence();
-              const double yj = sh.delta[0] * fast_rcp(U[j * WIN_NMAX + j]);
-              if (lane < j) b -= U[lane * WIN_NMAX + j] * yj;
-              if (lane == j) y = yj;
-              wave_fence();
-            }
-            if (lane < n) sh.step[lane] = y;
+            // at step j only the first n - j columns are still live: four rolled loops of width 32 / 24 / 16 / 8
+            int j = 0;
+#define RANDT_GJ_STEPS(WIDTH)                                                                          \
+  for (; j < n && n - j > (WIDTH) - 8; ++j) {                                                         \
+    const double pj = readlane_f64(row[0], j);                                                        \
+    if (!(pj > 0.0)) okf = 0.0;                                                                       \
+    if (lane == j) dg = pj;                                                                           \
+    const double f = lane != j ? row[0] * fast_rcp(pj) : 0.0; /* lane j: f = 0, its row only shifts */ \
+    b = fma(-f, readlane_f64(b, j), b);                                                               \
+    _Pragma("clang loop unroll(full)") for (int k = 1; k < (WIDTH); ++k)                              \
+        row[k - 1] = fma(-f, readlane_f64(row[k], j), row[k]);                                        \
+    row[(WIDTH) - 1] = 0.0;                                                                           \
+  }
+            RANDT_GJ_STEPS(32)
+            RANDT_GJ_STEPS(24)
+            RANDT_GJ_STEPS(16)
+            RANDT_GJ_STEPS(8)
+#undef RANDT_GJ_STEPS
+            if (lane < n) sh.step[lane] = b * fast_rcp(dg);
           }
           wave_fence();
           WT(9);
@@ -949,7 +944,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         WT(5);
         reuse = true;
         const double mcc = sh.scal[0], sn2 = sh.scal[1];
-        const bool valid = sh.scal[3] != 0.0 && mcc > 0.0;
+        const bool valid = uni(sh.scal[3] != 0.0 && mcc > 0.0);
         if (!valid) {
           // ---- HandleInvalidStep
           if (++num_invalid >= P.max_invalid) { term = RANDT_TERM_FAILURE; break; }
@@ -964,7 +959,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         num_invalid = 0;
 
         // ---- candidate: factors + NDT terms with Jacobians (speculative)
-        const bool c_ok = ndt_pass<D, 1>(fixed, moving, W, corr, sh, 1 - p, L, sh.base[1 - p], parity, sh);
+        const bool c_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, corr, sh, 1 - p, L, sh.base[1 - p], parity, sh);
         WT(1);
         const double cf = factors_weight(W, sh, 1 - p);
         WT(2);
@@ -972,16 +967,16 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         double cand_cost = cf;
 #pragma unroll
         for (int j = 0; j < WIN_SMAX; ++j) cand_cost += sh.base[1 - p][j * 10];
-        const bool cfin = c_ok && isfinite(cand_cost);
+        const bool cfin = uni(c_ok && isfinite(cand_cost));
         if (!cfin) cand_cost = DBL_MAX;
 
         // ---- ParameterToleranceReached / FunctionToleranceReached
         const double ptol_abs = P.ptol * (x_norm + P.ptol);
-        if (sn2 <= ptol_abs * ptol_abs) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
+        if (uni(sn2 <= ptol_abs * ptol_abs)) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
         const double cost_change = cost - cand_cost;
-        if (fabs(cost_change) <= P.ftol * cost) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
+        if (uni(fabs(cost_change) <= P.ftol * cost)) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
         const double rel = cfin ? cost_change / mcc : -DBL_MAX;
-        if (rel > P.min_rel) {
+        if (uni(rel > P.min_rel)) {
           // ---- HandleSuccessfulStep: the candidate buffer becomes current
           p = 1 - p;
           cost = cand_cost;
@@ -1008,7 +1003,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       }
       res.gnc_solves++;
       gnc_mu /= P.gnc_div;
-    } while (gnc_mu > 1.0 / sqrt(P.gnc_div));
+    } while (uni(gnc_mu > 1.0 / sqrt(P.gnc_div)));
   }
   __syncthreads();
   for (int e = tid; e < (S + 1) * ST_STRIDE; e += WIN_BLOCK) states[e] = sh.xs[p][e / ST_STRIDE][e % ST_STRIDE];
@@ -1022,7 +1017,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
 
 }  // namespace
 
-int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc,
+int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
                         const int32_t* d_corr, const randt_matcher_params* mp, double* d_states, randt_result* d_result) {
   SolveParams P;
   P.loss_a = mp->loss_scale;
@@ -1045,12 +1040,16 @@ int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& mov
   P.max_invalid = mp->max_consecutive_invalid_steps;
   if (desc.n_tan > WIN_NMAX || desc.S > WIN_SMAX)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window too large for the device solver", hipSuccess);
-  if (desc.d3)
-    hipLaunchKernelGGL(k_solve_window<3>, dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, desc, d_corr, P, d_states,
-                       d_result, ctx->d_trace, ctx->trace_len);
-  else
-    hipLaunchKernelGGL(k_solve_window<2>, dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, desc, d_corr, P, d_states,
-                       d_result, ctx->d_trace, ctx->trace_len);
+#define RANDT_WIN_LAUNCH(DD, AA)                                                                                          \
+  hipLaunchKernelGGL((k_solve_window<DD, AA>), dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
+                     d_states, d_result, ctx->d_trace, ctx->trace_len)
+  const bool am2 = P.alpha == -2.0;
+  if (desc.d3) {
+    if (am2) RANDT_WIN_LAUNCH(3, true); else RANDT_WIN_LAUNCH(3, false);
+  } else {
+    if (am2) RANDT_WIN_LAUNCH(2, true); else RANDT_WIN_LAUNCH(2, false);
+  }
+#undef RANDT_WIN_LAUNCH
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
