@@ -26,8 +26,11 @@
 // control flow, no broadcast).  The candidate is evaluated WITH its Jacobian so an accepted step
 // needs no second pass.
 #include "randt_internal.h"
+#include "solve_math.h"
 
 #include <float.h>
+
+using namespace randt_solve;
 
 namespace {
 
@@ -35,28 +38,6 @@ namespace {
 struct Base {
   double v[10];
 };
-
-// 1/x and 1/sqrt(x) to ~1 ulp: hardware seed (2^-23 relative) + two Newton-Raphson steps.  A correctly
-// rounded fp64 division costs ~25 instructions on gfx950, these 5 / 9.
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
-}
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double e = fma(-x * y, y, 1.0);
-  y = fma(0.5 * y, e, y);
-  e = fma(-x * y, y, 1.0);
-  return fma(0.5 * y, e, y);
-}
-
-// The solver state is the same in every lane, but it lives in VGPRs (fp64 has no scalar unit), so the compiler
-// must treat a branch on it as divergent: exec-mask bookkeeping and select/copy merges at every join.  uni()
-// turns such a condition into a scalar one (one compare into an SGPR pair + s_cmp): real scalar branches.
-__device__ __forceinline__ bool uni(bool c) { return __ballot(c) != 0ull; }
 
 // ---------------------------------------------------------------- Sophus SE(2) pieces ----------
 __device__ __forceinline__ void so2_normalize(double& c, double& s) {
@@ -108,182 +89,6 @@ __device__ __forceinline__ void plus(const double* x, const double* d, double* x
     for (int i = 0; i < 3; ++i) xp[i] = x[i] + d[i];
     xp[3] = 0.0;
   }
-}
-
-// ---------------------------------------------------------------- loss -------------------------
-struct Loss {
-  double b, c, factor, exponent, pre, ts, alpha, weight, sqrt_w, half_w_pre;
-  int mode;  // 0: identity (alpha >= 2), 1: log (|alpha| <= 0.05), 2: alpha == -2 closed form, 3: general pow
-};
-
-// BarronLoss ctor (ceres_loss_functions.h:27-35)
-__device__ __forceinline__ Loss make_loss(double a, double alpha, double mu, double weight) {
-  Loss L;
-  L.alpha = alpha;
-  L.b = mu * a * a;
-  L.c = 1 / L.b;
-  L.factor = fabs(alpha - 2.0);
-  L.exponent = 0.5 * alpha;
-  L.pre = L.b * L.factor / alpha;
-  L.ts = 2 * L.c / L.factor;
-  L.weight = weight;
-  L.sqrt_w = sqrt(weight);
-  L.half_w_pre = 0.5 * weight * L.pre;
-  L.mode = alpha >= 2.0 ? 0 : (fabs(alpha) <= 0.05 ? 1 : (alpha == -2.0 ? 2 : 3));
-  return L;
-}
-
-// BarronLoss::Evaluate (ceres_loss_functions.cpp:19-39) x ScaledLoss, general branches
-__device__ __forceinline__ void loss_eval(const Loss& L, double s, double& r0, double& r1, double& r2) {
-  if (L.mode == 0) {
-    r0 = s;
-    r1 = 1;
-    r2 = 0;
-  } else if (L.mode == 1) {
-    const double sum = 1.0 + s * L.c;
-    const double inv = 1.0 / sum;
-    r0 = L.b * log(sum);
-    r1 = inv > DBL_MIN ? inv : DBL_MIN;
-    r2 = -L.c * (inv * inv);
-  } else {
-    const double u = s * L.ts + 1.0;
-    r0 = L.pre * (pow(u, L.exponent) - 1.);
-    r1 = L.pre * L.exponent * pow(u, L.exponent - 1.) * L.ts;
-    r2 = L.pre * L.exponent * (L.exponent - 1) * pow(u, L.exponent - 2.) * L.ts * L.ts;
-  }
-  r0 *= L.weight;
-  r1 *= L.weight;
-  r2 *= L.weight;
-}
-
-// ---------------------------------------------------------------- residual ---------------------
-// One D2D residual: ssq = d^T (R Sm R^T + Sf)^-1 d and, if WANT_JAC,
-// jb = r * d r / d (tx, ty, theta) with r = sqrt(ssq) (A.2 in the global frame): the 1/r factor is
-// folded into the accumulation by the caller, so no square root is taken per residual.
-// mv/fv: first 9 floats of a cell record (mean xyz, cov xx xy xi yy yi ii); c, s = cos/sin(theta).
-template <int D, bool WANT_JAC>
-__device__ __forceinline__ double residual_sq(const float4* mrec, const float4* frec, double c, double s,
-                                              double tx, double ty, double* jb) {
-  // 48-byte records as three 16-byte loads each (global: dwordx4, LDS: ds_read_b128, conflict-free at stride 48)
-  const float4 ma = mrec[0], mb = mrec[1], mc4 = mrec[2];
-  const float4 fa = frec[0], fb = frec[1], fc4 = frec[2];
-  const float mv[9] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w, mc4.x};
-  const float fv[9] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc4.x};
-  const double m0 = mv[0], m1 = mv[1];
-  const double a = mv[3], b = mv[4], dd = mv[6];
-  const double RS00 = c * a - s * b, RS01 = c * b - s * dd;
-  const double RS10 = s * a + c * b, RS11 = s * b + c * dd;
-  const double C00 = (RS00 * c - RS01 * s) + (double)fv[3];
-  const double C01 = (RS00 * s + RS01 * c) + (double)fv[4];
-  const double C11 = (RS10 * s + RS11 * c) + (double)fv[6];
-  const double d0 = (c * m0 - s * m1) + tx - (double)fv[0];
-  const double d1 = (s * m0 + c * m1) + ty - (double)fv[1];
-  double q0, q1, q2 = 0.0, ssq;
-  double cc = 0.0, e = 0.0;
-  if (D == 3) {
-    cc = mv[5];
-    e = mv[7];
-    const double C02 = (c * cc - s * e) + (double)fv[5];
-    const double C12 = (s * cc + c * e) + (double)fv[7];
-    const double C22 = (double)mv[8] + (double)fv[8];
-    const double d2 = (double)mv[2] - (double)fv[2];
-    const double k00 = C11 * C22 - C12 * C12;
-    const double k01 = C12 * C02 - C01 * C22;
-    const double k02 = C01 * C12 - C11 * C02;
-    const double det = C00 * k00 + C01 * k01 + C02 * k02;
-    const double id = fast_rcp(det);
-    const double k11 = C00 * C22 - C02 * C02;
-    const double k12 = C02 * C01 - C00 * C12;
-    const double k22 = C00 * C11 - C01 * C01;
-    q0 = (k00 * d0 + k01 * d1 + k02 * d2) * id;
-    q1 = (k01 * d0 + k11 * d1 + k12 * d2) * id;
-    q2 = (k02 * d0 + k12 * d1 + k22 * d2) * id;
-    ssq = d0 * q0 + d1 * q1 + d2 * q2;
-  } else {
-    const double det = C00 * C11 - C01 * C01;
-    const double id = fast_rcp(det);
-    q0 = (C11 * d0 - C01 * d1) * id;
-    q1 = (-C01 * d0 + C00 * d1) * id;
-    ssq = d0 * q0 + d1 * q1;
-  }
-  if (WANT_JAC) {
-    const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
-    double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
-    if (D == 3) {
-      Su0 += cc * q2;
-      Su1 += e * q2;
-    }
-    jb[0] = q0;
-    jb[1] = q1;
-    jb[2] = (u1 * m0 - u0 * m1) - (u1 * Su0 - u0 * Su1);
-  }
-  return ssq;
-}
-
-// ---------------------------------------------------------------- reductions -------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-// Sum over the 64 lanes, result in every lane; fixed association order.
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);  // row_half_mirror
-  v += dpp_f64<0x140>(v);  // row_mirror -> every lane holds its row's (16-lane) sum
-  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
-// The ten base sums at once: instead of ten independent butterflies (23 instructions each) the values are
-// folded pairwise with the gfx950 lane-swap instructions -- after the 32-lane swap one register carries two
-// values' half-sums, after the 16-lane (row) swap four values' quarter-sums -- so only three registers go
-// through the four in-row DPP steps.  ~80 instructions instead of ~230; fixed association order.
-__device__ __forceinline__ double swap_add32(double a, double b) {
-  // v_permlane32_swap: lanes [32,63] of a <-> lanes [0,31] of b; a + b = {a over lane pairs | b over lane pairs}
-  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ double swap_add16(double a, double b) {
-  // v_permlane16_swap: odd rows of a <-> even rows of b
-  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
-  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ double row_sum(double v) {
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);  // row_half_mirror
-  v += dpp_f64<0x140>(v);  // row_mirror -> every lane holds its row's (16-lane) sum
-  return v;
-}
-__device__ __forceinline__ void wave_sum10(double* v) {
-  const double w0 = swap_add32(v[0], v[1]), w1 = swap_add32(v[2], v[3]), w2 = swap_add32(v[4], v[5]);
-  const double w3 = swap_add32(v[6], v[7]), w4 = swap_add32(v[8], v[9]);
-  // rows of u0: v0 v2 v1 v3; u1: v4 v6 v5 v7; u2: v8 - v9 -
-  const double u0 = row_sum(swap_add16(w0, w1)), u1 = row_sum(swap_add16(w2, w3)), u2 = row_sum(swap_add16(w4, 0.0));
-  v[0] = readlane_f64(u0, 0);
-  v[2] = readlane_f64(u0, 16);
-  v[1] = readlane_f64(u0, 32);
-  v[3] = readlane_f64(u0, 48);
-  v[4] = readlane_f64(u1, 0);
-  v[6] = readlane_f64(u1, 16);
-  v[5] = readlane_f64(u1, 32);
-  v[7] = readlane_f64(u1, 48);
-  v[8] = readlane_f64(u2, 0);
-  v[9] = readlane_f64(u2, 32);
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
 }
 
 // valid correspondences of one registration, compacted once into LDS: (moving index << 21) | fixed index
@@ -348,44 +153,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     if (MODE == 0) {
       mx = sq > mx ? sq : mx;
     } else {
-      double rs;  // residual and Jacobian scale of the corrector (equal for a scalar residual when rho'' <= 0)
-      double js;
-      if (AM2) {
-        // alpha = -2: rho' = w / u^2 > 0, rho'' < 0 always => corrector is sqrt(rho') = sqrt(w) / u
-        const double iu = fast_rcp(sq * L.ts + 1.0);
-        acc[0] += L.half_w_pre * (iu - 1.);
-        rs = js = L.sqrt_w * iu;
-      } else {
-        double r0, r1, r2;
-        loss_eval(L, sq, r0, r1, r2);
-        acc[0] += 0.5 * r0;
-        const double sqrt_rho1 = sqrt(r1);
-        if (sq == 0.0 || r2 <= 0.0) {
-          rs = js = sqrt_rho1;
-        } else {
-          const double Dc = 1.0 + 2.0 * sq * r2 / r1;
-          const double al = 1.0 - sqrt(Dc);
-          rs = sqrt_rho1 / (1 - al);
-          js = sqrt_rho1 * (1.0 - al);  // J - (alpha/sq) r r^T J for a scalar residual
-        }
-      }
-      // With r = sqrt(sq) and the true Jacobian row J = jb / r: the corrected residual is rs * r and the
-      // corrected row js * J, so  J^T r += (js rs) jb  and  J^T J += (js^2 / sq) jb jb^T  -- no square root.
-      // sq == 0: autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545); zero row instead.
-      if (sq > DBL_MIN) {
-        const double jr = js * rs;
-        const double h = js * js * fast_rcp(sq);
-        const double h0 = h * jb[0], h1 = h * jb[1], h2 = h * jb[2];
-        acc[1] += jr * jb[0];
-        acc[2] += jr * jb[1];
-        acc[3] += jr * jb[2];
-        acc[4] += h0 * jb[0];
-        acc[5] += h0 * jb[1];
-        acc[6] += h0 * jb[2];
-        acc[7] += h1 * jb[1];
-        acc[8] += h1 * jb[2];
-        acc[9] += h2 * jb[2];
-      }
+      accumulate_residual<AM2>(L, sq, jb, acc);
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -25,6 +25,7 @@
 #include <float.h>
 
 #include "randt_internal.h"
+#include "solve_math.h"
 
 #ifdef RANDT_TIMING
 __device__ long long g_randt_win_timing[16];
@@ -44,6 +45,8 @@ extern "C" int randt_debug_win_timing(long long* out) {
 #define WIN_WAVES 4
 #define WIN_NMAX 32  // tangent dimensions
 #define WIN_SMAX 3   // optimised states
+
+using namespace randt_solve;
 
 namespace {
 
@@ -234,142 +237,6 @@ __device__ void imu_factor(const double* x0, const double* x1, double raw_dt, do
 }
 
 // ---------------------------------------------------------------- loss (as in solve.hip) -------
-struct Loss {
-  double b, c, factor, exponent, pre, ts, alpha, weight, sqrt_w, half_w_pre;
-  int mode;
-};
-__device__ __forceinline__ Loss make_loss(double a, double alpha, double mu, double weight) {
-  Loss L;
-  L.alpha = alpha;
-  L.b = mu * a * a;
-  L.c = 1 / L.b;
-  L.factor = fabs(alpha - 2.0);
-  L.exponent = 0.5 * alpha;
-  L.pre = L.b * L.factor / alpha;
-  L.ts = 2 * L.c / L.factor;
-  L.weight = weight;
-  L.sqrt_w = sqrt(weight);
-  L.half_w_pre = 0.5 * weight * L.pre;
-  L.mode = alpha >= 2.0 ? 0 : (fabs(alpha) <= 0.05 ? 1 : (alpha == -2.0 ? 2 : 3));
-  return L;
-}
-__device__ __forceinline__ void loss_eval(const Loss& L, double s, double& r0, double& r1, double& r2) {
-  if (L.mode == 0) {
-    r0 = s;
-    r1 = 1;
-    r2 = 0;
-  } else if (L.mode == 1) {
-    const double sum = 1.0 + s * L.c;
-    const double inv = 1.0 / sum;
-    r0 = L.b * log(sum);
-    r1 = inv > DBL_MIN ? inv : DBL_MIN;
-    r2 = -L.c * (inv * inv);
-  } else {
-    const double u = s * L.ts + 1.0;
-    r0 = L.pre * (pow(u, L.exponent) - 1.);
-    r1 = L.pre * L.exponent * pow(u, L.exponent - 1.) * L.ts;
-    r2 = L.pre * L.exponent * (L.exponent - 1) * pow(u, L.exponent - 2.) * L.ts * L.ts;
-  }
-  r0 *= L.weight;
-  r1 *= L.weight;
-  r2 *= L.weight;
-}
-
-// D2D residual: ssq and d r / d (tx, ty, theta); same formulas as solve.hip
-template <int D, bool WANT_JAC>
-__device__ __forceinline__ double residual_sq(const float* __restrict__ mv, const float* __restrict__ fv, double c, double s,
-                                              double tx, double ty, double* jb) {
-  const double m0 = mv[0], m1 = mv[1];
-  const double a = mv[3], b = mv[4], dd = mv[6];
-  const double RS00 = c * a - s * b, RS01 = c * b - s * dd;
-  const double RS10 = s * a + c * b, RS11 = s * b + c * dd;
-  const double C00 = (RS00 * c - RS01 * s) + (double)fv[3];
-  const double C01 = (RS00 * s + RS01 * c) + (double)fv[4];
-  const double C11 = (RS10 * s + RS11 * c) + (double)fv[6];
-  const double d0 = (c * m0 - s * m1) + tx - (double)fv[0];
-  const double d1 = (s * m0 + c * m1) + ty - (double)fv[1];
-  double q0, q1, q2 = 0.0, ssq;
-  double cc = 0.0, e = 0.0;
-  if (D == 3) {
-    cc = mv[5];
-    e = mv[7];
-    const double C02 = (c * cc - s * e) + (double)fv[5];
-    const double C12 = (s * cc + c * e) + (double)fv[7];
-    const double C22 = (double)mv[8] + (double)fv[8];
-    const double d2 = (double)mv[2] - (double)fv[2];
-    const double k00 = C11 * C22 - C12 * C12;
-    const double k01 = C12 * C02 - C01 * C22;
-    const double k02 = C01 * C12 - C11 * C02;
-    const double det = C00 * k00 + C01 * k01 + C02 * k02;
-    const double id = 1.0 / det;
-    const double k11 = C00 * C22 - C02 * C02;
-    const double k12 = C02 * C01 - C00 * C12;
-    const double k22 = C00 * C11 - C01 * C01;
-    q0 = (k00 * d0 + k01 * d1 + k02 * d2) * id;
-    q1 = (k01 * d0 + k11 * d1 + k12 * d2) * id;
-    q2 = (k02 * d0 + k12 * d1 + k22 * d2) * id;
-    ssq = d0 * q0 + d1 * q1 + d2 * q2;
-  } else {
-    const double det = C00 * C11 - C01 * C01;
-    const double id = 1.0 / det;
-    q0 = (C11 * d0 - C01 * d1) * id;
-    q1 = (-C01 * d0 + C00 * d1) * id;
-    ssq = d0 * q0 + d1 * q1;
-  }
-  if (WANT_JAC) {
-    if (!(ssq > 0.0)) {
-      jb[0] = jb[1] = jb[2] = 0.0;
-    } else {
-      const double ir = rsqrt(ssq);
-      const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
-      double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
-      if (D == 3) {
-        Su0 += cc * q2;
-        Su1 += e * q2;
-      }
-      jb[0] = q0 * ir;
-      jb[1] = q1 * ir;
-      jb[2] = ((u1 * m0 - u0 * m1) - (u1 * Su0 - u0 * Su1)) * ir;
-    }
-  }
-  return ssq;
-}
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_f64<0xB1>(v);
-  v += dpp_f64<0x4E>(v);
-  v += dpp_f64<0x141>(v);
-  v += dpp_f64<0x140>(v);
-  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-// The solver scalars are the same in every lane but live in VGPRs (no fp64 scalar unit): a branch on them looks
-// divergent to the compiler.  uni() makes the condition scalar (compare into an SGPR pair + s_cmp).
-__device__ __forceinline__ bool uni(bool c) { return __ballot(c) != 0ull; }
-// 1/x to ~1 ulp: hardware reciprocal seed + two Newton-Raphson steps
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
-}
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -420,113 +287,79 @@ __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
 template <int D, int MODE, bool AM2>
 __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const int32_t* __restrict__ corr,
                          const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw) {
-  const bool factor_wave = MODE == 1 && (threadIdx.x >> 6) == 3;
+  // One wavefront per NDT term (state x fixed map), round robin: a term's ~M k slots are a handful of trips for
+  // 64 lanes, its ten base sums need ONE ten-value wave reduction and no cross-wave combine.  MODE 1: wavefront 3
+  // evaluates the motion / IMU factors meanwhile.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool factor_wave = MODE == 1 && wave == 3;
   if (factor_wave) factors_unweighted(W, shw, buf);
-  const int wtid = MODE == 1 ? (factor_wave ? (1 << 30) : (int)threadIdx.x) : (int)threadIdx.x;
-  const int wstride = MODE == 1 ? 192 : WIN_BLOCK;
-  double acc[WIN_SMAX * 10];
-#pragma unroll
-  for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] = 0.0;
+  const int n_ndt_waves = MODE == 1 ? 3 : WIN_WAVES;
+  double* r = shw.red[parity][0];  // [6 terms][10] | [64 + wave] bad | [72 + wave] max
+  parity ^= 1;
   double mx = -DBL_MAX;
   int bad = 0;
-  for (int t = 0; t < W.n_terms; ++t) {
-    const int j = W.term_state[t];
-    const double* xp = sh.xs[buf][j];
-    const double inv = rsqrt(xp[0] * xp[0] + xp[1] * xp[1]);
-    const double c = xp[0] * inv, s = xp[1] * inv, tx = xp[2], ty = xp[3];
-    const int mmap = W.term_moving[t], fmap = W.term_fixed[t];
-    int M = moving.counts[mmap];
-    M = M > moving.cap ? moving.cap : M;
-    const float* mov = reinterpret_cast<const float*>(moving.cells + (size_t)mmap * moving.cap);
-    const float* fix = reinterpret_cast<const float*>(fixed.cells + (size_t)fmap * fixed.cap);
-    const int32_t* pc = corr + (size_t)t * moving.cap * W.k;
-    const int n_slots = M * W.k;
-    double a10[10];
+  if (!factor_wave) {
+    for (int t = wave; t < W.n_terms; t += n_ndt_waves) {
+      const int j = W.term_state[t];
+      const double* xp = sh.xs[buf][j];
+      const double inv = fast_rsqrt(xp[0] * xp[0] + xp[1] * xp[1]);
+      const double c = xp[0] * inv, s = xp[1] * inv, tx = xp[2], ty = xp[3];
+      const int mmap = W.term_moving[t], fmap = W.term_fixed[t];
+      int M = moving.counts[mmap];
+      M = M > moving.cap ? moving.cap : M;
+      const float4* mov = reinterpret_cast<const float4*>(moving.cells + (size_t)mmap * moving.cap);
+      const float4* fix = reinterpret_cast<const float4*>(fixed.cells + (size_t)fmap * fixed.cap);
+      const int32_t* pc = corr + (size_t)t * moving.cap * W.k;
+      const int n_slots = M * W.k;
+      const unsigned kmagic = W.k > 1 ? (unsigned)((0x100000000ull + (unsigned)W.k - 1) / (unsigned)W.k) : 0u;
+      double a10[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) a10[i] = 0.0;
-    for (int slot = wtid; slot < n_slots; slot += wstride) {
-      const int ci = pc[slot];
-      if (ci < 0 || ci >= fixed.cap) continue;
-      double jb[3];
-      const double sq = residual_sq<D, MODE == 1>(mov + (size_t)(slot / W.k) * 12, fix + (size_t)ci * 12, c, s, tx, ty, jb);
-      if (!isfinite(sq)) bad = 1;
-      if (MODE == 0) {
-        mx = sq > mx ? sq : mx;
-      } else {
-        double rs, js;
-        if (AM2) {
-          const double iu = 1.0 / (sq * L.ts + 1.0);
-          a10[0] += L.half_w_pre * (iu - 1.);
-          rs = js = L.sqrt_w * iu;
-        } else {
-          double r0, r1, r2;
-          loss_eval(L, sq, r0, r1, r2);
-          a10[0] += 0.5 * r0;
-          const double sqrt_rho1 = sqrt(r1);
-          if (sq == 0.0 || r2 <= 0.0) {
-            rs = js = sqrt_rho1;
-          } else {
-            const double Dc = 1.0 + 2.0 * sq * r2 / r1;
-            const double al = 1.0 - sqrt(Dc);
-            rs = sqrt_rho1 / (1 - al);
-            js = sqrt_rho1 * (1.0 - al);
-          }
+      for (int i = 0; i < 10; ++i) a10[i] = 0.0;
+      for (int slot = lane; slot < n_slots; slot += 64) {
+        const int ci = pc[slot];
+        if (ci < 0 || ci >= fixed.cap) continue;
+        const unsigned mi = W.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, kmagic);  // slot / k
+        const float4* mv = mov + (size_t)mi * 3;
+        const float4* fv = fix + (size_t)ci * 3;
+        double jb[3];
+        const double sq = residual_sq<D, MODE == 1>(mv, fv, c, s, tx, ty, jb);
+        if (!isfinite(sq)) bad = 1;
+        if (MODE == 0) mx = sq > mx ? sq : mx;
+        else accumulate_residual<AM2>(L, sq, jb, a10);
+      }
+      if (MODE == 1) {
+        wave_sum10(a10);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < 10; ++i) r[t * 10 + i] = a10[i];
         }
-        const double r = sq > 0.0 ? sq * rsqrt(sq) : 0.0;
-        const double wr = rs * r;
-        const double w0 = js * jb[0], w1 = js * jb[1], w2 = js * jb[2];
-        a10[1] += w0 * wr;
-        a10[2] += w1 * wr;
-        a10[3] += w2 * wr;
-        a10[4] += w0 * w0;
-        a10[5] += w0 * w1;
-        a10[6] += w0 * w2;
-        a10[7] += w1 * w1;
-        a10[8] += w1 * w2;
-        a10[9] += w2 * w2;
       }
     }
-    if (MODE == 1) {
-#pragma unroll
-      for (int jj = 1; jj <= WIN_SMAX; ++jj)
-        if (jj == j) {
-#pragma unroll
-          for (int i = 0; i < 10; ++i) acc[(jj - 1) * 10 + i] += a10[i];
-        }
-    }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double badf = wave_max((double)bad);
-  double* r = shw.red[parity][0];
-  parity ^= 1;
-  if (MODE == 0) {
-    mx = wave_max(mx);
-    if (lane == 0) {
-      r[wave * 34 + 0] = mx;
-      r[wave * 34 + 1] = badf;
-    }
-    __syncthreads();
+  if (MODE == 0) mx = wave_max(mx);
+  if (lane == 0) {
+    r[64 + wave] = badf;
+    r[72 + wave] = mx;
+  }
+  __syncthreads();
 #pragma unroll
-    for (int w = 0; w < WIN_WAVES; ++w) {
-      mx = r[w * 34] > mx ? r[w * 34] : mx;
-      badf = r[w * 34 + 1] > badf ? r[w * 34 + 1] : badf;
-    }
+  for (int w = 0; w < WIN_WAVES; ++w) badf = r[64 + w] > badf ? r[64 + w] : badf;
+  if (MODE == 0) {
+#pragma unroll
+    for (int w = 0; w < WIN_WAVES; ++w) mx = r[72 + w] > mx ? r[72 + w] : mx;
     if (threadIdx.x == 0) out[0] = mx > 0.0 ? sqrt(mx) : 0.0;
     __syncthreads();
     return uni(badf == 0.0);
   }
-#pragma unroll
-  for (int i = 0; i < WIN_SMAX * 10; ++i) acc[i] = wave_sum(acc[i]);
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < WIN_SMAX * 10; ++i) r[wave * 34 + i] = acc[i];
-    r[wave * 34 + 30] = badf;
+  // per-state sums in term order, one thread per sum; published by the caller's next barrier
+  if (threadIdx.x < WIN_SMAX * 10) {
+    const int jj = (int)threadIdx.x / 10 + 1, i = (int)threadIdx.x % 10;
+    double a = 0.0;
+    for (int t = 0; t < W.n_terms; ++t)
+      if (W.term_state[t] == jj) a += r[t * 10 + i];
+    out[threadIdx.x] = a;
   }
-  __syncthreads();
-#pragma unroll
-  for (int w = 0; w < WIN_WAVES; ++w) badf = r[w * 34 + 30] > badf ? r[w * 34 + 30] : badf;
-  // fixed-order 4-way combine, one thread per sum; published by the caller's next barrier
-  if (threadIdx.x < WIN_SMAX * 10) out[threadIdx.x] = ((r[0 * 34 + threadIdx.x] + r[1 * 34 + threadIdx.x]) + r[2 * 34 + threadIdx.x]) + r[3 * 34 + threadIdx.x];
   return uni(badf == 0.0);
 }
 
