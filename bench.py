@@ -48,13 +48,16 @@ def main():
                     help="diagnostic: registrations per step = 512 x this (the headline workload is 1)")
     ap.add_argument("--only", choices=["build", "associate", "solve"], default=None,
                     help="diagnostic: time ONE stage alone at saturation (the printed value is then not the headline metric)")
-    ap.add_argument("--streams", type=int, default=4, help="in-flight batches: step i runs on HIP stream i %% streams")
+    ap.add_argument("--streams", type=int, default=16, help="in-flight batches: step i runs on HIP stream i %% streams "
+                    "(GPU_MAX_HW_QUEUES is raised to match unless already set: HIP maps streams onto 4 hardware queues by default)")
     ap.add_argument("--odometry-scans", type=int, default=200, help="BASELINE config 3 side measurement (0 = skip)")
     ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock budget of the CPU baseline leg")
     args = ap.parse_args()
 
+    # in-flight batches need their own hardware queues to overlap (must be set before the HIP runtime starts)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(32, args.streams))))
     import torch
     import torch.distributed as dist
 

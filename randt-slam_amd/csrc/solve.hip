@@ -131,20 +131,8 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   for (int i = 0; i < 10; ++i) acc[i] = 0.0;
   double mx = -DBL_MAX;
   int bad = 0;
-  const bool compact = S.pairs != nullptr;
-  const int n_it = compact ? S.n_pairs : S.n_slots;
-  for (int slot = threadIdx.x; slot < n_it; slot += BLOCK) {
-    unsigned mi, ci;
-    if (compact) {
-      const unsigned u = S.pairs[slot];
-      mi = u >> PAIR_SHIFT;
-      ci = u & PAIR_MASK;
-    } else {
-      const int cr = S.corr[slot];
-      if (cr < 0 || cr >= S.fixed_cap) continue;
-      ci = (unsigned)cr;
-      mi = S.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, S.kmagic);  // slot / k
-    }
+  // one residual; mi / ci = moving / fixed compact cell index
+  auto one = [&](unsigned mi, unsigned ci) {
     const float4* mv = S.mov + (size_t)mi * 3;
     const float4* fv = S.fix + (size_t)ci * 3;
     double jb[3];
@@ -154,6 +142,18 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
       mx = sq > mx ? sq : mx;
     } else {
       accumulate_residual<AM2>(L, sq, jb, acc);
+    }
+  };
+  if (S.n_pairs > 0) {  // scalar: the dense list in LDS
+    for (int e = threadIdx.x; e < S.n_pairs; e += BLOCK) {
+      const unsigned u = S.pairs[e];
+      one(u >> PAIR_SHIFT, u & PAIR_MASK);
+    }
+  } else {
+    for (int slot = threadIdx.x; slot < S.n_slots; slot += BLOCK) {
+      const int cr = S.corr[slot];
+      if (cr < 0 || cr >= S.fixed_cap) continue;
+      one(S.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, S.kmagic) /* slot / k */, (unsigned)cr);
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) n_res += s_count[w];
   }
+  n_res = __builtin_amdgcn_readfirstlane(n_res);  // same in every lane: keep it (and what hangs off it) scalar
   int parity = 0;
 
   // Compact the valid correspondences once (ascending slot order): every pass then walks a dense list,

@@ -167,20 +167,19 @@ __device__ __forceinline__ void accumulate_residual(const Loss& L, double sq, co
   // With r = sqrt(sq) and the true Jacobian row J = jb / r: the corrected residual is rs * r and the
   // corrected row js * J, so  J^T r += (js rs) jb  and  J^T J += (js^2 / sq) jb jb^T  -- no square root.
   // sq == 0: autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545); zero row instead.
-  if (sq > DBL_MIN) {
-    const double jr = js * rs;
-    const double h = js * js * fast_rcp(sq);
-    const double h0 = h * jb[0], h1 = h * jb[1], h2 = h * jb[2];
-    acc[1] += jr * jb[0];
-    acc[2] += jr * jb[1];
-    acc[3] += jr * jb[2];
-    acc[4] += h0 * jb[0];
-    acc[5] += h0 * jb[1];
-    acc[6] += h0 * jb[2];
-    acc[7] += h1 * jb[1];
-    acc[8] += h1 * jb[2];
-    acc[9] += h2 * jb[2];
-  }
+  // (branch-free: jb is exactly zero when sq is, so clamping the reciprocal's argument suffices)
+  const double jr = js * rs;
+  const double h = js * js * fast_rcp(fmax(sq, DBL_MIN));
+  const double h0 = h * jb[0], h1 = h * jb[1], h2 = h * jb[2];
+  acc[1] += jr * jb[0];
+  acc[2] += jr * jb[1];
+  acc[3] += jr * jb[2];
+  acc[4] += h0 * jb[0];
+  acc[5] += h0 * jb[1];
+  acc[6] += h0 * jb[2];
+  acc[7] += h1 * jb[1];
+  acc[8] += h1 * jb[2];
+  acc[9] += h2 * jb[2];
 }
 
 // ---------------------------------------------------------------- reductions -------------------

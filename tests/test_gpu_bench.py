@@ -38,7 +38,7 @@ def test_bench_two_ranks_control_flow():
     env = dict(os.environ, RANDT_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
-           "--odometry-scans", "0", "--polar-scans", "0"]
+           "--odometry-scans", "0", "--polar-scans", "0", "--streams", "2"]   # two processes share ONE GPU here
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 1e5
