@@ -26,7 +26,10 @@ using namespace randt_dev;
 #define ASSOC_WAVES (ASSOC_BLOCK / 64)
 #define ASSOC_MAX_R 7    // window <= 15x15 = 225 slots = 4 lane passes
 #define ASSOC_PASSES 4
-#define ASSOC_CH 64      // moving cells per chunk
+#ifndef ASSOC_CH
+#define ASSOC_CH 64      // moving cells per chunk (64 or 128)
+#endif
+#define ASSOC_CH_LOG2 (ASSOC_CH == 128 ? 7 : 6)
 #define ASSOC_CAND 64    // candidates per cell: <= (k-1) + 8R = 63 for k <= 8, R <= 7
 #define ASSOC_QS 11      // LDS stride of a query record (odd => conflict-free)
 
@@ -282,24 +285,30 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
 
     // exclusive prefix of clen over the chunk (one wavefront)
     if (wave == 0) {
-      const int v = lane < nch ? clen[lane] : 0;
-      int incl = v;
+      int carry = 0;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
+      for (int h = 0; h < ASSOC_CH / 64; ++h) {
+        const int e = h * 64 + lane;
+        const int v = e < nch ? clen[e] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int t = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += t;
+        }
+        cpref[e] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
       }
-      cpref[lane] = incl - v;
-      if (lane == 63) cpref[64] = incl;
+      if (lane == 0) cpref[ASSOC_CH] = carry;
     }
     __syncthreads();
-    const int total = cpref[64];
+    const int total = cpref[ASSOC_CH];
 
     // ---- P3: one thread per (cell, candidate): gather + fp32 distance
     for (int p = tid; p < total; p += ASSOC_BLOCK) {
       int lo = 0, hi = nch;  // largest c with cpref[c] <= p
 #pragma unroll
-      for (int s = 0; s < 7; ++s) {
+      for (int s = 0; s < ASSOC_CH_LOG2 + 1; ++s) {
         const int mid = (lo + hi) >> 1;
         if (hi - lo > 1) {
           if (cpref[mid] <= p) lo = mid; else hi = mid;
