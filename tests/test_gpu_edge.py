@@ -159,3 +159,108 @@ def test_run_to_run_bitwise_determinism(env):
         outs.append((pose.cpu().numpy().copy(), res.cpu().numpy().copy()))
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])   # fixed reduction tree
+
+
+# ---------------------------------------------------------------------------------------------------
+# paths added with the round-1 kernel rewrites
+def _build_both(env, pts, mapp_args, clu_args, cap, ioff=3):
+    torch, dev, ctx = env
+    mapp, clu = R.MapParams(*mapp_args), R.ClusterParams(*clu_args)
+    maps = R.Maps(ctx, 1, mapp, cap, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(pts[None]).to(dev), clu, maps)
+    om = po.Map(mapp_args[0], mapp_args[1], mapp_args[2], (mapp_args[3], mapp_args[4]), mapp_args[5], mapp_args[6], cap)
+    om.build(pts, clu.n_clusters, clu.max_range, ioff=ioff)
+    cells, grid = maps.download(0)
+    return cells, grid, om, maps
+
+
+def test_cluster_means_outside_the_map_shift_the_cell_indices(env):
+    """clusters whose mean leaves a SMALL map are dropped (vector::at in the reference): every later cell's
+    compact index shifts, which the build kernel handles by redoing the statistics in strict cluster order."""
+    rng = np.random.default_rng(3)
+    pts = np.zeros((2000, 4), dtype=F)
+    pts[:, :2] = rng.uniform(-20, 20, (2000, 2))                # map below is only +-6 m
+    pts[:, 3] = rng.uniform(10, 90, 2000)
+    # dense blobs so that clusters pass min_points both inside and outside the map
+    pts[:900, :2] = rng.normal(0, 0.08, (900, 2)) + rng.integers(-18, 18, (900, 1)).astype(F) * np.array([[1.0, 0.7]], dtype=F)
+    cells, grid, om, _ = _build_both(env, pts, (24, 24, 0.5, 0.0, 0.0, 4.0, 3, 0), (6400, 20.0), 512)
+    assert om.n_cells > 5
+    assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+
+
+def test_cell_capacity_overflow_keeps_the_first_cells(env):
+    rng = np.random.default_rng(4)
+    pts = np.zeros((4000, 4), dtype=F)
+    pts[:, :2] = (rng.integers(-30, 30, (4000, 2)) * 0.5 + 0.25 + rng.normal(0, 0.03, (4000, 2))).astype(F)
+    pts[:, 3] = rng.uniform(10, 90, 4000)
+    cells, grid, om, maps = _build_both(env, pts, (100, 100, 0.5, 0.0, 0.0, 4.0, 0, 0), (2304, 24.0), 64)
+    assert len(cells) == 64 == om.n_cells                       # more clusters than capacity
+    assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+
+
+def test_many_small_clusters_take_the_unranked_order(env):
+    """> 256 clusters: the size-class hand-out still applies (any order gives the same cells)."""
+    rng = np.random.default_rng(5)
+    pts = np.zeros((7000, 4), dtype=F)
+    pts[:, :2] = rng.uniform(-23.9, 23.9, (7000, 2))
+    pts[:, 3] = rng.uniform(10, 90, 7000)
+    cells, grid, om, _ = _build_both(env, pts, (100, 100, 0.5, 0.0, 0.0, 4.0, 1, 0), (2304, 24.0), 4096)
+    assert om.n_cells > 256
+    assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+
+
+def _assoc_both(env, fixed_pts, moving_pts, mapp_args, clu_args, k, mahal=1, intensity=1, guess=(1.0, 0.0, 0.0, 0.0)):
+    torch, dev, ctx = env
+    mapp, clu = R.MapParams(*mapp_args), R.ClusterParams(*clu_args)
+    fmap = R.Maps(ctx, 1, mapp, 4096, with_grid=True)
+    mmap = R.Maps(ctx, 1, mapp, 512, with_grid=False)
+    R.ndt_build_batch(ctx, torch.from_numpy(fixed_pts[None]).to(dev), clu, fmap)
+    R.ndt_build_batch(ctx, torch.from_numpy(moving_pts[None]).to(dev), clu, mmap)
+    mp = R.default_matcher_params(n_neighbours=k, lookup_mahalanobis=mahal, use_intensity=intensity)
+    g = torch.tensor([guess], dtype=torch.float64, device=dev)
+    corr = torch.full((1, 512, k), -7, dtype=torch.int32, device=dev)
+    R.associate_batch(ctx, fmap, torch.zeros(1, dtype=torch.int32, device=dev), mmap, 0, 1, g, mp, corr)
+    ctx.synchronize()
+
+    def omap(cap):
+        return po.Map(mapp_args[0], mapp_args[1], mapp_args[2], (mapp_args[3], mapp_args[4]), mapp_args[5], mapp_args[6], cap)
+
+    of, om = omap(4096), omap(512)
+    of.build(fixed_pts, clu.n_clusters, clu.max_range)
+    om.build(moving_pts, clu.n_clusters, clu.max_range)
+    oc, _ = po.associate(of, om, np.array(guess), k, mahal, intensity)
+    return corr.cpu().numpy()[0, : om.n_cells], oc, om.n_cells, of.n_cells
+
+
+def _blobs(seed, n_blobs, extent, n=2000, sigma=0.07):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-extent, extent, (n_blobs, 2))
+    pts = np.zeros((n, 4), dtype=F)
+    pts[:, :2] = (c[rng.integers(0, n_blobs, n)] + rng.normal(0, sigma, (n, 2))).astype(F)
+    pts[:, 3] = rng.uniform(10, 90, n)
+    return pts
+
+
+@pytest.mark.parametrize("max_dist,k", [(0.5, 1), (1.0, 3), (2.0, 8), (4.0, 8), (4.0, 1)])
+@pytest.mark.parametrize("n_fixed_blobs", [6, 60])
+def test_association_termination_radius_variants(env, max_dist, k, n_fixed_blobs):
+    """sparse and dense fixed maps, every window limit rmax = max_dist / 0.5 in {1, 2, 4, 8}: the search stops at
+    different radii (enough targets, or the last radius), which the kernel decides with one ballot."""
+    mapp = (100, 100, 0.5, 0.0, 0.0, max_dist, 3, 0)
+    got, want, nm, nf = _assoc_both(env, _blobs(11, n_fixed_blobs, 20.0), _blobs(12, 40, 20.0), mapp, (2304, 24.0), k,
+                                    guess=(np.cos(0.05), np.sin(0.05), 0.3, -0.2))
+    assert nm > 5 and nf > 3
+    assert np.array_equal(got, want)
+
+
+def test_association_on_a_map_narrower_than_the_window(env):
+    """size_x <= 2 (rmax - 1): the search window wraps onto itself and the reference removes repeated
+    entries (std::find) -- the radius-by-radius path of the kernel."""
+    mapp = (12, 40, 0.5, 0.0, 0.0, 4.0, 3, 0)
+    fixed = _blobs(21, 30, 2.5)
+    fixed[:, 1] *= 3.5
+    moving = _blobs(22, 20, 2.5)
+    moving[:, 1] *= 3.5
+    got, want, nm, nf = _assoc_both(env, fixed, moving, mapp, (2304, 24.0), 5)
+    assert nm > 3 and nf > 3
+    assert np.array_equal(got, want)
