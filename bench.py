@@ -236,6 +236,10 @@ def main():
                 "bound": "fp64_valu", "kernel": "k_solve", "achieved": flops / (float(stage_ms[2]) * 1e-3) / 1e12,
                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / (float(stage_ms[2]) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "note": "per launch: useful fp64 flops of one 512-registration solve / its duration while %d batches share the chip" % n_streams,
+                # whole-path figure: the solve's useful flops per registration x registrations/s of one GPU
+                "path_effective": {"achieved": flops / B * (value / world) / 1e12,
+                                   "frac": flops / B * (value / world) / 1e12 / FP64_PEAK_TFLOPS},
             },
         }
         if not args.no_cpu_baseline and world == 1:
