@@ -18,9 +18,13 @@
 //                    points in the reference's order.
 #include "randt_internal.h"
 
+#include <math.h>
+#include <string.h>
+
 #pragma clang fp contract(off)
 
 #define FILT_BLOCK 256
+#define FILT_XBLOCK 512  // expansion kernel: all azimuth rows of a 400-row scan in one round
 
 namespace {
 
@@ -31,6 +35,7 @@ struct FilterArgs {
   const float* raw;   // [n_scans][n_az][n_bins][stride]
   int n_az, n_bins, stride, ioff;
   float min_d, max_d, min_i, thr;
+  double lo2, hi2;    // range test on the squared distance: min_d < hypot(x, y) < max_d  <=>  lo2 <= x^2 + y^2 <= hi2
   float T[12];
   float* out_pts;     // [n_scans][pitch_out][4]
   float* out_polar;   // nullable [n_scans][pitch_out][2]
@@ -73,6 +78,12 @@ __global__ __launch_bounds__(FILT_BLOCK) void k_filter_peaks(FilterArgs A) {
   float best_i = 0.f;  // max_intensity starts at 0: only intensity > 0 can win
   int best_idx = 0x7fffffff;
   int bad = 0;
+  // The kernel must stay on the HBM roofline, so the two per-point tests are restated without transcendental
+  // work: (a) range: hypot() in float after a double sqrt is monotone in d2 = x^2 + y^2, so the launcher
+  // bisects the two double thresholds once; (b) organisation: a point whose direction is within 4e-5 rad of
+  // the row's first point (|cross| <= 4e-5 dot) cannot differ from it by 1e-4 in atan2f; only other points
+  // (none in an organised scan) and rows next to the +-pi cut take the exact atan2f comparison.
+  const bool near_cut = !(fabsf(a0) < 3.14f);
   for (int b0 = tid; b0 < A.n_bins; b0 += 4 * FILT_BLOCK) {
     float x[4], y[4], in[4];
 #pragma unroll
@@ -85,10 +96,13 @@ __global__ __launch_bounds__(FILT_BLOCK) void k_filter_peaks(FilterArgs A) {
     for (int u = 0; u < 4; ++u) {
       const int b = b0 + u * FILT_BLOCK;
       if (b < A.n_bins) {
-        const float dist = hypot_f(x[u], y[u]);
-        const float ang = atan2f(y[u], x[u]);
-        if (fabsf(ang - a0) > 0.0001) bad = 1;  // an azimuth change inside the row
-        if ((double)dist > (double)A.min_d && (double)dist < (double)A.max_d) {
+        const float cross = x0 * y[u] - y0 * x[u], dot = x0 * x[u] + y0 * y[u];
+        if (near_cut || !(fabsf(cross) <= 4e-5f * dot)) {
+          const float ang = atan2f(y[u], x[u]);
+          if (fabsf(ang - a0) > 0.0001) bad = 1;  // an azimuth change inside the row
+        }
+        const double d2 = (double)x[u] * (double)x[u] + (double)y[u] * (double)y[u];
+        if (d2 >= A.lo2 && d2 <= A.hi2) {
           if (in[u] > best_i || (in[u] == best_i && in[u] > 0.f && b < best_idx)) {
             best_i = in[u];
             best_idx = b;
@@ -144,7 +158,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total) 
   __syncthreads();
   int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < FILT_XBLOCK / 64; ++w) {
     const int s = scratch[w];
     if (w < wave) base += s;
     tot += s;
@@ -153,8 +167,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total) 
   return base + incl - v;
 }
 
-__global__ __launch_bounds__(FILT_BLOCK) void k_filter_expand(FilterArgs A) {
-  __shared__ int scratch[8];
+__global__ __launch_bounds__(FILT_XBLOCK) void k_filter_expand(FilterArgs A) {
+  __shared__ int scratch[FILT_XBLOCK / 64];
   const int scan = blockIdx.x, tid = threadIdx.x;
   const float* base = A.raw + (size_t)scan * A.n_az * A.n_bins * A.stride;
   const long long n = (long long)A.n_az * A.n_bins;
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(FILT_BLOCK) void k_filter_expand(FilterArgs A) {
   const float* row_maxi = A.row_maxi + (size_t)scan * A.n_az;
   // consecutive azimuths must differ by more than the reference's 1e-4 rad threshold
   int bad = 0;
-  for (int r = 1 + tid; r < A.n_az; r += FILT_BLOCK)
+  for (int r = 1 + tid; r < A.n_az; r += FILT_XBLOCK)
     if (!(fabsf(row_angle[r] - row_angle[r - 1]) > 0.0001)) bad = 1;
   if (bad) atomicMax(&A.status[scan], 1);
 
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(FILT_BLOCK) void k_filter_expand(FilterArgs A) {
   float* pk = A.peaks ? A.peaks + (size_t)scan * A.n_az * 3 : nullptr;
   // the last azimuth is never flushed (the push happens when the NEXT azimuth starts)
   const int n_rows = A.n_az - 1;
-  for (int r0 = 0; r0 < n_rows; r0 += FILT_BLOCK) {
+  for (int r0 = 0; r0 < n_rows; r0 += FILT_XBLOCK) {
     const int r = r0 + tid;
     long long m = -1;
     float pk_i = 0.f;
@@ -267,6 +281,27 @@ __global__ __launch_bounds__(FILT_BLOCK) void k_filter_expand(FilterArgs A) {
 
 }  // namespace
 
+namespace {
+// host twin of hypot_f (glibc: correctly rounded double sqrt, one rounding to float)
+inline float hypot_from_d2(double d2) { return (float)sqrt(d2); }
+// smallest non-negative double d2 with pred(d2) true, for a predicate that is monotone (false ... true) in d2
+template <typename Pred>
+double first_true(Pred pred) {
+  unsigned long long lo = 0, hi = 0x7ff0000000000000ull;  // bit patterns of +0 .. +inf are ordered like the values
+  if (pred(0.0)) return 0.0;
+  if (!pred(INFINITY)) return NAN;  // never true: every comparison with the threshold is false
+  while (hi - lo > 1) {
+    const unsigned long long mid = lo + (hi - lo) / 2;
+    double v;
+    memcpy(&v, &mid, 8);
+    if (pred(v)) hi = mid; else lo = mid;
+  }
+  double v;
+  memcpy(&v, &hi, 8);
+  return v;
+}
+}  // namespace
+
 int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az, int n_bins, int stride, int ioff,
                        const randt_filter_params* fp, float* d_out_pts, int pitch_out, int32_t* d_out_counts, float* d_polar,
                        float* d_peaks, int32_t* d_peak_counts, int32_t* d_status, void* d_scratch) {
@@ -280,6 +315,13 @@ int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az
   A.max_d = fp->max_range;
   A.min_i = fp->min_intensity;
   A.thr = fp->beam_distance_increment_threshold;
+  {
+    const float mn = A.min_d, mx = A.max_d;
+    A.lo2 = first_true([mn](double d2) { return (double)hypot_from_d2(d2) > (double)mn; });
+    // largest d2 still below max_d = predecessor of the first d2 that is not
+    const double first_not_below = first_true([mx](double d2) { return !((double)hypot_from_d2(d2) < (double)mx); });
+    A.hi2 = first_not_below > 0.0 ? nextafter(first_not_below, -1.0) : (first_not_below == 0.0 ? -1.0 : (double)INFINITY);
+  }
   for (int i = 0; i < 12; ++i) A.T[i] = fp->sensor_to_base[i];
   A.out_pts = d_out_pts;
   A.out_polar = d_polar;
@@ -293,7 +335,7 @@ int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az
   A.row_maxi = A.row_angle + (size_t)n_scans * n_az;
   RANDT_HIP_CHECK(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t) * n_scans, ctx->stream));
   hipLaunchKernelGGL(k_filter_peaks, dim3(n_az, n_scans), dim3(FILT_BLOCK), 0, ctx->stream, A);
-  hipLaunchKernelGGL(k_filter_expand, dim3(n_scans), dim3(FILT_BLOCK), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_filter_expand, dim3(n_scans), dim3(FILT_XBLOCK), 0, ctx->stream, A);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
