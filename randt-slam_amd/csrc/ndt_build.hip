@@ -124,11 +124,15 @@ __device__ void cluster_stats_sequential(const float* sx, const float* sy, const
 // each lane walks ONE chain.  Clusters are handed to the 32 groups in descending size so that a
 // round's wavefronts finish together.
 // Dynamic LDS: sx | sy | si [npad] | cstart[npad+2] | aux (bins u64[nb_cap] / labels / order+prefix) | scratch
-template <int PPT, bool KEEP>
+// REG: scans of <= 2048 points keep their points and labels in registers (8 per lane, loops fully unrolled);
+// larger scans keep the per-point word in LDS and re-read the points (L2-hot) with rolled loops.
+template <bool REG>
 __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restrict__ pts, int pitch,
                                                            const int32_t* __restrict__ n_pts_arr, int stride,
                                                            int ioff, int row_size, float resolution, MapView out,
                                                            int first_map, int npad, int nb_cap, int aux_bytes) {
+  constexpr int PPT = 8;
+  constexpr bool KEEP = REG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // points in labelClouds order; the three arrays are shifted by 16 banks against each other because the
   // lanes of a cluster group read x[j], y[j] and i[j] in the same instruction
@@ -137,10 +141,13 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   float* si = sy + npad + 16;
   int* cstart = reinterpret_cast<int*>(si + npad + 16);                       // [npad + 1] (+1 pad)
   unsigned long long* bins = reinterpret_cast<unsigned long long*>(cstart + npad + 2);
-  int32_t* lab = reinterpret_cast<int32_t*>(bins);                            // fallback only (aliases bins)
-  uint16_t* order = reinterpret_cast<uint16_t*>(bins);                        // after placement (aliases bins)
+  int* scratch = reinterpret_cast<int*>(reinterpret_cast<char*>(bins) + aux_bytes);  // [64]
+  int32_t* plab = scratch + 64;  // !REG: per-point word [npad] (label, later bin | rank)
+  // re-used regions: the fallback's label array and, after the placement, the cluster order + index prefix
+  // (2 x u16 per cluster) alias the bins (REG) or the per-point words (!REG)
+  int32_t* lab = REG ? reinterpret_cast<int32_t*>(bins) : plab;
+  uint16_t* order = reinterpret_cast<uint16_t*>(lab);
   uint16_t* pre = order + npad;
-  int* scratch = reinterpret_cast<int*>(reinterpret_cast<char*>(bins) + aux_bytes);  // [48]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scan = blockIdx.x;
@@ -186,11 +193,13 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   const int q = (n + 3) >> 2;
   const int w_beg = wave * q, w_end = (w_beg + q) < n ? (w_beg + q) : n;
   float px[KEEP ? PPT : 1], py[KEEP ? PPT : 1], pin[KEEP ? PPT : 1];
-  int32_t pl[PPT];  // label, later: rank inside (label, wave)
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) {
+  int32_t pl[REG ? PPT : 1];  // label, later: rank inside (label, wave)
+  const int nsteps = REG ? PPT : (q + 63) >> 6;
+#define RANDT_PL(j, i) (*(REG ? &pl[REG ? (j) : 0] : &plab[i]))
+#pragma unroll 8
+  for (int j = 0; j < nsteps; ++j) {
     const int i = w_beg + 64 * j + lane;
-    pl[j] = 0;
+    if (REG) pl[REG ? j : 0] = 0;
     if (i < w_end) {
       float x, y, in;
       RANDT_FETCH_POINT(i, x, y, in);
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
         pin[j] = in;
       }
       const int32_t l = point_label(x, y, row_size, resolution);
-      pl[j] = l;
+      RANDT_PL(j, i) = l;
       lmin = l < lmin ? l : lmin;
       lmax = l > lmax ? l : lmax;
     }
@@ -236,11 +245,11 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     const int nbits = nb > 1 ? 32 - __clz(nb - 1) : 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int sh = 16 * wave;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
+#pragma unroll 8
+    for (int j = 0; j < nsteps; ++j) {
       const int i = w_beg + 64 * j + lane;
       const bool valid = i < w_end;
-      const int b = pl[j] - lmin;
+      const int b = (valid ? RANDT_PL(j, i) : 0) - lmin;
       unsigned long long mask = __ballot(valid);  // lanes of this step with my label
       if (mask == 0ull) break;                    // wave-uniform: this quarter is exhausted
       for (int bit = 0; bit < nbits; ++bit) {
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
         field = (int)((old >> sh) & 0xffff);
       }
       field = __shfl(field, valid ? leader : lane, 64);
-      pl[j] = b | ((field + __popcll(mask & lt)) << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
+      if (valid) RANDT_PL(j, i) = b | ((field + __popcll(mask & lt)) << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
     }
     __syncthreads();
     RANDT_TICK(3);
@@ -286,11 +295,12 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     __syncthreads();
     RANDT_TICK(4);
     // ---- placement: position = start of (bin, wave) + rank inside it
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
+#pragma unroll 8
+    for (int j = 0; j < nsteps; ++j) {
       const int i = w_beg + 64 * j + lane;
       if (i < w_end) {
-        const int b = pl[j] & 0xffff, r = (int)((unsigned)pl[j] >> 16);
+        const int word = RANDT_PL(j, i);
+        const int b = word & 0xffff, r = (int)((unsigned)word >> 16);
         const int pos = (int)((bins[b] >> sh) & 0xffff) + r;
         float x, y, in;
         if (KEEP) {
@@ -308,10 +318,10 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     __syncthreads();
   } else {
     // fallback: rank of (label, index) by counting -- unique keys => a permutation
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
+#pragma unroll 8
+    for (int j = 0; j < nsteps; ++j) {
       const int i = w_beg + 64 * j + lane;
-      if (i < w_end) lab[i] = pl[j];
+      if (i < w_end) lab[i] = RANDT_PL(j, i);
     }
     __syncthreads();
     for (int i = tid; i < n; i += BUILD_BLOCK) {
@@ -454,7 +464,9 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
           if (grid) atomicMax(&grid[slot], target);
         }
       } else {
-        scratch[4] = 1;
+        // dropped: later cells move down.  2 = cannot be repaired by moving cells (index marker overflow)
+        atomicMax(&scratch[4], target == 0xfffe ? 2 : 1);
+        if (target != 0xfffe) pre[c] = 0xfffd;
       }
     }
     if (r0 == 0) RANDT_TICK(12);
@@ -462,8 +474,35 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   }
   __syncthreads();
   RANDT_TICK(8);
-  if (scratch[4]) {
-    // rare: indices shift behind a dropped cluster (or > 65534 cells) -- redo in strict cluster order
+  const int dropped = scratch[4];
+  if (dropped == 1 && n_cells <= out.cap) {
+    // Cluster means outside the map (dropped like the reference's vector::at would): the statistics are done,
+    // only the compact indices behind a dropped cluster are too high.  Move the cells down in cluster order --
+    // 256 clusters at a time: read, barrier, write (a cell's final index never exceeds its provisional one, and
+    // a chunk's final range ends below the next chunk's provisional range) -- and redo the slot -> cell grid.
+    if (grid) {
+      for (int i = tid; i < out.n_slots; i += BUILD_BLOCK) grid[i] = -1;
+    }
+    __syncthreads();
+    int n_final = 0;
+    for (int c0 = 0; c0 < nc; c0 += BUILD_BLOCK) {
+      const int c = c0 + tid;
+      const int prov = c < nc ? (int)pre[c] : 0xffff;
+      const bool keep = prov < 0xfffd;
+      randt_cell cell;
+      if (keep) cell = load_cell(cells + prov);
+      int tot;
+      const int fin = n_final + block_exclusive_scan_256(keep ? 1 : 0, scratch, &tot);  // barriers: all reads done
+      if (keep) {
+        store_cell(cells + fin, cell);
+        if (grid) atomicMax(&grid[coord_to_index(out, cell.mean[0], cell.mean[1])], fin);
+      }
+      n_final += tot;
+      __syncthreads();
+    }
+    n_cells = n_final;
+  } else if (dropped) {
+    // (capacity overflow or > 65534 cells together with a dropped cluster) -- redo in strict cluster order
     if (grid) {
       for (int i = tid; i < out.n_slots; i += BUILD_BLOCK) grid[i] = -1;
     }
@@ -577,12 +616,13 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   // Grid::cluster (grid.cpp:8-9)
   const int row_size = (int)sqrt((double)cp->n_clusters);
   const float resolution = cp->max_range * 2 / (float)row_size;
+  const bool reg = pitch <= 2048;  // 8 points per lane in registers
   // label bins: coordinates inside +-max_range (what RadarPreprocessor hands over) in fast mode: int(x/res) and
   // int(y/res) in [-row/2, row/2]; anything wider takes the fallback
-  const size_t fixed_bytes = (size_t)npad * 12 + 192 + (size_t)(npad + 2) * 4 + 256;
+  const size_t fixed_bytes = (size_t)npad * 12 + 192 + (size_t)(npad + 2) * 4 + 256 + (reg ? 0 : (size_t)npad * 4);
   // aux region: label bins (8 B each) during the sort, then order + index prefix (2 x u16 per cluster);
   // the fallback parks the labels there (4 B per point)
-  const size_t aux_min = (size_t)npad * 4;
+  const size_t aux_min = reg ? (size_t)npad * 4 : 64;
   int nb_want = row_size * row_size + 2 * row_size + 2;
   if (nb_want > 65535) nb_want = 65535;  // bin index is packed into 16 bits
   // smallest occupancy tier (3, 2, 1 workgroups per CU) that holds all the bins
@@ -597,17 +637,15 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   if (aux < aux_min) aux = aux_min;
   aux = (aux + 15) & ~(size_t)15;
   const size_t lds = fixed_bytes + aux;
-#define RANDT_BUILD_LAUNCH(PPT, KEEP)                                                                                      \
+#define RANDT_BUILD_LAUNCH(REG)                                                                                            \
   do {                                                                                                                     \
-    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<PPT, KEEP>),                        \
+    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<REG>),                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
-    hipLaunchKernelGGL((k_ndt_build<PPT, KEEP>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,      \
+    hipLaunchKernelGGL((k_ndt_build<REG>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,            \
                        d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux);            \
   } while (0)
-  // points per lane: a wave owns a quarter of the scan
-  if (pitch <= 2048) RANDT_BUILD_LAUNCH(8, true);
-  else if (pitch <= 4096) RANDT_BUILD_LAUNCH(16, false);
-  else RANDT_BUILD_LAUNCH(28, false);
+  if (reg) RANDT_BUILD_LAUNCH(true);
+  else RANDT_BUILD_LAUNCH(false);
 #undef RANDT_BUILD_LAUNCH
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
