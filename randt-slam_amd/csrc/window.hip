@@ -52,13 +52,14 @@ namespace {
 
 // ---------------------------------------------------------------- SE(2) (Sophus 1.22.10) -------
 __device__ __forceinline__ void so2_normalize(double& c, double& s) {
-  const double len = sqrt(c * c + s * s);
-  c = c / len;
-  s = s / len;
+  const double inv = fast_rsqrt(c * c + s * s);  // Newton-refined reciprocal square root (~1 ulp) instead of sqrt + 2 divisions
+  c = c * inv;
+  s = s * inv;
 }
 __device__ __forceinline__ void se2_exp(const double* xi, double* out) {
   const double theta = xi[2];
-  double c = cos(theta), s = sin(theta);
+  double c, s;
+  sincos(theta, &s, &c);
   so2_normalize(c, s);
   double sbt, omcbt;
   if (fabs(theta) < 1e-10) {
@@ -66,8 +67,9 @@ __device__ __forceinline__ void se2_exp(const double* xi, double* out) {
     sbt = 1.0 - (1.0 / 6.0) * tsq;
     omcbt = 0.5 * theta - (1.0 / 24.0) * theta * tsq;
   } else {
-    sbt = s / theta;
-    omcbt = (1.0 - c) / theta;
+    const double it = fast_rcp(theta);
+    sbt = s * it;
+    omcbt = (1.0 - c) * it;
   }
   out[0] = c;
   out[1] = s;
@@ -79,7 +81,7 @@ __device__ __forceinline__ void se2_mul(const double* a, const double* b, double
   double im = a[0] * b[1] + a[1] * b[0];
   const double sq = re * re + im * im;
   if (sq != 1.0) {
-    const double scale = 2.0 / (1.0 + sq);
+    const double scale = 2.0 * fast_rcp(1.0 + sq);
     re *= scale;
     im *= scale;
   }
@@ -107,7 +109,7 @@ __device__ __forceinline__ void se2_log(const double* p, double* xi) {
   if (fabs(rm1) < 1e-10) {
     hbt = 1.0 - (1.0 / 12) * theta * theta;
   } else {
-    hbt = -(half * p[1]) / rm1;
+    hbt = -(half * p[1]) * fast_rcp(rm1);
   }
   xi[0] = hbt * p[2] + half * p[3];
   xi[1] = -half * p[2] + hbt * p[3];
@@ -136,7 +138,7 @@ __device__ void motion_factor(const double* x0, const double* x1, double raw_dt,
   r[5] = x1[6] - x0[6];
   r[6] = x1[7] - x0[7];
   r[7] = x1[8] - x0[8];
-  for (int i = 0; i < 128; ++i) Ju[i] = 0.0;
+  // (Ju was zeroed by the whole wavefront in factors_unweighted)
   const double phi = lg[2];
   const double cE = E[0], sE = E[1], tEx = E[2], tEy = E[3];
   double h, dh;  // Vinv(phi) = [[h, phi/2], [-phi/2, h]]
@@ -144,9 +146,12 @@ __device__ void motion_factor(const double* x0, const double* x1, double raw_dt,
     h = 1.0 - phi * phi / 12.0;
     dh = -phi / 6.0;
   } else {
-    const double half = 0.5 * phi, sh = sin(half), ch = cos(half);
-    h = half * ch / sh;
-    dh = 0.5 * ch / sh - 0.5 * half / (sh * sh);
+    const double half = 0.5 * phi;
+    double sh, ch;
+    sincos(half, &sh, &ch);
+    const double ish = fast_rcp(sh), cot = ch * ish;
+    h = half * cot;
+    dh = 0.5 * cot - 0.5 * half * (ish * ish);
   }
   const double Vi00 = h, Vi01 = 0.5 * phi, Vi10 = -0.5 * phi, Vi11 = h;
   const double dVt0 = dh * tEx + 0.5 * tEy, dVt1 = -0.5 * tEx + dh * tEy;
@@ -167,11 +172,14 @@ __device__ void motion_factor(const double* x0, const double* x1, double raw_dt,
     da = -w / 3.0;
     db = 0.5 - w * w / 8.0;
   } else {
-    const double w = xi[2], s = sin(w), c = cos(w);
-    a = s / w;
-    b = (1.0 - c) / w;
-    da = (w * c - s) / (w * w);
-    db = (w * s - (1.0 - c)) / (w * w);
+    const double w = xi[2];
+    double s, c;
+    sincos(w, &s, &c);
+    const double iw = fast_rcp(w), iw2 = iw * iw;
+    a = s * iw;
+    b = (1.0 - c) * iw;
+    da = (w * c - s) * iw2;
+    db = (w * s - (1.0 - c)) * iw2;
   }
   const double c0 = x0[0], s0 = x0[1];
   const double Vx = a * xi[0] - b * xi[1], Vy = b * xi[0] + a * xi[1];
@@ -265,6 +273,8 @@ struct Shared {
 // Unweighted motion / IMU factors at xs[buf], one lane per factor (called by ONE wavefront).
 __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
   const int lane = threadIdx.x & 63;
+  for (int e = lane; e < W.S * 128; e += 64) (&sh.Ju[0][0])[e] = 0.0;  // all lanes clear the Jacobian blocks
+  wave_fence();
   if (lane < W.S) {
     const int f = lane;  // factor between states f and f+1
     double r[8];
@@ -528,6 +538,9 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   const WinDesc& W = *Wp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = W.n_tan, S = W.S;
+  // entry e = lane + 64 t of an n x n matrix is (ent_i0 + t ent_di + carries, ...): one division per kernel
+  const int nn = n > 0 ? n : 1;
+  const int ent_i0 = lane / nn, ent_j0 = lane % nn, ent_di = 64 / nn, ent_dj = 64 % nn;
   int parity = 0;
 
   // ---- load states, build column maps
@@ -659,7 +672,19 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
               if (lane < n) sh.sigma[lane] = 1.0 / (1.0 + sqrt(sh.H[lane * n + lane]));
               wave_fence();
             }
-            for (int e = lane; e < n * n; e += 64) sh.Hs[e] = sh.H[e] * sh.sigma[e / n] * sh.sigma[e % n];
+            // all 64 lanes over the n^2 entries; (row, column) of entry e advance incrementally (no division)
+            {
+              int ei = ent_i0, ej = ent_j0;
+              for (int e = lane; e < n * n; e += 64) {
+                sh.Hs[e] = sh.H[e] * sh.sigma[ei] * sh.sigma[ej];
+                ei += ent_di;
+                ej += ent_dj;
+                if (ej >= n) {
+                  ej -= n;
+                  ++ei;
+                }
+              }
+            }
             if (lane < n) sh.gs[lane] = sh.g[lane] * sh.sigma[lane];
             // gradient tolerance: ||x - Plus(x, -g)||_inf <= gtol
             double gm = lane < n ? fabs(sh.g[lane]) : 0.0;
@@ -707,9 +732,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         if (wave == 0) {
           if (!reuse && lane < n) sh.diag[lane] = fmin(fmax(sh.Hs[lane * n + lane], P.dmin), P.dmax);
           wave_fence();
-          const double inv_radius = 1.0 / radius;
-          for (int e = lane; e < n * n; e += 64) sh.A[e] = sh.Hs[e] + ((e / n) == (e % n) ? sh.diag[e / n] * inv_radius : 0.0);
-          wave_fence();
+          const double inv_radius = fast_rcp(radius);
           WT(8);
           // SPD solve A y = gs by Gauss-Jordan elimination entirely in registers.  Lane i keeps row i of A and
           // gs_i; after every step all rows are shifted left by one column, so the pivot column is ALWAYS register
@@ -719,9 +742,15 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           // round trips, no barriers; the j loop stays rolled (~130 instructions per step).
           double okf = 1.0;
           {
+            // row i of the damped matrix straight into registers: Hs is symmetric, so lane i reads COLUMN i
+            // (consecutive lanes -> consecutive words, no bank conflicts); (sqrt(D^2 / radius))^2 on the diagonal
             double row[WIN_NMAX], b = lane < n ? sh.gs[lane] : 0.0, dg = 1.0;
+            const double damp = lane < n ? sh.diag[lane] * inv_radius : 0.0;
 #pragma clang loop unroll(full)
-            for (int k = 0; k < WIN_NMAX; ++k) row[k] = (lane < n && k < n) ? sh.A[lane * n + k] : 0.0;
+            for (int k = 0; k < WIN_NMAX; ++k) {
+              row[k] = (lane < n && k < n) ? sh.Hs[k * n + lane] : 0.0;
+              if (k == lane) row[k] += damp;
+            }
             // at step j only the first n - j columns are still live: four rolled loops of width 32 / 24 / 16 / 8
             int j = 0;
 #define RANDT_GJ_STEPS(WIDTH)                                                                          \
@@ -755,7 +784,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           double t = 0.0;
           if (lane < n) {
             double hs = 0.0;
-            for (int b = 0; b < n; ++b) hs += sh.Hs[lane * n + b] * sh.step[b];
+            for (int b = 0; b < n; ++b) hs += sh.Hs[b * n + lane] * sh.step[b];  // symmetric: column read, conflict-free
             t = sh.step[lane] * (sh.gs[lane] + 0.5 * hs);
             sh.delta[lane] = sh.step[lane] * sh.sigma[lane];
           }
