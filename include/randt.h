@@ -278,6 +278,30 @@ int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int f
                                   const int32_t* d_fixed_idx, const randt_maps* moving, int moving_first, int n_pairs,
                                   const double* d_pose4, double* d_out, double* d_terms);
 
+/* ------------------------------------------------------------------ Scan Context (f-4) -------- */
+/* ScanContextParameters (src/ndt_slam/ndt_slam.cpp:515-552; config/parameters_*.yaml "scan_context"). */
+typedef struct randt_sc_params {
+  int32_t num_ring, num_sector;        /* PC_NUM_RING (<= 64), PC_NUM_SECTOR (<= 128) */
+  double max_radius;                   /* PC_MAX_RADIUS */
+  int32_t num_exclude_recent, num_candidates;  /* NUM_EXCLUDE_RECENT, NUM_CANDIDATES_FROM_TREE (<= 32) */
+  double search_ratio, dist_thresh, assumed_drift, odom_eps, odom_weight, intensity_factor;
+} randt_sc_params;
+/* SCManager::makeScancontext + makeRingkeyFromScancontext + makeSectorkeyFromScancontext
+ * (src/local_fuser/Scancontext/Scancontext.cpp:156-237) for a batch of keyframe scans (same point layout as
+ * randt_ndt_build_batch_dev).  d_desc: [n_scans][num_sector][num_ring] doubles (one sector = one contiguous column, like
+ * the reference's column-major MatrixXd), d_ring_keys [n_scans][num_ring], d_sector_keys [n_scans][num_sector]. */
+int randt_sc_make_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int points_pitch, const int32_t* d_n_points,
+                            int stride_floats, int intensity_index, const randt_sc_params* p, double* d_desc, double* d_ring_keys,
+                            double* d_sector_keys);
+/* SCManager::detectLoopClosureID (Scancontext.cpp:261-341) for a batch of query nodes over a database of n_db nodes
+ * (descriptors / ring keys as produced above, odometry positions [n_db][2], traversed distances [n_db]).  Query q is node
+ * d_query_ids[q] (NULL: q) and searches nodes [0, node - num_exclude_recent].  d_loop_id[q] = matched node or -1,
+ * d_yaw[q] = relative yaw [rad], d_min_dist (nullable) = best combined distance.  The reference's KD-tree (rebuilt only
+ * every tree_making_period queries) is replaced by an exact search over the current database. */
+int randt_sc_detect_batch_dev(randt_ctx* ctx, const randt_sc_params* p, const double* d_desc, const double* d_ring_keys,
+                              const double* d_pos, const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries,
+                              int32_t* d_loop_id, float* d_yaw, double* d_min_dist);
+
 /* ------------------------------------------------------------------ scan filter (f-1) -------- */
 /* RadarPreprocessorParameters used by filterScan + initial_transform_radar_baselink_ as a row-major
  * 3x4 matrix (radar_preprocessor.cpp:7-28,124). */

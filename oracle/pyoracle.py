@@ -148,6 +148,12 @@ def lib():
     L.orc_search_global_bnb.restype = C.c_double
     L.orc_search_global_bnb.argtypes = [P(OrcMap), P(OrcMap), P(MatcherParams), P(BnbParams), C.c_double, C.c_double, C.c_double,
                                         C.c_void_p, P(C.c_int)]
+    L.orc_sc_make.restype = None
+    L.orc_sc_make.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_sc_distance.restype = C.c_double
+    L.orc_sc_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, P(C.c_int)]
+    L.orc_sc_detect.restype = C.c_int
+    L.orc_sc_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(C.c_float), P(C.c_double)]
     L.orc_cs_divergence.restype = C.c_double
     L.orc_cs_divergence.argtypes = [P(OrcMap), P(OrcMap), C.c_void_p]
     L.orc_filter_scan.restype = C.c_int
@@ -472,6 +478,40 @@ def cs_divergence(fixed, moving):
     terms = np.zeros(3)
     v = lib().orc_cs_divergence(fixed._p, moving._p, _ptr(terms))
     return v, terms
+
+
+# ------------------------------------------------------------------ f-4 Scan Context -----------
+class ScParams(C.Structure):
+    _fields_ = [("num_ring", C.c_int), ("num_sector", C.c_int), ("max_radius", C.c_double), ("num_exclude_recent", C.c_int),
+                ("num_candidates", C.c_int), ("search_ratio", C.c_double), ("dist_thresh", C.c_double), ("assumed_drift", C.c_double),
+                ("odom_eps", C.c_double), ("odom_weight", C.c_double), ("intensity_factor", C.c_double)]
+
+
+def sc_make(pts, sp, ioff=None):
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    n, stride = pts.shape
+    ioff = (3 if stride == 4 else 4) if ioff is None else ioff
+    desc = np.zeros((sp.num_sector, sp.num_ring))
+    rk, sk = np.zeros(sp.num_ring), np.zeros(sp.num_sector)
+    lib().orc_sc_make(_ptr(pts), n, stride, ioff, C.byref(sp), _ptr(desc), _ptr(rk), _ptr(sk))
+    return desc, rk, sk
+
+
+def sc_distance(sp, sc1, sc2, pos1, pos2, dist1, dist2):
+    sc1, sc2 = np.ascontiguousarray(sc1, dtype=np.float64), np.ascontiguousarray(sc2, dtype=np.float64)
+    p1, p2 = np.ascontiguousarray(pos1, dtype=np.float64), np.ascontiguousarray(pos2, dtype=np.float64)
+    sh = C.c_int(0)
+    d = lib().orc_sc_distance(C.byref(sp), _ptr(sc1), _ptr(sc2), _ptr(p1), _ptr(p2), C.c_double(dist1), C.c_double(dist2), C.byref(sh))
+    return d, sh.value
+
+
+def sc_detect(sp, desc, ring_keys, pos, dist, node_id):
+    desc = np.ascontiguousarray(desc, dtype=np.float64)
+    rk = np.ascontiguousarray(ring_keys, dtype=np.float64)
+    pos, dist = np.ascontiguousarray(pos, dtype=np.float64), np.ascontiguousarray(dist, dtype=np.float64)
+    yaw, md = C.c_float(0), C.c_double(0)
+    lid = lib().orc_sc_detect(C.byref(sp), _ptr(desc), _ptr(rk), _ptr(pos), _ptr(dist), desc.shape[0], int(node_id), C.byref(yaw), C.byref(md))
+    return lid, yaw.value, md.value
 
 
 # ------------------------------------------------------------------ f-3 correlative search -----

@@ -1997,3 +1997,174 @@ double orc_search_global_bnb(const orc_map* fixed, const orc_map* moving, const 
   free(q); free(keys); free(corr);
   return min_cost;
 }
+
+/* ================================================================ f-4: Scan Context ========= */
+/* xy2theta (Scancontext.cpp:24-37): degrees in [0, 360].  SPEC DECISION: the reference's float arctangent is taken as
+ * the correctly rounded one, (float)atan((double)t) -- glibc's atanf may differ from it by one ulp, which moves a
+ * point to the neighbouring sector only if it lies within ~1e-7 of a sector boundary; this form is identical on
+ * every platform (host libm and device). */
+static float sc_atanf(float t) { return (float)atan((double)t); }
+static float sc_xy2theta(float x, float y) {
+  if (x >= 0 && y >= 0) return (float)((180 / M_PI) * sc_atanf(y / x));
+  if (x < 0 && y >= 0) return (float)(180 - ((180 / M_PI) * sc_atanf(y / (-x))));
+  if (x < 0 && y < 0) return (float)(180 + ((180 / M_PI) * sc_atanf(y / x)));
+  if (x >= 0 && y < 0) return (float)(360 - ((180 / M_PI) * sc_atanf((-y) / x)));
+  return 0.0f; /* NaN coordinates: the reference falls off the end of the function (undefined) */
+}
+
+void orc_sc_make(const float* pts, int n, int stride, int ioff, const orc_sc_params* p, double* desc, double* ring_key,
+                 double* sector_key) {
+  const int R = p->num_ring, S = p->num_sector;
+  const double NO_POINT = -1000;
+  for (int i = 0; i < R * S; ++i) desc[i] = NO_POINT;
+  for (int i = 0; i < n; ++i) {
+    const float x = pts[(size_t)i * stride], y = pts[(size_t)i * stride + 1];
+    const float z = (float)(pts[(size_t)i * stride + ioff] * p->intensity_factor); /* pt.z = intensity * factor (:171) */
+    const float azim_range = sqrtf(x * x + y * y);
+    const float azim_angle = sc_xy2theta(x, y);
+    if (azim_range > p->max_radius) continue;
+    int ring = (int)ceil((azim_range / p->max_radius) * R);
+    ring = ring < R ? ring : R;
+    ring = ring > 1 ? ring : 1;
+    int sect = (int)ceil((azim_angle / 360.0) * S);
+    sect = sect < S ? sect : S;
+    sect = sect > 1 ? sect : 1;
+    /* quirk (:187): the bin started at NO_POINT and the values are ADDED to it */
+    desc[(size_t)(sect - 1) * R + (ring - 1)] += z;
+  }
+  for (int i = 0; i < R * S; ++i)
+    if (desc[i] == NO_POINT) desc[i] = 0;
+  for (int r = 0; r < R; ++r) { /* rowwise mean */
+    double a = 0;
+    for (int s = 0; s < S; ++s) a += desc[(size_t)s * R + r];
+    ring_key[r] = a / S;
+  }
+  for (int s = 0; s < S; ++s) { /* columnwise mean */
+    double a = 0;
+    for (int r = 0; r < R; ++r) a += desc[(size_t)s * R + r];
+    sector_key[s] = a / R;
+  }
+}
+
+/* distDirectSC (:64-87) of sc1 against sc2 circularly shifted right by `shift` columns */
+static double sc_dist_direct(const double* sc1, const double* sc2, int R, int S, int shift) {
+  int n_eff = 0;
+  double sum = 0;
+  for (int col = 0; col < S; ++col) {
+    const double* a = sc1 + (size_t)col * R;
+    const double* b = sc2 + (size_t)((col - shift + S) % S) * R; /* shifted.col(col) = sc2.col(col - shift) */
+    double na = 0, nb = 0, dot = 0;
+    for (int r = 0; r < R; ++r) {
+      na += a[r] * a[r];
+      nb += b[r] * b[r];
+      dot += a[r] * b[r];
+    }
+    na = sqrt(na);
+    nb = sqrt(nb);
+    if (na == 0 || nb == 0) continue;
+    sum = sum + dot / (na * nb);
+    n_eff = n_eff + 1;
+  }
+  return 1.0 - sum / n_eff; /* 0/0 = NaN when no column counts, like the reference */
+}
+
+static int sc_cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+
+double orc_sc_distance(const orc_sc_params* p, const double* sc1, const double* sc2, const double pos1[2], const double pos2[2],
+                       double dist1, double dist2, int* shift_out) {
+  const int R = p->num_ring, S = p->num_sector;
+  double* k1 = (double*)malloc(sizeof(double) * 2 * S);
+  double* k2 = k1 + S;
+  for (int s = 0; s < S; ++s) {
+    double a = 0, b = 0;
+    for (int r = 0; r < R; ++r) {
+      a += sc1[(size_t)s * R + r];
+      b += sc2[(size_t)s * R + r];
+    }
+    k1[s] = a / R;
+    k2[s] = b / R;
+  }
+  /* fastAlignUsingVkey (:90-112) */
+  int argmin_vkey = 0;
+  double min_norm = 10000000;
+  for (int sh = 0; sh < S; ++sh) {
+    double nn = 0;
+    for (int s = 0; s < S; ++s) {
+      const double d = k1[s] - k2[(s - sh + S) % S];
+      nn += d * d;
+    }
+    nn = sqrt(nn);
+    if (nn < min_norm) {
+      argmin_vkey = sh;
+      min_norm = nn;
+    }
+  }
+  free(k1);
+  const int radius = (int)round(0.5 * p->search_ratio * S);
+  int* space = (int*)malloc(sizeof(int) * (2 * radius + 1));
+  int ns = 0;
+  space[ns++] = argmin_vkey;
+  for (int ii = 1; ii < radius + 1; ++ii) {
+    space[ns++] = (argmin_vkey + ii + S) % S;
+    space[ns++] = (argmin_vkey - ii + S) % S;
+  }
+  qsort(space, ns, sizeof(int), sc_cmp_int);
+  int argmin_shift = 0;
+  double min_sc = 10000000;
+  for (int i = 0; i < ns; ++i) {
+    const double d = sc_dist_direct(sc1, sc2, R, S, space[i]);
+    if (d < min_sc) {
+      argmin_shift = space[i];
+      min_sc = d;
+    }
+  }
+  free(space);
+  const double dx = pos2[0] - pos1[0], dy = pos2[1] - pos1[1];
+  double t_err = sqrt(dx * dx + dy * dy) - p->odom_eps;
+  t_err = (t_err > 0.0 ? t_err : 0.0) / (dist2 - dist1);
+  const double odom_dist = 1 - exp(-(t_err * t_err) / (2 * p->assumed_drift * p->assumed_drift));
+  if (shift_out) *shift_out = argmin_shift;
+  return min_sc + odom_dist * R * p->odom_weight;
+}
+
+int orc_sc_detect(const orc_sc_params* p, const double* desc, const double* ring_keys, const double* pos, const double* dist,
+                  int n_db, int node_id, float* yaw, double* min_dist_out) {
+  const int R = p->num_ring, S = p->num_sector, K = p->num_candidates;
+  if (yaw) *yaw = 0.0f;
+  if (min_dist_out) *min_dist_out = 10000000;
+  if (node_id < p->num_exclude_recent + 1 || node_id >= n_db) return -1;
+  const int n_search = node_id + 1 - p->num_exclude_recent; /* keys[0 .. node_id - NUM_EXCLUDE_RECENT] */
+  /* exact kNN on the float ring keys (squared L2 accumulated in float like nanoflann's L2 adaptor) */
+  float* d2 = (float*)malloc(sizeof(float) * n_search);
+  for (int i = 0; i < n_search; ++i) {
+    float acc = 0.0f;
+    for (int r = 0; r < R; ++r) {
+      const float a = (float)ring_keys[(size_t)node_id * R + r], b = (float)ring_keys[(size_t)i * R + r];
+      const float d = a - b;
+      acc += d * d;
+    }
+    d2[i] = acc;
+  }
+  double min_d = 10000000;
+  int nn_align = 0, nn_idx = 0;
+  const int kk = K < n_search ? K : n_search;
+  for (int c = 0; c < kk; ++c) {
+    int best = -1;
+    for (int i = 0; i < n_search; ++i)
+      if (d2[i] >= 0.0f && (best < 0 || d2[i] < d2[best])) best = i;
+    d2[best] = -1.0f; /* taken */
+    int sh;
+    const double d = orc_sc_distance(p, desc + (size_t)node_id * R * S, desc + (size_t)best * R * S, pos + 2 * (size_t)node_id,
+                                     pos + 2 * (size_t)best, dist[node_id], dist[best], &sh);
+    if (d < min_d) {
+      min_d = d;
+      nn_align = sh;
+      nn_idx = best;
+    }
+  }
+  free(d2);
+  if (min_dist_out) *min_dist_out = min_d;
+  /* deg2rad(nn_align * PC_UNIT_SECTORANGLE) in float (:336, :17-20) */
+  if (yaw) *yaw = (float)((float)(nn_align * (360.0 / (double)S)) * M_PI / 180.0);
+  return min_d < p->dist_thresh ? nn_idx : -1;
+}

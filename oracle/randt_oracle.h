@@ -245,6 +245,33 @@ typedef struct orc_filter_params {
 int orc_filter_scan(const float* raw, int n, int stride, int ioff, const orc_filter_params* p, float* out_pts,
                     float* out_polar, int capacity, float* peaks, int peak_cap, int* n_peaks);
 
+/* ---------------------------------------------------------------- f-4: Scan Context ------- */
+/* SCManager (src/local_fuser/Scancontext/Scancontext.cpp:64-341, parameters ndt_slam.cpp:515-552): the
+ * loop-closure candidate generator in front of estimateLoopConstraint (local_fuser.cpp:323).
+ * SPEC DECISIONS: xy2theta calls the unqualified atan on a float -> the correctly rounded float arctangent; Eigen's .mean() /
+ * .norm() / .dot() reduction order depends on the reference's build flags -> plain left-to-right sums here
+ * (GPU parity is by tolerance); the nanoflann KD-tree search is restated as an exact brute-force kNN in float
+ * (ties: lower index first); the tree is rebuilt on every query (TREE_MAKING_PERIOD = 1 semantics). */
+typedef struct orc_sc_params {
+  int num_ring, num_sector;          /* PC_NUM_RING, PC_NUM_SECTOR */
+  double max_radius;                 /* PC_MAX_RADIUS */
+  int num_exclude_recent, num_candidates;
+  double search_ratio, dist_thresh, assumed_drift, odom_eps, odom_weight, intensity_factor;
+} orc_sc_params;
+/* makeScancontext (:156-204) + makeRingkey / makeSectorkey (:207-237).  pts: n points, stride floats, intensity at
+ * ioff.  desc: [num_sector][num_ring] (Eigen column-major: one sector = one contiguous column); ring_key [num_ring],
+ * sector_key [num_sector]. */
+void orc_sc_make(const float* pts, int n, int stride, int ioff, const orc_sc_params* p, double* desc, double* ring_key,
+                 double* sector_key);
+/* distanceBtnScanContext (:115-152): returns the combined distance, *shift = argmin column shift. */
+double orc_sc_distance(const orc_sc_params* p, const double* sc1, const double* sc2, const double pos1[2], const double pos2[2],
+                       double dist1, double dist2, int* shift);
+/* detectLoopClosureID (:261-341) for query node_id over a database of n_db nodes (desc [n_db][S*R], ring keys [n_db][R],
+ * positions [n_db][2], traversed distances [n_db]).  Returns the loop id or -1; *yaw = relative yaw [rad] (float arithmetic
+ * as in the reference), *min_dist (nullable) = best combined distance. */
+int orc_sc_detect(const orc_sc_params* p, const double* desc, const double* ring_keys, const double* pos, const double* dist,
+                  int n_db, int node_id, float* yaw, double* min_dist);
+
 /* ---------------------------------------------------------------- SE(2) helpers (Sophus) --- */
 void orc_se2_exp(const double xi[3], double out4[4]);
 void orc_se2_log(const double p4[4], double xi[3]);

@@ -56,6 +56,13 @@ class FilterParams(C.Structure):
                 ("beam_distance_increment_threshold", C.c_float), ("sensor_to_base", C.c_float * 12)]
 
 
+class ScParams(C.Structure):
+    _fields_ = [("num_ring", C.c_int32), ("num_sector", C.c_int32), ("max_radius", C.c_double),
+                ("num_exclude_recent", C.c_int32), ("num_candidates", C.c_int32), ("search_ratio", C.c_double),
+                ("dist_thresh", C.c_double), ("assumed_drift", C.c_double), ("odom_eps", C.c_double),
+                ("odom_weight", C.c_double), ("intensity_factor", C.c_double)]
+
+
 class BnbParams(C.Structure):
     _fields_ = [("csm_window_linear", C.c_double), ("csm_window_angular", C.c_double), ("csm_linear_step", C.c_double),
                 ("csm_cost_threshold", C.c_double), ("csm_max_px_accurate_range", C.c_double), ("csm_n_iter", C.c_int32),
@@ -111,6 +118,8 @@ SYMBOLS = {
                                  _P(C.c_double), _P(_I)]),
     "randt_cs_divergence_batch_dev": (_I, [_V, _V, _I, _I, _V, _V, _I, _I, _V, _V, _V]),
     "randt_filter_scan_batch_dev": (_I, [_V, _V, _I, _I, _I, _I, _I, _P(FilterParams), _V, _I, _V, _V, _V, _V, _V]),
+    "randt_sc_make_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ScParams), _V, _V, _V]),
+    "randt_sc_detect_batch_dev": (_I, [_V, _P(ScParams), _V, _V, _V, _V, _I, _V, _I, _V, _V, _V]),
     "randt_predict_state": (_I, [_V, C.c_double, _V]),
     "randt_register_window": (_I, [_V, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _P(_I), _V]),
 }

@@ -483,6 +483,29 @@ int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int f
                               (double*)ctx->ws, d_out, d_terms);
 }
 
+int randt_sc_make_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int points_pitch, const int32_t* d_n_points,
+                            int stride_floats, int intensity_index, const randt_sc_params* p, double* d_desc, double* d_ring_keys,
+                            double* d_sector_keys) {
+  if (!ctx || !p || n_scans < 0 || points_pitch <= 0 || stride_floats < 3 || intensity_index < 0 || intensity_index >= stride_floats)
+    return RANDT_ERR_INVALID;
+  if (n_scans == 0) return RANDT_OK;
+  if (!d_points || !d_desc || !d_ring_keys || !d_sector_keys) return RANDT_ERR_INVALID;
+  return launch_sc_make(ctx, d_points, n_scans, points_pitch, d_n_points, stride_floats, intensity_index, p, d_desc, d_ring_keys,
+                        d_sector_keys);
+}
+
+int randt_sc_detect_batch_dev(randt_ctx* ctx, const randt_sc_params* p, const double* d_desc, const double* d_ring_keys,
+                              const double* d_pos, const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries,
+                              int32_t* d_loop_id, float* d_yaw, double* d_min_dist) {
+  if (!ctx || !p || n_db < 0 || n_queries < 0) return RANDT_ERR_INVALID;
+  if (n_queries == 0) return RANDT_OK;
+  if (!d_desc || !d_ring_keys || !d_pos || !d_dist || !d_loop_id || !d_yaw) return RANDT_ERR_INVALID;
+  int rc = ensure_ws(ctx, sizeof(float) * (size_t)n_queries * (size_t)(n_db > 0 ? n_db : 1) + 256);
+  if (rc) return rc;
+  return launch_sc_detect(ctx, p, d_desc, d_ring_keys, d_pos, d_dist, n_db, d_query_ids, n_queries, (float*)ctx->ws, d_loop_id, d_yaw,
+                          d_min_dist);
+}
+
 int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans, int n_azimuths, int n_bins,
                                 int stride_floats, int intensity_index, const randt_filter_params* fp,
                                 float* d_out_points, int pitch_out, int32_t* d_out_counts, float* d_out_polar,

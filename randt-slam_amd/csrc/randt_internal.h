@@ -95,6 +95,12 @@ int launch_cs_divergence(randt_ctx* ctx, const MapView& fixed, int fixed_first, 
                          const MapView& moving, int moving_first, int n_pairs, const double* d_pose4, double* d_partial,
                          double* d_out, double* d_terms);
 
+int launch_sc_make(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride, int ioff,
+                   const randt_sc_params* p, double* d_desc, double* d_ring_keys, double* d_sector_keys);
+int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_desc, const double* d_ring_keys, const double* d_pos,
+                     const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries, float* d_ws, int32_t* d_loop_id,
+                     float* d_yaw, double* d_min_dist);
+
 int launch_eval_cost(randt_ctx* ctx, const MapView& fixed, int fmap, const MapView& moving, int mmap, const int32_t* d_corr, int k,
                      int use_intensity, double scale, double alpha, const double* d_poses4, int n_poses, double* d_cost,
                      int32_t* d_n_res);

@@ -1,0 +1,323 @@
+// Scan Context loop-closure candidate search for gfx950 -- SURVEY row f-4 (compiled with -ffp-contract=off).
+//
+// Replaces SCManager (src/local_fuser/Scancontext/Scancontext.cpp of the reference; parameters
+// src/ndt_slam/ndt_slam.cpp:515-552), the stage that hands loop-closure candidates to
+// Matcher::estimateLoopConstraint (local_fuser.cpp:323-335):
+//   k_sc_make     makeScancontext + makeRingkey / makeSectorkey (:156-237), one workgroup per keyframe scan:
+//                 bin index and value of every point into LDS, then ONE THREAD PER BIN walks the points in input
+//                 order, so every bin sum runs in the reference's sequential order (no atomics, bit-reproducible,
+//                 including the quirk that a touched bin starts at NO_POINT = -1000);
+//   k_sc_detect   detectLoopClosureID (:261-341), one workgroup per query node: float ring-key distances to the
+//                 searchable part of the database, k rounds of (distance, index) arg-min = the k nearest keys,
+//                 then per candidate the sector-key alignment, the column-shift search of the cosine distance and
+//                 the odometry term (distanceBtnScanContext, :115-152).
+// Every reduction is a per-thread left-to-right loop in the oracle's order.
+#include "randt_internal.h"
+
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+#define SC_BLOCK 256
+#define SC_MAX_SECTOR 128
+#define SC_MAX_RING 64
+#define SC_MAX_CAND 32
+
+namespace {
+
+struct ScParams {
+  int R, S, exclude_recent, n_cand, radius;
+  double max_radius, dist_thresh, assumed_drift, odom_eps, odom_weight, intensity_factor;
+};
+
+// xy2theta (Scancontext.cpp:24-37); the arctangent is evaluated in double and rounded to float (= the correctly
+// rounded float arctangent, identical on host and device)
+__device__ __forceinline__ float xy2theta(float x, float y) {
+  const double k = 180 / M_PI;
+  if (x >= 0 && y >= 0) return (float)(k * (float)atan((double)(y / x)));
+  if (x < 0 && y >= 0) return (float)(180 - (k * (float)atan((double)(y / (-x)))));
+  if (x < 0 && y < 0) return (float)(180 + (k * (float)atan((double)(y / x))));
+  if (x >= 0 && y < 0) return (float)(360 - (k * (float)atan((double)((-y) / x))));
+  return 0.0f;
+}
+
+__global__ __launch_bounds__(SC_BLOCK) void k_sc_make(const float* __restrict__ pts, int pitch, const int32_t* __restrict__ n_pts_arr,
+                                                      int stride, int ioff, ScParams P, double* __restrict__ desc,
+                                                      double* __restrict__ ring_key, double* __restrict__ sector_key) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* pz = reinterpret_cast<float*>(smem);                     // [pitch]
+  uint16_t* pbin = reinterpret_cast<uint16_t*>(pz + pitch);      // [pitch]
+  const int scan = blockIdx.x, tid = threadIdx.x;
+  int n = n_pts_arr ? n_pts_arr[scan] : pitch;
+  n = n < 0 ? 0 : (n > pitch ? pitch : n);
+  const float* sp = pts + (size_t)scan * pitch * stride;
+  const int R = P.R, S = P.S, nb = R * S;
+  for (int i = tid; i < n; i += SC_BLOCK) {
+    const float x = sp[(size_t)i * stride], y = sp[(size_t)i * stride + 1];
+    const float z = (float)(sp[(size_t)i * stride + ioff] * P.intensity_factor);
+    const float azim_range = sqrtf(x * x + y * y);
+    const float azim_angle = xy2theta(x, y);
+    int bin = 0xffff;
+    if (!(azim_range > P.max_radius)) {
+      int ring = (int)ceil((azim_range / P.max_radius) * R);
+      ring = ring < R ? ring : R;
+      ring = ring > 1 ? ring : 1;
+      int sect = (int)ceil((azim_angle / 360.0) * S);
+      sect = sect < S ? sect : S;
+      sect = sect > 1 ? sect : 1;
+      bin = (sect - 1) * R + (ring - 1);
+    }
+    pz[i] = z;
+    pbin[i] = (uint16_t)bin;
+  }
+  __syncthreads();
+  double* d = desc + (size_t)scan * nb;
+  // thread t owns bins t, t + 256, ...: one pass over the points per group of four bins
+  for (int b0 = tid; b0 < nb; b0 += 4 * SC_BLOCK) {
+    double acc[4] = {-1000, -1000, -1000, -1000};  // NO_POINT; values are ADDED to it (:187)
+    for (int i = 0; i < n; ++i) {
+      const int b = pbin[i];
+      const double z = (double)pz[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (b == b0 + u * SC_BLOCK) acc[u] += z;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + u * SC_BLOCK;
+      if (b < nb) d[b] = acc[u] == -1000 ? 0.0 : acc[u];
+    }
+  }
+  __syncthreads();
+  if (tid < R) {  // rowwise mean
+    double a = 0;
+    for (int s = 0; s < S; ++s) a += d[(size_t)s * R + tid];
+    ring_key[(size_t)scan * R + tid] = a / S;
+  }
+  if (tid >= 64 && tid - 64 < S) {  // columnwise mean (second wavefront onwards)
+    const int s = tid - 64;
+    double a = 0;
+    for (int r = 0; r < R; ++r) a += d[(size_t)s * R + r];
+    sector_key[(size_t)scan * S + s] = a / R;
+  }
+}
+
+// lexicographic (value, index) block arg-min over 256 threads; result broadcast.  scratch: 2 x 4 words.
+__device__ __forceinline__ void block_argmin(double& v, int& idx, double* sv, int* si) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_xor(v, off, 64);
+    const int oi = __shfl_xor(idx, off, 64);
+    if (ov < v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    sv[wave] = v;
+    si[wave] = idx;
+  }
+  __syncthreads();
+  v = sv[0];
+  idx = si[0];
+#pragma unroll
+  for (int w = 1; w < SC_BLOCK / 64; ++w)
+    if (sv[w] < v || (sv[w] == v && si[w] < idx)) {
+      v = sv[w];
+      idx = si[w];
+    }
+}
+
+__global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double* __restrict__ desc, const double* __restrict__ ring_keys,
+                                                        const double* __restrict__ pos, const double* __restrict__ dist, int n_db,
+                                                        const int32_t* __restrict__ query_ids, float* __restrict__ d2ws, int d2pitch,
+                                                        int32_t* __restrict__ loop_id, float* __restrict__ yaw,
+                                                        double* __restrict__ min_dist_out) {
+  __shared__ double k1[SC_MAX_SECTOR], k2[SC_MAX_SECTOR];
+  __shared__ double sv[4];
+  __shared__ int si[4];
+  __shared__ int cand[SC_MAX_CAND];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int node = query_ids ? query_ids[q] : q;
+  const int R = P.R, S = P.S;
+  float* d2 = d2ws + (size_t)q * d2pitch;
+  if (node < P.exclude_recent + 1 || node >= n_db) {  // early return (:274-278)
+    if (tid == 0) {
+      loop_id[q] = -1;
+      yaw[q] = 0.0f;
+      if (min_dist_out) min_dist_out[q] = 10000000;
+    }
+    return;
+  }
+  const int n_search = node + 1 - P.exclude_recent;
+  // ---- squared float distances of the ring keys (nanoflann L2, accumulated in float)
+  for (int i = tid; i < n_search; i += SC_BLOCK) {
+    float acc = 0.0f;
+    for (int r = 0; r < R; ++r) {
+      const float a = (float)ring_keys[(size_t)node * R + r], b = (float)ring_keys[(size_t)i * R + r];
+      const float d = a - b;
+      acc += d * d;
+    }
+    d2[i] = acc;
+  }
+  __syncthreads();
+  // ---- the k nearest keys in ascending (distance, index) order
+  const int kk = P.n_cand < n_search ? P.n_cand : n_search;
+  for (int c = 0; c < kk; ++c) {
+    double bv = 1e300;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n_search; i += SC_BLOCK) {
+      const float v = d2[i];
+      if (v >= 0.0f && ((double)v < bv || ((double)v == bv && i < bi))) {
+        bv = (double)v;
+        bi = i;
+      }
+    }
+    block_argmin(bv, bi, sv, si);
+    if (tid == 0) {
+      cand[c] = bi;
+      d2[bi] = -1.0f;
+    }
+    __syncthreads();
+  }
+  // ---- pairwise distances (distanceBtnScanContext) in candidate order
+  const double* sc1 = desc + (size_t)node * R * S;
+  if (tid < S) {
+    double a = 0;
+    for (int r = 0; r < R; ++r) a += sc1[(size_t)tid * R + r];
+    k1[tid] = a / R;
+  }
+  double min_d = 10000000;
+  int nn_align = 0, nn_idx = 0;
+  for (int c = 0; c < kk; ++c) {
+    const int ci = cand[c];
+    const double* sc2 = desc + (size_t)ci * R * S;
+    __syncthreads();
+    if (tid < S) {
+      double b = 0;
+      for (int r = 0; r < R; ++r) b += sc2[(size_t)tid * R + r];
+      k2[tid] = b / R;
+    }
+    __syncthreads();
+    // fastAlignUsingVkey: thread = shift, first minimal shift wins
+    double nv = 1e300;
+    int ns = 0x7fffffff;
+    if (tid < S) {
+      double nn = 0;
+      for (int s = 0; s < S; ++s) {
+        int j = s - tid;
+        j = j < 0 ? j + S : j;
+        const double d = k1[s] - k2[j];
+        nn += d * d;
+      }
+      nv = sqrt(nn);
+      ns = tid;
+      if (!(nv < 10000000)) {  // "cur_diff_norm < min" never true: shift 0 stays
+        nv = 1e300;
+        ns = 0x7fffffff;
+      }
+    }
+    block_argmin(nv, ns, sv, si);
+    const int argmin_vkey = ns == 0x7fffffff ? 0 : ns;
+    // column-shift search: the 2 radius + 1 shifts around it, ascending shift value = thread order
+    double dv = 1e300;
+    int ds = 0x7fffffff;
+    if (tid < S) {
+      // is shift `tid` in the search space {argmin + ii mod S, |ii| <= radius}?
+      int delta = tid - argmin_vkey;
+      delta = delta < 0 ? delta + S : delta;
+      const bool in = delta <= P.radius || S - delta <= P.radius;
+      if (in) {
+        int n_eff = 0;
+        double sum = 0;
+        for (int col = 0; col < S; ++col) {
+          int j = col - tid;
+          j = j < 0 ? j + S : j;
+          const double* a = sc1 + (size_t)col * R;
+          const double* b = sc2 + (size_t)j * R;
+          double na = 0, nb2 = 0, dot = 0;
+          for (int r = 0; r < R; ++r) {
+            na += a[r] * a[r];
+            nb2 += b[r] * b[r];
+            dot += a[r] * b[r];
+          }
+          na = sqrt(na);
+          nb2 = sqrt(nb2);
+          if (na == 0 || nb2 == 0) continue;
+          sum = sum + dot / (na * nb2);
+          n_eff = n_eff + 1;
+        }
+        const double d = 1.0 - sum / n_eff;
+        if (d < 10000000) {  // NaN (no effective column) never wins, like "cur < min"
+          dv = d;
+          ds = tid;
+        }
+      }
+    }
+    block_argmin(dv, ds, sv, si);
+    const int argmin_shift = ds == 0x7fffffff ? 0 : ds;
+    const double min_sc = ds == 0x7fffffff ? 10000000 : dv;
+    const double dx = pos[2 * (size_t)ci] - pos[2 * (size_t)node], dy = pos[2 * (size_t)ci + 1] - pos[2 * (size_t)node + 1];
+    double t_err = sqrt(dx * dx + dy * dy) - P.odom_eps;
+    t_err = (t_err > 0.0 ? t_err : 0.0) / (dist[ci] - dist[node]);
+    const double odom_dist = 1 - exp(-(t_err * t_err) / (2 * P.assumed_drift * P.assumed_drift));
+    const double cd = min_sc + odom_dist * R * P.odom_weight;
+    if (cd < min_d) {
+      min_d = cd;
+      nn_align = argmin_shift;
+      nn_idx = ci;
+    }
+  }
+  if (tid == 0) {
+    loop_id[q] = min_d < P.dist_thresh ? nn_idx : -1;
+    yaw[q] = (float)((float)(nn_align * (360.0 / (double)S)) * M_PI / 180.0);
+    if (min_dist_out) min_dist_out[q] = min_d;
+  }
+}
+
+ScParams to_dev(const randt_sc_params* p) {
+  ScParams P;
+  P.R = p->num_ring;
+  P.S = p->num_sector;
+  P.exclude_recent = p->num_exclude_recent;
+  P.n_cand = p->num_candidates;
+  P.radius = (int)round(0.5 * p->search_ratio * p->num_sector);
+  P.max_radius = p->max_radius;
+  P.dist_thresh = p->dist_thresh;
+  P.assumed_drift = p->assumed_drift;
+  P.odom_eps = p->odom_eps;
+  P.odom_weight = p->odom_weight;
+  P.intensity_factor = p->intensity_factor;
+  return P;
+}
+
+}  // namespace
+
+int launch_sc_make(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride, int ioff,
+                   const randt_sc_params* p, double* d_desc, double* d_ring_keys, double* d_sector_keys) {
+  if (n_scans <= 0) return RANDT_OK;
+  if (p->num_ring < 1 || p->num_ring > SC_MAX_RING || p->num_sector < 1 || p->num_sector > SC_MAX_SECTOR)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan context: num_ring <= 64 and num_sector <= 128", hipSuccess);
+  const size_t lds = (size_t)pitch * 6 + 16;
+  if (lds > (size_t)ctx->lds_limit) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the scan-context kernel", hipSuccess);
+  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_make), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sc_make, dim3(n_scans), dim3(SC_BLOCK), lds, ctx->stream, d_points, pitch, d_n_points, stride, ioff, to_dev(p),
+                     d_desc, d_ring_keys, d_sector_keys);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
+
+int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_desc, const double* d_ring_keys, const double* d_pos,
+                     const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries, float* d_ws, int32_t* d_loop_id,
+                     float* d_yaw, double* d_min_dist) {
+  if (n_queries <= 0) return RANDT_OK;
+  if (p->num_ring < 1 || p->num_ring > SC_MAX_RING || p->num_sector < 1 || p->num_sector > SC_MAX_SECTOR || p->num_candidates < 1 ||
+      p->num_candidates > SC_MAX_CAND)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan context: num_ring <= 64, num_sector <= 128, num_candidates <= 32", hipSuccess);
+  hipLaunchKernelGGL(k_sc_detect, dim3(n_queries), dim3(SC_BLOCK), 0, ctx->stream, to_dev(p), d_desc, d_ring_keys, d_pos, d_dist, n_db,
+                     d_query_ids, d_ws, n_db, d_loop_id, d_yaw, d_min_dist);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}

@@ -10,7 +10,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, BnbParams, ClusterParams, FilterParams, MapParams, MatcherParams, WindowParams
+from ._capi import (CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, BnbParams, ClusterParams, FilterParams, MapParams, MatcherParams, ScParams,
+                    WindowParams)
 
 
 class RandtError(RuntimeError):
@@ -330,6 +331,32 @@ def cs_divergence_batch(ctx, fixed, fixed_first, fixed_count, fixed_idx, moving,
     ctx._check(ctx._lib.randt_cs_divergence_batch_dev(ctx._h, fixed._h, fixed_first, fixed_count, _dptr(fixed_idx), moving._h,
                                                       moving_first, n_pairs, _dptr(pose4), _dptr(out), _dptr(terms)),
                "randt_cs_divergence_batch_dev")
+
+
+# ------------------------------------------------------------------ Scan Context (f-4) --------------
+def sc_params(num_ring=20, num_sector=45, max_radius=15.0, num_exclude_recent=15, num_candidates=10, search_ratio=0.3,
+              dist_thresh=0.6, assumed_drift=0.05, odom_eps=1.2, odom_weight=0.2, intensity_factor=0.04):
+    """config/parameters_indoor.yaml "scan_context" (:45-58) through ndt_slam.cpp:515-552."""
+    return ScParams(num_ring, num_sector, max_radius, num_exclude_recent, num_candidates, search_ratio, dist_thresh, assumed_drift,
+                    odom_eps, odom_weight, intensity_factor)
+
+
+def sc_make_batch(ctx, points, sp, desc, ring_keys, sector_keys, n_points=None, intensity_index=None):
+    """randt_sc_make_batch_dev (SCManager::makeScancontext + keys).  points: (B, N, stride) float32 device tensor;
+    desc (B, num_sector, num_ring), ring_keys (B, num_ring), sector_keys (B, num_sector): float64 device tensors."""
+    B, N, S = (int(v) for v in points.shape)
+    ioff = (3 if S == 4 else 4) if intensity_index is None else intensity_index
+    ctx._check(ctx._lib.randt_sc_make_batch_dev(ctx._h, _dptr(points), B, N, _dptr(n_points), S, ioff, C.byref(sp), _dptr(desc),
+                                                _dptr(ring_keys), _dptr(sector_keys)), "randt_sc_make_batch_dev")
+
+
+def sc_detect_batch(ctx, sp, desc, ring_keys, pos, dist, query_ids, loop_id, yaw, min_dist=None):
+    """randt_sc_detect_batch_dev (SCManager::detectLoopClosureID for a batch of query nodes)."""
+    n_db = int(desc.shape[0])
+    nq = int(loop_id.shape[0])
+    ctx._check(ctx._lib.randt_sc_detect_batch_dev(ctx._h, C.byref(sp), _dptr(desc), _dptr(ring_keys), _dptr(pos), _dptr(dist), n_db,
+                                                  _dptr(query_ids), nq, _dptr(loop_id), _dptr(yaw), _dptr(min_dist)),
+               "randt_sc_detect_batch_dev")
 
 
 # ------------------------------------------------------------------ correlative search (f-3) --------
