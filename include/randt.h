@@ -302,6 +302,24 @@ int randt_sc_detect_batch_dev(randt_ctx* ctx, const randt_sc_params* p, const do
                               const double* d_pos, const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries,
                               int32_t* d_loop_id, float* d_yaw, double* d_min_dist);
 
+/* Device-resident Scan Context database = the state SCManager keeps (polarcontexts_, polarcontext_invkeys_mat_,
+ * odom_positions_, distances_; include/local_fuser/Scancontext.h:88-99).  Nodes are appended in keyframe order. */
+typedef struct randt_sc_db randt_sc_db;
+int randt_sc_db_create(randt_ctx* ctx, const randt_sc_params* p, int initial_capacity, randt_sc_db** out);
+void randt_sc_db_destroy(randt_sc_db* db);
+int randt_sc_db_size(const randt_sc_db* db);
+/* SCManager::makeAndSaveScancontextAndKeys (Scancontext.cpp:240-258): descriptor + keys of one HOST scan, stored as node
+ * randt_sc_db_size() together with its odometry position and traversed distance.  Returns the status; *node_id (nullable)
+ * receives the new node's index. */
+int randt_sc_db_append(randt_sc_db* db, const float* h_points, int n_points, int stride_floats, int intensity_index,
+                       const double odom_position[2], double traversed_distance, int* node_id);
+/* SCManager::detectLoopClosureID (Scancontext.cpp:261-341) for one node of the database: *loop_id = match or -1,
+ * *yaw_diff_rad as in the reference's return value, *min_dist (nullable). */
+int randt_sc_db_detect(randt_sc_db* db, int node_id, int* loop_id, float* yaw_diff_rad, double* min_dist);
+/* host copies of one node (debug / tests): h_desc [num_sector][num_ring], h_ring_key [num_ring], h_sector_key [num_sector]
+ * (each nullable) */
+int randt_sc_db_download(const randt_sc_db* db, int node_id, double* h_desc, double* h_ring_key, double* h_sector_key);
+
 /* ------------------------------------------------------------------ scan filter (f-1) -------- */
 /* RadarPreprocessorParameters used by filterScan + initial_transform_radar_baselink_ as a row-major
  * 3x4 matrix (radar_preprocessor.cpp:7-28,124). */

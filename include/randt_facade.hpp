@@ -4,6 +4,7 @@
 //   rc::navigation::ndt::Cell     include/ndt_representation/ndt_cell.h:16-170
 //   rc::navigation::ndt::Map      include/ndt_representation/ndt_map.h:14-199
 //   rc::navigation::ndt::Matcher  include/ndt_registration/ndt_matcher.h:46-87
+//   SCManager                     include/local_fuser/Scancontext.h:50-103 (loop-closure candidates)
 // This header keeps their names, argument meaning and error behaviour (void/double returns, a
 // warning on std::cout, "keep the previous pose" on failure) but is free of Eigen / Sophus / PCL /
 // Ceres: vectors are std::array, poses are the 4 doubles of Sophus::SE2d::data().  A ROS node built
@@ -20,6 +21,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "randt.h"
@@ -354,6 +356,69 @@ class Matcher {
  private:
   NDTMatcherParameters parameters_;
   std::vector<double> imu_constraints_;
+};
+
+// rc::navigation::ndt::ScanContextParameters (include/ndt_slam/ndt_slam_parameters.h; ndt_slam.cpp:515-552)
+struct ScanContextParameters {
+  int PC_NUM_RING = 20, PC_NUM_SECTOR = 45;
+  double PC_MAX_RADIUS = 15.0;
+  int NUM_EXCLUDE_RECENT = 15, NUM_CANDIDATES_FROM_TREE = 10;
+  double SEARCH_RATIO = 0.3, SC_DIST_THRES = 0.6;
+  int TREE_MAKING_PERIOD_ = 10;  // accepted for source compatibility; the device search always sees the current database
+  double assumed_drift = 0.05, odom_eps = 1.2, odom_weight = 0.2, intensity_factor = 0.04;
+};
+
+// SCManager (include/local_fuser/Scancontext.h:50-103): the user-side API LocalFuser calls
+// (local_fuser.cpp:30,207,284,323); the descriptor database lives on the device.
+class SCManager {
+ public:
+  SCManager() = default;
+  SCManager(const SCManager&) = delete;
+  SCManager& operator=(const SCManager&) = delete;
+  ~SCManager() { randt_sc_db_destroy(db_); }
+
+  void initialize(const std::shared_ptr<Context>& ctx, const ScanContextParameters& params) {
+    ctx_ = ctx;
+    randt_sc_params p{};
+    p.num_ring = params.PC_NUM_RING;
+    p.num_sector = params.PC_NUM_SECTOR;
+    p.max_radius = params.PC_MAX_RADIUS;
+    p.num_exclude_recent = params.NUM_EXCLUDE_RECENT;
+    p.num_candidates = params.NUM_CANDIDATES_FROM_TREE;
+    p.search_ratio = params.SEARCH_RATIO;
+    p.dist_thresh = params.SC_DIST_THRES;
+    p.assumed_drift = params.assumed_drift;
+    p.odom_eps = params.odom_eps;
+    p.odom_weight = params.odom_weight;
+    p.intensity_factor = params.intensity_factor;
+    randt_sc_db_destroy(db_);
+    db_ = nullptr;
+    const int rc = randt_sc_db_create(ctx_->get(), &p, 256, &db_);
+    if (rc != RANDT_OK) throw std::runtime_error(std::string("randt_sc_db_create: ") + randt_status_string(rc));
+  }
+
+  // void makeAndSaveScancontextAndKeys(pcl::PointCloud<SCPointType>::Ptr scan, Eigen::Vector2d& odom_position,
+  //                                    double& traversed_distance)                       (Scancontext.cpp:240-258)
+  void makeAndSaveScancontextAndKeys(const float* points, int n, int stride, int intensity_index,
+                                     const std::array<double, 2>& odom_position, const double& traversed_distance) {
+    const int rc = randt_sc_db_append(db_, points, n, stride, intensity_index, odom_position.data(), traversed_distance, nullptr);
+    if (rc != RANDT_OK) throw std::runtime_error(std::string("randt_sc_db_append: ") + randt_status_string(rc));
+  }
+
+  // std::pair<int, float> detectLoopClosureID(int node_id): nearest node index or -1, relative yaw  (:261-341)
+  std::pair<int, float> detectLoopClosureID(int node_id) const {
+    int loop_id = -1;
+    float yaw = 0.f;
+    const int rc = randt_sc_db_detect(db_, node_id, &loop_id, &yaw, nullptr);
+    if (rc != RANDT_OK) throw std::runtime_error(std::string("randt_sc_db_detect: ") + randt_status_string(rc));
+    return {loop_id, yaw};
+  }
+
+  int size() const { return randt_sc_db_size(db_); }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  randt_sc_db* db_ = nullptr;
 };
 
 }  // namespace randt

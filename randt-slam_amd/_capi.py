@@ -120,6 +120,12 @@ SYMBOLS = {
     "randt_filter_scan_batch_dev": (_I, [_V, _V, _I, _I, _I, _I, _I, _P(FilterParams), _V, _I, _V, _V, _V, _V, _V]),
     "randt_sc_make_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ScParams), _V, _V, _V]),
     "randt_sc_detect_batch_dev": (_I, [_V, _P(ScParams), _V, _V, _V, _V, _I, _V, _I, _V, _V, _V]),
+    "randt_sc_db_create": (_I, [_V, _P(ScParams), _I, _P(_V)]),
+    "randt_sc_db_destroy": (None, [_V]),
+    "randt_sc_db_size": (_I, [_V]),
+    "randt_sc_db_append": (_I, [_V, _V, _I, _I, _I, _V, C.c_double, _P(_I)]),
+    "randt_sc_db_detect": (_I, [_V, _I, _P(_I), _P(C.c_float), _P(C.c_double)]),
+    "randt_sc_db_download": (_I, [_V, _I, _V, _V, _V]),
     "randt_predict_state": (_I, [_V, C.c_double, _V]),
     "randt_register_window": (_I, [_V, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _P(_I), _V]),
 }

@@ -506,6 +506,135 @@ int randt_sc_detect_batch_dev(randt_ctx* ctx, const randt_sc_params* p, const do
                           d_min_dist);
 }
 
+// ---------------------------------------------------------------- Scan Context database -----------------
+struct randt_sc_db {
+  randt_ctx* ctx = nullptr;
+  randt_sc_params p{};
+  int n = 0, cap = 0;
+  double *desc = nullptr, *ring = nullptr, *sector = nullptr, *pos = nullptr, *dist = nullptr;  // device
+  int32_t* out_id = nullptr;  // device scratch: loop id | yaw | min dist
+  float* out_yaw = nullptr;
+  double* out_md = nullptr;
+};
+
+namespace {
+int sc_db_reserve(randt_sc_db* db, int want) {
+  if (want <= db->cap) return RANDT_OK;
+  randt_ctx* ctx = db->ctx;
+  int cap = db->cap > 0 ? db->cap : 64;
+  while (cap < want) cap *= 2;
+  const size_t nd = (size_t)db->p.num_ring * db->p.num_sector;
+  struct Arr { double** p; size_t per; } arrs[5] = {{&db->desc, nd}, {&db->ring, (size_t)db->p.num_ring}, {&db->sector, (size_t)db->p.num_sector},
+                                                   {&db->pos, 2}, {&db->dist, 1}};
+  for (auto& a : arrs) {
+    double* fresh = nullptr;
+    RANDT_HIP_CHECK(ctx, hipMalloc(&fresh, sizeof(double) * a.per * cap));
+    if (db->n > 0)
+      RANDT_HIP_CHECK(ctx, hipMemcpyAsync(fresh, *a.p, sizeof(double) * a.per * db->n, hipMemcpyDeviceToDevice, ctx->stream));
+    RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*a.p) (void)hipFree(*a.p);
+    *a.p = fresh;
+  }
+  db->cap = cap;
+  return RANDT_OK;
+}
+}  // namespace
+
+int randt_sc_db_create(randt_ctx* ctx, const randt_sc_params* p, int initial_capacity, randt_sc_db** out) {
+  if (!ctx || !p || !out || p->num_ring < 1 || p->num_sector < 1) return RANDT_ERR_INVALID;
+  randt_sc_db* db = new randt_sc_db();
+  db->ctx = ctx;
+  db->p = *p;
+  hipError_t e = hipMalloc(&db->out_id, 64);
+  if (e != hipSuccess) {
+    delete db;
+    return randt_set_error(ctx, RANDT_ERR_HIP, "hipMalloc", e);
+  }
+  db->out_yaw = reinterpret_cast<float*>(db->out_id + 2);
+  db->out_md = reinterpret_cast<double*>(db->out_id + 4);
+  int rc = sc_db_reserve(db, initial_capacity > 0 ? initial_capacity : 64);
+  if (rc) {
+    randt_sc_db_destroy(db);
+    return rc;
+  }
+  *out = db;
+  return RANDT_OK;
+}
+
+void randt_sc_db_destroy(randt_sc_db* db) {
+  if (!db) return;
+  for (double* p : {db->desc, db->ring, db->sector, db->pos, db->dist})
+    if (p) (void)hipFree(p);
+  if (db->out_id) (void)hipFree(db->out_id);
+  delete db;
+}
+
+int randt_sc_db_size(const randt_sc_db* db) { return db ? db->n : 0; }
+
+int randt_sc_db_append(randt_sc_db* db, const float* h_points, int n_points, int stride_floats, int intensity_index,
+                       const double odom_position[2], double traversed_distance, int* node_id) {
+  if (!db || n_points < 0 || (n_points > 0 && !h_points) || !odom_position || stride_floats < 3 || intensity_index < 0 ||
+      intensity_index >= stride_floats)
+    return RANDT_ERR_INVALID;
+  randt_ctx* ctx = db->ctx;
+  int rc = sc_db_reserve(db, db->n + 1);
+  if (rc) return rc;
+  const int pitch = n_points > 0 ? n_points : 1;
+  const size_t bytes = sizeof(float) * (size_t)pitch * stride_floats;
+  rc = ensure_ws(ctx, bytes + 64);
+  if (rc) return rc;
+  if (n_points > 0) RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_points, bytes, hipMemcpyHostToDevice, ctx->stream));
+  int32_t* d_n = reinterpret_cast<int32_t*>((char*)ctx->ws + ((bytes + 15) & ~(size_t)15));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(d_n, &n_points, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  const size_t nd = (size_t)db->p.num_ring * db->p.num_sector;
+  rc = launch_sc_make(ctx, (const float*)ctx->ws, 1, pitch, d_n, stride_floats, intensity_index, &db->p, db->desc + nd * db->n,
+                      db->ring + (size_t)db->p.num_ring * db->n, db->sector + (size_t)db->p.num_sector * db->n);
+  if (rc) return rc;
+  const double pd[3] = {odom_position[0], odom_position[1], traversed_distance};
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(db->pos + 2 * (size_t)db->n, pd, sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(db->dist + db->n, pd + 2, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the host buffers may go away
+  if (node_id) *node_id = db->n;
+  db->n += 1;
+  return RANDT_OK;
+}
+
+int randt_sc_db_detect(randt_sc_db* db, int node_id, int* loop_id, float* yaw_diff_rad, double* min_dist) {
+  if (!db || !loop_id || !yaw_diff_rad || node_id < 0 || node_id >= db->n) return RANDT_ERR_INVALID;
+  randt_ctx* ctx = db->ctx;
+  int rc = ensure_ws(ctx, sizeof(float) * (size_t)db->n + 256);
+  if (rc) return rc;
+  int32_t* d_q = db->out_id + 1;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(d_q, &node_id, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_sc_detect(ctx, &db->p, db->desc, db->ring, db->pos, db->dist, db->n, d_q, 1, (float*)ctx->ws, db->out_id, db->out_yaw,
+                        db->out_md);
+  if (rc) return rc;
+  int32_t id = -1;
+  double md = 0;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&id, db->out_id, sizeof(id), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(yaw_diff_rad, db->out_yaw, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&md, db->out_md, sizeof(md), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *loop_id = id;
+  if (min_dist) *min_dist = md;
+  return RANDT_OK;
+}
+
+int randt_sc_db_download(const randt_sc_db* db, int node_id, double* h_desc, double* h_ring_key, double* h_sector_key) {
+  if (!db || node_id < 0 || node_id >= db->n) return RANDT_ERR_INVALID;
+  randt_ctx* ctx = db->ctx;
+  const size_t nd = (size_t)db->p.num_ring * db->p.num_sector;
+  if (h_desc) RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_desc, db->desc + nd * node_id, sizeof(double) * nd, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_ring_key)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_ring_key, db->ring + (size_t)db->p.num_ring * node_id, sizeof(double) * db->p.num_ring,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+  if (h_sector_key)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_sector_key, db->sector + (size_t)db->p.num_sector * node_id, sizeof(double) * db->p.num_sector,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RANDT_OK;
+}
+
 int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans, int n_azimuths, int n_bins,
                                 int stride_floats, int intensity_index, const randt_filter_params* fp,
                                 float* d_out_points, int pitch_out, int32_t* d_out_counts, float* d_out_polar,

@@ -359,6 +359,53 @@ def sc_detect_batch(ctx, sp, desc, ring_keys, pos, dist, query_ids, loop_id, yaw
                "randt_sc_detect_batch_dev")
 
 
+class ScDatabase:
+    """SCManager's state on the device (randt_sc_db_*): append keyframe scans, query loop closures."""
+
+    def __init__(self, ctx, sp, capacity=64):
+        self._ctx, self.sp = ctx, sp
+        self._h = C.c_void_p()
+        ctx._check(ctx._lib.randt_sc_db_create(ctx._h, C.byref(sp), int(capacity), C.byref(self._h)), "randt_sc_db_create")
+
+    def __len__(self):
+        return int(self._ctx._lib.randt_sc_db_size(self._h))
+
+    def append(self, points, odom_position, traversed_distance, intensity_index=None):
+        """makeAndSaveScancontextAndKeys: points (N, stride) float32 host array.  Returns the node id."""
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        n, stride = pts.shape
+        ioff = (3 if stride == 4 else 4) if intensity_index is None else intensity_index
+        pos = np.ascontiguousarray(odom_position, dtype=np.float64)
+        node = C.c_int(-1)
+        self._ctx._check(self._ctx._lib.randt_sc_db_append(self._h, pts.ctypes.data, n, stride, ioff, pos.ctypes.data, float(traversed_distance),
+                                                          C.byref(node)), "randt_sc_db_append")
+        return node.value
+
+    def detect(self, node_id):
+        """detectLoopClosureID: (loop_id or -1, yaw_diff_rad, min_dist)."""
+        lid, yaw, md = C.c_int(-1), C.c_float(0), C.c_double(0)
+        self._ctx._check(self._ctx._lib.randt_sc_db_detect(self._h, int(node_id), C.byref(lid), C.byref(yaw), C.byref(md)), "randt_sc_db_detect")
+        return lid.value, yaw.value, md.value
+
+    def download(self, node_id):
+        d = np.zeros((self.sp.num_sector, self.sp.num_ring))
+        rk, sk = np.zeros(self.sp.num_ring), np.zeros(self.sp.num_sector)
+        self._ctx._check(self._ctx._lib.randt_sc_db_download(self._h, int(node_id), d.ctypes.data, rk.ctypes.data, sk.ctypes.data),
+                         "randt_sc_db_download")
+        return d, rk, sk
+
+    def close(self):
+        if self._h and getattr(self._ctx, "_h", None):
+            self._ctx._lib.randt_sc_db_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ correlative search (f-3) --------
 def bnb_params(window_linear=4.5, window_angular=0.45, linear_step=0.4, cost_threshold=0.82, max_px_accurate_range=4.0, n_iter=2):
     """config/ndt_radar_slam_base_parameters.yaml:50-56."""

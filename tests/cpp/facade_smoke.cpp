@@ -95,5 +95,25 @@ int main() {
     randt_maps_destroy(fixed_batch);
     randt_maps_destroy(scan_batch);
   }
-  return (ok && kept && win_ok) ? 0 : 2;
+  // loop-closure candidates through the SCManager mirror: 20 keyframes on a line, the last one back at keyframe 2
+  bool sc_ok = true;
+  {
+    ScanContextParameters scp;
+    scp.PC_MAX_RADIUS = 12.0;
+    scp.NUM_EXCLUDE_RECENT = 5;
+    SCManager sc;
+    sc.initialize(ctx, scp);
+    for (int kf = 0; kf < 20; ++kf) {
+      const double ox = kf == 19 ? 2 * 0.8 : kf * 0.8;  // sensor position along x
+      std::vector<float> pts;
+      for (size_t i = 0; i < fixed_pts.size(); i += 4)
+        pts.insert(pts.end(), {fixed_pts[i] - (float)ox, fixed_pts[i + 1], 0.f, fixed_pts[i + 3]});
+      sc.makeAndSaveScancontextAndKeys(pts.data(), (int)pts.size() / 4, 4, 3, {ox, 0.0}, kf * 0.8);
+    }
+    const auto early = sc.detectLoopClosureID(3);   // node_id < NUM_EXCLUDE_RECENT + 1
+    const auto hit = sc.detectLoopClosureID(19);
+    std::printf("scan context: %d nodes, query 19 -> %d (yaw %.3f)\n", sc.size(), hit.first, hit.second);
+    sc_ok = sc.size() == 20 && early.first == -1 && hit.first == 2;
+  }
+  return (ok && kept && win_ok && sc_ok) ? 0 : 2;
 }

@@ -180,3 +180,36 @@ def test_hip_scan_context_other_shapes(built):
     for j, i in enumerate(q):
         lid, y, _ = po.sc_detect(sp_o, descs, rks, pos, dist, int(i))
         assert loop.cpu().numpy()[j] == lid and yaw.cpu().numpy()[j] == np.float32(y)
+
+
+@pytest.mark.gpu
+def test_hip_scan_context_database_object(built):
+    """randt_sc_db_*: the SCManager call pattern (append keyframes one by one, query a node) grows its device
+    arrays and answers like the batch entry points / the oracle."""
+    import torch
+
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    sp_o = osp(max_radius=20.0, dist_thresh=0.5)
+    sp = host.sc_params(max_radius=20.0, dist_thresh=0.5)
+    scans, pos, dist = _database(n_db=70, revisit=(66, 9))
+    db = host.ScDatabase(ctx, sp, capacity=8)               # forces several re-allocations
+    descs, rks = [], []
+    for i, s in enumerate(scans):
+        n = len(s) if i % 3 else 1200                        # ragged scans
+        assert db.append(s[:n], pos[i], dist[i]) == i
+        d, rk, _ = po.sc_make(s[:n], sp_o)
+        descs.append(d)
+        rks.append(rk)
+    assert len(db) == 70
+    descs, rks = np.stack(descs), np.stack(rks)
+    for i in (0, 7, 33, 69):
+        d, rk, sk = db.download(i)
+        assert np.array_equal(d, descs[i]) and np.array_equal(rk, rks[i])
+    hits = 0
+    for i in (5, 16, 40, 66, 69):
+        lid, yaw, md = db.detect(i)
+        olid, oyaw, omd = po.sc_detect(sp_o, descs, rks, pos, dist, i)
+        assert lid == olid and yaw == np.float32(oyaw) and abs(md - omd) <= 1e-12 * max(1.0, abs(omd))
+        hits += lid >= 0
+    assert hits >= 1
+    db.close()
