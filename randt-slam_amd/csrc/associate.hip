@@ -33,6 +33,20 @@ using namespace randt_dev;
 #define ASSOC_CAND 64    // candidates per cell: <= (k-1) + 8R = 63 for k <= 8, R <= 7
 #define ASSOC_QS 11      // LDS stride of a query record (odd => conflict-free)
 
+#ifdef RANDT_TIMING
+__device__ long long g_randt_assoc_timing[16];
+#define ASSOC_TICK(slot)                                                                  \
+  do {                                                                                    \
+    __syncthreads();                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && c0 == 0) g_randt_assoc_timing[slot] = wall_clock64(); \
+  } while (0)
+extern "C" int randt_debug_assoc_timing(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_randt_assoc_timing), sizeof(long long) * 16);
+}
+#else
+#define ASSOC_TICK(slot) do {} while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ bool cand_less(float da, int32_t ia, float db, int32_t ib) {
@@ -70,6 +84,14 @@ __device__ __forceinline__ void ring_offset(int w, int& i, int& j) {
     case 2: i = r - pos; j = r; break;
     default: i = -r; j = r - pos; break;
   }
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long min_u64_dpp(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return o < v ? o : v;
 }
 
 __device__ __forceinline__ unsigned long long prefix_mask(int n) {
@@ -134,6 +156,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
   for (int c0 = 0; c0 < M; c0 += ASSOC_CH) {
     const int nch = M - c0 < ASSOC_CH ? M - c0 : ASSOC_CH;
     __syncthreads();  // previous chunk fully consumed (also orders P0 before first use)
+    ASSOC_TICK(0);
 
     // ---- P1: transform the query cells of this chunk
     if (tid < nch) {
@@ -154,14 +177,33 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     }
     __syncthreads();
 
+    ASSOC_TICK(1);
     // ---- P2: window scan (LDS only), one wavefront per moving cell.
     // Reference loop (ndt_map.cpp:101-152): evaluate radius 0, 1, ... until enough targets (nt >= k) or
     // enough adjacent slots (nadj >= n_slots) were seen or the radius reaches rmax.  The window is
     // enumerated ring-major, so "everything up to radius r" is a prefix of (2r+1)^2 entries: 64 lanes
     // fetch a pass of the window, two ballots give its occupied / in-range masks, and LANE r evaluates
     // radius r from those masks -- the termination radius is one more ballot instead of a scalar loop.
+    // pass 0 (the 64 innermost window slots) of a cell's index-grid gather; issued one cell ahead so that its
+    // L2 latency is hidden behind the previous cell's ballots
+    const int lane_i = (wtab[lane] >> 8) - 128, lane_j = (wtab[lane] & 255) - 128;
+    auto fetch_pass0 = [&](int cc) -> int32_t {
+      int32_t ci = -2;  // -2: not a valid window slot, -1: empty slot
+      if (lane < nwin) {
+        const uint32_t ctr = __float_as_uint(qrec[cc * ASSOC_QS + 9]);
+        const uint32_t ni = ctr + (uint32_t)lane_i + (uint32_t)lane_j * (uint32_t)fixed.size_x;
+        if (ni < (uint32_t)n_slots) {
+          ci = grid[ni];
+          if (ci < -1) ci = -1;
+        }
+      }
+      return ci;
+    };
+    int32_t ci_next = wave < nch ? fetch_pass0(wave) : -2;
     for (int c = wave; c < nch; c += ASSOC_WAVES) {
       const uint32_t center = __float_as_uint(qrec[c * ASSOC_QS + 9]);
+      const int32_t ci_pass0 = ci_next;
+      if (c + ASSOC_WAVES < nch) ci_next = fetch_pass0(c + ASSOC_WAVES);
       int32_t cidx[ASSOC_PASSES];
       unsigned long long occ[ASSOC_PASSES], val[ASSOC_PASSES];
       int rstar = -1;
@@ -176,8 +218,10 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
           const int r_first = p == 0 ? 0 : (p == 1 ? 4 : (p == 2 ? 6 : 7));
           if (rstar < 0 && r_first <= R) {
             const int w = p * 64 + lane;
-            int32_t ci = -2;  // -2: not a valid window slot, -1: empty slot
-            if (w < nwin) {
+            int32_t ci = -2;
+            if (p == 0) {
+              ci = ci_pass0;
+            } else if (w < nwin) {
               const int packed = wtab[w];
               const int i = (packed >> 8) - 128, j = (packed & 255) - 128;
               const uint32_t ni = center + (uint32_t)i + (uint32_t)j * (uint32_t)fixed.size_x;
@@ -283,6 +327,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     }
     __syncthreads();
 
+    ASSOC_TICK(2);
     // exclusive prefix of clen over the chunk (one wavefront)
     if (wave == 0) {
       int carry = 0;
@@ -304,6 +349,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     __syncthreads();
     const int total = cpref[ASSOC_CH];
 
+    ASSOC_TICK(3);
     // ---- P3: one thread per (cell, candidate): gather + fp32 distance
     for (int p = tid; p < total; p += ASSOC_BLOCK) {
       int lo = 0, hi = nch;  // largest c with cpref[c] <= p
@@ -334,44 +380,42 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     }
     __syncthreads();
 
-    // ---- P4: top-k per cell by (dist, idx), one 16-lane group per cell
+    ASSOC_TICK(4);
+    // ---- P4: top-k per cell by (dist, idx), one 16-lane group per cell.  A candidate is ONE sortable 64-bit key
+    // (order-preserving image of the float distance, then the compact index), so a selection round is an unsigned
+    // 64-bit min over the group: four DPP steps inside the 16-lane row, no LDS shuffles, no branches.
     {
       const int grp = tid >> 4, gl = tid & 15;
+      constexpr unsigned long long EMPTY = ~0ull;
       for (int c = grp; c < nch; c += ASSOC_BLOCK / 16) {
         const int n = clen[c];
-        float cd[4];
-        int32_t ci[4];
+        unsigned long long key[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int jj = gl + 16 * s;
-          ci[s] = jj < n ? cand[c * ASSOC_CAND + jj] : -1;
-          cd[s] = jj < n ? cdist[c * ASSOC_CAND + jj] : 0.f;
+          key[s] = EMPTY;
+          if (jj < n) {
+            const uint32_t u = __float_as_uint(cdist[c * ASSOC_CAND + jj] + 0.0f);  // -0 -> +0
+            const uint32_t ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // numeric order as unsigned order
+            key[s] = ((unsigned long long)ord << 32) | (uint32_t)cand[c * ASSOC_CAND + jj];
+          }
         }
         for (int kk = 0; kk < k; ++kk) {
-          float bd = cd[0];
-          int32_t bi = ci[0];
+          unsigned long long b = key[0];
 #pragma unroll
-          for (int s = 1; s < 4; ++s)
-            if (cand_less(cd[s], ci[s], bd, bi)) {
-              bd = cd[s];
-              bi = ci[s];
-            }
-#pragma unroll
-          for (int off = 8; off > 0; off >>= 1) {
-            const float od = __shfl_xor(bd, off, 16);
-            const int32_t oi = __shfl_xor(bi, off, 16);
-            if (cand_less(od, oi, bd, bi)) {
-              bd = od;
-              bi = oi;
-            }
-          }
-          if (gl == 0) out[(size_t)(c0 + c) * k + kk] = bi;
+          for (int s = 1; s < 4; ++s) b = key[s] < b ? key[s] : b;
+          b = min_u64_dpp<0xB1>(b);   // quad_perm [1,0,3,2]
+          b = min_u64_dpp<0x4E>(b);   // quad_perm [2,3,0,1]
+          b = min_u64_dpp<0x141>(b);  // row_half_mirror
+          b = min_u64_dpp<0x140>(b);  // row_mirror: every lane of the 16-lane row holds the minimum
+          if (gl == 0) out[(size_t)(c0 + c) * k + kk] = b == EMPTY ? -1 : (int32_t)(uint32_t)b;
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            if (bi >= 0 && ci[s] == bi) ci[s] = -1;
+            if (key[s] == b) key[s] = EMPTY;
         }
       }
     }
+    ASSOC_TICK(5);
   }
 }
 
