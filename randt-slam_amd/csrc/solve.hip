@@ -126,6 +126,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     tx = x[2];
     ty = x[3];
   }
+  const Rot rot = make_rot(c, s);
   double acc[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) acc[i] = 0.0;
@@ -136,7 +137,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     const float4* mv = S.mov + (size_t)mi * 3;
     const float4* fv = S.fix + (size_t)ci * 3;
     double jb[3];
-    const double sq = residual_sq<D, MODE == 1>(mv, fv, c, s, tx, ty, jb);
+    const double sq = residual_sq<D, MODE == 1>(mv, fv, rot, tx, ty, jb);
     if (!isfinite(sq)) bad = 1;
     if (MODE == 0) {
       mx = sq > mx ? sq : mx;
@@ -632,13 +633,14 @@ __global__ __launch_bounds__(64) void k_eval_cost(MapView fixed, int fmap, MapVi
   const double* x = poses4 + 4 * (size_t)p;
   const double inv = rsqrt(x[0] * x[0] + x[1] * x[1]);
   const double c = x[0] * inv, s = x[1] * inv, tx = x[2], ty = x[3];
+  const Rot rot = make_rot(c, s);
   double acc = 0.0;
   int n = 0;
   for (int slot = lane; slot < M * k; slot += 64) {
     const int ci = corr[slot];
     if (ci < 0 || ci >= fixed.cap) continue;
     double jb[3];
-    const double sq = residual_sq<D, false>(mov + (size_t)(slot / k) * 3, fix + (size_t)ci * 3, c, s, tx, ty, jb);
+    const double sq = residual_sq<D, false>(mov + (size_t)(slot / k) * 3, fix + (size_t)ci * 3, rot, tx, ty, jb);
     ++n;
     if (L.mode == 2) {
       const double iu = 1.0 / (sq * L.ts + 1.0);

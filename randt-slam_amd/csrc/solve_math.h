@@ -80,30 +80,45 @@ __device__ __forceinline__ void loss_eval(const Loss& L, double s, double& r0, d
 // jb = r * d r / d (tx, ty, theta) with r = sqrt(ssq) (A.2 in the global frame): the 1/r factor is
 // folded into the accumulation by the caller, so no square root is taken per residual.
 // mv/fv: first 9 floats of a cell record (mean xyz, cov xx xy xi yy yi ii); c, s = cos/sin(theta).
+// Rotation of one pass, with the products the covariance rotation needs: R S R^T is linear in (c^2, cs, s^2),
+// so the 2 x 2 block of C = R Sm R^T + Sf costs nine fused multiply-adds instead of seventeen operations.
+struct Rot {
+  double c, s, c2, s2, cs, cs2, c2ms2;
+};
+__device__ __forceinline__ Rot make_rot(double c, double s) {
+  Rot R;
+  R.c = c;
+  R.s = s;
+  R.c2 = c * c;
+  R.s2 = s * s;
+  R.cs = c * s;
+  R.cs2 = 2.0 * R.cs;
+  R.c2ms2 = R.c2 - R.s2;
+  return R;
+}
+
 template <int D, bool WANT_JAC>
-__device__ __forceinline__ double residual_sq(const float4* mrec, const float4* frec, double c, double s,
-                                              double tx, double ty, double* jb) {
+__device__ __forceinline__ double residual_sq(const float4* mrec, const float4* frec, const Rot& R, double tx, double ty, double* jb) {
   // 48-byte records as three 16-byte loads each (global: dwordx4, LDS: ds_read_b128, conflict-free at stride 48)
   const float4 ma = mrec[0], mb = mrec[1], mc4 = mrec[2];
   const float4 fa = frec[0], fb = frec[1], fc4 = frec[2];
   const float mv[9] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w, mc4.x};
   const float fv[9] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc4.x};
+  const double c = R.c, s = R.s;
   const double m0 = mv[0], m1 = mv[1];
   const double a = mv[3], b = mv[4], dd = mv[6];
-  const double RS00 = c * a - s * b, RS01 = c * b - s * dd;
-  const double RS10 = s * a + c * b, RS11 = s * b + c * dd;
-  const double C00 = (RS00 * c - RS01 * s) + (double)fv[3];
-  const double C01 = (RS00 * s + RS01 * c) + (double)fv[4];
-  const double C11 = (RS10 * s + RS11 * c) + (double)fv[6];
-  const double d0 = (c * m0 - s * m1) + tx - (double)fv[0];
-  const double d1 = (s * m0 + c * m1) + ty - (double)fv[1];
+  const double C00 = fma(R.c2, a, fma(-R.cs2, b, fma(R.s2, dd, (double)fv[3])));
+  const double C11 = fma(R.s2, a, fma(R.cs2, b, fma(R.c2, dd, (double)fv[6])));
+  const double C01 = fma(R.cs, a - dd, fma(R.c2ms2, b, (double)fv[4]));
+  const double d0 = fma(c, m0, fma(-s, m1, tx - (double)fv[0]));
+  const double d1 = fma(s, m0, fma(c, m1, ty - (double)fv[1]));
   double q0, q1, q2 = 0.0, ssq;
   double cc = 0.0, e = 0.0;
   if (D == 3) {
     cc = mv[5];
     e = mv[7];
-    const double C02 = (c * cc - s * e) + (double)fv[5];
-    const double C12 = (s * cc + c * e) + (double)fv[7];
+    const double C02 = fma(c, cc, fma(-s, e, (double)fv[5]));
+    const double C12 = fma(s, cc, fma(c, e, (double)fv[7]));
     const double C22 = (double)mv[8] + (double)fv[8];
     const double d2 = (double)mv[2] - (double)fv[2];
     const double k00 = C11 * C22 - C12 * C12;

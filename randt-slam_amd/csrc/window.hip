@@ -314,6 +314,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
       const double* xp = sh.xs[buf][j];
       const double inv = fast_rsqrt(xp[0] * xp[0] + xp[1] * xp[1]);
       const double c = xp[0] * inv, s = xp[1] * inv, tx = xp[2], ty = xp[3];
+      const Rot rot = make_rot(c, s);
       const int mmap = W.term_moving[t], fmap = W.term_fixed[t];
       int M = moving.counts[mmap];
       M = M > moving.cap ? moving.cap : M;
@@ -332,7 +333,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
         const float4* mv = mov + (size_t)mi * 3;
         const float4* fv = fix + (size_t)ci * 3;
         double jb[3];
-        const double sq = residual_sq<D, MODE == 1>(mv, fv, c, s, tx, ty, jb);
+        const double sq = residual_sq<D, MODE == 1>(mv, fv, rot, tx, ty, jb);
         if (!isfinite(sq)) bad = 1;
         if (MODE == 0) mx = sq > mx ? sq : mx;
         else accumulate_residual<AM2>(L, sq, jb, a10);
