@@ -7,17 +7,19 @@
 //
 // One workgroup (512 threads) per (scan, submap) pair, four phases per chunk of 64 moving cells so
 // that every global-memory round trip is taken once by all lanes together instead of once per cell:
-//   P0  the submap's dense int32 index grid (40 KB for the 100x100 indoor map) is staged into LDS
-//       with 16-byte coalesced loads; a ring-major table of the (2R+1)^2 window offsets is built;
+//   P0  a ring-major table of the (2R+1)^2 window offsets is built; optionally (RANDT_ASSOC_STAGE_GRID=1) the
+//       submap's dense int32 index grid (40 KB for the 100x100 indoor map) is staged into LDS with 16-byte
+//       loads -- by default it is gathered from L2, which is as fast and leaves the LDS to co-running kernels;
 //   P1  one thread per moving cell: 48-byte record from HBM/L2, fp32 transform by the initial guess
 //       (reference operation order), centre slot; query cells parked in LDS;
-//   P2  one wavefront per moving cell, LDS only: lanes cover the window ring by ring, one ballot per
-//       64 slots gives the occupied / valid counts of every Chebyshev radius, the reference's
-//       termination rule picks the final radius, occupied slots are compacted into a candidate list;
+//   P2  one wavefront per moving cell: lanes cover the window ring by ring (the first 64 slots are gathered one
+//       cell ahead), two ballots per 64 slots give the occupied / in-range masks, LANE r evaluates radius r from
+//       them and one more ballot picks the reference's termination radius; occupied slots are compacted into
+//       a candidate list;
 //   P3  one thread per (cell, candidate): gather the fixed cell's 48-byte record (L2), fp32
 //       Mahalanobis / Euclidean distance in Eigen's operation order;
-//   P4  one 16-lane group per cell: k rounds of lexicographic arg-min on (distance, compact index)
-//       = the order std::sort produces on std::pair<double,size_t>.
+//   P4  one 16-lane group per cell: k rounds of an unsigned 64-bit min over sortable (distance, compact index)
+//       keys with in-row DPP = the order std::sort produces on std::pair<double,size_t>.
 #include "cell_math.h"
 
 using namespace randt_dev;
@@ -48,15 +50,6 @@ extern "C" int randt_debug_assoc_timing(long long* out) {
 #endif
 
 namespace {
-
-__device__ __forceinline__ bool cand_less(float da, int32_t ia, float db, int32_t ib) {
-  // std::pair<double,size_t> ordering (ndt_map.cpp:122,147); idx < 0 = empty = +inf
-  if (ia < 0) return false;
-  if (ib < 0) return true;
-  if (da < db) return true;
-  if (db < da) return false;
-  return ia < ib;
-}
 
 // duplicate test of Map::getAdjacentIndizes' std::find (ndt_map.cpp:169): slot (i, j) of the window
 // of radius r repeats an EARLIER (x-offset-major) window entry iff some t >= 1 has

@@ -32,7 +32,7 @@ struct randt_ctx {
   double* d_trace = nullptr;
   int trace_len = 0;
   int lds_limit = 160 * 1024;
-  // solve-kernel geometry (tunable through RANDT_SOLVE_BLOCK / RANDT_SOLVE_STAGE for experiments)
+  // kernel geometry knobs (RANDT_SOLVE_BLOCK, RANDT_ASSOC_STAGE_GRID; for experiments)
   int solve_block = 64;
   int assoc_stage_grid = 0;  // 1: stage the fixed map's index grid in LDS; 0: gather it from L2 (same speed alone, but 36 KB instead of 76 KB of LDS leaves room for co-running build workgroups: +2 % end to end)
 };
