@@ -11,10 +11,11 @@
 //   src/ndt_representation/ndt_cell.cpp:25-114                 Cell::addPointCloud / updateCell
 //   src/ndt_representation/ndt_map.cpp:177-207, ndt_cell.h:133-142   transformMap / mergeMapCell / operator+=
 //
-// Data layout: points are read once from HBM as 16-byte (stride 4) or strided records and staged
-// as SoA x/y/intensity in LDS; labels, per-label bins and the sorted index list live in LDS as well, so the
-// only HBM traffic is N*16 B in, M*48 B + grid out.  fp32 sums run in the reference's sequential
-// point order (one lane per cluster) so the cell statistics are bit-identical to the CPU path.
+// Data layout: points are read once from HBM as 16-byte (stride 4) or strided records, kept in registers while
+// they are sorted (scans <= 2048 points) and scattered as label-sorted SoA x/y/intensity into LDS; per-label
+// bins and cluster bounds live in LDS as well, so the only HBM traffic is N*16 B in, M*48 B + grid out.  fp32
+// sums run in the reference's sequential point order (one lane per accumulator chain, eight lanes per
+// cluster) so the cell statistics are bit-identical to the CPU path.
 #include "cell_math.h"
 
 using namespace randt_dev;

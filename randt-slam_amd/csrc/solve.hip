@@ -15,16 +15,19 @@
 // across the ~30 passes of a registration and are cast to fp64 in registers like the reference
 // does (ndt_matcher.cpp:231).  (Staging the records themselves in LDS was measured slower: the LDS
 // it takes costs the co-running kernels more than the solve gains.)
-// Every LM iteration is one pass over the M*k correspondence slots: fp64 residual, its Jacobian
-// with respect to (tx, ty, theta), loss + Ceres corrector, and TEN accumulators {cost, J^T r (3),
-// upper J^T J (6)} reduced in a fixed order (DPP row reduction -> readlane across rows -> LDS
-// combine across wavefronts): deterministic, run-to-run bit-identical.  The Jacobian of the actual
+// Every LM iteration is one pass over the valid correspondences: fp64 residual, its (un-normalised) Jacobian
+// with respect to (tx, ty, theta), loss + Ceres corrector -- no square root, no IEEE division per residual
+// (solve_math.h) -- and TEN accumulators {cost, J^T r (3), upper J^T J (6)} reduced in a fixed order
+// (lane-swap folding -> DPP row reduction -> readlane; LDS combine across wavefronts): deterministic,
+// run-to-run bit-identical.  The Jacobian of the actual
 // parameterisation (SE(2) tangent / ambient [c,s,tx,ty] / vector) is a per-evaluation-constant
 // linear map T of that base Jacobian, so H = T G T^T and g = T g_b are formed after the reduction.
-// Jacobi scaling, LM diagonal clamp, damped normal equations (LDL^T), model-cost change, Plus,
-// both convergence tests, accept/reject and radius update run redundantly on all lanes (uniform
-// control flow, no broadcast).  The candidate is evaluated WITH its Jacobian so an accepted step
-// needs no second pass.
+// Jacobi scaling, LM diagonal clamp, damped normal equations (packed LDL^T), model-cost change, Plus,
+// both convergence tests, accept/reject and radius update run redundantly on all lanes; every branch on
+// that uniform state goes through a ballot (uni()) so that the compiler emits scalar branches.  The
+// candidate is evaluated WITH its Jacobian so an accepted step needs no second pass.  The template
+// parameter AM2 selects the closed-form loss of the shipped Barron shape (-2), which keeps pow() out of
+// the kernel.
 #include "randt_internal.h"
 #include "solve_math.h"
 

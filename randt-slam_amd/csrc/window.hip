@@ -10,15 +10,17 @@
 //
 // One 256-thread workgroup owns one window problem (<= 3 optimised states, <= 2 fixed maps, 21-32
 // tangent dimensions) and runs the whole GNC x LM loop without host round trips:
-//   * NDT terms: all lanes stream the correspondence slots of every (state, fixed map) term, cell
-//     records read in place from L1/L2, ten fp64 base sums PER STATE, fixed-order reduction;
+//   * NDT terms: one wavefront per (state, fixed map) term streams that term's correspondence slots, cell
+//     records read in place from L1/L2, ten fp64 base sums per term (one lane-swap reduction), combined per
+//     state in term order;
 //   * motion / IMU factors: one lane per factor evaluates residual + analytic Jacobian (right
 //     perturbations, verified against finite differences in tests/test_oracle_window.py), all lanes
 //     apply the 8x8 square-root information;
 //   * J^T J / J^T r: one thread per matrix entry gathers the factor blocks and the per-state
 //     3x3 NDT blocks (T G T^T with Sophus' PlusJacobian) into LDS;
-//   * Jacobi scaling, LM damping, LDL^T of the dense n x n system, model-cost change, Plus on every
-//     manifold block and the step norms run on wavefront 0 with LDS-resident matrices;
+//   * Jacobi scaling, LM damping, the dense n x n solve (Gauss-Jordan in registers: lane = row, pivot rows
+//     broadcast with v_readlane, rows shifted so that the pivot column is always register 0), model-cost
+//     change, Plus on every manifold block and the step norms run on wavefront 0;
 //   * convergence tests / accept-reject / radius update are evaluated redundantly by every lane
 //     from broadcast scalars (uniform control flow).
 // The candidate point is evaluated with its Jacobians so that an accepted step costs one pass.
