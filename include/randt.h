@@ -320,6 +320,11 @@ int randt_sc_db_detect(randt_sc_db* db, int node_id, int* loop_id, float* yaw_di
  * (each nullable) */
 int randt_sc_db_download(const randt_sc_db* db, int node_id, double* h_desc, double* h_ring_key, double* h_sector_key);
 
+/* One pair, host result (Map::calculateCSDivergence as LocalFuser::detectLoopClosures calls it, local_fuser.cpp:338-339):
+ * h_pose4 (nullable) transforms the moving map first; *out = the divergence; h_terms (nullable) = the three sums. */
+int randt_cs_divergence(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
+                        const double* h_pose4, double* out, double* h_terms);
+
 /* ------------------------------------------------------------------ scan filter (f-1) -------- */
 /* RadarPreprocessorParameters used by filterScan + initial_transform_radar_baselink_ as a row-major
  * 3x4 matrix (radar_preprocessor.cpp:7-28,124). */

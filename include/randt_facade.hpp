@@ -225,6 +225,14 @@ class Map {
 
   void clear() { check(randt_maps_clear(m_, 0, 1), "randt_maps_clear"); }
 
+  // double Map::calculateCSDivergence(const Map& m_map)                       (ndt_map.cpp:42-99)
+  // (the moving map already transformed by the caller, like local_fuser.cpp:338-339)
+  double calculateCSDivergence(const Map& m_map) const {
+    double v = 0.0;
+    check(randt_cs_divergence(ctx_->get(), m_, 0, m_map.m_, 0, nullptr, &v, nullptr), "randt_cs_divergence");
+    return v;
+  }
+
   randt_maps* handle() const { return m_; }
   const std::shared_ptr<Context>& context() const { return ctx_; }
 
@@ -282,6 +290,25 @@ class Matcher {
     }
     if (r.n_residuals == 0) std::cout << "WARNING: NO RESIDUALS ADDED!" << std::endl;
     return r.cost;
+  }
+
+  // double Matcher::estimateTransformGlobalBNB(Sophus::SE2d& trans, const Map& fixed_ndt, Map& moving_ndt,
+  //   bool use_intensity_as_dimension, double scale, double search_window_size_linear,
+  //   double search_window_size_angular)                                       (ndt_matcher.cpp:495-608)
+  // csm: the csm_* members of NDTMatcherParameters (ndt_slam_parameters.h:76-83).
+  double estimateTransformGlobalBNB(SE2d& trans, const Map& fixed_ndt, Map& moving_ndt, bool use_intensity_as_dimension, double scale,
+                                    double search_window_size_linear, double search_window_size_angular,
+                                    const randt_bnb_params& csm) const {
+    randt_matcher_params mp;
+    randt_matcher_params_default(&mp);
+    mp.loss_alpha = parameters_.loss_function_convexity;
+    mp.lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
+    mp.use_intensity = use_intensity_as_dimension ? 1 : 0;
+    double min_cost = 0.0;
+    const int rc = randt_search_global(fixed_ndt.context()->get(), fixed_ndt.handle(), 0, moving_ndt.handle(), 0, &mp, &csm, scale,
+                                       search_window_size_linear, search_window_size_angular, trans.data(), &min_cost, nullptr);
+    if (rc != RANDT_OK) std::cout << "WARNING: global search failed: " << randt_status_string(rc) << std::endl;
+    return min_cost;
   }
 
   void resetMatcher() { imu_constraints_.clear(); }  // ndt_matcher.cpp:18-20

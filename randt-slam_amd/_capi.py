@@ -117,6 +117,7 @@ SYMBOLS = {
     "randt_search_global": (_I, [_V, _V, _I, _V, _I, _P(MatcherParams), _P(BnbParams), C.c_double, C.c_double, C.c_double, _V,
                                  _P(C.c_double), _P(_I)]),
     "randt_cs_divergence_batch_dev": (_I, [_V, _V, _I, _I, _V, _V, _I, _I, _V, _V, _V]),
+    "randt_cs_divergence": (_I, [_V, _V, _I, _V, _I, _V, _V, _V]),
     "randt_filter_scan_batch_dev": (_I, [_V, _V, _I, _I, _I, _I, _I, _P(FilterParams), _V, _I, _V, _V, _V, _V, _V]),
     "randt_sc_make_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ScParams), _V, _V, _V]),
     "randt_sc_detect_batch_dev": (_I, [_V, _P(ScParams), _V, _V, _V, _V, _I, _V, _I, _V, _V, _V]),

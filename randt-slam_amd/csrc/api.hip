@@ -483,6 +483,34 @@ int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int f
                               (double*)ctx->ws, d_out, d_terms);
 }
 
+int randt_cs_divergence(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
+                        const double* h_pose4, double* out, double* h_terms) {
+  if (!ctx || !out || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1)) return RANDT_ERR_INVALID;
+  // device scratch of this call: pose | fixed index | result | terms (kept apart from the workspace the batch entry uses)
+  char* d_blk = nullptr;
+  RANDT_HIP_CHECK(ctx, hipMalloc(&d_blk, 256));
+  double* d_pose = reinterpret_cast<double*>(d_blk);
+  int32_t* d_fi = reinterpret_cast<int32_t*>(d_blk + 64);
+  double* d_out = reinterpret_cast<double*>(d_blk + 128);
+  double* d_terms = d_out + 1;
+  int rc = RANDT_OK;
+  hipError_t e = hipSuccess;
+  if (h_pose4) e = hipMemcpyAsync(d_pose, h_pose4, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_fi, &fixed_idx, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "hipMemcpyAsync", e);
+  if (!rc) rc = randt_cs_divergence_batch_dev(ctx, fixed, fixed_idx, 1, d_fi, moving, moving_idx, 1, h_pose4 ? d_pose : nullptr, d_out, d_terms);
+  if (!rc) {
+    e = hipMemcpyAsync(out, d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && h_terms) e = hipMemcpyAsync(h_terms, d_terms, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "cs divergence read-back", e);
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(d_blk);
+  return rc;
+}
+
 int randt_sc_make_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int points_pitch, const int32_t* d_n_points,
                             int stride_floats, int intensity_index, const randt_sc_params* p, double* d_desc, double* d_ring_keys,
                             double* d_sector_keys) {

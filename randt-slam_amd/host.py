@@ -333,6 +333,15 @@ def cs_divergence_batch(ctx, fixed, fixed_first, fixed_count, fixed_idx, moving,
                "randt_cs_divergence_batch_dev")
 
 
+def cs_divergence(ctx, fixed, fixed_idx, moving, moving_idx, pose4=None):
+    """randt_cs_divergence: one pair, host result.  Returns (divergence, terms[3])."""
+    out, terms = C.c_double(0), np.zeros(3)
+    p = None if pose4 is None else np.ascontiguousarray(pose4, dtype=np.float64)
+    ctx._check(ctx._lib.randt_cs_divergence(ctx._h, fixed._h, int(fixed_idx), moving._h, int(moving_idx),
+                                            None if p is None else p.ctypes.data, C.byref(out), terms.ctypes.data), "randt_cs_divergence")
+    return out.value, terms
+
+
 # ------------------------------------------------------------------ Scan Context (f-4) --------------
 def sc_params(num_ring=20, num_sector=45, max_radius=15.0, num_exclude_recent=15, num_candidates=10, search_ratio=0.3,
               dist_thresh=0.6, assumed_drift=0.05, odom_eps=1.2, odom_weight=0.2, intensity_factor=0.04):

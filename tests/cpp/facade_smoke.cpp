@@ -95,6 +95,39 @@ int main() {
     randt_maps_destroy(fixed_batch);
     randt_maps_destroy(scan_batch);
   }
+  // loop-closure gate and global search through the facade (local_fuser.cpp:338-339, :370-386).  The reference skips
+  // cells with det(cov) < 1e-5 (ndt_map.cpp:47), so the gate gets broader blobs than the registration scene.
+  bool gate_ok = true;
+  {
+    std::normal_distribution<float> wide(0.f, 0.15f), inoise(0.f, 2.f);
+    std::vector<float> pa, pb;
+    for (int b = 0; b < 40; ++b) {
+      const float ang = 6.2831853f * b / 40.f, rad = 5.f + 3.f * ((b * 7) % 5) / 5.f;
+      const float cx = rad * std::cos(ang) + 0.25f, cy = rad * std::sin(ang) + 0.25f, I0 = 20.f + (b * 13) % 60;
+      for (int k = 0; k < 30; ++k) {
+        pa.insert(pa.end(), {cx + wide(rng), cy + wide(rng), 0.f, I0 + inoise(rng)});
+        pb.insert(pb.end(), {cx + wide(rng), cy + wide(rng), 0.f, I0 + inoise(rng)});
+      }
+    }
+    Map fa, fb, sub2;
+    fa.initialize(ctx, mp, 0.0, 0.0, 512);
+    fb.initialize(ctx, mp, 0.0, 0.0, 512);
+    sub2.initialize(ctx, mp, 0.0, 0.0);
+    fa.addScan(pa.data(), (int)pa.size() / 4, 4, 3, rp);
+    fb.addScan(pb.data(), (int)pb.size() / 4, 4, 3, rp);
+    sub2.mergeMapCell(fa);
+    const double cs_good = sub2.calculateCSDivergence(fb);   // same place
+    Map off = fb;                                            // value copy, then transformMap like :338
+    off.transformMap(SE2d(0.6, 1.5, -1.0));
+    const double cs_bad = sub2.calculateCSDivergence(off);
+    randt_bnb_params csm{4.5, 0.45, 0.4, 1e9, 4.0, 2, 0};
+    SE2d g(0.0, 0.0, 0.0);
+    const double bnb_cost = matcher.estimateTransformGlobalBNB(g, submap, scan_b, true, 1.5, 1.0, 0.3, csm);
+    std::printf("cs divergence aligned %.4f vs displaced %.4f; global search -> %.3f %.3f %.3f (cost %.4f)\n", cs_good, cs_bad, g.d[2],
+                g.d[3], g.angle(), bnb_cost);
+    // the correlative search is a coarse grid (0.1 m / finest level) over correspondences frozen at the guess
+    gate_ok = cs_good < cs_bad && bnb_cost < 1e5 && std::fabs(g.d[2] - 0.3) < 0.5 && std::fabs(g.d[3] + 0.2) < 0.5 && std::fabs(g.angle() - 0.1) < 0.2;
+  }
   // loop-closure candidates through the SCManager mirror: 20 keyframes on a line, the last one back at keyframe 2
   bool sc_ok = true;
   {
@@ -115,5 +148,5 @@ int main() {
     std::printf("scan context: %d nodes, query 19 -> %d (yaw %.3f)\n", sc.size(), hit.first, hit.second);
     sc_ok = sc.size() == 20 && early.first == -1 && hit.first == 2;
   }
-  return (ok && kept && win_ok && sc_ok) ? 0 : 2;
+  return (ok && kept && win_ok && sc_ok && gate_ok) ? 0 : 2;
 }

@@ -57,3 +57,7 @@ def test_hip_cs_divergence_matches_oracle(built):
         v, t = po.cs_divergence(osub[rig.prob["submap_of"][i]], m)
         assert np.allclose(terms[i], t, rtol=1e-10), (i, terms[i], t)     # same fp32 pair terms, different fp64 summation order
         assert np.isclose(out[i], v, rtol=1e-10, atol=1e-10)
+    # the one-pair host entry point (Map::calculateCSDivergence as detectLoopClosures calls it) gives the batch's numbers
+    for i in (0, rig.B - 1):
+        v1, t1 = host.cs_divergence(rig.ctx, rig.submaps, int(rig.prob["submap_of"][i]), rig.scan_maps, i, poses[i])
+        assert v1 == out[i] and np.array_equal(t1, terms[i])
