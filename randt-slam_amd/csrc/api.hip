@@ -146,6 +146,7 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
 int randt_ctx_destroy(randt_ctx* ctx) {
   if (!ctx) return RANDT_OK;
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->build_ws) (void)hipFree(ctx->build_ws);
   delete ctx;
   return RANDT_OK;
 }

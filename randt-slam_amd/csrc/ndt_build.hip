@@ -46,7 +46,7 @@ __device__ __forceinline__ int32_t point_label(float x, float y, int row_size, f
 // Per-cluster cell statistics with one lane per cluster, strictly in cluster order: the reference
 // arithmetic spelled out once.  Used for the rare case where a cluster mean falls outside the map
 // (the compact cell index of every later cluster then shifts), after the fast path below.
-__device__ void cluster_stats_sequential(const float* sx, const float* sy, const float* si, const int* cstart, int nc,
+__device__ void cluster_stats_sequential(const float* sx, const float* sy, const float* si, const uint16_t* cstart, int nc,
                                          const MapView& out, randt_cell* cells, int32_t* grid, int* scratch, int* n_cells_out) {
   const int tid = threadIdx.x;
   int n_cells = 0;
@@ -131,24 +131,45 @@ template <bool REG>
 __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restrict__ pts, int pitch,
                                                            const int32_t* __restrict__ n_pts_arr, int stride,
                                                            int ioff, int row_size, float resolution, MapView out,
-                                                           int first_map, int npad, int nb_cap, int aux_bytes) {
+                                                           int first_map, int npad, int nb_cap, int aux_bytes,
+                                                           int32_t* __restrict__ fallback_ws) {
   constexpr int PPT = 8;
   constexpr bool KEEP = REG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // points in labelClouds order; the three arrays are shifted by 16 banks against each other because the
-  // lanes of a cluster group read x[j], y[j] and i[j] in the same instruction
+  // lanes of a cluster group read x[j], y[j] and i[j] in the same instruction.
+  // REG  : [ sx | sy | si  ==  bins ] | cstart u16 | order u16 | pre u16 | scratch        (37 KB at N = 2048: 4 per CU)
+  //        the label bins are dead once every point knows its final position (kept in registers), so the sorted
+  //        points are scattered over them;
+  // !REG : sx | sy | si | cstart u16 | bins | scratch | per-point words (order / pre alias them after the placement).
   float* sx = reinterpret_cast<float*>(smem);
   float* sy = sx + npad + 16;
   float* si = sy + npad + 16;
-  int* cstart = reinterpret_cast<int*>(si + npad + 16);                       // [npad + 1] (+1 pad)
-  unsigned long long* bins = reinterpret_cast<unsigned long long*>(cstart + npad + 2);
-  int* scratch = reinterpret_cast<int*>(reinterpret_cast<char*>(bins) + aux_bytes);  // [64]
-  int32_t* plab = scratch + 64;  // !REG: per-point word [npad] (label, later bin | rank)
-  // re-used regions: the fallback's label array and, after the placement, the cluster order + index prefix
-  // (2 x u16 per cluster) alias the bins (REG) or the per-point words (!REG)
-  int32_t* lab = REG ? reinterpret_cast<int32_t*>(bins) : plab;
-  uint16_t* order = reinterpret_cast<uint16_t*>(lab);
-  uint16_t* pre = order + npad;
+  char* after_pts = reinterpret_cast<char*>(si + npad + 16);
+  const int cstart_bytes = ((npad + 2) * 2 + 15) & ~15;
+  uint16_t* cstart;
+  unsigned long long* bins;
+  int* scratch;
+  int32_t* plab = nullptr;
+  uint16_t *order, *pre;
+  if (REG) {
+    bins = reinterpret_cast<unsigned long long*>(smem);
+    char* p = smem + aux_bytes;  // aux_bytes = max(points, bins)
+    cstart = reinterpret_cast<uint16_t*>(p);
+    order = reinterpret_cast<uint16_t*>(p + cstart_bytes);
+    pre = order + npad;
+    scratch = reinterpret_cast<int*>(pre + npad);
+  } else {
+    cstart = reinterpret_cast<uint16_t*>(after_pts);
+    bins = reinterpret_cast<unsigned long long*>(after_pts + cstart_bytes);
+    scratch = reinterpret_cast<int*>(reinterpret_cast<char*>(bins) + aux_bytes);  // [64]
+    plab = scratch + 64;  // per-point word [npad] (label, later bin | rank)
+    order = reinterpret_cast<uint16_t*>(plab);
+    pre = order + npad;
+  }
+  // fallback only: unsorted / sorted labels in global memory (rare path, 2 x npad words per scan)
+  int32_t* lab = fallback_ws + (size_t)blockIdx.x * 2 * npad;
+  int32_t* slab = lab + npad;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scan = blockIdx.x;
@@ -286,16 +307,18 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       const int c0 = (int)(c & 0xffff), c1 = (int)((c >> 16) & 0xffff), c2 = (int)((c >> 32) & 0xffff), c3 = (int)((c >> 48) & 0xffff);
       const int tot = c0 + c1 + c2 + c3;
       const int start = run >> 16;
-      if (tot > 0) cstart[run & 0xffff] = start;
+      if (tot > 0) cstart[run & 0xffff] = (uint16_t)start;
       // packed start positions of the four waves inside this bin
       bins[b] = (unsigned long long)start | ((unsigned long long)(start + c0) << 16) |
                 ((unsigned long long)(start + c0 + c1) << 32) | ((unsigned long long)(start + c0 + c1 + c2) << 48);
       run += (tot << 16) | (tot > 0 ? 1 : 0);
     }
-    if (tid == 0) cstart[nc] = n;
+    if (tid == 0) cstart[nc] = (uint16_t)n;
     __syncthreads();
     RANDT_TICK(4);
-    // ---- placement: position = start of (bin, wave) + rank inside it
+    // ---- placement: position = start of (bin, wave) + rank inside it.  REG: all positions are taken first (the
+    // bins are read for the last time), then the points are scattered over the bins' storage.
+    int ppos[REG ? PPT : 1];
 #pragma unroll 8
     for (int j = 0; j < nsteps; ++j) {
       const int i = w_beg + 64 * j + lane;
@@ -303,17 +326,28 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
         const int word = RANDT_PL(j, i);
         const int b = word & 0xffff, r = (int)((unsigned)word >> 16);
         const int pos = (int)((bins[b] >> sh) & 0xffff) + r;
-        float x, y, in;
-        if (KEEP) {
-          x = px[j];
-          y = py[j];
-          in = pin[j];
+        if (REG) {
+          ppos[REG ? j : 0] = pos;
         } else {
+          float x, y, in;
           RANDT_FETCH_POINT(i, x, y, in);
+          sx[pos] = x;
+          sy[pos] = y;
+          si[pos] = in;
         }
-        sx[pos] = x;
-        sy[pos] = y;
-        si[pos] = in;
+      }
+    }
+    if (REG) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        const int i = w_beg + 64 * j + lane;
+        if (i < w_end) {
+          const int pos = ppos[REG ? j : 0];
+          sx[pos] = px[KEEP ? j : 0];
+          sy[pos] = py[KEEP ? j : 0];
+          si[pos] = pin[KEEP ? j : 0];
+        }
       }
     }
     __syncthreads();
@@ -337,20 +371,17 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       sx[rank] = x;
       sy[rank] = y;
       si[rank] = in;
-      cstart[rank] = li;  // sorted labels, parked in cstart until the heads are known
+      slab[rank] = li;  // sorted labels
     }
-    __syncthreads();
-    // cluster heads from the sorted labels (cstart[] is rewritten in place, so park the sorted labels in lab[])
-    for (int p = tid; p < n; p += BUILD_BLOCK) lab[p] = cstart[p];
-    __syncthreads();
+    __syncthreads();  // (workgroup-scope fence: the global writes above are visible to the whole workgroup)
     const int chunk = (n + BUILD_BLOCK - 1) / BUILD_BLOCK;
     const int b0 = tid * chunk, b1 = (b0 + chunk) < n ? (b0 + chunk) : n;
     int heads = 0;
-    for (int p = b0; p < b1; ++p) heads += (p == 0 || lab[p] != lab[p - 1]) ? 1 : 0;
+    for (int p = b0; p < b1; ++p) heads += (p == 0 || slab[p] != slab[p - 1]) ? 1 : 0;
     int cbase = block_exclusive_scan_256(heads, scratch, &nc);
     for (int p = b0; p < b1; ++p)
-      if (p == 0 || lab[p] != lab[p - 1]) cstart[cbase++] = p;
-    if (tid == 0) cstart[nc] = n;
+      if (p == 0 || slab[p] != slab[p - 1]) cstart[cbase++] = (uint16_t)p;
+    if (tid == 0) cstart[nc] = (uint16_t)n;
     __syncthreads();
   }
 
@@ -619,31 +650,58 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   const float resolution = cp->max_range * 2 / (float)row_size;
   const bool reg = pitch <= 2048;  // 8 points per lane in registers
   // label bins: coordinates inside +-max_range (what RadarPreprocessor hands over) in fast mode: int(x/res) and
-  // int(y/res) in [-row/2, row/2]; anything wider takes the fallback
-  const size_t fixed_bytes = (size_t)npad * 12 + 192 + (size_t)(npad + 2) * 4 + 256 + (reg ? 0 : (size_t)npad * 4);
-  // aux region: label bins (8 B each) during the sort, then order + index prefix (2 x u16 per cluster);
-  // the fallback parks the labels there (4 B per point)
-  const size_t aux_min = reg ? (size_t)npad * 4 : 64;
+  // int(y/res) in [-row/2, row/2]; anything wider takes the fallback (labels in the global scratch)
   int nb_want = row_size * row_size + 2 * row_size + 2;
   if (nb_want > 65535) nb_want = 65535;  // bin index is packed into 16 bits
-  // smallest occupancy tier (3, 2, 1 workgroups per CU) that holds all the bins
-  const size_t want = fixed_bytes + ((size_t)nb_want * 8 > aux_min ? (size_t)nb_want * 8 : aux_min) + 16;
-  size_t budget = (size_t)ctx->lds_limit / 3;
-  if (want > budget) budget = (size_t)ctx->lds_limit / 2;
-  if (want > budget) budget = (size_t)ctx->lds_limit;
-  if (fixed_bytes + aux_min + 1024 > budget) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel", hipSuccess);
-  const size_t room = (budget - fixed_bytes - 16) / 8;
-  const int nb_cap = (int)((size_t)nb_want < room ? (size_t)nb_want : room);
-  size_t aux = (size_t)nb_cap * 8;
-  if (aux < aux_min) aux = aux_min;
-  aux = (aux + 15) & ~(size_t)15;
-  const size_t lds = fixed_bytes + aux;
+  const size_t pts_bytes = (size_t)npad * 12 + 192;
+  const size_t cstart_bytes = (((size_t)npad + 2) * 2 + 15) & ~(size_t)15;
+  size_t lds, aux;
+  int nb_cap;
+  if (reg) {
+    // [points == bins] | cstart | order + pre | scratch
+    const size_t tail = cstart_bytes + (size_t)npad * 4 + 256;
+    size_t budget = (size_t)ctx->lds_limit / 4;
+    if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit / 3;
+    if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit / 2;
+    if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit;
+    if (tail + pts_bytes + 1024 > budget) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel", hipSuccess);
+    const size_t room = (budget - tail) / 8;
+    nb_cap = (int)((size_t)nb_want < room ? (size_t)nb_want : room);
+    aux = (size_t)nb_cap * 8 > pts_bytes ? (size_t)nb_cap * 8 : pts_bytes;
+    aux = (aux + 15) & ~(size_t)15;
+    lds = aux + tail;
+  } else {
+    // points | cstart | bins | scratch | per-point words
+    const size_t fixed_bytes = pts_bytes + cstart_bytes + 256 + (size_t)npad * 4;
+    size_t budget = (size_t)ctx->lds_limit / 2;
+    if (fixed_bytes + (size_t)nb_want * 8 + 16 > budget) budget = (size_t)ctx->lds_limit;
+    if (fixed_bytes + 1024 > budget) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel", hipSuccess);
+    const size_t room = (budget - fixed_bytes - 16) / 8;
+    nb_cap = (int)((size_t)nb_want < room ? (size_t)nb_want : room);
+    aux = ((size_t)nb_cap * 8 + 15) & ~(size_t)15;
+    lds = fixed_bytes + aux;
+  }
+  // fallback scratch: 2 x npad label words per scan
+  {
+    const size_t want = sizeof(int32_t) * 2 * (size_t)npad * n_scans + 256;
+    if (want > ctx->build_ws_bytes) {
+      if (ctx->build_ws) {
+        RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        RANDT_HIP_CHECK(ctx, hipFree(ctx->build_ws));
+        ctx->build_ws = nullptr;
+        ctx->build_ws_bytes = 0;
+      }
+      RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->build_ws, want + want / 4));
+      ctx->build_ws_bytes = want + want / 4;
+    }
+  }
+  int32_t* d_fallback = reinterpret_cast<int32_t*>(ctx->build_ws);
 #define RANDT_BUILD_LAUNCH(REG)                                                                                            \
   do {                                                                                                                     \
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<REG>),                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
     hipLaunchKernelGGL((k_ndt_build<REG>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,            \
-                       d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux);            \
+                       d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux, d_fallback);            \
   } while (0)
   if (reg) RANDT_BUILD_LAUNCH(true);
   else RANDT_BUILD_LAUNCH(false);

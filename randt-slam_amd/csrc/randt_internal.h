@@ -29,6 +29,8 @@ struct randt_ctx {
   // scratch (grown on demand, never inside a timed region after warm-up)
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  void* build_ws = nullptr;  // label scratch of k_ndt_build's fallback sort (its own buffer: callers stage points in ws)
+  size_t build_ws_bytes = 0;
   double* d_trace = nullptr;
   int trace_len = 0;
   int lds_limit = 160 * 1024;
