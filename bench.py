@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # vector fp64 (half the 157.3 TF fp32 vector rate)
 # HBM bytes of one 512-registration step measured with PMC counters (profiles/r01_pmc_summary.csv):
 # FETCH_SIZE KB x2 (gfx950 correction) of k_ndt_build + k_associate + k_solve, plus their WRITE_SIZE KB
-PMC_TRAFFIC_BYTES_PER_STEP = int(((8155.1 + 2085.4 + 1842.9) * 2 + (1834.9 + 609.2 + 48.0)) * 1024)  # profiles/r01_e_pmc_summary.csv
+PMC_TRAFFIC_BYTES_PER_STEP = int(((8156.6 + 2082.4 + 1835.4) * 2 + (1834.9 + 609.2 + 48.0)) * 1024)  # profiles/r01_f_pmc_summary.csv
 
 
 def algorithmic_bytes(n_points, n_slots, m_cells, k):
@@ -228,7 +228,7 @@ def main():
                                    "note": "SURVEY 8(d) definition: registrations/s x algorithmic bytes (batches overlap on %d streams)" % n_streams},
                 "traffic_note": "HBM bytes per step (the three launches) from separate rocprofv3 --pmc passes, FETCH_SIZE x2 "
                                 "(gfx950 correction, calibrated on k_ndt_build / k_filter_peaks whose byte counts are known) + "
-                                "WRITE_SIZE, profiles/r01_e_pmc_summary.csv; ~10x BELOW the algorithmic bytes because the compact "
+                                "WRITE_SIZE, profiles/r01_f_pmc_summary.csv; ~10x BELOW the algorithmic bytes because the compact "
                                 "cell tables never touch the empty slots of the dense submap grid",
                 "note": "path is fp64-VALU / iteration-latency bound (SURVEY 8(d)); see roofline_fp64",
             },
