@@ -264,3 +264,42 @@ def test_association_on_a_map_narrower_than_the_window(env):
     got, want, nm, nf = _assoc_both(env, fixed, moving, mapp, (2304, 24.0), 5)
     assert nm > 3 and nf > 3
     assert np.array_equal(got, want)
+
+
+def test_error_convention_status_codes_not_exceptions(env):
+    """the ABI never throws and never falls back: bad arguments -> RANDT_ERR_INVALID, sizes beyond the kernels ->
+    RANDT_ERR_UNSUPPORTED with a message, outputs untouched (SURVEY 8(b) error convention)."""
+    import ctypes as C
+
+    torch, dev, ctx = env
+    lib = R._capi.load()
+    mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
+    maps = R.Maps(ctx, 2, mapp, 512, with_grid=True)
+    pts = torch.from_numpy(_scan(1001)[None]).to(dev)
+    # null / out-of-range arguments
+    assert lib.randt_ndt_build_batch_dev(ctx._h, None, 1, 2000, None, 4, 3, C.byref(clu), maps._h, 0) == 1
+    assert lib.randt_ndt_build_batch_dev(ctx._h, pts.data_ptr(), 3, 2000, None, 4, 3, C.byref(clu), maps._h, 0) == 1   # 3 scans into 2 maps
+    assert lib.randt_ndt_build_batch_dev(ctx._h, pts.data_ptr(), 1, 2000, None, 4, 7, C.byref(clu), maps._h, 0) == 1   # intensity index >= stride
+    # association limits: k > 8 and a window radius beyond 7
+    R.ndt_build_batch(ctx, pts, clu, maps)
+    mp = R.default_matcher_params(n_neighbours=9)
+    guess = torch.tensor([[1.0, 0, 0, 0]], dtype=torch.float64, device=dev)
+    corr = torch.full((1, 512, 9), -5, dtype=torch.int32, device=dev)
+    fidx = torch.zeros(1, dtype=torch.int32, device=dev)
+    with pytest.raises(R.RandtError) as e:
+        R.associate_batch(ctx, maps, fidx, maps, 1, 1, guess, mp, corr)
+    assert e.value.status == 3 and "n_neighbours" in str(e.value)
+    ctx.synchronize()
+    assert int((corr.cpu() != -5).sum()) == 0                                      # nothing was written
+    far = R.Maps(ctx, 1, R.MapParams(100, 100, 0.5, 0.0, 0.0, 6.0, 5, 0), 512, with_grid=True)   # rmax = 12
+    with pytest.raises(R.RandtError) as e:
+        R.associate_batch(ctx, far, fidx, maps, 1, 1, guess, R.default_matcher_params(), corr[:, :, :4].contiguous())
+    assert e.value.status == 3
+    # a map batch without an index grid cannot be the fixed side
+    nogrid = R.Maps(ctx, 1, mapp, 512, with_grid=False)
+    with pytest.raises(R.RandtError) as e:
+        R.associate_batch(ctx, nogrid, fidx, maps, 1, 1, guess, R.default_matcher_params(), corr[:, :, :4].contiguous())
+    assert e.value.status == 1 and "index grid" in str(e.value)
+    # the context stays usable after errors
+    R.associate_batch(ctx, maps, fidx, maps, 1, 1, guess, R.default_matcher_params(), corr[:, :, :4].contiguous())
+    ctx.synchronize()
