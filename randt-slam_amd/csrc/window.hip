@@ -754,10 +754,10 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
               row[k] = (lane < n && k < n) ? sh.Hs[k * n + lane] : 0.0;
               if (k == lane) row[k] += damp;
             }
-            // at step j only the first n - j columns are still live: four rolled loops of width 32 / 24 / 16 / 8
+            // at step j only the first n - j columns are still live: eight rolled loops of width 32, 28, ... 4
             int j = 0;
 #define RANDT_GJ_STEPS(WIDTH)                                                                          \
-  for (; j < n && n - j > (WIDTH) - 8; ++j) {                                                         \
+  for (; j < n && n - j > (WIDTH) - 4; ++j) {                                                         \
     const double pj = readlane_f64(row[0], j);                                                        \
     if (!(pj > 0.0)) okf = 0.0;                                                                       \
     if (lane == j) dg = pj;                                                                           \
@@ -768,9 +768,13 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
     row[(WIDTH) - 1] = 0.0;                                                                           \
   }
             RANDT_GJ_STEPS(32)
+            RANDT_GJ_STEPS(28)
             RANDT_GJ_STEPS(24)
+            RANDT_GJ_STEPS(20)
             RANDT_GJ_STEPS(16)
+            RANDT_GJ_STEPS(12)
             RANDT_GJ_STEPS(8)
+            RANDT_GJ_STEPS(4)
 #undef RANDT_GJ_STEPS
             if (lane < n) sh.step[lane] = b * fast_rcp(dg);
           }
