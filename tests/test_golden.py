@@ -2,6 +2,7 @@
 the oracle): the oracle must keep reproducing them (CPU), and the HIP path must reproduce them
 through the C ABI without needing the oracle binary (GPU)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -87,3 +88,52 @@ def test_hip_path_reproduces_golden(gold):
             t = trace[i, 1 : 1 + 3 * n].reshape(n, 3)
             assert np.allclose(t[:, 0], gold[f"scan{i}_{name}_trace_cost"], rtol=1e-8)
             assert np.array_equal(t[:, 2].astype(int), gold[f"scan{i}_{name}_trace_flag"])
+
+
+# ------------------------------------------------------------------------------------------------
+# fixed-lag path: tests/golden/odometry_drive.npz (made by tests/golden/make_golden_odometry.py)
+def _odometry_golden():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_odometry as mg
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "odometry_drive.npz"))
+    return mg, z
+
+
+def test_oracle_reproduces_odometry_golden():
+    """the CPU oracle backend through the processScan call pattern still lands on the committed poses (first 16
+    scans keep the CPU suite short); libm differences between machines stay far below the bar"""
+    import randt_slam_amd as R
+    from randt_slam_amd import odometry
+    from oracle_backend import OracleBackend
+
+    mg, z = _odometry_golden()
+    traj, scans = mg.drive_inputs()
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    odo = odometry.Odometry(OracleBackend(), mp, R.window_params(), mg.SMALL)
+    for i in range(16):
+        p = odo.process_scan(scans[i], i * mg.DT)
+        assert np.abs(p - z["poses4"][i]).max() < 1e-8, i
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_odometry_golden(built):
+    """the HIP fixed-lag path against the committed drive (window solve, keyframe merges, one submap roll-over) --
+    no oracle involved"""
+    import torch
+    import randt_slam_amd as R
+    from randt_slam_amd import odometry
+
+    mg, z = _odometry_golden()
+    traj, scans = mg.drive_inputs()
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    odo = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, R.window_params(), mg.SMALL)
+    worst = 0.0
+    for i in range(mg.N_SCANS):
+        p = odo.process_scan(scans[i], i * mg.DT)
+        worst = max(worst, float(np.abs(p - z["poses4"][i]).max()))
+        assert worst <= 1e-4, (i, p, z["poses4"][i])
+        assert int(odo.last_result["iterations"]) == int(z["lm_iterations"][i]) if odo.last_result is not None and z["lm_iterations"][i] > 0 else True
+    assert odo.n_finished_submaps == int(z["submaps_finished"]) and odo.n_registrations == int(z["registrations"])
+    assert worst < 1e-6
