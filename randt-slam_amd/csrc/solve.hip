@@ -297,7 +297,7 @@ __device__ __forceinline__ double ambient_norm(const double* x) {
   constexpr int NA = PARAM == RANDT_PARAM_VECTOR ? 3 : 4;
 #pragma unroll
   for (int i = 0; i < NA; ++i) n += x[i] * x[i];
-  return sqrt(n);
+  return n > 0.0 ? n * fast_rsqrt(n) : 0.0;  // sqrt to ~1 ulp without the IEEE sequence (only feeds the parameter-tolerance test)
 }
 
 // Is ||x - Plus(x, -g)||_inf <= gtol (TrustRegionMinimizer::GradientToleranceReached)?  For the
