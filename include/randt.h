@@ -362,6 +362,44 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
                           const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
                           double h_trans4[4], int* rejected, randt_result* h_result);
 
+/* ------------------------------------------------------------------ pose graph (f-4) */
+/* GlobalFuser::optimizePoseGraph (src/global_fuser/global_fuser.cpp:13-105): 2-D pose graph with
+ * PoseGraph2dErrorTerm residuals (include/global_fuser/pose_graph_2d_error_term.h:33-80), optional
+ * ceres::HuberLoss(loss_function_scale) (:17-23), first pose constant (:48-49), Ceres 2.1.0 trust-region LM.
+ * The reference's SPARSE_NORMAL_CHOLESKY step (:54-57) is computed exactly on the device: block-tridiagonal
+ * Cholesky along the odometry chain, one lane per right-hand side, dense Schur complement on the poses that
+ * loop closures touch (see csrc/posegraph.hip).  The defaults are Ceres' Solver::Options defaults plus
+ * max_num_iterations = 200000 (:52). */
+#define RANDT_PG_MAX_SEPARATORS 2048
+typedef struct randt_pg_params {
+  int32_t use_robust_loss;  /* GlobalFuserParameters::use_robust_loss */
+  int32_t max_iterations;
+  int32_t max_consecutive_invalid_steps;
+  int32_t reserved;
+  double loss_scale;        /* GlobalFuserParameters::loss_function_scale */
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_radius, max_radius, min_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+} randt_pg_params;
+typedef struct randt_pg_result {
+  double initial_cost, final_cost;
+  int32_t iterations;         /* Summary::iterations.size() */
+  int32_t termination;        /* RANDT_TERM_* */
+  int32_t n_residual_blocks;  /* edges that pass the max_update_index rule (:32) */
+  int32_t n_loop_closures;    /* edges.size() + 1 - poses.size(), the count the reference prints (:26) */
+  int32_t n_separator_poses;  /* poses eliminated through the dense Schur complement */
+  int32_t reserved;
+} randt_pg_result;
+void randt_pg_params_default(randt_pg_params* p);
+/* h_poses [n_poses][3] = (pos.x, pos.y, rot) in/out (pose i = key i of the reference's std::map<int, Pose>);
+ * edge e: h_id_begin/h_id_end, h_meas [E][3] = (trans.translation(), trans.log()(2)), h_sqrt_info [E][9]
+ * row-major.  An edge is used iff id_begin + 1 == id_end || id_end <= max_update_index.  Host buffers: the graph
+ * lives on the host in the reference and is a few hundred KB.  RANDT_ERR_UNSUPPORTED if more than
+ * RANDT_PG_MAX_SEPARATORS poses carry loop closures. */
+int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int n_edges, const int32_t* h_id_begin,
+                              const int32_t* h_id_end, const double* h_meas, const double* h_sqrt_info,
+                              int max_update_index, const randt_pg_params* p, randt_pg_result* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,23 @@ STATE_DTYPE = np.dtype([("pose", "<f8", (4,)), ("pos", "<f8", (2,)), ("rot", "<f
 assert STATE_DTYPE.itemsize == C.sizeof(State) == 112
 
 
+class PgParams(C.Structure):
+    _fields_ = [
+        ("use_robust_loss", C.c_int32), ("max_iterations", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
+        ("reserved", C.c_int32), ("loss_scale", C.c_double),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+    ]
+
+
+class PgResult(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("iterations", C.c_int32), ("termination", C.c_int32), ("n_residual_blocks", C.c_int32), ("n_loop_closures", C.c_int32),
+    ]
+
+
 def build(force=False):
     src = os.path.join(_HERE, "randt_oracle.c")
     hdr = os.path.join(_HERE, "randt_oracle.h")
@@ -165,6 +182,11 @@ def lib():
     L.orc_register_window.restype = C.c_int
     L.orc_register_window.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, P(MatcherParams),
                                       P(WindowParams), C.c_void_p, P(SolveStats)]
+    L.orc_pg_params_default.argtypes = [P(PgParams)]
+    L.orc_pg_edge.argtypes = [C.c_void_p] * 7
+    L.orc_pose_graph_optimize.restype = C.c_int
+    L.orc_pose_graph_optimize.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          P(PgParams), P(PgResult)]
     _lib = L
     return L
 
@@ -535,3 +557,38 @@ def search_global_bnb(fixed, moving, params, bp, trans4, scale=1.5, window_linea
     n = C.c_int(0)
     mc = lib().orc_search_global_bnb(fixed._p, moving._p, C.byref(params), C.byref(bp), scale, window_linear, window_angular, _ptr(t), C.byref(n))
     return mc, t, n.value
+
+
+def pg_params(**over):
+    p = PgParams()
+    lib().orc_pg_params_default(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def pg_edge(pose_a, pose_b, meas, sqrt_info):
+    a = np.ascontiguousarray(pose_a, np.float64)
+    b = np.ascontiguousarray(pose_b, np.float64)
+    m = np.ascontiguousarray(meas, np.float64)
+    sq = np.ascontiguousarray(sqrt_info, np.float64).reshape(9)
+    r, Ja, Jb = np.zeros(3), np.zeros(9), np.zeros(9)
+    lib().orc_pg_edge(_ptr(a), _ptr(b), _ptr(m), _ptr(sq), _ptr(r), _ptr(Ja), _ptr(Jb))
+    return r, Ja.reshape(3, 3), Jb.reshape(3, 3)
+
+
+def pose_graph_optimize(poses, id_begin, id_end, meas, sqrt_info, max_update_index, params=None):
+    """poses [N][3] (x, y, yaw); returns (optimised copy, result dict)."""
+    x = np.array(poses, np.float64, order="C").reshape(-1, 3)
+    ia = np.ascontiguousarray(id_begin, np.int32)
+    ib = np.ascontiguousarray(id_end, np.int32)
+    m = np.ascontiguousarray(meas, np.float64).reshape(-1, 3)
+    sq = np.ascontiguousarray(sqrt_info, np.float64).reshape(-1, 9)
+    assert len(ia) == len(ib) == len(m) == len(sq)
+    p = params if params is not None else pg_params()
+    res = PgResult()
+    rc = lib().orc_pose_graph_optimize(len(x), _ptr(x), len(ia), _ptr(ia), _ptr(ib), _ptr(m), _ptr(sq), int(max_update_index),
+                                       C.byref(p), C.byref(res))
+    if rc != 0:
+        raise ValueError("orc_pose_graph_optimize: invalid graph")
+    return x, {k: getattr(res, k) for k, _ in PgResult._fields_}

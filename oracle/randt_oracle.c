@@ -2168,3 +2168,310 @@ int orc_sc_detect(const orc_sc_params* p, const double* desc, const double* ring
   if (yaw) *yaw = (float)((float)(nn_align * (360.0 / (double)S)) * M_PI / 180.0);
   return min_d < p->dist_thresh ? nn_idx : -1;
 }
+
+/* ============================================================ f-4: pose graph ================= */
+
+void orc_pg_params_default(orc_pg_params* p) {
+  memset(p, 0, sizeof(*p));
+  p->use_robust_loss = 0;  /* every shipped config (parameters_*.yaml global_fuser.use_robust_loss: false) */
+  p->loss_scale = 60.0;
+  p->max_iterations = 200000; /* global_fuser.cpp:52 */
+  p->max_consecutive_invalid_steps = 5;
+  p->function_tolerance = 1e-6;
+  p->gradient_tolerance = 1e-10;
+  p->parameter_tolerance = 1e-8;
+  p->initial_radius = 1e4;
+  p->max_radius = 1e16;
+  p->min_radius = 1e-32;
+  p->min_relative_decrease = 1e-3;
+  p->min_lm_diagonal = 1e-6;
+  p->max_lm_diagonal = 1e32;
+}
+
+/* state_manifold.h:17-23 */
+static double pg_normalize_angle(double a) {
+  const double two_pi = 2.0 * M_PI;
+  return a - two_pi * floor((a + M_PI) / two_pi);
+}
+
+/* pose_graph_2d_error_term.h:44-60; the autodiff Jacobian written out: d/dyaw_a of R(yaw_a)^T v = [[-s, c], [-c, -s]] v,
+ * floor() has derivative zero so the angle row is (-1, +1). */
+void orc_pg_edge(const double pa[3], const double pb[3], const double meas[3], const double sqi[9], double r[3], double Ja[9],
+                 double Jb[9]) {
+  const double c = cos(pa[2]), s = sin(pa[2]);
+  const double dx = pb[0] - pa[0], dy = pb[1] - pa[1];
+  double e[3], A[9], B[9];
+  e[0] = (c * dx + s * dy) - meas[0];
+  e[1] = (-s * dx + c * dy) - meas[1];
+  e[2] = pg_normalize_angle((pb[2] - pa[2]) - meas[2]);
+  /* unweighted Jacobians, row-major 3x3 */
+  A[0] = -c; A[1] = -s; A[2] = -s * dx + c * dy;
+  A[3] = s;  A[4] = -c; A[5] = -c * dx - s * dy;
+  A[6] = 0;  A[7] = 0;  A[8] = -1.0;
+  B[0] = c;  B[1] = s;  B[2] = 0;
+  B[3] = -s; B[4] = c;  B[5] = 0;
+  B[6] = 0;  B[7] = 0;  B[8] = 1.0;
+  for (int i = 0; i < 3; ++i) {
+    r[i] = sqi[i * 3 + 0] * e[0] + sqi[i * 3 + 1] * e[1] + sqi[i * 3 + 2] * e[2];
+    for (int j = 0; j < 3; ++j) {
+      Ja[i * 3 + j] = sqi[i * 3 + 0] * A[0 + j] + sqi[i * 3 + 1] * A[3 + j] + sqi[i * 3 + 2] * A[6 + j];
+      Jb[i * 3 + j] = sqi[i * 3 + 0] * B[0 + j] + sqi[i * 3 + 1] * B[3 + j] + sqi[i * 3 + 2] * B[6 + j];
+    }
+  }
+}
+
+typedef struct pg_problem {
+  int n_poses, n_used;
+  const int32_t* ia;  /* per used edge */
+  const int32_t* ib;
+  const double* meas; /* [n_used][3] */
+  const double* sqi;  /* [n_used][9] */
+  int robust;
+  double huber_a;
+  const int32_t* var; /* pose -> first tangent index, or -1 (constant / not in the problem) */
+  int nt;
+} pg_problem;
+
+/* cost = sum 1/2 rho(|r|^2); r / Ja / Jb are the loss-corrected ones (corrector.cc with rho'' <= 0: scale by sqrt(rho')) */
+static double pg_eval(const pg_problem* P, const double* poses, double* r, double* Ja, double* Jb) {
+  double cost = 0.0;
+  for (int e = 0; e < P->n_used; ++e) {
+    double re[3], A[9], B[9];
+    orc_pg_edge(poses + 3 * P->ia[e], poses + 3 * P->ib[e], P->meas + 3 * e, P->sqi + 9 * e, re, A, B);
+    const double s = re[0] * re[0] + re[1] * re[1] + re[2] * re[2];
+    double rho0 = s, rho1 = 1.0;
+    if (P->robust) {
+      const double b = P->huber_a * P->huber_a; /* HuberLoss: b_ = a * a */
+      if (s > b) {
+        const double rr = sqrt(s);
+        rho0 = 2.0 * P->huber_a * rr - b;
+        rho1 = fmax(DBL_MIN, P->huber_a / rr);
+      }
+    }
+    cost += 0.5 * rho0;
+    if (r) {
+      const double w = sqrt(rho1);
+      for (int i = 0; i < 3; ++i) r[3 * e + i] = re[i] * w;
+      for (int i = 0; i < 9; ++i) {
+        Ja[9 * e + i] = A[i] * w;
+        Jb[9 * e + i] = B[i] * w;
+      }
+    }
+  }
+  return cost;
+}
+
+int orc_pose_graph_optimize(int n_poses, double* poses, int n_edges, const int32_t* id_begin, const int32_t* id_end,
+                            const double* meas, const double* sqrt_info, int max_update_index, const orc_pg_params* opt,
+                            orc_pg_result* out) {
+  if (n_poses <= 0 || n_edges < 0) return -1;
+  int32_t* ia = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_edges + 1));
+  int32_t* ib = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_edges + 1));
+  double* um = (double*)malloc(sizeof(double) * 3 * (size_t)(n_edges + 1));
+  double* us = (double*)malloc(sizeof(double) * 9 * (size_t)(n_edges + 1));
+  int32_t* var = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_poses);
+  for (int i = 0; i < n_poses; ++i) var[i] = -2; /* -2 = not referenced */
+  int nu = 0, bad = 0;
+  for (int e = 0; e < n_edges; ++e) {
+    const int a = id_begin[e], b = id_end[e];
+    if (!(a + 1 == b || b <= max_update_index)) continue; /* global_fuser.cpp:32 */
+    if (a < 0 || b < 0 || a >= n_poses || b >= n_poses || a == b) { bad = 1; break; }
+    ia[nu] = a; ib[nu] = b;
+    memcpy(um + 3 * nu, meas + 3 * e, sizeof(double) * 3);
+    memcpy(us + 9 * nu, sqrt_info + 9 * e, sizeof(double) * 9);
+    var[a] = var[b] = -1;
+    ++nu;
+  }
+  int nt = 0;
+  if (!bad) {
+    for (int i = 1; i < n_poses; ++i) /* pose 0 = poses.begin(): SetParameterBlockConstant (:48-49) */
+      if (var[i] == -1) { var[i] = nt; nt += 3; }
+    var[0] = -1;
+    for (int i = 1; i < n_poses; ++i) if (var[i] == -2) var[i] = -1;
+  }
+  if (out) {
+    memset(out, 0, sizeof(*out));
+    out->n_residual_blocks = nu;
+    out->n_loop_closures = n_edges + 1 - n_poses; /* :26 */
+  }
+  if (bad || nu == 0 || nt == 0) {
+    free(ia); free(ib); free(um); free(us); free(var);
+    return bad ? -1 : 0;
+  }
+  pg_problem P = {n_poses, nu, ia, ib, um, us, opt->use_robust_loss, opt->loss_scale, var, nt};
+
+  double* x = (double*)malloc(sizeof(double) * 3 * (size_t)n_poses);
+  double* cand = (double*)malloc(sizeof(double) * 3 * (size_t)n_poses);
+  double* best = (double*)malloc(sizeof(double) * 3 * (size_t)n_poses);
+  double* r = (double*)malloc(sizeof(double) * 3 * (size_t)nu);
+  double* Ja = (double*)malloc(sizeof(double) * 9 * (size_t)nu);
+  double* Jb = (double*)malloc(sizeof(double) * 9 * (size_t)nu);
+  double* H = (double*)malloc(sizeof(double) * (size_t)nt * nt);
+  double* Hw = (double*)malloc(sizeof(double) * (size_t)nt * nt);
+  double* g = (double*)malloc(sizeof(double) * (size_t)nt);
+  double* gw = (double*)malloc(sizeof(double) * (size_t)nt);
+  double* scaling = (double*)malloc(sizeof(double) * (size_t)nt);
+  double* diagonal = (double*)malloc(sizeof(double) * (size_t)nt);
+  double* step = (double*)malloc(sizeof(double) * (size_t)nt);
+  double* delta = (double*)malloc(sizeof(double) * (size_t)nt);
+  memcpy(x, poses, sizeof(double) * 3 * (size_t)n_poses);
+  memcpy(best, poses, sizeof(double) * 3 * (size_t)n_poses);
+
+  int term = ORC_TERM_FAILURE;
+  double x_cost = 0, x_norm = 0, cand_cost = 0, grad_max_norm = 0;
+  double radius = opt->initial_radius, decrease_factor = 2.0;
+  int reuse_diagonal = 0, num_invalid = 0, iteration = 0, step_successful = 1, n_it = 0;
+  double minimum_cost = DBL_MAX, summary_min_cost;
+
+  /* gradient, Jacobi scaling (first call), scaled J^T J (dense, tangent order = ascending pose id) */
+#define PG_LINEARIZE(FIRST)                                                                               \
+  do {                                                                                                    \
+    x_cost = pg_eval(&P, x, r, Ja, Jb);                                                                   \
+    memset(H, 0, sizeof(double) * (size_t)nt * nt);                                                       \
+    memset(g, 0, sizeof(double) * (size_t)nt);                                                            \
+    for (int e = 0; e < nu; ++e) {                                                                        \
+      const int va = var[ia[e]], vb = var[ib[e]];                                                         \
+      const double* A = Ja + 9 * e;                                                                       \
+      const double* B = Jb + 9 * e;                                                                       \
+      for (int i = 0; i < 3; ++i)                                                                         \
+        for (int j = 0; j < 3; ++j) {                                                                     \
+          double aa = 0, ab = 0, bb = 0;                                                                  \
+          for (int k = 0; k < 3; ++k) {                                                                   \
+            aa += A[k * 3 + i] * A[k * 3 + j];                                                            \
+            ab += A[k * 3 + i] * B[k * 3 + j];                                                            \
+            bb += B[k * 3 + i] * B[k * 3 + j];                                                            \
+          }                                                                                               \
+          if (va >= 0) H[(size_t)(va + i) * nt + va + j] += aa;                                           \
+          if (vb >= 0) H[(size_t)(vb + i) * nt + vb + j] += bb;                                           \
+          if (va >= 0 && vb >= 0) {                                                                       \
+            H[(size_t)(va + i) * nt + vb + j] += ab;                                                      \
+            H[(size_t)(vb + j) * nt + va + i] += ab;                                                      \
+          }                                                                                               \
+        }                                                                                                 \
+      for (int i = 0; i < 3; ++i) {                                                                       \
+        double ga = 0, gb = 0;                                                                            \
+        for (int k = 0; k < 3; ++k) {                                                                     \
+          ga += A[k * 3 + i] * r[3 * e + k];                                                              \
+          gb += B[k * 3 + i] * r[3 * e + k];                                                              \
+        }                                                                                                 \
+        if (va >= 0) g[va + i] += ga;                                                                     \
+        if (vb >= 0) g[vb + i] += gb;                                                                     \
+      }                                                                                                   \
+    }                                                                                                     \
+    if (FIRST)                                                                                            \
+      for (int j = 0; j < nt; ++j) scaling[j] = 1.0 / (1.0 + sqrt(H[(size_t)j * nt + j]));                \
+    grad_max_norm = 0;                                                                                    \
+    for (int j = 0; j < nt; ++j) grad_max_norm = fmax(grad_max_norm, fabs(g[j]));                         \
+    for (int i = 0; i < nt; ++i)                                                                          \
+      for (int j = 0; j < nt; ++j) H[(size_t)i * nt + j] *= scaling[i] * scaling[j];                      \
+    for (int j = 0; j < nt; ++j) g[j] *= scaling[j];                                                      \
+  } while (0)
+#define PG_XNORM(V, OUT)                                                                                  \
+  do {                                                                                                    \
+    double acc_ = 0;                                                                                      \
+    for (int i = 0; i < n_poses; ++i)                                                                     \
+      if (var[i] >= 0) acc_ += V[3 * i] * V[3 * i] + V[3 * i + 1] * V[3 * i + 1] + V[3 * i + 2] * V[3 * i + 2]; \
+    OUT = sqrt(acc_);                                                                                     \
+  } while (0)
+
+  PG_XNORM(x, x_norm);
+  PG_LINEARIZE(1);
+  if (out) out->initial_cost = x_cost;
+  summary_min_cost = x_cost;
+  n_it = 1;
+
+  for (;;) {
+    if (step_successful && x_cost < minimum_cost) {
+      minimum_cost = x_cost;
+      memcpy(best, x, sizeof(double) * 3 * (size_t)n_poses);
+    }
+    if (iteration >= opt->max_iterations) { term = ORC_TERM_NO_CONVERGENCE; break; }
+    if (step_successful && grad_max_norm <= opt->gradient_tolerance) { term = ORC_TERM_CONVERGENCE_GRADIENT; break; }
+    if (radius <= opt->min_radius) { term = ORC_TERM_CONVERGENCE_RADIUS; break; }
+    ++iteration;
+    ++n_it;
+
+    if (!reuse_diagonal)
+      for (int j = 0; j < nt; ++j) diagonal[j] = fmin(fmax(H[(size_t)j * nt + j], opt->min_lm_diagonal), opt->max_lm_diagonal);
+    memcpy(Hw, H, sizeof(double) * (size_t)nt * nt);
+    for (int j = 0; j < nt; ++j) {
+      const double d = sqrt(diagonal[j] / radius);
+      Hw[(size_t)j * nt + j] += d * d;
+    }
+    memcpy(gw, g, sizeof(double) * (size_t)nt);
+    int solved = chol_solve(Hw, gw, nt, step);
+    for (int j = 0; j < nt; ++j) {
+      if (!isfinite(step[j])) solved = 0;
+      step[j] = -step[j];
+    }
+    reuse_diagonal = 1;
+    int step_valid = 0;
+    double model_cost_change = 0;
+    if (solved) {
+      /* -(J step)^T (r + J step / 2) = -(step.g + step^T H step / 2) on the scaled system */
+      double acc = 0;
+      for (int i = 0; i < nt; ++i) {
+        double hs = 0;
+        for (int j = 0; j < nt; ++j) hs += H[(size_t)i * nt + j] * step[j];
+        acc += step[i] * (g[i] + 0.5 * hs);
+      }
+      model_cost_change = -acc;
+      step_valid = model_cost_change > 0.0;
+    }
+    if (!step_valid) {
+      if (++num_invalid >= opt->max_consecutive_invalid_steps) { term = ORC_TERM_FAILURE; break; }
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      reuse_diagonal = 1;
+      step_successful = 0;
+      if (x_cost < summary_min_cost) summary_min_cost = x_cost;
+      continue;
+    }
+    num_invalid = 0;
+    for (int j = 0; j < nt; ++j) delta[j] = step[j] * scaling[j];
+    memcpy(cand, x, sizeof(double) * 3 * (size_t)n_poses);
+    for (int i = 0; i < n_poses; ++i)
+      if (var[i] >= 0)
+        for (int k = 0; k < 3; ++k) cand[3 * i + k] = x[3 * i + k] + delta[var[i] + k];
+    cand_cost = pg_eval(&P, cand, NULL, NULL, NULL);
+
+    double step_norm = 0;
+    for (int i = 0; i < n_poses; ++i)
+      if (var[i] >= 0)
+        for (int k = 0; k < 3; ++k) step_norm += (x[3 * i + k] - cand[3 * i + k]) * (x[3 * i + k] - cand[3 * i + k]);
+    step_norm = sqrt(step_norm);
+    if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { term = ORC_TERM_CONVERGENCE_PARAMETER; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= opt->function_tolerance * x_cost) { term = ORC_TERM_CONVERGENCE_FUNCTION; break; }
+    const double relative_decrease = cost_change / model_cost_change;
+    if (relative_decrease > opt->min_relative_decrease) {
+      memcpy(x, cand, sizeof(double) * 3 * (size_t)n_poses);
+      PG_XNORM(x, x_norm);
+      PG_LINEARIZE(0);
+      step_successful = 1;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3));
+      radius = fmin(opt->max_radius, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = 0;
+      if (x_cost < summary_min_cost) summary_min_cost = x_cost;
+    } else {
+      step_successful = 0;
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      reuse_diagonal = 1;
+      if (cand_cost < summary_min_cost) summary_min_cost = cand_cost;
+    }
+  }
+#undef PG_LINEARIZE
+#undef PG_XNORM
+  memcpy(poses, best, sizeof(double) * 3 * (size_t)n_poses);
+  if (out) {
+    out->final_cost = summary_min_cost;
+    out->iterations = n_it;
+    out->termination = term;
+  }
+  free(x); free(cand); free(best); free(r); free(Ja); free(Jb); free(H); free(Hw); free(g); free(gw);
+  free(scaling); free(diagonal); free(step); free(delta);
+  free(ia); free(ib); free(um); free(us); free(var);
+  return 0;
+}

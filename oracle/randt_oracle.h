@@ -272,6 +272,36 @@ double orc_sc_distance(const orc_sc_params* p, const double* sc1, const double* 
 int orc_sc_detect(const orc_sc_params* p, const double* desc, const double* ring_keys, const double* pos, const double* dist,
                   int n_db, int node_id, float* yaw, double* min_dist);
 
+/* ---------------------------------------------------------------- f-4: pose graph ----------- */
+/* GlobalFuser::optimizePoseGraph (src/global_fuser/global_fuser.cpp:13-105) with PoseGraph2dErrorTerm
+ * (include/global_fuser/pose_graph_2d_error_term.h:33-80) and NormalizeAngle (include/ndt_registration/
+ * state_manifold.h:17-23).  Ceres 2.1.0 trust-region LM, SPARSE_NORMAL_CHOLESKY restated as a dense Cholesky of the
+ * same damped normal equations (same step up to rounding); optional HuberLoss with the Ceres corrector. */
+typedef struct orc_pg_params {
+  int32_t use_robust_loss;  /* GlobalFuserParameters::use_robust_loss -> ceres::HuberLoss(loss_function_scale) (:17-23) */
+  int32_t max_iterations;   /* 200000 (:52) */
+  int32_t max_consecutive_invalid_steps;
+  int32_t reserved;
+  double loss_scale;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_radius, max_radius, min_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+} orc_pg_params;
+typedef struct orc_pg_result {
+  double initial_cost, final_cost;
+  int32_t iterations, termination, n_residual_blocks, n_loop_closures;
+} orc_pg_result;
+void orc_pg_params_default(orc_pg_params* p);
+/* residual (3) and the 3x3 Jacobians w.r.t. (x_a, y_a, yaw_a) and (x_b, y_b, yaw_b), sqrt-information applied, no loss */
+void orc_pg_edge(const double pose_a[3], const double pose_b[3], const double meas[3], const double sqrt_info[9], double r[3],
+                 double Ja[9], double Jb[9]);
+/* poses [n_poses][3] = (pos.x, pos.y, rot), in/out; edges: id_begin/id_end, meas [E][3] = (trans.translation(), trans.log()(2)),
+ * sqrt_info [E][9] row-major.  Edge e is used iff id_begin+1 == id_end || id_end <= max_update_index (:32); pose 0 is
+ * constant (:48-49).  Returns 0 on success. */
+int orc_pose_graph_optimize(int n_poses, double* poses, int n_edges, const int32_t* id_begin, const int32_t* id_end,
+                            const double* meas, const double* sqrt_info, int max_update_index, const orc_pg_params* p,
+                            orc_pg_result* out);
+
 /* ---------------------------------------------------------------- SE(2) helpers (Sophus) --- */
 void orc_se2_exp(const double xi[3], double out4[4]);
 void orc_se2_log(const double p4[4], double xi[3]);

@@ -69,6 +69,20 @@ class BnbParams(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class PgParams(C.Structure):
+    _fields_ = [("use_robust_loss", C.c_int32), ("max_iterations", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
+                ("reserved", C.c_int32), ("loss_scale", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double)]
+
+
+class PgResult(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int32), ("termination", C.c_int32),
+                ("n_residual_blocks", C.c_int32), ("n_loop_closures", C.c_int32), ("n_separator_poses", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class WindowParams(C.Structure):
     _fields_ = [("motion_sqrtI", C.c_double * 64), ("ndt_weight", C.c_double), ("weight_imu", C.c_double),
                 ("weight_imu_bias", C.c_double), ("pose_reject_translation", C.c_double), ("pose_reject_rotation", C.c_double),
@@ -127,6 +141,8 @@ SYMBOLS = {
     "randt_sc_db_append": (_I, [_V, _V, _I, _I, _I, _V, C.c_double, _P(_I)]),
     "randt_sc_db_detect": (_I, [_V, _I, _P(_I), _P(C.c_float), _P(C.c_double)]),
     "randt_sc_db_download": (_I, [_V, _I, _V, _V, _V]),
+    "randt_pg_params_default": (None, [_P(PgParams)]),
+    "randt_pose_graph_optimize": (_I, [_V, _I, _V, _I, _V, _V, _V, _V, _I, _P(PgParams), _P(PgResult)]),
     "randt_predict_state": (_I, [_V, C.c_double, _V]),
     "randt_register_window": (_I, [_V, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _P(_I), _V]),
 }

@@ -1,0 +1,841 @@
+// f-4: 2-D pose-graph optimisation on the device -- the GPU side of GlobalFuser::optimizePoseGraph
+// (src/global_fuser/global_fuser.cpp:13-105) with PoseGraph2dErrorTerm (include/global_fuser/
+// pose_graph_2d_error_term.h:33-80), optional ceres::HuberLoss, and the Ceres 2.1.0 trust-region
+// Levenberg-Marquardt loop driven from the host, one small read-back per iteration.
+//
+// The reference hands the damped normal equations to SuiteSparse (SPARSE_NORMAL_CHOLESKY, :54-57).  Here the same
+// system is factorised exactly, with an elimination order chosen for the shape a SLAM graph has -- a long odometry
+// chain plus a few loop closures:
+//   * "separator" poses = variable poses touched by an edge that is not chain-adjacent (|i - j| != 1) to another
+//     variable pose; everything else is "interior".  Interior poses, in id order, form a block-tridiagonal system T
+//     (3x3 blocks; the chain simply breaks where a separator sits between two interiors).
+//   * T = L L^T is factorised by one lane walking the chain (k_pg_factor); then ONE LANE PER RIGHT-HAND SIDE solves
+//     T W = [C | g_int] for the 3 n_sep coupling columns and the gradient at once (k_pg_chain_solve, W is
+//     [3 n_int][3 n_sep + 1] in HBM, column index fastest so a wavefront's accesses coalesce);
+//   * the Schur complement S - C^T W on the separators is a small dense SPD system: one workgroup factorises it in
+//     place (k_pg_dense) and back-substitutes; interiors follow from W (k_pg_backsub).
+// That is block Cholesky in a nested-dissection order -- no Woodbury-style cancellation when loop closures carry
+// weights of 4e4 (parameters_indoor.yaml:10).  Everything is fp64 and deterministic (gathers through host-built
+// incidence lists and fixed-order reductions; no floating-point atomics).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "randt_internal.h"
+#include "solve_math.h"
+
+namespace {
+
+using randt_solve::fast_rcp;
+using randt_solve::fast_rsqrt;
+
+struct PgDev {
+  int n_poses, n_edges, n_int, n_sep, ncols, ns;
+  const int32_t *ia, *ib;
+  const double *meas, *sqi;
+  const int32_t *inc_off, *inc_ent;  // per pose: incident (edge << 1 | side) entries, ascending edge order
+  const int32_t *is_var, *int_of, *sep_of;
+  const int32_t *int_pose, *sep_pose;
+  const int32_t *link;         // interior m and m+1 are chain-adjacent poses
+  const int32_t *sepL, *sepR;  // interior m: separator index of pose-1 / pose+1, or -1
+  const int32_t *nbL, *nbR;    // separator q: interior index of pose-1 / pose+1, or -1
+  double *x, *cand;
+  double *r[2], *Ja[2], *Jb[2], *cost_e[2];
+  double *Ds;        // [n_poses][6] Jacobi-scaled diagonal block (xx, xy, xt, yy, yt, tt)
+  double *gs;        // [n_poses][3] scaled gradient
+  double *sigma;     // [n_poses][3] Jacobi scaling, fixed per solve
+  double *diagonal;  // [n_poses][3] clamp(diag(J_s^T J_s)), refreshed on successful steps
+  double *E, *CL, *CR;  // per interior: H[m+1, m], H[m, sep(pose-1)], H[m, sep(pose+1)], scaled, row-major 3x3
+  double *Lf, *Ff;      // per interior: l00 l10 l11 l20 l21 l22 1/l00 1/l11 1/l22 ; L[m+1, m] row-major
+  double *W, *S0, *Sw, *xsep, *step;
+  double *p_gabs, *p_xsq, *p_sn, *p_mcc;  // per-pose / per-edge partials
+  double *scal;                            // [8]: cost cur, cost cand, mcc sum, step norm^2, x norm^2, grad max
+  int32_t* flags;                          // [0] factor ok, [1] dense ok, [2] step finite
+};
+
+__device__ __forceinline__ double pg_normalize_angle(double a) {
+  const double two_pi = 2.0 * M_PI;
+  return a - two_pi * floor((a + M_PI) / two_pi);  // state_manifold.h:17-23
+}
+
+// One thread per residual block: residual, both 3x3 Jacobians (autodiff written out), loss correction.
+__global__ __launch_bounds__(256) void k_pg_edges(PgDev d, const double* __restrict__ x, int b, int robust, double huber_a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.n_edges) return;
+  const double* pa = x + 3 * (size_t)d.ia[e];
+  const double* pb = x + 3 * (size_t)d.ib[e];
+  const double* ms = d.meas + 3 * (size_t)e;
+  const double* sq = d.sqi + 9 * (size_t)e;
+  double s, c;
+  sincos(pa[2], &s, &c);
+  const double dx = pb[0] - pa[0], dy = pb[1] - pa[1];
+  double ev[3];
+  ev[0] = (c * dx + s * dy) - ms[0];
+  ev[1] = (-s * dx + c * dy) - ms[1];
+  ev[2] = pg_normalize_angle((pb[2] - pa[2]) - ms[2]);
+  const double A[9] = {-c, -s, -s * dx + c * dy, s, -c, -c * dx - s * dy, 0.0, 0.0, -1.0};
+  const double B[9] = {c, s, 0.0, -s, c, 0.0, 0.0, 0.0, 1.0};
+  double r[3], Ja[9], Jb[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    r[i] = sq[i * 3 + 0] * ev[0] + sq[i * 3 + 1] * ev[1] + sq[i * 3 + 2] * ev[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Ja[i * 3 + j] = sq[i * 3 + 0] * A[0 + j] + sq[i * 3 + 1] * A[3 + j] + sq[i * 3 + 2] * A[6 + j];
+      Jb[i * 3 + j] = sq[i * 3 + 0] * B[0 + j] + sq[i * 3 + 1] * B[3 + j] + sq[i * 3 + 2] * B[6 + j];
+    }
+  }
+  const double sn = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double rho0 = sn, rho1 = 1.0;
+  if (robust) {  // ceres::HuberLoss(a): b = a^2; rho'' <= 0 so the corrector is a plain sqrt(rho') scaling
+    const double bb = huber_a * huber_a;
+    if (sn > bb) {
+      const double rr = sqrt(sn);
+      rho0 = 2.0 * huber_a * rr - bb;
+      rho1 = fmax(DBL_MIN, huber_a / rr);
+    }
+  }
+  const double w = sqrt(rho1);
+  d.cost_e[b][e] = 0.5 * rho0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d.r[b][3 * (size_t)e + i] = r[i] * w;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    d.Ja[b][9 * (size_t)e + i] = Ja[i] * w;
+    d.Jb[b][9 * (size_t)e + i] = Jb[i] * w;
+  }
+}
+
+// Fixed-order block reductions: block k reduces one (array, length) pair into scal[slot]; op 0 = sum, 1 = max.
+struct PgReduce {
+  const double* in[4];
+  int n[4], slot[4], op[4];
+};
+__global__ __launch_bounds__(1024) void k_pg_reduce(PgReduce R, double* __restrict__ scal) {
+  __shared__ double sh[1024];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const double* in = R.in[k];
+  const int n = R.n[k];
+  const bool mx = R.op[k] == 1;
+  double acc = 0.0;
+  for (int i = tid; i < n; i += 1024) acc = mx ? fmax(acc, in[i]) : acc + in[i];
+  sh[tid] = acc;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (tid < off) sh[tid] = mx ? fmax(sh[tid], sh[tid + off]) : sh[tid] + sh[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) scal[R.slot[k]] = sh[0];
+}
+
+// One thread per pose: gather J^T J diagonal block and J^T r over the pose's incident edges (list order), Jacobi
+// scaling on the first linearisation of the solve, |g|_max and |x|^2 partials.
+__global__ __launch_bounds__(256) void k_pg_pose_diag(PgDev d, int b, int first) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= d.n_poses) return;
+  if (!d.is_var[v]) {
+    d.p_gabs[v] = 0.0;
+    d.p_xsq[v] = 0.0;
+    return;
+  }
+  double D[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int k = d.inc_off[v]; k < d.inc_off[v + 1]; ++k) {
+    const int ent = d.inc_ent[k];
+    const int e = ent >> 1;
+    const double* J = ((ent & 1) ? d.Jb[b] : d.Ja[b]) + 9 * (size_t)e;
+    const double* r = d.r[b] + 3 * (size_t)e;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double j0 = J[q * 3 + 0], j1 = J[q * 3 + 1], j2 = J[q * 3 + 2], rq = r[q];
+      D[0] += j0 * j0; D[1] += j0 * j1; D[2] += j0 * j2;
+      D[3] += j1 * j1; D[4] += j1 * j2; D[5] += j2 * j2;
+      g[0] += j0 * rq; g[1] += j1 * rq; g[2] += j2 * rq;
+    }
+  }
+  double sg[3];
+  if (first) {
+    sg[0] = 1.0 / (1.0 + sqrt(D[0]));
+    sg[1] = 1.0 / (1.0 + sqrt(D[3]));
+    sg[2] = 1.0 / (1.0 + sqrt(D[5]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d.sigma[3 * (size_t)v + i] = sg[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sg[i] = d.sigma[3 * (size_t)v + i];
+  }
+  d.p_gabs[v] = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+  const double* xv = d.x + 3 * (size_t)v;
+  d.p_xsq[v] = xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2];
+  double* Ds = d.Ds + 6 * (size_t)v;
+  Ds[0] = D[0] * sg[0] * sg[0]; Ds[1] = D[1] * sg[0] * sg[1]; Ds[2] = D[2] * sg[0] * sg[2];
+  Ds[3] = D[3] * sg[1] * sg[1]; Ds[4] = D[4] * sg[1] * sg[2]; Ds[5] = D[5] * sg[2] * sg[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d.gs[3 * (size_t)v + i] = g[i] * sg[i];
+}
+
+// One thread per pose: off-diagonal blocks H[v, u] = sum_e J_v^T J_u (scaled) routed to where the elimination needs
+// them -- interior/interior chain neighbours (E), interior/separator couplings (CL, CR), separator/separator (S0).
+// A separator thread owns its block row of S0, so no two threads write the same word.  S0 is zeroed beforehand.
+__global__ __launch_bounds__(256) void k_pg_pose_offdiag(PgDev d, int b) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= d.n_poses || !d.is_var[v]) return;
+  const int m = d.int_of[v], q = d.sep_of[v];
+  double E[9], CL[9], CR[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) E[i] = CL[i] = CR[i] = 0.0;
+  const double* sv = d.sigma + 3 * (size_t)v;
+  if (q >= 0) {
+    const double* Ds = d.Ds + 6 * (size_t)v;
+    double* S = d.S0 + (size_t)(3 * q) * d.ns + 3 * q;
+    S[0] = Ds[0]; S[1] = Ds[1]; S[2] = Ds[2];
+    S[d.ns + 0] = Ds[1]; S[d.ns + 1] = Ds[3]; S[d.ns + 2] = Ds[4];
+    S[2 * (size_t)d.ns + 0] = Ds[2]; S[2 * (size_t)d.ns + 1] = Ds[4]; S[2 * (size_t)d.ns + 2] = Ds[5];
+  }
+  for (int k = d.inc_off[v]; k < d.inc_off[v + 1]; ++k) {
+    const int ent = d.inc_ent[k];
+    const int e = ent >> 1, side = ent & 1;
+    const int u = side ? d.ia[e] : d.ib[e];
+    if (!d.is_var[u]) continue;
+    const double* Jv = (side ? d.Jb[b] : d.Ja[b]) + 9 * (size_t)e;
+    const double* Ju = (side ? d.Ja[b] : d.Jb[b]) + 9 * (size_t)e;
+    const double* su = d.sigma + 3 * (size_t)u;
+    double B[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        B[i * 3 + j] = (Jv[0 + i] * Ju[0 + j] + Jv[3 + i] * Ju[3 + j] + Jv[6 + i] * Ju[6 + j]) * (sv[i] * su[j]);
+    if (m >= 0) {
+      if (u == v + 1) {
+        if (d.int_of[u] >= 0) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) E[j * 3 + i] += B[i * 3 + j];  // stored as H[m+1, m]
+        } else {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) CR[i] += B[i];
+        }
+      } else if (u == v - 1 && d.sep_of[u] >= 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) CL[i] += B[i];
+      }
+    } else {
+      const int q2 = d.sep_of[u];
+      if (q2 >= 0) {
+        double* S = d.S0 + (size_t)(3 * q) * d.ns + 3 * q2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) S[(size_t)i * d.ns + j] += B[i * 3 + j];
+      }
+    }
+  }
+  if (m >= 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      d.E[9 * (size_t)m + i] = E[i];
+      d.CL[9 * (size_t)m + i] = CL[i];
+      d.CR[9 * (size_t)m + i] = CR[i];
+    }
+  }
+}
+
+// LevenbergMarquardtStrategy: diagonal = clamp(diag(J_s^T J_s), min, max), refreshed only after a successful step.
+__global__ __launch_bounds__(256) void k_pg_lm_diagonal(PgDev d, double dmin, double dmax) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= d.n_poses || !d.is_var[v]) return;
+  const double* Ds = d.Ds + 6 * (size_t)v;
+  d.diagonal[3 * (size_t)v + 0] = fmin(fmax(Ds[0], dmin), dmax);
+  d.diagonal[3 * (size_t)v + 1] = fmin(fmax(Ds[3], dmin), dmax);
+  d.diagonal[3 * (size_t)v + 2] = fmin(fmax(Ds[5], dmin), dmax);
+}
+
+// Block-tridiagonal Cholesky along the interior chain: a strictly serial recurrence of 3x3 blocks, walked by one lane
+// with the next block's operands loaded ahead of the arithmetic that depends on the previous block.
+__global__ __launch_bounds__(64) void k_pg_factor(PgDev d, double inv_radius) {
+  if (threadIdx.x != 0) return;
+  const int n = d.n_int;
+  double F[9];
+  bool prev = false;
+  int ok = 1;
+  double a[6], dg[3], En[9];
+  int lk = 0;
+  auto load = [&](int m) {
+    const int v = d.int_pose[m];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a[i] = d.Ds[6 * (size_t)v + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dg[i] = d.diagonal[3 * (size_t)v + i];
+    lk = d.link[m];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) En[i] = d.E[9 * (size_t)m + i];
+  };
+  if (n > 0) load(0);
+  for (int m = 0; m < n; ++m) {
+    double a00 = a[0] + dg[0] * inv_radius, a10 = a[1], a20 = a[2];
+    double a11 = a[3] + dg[1] * inv_radius, a21 = a[4], a22 = a[5] + dg[2] * inv_radius;
+    double Ec[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ec[i] = En[i];
+    const int lkc = lk;
+    if (m + 1 < n) load(m + 1);
+    if (prev) {
+      a00 -= F[0] * F[0] + F[1] * F[1] + F[2] * F[2];
+      a10 -= F[3] * F[0] + F[4] * F[1] + F[5] * F[2];
+      a11 -= F[3] * F[3] + F[4] * F[4] + F[5] * F[5];
+      a20 -= F[6] * F[0] + F[7] * F[1] + F[8] * F[2];
+      a21 -= F[6] * F[3] + F[7] * F[4] + F[8] * F[5];
+      a22 -= F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
+    }
+    if (!(a00 > 0.0)) ok = 0;
+    const double l00 = sqrt(a00), i00 = 1.0 / l00;
+    const double l10 = a10 * i00, l20 = a20 * i00;
+    const double t11 = a11 - l10 * l10;
+    if (!(t11 > 0.0)) ok = 0;
+    const double l11 = sqrt(t11), i11 = 1.0 / l11;
+    const double l21 = (a21 - l20 * l10) * i11;
+    const double t22 = a22 - l20 * l20 - l21 * l21;
+    if (!(t22 > 0.0)) ok = 0;
+    const double l22 = sqrt(t22), i22 = 1.0 / l22;
+    double* Lf = d.Lf + 9 * (size_t)m;
+    Lf[0] = l00; Lf[1] = l10; Lf[2] = l11; Lf[3] = l20; Lf[4] = l21; Lf[5] = l22; Lf[6] = i00; Lf[7] = i11; Lf[8] = i22;
+    double* Ff = d.Ff + 9 * (size_t)m;
+    if (lkc) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {  // row i of F solves F L^T = E
+        const double x0 = Ec[i * 3 + 0] * i00;
+        const double x1 = (Ec[i * 3 + 1] - x0 * l10) * i11;
+        const double x2 = (Ec[i * 3 + 2] - x0 * l20 - x1 * l21) * i22;
+        F[i * 3 + 0] = x0; F[i * 3 + 1] = x1; F[i * 3 + 2] = x2;
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Ff[i] = F[i];
+      prev = true;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Ff[i] = 0.0;
+      prev = false;
+    }
+  }
+  d.flags[0] = ok;
+}
+
+// T W = [C | g_int]: one lane per right-hand side, all lanes walking the chain together.  The factor blocks are the
+// same for every lane (scalar loads); W's accesses are consecutive across lanes.
+__global__ __launch_bounds__(64) void k_pg_chain_solve(PgDev d) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= d.ncols) return;
+  const int n = d.n_int, nc = d.ncols;
+  const bool isg = c == nc - 1;
+  const int q = c / 3, j = c - 3 * q;
+  double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+  for (int m = 0; m < n; ++m) {
+    double b0, b1, b2;
+    if (isg) {
+      const int v = d.int_pose[m];
+      b0 = d.gs[3 * (size_t)v + 0]; b1 = d.gs[3 * (size_t)v + 1]; b2 = d.gs[3 * (size_t)v + 2];
+    } else {
+      b0 = b1 = b2 = 0.0;
+      if (d.sepL[m] == q) {
+        const double* C = d.CL + 9 * (size_t)m;
+        b0 += C[0 + j]; b1 += C[3 + j]; b2 += C[6 + j];
+      }
+      if (d.sepR[m] == q) {
+        const double* C = d.CR + 9 * (size_t)m;
+        b0 += C[0 + j]; b1 += C[3 + j]; b2 += C[6 + j];
+      }
+    }
+    if (m > 0 && d.link[m - 1]) {
+      const double* F = d.Ff + 9 * (size_t)(m - 1);
+      b0 -= F[0] * y0 + F[1] * y1 + F[2] * y2;
+      b1 -= F[3] * y0 + F[4] * y1 + F[5] * y2;
+      b2 -= F[6] * y0 + F[7] * y1 + F[8] * y2;
+    }
+    const double* L = d.Lf + 9 * (size_t)m;
+    y0 = b0 * L[6];
+    y1 = (b1 - L[1] * y0) * L[7];
+    y2 = (b2 - L[3] * y0 - L[4] * y1) * L[8];
+    double* w = d.W + (size_t)(3 * m) * nc + c;
+    w[0] = y0; w[nc] = y1; w[2 * (size_t)nc] = y2;
+  }
+  double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+  for (int m = n - 1; m >= 0; --m) {
+    double* w = d.W + (size_t)(3 * m) * nc + c;
+    double t0 = w[0], t1 = w[nc], t2 = w[2 * (size_t)nc];
+    if (d.link[m]) {  // (L^T)[m, m+1] = F_m^T
+      const double* F = d.Ff + 9 * (size_t)m;
+      t0 -= F[0] * x0 + F[3] * x1 + F[6] * x2;
+      t1 -= F[1] * x0 + F[4] * x1 + F[7] * x2;
+      t2 -= F[2] * x0 + F[5] * x1 + F[8] * x2;
+    }
+    const double* L = d.Lf + 9 * (size_t)m;
+    x2 = t2 * L[8];
+    x1 = (t1 - L[4] * x2) * L[7];
+    x0 = (t0 - L[1] * x1 - L[3] * x2) * L[6];
+    w[0] = x0; w[nc] = x1; w[2 * (size_t)nc] = x2;
+  }
+}
+
+// (C^T W)[r][wcol] for separator scalar r: only the (at most two) interior chain neighbours of r's pose contribute.
+__device__ __forceinline__ double pg_ctw(const PgDev& d, int r, int wcol) {
+  const int q = r / 3, jr = r - 3 * q;
+  double acc = 0.0;
+  const int mL = d.nbL[q], mR = d.nbR[q];
+  if (mL >= 0) {  // interior at pose-1 couples through its CR block
+    const double* C = d.CR + 9 * (size_t)mL;
+    const double* w = d.W + (size_t)(3 * mL) * d.ncols + wcol;
+    acc += C[0 + jr] * w[0] + C[3 + jr] * w[d.ncols] + C[6 + jr] * w[2 * (size_t)d.ncols];
+  }
+  if (mR >= 0) {
+    const double* C = d.CL + 9 * (size_t)mR;
+    const double* w = d.W + (size_t)(3 * mR) * d.ncols + wcol;
+    acc += C[0 + jr] * w[0] + C[3 + jr] * w[d.ncols] + C[6 + jr] * w[2 * (size_t)d.ncols];
+  }
+  return acc;
+}
+
+// Schur complement on the separators, lower triangle, with the right-hand side stored as an extra ROW ns so that the
+// factorisation's trailing updates forward-substitute it for free.
+__global__ __launch_bounds__(256) void k_pg_schur(PgDev d, double inv_radius) {
+  const int ns = d.ns;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)(ns + 1) * ns) return;
+  const int r = (int)(idx / ns), c = (int)(idx - (size_t)r * ns);
+  if (r < ns) {
+    if (c > r) return;
+    double val = d.S0[(size_t)r * ns + c];
+    if (r == c) val += d.diagonal[3 * (size_t)d.sep_pose[r / 3] + (r % 3)] * inv_radius;
+    if (d.n_int > 0) val -= pg_ctw(d, r, c);
+    d.Sw[(size_t)r * ns + c] = val;
+  } else {
+    double val = d.gs[3 * (size_t)d.sep_pose[c / 3] + (c % 3)];
+    if (d.n_int > 0) val -= pg_ctw(d, c, ns);
+    d.Sw[(size_t)ns * ns + c] = val;
+  }
+}
+
+// Dense Cholesky of the Schur complement by one workgroup, in place in HBM/L2 (right-looking, column by column), then
+// the back-substitution.  Row ns carries the right-hand side.
+__global__ __launch_bounds__(1024) void k_pg_dense(PgDev d) {
+  const int n = d.ns, tid = threadIdx.x;
+  double* A = d.Sw;
+  __shared__ int s_fail;
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    const double piv = A[(size_t)j * n + j];
+    if (!(piv > 0.0)) {
+      if (tid == 0) s_fail = 1;
+      break;  // uniform: every lane reads the same pivot
+    }
+    __syncthreads();
+    const double ljj = sqrt(piv), inv = 1.0 / ljj;
+    for (int i = j + 1 + tid; i <= n; i += 1024) A[(size_t)i * n + j] *= inv;
+    if (tid == 0) A[(size_t)j * n + j] = ljj;
+    __syncthreads();
+    const int w = n - j - 1;  // trailing columns j+1 .. n-1, rows j+1 .. n
+    if (w > 0) {
+      const size_t total = (size_t)(w + 1) * w;
+      for (size_t t = tid; t < total; t += 1024) {
+        const int ri = (int)(t / w), ci = (int)(t - (size_t)ri * w);
+        if (ci > ri) continue;  // upper triangle (the RHS row ri == w keeps every column)
+        const int i = j + 1 + ri, k = j + 1 + ci;
+        A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (tid == 0) d.flags[1] = 0;
+    return;
+  }
+  double* y = A + (size_t)n * n;
+  for (int j = n - 1; j >= 0; --j) {
+    const double zj = y[j] / A[(size_t)j * n + j];
+    __syncthreads();
+    if (tid == 0) d.xsep[j] = zj;
+    for (int i = tid; i < j; i += 1024) y[i] -= A[(size_t)j * n + i] * zj;
+    __syncthreads();
+  }
+  if (tid == 0) d.flags[1] = 1;
+}
+
+// Interior unknowns z = W[:, ns] - W[:, :ns] z_sep, one wavefront per scalar row; separators copy z_sep.  step = -z.
+__global__ __launch_bounds__(64) void k_pg_backsub(PgDev d) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int n_rows_int = 3 * d.n_int;
+  if (row < n_rows_int) {
+    const double* w = d.W + (size_t)row * d.ncols;
+    double acc = 0.0;
+    for (int c = lane; c < d.ns; c += 64) acc += w[c] * d.xsep[c];
+    acc = randt_solve::wave_sum(acc);
+    if (lane == 0) {
+      const int m = row / 3;
+      d.step[3 * (size_t)d.int_pose[m] + (row - 3 * m)] = -(w[d.ns] - acc);
+    }
+  } else if (lane == 0) {
+    const int r = row - n_rows_int;
+    d.step[3 * (size_t)d.sep_pose[r / 3] + (r % 3)] = -d.xsep[r];
+  }
+}
+
+// candidate = x + step .* sigma (Euclidean blocks), |delta|^2 partials, finiteness flag
+__global__ __launch_bounds__(256) void k_pg_candidate(PgDev d) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= d.n_poses) return;
+  double sn = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double xv = d.x[3 * (size_t)v + i];
+    double dl = 0.0;
+    if (d.is_var[v]) {
+      const double st = d.step[3 * (size_t)v + i];
+      if (!isfinite(st)) d.flags[2] = 0;
+      dl = st * d.sigma[3 * (size_t)v + i];
+    }
+    const double cv = xv + dl;
+    d.cand[3 * (size_t)v + i] = cv;
+    sn += (xv - cv) * (xv - cv);
+  }
+  d.p_sn[v] = sn;
+}
+
+// model_cost_change = -(J step)^T (r + J step / 2), per residual block
+__global__ __launch_bounds__(256) void k_pg_mcc(PgDev d, int b) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.n_edges) return;
+  const int a = d.ia[e], bb = d.ib[e];
+  double da[3] = {0, 0, 0}, db[3] = {0, 0, 0};
+  if (d.is_var[a])
+#pragma unroll
+    for (int i = 0; i < 3; ++i) da[i] = d.step[3 * (size_t)a + i] * d.sigma[3 * (size_t)a + i];
+  if (d.is_var[bb])
+#pragma unroll
+    for (int i = 0; i < 3; ++i) db[i] = d.step[3 * (size_t)bb + i] * d.sigma[3 * (size_t)bb + i];
+  const double* Ja = d.Ja[b] + 9 * (size_t)e;
+  const double* Jb = d.Jb[b] + 9 * (size_t)e;
+  const double* r = d.r[b] + 3 * (size_t)e;
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double mr = Ja[i * 3 + 0] * da[0] + Ja[i * 3 + 1] * da[1] + Ja[i * 3 + 2] * da[2] + Jb[i * 3 + 0] * db[0] +
+                      Jb[i * 3 + 1] * db[1] + Jb[i * 3 + 2] * db[2];
+    acc += mr * (r[i] + mr / 2.0);
+  }
+  d.p_mcc[e] = acc;
+}
+
+struct Carver {  // bump allocator over one device block
+  char* base = nullptr;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += sizeof(T) * (n > 0 ? n : 1);
+    return p;
+  }
+};
+
+inline int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
+
+}  // namespace
+
+void randt_pg_params_default(randt_pg_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->use_robust_loss = 0;
+  p->loss_scale = 60.0;
+  p->max_iterations = 200000;  // global_fuser.cpp:52
+  p->max_consecutive_invalid_steps = 5;
+  p->function_tolerance = 1e-6;
+  p->gradient_tolerance = 1e-10;
+  p->parameter_tolerance = 1e-8;
+  p->initial_radius = 1e4;
+  p->max_radius = 1e16;
+  p->min_radius = 1e-32;
+  p->min_relative_decrease = 1e-3;
+  p->min_lm_diagonal = 1e-6;
+  p->max_lm_diagonal = 1e32;
+}
+
+int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int n_edges, const int32_t* h_id_begin,
+                                         const int32_t* h_id_end, const double* h_meas, const double* h_sqrt_info,
+                                         int max_update_index, const randt_pg_params* opt, randt_pg_result* out) {
+  if (!ctx || !opt || n_poses <= 0 || n_edges < 0 || !h_poses) return RANDT_ERR_INVALID;
+  if (n_edges > 0 && (!h_id_begin || !h_id_end || !h_meas || !h_sqrt_info)) return RANDT_ERR_INVALID;
+  if (out) {
+    memset(out, 0, sizeof(*out));
+    out->n_loop_closures = n_edges + 1 - n_poses;  // global_fuser.cpp:26
+  }
+  // ---- the residual blocks the reference adds (global_fuser.cpp:31-46)
+  std::vector<int32_t> ia, ib;
+  std::vector<double> meas, sqi;
+  std::vector<int32_t> is_var(n_poses, 0);
+  for (int e = 0; e < n_edges; ++e) {
+    const int a = h_id_begin[e], b = h_id_end[e];
+    if (!(a + 1 == b || b <= max_update_index)) continue;
+    if (a < 0 || b < 0 || a >= n_poses || b >= n_poses || a == b)
+      return randt_set_error(ctx, RANDT_ERR_INVALID, "pose graph: edge endpoints out of range or identical", hipSuccess);
+    ia.push_back(a);
+    ib.push_back(b);
+    meas.insert(meas.end(), h_meas + 3 * (size_t)e, h_meas + 3 * (size_t)e + 3);
+    sqi.insert(sqi.end(), h_sqrt_info + 9 * (size_t)e, h_sqrt_info + 9 * (size_t)e + 9);
+    is_var[a] = is_var[b] = 1;
+  }
+  is_var[0] = 0;  // poses.begin(): SetParameterBlockConstant (:48-49)
+  const int nu = (int)ia.size();
+  int n_var = 0;
+  for (int i = 0; i < n_poses; ++i) n_var += is_var[i];
+  if (out) out->n_residual_blocks = nu;
+  if (nu == 0 || n_var == 0) return RANDT_OK;
+
+  // ---- elimination order: separators last
+  std::vector<int32_t> is_sep(n_poses, 0);
+  for (int e = 0; e < nu; ++e) {
+    const int a = ia[e], b = ib[e];
+    if (is_var[a] && is_var[b] && std::abs(a - b) != 1) is_sep[a] = is_sep[b] = 1;
+  }
+  std::vector<int32_t> int_of(n_poses, -1), sep_of(n_poses, -1), int_pose, sep_pose;
+  for (int i = 0; i < n_poses; ++i) {
+    if (!is_var[i]) continue;
+    if (is_sep[i]) {
+      sep_of[i] = (int)sep_pose.size();
+      sep_pose.push_back(i);
+    } else {
+      int_of[i] = (int)int_pose.size();
+      int_pose.push_back(i);
+    }
+  }
+  const int n_int = (int)int_pose.size(), n_sep = (int)sep_pose.size();
+  const int ns = 3 * n_sep, ncols = ns + 1;
+  if (out) out->n_separator_poses = n_sep;
+  if (n_sep > RANDT_PG_MAX_SEPARATORS)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "pose graph: too many loop-closure poses for the dense Schur complement", hipSuccess);
+  std::vector<int32_t> link(n_int > 0 ? n_int : 1, 0), sepL(n_int > 0 ? n_int : 1, -1), sepR(n_int > 0 ? n_int : 1, -1);
+  std::vector<int32_t> nbL(n_sep > 0 ? n_sep : 1, -1), nbR(n_sep > 0 ? n_sep : 1, -1);
+  for (int m = 0; m < n_int; ++m) {
+    const int v = int_pose[m];
+    link[m] = (m + 1 < n_int && int_pose[m + 1] == v + 1) ? 1 : 0;
+    if (v - 1 >= 0 && sep_of[v - 1] >= 0) {
+      sepL[m] = sep_of[v - 1];
+      nbR[sep_of[v - 1]] = m;
+    }
+    if (v + 1 < n_poses && sep_of[v + 1] >= 0) {
+      sepR[m] = sep_of[v + 1];
+      nbL[sep_of[v + 1]] = m;
+    }
+  }
+  // incidence lists (ascending edge order per pose)
+  std::vector<int32_t> inc_off(n_poses + 1, 0), inc_ent(2 * (size_t)nu);
+  for (int e = 0; e < nu; ++e) {
+    inc_off[ia[e] + 1]++;
+    inc_off[ib[e] + 1]++;
+  }
+  for (int i = 0; i < n_poses; ++i) inc_off[i + 1] += inc_off[i];
+  {
+    std::vector<int32_t> fill(inc_off.begin(), inc_off.end() - 1);
+    for (int e = 0; e < nu; ++e) {
+      inc_ent[fill[ia[e]]++] = (e << 1) | 0;
+      inc_ent[fill[ib[e]]++] = (e << 1) | 1;
+    }
+  }
+
+  // ---- device block
+  PgDev d{};
+  d.n_poses = n_poses; d.n_edges = nu; d.n_int = n_int; d.n_sep = n_sep; d.ncols = ncols; d.ns = ns;
+  int32_t *d_ia, *d_ib, *d_inc_off, *d_inc_ent, *d_is_var, *d_int_of, *d_sep_of, *d_int_pose, *d_sep_pose, *d_link, *d_sepL, *d_sepR,
+      *d_nbL, *d_nbR;
+  double *d_meas, *d_sqi;
+  Carver cv;
+  auto carve = [&]() {
+    d_ia = cv.take<int32_t>(nu); d_ib = cv.take<int32_t>(nu);
+    d_meas = cv.take<double>(3 * (size_t)nu); d_sqi = cv.take<double>(9 * (size_t)nu);
+    d_inc_off = cv.take<int32_t>(n_poses + 1); d_inc_ent = cv.take<int32_t>(2 * (size_t)nu);
+    d_is_var = cv.take<int32_t>(n_poses); d_int_of = cv.take<int32_t>(n_poses); d_sep_of = cv.take<int32_t>(n_poses);
+    d_int_pose = cv.take<int32_t>(n_int); d_sep_pose = cv.take<int32_t>(n_sep);
+    d_link = cv.take<int32_t>(n_int); d_sepL = cv.take<int32_t>(n_int); d_sepR = cv.take<int32_t>(n_int);
+    d_nbL = cv.take<int32_t>(n_sep); d_nbR = cv.take<int32_t>(n_sep);
+    d.x = cv.take<double>(3 * (size_t)n_poses); d.cand = cv.take<double>(3 * (size_t)n_poses);
+    for (int b = 0; b < 2; ++b) {
+      d.r[b] = cv.take<double>(3 * (size_t)nu); d.Ja[b] = cv.take<double>(9 * (size_t)nu);
+      d.Jb[b] = cv.take<double>(9 * (size_t)nu); d.cost_e[b] = cv.take<double>(nu);
+    }
+    d.Ds = cv.take<double>(6 * (size_t)n_poses); d.gs = cv.take<double>(3 * (size_t)n_poses);
+    d.sigma = cv.take<double>(3 * (size_t)n_poses); d.diagonal = cv.take<double>(3 * (size_t)n_poses);
+    d.E = cv.take<double>(9 * (size_t)n_int); d.CL = cv.take<double>(9 * (size_t)n_int); d.CR = cv.take<double>(9 * (size_t)n_int);
+    d.Lf = cv.take<double>(9 * (size_t)n_int); d.Ff = cv.take<double>(9 * (size_t)n_int);
+    d.W = cv.take<double>(3 * (size_t)n_int * ncols);
+    d.S0 = cv.take<double>((size_t)ns * ns); d.Sw = cv.take<double>((size_t)(ns + 1) * ns);
+    d.xsep = cv.take<double>(ns); d.step = cv.take<double>(3 * (size_t)n_poses);
+    d.p_gabs = cv.take<double>(n_poses); d.p_xsq = cv.take<double>(n_poses); d.p_sn = cv.take<double>(n_poses);
+    d.p_mcc = cv.take<double>(nu);
+    d.scal = cv.take<double>(8); d.flags = cv.take<int32_t>(4);
+  };
+  carve();  // sizing pass
+  const size_t bytes = cv.off + 256;
+  char* blk = nullptr;
+  RANDT_HIP_CHECK(ctx, hipMalloc(&blk, bytes));
+  cv = Carver{blk, 0};
+  carve();
+  d.ia = d_ia; d.ib = d_ib; d.meas = d_meas; d.sqi = d_sqi; d.inc_off = d_inc_off; d.inc_ent = d_inc_ent;
+  d.is_var = d_is_var; d.int_of = d_int_of; d.sep_of = d_sep_of; d.int_pose = d_int_pose; d.sep_pose = d_sep_pose;
+  d.link = d_link; d.sepL = d_sepL; d.sepR = d_sepR; d.nbL = d_nbL; d.nbR = d_nbR;
+
+  hipStream_t st = ctx->stream;
+  int rc = RANDT_OK;
+#define PG_TRY(call)                                                                \
+  do {                                                                              \
+    hipError_t e__ = (call);                                                        \
+    if (e__ != hipSuccess && rc == RANDT_OK) rc = randt_set_error(ctx, RANDT_ERR_HIP, #call, e__); \
+  } while (0)
+#define PG_UP(dst, vec, T) \
+  if (!(vec).empty()) PG_TRY(hipMemcpyAsync((dst), (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, st))
+  PG_UP(d_ia, ia, int32_t); PG_UP(d_ib, ib, int32_t); PG_UP(d_meas, meas, double); PG_UP(d_sqi, sqi, double);
+  PG_UP(d_inc_off, inc_off, int32_t); PG_UP(d_inc_ent, inc_ent, int32_t); PG_UP(d_is_var, is_var, int32_t);
+  PG_UP(d_int_of, int_of, int32_t); PG_UP(d_sep_of, sep_of, int32_t); PG_UP(d_int_pose, int_pose, int32_t);
+  PG_UP(d_sep_pose, sep_pose, int32_t);
+  if (n_int > 0) {
+    PG_UP(d_link, link, int32_t); PG_UP(d_sepL, sepL, int32_t); PG_UP(d_sepR, sepR, int32_t);
+  }
+  if (n_sep > 0) {
+    PG_UP(d_nbL, nbL, int32_t); PG_UP(d_nbR, nbR, int32_t);
+  }
+#undef PG_UP
+  PG_TRY(hipMemcpyAsync(d.x, h_poses, sizeof(double) * 3 * (size_t)n_poses, hipMemcpyHostToDevice, st));
+  PG_TRY(hipMemsetAsync(d.step, 0, sizeof(double) * 3 * (size_t)n_poses, st));
+  // the host arrays above must outlive the copies
+  PG_TRY(hipStreamSynchronize(st));
+
+  const int robust = opt->use_robust_loss ? 1 : 0;
+  double h_scal[8];
+  int32_t h_flags[4];
+  int cur = 0;
+  auto eval_edges = [&](const double* xp, int b, int slot) {
+    hipLaunchKernelGGL(k_pg_edges, dim3(grid_for(nu, 256)), dim3(256), 0, st, d, xp, b, robust, opt->loss_scale);
+    PgReduce R{};
+    R.in[0] = d.cost_e[b]; R.n[0] = nu; R.slot[0] = slot; R.op[0] = 0;
+    hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(1024), 0, st, R, d.scal);
+  };
+  auto linearize = [&](int b, int first) {
+    hipLaunchKernelGGL(k_pg_pose_diag, dim3(grid_for(n_poses, 256)), dim3(256), 0, st, d, b, first);
+    if (ns > 0) PG_TRY(hipMemsetAsync(d.S0, 0, sizeof(double) * (size_t)ns * ns, st));
+    hipLaunchKernelGGL(k_pg_pose_offdiag, dim3(grid_for(n_poses, 256)), dim3(256), 0, st, d, b);
+    PgReduce R{};
+    R.in[0] = d.p_xsq; R.n[0] = n_poses; R.slot[0] = 4; R.op[0] = 0;
+    R.in[1] = d.p_gabs; R.n[1] = n_poses; R.slot[1] = 5; R.op[1] = 1;
+    hipLaunchKernelGGL(k_pg_reduce, dim3(2), dim3(1024), 0, st, R, d.scal);
+  };
+  auto read_back = [&]() {
+    PG_TRY(hipMemcpyAsync(h_scal, d.scal, sizeof(h_scal), hipMemcpyDeviceToHost, st));
+    PG_TRY(hipMemcpyAsync(h_flags, d.flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+    PG_TRY(hipStreamSynchronize(st));
+    PG_TRY(hipGetLastError());
+  };
+
+  // ---- TrustRegionMinimizer::Minimize (host control flow)
+  int term = RANDT_TERM_FAILURE;
+  double radius = opt->initial_radius, decrease_factor = 2.0;
+  bool reuse_diagonal = false, step_successful = true;
+  int num_invalid = 0, iteration = 0, n_it = 1;
+  double minimum_cost = DBL_MAX, summary_min_cost = 0.0;
+  std::vector<double> best(h_poses, h_poses + 3 * (size_t)n_poses), h_x(3 * (size_t)n_poses);
+
+  eval_edges(d.x, cur, 0);
+  linearize(cur, 1);
+  read_back();
+  double x_cost = h_scal[0], x_norm = std::sqrt(h_scal[4]), grad_max_norm = h_scal[5];
+  if (out) out->initial_cost = x_cost;
+  summary_min_cost = x_cost;
+
+  while (rc == RANDT_OK) {
+    if (step_successful && x_cost < minimum_cost) {
+      minimum_cost = x_cost;
+      PG_TRY(hipMemcpyAsync(best.data(), d.x, sizeof(double) * 3 * (size_t)n_poses, hipMemcpyDeviceToHost, st));
+      PG_TRY(hipStreamSynchronize(st));
+    }
+    if (iteration >= opt->max_iterations) { term = RANDT_TERM_NO_CONVERGENCE; break; }
+    if (step_successful && grad_max_norm <= opt->gradient_tolerance) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
+    if (radius <= opt->min_radius) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
+    ++iteration;
+    ++n_it;
+
+    if (!reuse_diagonal)
+      hipLaunchKernelGGL(k_pg_lm_diagonal, dim3(grid_for(n_poses, 256)), dim3(256), 0, st, d, opt->min_lm_diagonal, opt->max_lm_diagonal);
+    const double inv_radius = 1.0 / radius;
+    PG_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d.flags), 1, 4, st));
+    if (n_int > 0) {
+      hipLaunchKernelGGL(k_pg_factor, dim3(1), dim3(64), 0, st, d, inv_radius);
+      hipLaunchKernelGGL(k_pg_chain_solve, dim3(grid_for(ncols, 64)), dim3(64), 0, st, d);
+    }
+    if (ns > 0) {
+      hipLaunchKernelGGL(k_pg_schur, dim3(grid_for((size_t)(ns + 1) * ns, 256)), dim3(256), 0, st, d, inv_radius);
+      hipLaunchKernelGGL(k_pg_dense, dim3(1), dim3(1024), 0, st, d);
+    }
+    hipLaunchKernelGGL(k_pg_backsub, dim3(3 * n_int + ns), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_pg_candidate, dim3(grid_for(n_poses, 256)), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_pg_mcc, dim3(grid_for(nu, 256)), dim3(256), 0, st, d, cur);
+    {
+      PgReduce R{};
+      R.in[0] = d.p_mcc; R.n[0] = nu; R.slot[0] = 2; R.op[0] = 0;
+      R.in[1] = d.p_sn; R.n[1] = n_poses; R.slot[1] = 3; R.op[1] = 0;
+      hipLaunchKernelGGL(k_pg_reduce, dim3(2), dim3(1024), 0, st, R, d.scal);
+    }
+    eval_edges(d.cand, cur ^ 1, 1);  // residuals AND Jacobians at the candidate: reused if the step is accepted
+    read_back();
+    if (rc != RANDT_OK) break;
+    reuse_diagonal = true;
+    const bool solved = h_flags[0] && h_flags[1] && h_flags[2];
+    const double model_cost_change = -h_scal[2];
+    if (!(solved && model_cost_change > 0.0)) {
+      if (++num_invalid >= opt->max_consecutive_invalid_steps) { term = RANDT_TERM_FAILURE; break; }
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      step_successful = false;
+      summary_min_cost = std::min(summary_min_cost, x_cost);
+      continue;
+    }
+    num_invalid = 0;
+    const double cand_cost = h_scal[1];
+    const double step_norm = std::sqrt(h_scal[3]);
+    if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (std::fabs(cost_change) <= opt->function_tolerance * x_cost) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
+    const double relative_decrease = cost_change / model_cost_change;
+    if (relative_decrease > opt->min_relative_decrease) {
+      std::swap(d.x, d.cand);
+      cur ^= 1;
+      x_cost = cand_cost;
+      linearize(cur, 0);
+      read_back();
+      x_norm = std::sqrt(h_scal[4]);
+      grad_max_norm = h_scal[5];
+      step_successful = true;
+      radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+      radius = std::fmin(opt->max_radius, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = false;
+      summary_min_cost = std::min(summary_min_cost, x_cost);
+    } else {
+      step_successful = false;
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      summary_min_cost = std::min(summary_min_cost, cand_cost);
+    }
+  }
+#undef PG_TRY
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(blk);
+  if (rc != RANDT_OK) return rc;
+  memcpy(h_poses, best.data(), sizeof(double) * 3 * (size_t)n_poses);
+  if (out) {
+    out->final_cost = summary_min_cost;
+    out->iterations = n_it;
+    out->termination = term;
+  }
+  return RANDT_OK;
+}

@@ -10,8 +10,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, BnbParams, ClusterParams, FilterParams, MapParams, MatcherParams, ScParams,
-                    WindowParams)
+from ._capi import (CELL_DTYPE, RESULT_DTYPE, STATE_DTYPE, BnbParams, ClusterParams, FilterParams, MapParams, MatcherParams, PgParams, PgResult,
+                    ScParams, WindowParams)
 
 
 class RandtError(RuntimeError):
@@ -340,6 +340,34 @@ def cs_divergence(ctx, fixed, fixed_idx, moving, moving_idx, pose4=None):
     ctx._check(ctx._lib.randt_cs_divergence(ctx._h, fixed._h, int(fixed_idx), moving._h, int(moving_idx),
                                             None if p is None else p.ctypes.data, C.byref(out), terms.ctypes.data), "randt_cs_divergence")
     return out.value, terms
+
+
+# ------------------------------------------------------------------ pose graph (f-4) ----------------
+def pg_params(**over):
+    """Ceres Solver::Options defaults + global_fuser.cpp:52; use_robust_loss / loss_scale = GlobalFuserParameters."""
+    p = PgParams()
+    _capi.load().randt_pg_params_default(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def pose_graph_optimize(ctx, poses, id_begin, id_end, meas, sqrt_info, max_update_index, params=None):
+    """randt_pose_graph_optimize (GlobalFuser::optimizePoseGraph).  poses [N][3] = (x, y, yaw); edges as parallel arrays
+    (meas [E][3] = translation + log angle, sqrt_info [E][3][3]).  Returns (optimised poses, result dict)."""
+    x = np.array(poses, dtype=np.float64, order="C").reshape(-1, 3)
+    ia = np.ascontiguousarray(id_begin, dtype=np.int32)
+    ib = np.ascontiguousarray(id_end, dtype=np.int32)
+    m = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 3)
+    sq = np.ascontiguousarray(sqrt_info, dtype=np.float64).reshape(-1, 9)
+    if not (len(ia) == len(ib) == len(m) == len(sq)):
+        raise ValueError("edge arrays differ in length")
+    p = params if params is not None else pg_params()
+    res = PgResult()
+    ctx._check(ctx._lib.randt_pose_graph_optimize(ctx._h, len(x), x.ctypes.data, len(ia), ia.ctypes.data, ib.ctypes.data, m.ctypes.data,
+                                                  sq.ctypes.data, int(max_update_index), C.byref(p), C.byref(res)),
+               "randt_pose_graph_optimize")
+    return x, {k: getattr(res, k) for k, _ in PgResult._fields_}
 
 
 # ------------------------------------------------------------------ Scan Context (f-4) --------------

@@ -37,11 +37,11 @@ def test_struct_layouts_match_c(tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "randt.h"\n'
-        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(randt_cell), sizeof(randt_result),"
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(randt_cell), sizeof(randt_result),"
         " sizeof(randt_map_params), sizeof(randt_cluster_params), sizeof(randt_matcher_params),"
         " offsetof(randt_result, n_residuals), offsetof(randt_matcher_params, function_tolerance),"
         " offsetof(randt_cell, n), sizeof(randt_sc_params), offsetof(randt_sc_params, search_ratio),"
-        " sizeof(randt_filter_params), sizeof(randt_bnb_params)); return 0;}\n"
+        " sizeof(randt_filter_params), sizeof(randt_bnb_params), sizeof(randt_pg_params), sizeof(randt_pg_result)); return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -56,6 +56,7 @@ def test_struct_layouts_match_c(tmp_path):
     assert out[7] == _capi.CELL_DTYPE.fields["n"][1]
     assert out[8] == C.sizeof(_capi.ScParams) and out[9] == _capi.ScParams.search_ratio.offset
     assert out[10] == C.sizeof(_capi.FilterParams) and out[11] == C.sizeof(_capi.BnbParams)
+    assert out[12] == C.sizeof(_capi.PgParams) and out[13] == C.sizeof(_capi.PgResult)
 
 
 def test_defaults_are_the_indoor_loop_closure_values():
