@@ -9,17 +9,22 @@
 //   * "separator" poses = variable poses touched by an edge that is not chain-adjacent (|i - j| != 1) to another
 //     variable pose; everything else is "interior".  Interior poses, in id order, form a block-tridiagonal system T
 //     (3x3 blocks; the chain simply breaks where a separator sits between two interiors).
-//   * T = L L^T is factorised by one lane walking the chain (k_pg_factor); then ONE LANE PER RIGHT-HAND SIDE solves
-//     T W = [C | g_int] for the 3 n_sep coupling columns and the gradient at once (k_pg_chain_solve, W is
-//     [3 n_int][3 n_sep + 1] in HBM, column index fastest so a wavefront's accesses coalesce);
-//   * the Schur complement S - C^T W on the separators is a small dense SPD system: one workgroup factorises it in
-//     place (k_pg_dense) and back-substitutes; interiors follow from W (k_pg_backsub).
+//   * T = L L^T is block diagonal over the chain SEGMENTS between separators: one lane per segment factorises it
+//     (k_pg_factor) and one lane per (segment, right-hand side) solves T W = [C | g_int] (k_pg_chain_solve) -- a separator
+//     couples only to the two interiors next to it, so a segment has just seven right-hand sides and W is [3 n_int][8].
+//     Long runs are cut by extra separators every 128 poses so that the serial recurrences stay short;
+//   * the Schur complement S - C^T W on the separators is a dense SPD system (k_pg_schur): right-looking blocked Cholesky
+//     over the whole device -- per 32-column panel a diagonal-block factor (k_pg_potrf), a panel solve (k_pg_trsm) and a
+//     tiled trailing update (k_pg_syrk); the right-hand side rides along as an extra row; k_pg_trsv back-substitutes and
+//     k_pg_backsub recovers the interiors from W.
 // That is block Cholesky in a nested-dissection order -- no Woodbury-style cancellation when loop closures carry
 // weights of 4e4 (parameters_indoor.yaml:10).  Everything is fp64 and deterministic (gathers through host-built
 // incidence lists and fixed-order reductions; no floating-point atomics).
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -32,14 +37,15 @@ using randt_solve::fast_rcp;
 using randt_solve::fast_rsqrt;
 
 struct PgDev {
-  int n_poses, n_edges, n_int, n_sep, ncols, ns;
+  int n_poses, n_edges, n_int, n_sep, ns;
   const int32_t *ia, *ib;
   const double *meas, *sqi;
   const int32_t *inc_off, *inc_ent;  // per pose: incident (edge << 1 | side) entries, ascending edge order
   const int32_t *is_var, *int_of, *sep_of;
   const int32_t *int_pose, *sep_pose;
-  const int32_t *link;         // interior m and m+1 are chain-adjacent poses
-  const int32_t *sepL, *sepR;  // interior m: separator index of pose-1 / pose+1, or -1
+  int n_seg;
+  const int32_t *seg_first, *seg_len;  // maximal runs of chain-adjacent interiors
+  const int32_t *bndL, *bndR;  // interior m: separator bounding its segment on the left / right, or -1
   const int32_t *nbL, *nbR;    // separator q: interior index of pose-1 / pose+1, or -1
   double *x, *cand;
   double *r[2], *Ja[2], *Jb[2], *cost_e[2];
@@ -253,35 +259,34 @@ __global__ __launch_bounds__(256) void k_pg_lm_diagonal(PgDev d, double dmin, do
   d.diagonal[3 * (size_t)v + 2] = fmin(fmax(Ds[5], dmin), dmax);
 }
 
-// Block-tridiagonal Cholesky along the interior chain: a strictly serial recurrence of 3x3 blocks, walked by one lane
-// with the next block's operands loaded ahead of the arithmetic that depends on the previous block.
+// Block-tridiagonal Cholesky, one lane per chain segment (the chain breaks at every separator): a strictly serial
+// recurrence of 3x3 blocks with the next block's operands loaded ahead of the arithmetic that depends on the previous one.
 __global__ __launch_bounds__(64) void k_pg_factor(PgDev d, double inv_radius) {
-  if (threadIdx.x != 0) return;
-  const int n = d.n_int;
+  const int sgi = blockIdx.x * 64 + threadIdx.x;
+  if (sgi >= d.n_seg) return;
+  const int m0 = d.seg_first[sgi], n = d.seg_len[sgi];
   double F[9];
   bool prev = false;
   int ok = 1;
   double a[6], dg[3], En[9];
-  int lk = 0;
   auto load = [&](int m) {
     const int v = d.int_pose[m];
 #pragma unroll
     for (int i = 0; i < 6; ++i) a[i] = d.Ds[6 * (size_t)v + i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) dg[i] = d.diagonal[3 * (size_t)v + i];
-    lk = d.link[m];
 #pragma unroll
     for (int i = 0; i < 9; ++i) En[i] = d.E[9 * (size_t)m + i];
   };
-  if (n > 0) load(0);
-  for (int m = 0; m < n; ++m) {
+  load(m0);
+  for (int t = 0; t < n; ++t) {
+    const int m = m0 + t;
     double a00 = a[0] + dg[0] * inv_radius, a10 = a[1], a20 = a[2];
     double a11 = a[3] + dg[1] * inv_radius, a21 = a[4], a22 = a[5] + dg[2] * inv_radius;
     double Ec[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Ec[i] = En[i];
-    const int lkc = lk;
-    if (m + 1 < n) load(m + 1);
+    if (t + 1 < n) load(m + 1);
     if (prev) {
       a00 -= F[0] * F[0] + F[1] * F[1] + F[2] * F[2];
       a10 -= F[3] * F[0] + F[4] * F[1] + F[5] * F[2];
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(64) void k_pg_factor(PgDev d, double inv_radius) {
     double* Lf = d.Lf + 9 * (size_t)m;
     Lf[0] = l00; Lf[1] = l10; Lf[2] = l11; Lf[3] = l20; Lf[4] = l21; Lf[5] = l22; Lf[6] = i00; Lf[7] = i11; Lf[8] = i22;
     double* Ff = d.Ff + 9 * (size_t)m;
-    if (lkc) {
+    if (t + 1 < n) {  // inside a segment consecutive interiors are chain-adjacent by construction
 #pragma unroll
       for (int i = 0; i < 3; ++i) {  // row i of F solves F L^T = E
         const double x0 = Ec[i * 3 + 0] * i00;
@@ -317,38 +322,41 @@ __global__ __launch_bounds__(64) void k_pg_factor(PgDev d, double inv_radius) {
     } else {
 #pragma unroll
       for (int i = 0; i < 9; ++i) Ff[i] = 0.0;
-      prev = false;
     }
   }
-  d.flags[0] = ok;
+  if (!ok) d.flags[0] = 0;
 }
 
-// T W = [C | g_int]: one lane per right-hand side, all lanes walking the chain together.  The factor blocks are the
-// same for every lane (scalar loads); W's accesses are consecutive across lanes.
+// T W = [C | g_int], segment by segment.  T is block diagonal over segments and a separator couples only to the last
+// interior of the segment on its left and the first interior of the segment on its right, so each segment has just seven
+// right-hand sides: three for its left-bounding separator, three for its right-bounding one, and the gradient.
+// One lane per (segment, right-hand side); W is [3 n_int][8].
 __global__ __launch_bounds__(64) void k_pg_chain_solve(PgDev d) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= d.ncols) return;
-  const int n = d.n_int, nc = d.ncols;
-  const bool isg = c == nc - 1;
-  const int q = c / 3, j = c - 3 * q;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int sgi = t >> 3, col = t & 7;
+  if (sgi >= d.n_seg || col == 7) return;
+  const int m0 = d.seg_first[sgi], n = d.seg_len[sgi], mlast = m0 + n - 1;
+  const bool left = col < 3, right = col >= 3 && col < 6;
+  const bool empty = (left && d.bndL[m0] < 0) || (right && d.bndR[m0] < 0);
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-  for (int m = 0; m < n; ++m) {
-    double b0, b1, b2;
-    if (isg) {
+  for (int m = m0; m <= mlast; ++m) {
+    double* w = d.W + (size_t)(3 * m) * 8 + col;
+    if (empty) {
+      w[0] = w[8] = w[16] = 0.0;
+      continue;
+    }
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+    if (col == 6) {
       const int v = d.int_pose[m];
       b0 = d.gs[3 * (size_t)v + 0]; b1 = d.gs[3 * (size_t)v + 1]; b2 = d.gs[3 * (size_t)v + 2];
-    } else {
-      b0 = b1 = b2 = 0.0;
-      if (d.sepL[m] == q) {
-        const double* C = d.CL + 9 * (size_t)m;
-        b0 += C[0 + j]; b1 += C[3 + j]; b2 += C[6 + j];
-      }
-      if (d.sepR[m] == q) {
-        const double* C = d.CR + 9 * (size_t)m;
-        b0 += C[0 + j]; b1 += C[3 + j]; b2 += C[6 + j];
-      }
+    } else if (left && m == m0) {
+      const double* C = d.CL + 9 * (size_t)m;
+      b0 = C[0 + col]; b1 = C[3 + col]; b2 = C[6 + col];
+    } else if (right && m == mlast) {
+      const double* C = d.CR + 9 * (size_t)m;
+      b0 = C[0 + col - 3]; b1 = C[3 + col - 3]; b2 = C[6 + col - 3];
     }
-    if (m > 0 && d.link[m - 1]) {
+    if (m > m0) {
       const double* F = d.Ff + 9 * (size_t)(m - 1);
       b0 -= F[0] * y0 + F[1] * y1 + F[2] * y2;
       b1 -= F[3] * y0 + F[4] * y1 + F[5] * y2;
@@ -358,14 +366,14 @@ __global__ __launch_bounds__(64) void k_pg_chain_solve(PgDev d) {
     y0 = b0 * L[6];
     y1 = (b1 - L[1] * y0) * L[7];
     y2 = (b2 - L[3] * y0 - L[4] * y1) * L[8];
-    double* w = d.W + (size_t)(3 * m) * nc + c;
-    w[0] = y0; w[nc] = y1; w[2 * (size_t)nc] = y2;
+    w[0] = y0; w[8] = y1; w[16] = y2;
   }
+  if (empty) return;
   double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-  for (int m = n - 1; m >= 0; --m) {
-    double* w = d.W + (size_t)(3 * m) * nc + c;
-    double t0 = w[0], t1 = w[nc], t2 = w[2 * (size_t)nc];
-    if (d.link[m]) {  // (L^T)[m, m+1] = F_m^T
+  for (int m = mlast; m >= m0; --m) {
+    double* w = d.W + (size_t)(3 * m) * 8 + col;
+    double t0 = w[0], t1 = w[8], t2 = w[16];
+    if (m < mlast) {  // (L^T)[m, m+1] = F_m^T
       const double* F = d.Ff + 9 * (size_t)m;
       t0 -= F[0] * x0 + F[3] * x1 + F[6] * x2;
       t1 -= F[1] * x0 + F[4] * x1 + F[7] * x2;
@@ -375,111 +383,216 @@ __global__ __launch_bounds__(64) void k_pg_chain_solve(PgDev d) {
     x2 = t2 * L[8];
     x1 = (t1 - L[4] * x2) * L[7];
     x0 = (t0 - L[1] * x1 - L[3] * x2) * L[6];
-    w[0] = x0; w[nc] = x1; w[2 * (size_t)nc] = x2;
+    w[0] = x0; w[8] = x1; w[16] = x2;
   }
 }
 
-// (C^T W)[r][wcol] for separator scalar r: only the (at most two) interior chain neighbours of r's pose contribute.
-__device__ __forceinline__ double pg_ctw(const PgDev& d, int r, int wcol) {
-  const int q = r / 3, jr = r - 3 * q;
+// (C^T W) entry for separator scalar (q, jr) against the column of separator scalar (qc, jc), or the gradient column if
+// qc < 0: only q's two interior chain neighbours contribute, and only if qc bounds their segment.
+__device__ __forceinline__ double pg_ctw(const PgDev& d, int q, int jr, int qc, int jc) {
   double acc = 0.0;
   const int mL = d.nbL[q], mR = d.nbR[q];
-  if (mL >= 0) {  // interior at pose-1 couples through its CR block
-    const double* C = d.CR + 9 * (size_t)mL;
-    const double* w = d.W + (size_t)(3 * mL) * d.ncols + wcol;
-    acc += C[0 + jr] * w[0] + C[3 + jr] * w[d.ncols] + C[6 + jr] * w[2 * (size_t)d.ncols];
+  if (mL >= 0) {  // interior at pose-1: last of its segment, coupled through its CR block; q is that segment's right bound
+    const int col = qc < 0 ? 6 : (qc == q ? 3 + jc : (qc == d.bndL[mL] ? jc : -1));
+    if (col >= 0) {
+      const double* C = d.CR + 9 * (size_t)mL;
+      const double* w = d.W + (size_t)(3 * mL) * 8 + col;
+      acc += C[0 + jr] * w[0] + C[3 + jr] * w[8] + C[6 + jr] * w[16];
+    }
   }
-  if (mR >= 0) {
-    const double* C = d.CL + 9 * (size_t)mR;
-    const double* w = d.W + (size_t)(3 * mR) * d.ncols + wcol;
-    acc += C[0 + jr] * w[0] + C[3 + jr] * w[d.ncols] + C[6 + jr] * w[2 * (size_t)d.ncols];
+  if (mR >= 0) {  // interior at pose+1: first of its segment, coupled through its CL block; q is that segment's left bound
+    const int col = qc < 0 ? 6 : (qc == q ? jc : (qc == d.bndR[mR] ? 3 + jc : -1));
+    if (col >= 0) {
+      const double* C = d.CL + 9 * (size_t)mR;
+      const double* w = d.W + (size_t)(3 * mR) * 8 + col;
+      acc += C[0 + jr] * w[0] + C[3 + jr] * w[8] + C[6 + jr] * w[16];
+    }
   }
   return acc;
 }
 
 // Schur complement on the separators, lower triangle, with the right-hand side stored as an extra ROW ns so that the
-// factorisation's trailing updates forward-substitute it for free.
+// factorisation's panel solves and trailing updates forward-substitute it for free.
 __global__ __launch_bounds__(256) void k_pg_schur(PgDev d, double inv_radius) {
   const int ns = d.ns;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)(ns + 1) * ns) return;
-  const int r = (int)(idx / ns), c = (int)(idx - (size_t)r * ns);
+  const int r = (int)(idx / (unsigned)ns), c = (int)(idx - (size_t)r * ns);
   if (r < ns) {
     if (c > r) return;
     double val = d.S0[(size_t)r * ns + c];
     if (r == c) val += d.diagonal[3 * (size_t)d.sep_pose[r / 3] + (r % 3)] * inv_radius;
-    if (d.n_int > 0) val -= pg_ctw(d, r, c);
+    if (d.n_int > 0) val -= pg_ctw(d, r / 3, r % 3, c / 3, c % 3);
     d.Sw[(size_t)r * ns + c] = val;
   } else {
     double val = d.gs[3 * (size_t)d.sep_pose[c / 3] + (c % 3)];
-    if (d.n_int > 0) val -= pg_ctw(d, c, ns);
+    if (d.n_int > 0) val -= pg_ctw(d, c / 3, c % 3, -1, 0);
     d.Sw[(size_t)ns * ns + c] = val;
   }
 }
 
-// Dense Cholesky of the Schur complement by one workgroup, in place in HBM/L2 (right-looking, column by column), then
-// the back-substitution.  Row ns carries the right-hand side.
-__global__ __launch_bounds__(1024) void k_pg_dense(PgDev d) {
-  const int n = d.ns, tid = threadIdx.x;
+// ---- dense Cholesky of the Schur complement: right-looking, panels of PG_NB columns, three launches per panel so
+// that the O(ns^3) trailing update is spread over the whole device.  Row ns carries the right-hand side.
+#define PG_NB 32
+
+// (1) factor the diagonal block in LDS (one workgroup, thread (i, k))
+__global__ __launch_bounds__(PG_NB* PG_NB) void k_pg_potrf(PgDev d, int k0) {
+  __shared__ double a[PG_NB][PG_NB + 1];
+  const int n = d.ns, nb = min(PG_NB, n - k0);
+  const int i = threadIdx.x / PG_NB, k = threadIdx.x % PG_NB;
   double* A = d.Sw;
-  __shared__ int s_fail;
-  if (tid == 0) s_fail = 0;
+  a[i][k] = (i < nb && k <= i) ? A[(size_t)(k0 + i) * n + k0 + k] : (i == k ? 1.0 : 0.0);
   __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    const double piv = A[(size_t)j * n + j];
-    if (!(piv > 0.0)) {
-      if (tid == 0) s_fail = 1;
-      break;  // uniform: every lane reads the same pivot
-    }
+  int ok = 1;
+  for (int j = 0; j < PG_NB; ++j) {
+    const double piv = a[j][j];
+    if (!(piv > 0.0)) ok = 0;
+    const double inv = 1.0 / sqrt(piv);
     __syncthreads();
-    const double ljj = sqrt(piv), inv = 1.0 / ljj;
-    for (int i = j + 1 + tid; i <= n; i += 1024) A[(size_t)i * n + j] *= inv;
-    if (tid == 0) A[(size_t)j * n + j] = ljj;
+    if (k == j && i >= j) a[i][j] = (i == j) ? sqrt(piv) : a[i][j] * inv;
     __syncthreads();
-    const int w = n - j - 1;  // trailing columns j+1 .. n-1, rows j+1 .. n
-    if (w > 0) {
-      const size_t total = (size_t)(w + 1) * w;
-      for (size_t t = tid; t < total; t += 1024) {
-        const int ri = (int)(t / w), ci = (int)(t - (size_t)ri * w);
-        if (ci > ri) continue;  // upper triangle (the RHS row ri == w keeps every column)
-        const int i = j + 1 + ri, k = j + 1 + ci;
-        A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
-      }
-    }
+    if (k > j && i >= k) a[i][k] -= a[i][j] * a[k][j];
     __syncthreads();
   }
-  __syncthreads();
-  if (s_fail) {
-    if (tid == 0) d.flags[1] = 0;
-    return;
-  }
-  double* y = A + (size_t)n * n;
-  for (int j = n - 1; j >= 0; --j) {
-    const double zj = y[j] / A[(size_t)j * n + j];
-    __syncthreads();
-    if (tid == 0) d.xsep[j] = zj;
-    for (int i = tid; i < j; i += 1024) y[i] -= A[(size_t)j * n + i] * zj;
-    __syncthreads();
-  }
-  if (tid == 0) d.flags[1] = 1;
+  if (i < nb && k <= i) A[(size_t)(k0 + i) * n + k0 + k] = a[i][k];
+  if (threadIdx.x == 0 && !ok) d.flags[1] = 0;
 }
 
-// Interior unknowns z = W[:, ns] - W[:, :ns] z_sep, one wavefront per scalar row; separators copy z_sep.  step = -z.
-__global__ __launch_bounds__(64) void k_pg_backsub(PgDev d) {
-  const int row = blockIdx.x, lane = threadIdx.x;
-  const int n_rows_int = 3 * d.n_int;
-  if (row < n_rows_int) {
-    const double* w = d.W + (size_t)row * d.ncols;
-    double acc = 0.0;
-    for (int c = lane; c < d.ns; c += 64) acc += w[c] * d.xsep[c];
-    acc = randt_solve::wave_sum(acc);
-    if (lane == 0) {
-      const int m = row / 3;
-      d.step[3 * (size_t)d.int_pose[m] + (row - 3 * m)] = -(w[d.ns] - acc);
+// (2) panel solve: every row below the diagonal block (the right-hand-side row included) becomes row * L^-T.
+// One lane per row; the row's panel entries live in LDS transposed ([column][lane]: conflict-free).
+__global__ __launch_bounds__(64) void k_pg_trsm(PgDev d, int k0) {
+  __shared__ double l[PG_NB][PG_NB + 1];
+  __shared__ double xs[PG_NB][64];
+  const int n = d.ns, nb = min(PG_NB, n - k0), tid = threadIdx.x;
+  double* A = d.Sw;
+  for (int t = tid; t < PG_NB * PG_NB; t += 64) {
+    const int i = t / PG_NB, k = t % PG_NB;
+    l[i][k] = (i < nb && k <= i) ? A[(size_t)(k0 + i) * n + k0 + k] : (i == k ? 1.0 : 0.0);
+  }
+  const int row = k0 + nb + blockIdx.x * 64 + tid;
+  const bool live = row <= n;
+  double* ar = A + (size_t)(live ? row : n) * n + k0;
+  for (int p = 0; p < nb; ++p) xs[p][tid] = live ? ar[p] : 0.0;
+  __syncthreads();
+  for (int p = 0; p < nb; ++p) {
+    double acc = xs[p][tid];
+    for (int q = 0; q < p; ++q) acc -= xs[q][tid] * l[p][q];
+    xs[p][tid] = acc / l[p][p];
+  }
+  if (live)
+    for (int p = 0; p < nb; ++p) ar[p] = xs[p][tid];
+}
+
+// (3) trailing update A[i][j] -= sum_p P[i][p] P[j][p] on 64 x 64 tiles of the lower triangle (4 x 4 outputs per thread)
+__global__ __launch_bounds__(256) void k_pg_syrk(PgDev d, int k0) {
+  __shared__ double pi[64][PG_NB + 1], pj[64][PG_NB + 1];
+  const int n = d.ns, nb = min(PG_NB, n - k0), k1 = k0 + nb;
+  // linear tile index -> (bi >= bj)
+  int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
+  while (bi * (bi + 1) / 2 > (int)blockIdx.x) --bi;
+  const int bj = (int)blockIdx.x - bi * (bi + 1) / 2;
+  const int r0 = k1 + 64 * bi, c0 = k1 + 64 * bj;
+  double* A = d.Sw;
+  for (int t = threadIdx.x; t < 64 * PG_NB; t += 256) {
+    const int rr = t / PG_NB, p = t % PG_NB;
+    pi[rr][p] = (r0 + rr <= n && p < nb) ? A[(size_t)(r0 + rr) * n + k0 + p] : 0.0;
+    pj[rr][p] = (c0 + rr < n && p < nb) ? A[(size_t)(c0 + rr) * n + k0 + p] : 0.0;
+  }
+  __syncthreads();
+  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+#pragma unroll 8
+  for (int p = 0; p < PG_NB; ++p) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) av[u] = pi[ty * 4 + u][p];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bv[v] = pj[tx + 16 * v][p];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = r0 + ty * 4 + u;
+    if (row > n) continue;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int colg = c0 + tx + 16 * v;
+      if (colg >= n || (row < n && colg > row)) continue;
+      A[(size_t)row * n + colg] -= acc[u][v];
     }
-  } else if (lane == 0) {
-    const int r = row - n_rows_int;
-    d.step[3 * (size_t)d.sep_pose[r / 3] + (r % 3)] = -d.xsep[r];
+  }
+}
+
+// L^T z = y (y = row ns after the factorisation), blocks of PG_NB from the bottom: the diagonal block is solved by one
+// wavefront out of LDS, then every remaining y_i takes its update from that block's rows.
+__global__ __launch_bounds__(1024) void k_pg_trsv(PgDev d) {
+  __shared__ double l[PG_NB][PG_NB + 1];
+  __shared__ double z[PG_NB];
+  const int n = d.ns, tid = threadIdx.x;
+  double* A = d.Sw;
+  double* y = A + (size_t)n * n;
+  const int nblk = (n + PG_NB - 1) / PG_NB;
+  for (int blk = nblk - 1; blk >= 0; --blk) {
+    const int k0 = blk * PG_NB, nb = min(PG_NB, n - k0);
+    {
+      const int i = tid / PG_NB, k = tid % PG_NB;
+      l[i][k] = (i < nb && k <= i) ? A[(size_t)(k0 + i) * n + k0 + k] : (i == k ? 1.0 : 0.0);
+    }
+    if (tid < PG_NB) z[tid] = tid < nb ? y[k0 + tid] : 0.0;
+    __syncthreads();
+    if (tid < 64) {  // lane i holds z_i; the pivot value travels by lane broadcast
+      double zr = tid < PG_NB ? z[tid] : 0.0;
+#pragma unroll
+      for (int j = PG_NB - 1; j >= 0; --j) {
+        const double zj = __shfl(zr, j, 64) / l[j][j];
+        if (tid < j) zr -= l[j][tid] * zj;
+        if (tid == j) zr = zj;
+      }
+      if (tid < PG_NB) z[tid] = zr;
+    }
+    __syncthreads();
+    if (tid < nb) d.xsep[k0 + tid] = z[tid];
+    for (int i = tid; i < k0; i += 1024) {
+      double acc = y[i];
+      for (int p = 0; p < nb; ++p) acc -= A[(size_t)(k0 + p) * n + i] * z[p];
+      y[i] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// Interior unknowns z = W[:, g] - W[:, left] z_left - W[:, right] z_right, one thread per interior pose; separators copy
+// z_sep.  step = -z.
+__global__ __launch_bounds__(256) void k_pg_backsub(PgDev d) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < d.n_int) {
+    const int bl = d.bndL[t], br = d.bndR[t];
+    double zl[3] = {0, 0, 0}, zr[3] = {0, 0, 0};
+    if (bl >= 0)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) zl[j] = d.xsep[3 * bl + j];
+    if (br >= 0)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) zr[j] = d.xsep[3 * br + j];
+    const int v = d.int_pose[t];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double* w = d.W + (size_t)(3 * t + i) * 8;
+      const double z = w[6] - (w[0] * zl[0] + w[1] * zl[1] + w[2] * zl[2]) - (w[3] * zr[0] + w[4] * zr[1] + w[5] * zr[2]);
+      d.step[3 * (size_t)v + i] = -z;
+    }
+  } else if (t < d.n_int + d.n_sep) {
+    const int q = t - d.n_int;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d.step[3 * (size_t)d.sep_pose[q] + i] = -d.xsep[3 * q + i];
   }
 }
 
@@ -594,11 +707,21 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
   if (out) out->n_residual_blocks = nu;
   if (nu == 0 || n_var == 0) return RANDT_OK;
 
-  // ---- elimination order: separators last
+  // ---- elimination order: separators last.  Besides the poses loop closures touch, every seg_cap-th pose of a long
+  // uninterrupted run becomes a separator too: the chain recurrences are serial, so shorter segments = more lanes busy.
   std::vector<int32_t> is_sep(n_poses, 0);
   for (int e = 0; e < nu; ++e) {
     const int a = ia[e], b = ib[e];
     if (is_var[a] && is_var[b] && std::abs(a - b) != 1) is_sep[a] = is_sep[b] = 1;
+  }
+  {
+    int seg_cap = 128;
+    if (const char* env = getenv("RANDT_PG_SEGMENT")) seg_cap = std::max(2, atoi(env));
+    int run = 0;
+    for (int i = 0; i < n_poses; ++i) {
+      if (!is_var[i] || is_sep[i]) { run = 0; continue; }
+      if (++run > seg_cap) { is_sep[i] = 1; run = 0; }
+    }
   }
   std::vector<int32_t> int_of(n_poses, -1), sep_of(n_poses, -1), int_pose, sep_pose;
   for (int i = 0; i < n_poses; ++i) {
@@ -612,24 +735,28 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
     }
   }
   const int n_int = (int)int_pose.size(), n_sep = (int)sep_pose.size();
-  const int ns = 3 * n_sep, ncols = ns + 1;
+  const int ns = 3 * n_sep;
   if (out) out->n_separator_poses = n_sep;
   if (n_sep > RANDT_PG_MAX_SEPARATORS)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "pose graph: too many loop-closure poses for the dense Schur complement", hipSuccess);
-  std::vector<int32_t> link(n_int > 0 ? n_int : 1, 0), sepL(n_int > 0 ? n_int : 1, -1), sepR(n_int > 0 ? n_int : 1, -1);
+  std::vector<int32_t> seg_first, seg_len, bndL(n_int > 0 ? n_int : 1, -1), bndR(n_int > 0 ? n_int : 1, -1);
   std::vector<int32_t> nbL(n_sep > 0 ? n_sep : 1, -1), nbR(n_sep > 0 ? n_sep : 1, -1);
-  for (int m = 0; m < n_int; ++m) {
-    const int v = int_pose[m];
-    link[m] = (m + 1 < n_int && int_pose[m + 1] == v + 1) ? 1 : 0;
-    if (v - 1 >= 0 && sep_of[v - 1] >= 0) {
-      sepL[m] = sep_of[v - 1];
-      nbR[sep_of[v - 1]] = m;
+  for (int m = 0; m < n_int;) {
+    int len = 1;
+    while (m + len < n_int && int_pose[m + len] == int_pose[m + len - 1] + 1) ++len;
+    const int vf = int_pose[m], vl = int_pose[m + len - 1];
+    const int ql = (vf - 1 >= 0) ? sep_of[vf - 1] : -1, qr = (vl + 1 < n_poses) ? sep_of[vl + 1] : -1;
+    for (int t = 0; t < len; ++t) {
+      bndL[m + t] = ql;
+      bndR[m + t] = qr;
     }
-    if (v + 1 < n_poses && sep_of[v + 1] >= 0) {
-      sepR[m] = sep_of[v + 1];
-      nbL[sep_of[v + 1]] = m;
-    }
+    if (ql >= 0) nbR[ql] = m;
+    if (qr >= 0) nbL[qr] = m + len - 1;
+    seg_first.push_back(m);
+    seg_len.push_back(len);
+    m += len;
   }
+  const int n_seg = (int)seg_first.size();
   // incidence lists (ascending edge order per pose)
   std::vector<int32_t> inc_off(n_poses + 1, 0), inc_ent(2 * (size_t)nu);
   for (int e = 0; e < nu; ++e) {
@@ -647,8 +774,8 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
 
   // ---- device block
   PgDev d{};
-  d.n_poses = n_poses; d.n_edges = nu; d.n_int = n_int; d.n_sep = n_sep; d.ncols = ncols; d.ns = ns;
-  int32_t *d_ia, *d_ib, *d_inc_off, *d_inc_ent, *d_is_var, *d_int_of, *d_sep_of, *d_int_pose, *d_sep_pose, *d_link, *d_sepL, *d_sepR,
+  d.n_poses = n_poses; d.n_edges = nu; d.n_int = n_int; d.n_sep = n_sep; d.ns = ns; d.n_seg = n_seg;
+  int32_t *d_ia, *d_ib, *d_inc_off, *d_inc_ent, *d_is_var, *d_int_of, *d_sep_of, *d_int_pose, *d_sep_pose, *d_seg_first, *d_seg_len, *d_bndL, *d_bndR,
       *d_nbL, *d_nbR;
   double *d_meas, *d_sqi;
   Carver cv;
@@ -658,7 +785,8 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
     d_inc_off = cv.take<int32_t>(n_poses + 1); d_inc_ent = cv.take<int32_t>(2 * (size_t)nu);
     d_is_var = cv.take<int32_t>(n_poses); d_int_of = cv.take<int32_t>(n_poses); d_sep_of = cv.take<int32_t>(n_poses);
     d_int_pose = cv.take<int32_t>(n_int); d_sep_pose = cv.take<int32_t>(n_sep);
-    d_link = cv.take<int32_t>(n_int); d_sepL = cv.take<int32_t>(n_int); d_sepR = cv.take<int32_t>(n_int);
+    d_seg_first = cv.take<int32_t>(n_seg); d_seg_len = cv.take<int32_t>(n_seg);
+    d_bndL = cv.take<int32_t>(n_int); d_bndR = cv.take<int32_t>(n_int);
     d_nbL = cv.take<int32_t>(n_sep); d_nbR = cv.take<int32_t>(n_sep);
     d.x = cv.take<double>(3 * (size_t)n_poses); d.cand = cv.take<double>(3 * (size_t)n_poses);
     for (int b = 0; b < 2; ++b) {
@@ -669,7 +797,7 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
     d.sigma = cv.take<double>(3 * (size_t)n_poses); d.diagonal = cv.take<double>(3 * (size_t)n_poses);
     d.E = cv.take<double>(9 * (size_t)n_int); d.CL = cv.take<double>(9 * (size_t)n_int); d.CR = cv.take<double>(9 * (size_t)n_int);
     d.Lf = cv.take<double>(9 * (size_t)n_int); d.Ff = cv.take<double>(9 * (size_t)n_int);
-    d.W = cv.take<double>(3 * (size_t)n_int * ncols);
+    d.W = cv.take<double>(3 * (size_t)n_int * 8);
     d.S0 = cv.take<double>((size_t)ns * ns); d.Sw = cv.take<double>((size_t)(ns + 1) * ns);
     d.xsep = cv.take<double>(ns); d.step = cv.take<double>(3 * (size_t)n_poses);
     d.p_gabs = cv.take<double>(n_poses); d.p_xsq = cv.take<double>(n_poses); d.p_sn = cv.take<double>(n_poses);
@@ -684,7 +812,7 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
   carve();
   d.ia = d_ia; d.ib = d_ib; d.meas = d_meas; d.sqi = d_sqi; d.inc_off = d_inc_off; d.inc_ent = d_inc_ent;
   d.is_var = d_is_var; d.int_of = d_int_of; d.sep_of = d_sep_of; d.int_pose = d_int_pose; d.sep_pose = d_sep_pose;
-  d.link = d_link; d.sepL = d_sepL; d.sepR = d_sepR; d.nbL = d_nbL; d.nbR = d_nbR;
+  d.seg_first = d_seg_first; d.seg_len = d_seg_len; d.bndL = d_bndL; d.bndR = d_bndR; d.nbL = d_nbL; d.nbR = d_nbR;
 
   hipStream_t st = ctx->stream;
   int rc = RANDT_OK;
@@ -700,7 +828,7 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
   PG_UP(d_int_of, int_of, int32_t); PG_UP(d_sep_of, sep_of, int32_t); PG_UP(d_int_pose, int_pose, int32_t);
   PG_UP(d_sep_pose, sep_pose, int32_t);
   if (n_int > 0) {
-    PG_UP(d_link, link, int32_t); PG_UP(d_sepL, sepL, int32_t); PG_UP(d_sepR, sepR, int32_t);
+    PG_UP(d_seg_first, seg_first, int32_t); PG_UP(d_seg_len, seg_len, int32_t); PG_UP(d_bndL, bndL, int32_t); PG_UP(d_bndR, bndR, int32_t);
   }
   if (n_sep > 0) {
     PG_UP(d_nbL, nbL, int32_t); PG_UP(d_nbR, nbR, int32_t);
@@ -769,14 +897,21 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
     const double inv_radius = 1.0 / radius;
     PG_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d.flags), 1, 4, st));
     if (n_int > 0) {
-      hipLaunchKernelGGL(k_pg_factor, dim3(1), dim3(64), 0, st, d, inv_radius);
-      hipLaunchKernelGGL(k_pg_chain_solve, dim3(grid_for(ncols, 64)), dim3(64), 0, st, d);
+      hipLaunchKernelGGL(k_pg_factor, dim3(grid_for(n_seg, 64)), dim3(64), 0, st, d, inv_radius);
+      hipLaunchKernelGGL(k_pg_chain_solve, dim3(grid_for((size_t)n_seg * 8, 64)), dim3(64), 0, st, d);
     }
     if (ns > 0) {
       hipLaunchKernelGGL(k_pg_schur, dim3(grid_for((size_t)(ns + 1) * ns, 256)), dim3(256), 0, st, d, inv_radius);
-      hipLaunchKernelGGL(k_pg_dense, dim3(1), dim3(1024), 0, st, d);
+      for (int k0 = 0; k0 < ns; k0 += PG_NB) {
+        const int nb = std::min(PG_NB, ns - k0), below = ns - (k0 + nb) + 1;  // rows under the block, RHS row included
+        hipLaunchKernelGGL(k_pg_potrf, dim3(1), dim3(PG_NB * PG_NB), 0, st, d, k0);
+        hipLaunchKernelGGL(k_pg_trsm, dim3(grid_for(below, 64)), dim3(64), 0, st, d, k0);
+        const int tiles = (below + 63) / 64;
+        hipLaunchKernelGGL(k_pg_syrk, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, st, d, k0);
+      }
+      hipLaunchKernelGGL(k_pg_trsv, dim3(1), dim3(1024), 0, st, d);
     }
-    hipLaunchKernelGGL(k_pg_backsub, dim3(3 * n_int + ns), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_pg_backsub, dim3(grid_for(n_int + n_sep, 256)), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_pg_candidate, dim3(grid_for(n_poses, 256)), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_pg_mcc, dim3(grid_for(nu, 256)), dim3(256), 0, st, d, cur);
     {
@@ -789,6 +924,9 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
     read_back();
     if (rc != RANDT_OK) break;
     reuse_diagonal = true;
+    if (getenv("RANDT_PG_DEBUG"))
+      fprintf(stderr, "[pg] it %d radius %.3e flags %d %d %d cost %.9e cand %.9e mcc %.6e step2 %.3e n_int %d n_sep %d n_seg %d\n", iteration,
+              radius, h_flags[0], h_flags[1], h_flags[2], x_cost, h_scal[1], -h_scal[2], h_scal[3], n_int, n_sep, n_seg);
     const bool solved = h_flags[0] && h_flags[1] && h_flags[2];
     const double model_cost_change = -h_scal[2];
     if (!(solved && model_cost_change > 0.0)) {

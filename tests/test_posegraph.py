@@ -167,10 +167,14 @@ def test_hip_pose_graph_matches_oracle(built):
     # chain + four loop closures, default (reference) options
     truth, x0, ia, ib, meas, sq = make_graph(120, [(0, 119), (5, 110), (0, 60), (20, 100)], seed=0)
     xg, rg, _, _ = _gpu_vs_oracle(x0, ia, ib, meas, sq, 120)
-    assert rg["n_separator_poses"] == 7 and rg["final_cost"] < rg["initial_cost"] * 1e-3
+    assert rg["n_separator_poses"] == 4 and rg["final_cost"] < rg["initial_cost"] * 1e-3
     # tight tolerances: more iterations, rejected steps included
     kw = dict(function_tolerance=1e-13, parameter_tolerance=1e-12, max_iterations=60)
     _gpu_vs_oracle(x0, ia, ib, meas, sq, 120, po.pg_params(**kw), host.pg_params(**kw))
+    # a run longer than the 128-pose segment cap: extra separators cut it, the step stays the exact Cholesky step
+    truth, x0, ia, ib, meas, sq = make_graph(300, [(4, 290), (150, 20)], seed=12, laps=1.0, radius=25.0)
+    xg, rg, _, _ = _gpu_vs_oracle(x0, ia, ib, meas, sq, 300)
+    assert rg["n_separator_poses"] > 4
     # loop closures with the indoor weight (4e4 * I, parameters_indoor.yaml:10): ill-scaled normal equations
     truth, x0, ia, ib, meas, sq = make_graph(90, [(0, 89), (3, 80), (10, 50)], seed=11, loop_weight=4.0e4)
     _gpu_vs_oracle(x0, ia, ib, meas, sq, 90, tol=1e-6)
