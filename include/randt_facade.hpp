@@ -5,6 +5,8 @@
 //   rc::navigation::ndt::Map      include/ndt_representation/ndt_map.h:14-199
 //   rc::navigation::ndt::Matcher  include/ndt_registration/ndt_matcher.h:46-87
 //   SCManager                     include/local_fuser/Scancontext.h:50-103 (loop-closure candidates)
+//   GlobalFuser / Pose / Constraint  include/global_fuser/global_fuser.h:32-60, include/ndt_slam/
+//                                 trajectory_representation.h:25-52 (pose-graph back end)
 // This header keeps their names, argument meaning and error behaviour (void/double returns, a
 // warning on std::cout, "keep the previous pose" on failure) but is free of Eigen / Sophus / PCL /
 // Ceres: vectors are std::array, poses are the 4 doubles of Sophus::SE2d::data().  A ROS node built
@@ -18,6 +20,8 @@
 #include <cmath>
 #include <cstdint>
 #include <iostream>
+#include <map>
+#include <mutex>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -446,6 +450,99 @@ class SCManager {
  private:
   std::shared_ptr<Context> ctx_;
   randt_sc_db* db_ = nullptr;
+};
+
+// Pose / Constraint (include/ndt_slam/trajectory_representation.h:25-52): graph node and edge.  Matrices row-major.
+struct Pose {
+  SE2d pose;
+  std::array<double, 2> pos{0.0, 0.0};
+  double rot = 0.0;
+  std::array<double, 9> cov{};
+  std::array<double, 4> cov_pos_pos{};
+  std::array<double, 2> cov_pos_rot{};
+  double cov_rot_rot = 0.0;
+  double traversed_dist = 0.0;
+};
+struct Constraint {
+  int id_begin = 0, id_end = 0;
+  SE2d trans;
+  std::array<double, 9> sqrt_information{};
+};
+struct GlobalFuserParameters {  // include/ndt_slam/ndt_slam_parameters.h:134-139
+  double loss_function_scale = 60.0;
+  bool use_robust_loss = false;
+};
+
+// GlobalFuser (include/global_fuser/global_fuser.h:32-60, src/global_fuser/global_fuser.cpp:7-105)
+class GlobalFuser {
+ public:
+  void initialize(const std::shared_ptr<Context>& ctx, GlobalFuserParameters parameters) {
+    ctx_ = ctx;
+    parameters_ = parameters;
+    n_optimized_constraints_ = 0;
+    n_optimized_poses_ = 0;
+  }
+
+  // void optimizePoseGraph(std::map<int, Pose>& poses_ref, const std::vector<Constraint>& edges, std::mutex& poses_mutex,
+  //                        int max_update_index)                                        (global_fuser.cpp:13-105)
+  // Same protocol: copy the nodes under the mutex, optimise the copy, write back keys 0..size-1 under the mutex.  Node
+  // keys must be 0..size-1 (the reference's write-back loop assumes it, :100-102).  On a solver error the nodes are left
+  // as they were and a warning goes to std::cout.
+  void optimizePoseGraph(std::map<int, Pose>& poses_ref, const std::vector<Constraint>& edges, std::mutex& poses_mutex,
+                         int max_update_index) {
+    std::unique_lock<std::mutex> lock(poses_mutex);
+    std::map<int, Pose> poses(poses_ref);
+    lock.unlock();
+    const int n = static_cast<int>(poses.size());
+    const int loop_closures = static_cast<int>(edges.size()) + 1 - n;
+    std::cout << "detected " << loop_closures << " loop closure constraints so far" << std::endl;
+    std::vector<double> x(3 * static_cast<size_t>(n)), meas(3 * edges.size()), sqi(9 * edges.size());
+    std::vector<int32_t> ia(edges.size()), ib(edges.size());
+    for (int i = 0; i < n; ++i) {
+      const Pose& p = poses.at(i);
+      x[3 * i + 0] = p.pos[0];
+      x[3 * i + 1] = p.pos[1];
+      x[3 * i + 2] = p.rot;
+    }
+    for (size_t e = 0; e < edges.size(); ++e) {
+      ia[e] = edges[e].id_begin;
+      ib[e] = edges[e].id_end;
+      meas[3 * e + 0] = edges[e].trans.d[2];
+      meas[3 * e + 1] = edges[e].trans.d[3];
+      meas[3 * e + 2] = edges[e].trans.angle();  // trans.log()(2)
+      std::copy(edges[e].sqrt_information.begin(), edges[e].sqrt_information.end(), sqi.begin() + 9 * e);
+    }
+    randt_pg_params pp;
+    randt_pg_params_default(&pp);
+    pp.use_robust_loss = parameters_.use_robust_loss ? 1 : 0;
+    pp.loss_scale = parameters_.loss_function_scale;
+    randt_pg_result res{};
+    const int rc = randt_pose_graph_optimize(ctx_->get(), n, x.data(), static_cast<int>(edges.size()), ia.data(), ib.data(),
+                                             meas.data(), sqi.data(), max_update_index, &pp, &res);
+    if (rc != RANDT_OK) {
+      std::cout << "pose graph optimization failed: " << randt_last_error(ctx_->get()) << std::endl;
+      return;
+    }
+    std::cout << "Ceres-style report: iterations " << res.iterations << ", initial cost " << res.initial_cost << ", final cost "
+              << res.final_cost << ", termination " << res.termination << '\n';
+    for (int i = 0; i < n; ++i) {
+      Pose& p = poses.at(i);
+      p.pos = {x[3 * i + 0], x[3 * i + 1]};
+      p.rot = x[3 * i + 2];
+      p.pose = SE2d(p.rot, p.pos[0], p.pos[1]);  // Sophus::SE2d(rot, pos) (:85)
+      p.cov = {p.cov_pos_pos[0], p.cov_pos_pos[1], p.cov_pos_rot[0], p.cov_pos_pos[2], p.cov_pos_pos[3], p.cov_pos_rot[1],
+               p.cov_pos_rot[0], p.cov_pos_rot[1], p.cov_rot_rot};  // :86-89
+    }
+    n_optimized_constraints_ = static_cast<int>(edges.size());
+    n_optimized_poses_ = n;
+    lock.lock();
+    for (int i = 0; i < n; ++i) poses_ref.at(i) = poses.at(i);
+  }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  int n_optimized_poses_ = 0, n_optimized_constraints_ = 0;
+  GlobalFuserParameters parameters_;
 };
 
 }  // namespace randt

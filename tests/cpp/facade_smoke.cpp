@@ -148,5 +148,48 @@ int main() {
     std::printf("scan context: %d nodes, query 19 -> %d (yaw %.3f)\n", sc.size(), hit.first, hit.second);
     sc_ok = sc.size() == 20 && early.first == -1 && hit.first == 2;
   }
-  return (ok && kept && win_ok && sc_ok && gate_ok) ? 0 : 2;
+  // pose-graph back end through the GlobalFuser mirror: a drifting square drive closed by one loop constraint
+  bool pg_ok = true;
+  {
+    GlobalFuser gf;
+    gf.initialize(ctx, GlobalFuserParameters{});
+    std::map<int, Pose> nodes;
+    std::vector<Constraint> edges;
+    std::mutex mtx;
+    const int n = 41;
+    SE2d truth, drift;
+    const double kPi = 3.14159265358979323846;
+    for (int i = 0; i < n; ++i) {
+      Pose p;
+      p.pose = drift;
+      p.pos = drift.translation();
+      p.rot = drift.angle();
+      nodes[i] = p;
+      if (i + 1 == n) break;
+      const SE2d step((i % 10 == 9) ? kPi / 2 : 0.0, 1.0, 0.0);      // 10 m sides, left turns: back at the start after 40 steps
+      const SE2d noisy(step.angle() + 0.004, 1.0 + 0.01, 0.003);      // biased odometry
+      Constraint c;
+      c.id_begin = i;
+      c.id_end = i + 1;
+      c.trans = noisy;
+      c.sqrt_information = {10, 0, 0, 0, 10, 0, 0, 0, 50};            // local_fuser.cpp:203-205
+      edges.push_back(c);
+      truth = truth * step;
+      drift = drift * noisy;
+    }
+    Constraint loop;  // node 40 coincides with node 0
+    loop.id_begin = 0;
+    loop.id_end = n - 1;
+    loop.trans = SE2d(0.0, 0.0, 0.0);
+    loop.sqrt_information = {40, 0, 0, 0, 40, 0, 0, 0, 40};
+    edges.push_back(loop);
+    const auto before = nodes.at(n - 1).pos;
+    gf.optimizePoseGraph(nodes, edges, mtx, n - 1);
+    const auto after = nodes.at(n - 1).pos;
+    const double e0 = std::hypot(before[0], before[1]), e1 = std::hypot(after[0], after[1]);
+    std::printf("pose graph: end-point error %.3f m -> %.3f m, node 0 at (%.3f, %.3f)\n", e0, e1, nodes.at(0).pos[0], nodes.at(0).pos[1]);
+    pg_ok = e1 < 0.1 * e0 && nodes.at(0).pos[0] == 0.0 && nodes.at(0).pos[1] == 0.0 &&
+            std::fabs(nodes.at(n - 1).pose.d[2] - after[0]) < 1e-12;
+  }
+  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok) ? 0 : 2;
 }
