@@ -56,6 +56,7 @@ struct PgDev {
   double *E, *CL, *CR;  // per interior: H[m+1, m], H[m, sep(pose-1)], H[m, sep(pose+1)], scaled, row-major 3x3
   double *Lf, *Ff;      // per interior: l00 l10 l11 l20 l21 l22 1/l00 1/l11 1/l22 ; L[m+1, m] row-major
   double *W, *S0, *Sw, *xsep, *step;
+  double* Linv;  // [ceil(ns / PG_NB)][PG_NB][PG_NB] inverses of the factor's diagonal blocks
   double *p_gabs, *p_xsq, *p_sn, *p_mcc;  // per-pose / per-edge partials
   double *scal;                            // [8]: cost cur, cost cand, mcc sum, step norm^2, x norm^2, grad max
   int32_t* flags;                          // [0] factor ok, [1] dense ok, [2] step finite
@@ -435,52 +436,68 @@ __global__ __launch_bounds__(256) void k_pg_schur(PgDev d, double inv_radius) {
 // that the O(ns^3) trailing update is spread over the whole device.  Row ns carries the right-hand side.
 #define PG_NB 32
 
-// (1) factor the diagonal block in LDS (one workgroup, thread (i, k))
+// (1) factor the diagonal block in LDS (one workgroup, thread (i, k)) and invert the factor alongside: the elimination
+// runs in its square-root-free form (one barrier per column: a column is only read, never written, in its own step) and
+// the same row operations applied to the identity give the inverse of the unit factor; both are scaled by D^-1/2 at the end.
+// Writes L over the block and L^-1 (row-major, zero-padded to PG_NB) into Linv[k0 / PG_NB].
 __global__ __launch_bounds__(PG_NB* PG_NB) void k_pg_potrf(PgDev d, int k0) {
   __shared__ double a[PG_NB][PG_NB + 1];
+  __shared__ double m[PG_NB][PG_NB + 1];
   const int n = d.ns, nb = min(PG_NB, n - k0);
   const int i = threadIdx.x / PG_NB, k = threadIdx.x % PG_NB;
   double* A = d.Sw;
   a[i][k] = (i < nb && k <= i) ? A[(size_t)(k0 + i) * n + k0 + k] : (i == k ? 1.0 : 0.0);
+  m[i][k] = i == k ? 1.0 : 0.0;
   __syncthreads();
   int ok = 1;
   for (int j = 0; j < PG_NB; ++j) {
     const double piv = a[j][j];
     if (!(piv > 0.0)) ok = 0;
-    const double inv = 1.0 / sqrt(piv);
-    __syncthreads();
-    if (k == j && i >= j) a[i][j] = (i == j) ? sqrt(piv) : a[i][j] * inv;
-    __syncthreads();
-    if (k > j && i >= k) a[i][k] -= a[i][j] * a[k][j];
+    if (i > j) {
+      const double f = a[i][j] * fast_rcp(piv);
+      if (k > j && k <= i) a[i][k] -= f * a[k][j];
+      if (k <= j) m[i][k] -= f * m[j][k];
+    }
     __syncthreads();
   }
-  if (i < nb && k <= i) A[(size_t)(k0 + i) * n + k0 + k] = a[i][k];
+  const double sk = 1.0 / sqrt(a[k][k]), si = 1.0 / sqrt(a[i][i]);
+  const double lik = k < i ? a[i][k] * sk : (k == i ? sqrt(a[i][i]) : 0.0);  // L = (unit factor) D^1/2
+  const double vik = k <= i ? m[i][k] * si : 0.0;                           // L^-1 = D^-1/2 (unit factor)^-1
+  if (i < nb && k <= i) A[(size_t)(k0 + i) * n + k0 + k] = lik;
+  d.Linv[(size_t)(k0 / PG_NB) * PG_NB * PG_NB + threadIdx.x] = (i < nb && k < nb) ? vik : 0.0;
   if (threadIdx.x == 0 && !ok) d.flags[1] = 0;
 }
 
-// (2) panel solve: every row below the diagonal block (the right-hand-side row included) becomes row * L^-T.
-// One lane per row; the row's panel entries live in LDS transposed ([column][lane]: conflict-free).
-__global__ __launch_bounds__(64) void k_pg_trsm(PgDev d, int k0) {
-  __shared__ double l[PG_NB][PG_NB + 1];
-  __shared__ double xs[PG_NB][64];
+// (2) panel solve: every row below the diagonal block (the right-hand-side row included) becomes row * L^-T -- with the
+// inverse at hand a small matrix product: 64 rows per workgroup, thread = (row, 8 of the 32 columns).
+__global__ __launch_bounds__(256) void k_pg_trsm(PgDev d, int k0) {
+  __shared__ double v[PG_NB][PG_NB + 1];
+  __shared__ double bs[PG_NB][64];
   const int n = d.ns, nb = min(PG_NB, n - k0), tid = threadIdx.x;
   double* A = d.Sw;
-  for (int t = tid; t < PG_NB * PG_NB; t += 64) {
-    const int i = t / PG_NB, k = t % PG_NB;
-    l[i][k] = (i < nb && k <= i) ? A[(size_t)(k0 + i) * n + k0 + k] : (i == k ? 1.0 : 0.0);
+  const double* Li = d.Linv + (size_t)(k0 / PG_NB) * PG_NB * PG_NB;
+  for (int t = tid; t < PG_NB * PG_NB; t += 256) v[t / PG_NB][t % PG_NB] = Li[t];
+  const int r0 = k0 + nb + blockIdx.x * 64;
+  for (int t = tid; t < 64 * PG_NB; t += 256) {
+    const int rr = t / PG_NB, q = t % PG_NB;
+    bs[q][rr] = (r0 + rr <= n && q < nb) ? A[(size_t)(r0 + rr) * n + k0 + q] : 0.0;
   }
-  const int row = k0 + nb + blockIdx.x * 64 + tid;
-  const bool live = row <= n;
-  double* ar = A + (size_t)(live ? row : n) * n + k0;
-  for (int p = 0; p < nb; ++p) xs[p][tid] = live ? ar[p] : 0.0;
   __syncthreads();
-  for (int p = 0; p < nb; ++p) {
-    double acc = xs[p][tid];
-    for (int q = 0; q < p; ++q) acc -= xs[q][tid] * l[p][q];
-    xs[p][tid] = acc / l[p][p];
+  const int rr = tid & 63, pg = tid >> 6;
+  double acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+  for (int q = 0; q < PG_NB; ++q) {
+    const double bq = bs[q][rr];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += bq * v[pg * 8 + u][q];  // v[p][q] = 0 for q > p
   }
-  if (live)
-    for (int p = 0; p < nb; ++p) ar[p] = xs[p][tid];
+  if (r0 + rr <= n) {
+    double* ar = A + (size_t)(r0 + rr) * n + k0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (pg * 8 + u < nb) ar[pg * 8 + u] = acc[u];
+  }
 }
 
 // (3) trailing update A[i][j] -= sum_p P[i][p] P[j][p] on 64 x 64 tiles of the lower triangle (4 x 4 outputs per thread)
@@ -531,38 +548,37 @@ __global__ __launch_bounds__(256) void k_pg_syrk(PgDev d, int k0) {
   }
 }
 
-// L^T z = y (y = row ns after the factorisation), blocks of PG_NB from the bottom: the diagonal block is solved by one
-// wavefront out of LDS, then every remaining y_i takes its update from that block's rows.
+// L^T z = y (y = row ns after the factorisation), blocks of PG_NB from the bottom: z_blk = L_blk^-T y_blk is a product
+// with the stored inverse, then every remaining y_i takes its update from that block's rows.  The next block's inverse is
+// fetched while the update runs.
 __global__ __launch_bounds__(1024) void k_pg_trsv(PgDev d) {
-  __shared__ double l[PG_NB][PG_NB + 1];
-  __shared__ double z[PG_NB];
+  __shared__ double v[PG_NB][PG_NB + 1];
+  __shared__ double yb[PG_NB], z[PG_NB];
   const int n = d.ns, tid = threadIdx.x;
   double* A = d.Sw;
   double* y = A + (size_t)n * n;
   const int nblk = (n + PG_NB - 1) / PG_NB;
+  double vnext = d.Linv[(size_t)(nblk - 1) * PG_NB * PG_NB + tid];
   for (int blk = nblk - 1; blk >= 0; --blk) {
     const int k0 = blk * PG_NB, nb = min(PG_NB, n - k0);
-    {
-      const int i = tid / PG_NB, k = tid % PG_NB;
-      l[i][k] = (i < nb && k <= i) ? A[(size_t)(k0 + i) * n + k0 + k] : (i == k ? 1.0 : 0.0);
-    }
-    if (tid < PG_NB) z[tid] = tid < nb ? y[k0 + tid] : 0.0;
+    v[tid / PG_NB][tid % PG_NB] = vnext;
+    if (tid < PG_NB) yb[tid] = tid < nb ? y[k0 + tid] : 0.0;
     __syncthreads();
-    if (tid < 64) {  // lane i holds z_i; the pivot value travels by lane broadcast
-      double zr = tid < PG_NB ? z[tid] : 0.0;
-#pragma unroll
-      for (int j = PG_NB - 1; j >= 0; --j) {
-        const double zj = __shfl(zr, j, 64) / l[j][j];
-        if (tid < j) zr -= l[j][tid] * zj;
-        if (tid == j) zr = zj;
-      }
-      if (tid < PG_NB) z[tid] = zr;
+    if (blk > 0) vnext = d.Linv[(size_t)(blk - 1) * PG_NB * PG_NB + tid];
+    if (tid < PG_NB) {  // z_j = sum_{i >= j} Linv[i][j] y_i
+      double acc = 0.0;
+      for (int i = tid; i < PG_NB; ++i) acc += v[i][tid] * yb[i];
+      z[tid] = acc;
+      if (tid < nb) d.xsep[k0 + tid] = acc;
     }
     __syncthreads();
-    if (tid < nb) d.xsep[k0 + tid] = z[tid];
     for (int i = tid; i < k0; i += 1024) {
+      double lv[PG_NB];
+#pragma unroll
+      for (int p = 0; p < PG_NB; ++p) lv[p] = A[(size_t)min(k0 + p, n) * n + i];  // all loads in flight; z is zero past nb
       double acc = y[i];
-      for (int p = 0; p < nb; ++p) acc -= A[(size_t)(k0 + p) * n + i] * z[p];
+#pragma unroll
+      for (int p = 0; p < PG_NB; ++p) acc -= lv[p] * z[p];
       y[i] = acc;
     }
     __syncthreads();
@@ -800,6 +816,7 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
     d.W = cv.take<double>(3 * (size_t)n_int * 8);
     d.S0 = cv.take<double>((size_t)ns * ns); d.Sw = cv.take<double>((size_t)(ns + 1) * ns);
     d.xsep = cv.take<double>(ns); d.step = cv.take<double>(3 * (size_t)n_poses);
+    d.Linv = cv.take<double>((size_t)((ns + PG_NB - 1) / PG_NB) * PG_NB * PG_NB);
     d.p_gabs = cv.take<double>(n_poses); d.p_xsq = cv.take<double>(n_poses); d.p_sn = cv.take<double>(n_poses);
     d.p_mcc = cv.take<double>(nu);
     d.scal = cv.take<double>(8); d.flags = cv.take<int32_t>(4);
@@ -905,7 +922,7 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
       for (int k0 = 0; k0 < ns; k0 += PG_NB) {
         const int nb = std::min(PG_NB, ns - k0), below = ns - (k0 + nb) + 1;  // rows under the block, RHS row included
         hipLaunchKernelGGL(k_pg_potrf, dim3(1), dim3(PG_NB * PG_NB), 0, st, d, k0);
-        hipLaunchKernelGGL(k_pg_trsm, dim3(grid_for(below, 64)), dim3(64), 0, st, d, k0);
+        hipLaunchKernelGGL(k_pg_trsm, dim3(grid_for(below, 64)), dim3(256), 0, st, d, k0);
         const int tiles = (below + 63) / 64;
         hipLaunchKernelGGL(k_pg_syrk, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, st, d, k0);
       }

@@ -73,3 +73,72 @@ def test_loop_closure_chain_matches_oracle(built):
             assert lid in (4, 5, 6)
     assert n_loops >= 1
     db.close()
+
+
+def test_loop_closures_pull_a_drifting_drive_back(built):
+    """The whole back half of the reference's loop: Scan Context candidates -> estimateLoopConstraint -> CS gate ->
+    Constraint -> GlobalFuser::optimizePoseGraph (ndt_slam.cpp:351-361), all on the device.  A 1.25-lap circular drive
+    whose odometry drifts; the loop constraints found on the second lap must pull the graph back onto the truth."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    world = synth.make_world()
+    per_lap, n = 48, 60
+    th = 2 * np.pi * np.arange(n) / per_lap
+    truth = np.stack([5.0 * np.cos(th), 5.0 * np.sin(th), th + np.pi / 2], 1)
+    scans = np.stack([synth.make_scan(world, truth[i], 52000 + i) for i in range(n)])
+    # drifting odometry: every relative motion over-rotated by 3 mrad and stretched by 1 %
+    odom = [truth[0].copy()]
+    rels = []
+    for i in range(n - 1):
+        rel = synth.se2_mul3(synth.se2_inv3(truth[i]), truth[i + 1])
+        rel = np.array([rel[0] * 1.01, rel[1] * 1.01, rel[2] + 0.003])
+        rels.append(rel)
+        odom.append(synth.se2_mul3(odom[-1], rel))
+    odom = np.array(odom)
+    dist = np.concatenate([[0.0], np.cumsum(np.linalg.norm(np.diff(odom[:, :2], axis=0), axis=1))])
+    err_before = np.linalg.norm(odom[:, :2] - truth[:, :2], axis=1)
+    assert err_before[-1] > 0.5
+
+    mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
+    mp = R.default_matcher_params(gnc_steps=2)
+    kf = R.Maps(ctx, n, mapp, 512, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(scans).to(dev), clu, kf)
+    db = host.ScDatabase(ctx, host.sc_params(max_radius=20.0, dist_thresh=0.5))
+    ia, ib, meas, sqi = [], [], [], []
+    for i in range(n - 1):
+        ia.append(i); ib.append(i + 1); meas.append(rels[i]); sqi.append(np.diag([10.0, 10.0, 50.0]))   # local_fuser.cpp:203-205
+    n_loops = 0
+    for q in range(n):
+        db.append(scans[q], odom[q, :2], dist[q])
+        lid, yaw, _ = db.detect(q)
+        if lid < 0:
+            continue
+        g4 = np.array([np.cos(-yaw), np.sin(-yaw), 0.0, 0.0])
+        fidx = torch.tensor([lid], dtype=torch.int32, device=dev)
+        pose = torch.from_numpy(g4[None].copy()).to(dev)
+        corr = torch.full((1, 512, mp.n_neighbours), -1, dtype=torch.int32, device=dev)
+        res = torch.zeros((1, 64), dtype=torch.uint8, device=dev)
+        R.associate_batch(ctx, kf, fidx, kf, q, 1, pose, mp, corr)
+        R.solve_batch(ctx, kf, fidx, kf, q, 1, corr, mp, pose, res)
+        ctx.synchronize()
+        p4 = pose.cpu().numpy()[0]
+        cs, _ = host.cs_divergence(ctx, kf, lid, kf, q, p4)
+        if not (cs < 3.6):                                   # loop_closure_max_cs_divergence (parameters_indoor.yaml:8; local_fuser.cpp:340)
+            continue
+        # the registration must have found the true relative pose of the two places
+        want = synth.se2_mul3(synth.se2_inv3(truth[lid]), truth[q])
+        got = synth.pose4_to_pose3(p4)
+        assert np.abs(got[:2] - want[:2]).max() < 0.1 and abs(synth.wrap_angle(got[2] - want[2])) < 0.03
+        ia.append(lid); ib.append(q); meas.append(got); sqi.append(np.eye(3) * 40.0)
+        n_loops += 1
+    db.close()
+    assert n_loops >= 5
+    x, r = host.pose_graph_optimize(ctx, odom, ia, ib, meas, sqi, n - 1)
+    err_after = np.linalg.norm(x[:, :2] - truth[:, :2], axis=1)
+    assert r["n_loop_closures"] == n_loops and r["termination"] in (1, 2, 3)
+    assert err_after.max() < 0.35 * err_before.max() and err_after[-1] < 0.25 * err_before[-1]
+    # and the same graph through the dense CPU oracle lands on the same poses
+    xo, ro = po.pose_graph_optimize(odom, ia, ib, meas, sqi, n - 1)
+    assert np.abs(x - xo).max() < 1e-7 and ro["iterations"] == r["iterations"]
