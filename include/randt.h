@@ -210,6 +210,23 @@ int randt_maps_transform(randt_maps* m, int first, int count, const double* h_po
 int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_first,
                      int n_moving, const double* h_pose4);
 
+/* Cell-by-cell edits and single-cell queries of the reference's Map, host-level conveniences (a few tiny launches and
+ * a synchronisation each; the batched entries above are the hot path):
+ *  - randt_maps_insert_cluster: Map::insertCluster (ndt_map.cpp:238-245) -- ONE cell from all the points
+ *    (Cell::addPointCloud / updateCell), appended if accepted (n > min_points), its mean's slot pointed at it.
+ *    *accepted (nullable) = 1 if a cell was added.  RANDT_ERR_INVALID if the mean lies outside the index grid (the
+ *    reference's std::vector::at throws there).
+ *  - randt_maps_insert_cells: Map::insertCell (ndt_map.h:137-140) for set_grid = 0 (cells appended, index grid
+ *    untouched); set_grid = 1 also points each cell's slot at it (the tail of insertCluster).
+ *  - randt_closest_cells: Map::getClosestCells (ndt_map.cpp:101-151) for n_queries query cells: h_out[q][k] compact
+ *    cell indices in ascending (distance, index) order, -1 padded.  lookup_mahalanobis = 0 is the Vector2f overload
+ *    (Euclidean distance of the query mean to the cell means), 1 the Cell overload (mahalanobisSquaredIntensity). */
+int randt_maps_insert_cluster(randt_maps* m, int idx, const float* h_points, int n_points, int stride_floats,
+                              int intensity_index, int* accepted);
+int randt_maps_insert_cells(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, int set_grid);
+int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_cell* h_queries, int n_queries,
+                        int k, int lookup_mahalanobis, int use_intensity, int32_t* h_out);
+
 /* ------------------------------------------------------------------ association (a7,a8,a10) -- */
 /* Association half of Matcher::addNDTFactor (ndt_matcher.cpp:200-215,249-253) with
  * Map::getClosestCells / getAdjacentIndizes (ndt_map.cpp:101-175) and

@@ -181,6 +181,44 @@ class Map {
     check(randt_ndt_build(ctx_->get(), points, n, stride, intensity_index, &cp, m_, 0), "randt_ndt_build");
   }
 
+  // void insertCluster(const pcl::PointCloud<pcl::PointXYZI>& cluster, const std::vector<...>& angle_dists)
+  //                                                                                    (ndt_map.cpp:238-245)
+  // One cell from all the points of an already separated cluster; appended and indexed if it is accepted.
+  void insertCluster(const float* points, int n, int stride, int intensity_index) {
+    check(randt_maps_insert_cluster(m_, 0, points, n, stride, intensity_index, nullptr), "randt_maps_insert_cluster");
+  }
+  // int insertCell(const Cell& cell): grid_.push_back(cell), index grid untouched (ndt_map.h:137-140)
+  int insertCell(const Cell& cell) {
+    check(randt_maps_insert_cells(m_, 0, &cell.raw(), 1, 0), "randt_maps_insert_cells");
+    return static_cast<int>(get_n_cells()) - 1;
+  }
+  // void update(): Cell::updateCell on every cell (ndt_map.cpp:247-251).  Cells are always held in their updated
+  // form on the device (the build folds addPointCloud + updateCell), so there is nothing left to do.
+  void update() {}
+
+  // unsigned int coordinateToIndex(const Eigen::Vector2f& point) const (ndt_map.h:87-90,181-184): index arithmetic
+  // on the map's geometry, unsigned like the reference's.
+  unsigned int coordinateToIndex(const Vector2f& point) const {
+    const double offset_x = -static_cast<double>(params_.size_x) / 2.0 * params_.resolution + params_.center_x;
+    const double offset_y = -static_cast<double>(params_.size_y) / 2.0 * params_.resolution + params_.center_y;
+    const unsigned int mx = static_cast<unsigned int>((point[0] - offset_x) / params_.resolution);
+    const unsigned int my = static_cast<unsigned int>((point[1] - offset_y) / params_.resolution);
+    return my * static_cast<unsigned int>(params_.size_x) + mx;
+  }
+
+  // void getClosestCells(const Eigen::Vector2f& query_pt, const int& n_neighbours, std::vector<size_t>& indizes) const
+  // void getClosestCells(const Cell& query_cell, const int& n_neighbours, std::vector<size_t>& indizes) const
+  //                                                                                    (ndt_map.cpp:101-151)
+  void getClosestCells(const Vector2f& query_pt, const int& n_neighbours, std::vector<size_t>& indizes) const {
+    randt_cell q{};
+    q.mean[0] = query_pt[0];
+    q.mean[1] = query_pt[1];
+    closest(q, n_neighbours, 0, indizes);
+  }
+  void getClosestCells(const Cell& query_cell, const int& n_neighbours, std::vector<size_t>& indizes) const {
+    closest(query_cell.raw(), n_neighbours, 1, indizes);
+  }
+
   unsigned int get_n_cells() const {
     int32_t n = 0;
     check(randt_maps_counts(m_, 0, 1, &n), "randt_maps_counts");
@@ -250,6 +288,13 @@ class Map {
     if (rc != RANDT_OK)
       throw std::runtime_error(std::string(what) + ": " + randt_status_string(rc) + " (" +
                                (ctx_ ? randt_last_error(ctx_->get()) : "") + ")");
+  }
+  void closest(const randt_cell& q, int n_neighbours, int mahalanobis, std::vector<size_t>& indizes) const {
+    if (n_neighbours <= 0) return;
+    std::vector<int32_t> out(static_cast<size_t>(n_neighbours), -1);
+    check(randt_closest_cells(ctx_->get(), m_, 0, &q, 1, n_neighbours, mahalanobis, 1, out.data()), "randt_closest_cells");
+    for (int32_t v : out)
+      if (v >= 0) indizes.push_back(static_cast<size_t>(v));  // appended, like the reference's push_back
   }
   std::shared_ptr<Context> ctx_;
   randt_map_params params_{};

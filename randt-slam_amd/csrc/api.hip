@@ -346,6 +346,106 @@ int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int str
   return randt_ctx_synchronize(ctx);
 }
 
+// ---------------------------------------------------------------- single-cell / single-cluster map edits --------
+// The reference's Map can also be edited cell by cell (insertCluster, insertCell) and queried for one cell
+// (getClosestCells); these host-level entries keep those calls available.  They are convenience paths (a few tiny
+// launches and a synchronisation each), not the batched hot path.
+static int append_from(randt_maps* m, int idx, const randt_maps* src, int set_grid, int* n_dropped, int* n_outside) {
+  randt_ctx* ctx = m->ctx;
+  int32_t* d_status = nullptr;
+  RANDT_HIP_CHECK(ctx, hipMalloc(&d_status, 2 * sizeof(int32_t)));
+  int rc = launch_maps_append(ctx, m->v, idx, src->v, 0, set_grid, d_status);
+  int32_t h_status[2] = {0, 0};
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(h_status, d_status, sizeof(h_status), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "append status read-back", e);
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(d_status);
+  if (n_dropped) *n_dropped = h_status[0];
+  if (n_outside) *n_outside = h_status[1];
+  return rc;
+}
+
+int randt_maps_insert_cells(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, int set_grid) {
+  if (!range_ok(m, idx, 1) || n_cells < 0 || (n_cells > 0 && !h_cells)) return RANDT_ERR_INVALID;
+  if (n_cells == 0) return RANDT_OK;
+  randt_ctx* ctx = m->ctx;
+  randt_maps* tmp = nullptr;
+  int rc = randt_maps_create(ctx, 1, &m->p, n_cells, 0, &tmp);
+  if (rc) return rc;
+  rc = randt_maps_upload(tmp, 0, h_cells, n_cells, nullptr);
+  int dropped = 0, outside = 0;
+  if (!rc) rc = append_from(m, idx, tmp, set_grid, &dropped, &outside);
+  (void)randt_maps_destroy(tmp);
+  if (rc) return rc;
+  if (outside) return randt_set_error(ctx, RANDT_ERR_INVALID, "cell mean outside the map's index grid", hipSuccess);
+  if (dropped) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "map cell capacity exhausted", hipSuccess);
+  return RANDT_OK;
+}
+
+int randt_maps_insert_cluster(randt_maps* m, int idx, const float* h_points, int n_points, int stride_floats, int intensity_index,
+                              int* accepted) {
+  if (!range_ok(m, idx, 1) || n_points < 0 || (n_points > 0 && !h_points)) return RANDT_ERR_INVALID;
+  if (accepted) *accepted = 0;
+  if (n_points == 0) return RANDT_OK;
+  randt_ctx* ctx = m->ctx;
+  randt_maps* tmp = nullptr;
+  int rc = randt_maps_create(ctx, 1, &m->p, 4, 0, &tmp);
+  if (rc) return rc;
+  // one voxel that swallows every point: row = 1, res = 2 * max_range (grid.cpp:8-13) -> label 0 for |x|, |y| < res
+  randt_cluster_params one;
+  one.n_clusters = 1;
+  one.max_range = 1.0e9f;
+  rc = randt_ndt_build(ctx, h_points, n_points, stride_floats, intensity_index, &one, tmp, 0);
+  int32_t cnt = 0;
+  if (!rc) rc = randt_maps_counts(tmp, 0, 1, &cnt);
+  int dropped = 0, outside = 0;
+  if (!rc && cnt > 0) rc = append_from(m, idx, tmp, 1, &dropped, &outside);
+  (void)randt_maps_destroy(tmp);
+  if (rc) return rc;
+  if (outside) return randt_set_error(ctx, RANDT_ERR_INVALID, "cluster mean outside the map's index grid", hipSuccess);
+  if (dropped) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "map cell capacity exhausted", hipSuccess);
+  if (accepted) *accepted = cnt > 0 ? 1 : 0;
+  return RANDT_OK;
+}
+
+int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_cell* h_queries, int n_queries, int k,
+                        int lookup_mahalanobis, int use_intensity, int32_t* h_out) {
+  if (!ctx || !range_ok(fixed, fixed_idx, 1) || n_queries < 0 || k <= 0) return RANDT_ERR_INVALID;
+  if (n_queries == 0) return RANDT_OK;
+  if (!h_queries || !h_out) return RANDT_ERR_INVALID;
+  randt_maps* tmp = nullptr;
+  int rc = randt_maps_create(ctx, 1, &fixed->p, n_queries, 0, &tmp);
+  if (rc) return rc;
+  rc = randt_maps_upload(tmp, 0, h_queries, n_queries, nullptr);
+  char* d_blk = nullptr;
+  const size_t corr_bytes = sizeof(int32_t) * (size_t)n_queries * k;
+  if (!rc && hipMalloc(&d_blk, 256 + corr_bytes) != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_NOMEM, "hipMalloc", hipErrorOutOfMemory);
+  if (!rc) {
+    const double ident[4] = {1.0, 0.0, 0.0, 0.0};
+    double* d_pose = reinterpret_cast<double*>(d_blk);
+    int32_t* d_fi = reinterpret_cast<int32_t*>(d_blk + 64);
+    int32_t* d_corr = reinterpret_cast<int32_t*>(d_blk + 256);
+    hipError_t e = hipMemcpyAsync(d_pose, ident, sizeof(ident), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_fi, &fixed_idx, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "hipMemcpyAsync", e);
+    if (!rc) rc = launch_associate(ctx, fixed->v, d_fi, tmp->v, 0, 1, d_pose, k, lookup_mahalanobis, use_intensity, d_corr);
+    if (!rc) {
+      e = hipMemcpyAsync(h_out, d_corr, corr_bytes, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "closest cells read-back", e);
+    } else {
+      (void)hipStreamSynchronize(ctx->stream);
+    }
+  }
+  if (d_blk) (void)hipFree(d_blk);
+  (void)randt_maps_destroy(tmp);
+  return rc;
+}
+
 int randt_maps_transform(randt_maps* m, int first, int count, const double* h_pose4) {
   if (!range_ok(m, first, count) || (count > 0 && !h_pose4)) return RANDT_ERR_INVALID;
   if (count == 0) return RANDT_OK;

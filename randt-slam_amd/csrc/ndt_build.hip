@@ -710,6 +710,53 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   return RANDT_OK;
 }
 
+// Map::insertCell / the tail of Map::insertCluster (ndt_map.h:137-140, ndt_map.cpp:242-243): append the cells of one
+// map to another in order; with set_grid the slot of each cell's mean points at its new compact index.  Sequential
+// by construction (a later cell overwrites the slot of an earlier one), so one lane does it.  status[0] counts cells
+// dropped for capacity, status[1] cells whose mean lies outside the index grid (std::vector::at throws there).
+__global__ __launch_bounds__(64) void k_maps_append(MapView dst, int dst_idx, MapView src, int src_idx, int set_grid,
+                                                    int32_t* __restrict__ status) {
+  if (threadIdx.x != 0) return;
+  const int n_src = min(src.counts[src_idx], src.cap);
+  int n = dst.counts[dst_idx];
+  randt_cell* dcells = dst.cells + (size_t)dst_idx * dst.cap;
+  const randt_cell* scells = src.cells + (size_t)src_idx * src.cap;
+  int32_t* grid = dst.grid ? dst.grid + (size_t)dst_idx * dst.n_slots : nullptr;
+  int dropped = 0, outside = 0;
+  for (int i = 0; i < n_src; ++i) {
+    const randt_cell c = load_cell(scells + i);
+    if (set_grid && grid) {
+      const uint32_t slot = coord_to_index(dst, c.mean[0], c.mean[1]);
+      if (slot >= (uint32_t)dst.n_slots) {
+        ++outside;
+        continue;
+      }
+      if (n >= dst.cap) {
+        ++dropped;
+        continue;
+      }
+      grid[slot] = n;
+    } else if (n >= dst.cap) {
+      ++dropped;
+      continue;
+    }
+    store_cell(dcells + n, c);
+    ++n;
+  }
+  dst.counts[dst_idx] = n;
+  if (status) {
+    status[0] = dropped;
+    status[1] = outside;
+  }
+}
+
+int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,
+                       int32_t* d_status) {
+  hipLaunchKernelGGL(k_maps_append, dim3(1), dim3(64), 0, ctx->stream, dst, dst_idx, src, src_idx, set_grid, d_status);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
+
 int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count, const double* d_pose4) {
   if (count <= 0) return RANDT_OK;
   int bx = (m.cap + 255) / 256;

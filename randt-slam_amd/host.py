@@ -186,6 +186,30 @@ class Maps:
         self.ctx._check(self._lib.randt_maps_merge(self._h, fixed_idx, moving._h, moving_first, len(p), _dptr(p)),
                         "randt_maps_merge")
 
+    def insert_cluster(self, idx, points, intensity_index=None):
+        """Map::insertCluster: one cell from all `points` (n, stride) float32; returns True if the cell was accepted."""
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        stride = int(pts.shape[1])
+        ioff = (3 if stride == 4 else 4) if intensity_index is None else intensity_index
+        acc = C.c_int(0)
+        self.ctx._check(self._lib.randt_maps_insert_cluster(self._h, idx, _dptr(pts), len(pts), stride, ioff, C.byref(acc)),
+                        "randt_maps_insert_cluster")
+        return bool(acc.value)
+
+    def insert_cells(self, idx, cells, set_grid=False):
+        """Map::insertCell (set_grid False) or append-and-index (True)."""
+        cells = np.ascontiguousarray(cells, dtype=CELL_DTYPE)
+        self.ctx._check(self._lib.randt_maps_insert_cells(self._h, idx, _dptr(cells), len(cells), 1 if set_grid else 0),
+                        "randt_maps_insert_cells")
+
+    def closest_cells(self, idx, queries, k=4, lookup_mahalanobis=True, use_intensity=True):
+        """Map::getClosestCells for every query cell: (len(queries), k) int32 compact indices, -1 padded."""
+        q = np.ascontiguousarray(queries, dtype=CELL_DTYPE)
+        out = np.full((len(q), k), -1, dtype=np.int32)
+        self.ctx._check(self._lib.randt_closest_cells(self.ctx._h, self._h, idx, _dptr(q), len(q), k, 1 if lookup_mahalanobis else 0,
+                                                      1 if use_intensity else 0, _dptr(out)), "randt_closest_cells")
+        return out
+
     def device_ptrs(self):
         a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self.ctx._check(self._lib.randt_maps_device_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)), "randt_maps_device_ptrs")

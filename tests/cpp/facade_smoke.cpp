@@ -148,6 +148,30 @@ int main() {
     std::printf("scan context: %d nodes, query 19 -> %d (yaw %.3f)\n", sc.size(), hit.first, hit.second);
     sc_ok = sc.size() == 20 && early.first == -1 && hit.first == 2;
   }
+  // cell-by-cell Map API: insertCluster / insertCell / coordinateToIndex / getClosestCells
+  bool edit_ok = true;
+  {
+    Map m;
+    m.initialize(ctx, mp, 0.0, 0.0, 64);
+    std::vector<float> blob;
+    for (int i = 0; i < 30; ++i) blob.insert(blob.end(), {3.1f + 0.01f * (i % 6), 1.2f + 0.012f * (i / 6), 0.f, 40.f + (i % 5)});
+    m.insertCluster(blob.data(), 30, 4, 3);
+    std::vector<float> blob2(blob);
+    for (size_t i = 0; i < blob2.size(); i += 4) blob2[i] += 1.0f;
+    m.insertCluster(blob2.data(), 30, 4, 3);
+    m.insertCluster(blob.data(), 5, 4, 3);  // below the acceptance gate
+    const auto cells = m.getCells();
+    const auto grid = m.getGridIndizes();
+    std::vector<size_t> near_pt, near_cell;
+    m.getClosestCells(Vector2f{4.1f, 1.2f}, 2, near_pt);
+    m.getClosestCells(cells.at(0), 1, near_cell);
+    const int idx0 = (int)m.coordinateToIndex(cells.at(0).getMean());
+    const int pos = m.insertCell(cells.at(0));
+    std::printf("map edit: %u cells, slot of cell 0 -> %d, nearest to (4.1, 1.2): %zu, appended at %d\n", m.get_n_cells(), grid.at(idx0),
+                near_pt.empty() ? (size_t)99 : near_pt[0], pos);
+    edit_ok = cells.size() == 2 && grid.at(idx0) == 0 && near_pt.size() == 2 && near_pt[0] == 1 && near_cell.size() == 1 &&
+              near_cell[0] == 0 && pos == 2 && m.get_n_cells() == 3;
+  }
   // pose-graph back end through the GlobalFuser mirror: a drifting square drive closed by one loop constraint
   bool pg_ok = true;
   {
@@ -191,5 +215,5 @@ int main() {
     pg_ok = e1 < 0.1 * e0 && nodes.at(0).pos[0] == 0.0 && nodes.at(0).pos[1] == 0.0 &&
             std::fabs(nodes.at(n - 1).pose.d[2] - after[0]) < 1e-12;
   }
-  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok) ? 0 : 2;
+  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok && edit_ok) ? 0 : 2;
 }
