@@ -214,8 +214,8 @@ int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving,
  * a synchronisation each; the batched entries above are the hot path):
  *  - randt_maps_insert_cluster: Map::insertCluster (ndt_map.cpp:238-245) -- ONE cell from all the points
  *    (Cell::addPointCloud / updateCell), appended if accepted (n > min_points), its mean's slot pointed at it.
- *    *accepted (nullable) = 1 if a cell was added.  RANDT_ERR_INVALID if the mean lies outside the index grid (the
- *    reference's std::vector::at throws there).
+ *    *accepted (nullable) = 1 if a cell was added; a cluster whose mean lies outside the index grid is dropped like
+ *    the batched build drops it (the reference's std::vector::at throws there).
  *  - randt_maps_insert_cells: Map::insertCell (ndt_map.h:137-140) for set_grid = 0 (cells appended, index grid
  *    untouched); set_grid = 1 also points each cell's slot at it (the tail of insertCluster).
  *  - randt_closest_cells: Map::getClosestCells (ndt_map.cpp:101-151) for n_queries query cells: h_out[q][k] compact
