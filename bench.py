@@ -52,6 +52,8 @@ def main():
                     "(GPU_MAX_HW_QUEUES is raised to match unless already set: HIP maps streams onto 4 hardware queues by default)")
     ap.add_argument("--odometry-scans", type=int, default=200, help="BASELINE config 3 side measurement (0 = skip)")
     ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
+    ap.add_argument("--polar-odometry-scans", type=int, default=60,
+                    help="BASELINE config 5 side measurement: full local-fuser loop on raw polar scans (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock budget of the CPU baseline leg")
     args = ap.parse_args()
@@ -248,6 +250,8 @@ def main():
             out["config3_streaming_odometry"] = streaming_odometry(ctx, args.odometry_scans, not args.no_cpu_baseline)
         if args.polar_scans > 0 and world == 1:
             out["config5_polar_filter"] = polar_filter(ctx, args.polar_scans)
+        if args.polar_odometry_scans > 0 and world == 1:
+            out["config5_polar_odometry"] = polar_odometry(ctx, args.polar_odometry_scans)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -297,6 +301,47 @@ def polar_filter(ctx, n_scans):
             "filter_GBps": nbytes / t_f / 1e9, "filter_hbm_frac": nbytes / t_f / 1e9 / HBM_PEAK_GBS,
             "scans_per_sec_filter_plus_build": n_scans / (t_f + t_b), "mean_filtered_points": float(counts.float().mean().item()),
             "status_ok": bool((status == 0).all().item())}
+
+
+def polar_odometry(ctx, n_scans):
+    """BASELINE config 5, whole loop (side measurement): Oxford-shaped raw polar scans (400 azimuths x 3000 bins,
+    19.2 MB each, resident in HBM) -> filterScan -> clustering + NDT -> constant-velocity prediction -> fixed-lag window
+    registration -> keyframe merge / submap roll-over, one scan after the other (LocalFuser::processScan call pattern)."""
+    import torch
+
+    import randt_slam_amd as R
+    from randt_slam_amd import host, odometry, synth
+
+    world = synth.make_world()
+    dt = 0.25
+    traj = synth.make_trajectory(3300, n_scans, step=0.25)
+    dev = torch.device("cuda", ctx.device)
+    d_raw = [torch.from_numpy(synth.make_polar_scan(world, traj[i], 61000 + i)).to(dev) for i in range(n_scans)]
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    wp = R.window_params()
+    fp = host.filter_params()
+    odo = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, wp)
+    # One untimed pass (kernels, workspaces, first touch of the freshly uploaded scans), then three timed passes over the
+    # same drive: this loop keeps the GPU mostly idle between small launches, and the first passes after an idle period run
+    # ~1.6x slower than the settled rate (clock ramp); the median pass is reported, all three are listed.
+    passes = []
+    for rep in range(4):
+        odo = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, wp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_scans):
+            pose = odo.process_scan(d_raw[i], i * dt, polar_filter=fp)
+        torch.cuda.synchronize()
+        if rep:
+            passes.append(time.perf_counter() - t0)
+    el = sorted(passes)[1]
+    rel = synth.se2_mul3(synth.se2_inv3(traj[0]), traj[-1])
+    est = synth.pose4_to_pose3(pose)
+    raw_bytes = int(d_raw[0].numel() * 4)
+    return {"scans": n_scans, "scans_per_sec": n_scans / el, "ms_per_scan": el / n_scans * 1e3, "raw_bytes_per_scan": raw_bytes,
+            "raw_GBps": n_scans * raw_bytes / el / 1e9, "pass_ms_per_scan": [p / n_scans * 1e3 for p in passes],
+            "registrations": odo.n_registrations, "rejected": odo.n_rejected,
+            "end_pose_error_vs_truth_m": float(np.hypot(est[0] - rel[0], est[1] - rel[1]))}
 
 
 def streaming_odometry(ctx, n_scans, with_cpu):
