@@ -64,6 +64,11 @@ class HipBackend:
         host.ndt_build_batch(self.ctx, self._f_out, self.clu, self.scans, first_map=idx, n_points=self._f_cnt)
         return idx
 
+    def filtered_points(self):
+        """The points filterScan kept for the last polar scan, as a host array (synchronises)."""
+        n = int(self._f_cnt.cpu()[0])
+        return self._f_out[0, :n].cpu().numpy()
+
     def release_scan(self, idx):
         self.free_scans.append(idx)
 
@@ -92,6 +97,29 @@ class HipBackend:
     # ---- matcher
     def predict(self, state, stamp):
         return host.predict_state(state, stamp)
+
+    # ---- loop closure + back end (slam.py)
+    def register_pair(self, sub_idx, scan_idx, mp, guess4):
+        """Matcher::estimateLoopConstraint: submap (fixed) vs scan (moving); returns (pose4, cost)."""
+        p, res = host.register_pair(self.ctx, self.subs, sub_idx, self.scans, scan_idx, mp, guess4)
+        return p, float(res["cost"])
+
+    def cs_divergence(self, sub_idx, scan_idx, pose4):
+        return host.cs_divergence(self.ctx, self.subs, sub_idx, self.scans, scan_idx, pose4)[0]
+
+    def sc_open(self, sp_kwargs):
+        self._sc = host.ScDatabase(self.ctx, host.sc_params(**sp_kwargs))
+
+    def sc_append(self, points, pos, dist):
+        pts = points.cpu().numpy() if hasattr(points, "data_ptr") else points
+        return self._sc.append(pts, pos, dist)
+
+    def sc_detect(self, node_id):
+        lid, yaw, _ = self._sc.detect(node_id)
+        return lid, float(yaw)
+
+    def pose_graph_optimize(self, x, ia, ib, meas, sqi, max_update_index, params_kwargs):
+        return host.pose_graph_optimize(self.ctx, x, ia, ib, meas, sqi, max_update_index, host.pg_params(**params_kwargs))
 
     def register_window(self, fixed_idx, moving_idx, states, mp, wp, trans4):
         st, t, rej, res = host.register_window(self.ctx, self.subs, fixed_idx, self.scans, moving_idx, states, mp, wp, trans4, None)
@@ -125,6 +153,8 @@ class Odometry:
         self.n_registrations = 0
         self.n_rejected = 0
         self.last_result = None
+        self.next_scans_to_insert = []                                # keyframe queue: the scans' points (Scan Context input)
+        self._cur_points = None
 
     # LocalFuser::getTransform (local_fuser.h:113-127)
     def get_transform(self):
@@ -143,10 +173,11 @@ class Odometry:
         self.last_submap_transformed = b.copy_transformed(self.current_submap, old_to_new)
         for h in self.next_maps_to_insert + self.map_window:
             self._unref(h)
-        self.next_maps_to_insert, self.map_window = [], []
+        self.next_maps_to_insert, self.map_window, self.next_scans_to_insert = [], [], []
         self.current_transform = np.array([1.0, 0.0, 0.0, 0.0])
         self.current_global_transform = np.array(initial_transform, dtype=np.float64)
-        b.release_submap(self.current_submap)
+        if not self._on_submap_finished(self.current_submap):          # submaps_.insert(...) (:43) keeps it alive
+            b.release_submap(self.current_submap)
         self.current_submap = b.new_submap()
         self.trajectory = []
         self.n_finished_submaps += 1
@@ -162,6 +193,17 @@ class Odometry:
             self.b.release_scan(h)
 
     _refs = None
+    keep_filtered_points = False
+
+    # graph bookkeeping hooks of the SLAM layer (slam.py); the pure odometry loop does nothing here
+    def _on_first_scan(self, scan, points):
+        pass
+
+    def _on_keyframe(self, scan, points, smoothed_pose4):
+        pass
+
+    def _on_submap_finished(self, submap):
+        return False
 
     # LocalFuser::processScan (local_fuser.cpp:99-300), data path only
     def _process(self, scan, stamp):
@@ -187,11 +229,13 @@ class Odometry:
                 self._unref(self.map_window.pop(0))
             if n % self.insertion_step == 0:                                              # :155-161 keyframe
                 self.next_maps_to_insert.append(scan)
+                self.next_scans_to_insert.append(self._cur_points)
                 self._ref(scan)
             if n >= self.insertion_delay + self.insertion_step and (n - self.insertion_delay) % self.insertion_step == 0:  # :164
                 smoothed = self.trajectory[-self.insertion_delay - 1]["pose"]             # :165-166
                 kf = self.next_maps_to_insert.pop(0)
                 b.merge(self.current_submap, kf, smoothed)                                # :177,190
+                self._on_keyframe(kf, self.next_scans_to_insert.pop(0), smoothed)          # :192-222 node + edge
                 self._unref(kf)
         else:
             # first scan of the submap (:225-295)
@@ -204,6 +248,7 @@ class Odometry:
                 st["lin_acc"], st["imu_bias"] = self.last_state["lin_acc"], self.last_state["imu_bias"]
             st["stamp"] = stamp
             self.trajectory.append(st)
+            self._on_first_scan(scan, self._cur_points)                                   # :247-279 root node of the submap
             b.merge(self.current_submap, scan, self.current_transform)                    # :281,293
 
     def process_scan(self, points, stamp, polar_filter=None):
@@ -211,8 +256,11 @@ class Odometry:
         polar_filter: FilterParams -> `points` is a raw polar scan and goes through filterScan first."""
         if self._refs is None:
             self._refs = {}
+        self._cur_points = points
         if polar_filter is not None:
             scan = self.b.build_scan_from_polar(points, polar_filter)                     # :102 filterScan + clustering
+            if self.keep_filtered_points:                                                 # the SLAM layer feeds them to Scan Context
+                self._cur_points = self.b.filtered_points()
         else:
             scan = self.b.build_scan(points)                                              # :102-105
         self._ref(scan)

@@ -35,7 +35,48 @@ class OracleBackend:
                 setattr(fp, name, v)
         raw = np.ascontiguousarray(raw, dtype=np.float32)
         cnt, pts, _, _ = po_.filter_scan(raw.reshape(-1, raw.shape[-1]), fp, capacity=pitch_out)
+        self._filtered = pts
         return self.build_scan(pts)
+
+    def filtered_points(self):
+        return self._filtered
+
+    # ---- loop closure + back end (slam.py)
+    def register_pair(self, sub_h, scan_h, mp, guess4):
+        from util import to_oracle_params
+
+        rc, pose, cost, _ = po.register_pair(self.subs[sub_h], self.scans[scan_h], to_oracle_params(mp), np.asarray(guess4, dtype=np.float64))
+        return pose, cost
+
+    def cs_divergence(self, sub_h, scan_h, pose4):
+        m = self.scans[scan_h].copy()
+        m.transform(np.asarray(pose4, dtype=np.float64))
+        return po.cs_divergence(self.subs[sub_h], m)[0]
+
+    def sc_open(self, sp_kwargs):
+        d = dict(num_ring=20, num_sector=45, max_radius=15.0, num_exclude_recent=15, num_candidates=10, search_ratio=0.3,
+                 dist_thresh=0.6, assumed_drift=0.05, odom_eps=1.2, odom_weight=0.2, intensity_factor=0.04)
+        d.update(sp_kwargs)
+        self._sp = po.ScParams(*[d[k] for k in ("num_ring", "num_sector", "max_radius", "num_exclude_recent", "num_candidates",
+                                                  "search_ratio", "dist_thresh", "assumed_drift", "odom_eps", "odom_weight",
+                                                  "intensity_factor")])
+        self._sc_desc, self._sc_rk, self._sc_pos, self._sc_dist = [], [], [], []
+
+    def sc_append(self, points, pos, dist):
+        d, rk, _ = po.sc_make(np.ascontiguousarray(points, dtype=np.float32), self._sp)
+        self._sc_desc.append(d)
+        self._sc_rk.append(rk)
+        self._sc_pos.append(np.array(pos, dtype=np.float64))
+        self._sc_dist.append(float(dist))
+        return len(self._sc_desc) - 1
+
+    def sc_detect(self, node_id):
+        lid, yaw, _ = po.sc_detect(self._sp, np.stack(self._sc_desc), np.stack(self._sc_rk), np.stack(self._sc_pos),
+                                   np.array(self._sc_dist), node_id)
+        return lid, float(yaw)
+
+    def pose_graph_optimize(self, x, ia, ib, meas, sqi, max_update_index, params_kwargs):
+        return po.pose_graph_optimize(x, ia, ib, meas, sqi, max_update_index, po.pg_params(**params_kwargs))
 
     def release_scan(self, h):
         del self.scans[h]
