@@ -209,6 +209,11 @@ int randt_maps_transform(randt_maps* m, int first, int count, const double* h_po
  * strictly in order.  The moving maps themselves are not modified. */
 int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_first,
                      int n_moving, const double* h_pose4);
+/* NOT in the reference: rebuild the index grid of maps [first, first+count) from the cells' current means (async).
+ * Map::transformMap leaves grid_indizes_ stale (ndt_map.cpp:177-182), so a transformed map answers getClosestCells
+ * through the slots its cells USED to occupy -- which is what randt_maps_transform reproduces.  Callers that want a
+ * transformed map to be searchable again (the fixed submap hand-over, see DESIGN "reference quirks") call this. */
+int randt_maps_reindex(randt_maps* m, int first, int count);
 
 /* Cell-by-cell edits and single-cell queries of the reference's Map, host-level conveniences (a few tiny launches and
  * a synchronisation each; the batched entries above are the hot path):

@@ -122,6 +122,7 @@ SYMBOLS = {
     "randt_ndt_build": (_I, [_V, _V, _I, _I, _I, _P(ClusterParams), _V, _I]),
     "randt_maps_transform": (_I, [_V, _I, _I, _V]),
     "randt_maps_merge": (_I, [_V, _I, _V, _I, _I, _V]),
+    "randt_maps_reindex": (_I, [_V, _I, _I]),
     "randt_maps_insert_cluster": (_I, [_V, _I, _V, _I, _I, _I, _P(_I)]),
     "randt_maps_insert_cells": (_I, [_V, _I, _V, _I, _I]),
     "randt_closest_cells": (_I, [_V, _V, _I, _V, _I, _I, _I, _I, _V]),

@@ -446,6 +446,12 @@ int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   return rc;
 }
 
+int randt_maps_reindex(randt_maps* m, int first, int count) {
+  if (!range_ok(m, first, count)) return RANDT_ERR_INVALID;
+  if (!m->v.grid) return randt_set_error(m->ctx, RANDT_ERR_INVALID, "maps batch has no index grid", hipSuccess);
+  return launch_maps_reindex(m->ctx, m->v, first, count);
+}
+
 int randt_maps_transform(randt_maps* m, int first, int count, const double* h_pose4) {
   if (!range_ok(m, first, count) || (count > 0 && !h_pose4)) return RANDT_ERR_INVALID;
   if (count == 0) return RANDT_OK;

@@ -750,6 +750,30 @@ __global__ __launch_bounds__(64) void k_maps_append(MapView dst, int dst_idx, Ma
   }
 }
 
+// Rebuild the index grid of a map from its cells' current means (later cells win a shared slot, as insertion order
+// would have it).  The reference never does this after Map::transformMap (ndt_map.cpp:177-182 leaves grid_indizes_
+// stale); this is the opt-in repair.  One workgroup per map.
+__global__ __launch_bounds__(256) void k_maps_reindex(MapView m, int first) {
+  const int map = first + blockIdx.x;
+  if (!m.grid) return;
+  int32_t* grid = m.grid + (size_t)map * m.n_slots;
+  const randt_cell* cells = m.cells + (size_t)map * m.cap;
+  const int n = min(m.counts[map], m.cap);
+  for (int s = threadIdx.x; s < m.n_slots; s += 256) grid[s] = -1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint32_t slot = coord_to_index(m, cells[i].mean[0], cells[i].mean[1]);
+    if (slot < (uint32_t)m.n_slots) atomicMax(&grid[slot], i);
+  }
+}
+
+int launch_maps_reindex(randt_ctx* ctx, const MapView& m, int first, int count) {
+  if (count <= 0) return RANDT_OK;
+  hipLaunchKernelGGL(k_maps_reindex, dim3(count), dim3(256), 0, ctx->stream, m, first);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
+
 int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,
                        int32_t* d_status) {
   hipLaunchKernelGGL(k_maps_append, dim3(1), dim3(64), 0, ctx->stream, dst, dst_idx, src, src_idx, set_grid, d_status);

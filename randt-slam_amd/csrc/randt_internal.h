@@ -64,6 +64,7 @@ int randt_set_error(randt_ctx* ctx, int status, const char* what, hipError_t e);
 int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points,
                      int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map);
 int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count, const double* d_pose4);
+int launch_maps_reindex(randt_ctx* ctx, const MapView& m, int first, int count);
 int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,
                        int32_t* d_status);
 int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const MapView& moving, int moving_first,

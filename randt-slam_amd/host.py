@@ -180,6 +180,11 @@ class Maps:
         p = np.ascontiguousarray(poses4, dtype=np.float64).reshape(-1, 4)
         self.ctx._check(self._lib.randt_maps_transform(self._h, first, len(p), _dptr(p)), "randt_maps_transform")
 
+    def reindex(self, first=0, count=None):
+        """randt_maps_reindex: rebuild the index grid from the cells' current means (not in the reference)."""
+        count = self.n_maps - first if count is None else count
+        self.ctx._check(self._lib.randt_maps_reindex(self._h, first, count), "randt_maps_reindex")
+
     def merge(self, fixed_idx, moving, moving_first, poses4):
         """Rolling-submap update: merge moving maps [moving_first, +len(poses4)) into self[fixed_idx]."""
         p = np.ascontiguousarray(poses4, dtype=np.float64).reshape(-1, 4)

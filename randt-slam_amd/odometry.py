@@ -87,11 +87,14 @@ class HipBackend:
     def merge(self, sub_idx, scan_idx, pose4):
         self.subs.merge(sub_idx, self.scans, scan_idx, np.asarray(pose4, dtype=np.float64).reshape(1, 4))
 
-    def copy_transformed(self, src_idx, pose4):
-        """_last_submap_transformed = _current_submap; .transformMap(pose) (local_fuser.cpp:44-46)."""
+    def copy_transformed(self, src_idx, pose4, reindex=False):
+        """_last_submap_transformed = _current_submap; .transformMap(pose) (local_fuser.cpp:44-46).  reindex: also rebuild
+        the index grid (the reference leaves it stale)."""
         dst = self.free_subs.pop(0)
         self.subs.copy_from(self.subs, dst_first=dst, src_first=src_idx, count=1)
         self.subs.transform(dst, np.asarray(pose4, dtype=np.float64).reshape(1, 4))
+        if reindex:
+            self.subs.reindex(dst, 1)
         return dst
 
     # ---- matcher
@@ -140,6 +143,7 @@ class Odometry:
         self.smoothing_steps = p["smoothing_steps"]
         self.submap_size_poses = p["submap_size_poses"]
         self.submap_overlap = p["submap_overlap"]
+        self.fix_submap_handover = bool(p.get("fix_submap_handover", False))   # False = the reference's behaviour
         self.current_submap = backend.new_submap()
         self.last_submap_transformed = None
         self.trajectory = []                                          # list of STATE_DTYPE scalars
@@ -169,8 +173,14 @@ class Odometry:
         self.last_state = self.trajectory[-1].copy()
         if self.last_submap_transformed is not None:
             b.release_submap(self.last_submap_transformed)
-        old_to_new = _se2_mul4(_se2_inv4(self.current_global_transform), initial_transform)
-        self.last_submap_transformed = b.copy_transformed(self.current_submap, old_to_new)
+        old_to_new = _se2_mul4(_se2_inv4(self.current_global_transform), initial_transform)   # :45, name and all
+        if self.fix_submap_handover:
+            # The reference's product is the NEW origin expressed in the OLD frame, i.e. the inverse of the map it is named
+            # after, and transformMap leaves the index grid stale: the overlap map is misplaced unless the hand-over pose is
+            # near identity (DESIGN "reference quirks").  Opt-in repair: apply the inverse and re-index.
+            self.last_submap_transformed = b.copy_transformed(self.current_submap, _se2_inv4(old_to_new), reindex=True)
+        else:
+            self.last_submap_transformed = b.copy_transformed(self.current_submap, old_to_new)
         for h in self.next_maps_to_insert + self.map_window:
             self._unref(h)
         self.next_maps_to_insert, self.map_window, self.next_scans_to_insert = [], [], []

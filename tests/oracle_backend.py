@@ -97,9 +97,16 @@ class OracleBackend:
         tmp.transform(np.asarray(pose4, dtype=np.float64))
         self.subs[sub_h].merge(tmp)
 
-    def copy_transformed(self, src_h, pose4):
+    def copy_transformed(self, src_h, pose4, reindex=False):
         m = self.subs[src_h].copy()
         m.transform(np.asarray(pose4, dtype=np.float64))
+        if reindex:      # randt_maps_reindex: slots from the cells' current means, later cells win
+            cells, grid = m.cells(), np.full(m.n_slots, -1, dtype=np.int32)
+            for i, c in enumerate(cells):
+                idx = po.lib().orc_map_coord_to_index(m._p, float(c["mean"][0]), float(c["mean"][1]))
+                if idx < m.n_slots:
+                    grid[idx] = i
+            m.set(cells, grid)
         self._next += 1
         self.subs[self._next] = m
         return self._next
