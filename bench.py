@@ -52,6 +52,8 @@ def main():
                     "(GPU_MAX_HW_QUEUES is raised to match unless already set: HIP maps streams onto 4 hardware queues by default)")
     ap.add_argument("--odometry-scans", type=int, default=200, help="BASELINE config 3 side measurement (0 = skip)")
     ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
+    ap.add_argument("--slam-scans", type=int, default=300,
+                    help="side measurement: whole SLAM call pattern (odometry + loop closure + pose graph) on a two-lap drive (0 = skip)")
     ap.add_argument("--polar-odometry-scans", type=int, default=60,
                     help="BASELINE config 5 side measurement: full local-fuser loop on raw polar scans (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -250,6 +252,8 @@ def main():
             out["config3_streaming_odometry"] = streaming_odometry(ctx, args.odometry_scans, not args.no_cpu_baseline)
         if args.polar_scans > 0 and world == 1:
             out["config5_polar_filter"] = polar_filter(ctx, args.polar_scans)
+        if args.slam_scans > 0 and world == 1:
+            out["slam_loop"] = slam_loop(ctx, args.slam_scans)
         if args.polar_odometry_scans > 0 and world == 1:
             out["config5_polar_odometry"] = polar_odometry(ctx, args.polar_odometry_scans)
         print(json.dumps(out))
@@ -301,6 +305,56 @@ def polar_filter(ctx, n_scans):
             "filter_GBps": nbytes / t_f / 1e9, "filter_hbm_frac": nbytes / t_f / 1e9 / HBM_PEAK_GBS,
             "scans_per_sec_filter_plus_build": n_scans / (t_f + t_b), "mean_filtered_points": float(counts.float().mean().item()),
             "status_ok": bool((status == 0).all().item())}
+
+
+def slam_loop(ctx, n_scans):
+    """Side measurement: the reference's whole SLAM loop as a call pattern (randt_slam_amd/slam.py) -- fixed-lag odometry
+    with submap roll-overs, graph nodes / edges, Scan Context candidates, loop registration against finished submaps, CS
+    gate, pose-graph optimisation every 40 scans -- on a circular two-lap drive (160 scans per lap, 40-state submaps)."""
+    import torch
+
+    import randt_slam_amd as R
+    from randt_slam_amd import odometry, slam, synth
+
+    world = synth.make_world()
+    dt, per_lap = 0.25, 160
+    th = 2 * np.pi * np.arange(n_scans) / per_lap
+    truth = np.stack([5.0 * np.cos(th), 5.0 * np.sin(th), th + np.pi / 2], 1)
+    scans = np.stack([synth.make_scan(world, truth[i], 71000 + i) for i in range(n_scans)])
+    d_scans = torch.from_numpy(scans).to(torch.device("cuda", ctx.device))
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    loop_mp = R.default_matcher_params(gnc_steps=2)
+    wp = R.window_params()
+
+    def run():
+        s = slam.Slam(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params(), scan_slots=n_scans // 4 + 64,
+                                          submap_slots=n_scans // 40 + 8), mp, wp, loop_mp,
+                      params=dict(submap_size_poses=40, submap_overlap=10), sc_params=dict(max_radius=20.0, dist_thresh=0.5),
+                      loop_closure_weight=40.0)
+        t_loop = t_pg = 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_scans):
+            pose = s.process_scan(d_scans[i], i * dt)
+            t1 = time.perf_counter()
+            s.detect_loop_closures()
+            t2 = time.perf_counter()
+            if i % 40 == 39:
+                s.optimize_pose_graph()
+            t_loop += t2 - t1
+            t_pg += time.perf_counter() - t2
+        torch.cuda.synchronize()
+        return s, pose, time.perf_counter() - t0, t_loop, t_pg
+
+    run()                                                    # warm-up pass
+    s, pose, el, t_loop, t_pg = run()
+    rel = synth.se2_mul3(synth.se2_inv3(truth[0]), truth[-1])
+    est = synth.pose4_to_pose3(pose)
+    loops = [e for e in s.edges if e[0] + 1 != e[1]]
+    return {"scans": n_scans, "scans_per_sec": n_scans / el, "ms_per_scan": el / n_scans * 1e3, "graph_nodes": len(s.nodes),
+            "loop_constraints": len(loops), "loop_candidates_checked": len(s.loop_log), "pose_graph_optimisations": s.n_optimizations,
+            "submaps_finished": s.n_finished_submaps, "loop_closure_ms_total": t_loop * 1e3, "pose_graph_ms_total": t_pg * 1e3,
+            "end_pose_error_vs_truth_m": float(np.hypot(est[0] - rel[0], est[1] - rel[1]))}
 
 
 def polar_odometry(ctx, n_scans):
