@@ -147,7 +147,16 @@ int randt_ctx_destroy(randt_ctx* ctx) {
   if (!ctx) return RANDT_OK;
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->build_ws) (void)hipFree(ctx->build_ws);
+  if (ctx->small) (void)hipFree(ctx->small);
   delete ctx;
+  return RANDT_OK;
+}
+
+// 4 KB that the synchronous host-level entries carve their pose / index / result words from (they synchronise before
+// returning, so one block per context is enough and nothing is allocated per call).
+static int small_block(randt_ctx* ctx, char** out) {
+  if (!ctx->small) RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->small, 4096));
+  *out = static_cast<char*>(ctx->small);
   return RANDT_OK;
 }
 
@@ -352,9 +361,11 @@ int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int str
 // launches and a synchronisation each), not the batched hot path.
 static int append_from(randt_maps* m, int idx, const randt_maps* src, int set_grid, int* n_dropped, int* n_outside) {
   randt_ctx* ctx = m->ctx;
-  int32_t* d_status = nullptr;
-  RANDT_HIP_CHECK(ctx, hipMalloc(&d_status, 2 * sizeof(int32_t)));
-  int rc = launch_maps_append(ctx, m->v, idx, src->v, 0, set_grid, d_status);
+  char* d_blk = nullptr;
+  int rc = small_block(ctx, &d_blk);
+  if (rc) return rc;
+  int32_t* d_status = reinterpret_cast<int32_t*>(d_blk + 512);
+  rc = launch_maps_append(ctx, m->v, idx, src->v, 0, set_grid, d_status);
   int32_t h_status[2] = {0, 0};
   if (!rc) {
     hipError_t e = hipMemcpyAsync(h_status, d_status, sizeof(h_status), hipMemcpyDeviceToHost, ctx->stream);
@@ -363,7 +374,6 @@ static int append_from(randt_maps* m, int idx, const randt_maps* src, int set_gr
   } else {
     (void)hipStreamSynchronize(ctx->stream);
   }
-  (void)hipFree(d_status);
   if (n_dropped) *n_dropped = h_status[0];
   if (n_outside) *n_outside = h_status[1];
   return rc;
@@ -538,9 +548,10 @@ int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
                         const randt_matcher_params* mp, double h_pose4[4], randt_result* h_result) {
   if (!ctx || !h_pose4 || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1) || !mp) return RANDT_ERR_INVALID;
   // small staging block: [pose4 | result | fixed_idx]
-  void* stage = nullptr;
-  const size_t sz = sizeof(double) * 4 + sizeof(randt_result) + 16;
-  RANDT_HIP_CHECK(ctx, hipMalloc(&stage, sz));
+  char* stage = nullptr;
+  int rc0 = small_block(ctx, &stage);
+  if (rc0) return rc0;
+  stage += 1024;  // own region of the context's scratch block
   double* d_pose = (double*)stage;
   randt_result* d_res = (randt_result*)(d_pose + 4);
   int32_t* d_fi = (int32_t*)(d_res + 1);
@@ -560,7 +571,6 @@ int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   } else {
     (void)hipStreamSynchronize(ctx->stream);
   }
-  (void)hipFree(stage);
   if (h_result) *h_result = r;
   return rc;
 }
@@ -595,12 +605,12 @@ int randt_cs_divergence(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   if (!ctx || !out || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1)) return RANDT_ERR_INVALID;
   // device scratch of this call: pose | fixed index | result | terms (kept apart from the workspace the batch entry uses)
   char* d_blk = nullptr;
-  RANDT_HIP_CHECK(ctx, hipMalloc(&d_blk, 256));
+  int rc = small_block(ctx, &d_blk);
+  if (rc) return rc;
   double* d_pose = reinterpret_cast<double*>(d_blk);
   int32_t* d_fi = reinterpret_cast<int32_t*>(d_blk + 64);
   double* d_out = reinterpret_cast<double*>(d_blk + 128);
   double* d_terms = d_out + 1;
-  int rc = RANDT_OK;
   hipError_t e = hipSuccess;
   if (h_pose4) e = hipMemcpyAsync(d_pose, h_pose4, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_fi, &fixed_idx, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
@@ -614,7 +624,6 @@ int randt_cs_divergence(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   } else {
     (void)hipStreamSynchronize(ctx->stream);
   }
-  (void)hipFree(d_blk);
   return rc;
 }
 

@@ -29,6 +29,7 @@ struct randt_ctx {
   // scratch (grown on demand, never inside a timed region after warm-up)
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  void* small = nullptr;     // 4 KB of device scratch for the synchronous host-level conveniences (lazily allocated)
   void* build_ws = nullptr;  // label scratch of k_ndt_build's fallback sort (its own buffer: callers stage points in ws)
   size_t build_ws_bytes = 0;
   double* d_trace = nullptr;
