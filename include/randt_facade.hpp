@@ -255,8 +255,27 @@ class Map {
     return false;
   }
 
+  // the 2-D overload (ndt_map.cpp:23-31)
+  bool getCellMeanAndCovariance(unsigned int index, Vector2f& mean, Matrix2f& cov) const {
+    auto cells = getCells();
+    if (index < cells.size()) {
+      mean = cells[index].getMean();
+      cov = cells[index].getCov();
+      return true;
+    }
+    std::cout << "WARNING: requested cell out of range!" << "\n";
+    return false;
+  }
+  // const size_t getPointsInCell(size_t i) const (ndt_map.h:66-68)
+  size_t getPointsInCell(size_t i) const { return getCells().at(i).getNumCells(); }
+
   // Map::transformMap (ndt_map.cpp:177-182); index grid stays stale like in the reference
   void transformMap(const SE2d& trans) { check(randt_maps_transform(m_, 0, 1, trans.data()), "randt_maps_transform"); }
+  // Map::transformMapWithPointCloud (ndt_map.cpp:184-189): the per-cell point clouds only feed the OGM, which is not
+  // part of this path -- the cell statistics move exactly as in transformMap
+  void transformMapWithPointCloud(const SE2d& trans) { transformMap(trans); }
+  // NOT in the reference: make a transformed map searchable again (DESIGN "reference quirks")
+  void reindex() { check(randt_maps_reindex(m_, 0, 1), "randt_maps_reindex"); }
 
   // Map::mergeMapCell (ndt_map.cpp:191-207): moving_map is expected already transformed, as in
   // local_fuser.cpp:177,190; mergeMapCellAt fuses the transform.
