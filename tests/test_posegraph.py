@@ -247,3 +247,36 @@ def test_hip_pose_graph_error_convention(built):
     # nothing to optimise: poses returned unchanged, zero residual blocks
     x, r = host.pose_graph_optimize(ctx, np.ones((3, 3)), [], [], np.zeros((0, 3)), np.zeros((0, 9)), 9)
     assert np.array_equal(x, np.ones((3, 3))) and r["n_residual_blocks"] == 0
+
+
+# ------------------------------------------------------------------------------------------------- golden vector
+def _golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posegraph_01.npz"))
+
+
+def test_oracle_reaches_the_independently_computed_optimum(built):
+    """tests/golden/posegraph_01.npz: minimiser from scipy on residuals written out in the generator script, not by the oracle."""
+    g = _golden()
+    tight = po.pg_params(function_tolerance=1e-15, parameter_tolerance=1e-14, gradient_tolerance=1e-14, max_iterations=200)
+    x, res = po.pose_graph_optimize(g["x0"], g["id_begin"], g["id_end"], g["meas"], g["sqrt_info"], len(g["x0"]), tight)
+    assert abs(res["initial_cost"] - float(g["cost_init"])) < 1e-9 * float(g["cost_init"])
+    assert abs(res["final_cost"] - float(g["cost_opt"])) < 1e-10 * max(1.0, float(g["cost_opt"]))
+    assert np.abs(x - g["x_opt"]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_hip_reaches_the_independently_computed_optimum(built):
+    import torch
+
+    g = _golden()
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    kw = dict(function_tolerance=1e-15, parameter_tolerance=1e-14, gradient_tolerance=1e-14, max_iterations=200)
+    x, res = host.pose_graph_optimize(ctx, g["x0"], g["id_begin"], g["id_end"], g["meas"], g["sqrt_info"], len(g["x0"]), host.pg_params(**kw))
+    assert abs(res["final_cost"] - float(g["cost_opt"])) < 1e-10 * max(1.0, float(g["cost_opt"]))
+    assert np.abs(x - g["x_opt"]).max() < 1e-7
+    # reference options: stops on the function tolerance, within the path's 1e-4 bar of the true optimum... of the COST;
+    # poses are within a millimetre
+    xd, rd = host.pose_graph_optimize(ctx, g["x0"], g["id_begin"], g["id_end"], g["meas"], g["sqrt_info"], len(g["x0"]))
+    assert rd["termination"] == 1 and np.abs(xd - g["x_opt"]).max() < 2e-3
