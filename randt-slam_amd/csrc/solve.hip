@@ -161,7 +161,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double badf = wave_max((double)bad);
+  double badf = wave_any(bad != 0);
   if (MODE == 0) {
     mx = wave_max(mx);
     if (WAVES > 1) {

@@ -254,14 +254,16 @@ __device__ __forceinline__ void wave_sum10(double* v) {
   v[8] = readlane_f64(u2, 0);
   v[9] = readlane_f64(u2, 32);
 }
+// Maximum over the 64 lanes, result in every lane: four in-row DPP steps and four row broadcasts (no LDS crossbar).
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
+// Does any lane raise the flag?  One ballot.
+__device__ __forceinline__ double wave_any(bool flag) { return __ballot(flag) != 0ull ? 1.0 : 0.0; }
 
 
 }  // namespace randt_solve

@@ -349,7 +349,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
       }
     }
   }
-  double badf = wave_max((double)bad);
+  double badf = wave_any(bad != 0);
   if (MODE == 0) mx = wave_max(mx);
   if (lane == 0) {
     r[64 + wave] = badf;
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
             if (!isfinite(sh.step[lane])) fin = 0.0;
             sh.step[lane] = -sh.step[lane];
           }
-          fin = -wave_max(-fin);
+          fin = 1.0 - wave_any(fin == 0.0);
           wave_fence();
           // model_cost_change = -(step.gs + step^T Hs step / 2)
           double t = 0.0;
