@@ -328,14 +328,9 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
       for (int h = 0; h < ASSOC_CH / 64; ++h) {
         const int e = h * 64 + lane;
         const int v = e < nch ? clen[e] : 0;
-        int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int t = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += t;
-        }
+        const int incl = wave_inclusive_scan(v);
         cpref[e] = carry + incl - v;
-        carry += __shfl(incl, 63, 64);
+        carry += __builtin_amdgcn_readlane(incl, 63);
       }
       if (lane == 0) cpref[ASSOC_CH] = carry;
     }

@@ -168,16 +168,24 @@ __device__ __forceinline__ void store_cell(randt_cell* p, const randt_cell& r) {
   q[2] = make_float4(r.cov[5], __uint_as_float(r.n), r.max_intensity, __uint_as_float(r.reserved));
 }
 
+// Inclusive prefix sum over the 64 lanes of a wavefront in six DPP adds: four shifts inside each 16-lane row, then the
+// row totals travel with row_bcast15 (rows 1 and 3 take lane 15 of the row before) and row_bcast31 (rows 2 and 3 take
+// lane 31).  No LDS crossbar (ds_bpermute) round trips.
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // Exclusive prefix sum of one int per thread over a 256-thread block; returns the exclusive value,
 // *total receives the block sum.  scratch: >= 4 ints of LDS.  Contains two barriers.
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int* scratch, int* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int t = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += t;
-  }
+  const int incl = wave_inclusive_scan(v);
   __syncthreads();  // protect scratch reuse across calls
   if (lane == 63) scratch[wave] = incl;
   __syncthreads();

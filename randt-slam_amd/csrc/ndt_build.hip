@@ -413,12 +413,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   __syncthreads();
   if (tid < 64) {
     const int v = tid < 32 ? bcount[tid] : 0;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-      const int t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
+    const int incl = wave_inclusive_scan(v);
     if (tid < 32) bcount[tid] = incl - v;
   }
   __syncthreads();
