@@ -181,6 +181,18 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v;
 }
 
+// Minimum / maximum over the 64 lanes (result in every lane): four in-row DPP steps, then the four row results.
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax(int v) {
+  auto pick = [](int a, int b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  v = pick(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v = pick(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v = pick(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v = pick(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror
+  return pick(pick(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+              pick(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // Exclusive prefix sum of one int per thread over a 256-thread block; returns the exclusive value,
 // *total receives the block sum.  scratch: >= 4 ints of LDS.  Contains two barriers.
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int* scratch, int* total) {

@@ -236,12 +236,8 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       lmax = l > lmax ? l : lmax;
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int a = __shfl_xor(lmin, off, 64), b = __shfl_xor(lmax, off, 64);
-    lmin = a < lmin ? a : lmin;
-    lmax = b > lmax ? b : lmax;
-  }
+  lmin = wave_minmax<false>(lmin);
+  lmax = wave_minmax<true>(lmax);
   if (lane == 0) {
     scratch[8 + wave] = lmin;
     scratch[12 + wave] = lmax;
