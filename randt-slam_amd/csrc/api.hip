@@ -134,6 +134,10 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
   int lds = 0;
   if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
     ctx->lds_limit = lds;
+  if (const char* e = getenv("RANDT_SOLVE_RPB")) {
+    const int r = atoi(e);
+    if (r == 1 || r == 2 || r == 4 || r == 8) ctx->solve_rpb = r;
+  }
   if (const char* e = getenv("RANDT_SOLVE_BLOCK")) {
     int b = atoi(e);
     if (b == 64 || b == 128) ctx->solve_block = b;

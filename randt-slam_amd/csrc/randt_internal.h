@@ -37,6 +37,9 @@ struct randt_ctx {
   int lds_limit = 160 * 1024;
   // kernel geometry knobs (RANDT_SOLVE_BLOCK, RANDT_ASSOC_STAGE_GRID; for experiments)
   int solve_block = 64;
+  int solve_rpb = 4;         // independent registrations (one wavefront each) per workgroup in the pair solve: 1, 2, 4, 8
+                             // (RANDT_SOLVE_RPB).  4 = one per SIMD of a CU: +9 % end to end over single-wavefront workgroups,
+                             // which the dispatcher places unevenly when they arrive from 16 queues
   int assoc_stage_grid = 0;  // 1: stage the fixed map's index grid in LDS; 0: gather it from L2 (same speed alone, but 36 KB instead of 76 KB of LDS leaves room for co-running build workgroups: +2 % end to end)
 };
 

@@ -113,7 +113,7 @@ struct Stage {
 // MODE 1: the ten base sums with loss + corrector (Ceres residual_block.cc / corrector.cc).
 // Returns false if any residual was non-finite.  red: [2][BLOCK/64][12] LDS, parity alternates per call.
 template <int D, int PARAM, int MODE, int BLOCK, bool AM2>
-__device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const Loss& L, Base& out, double* red, int& parity) {
+__device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const Loss& L, Base& out, double* red, int& parity, int tid) {
   constexpr int WAVES = BLOCK / 64;
   double c, s, tx, ty;
   if (PARAM == RANDT_PARAM_VECTOR) {
@@ -149,12 +149,12 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     }
   };
   if (S.n_pairs > 0) {  // scalar: the dense list in LDS
-    for (int e = threadIdx.x; e < S.n_pairs; e += BLOCK) {
+    for (int e = tid; e < S.n_pairs; e += BLOCK) {
       const unsigned u = S.pairs[e];
       one(u >> PAIR_SHIFT, u & PAIR_MASK);
     }
   } else {
-    for (int slot = threadIdx.x; slot < S.n_slots; slot += BLOCK) {
+    for (int slot = tid; slot < S.n_slots; slot += BLOCK) {
       const int cr = S.corr[slot];
       if (cr < 0 || cr >= S.fixed_cap) continue;
       one(S.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, S.kmagic) /* slot / k */, (unsigned)cr);
@@ -324,7 +324,7 @@ __device__ __forceinline__ bool gradient_converged(const double* x, const double
 }
 
 __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost, double radius, int flag) {
-  if (tr && threadIdx.x == 0) {
+  if (tr && threadIdx.x == 0) {  // (tracing is a single-registration-per-workgroup feature)
     const int n = (int)tr[0];
     if (3 * (n + 1) + 1 <= max_len) {
       tr[1 + 3 * n + 0] = cost;
@@ -337,19 +337,28 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
 
 // AM2: the Barron shape is exactly -2 (the reference's shipped configurations): closed-form loss, no pow()
 // in the kernel -- 30 fewer VGPRs and a third of the code.
-template <int D, int PARAM, int BLOCK, bool AM2>
-__global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
-                                                 int moving_first, const int32_t* __restrict__ corr, SolveParams P,
-                                                 double* __restrict__ pose4, randt_result* __restrict__ results,
-                                                 double* trace, int trace_len) {
+// RPB > 1 (BLOCK = 64 only): RPB independent registrations per workgroup, one per wavefront -- nothing is shared between
+// them (no workgroup barrier); the point is placement: the dispatcher spreads the wavefronts of ONE workgroup over the four
+// SIMDs of a CU, which it does not do for single-wavefront workgroups arriving from many queues.
+template <int D, int PARAM, int BLOCK, bool AM2, int RPB>
+__global__ __launch_bounds__(BLOCK* RPB) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
+                                                      int moving_first, const int32_t* __restrict__ corr, SolveParams P,
+                                                      double* __restrict__ pose4, randt_result* __restrict__ results,
+                                                      double* trace, int trace_len, int n_total) {
+  static_assert(RPB == 1 || BLOCK == 64, "several registrations per workgroup: one wavefront each");
   constexpr int NT = PARAM == RANDT_PARAM_AMBIENT4 ? 4 : 3;
   constexpr int WAVES = BLOCK / 64;
-  __shared__ double red[2 * WAVES * 12];
-  __shared__ int s_count[WAVES];
-  __shared__ unsigned s_pairs[PAIR_CAP];
+  __shared__ double red_all[RPB][2 * WAVES * 12];
+  __shared__ int s_count_all[RPB][WAVES];
+  __shared__ unsigned s_pairs_all[RPB][PAIR_CAP];
 
-  const int tid = threadIdx.x;
-  const int pair = blockIdx.x;
+  const int sub = RPB > 1 ? (int)(threadIdx.x >> 6) : 0;
+  const int tid = RPB > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int pair = blockIdx.x * RPB + sub;
+  if (pair >= n_total) return;  // RPB > 1: a whole wavefront leaves; there is no workgroup barrier below in that mode
+  double* red = red_all[sub];
+  int* s_count = s_count_all[sub];
+  unsigned* s_pairs = s_pairs_all[sub];
   const int fmap = fixed_idx ? fixed_idx[pair] : 0;
   const int mmap = moving_first + pair;
   const int k = P.k;
@@ -403,7 +412,12 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         n_out += __popcll(mask);
       }
     }
-    __syncthreads();
+    if (WAVES > 1) {
+      __syncthreads();
+    } else {  // the list is written and read by the same wavefront
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
     S.pairs = s_pairs;
     S.n_pairs = n_res;
   }
@@ -442,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
   // ---- raw residuals at the initial point -> gnc_mu (ndt_matcher.cpp:466-476)
   Loss L = make_loss(P.loss_a, P.alpha, 1.0, P.weight);
   Base cur, cnd;
-  bool ok = eval_pass<D, PARAM, 0, BLOCK, AM2>(S, x, L, cur, red, parity);
+  bool ok = eval_pass<D, PARAM, 0, BLOCK, AM2>(S, x, L, cur, red, parity, tid);
   const double raw_max = cur.v[0];
   res.n_evals++;
   double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
 #pragma unroll
       for (int i = 0; i < 4; ++i) x[i] = best[i];
       double x_norm = ambient_norm<PARAM>(x);
-      const bool e_ok = eval_pass<D, PARAM, 1, BLOCK, AM2>(S, x, L, cur, red, parity);
+      const bool e_ok = eval_pass<D, PARAM, 1, BLOCK, AM2>(S, x, L, cur, red, parity, tid);
       res.n_evals++;
       res.iterations++;
       if (!e_ok) {
@@ -554,7 +568,7 @@ __global__ __launch_bounds__(BLOCK) void k_solve(MapView fixed, const int32_t* _
         plus<PARAM>(x, delta, cand);
 
         // ---- candidate cost (+ speculative gradient / J^T J)
-        const bool c_ok = eval_pass<D, PARAM, 1, BLOCK, AM2>(S, cand, L, cnd, red, parity);
+        const bool c_ok = eval_pass<D, PARAM, 1, BLOCK, AM2>(S, cand, L, cnd, red, parity, tid);
         res.n_evals++;
         const double cand_cost = c_ok ? cnd.v[0] : DBL_MAX;
 
@@ -662,11 +676,11 @@ __global__ __launch_bounds__(64) void k_eval_cost(MapView fixed, int fmap, MapVi
   }
 }
 
-template <int D, int PARAM, int BLOCK, bool AM2>
+template <int D, int PARAM, int BLOCK, bool AM2, int RPB = 1>
 int launch_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
                int n_pairs, const int32_t* d_corr, const SolveParams& P, double* d_pose4, randt_result* d_results) {
-  hipLaunchKernelGGL((k_solve<D, PARAM, BLOCK, AM2>), dim3(n_pairs), dim3(BLOCK), 0, ctx->stream, fixed, d_fixed_idx, moving,
-                     moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len);
+  hipLaunchKernelGGL((k_solve<D, PARAM, BLOCK, AM2, RPB>), dim3((n_pairs + RPB - 1) / RPB), dim3(BLOCK * RPB), 0, ctx->stream, fixed,
+                     d_fixed_idx, moving, moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len, n_pairs);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
@@ -677,6 +691,13 @@ int launch_one(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx,
 #define RANDT_CFG(BB, AA) \
   return launch_cfg<D, PARAM, BB, AA>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results)
   const bool am2 = P.alpha == -2.0;
+  if (block == 64 && am2 && !ctx->d_trace && ctx->solve_rpb > 1) {
+    if (ctx->solve_rpb == 2)
+      return launch_cfg<D, PARAM, 64, true, 2>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results);
+    if (ctx->solve_rpb == 8)
+      return launch_cfg<D, PARAM, 64, true, 8>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results);
+    return launch_cfg<D, PARAM, 64, true, 4>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results);
+  }
   if (block == 64) {
     if (am2) RANDT_CFG(64, true); else RANDT_CFG(64, false);
   }
