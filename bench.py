@@ -224,7 +224,7 @@ def main():
                 # registrations one launch processes / that kernel's average launch duration (HIP events on its stream)
                 "bound": "hbm", "achieved": solve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": solve_gbs / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_STEP,
-                "kernel": "k_solve<3,1,64,true> (dominant); k_ndt_build and k_associate run once per step as well",
+                "kernel": "k_solve<3,1,64,true,4> (dominant; four registrations = four wavefronts per workgroup); k_ndt_build and k_associate run once per step as well",
                 "algorithmic_bytes_per_registration": b_alg, "registrations_per_launch": B,
                 "avg_launch_ms": {"k_ndt_build": float(stage_ms[0]), "k_associate": float(stage_ms[1]), "k_solve": float(stage_ms[2])},
                 "all_three_kernels": {"achieved": achieved_gbs, "frac": achieved_gbs / HBM_PEAK_GBS},
