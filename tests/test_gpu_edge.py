@@ -303,3 +303,32 @@ def test_error_convention_status_codes_not_exceptions(env):
     # the context stays usable after errors
     R.associate_batch(ctx, maps, fidx, maps, 1, 1, guess, R.default_matcher_params(), corr[:, :, :4].contiguous())
     ctx.synchronize()
+
+
+def test_solve_workgroup_grouping_does_not_change_results(env, monkeypatch):
+    """RANDT_SOLVE_RPB: 1 / 2 / 4 / 8 registrations (one wavefront each) per solve workgroup is a placement choice only --
+    poses and result records must be bit-identical, also when the batch does not fill the last workgroup."""
+    torch, dev, _ = env
+    from util import GpuRig, problem
+
+    prob = problem()
+    mp = R.default_matcher_params(gnc_steps=2)
+    outs = {}
+    for rpb in ("1", "2", "4", "8"):
+        monkeypatch.setenv("RANDT_SOLVE_RPB", rpb)
+        rig = GpuRig(prob)                                   # the knob is read when the context is created
+        rig.build_submaps()
+        rig.build_scans()
+        for n_pairs in (1, 7, rig.B):
+            pose = torch.from_numpy(np.stack([synth.pose3_to_pose4(g) for g in prob["guess"][:n_pairs]])).to(dev)
+            corr = torch.full((n_pairs, rig.scan_cap, mp.n_neighbours), -1, dtype=torch.int32, device=dev)
+            res = torch.zeros((n_pairs, 64), dtype=torch.uint8, device=dev)
+            R.associate_batch(rig.ctx, rig.submaps, rig.fixed_idx, rig.scan_maps, 0, n_pairs, pose, mp, corr)
+            R.solve_batch(rig.ctx, rig.submaps, rig.fixed_idx, rig.scan_maps, 0, n_pairs, corr, mp, pose, res)
+            rig.ctx.synchronize()
+            outs[(rpb, n_pairs)] = (pose.cpu().numpy().copy(), res.cpu().numpy().copy())
+    for n_pairs in (1, 7, len(prob["scans"])):
+        p1, r1 = outs[("1", n_pairs)]
+        for rpb in ("2", "4", "8"):
+            p, r = outs[(rpb, n_pairs)]
+            assert np.array_equal(p, p1) and np.array_equal(r, r1), (rpb, n_pairs)
