@@ -12,6 +12,7 @@
 #include "randt_internal.h"
 
 int randt_set_error(randt_ctx* ctx, int status, const char* what, hipError_t e) {
+  DeviceGuard dev_guard__(ctx);
   if (ctx) {
     ctx->last_error = what ? what : "";
     if (e != hipSuccess) {
@@ -171,6 +172,7 @@ int randt_ctx_set_stream(randt_ctx* ctx, void* stream) {
 }
 
 int randt_ctx_synchronize(randt_ctx* ctx) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx) return RANDT_ERR_INVALID;
   RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return RANDT_OK;
@@ -191,6 +193,7 @@ size_t randt_maps_grid_bytes(int n_maps, const randt_map_params* p) {
 
 int randt_maps_create_external(randt_ctx* ctx, int n_maps, const randt_map_params* p, int cell_capacity, void* d_cells,
                                void* d_counts, void* d_grid, randt_maps** out) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !out || bad_params(p, n_maps, cell_capacity) || !d_cells || !d_counts) return RANDT_ERR_INVALID;
   if (((size_t)d_cells & 15) != 0) return randt_set_error(ctx, RANDT_ERR_INVALID, "cell storage must be 16-byte aligned", hipSuccess);
   randt_maps* m = new (std::nothrow) randt_maps();
@@ -207,24 +210,38 @@ int randt_maps_create_external(randt_ctx* ctx, int n_maps, const randt_map_param
 
 int randt_maps_create(randt_ctx* ctx, int n_maps, const randt_map_params* p, int cell_capacity, int with_grid,
                       randt_maps** out) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !out || bad_params(p, n_maps, cell_capacity)) return RANDT_ERR_INVALID;
   void *cells = nullptr, *counts = nullptr, *grid = nullptr;
-  RANDT_HIP_CHECK(ctx, hipMalloc(&cells, randt_maps_cells_bytes(n_maps, cell_capacity)));
-  RANDT_HIP_CHECK(ctx, hipMalloc(&counts, sizeof(int32_t) * n_maps));
-  if (with_grid) RANDT_HIP_CHECK(ctx, hipMalloc(&grid, randt_maps_grid_bytes(n_maps, p)));
-  int rc = randt_maps_create_external(ctx, n_maps, p, cell_capacity, cells, counts, grid, out);
-  if (rc != RANDT_OK) {
-    (void)hipFree(cells);
-    (void)hipFree(counts);
-    if (grid) (void)hipFree(grid);
+  *out = nullptr;
+  // every failure path below releases what was allocated before it (a long-running node retrying after an
+  // out-of-memory must not lose HBM on every attempt)
+  hipError_t e = hipMalloc(&cells, randt_maps_cells_bytes(n_maps, cell_capacity));
+  if (e == hipSuccess) e = hipMalloc(&counts, sizeof(int32_t) * n_maps);
+  if (e == hipSuccess && with_grid) e = hipMalloc(&grid, randt_maps_grid_bytes(n_maps, p));
+  int rc = RANDT_OK;
+  if (e != hipSuccess) rc = randt_set_error(ctx, e == hipErrorOutOfMemory ? RANDT_ERR_NOMEM : RANDT_ERR_HIP, "hipMalloc (map storage)", e);
+  if (!rc) rc = randt_maps_create_external(ctx, n_maps, p, cell_capacity, cells, counts, grid, out);
+  if (!rc) {
+    (*out)->owns = true;  // from here on randt_maps_destroy releases the buffers
+    e = hipMemsetAsync(cells, 0, randt_maps_cells_bytes(n_maps, cell_capacity), ctx->stream);
+    if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "hipMemsetAsync (map storage)", e);
+    if (!rc) rc = randt_maps_clear(*out, 0, n_maps);
+    if (rc) {
+      (void)randt_maps_destroy(*out);
+      *out = nullptr;
+    }
     return rc;
   }
-  (*out)->owns = true;
-  RANDT_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, randt_maps_cells_bytes(n_maps, cell_capacity), ctx->stream));
-  return randt_maps_clear(*out, 0, n_maps);
+  (void)hipGetLastError();  // a failed hipMalloc leaves a sticky last-error
+  if (cells) (void)hipFree(cells);
+  if (counts) (void)hipFree(counts);
+  if (grid) (void)hipFree(grid);
+  return rc;
 }
 
 int randt_maps_destroy(randt_maps* m) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!m) return RANDT_OK;
   if (m->owns) {
     (void)hipStreamSynchronize(m->ctx->stream);
@@ -258,6 +275,7 @@ static bool range_ok(const randt_maps* m, int first, int count) {
 }
 
 int randt_maps_clear(randt_maps* m, int first, int count) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, first, count)) return RANDT_ERR_INVALID;
   if (count == 0) return RANDT_OK;
   randt_ctx* ctx = m->ctx;
@@ -269,6 +287,7 @@ int randt_maps_clear(randt_maps* m, int first, int count) {
 }
 
 int randt_maps_upload(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, const int32_t* h_grid) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, idx, 1) || n_cells < 0 || n_cells > m->v.cap || (n_cells > 0 && !h_cells)) return RANDT_ERR_INVALID;
   randt_ctx* ctx = m->ctx;
   if (n_cells)
@@ -284,6 +303,7 @@ int randt_maps_upload(randt_maps* m, int idx, const randt_cell* h_cells, int n_c
 }
 
 int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cells, int* n_cells, int32_t* h_grid) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, idx, 1)) return RANDT_ERR_INVALID;
   randt_ctx* ctx = m->ctx;
   int32_t n = 0;
@@ -302,6 +322,7 @@ int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cel
 }
 
 int randt_maps_counts(randt_maps* m, int first, int count, int32_t* h_counts) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, first, count) || !h_counts) return RANDT_ERR_INVALID;
   randt_ctx* ctx = m->ctx;
   if (count)
@@ -311,6 +332,7 @@ int randt_maps_counts(randt_maps* m, int first, int count, int32_t* h_counts) {
 }
 
 int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int src_first, int count) {
+  DeviceGuard dev_guard__(dst ? dst->ctx : nullptr);
   if (!range_ok(dst, dst_first, count) || !range_ok(src, src_first, count)) return RANDT_ERR_INVALID;
   if (dst->v.n_slots != src->v.n_slots || dst->v.cap < src->v.cap) return RANDT_ERR_INVALID;
   randt_ctx* ctx = dst->ctx;
@@ -332,6 +354,7 @@ int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int s
 int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
                               const int32_t* d_n_points, int stride_floats, int intensity_index,
                               const randt_cluster_params* cp, randt_maps* out, int first_map) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !cp || !range_ok(out, first_map, n_scans < 0 ? 0 : n_scans) || n_scans < 0 || pitch_points < 0 ||
       stride_floats < 3 || intensity_index < 0 || intensity_index >= stride_floats || cp->n_clusters <= 0 ||
       !(cp->max_range > 0.f))
@@ -344,6 +367,7 @@ int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans
 
 int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int stride_floats, int intensity_index,
                     const randt_cluster_params* cp, randt_maps* out, int map_idx) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || n_points < 0 || (n_points > 0 && !h_points)) return RANDT_ERR_INVALID;
   if (n_points == 0) {
     int rc = randt_maps_clear(out, map_idx, 1);
@@ -384,6 +408,7 @@ static int append_from(randt_maps* m, int idx, const randt_maps* src, int set_gr
 }
 
 int randt_maps_insert_cells(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, int set_grid) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, idx, 1) || n_cells < 0 || (n_cells > 0 && !h_cells)) return RANDT_ERR_INVALID;
   if (n_cells == 0) return RANDT_OK;
   randt_ctx* ctx = m->ctx;
@@ -402,6 +427,7 @@ int randt_maps_insert_cells(randt_maps* m, int idx, const randt_cell* h_cells, i
 
 int randt_maps_insert_cluster(randt_maps* m, int idx, const float* h_points, int n_points, int stride_floats, int intensity_index,
                               int* accepted) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, idx, 1) || n_points < 0 || (n_points > 0 && !h_points)) return RANDT_ERR_INVALID;
   if (accepted) *accepted = 0;
   if (n_points == 0) return RANDT_OK;
@@ -428,6 +454,7 @@ int randt_maps_insert_cluster(randt_maps* m, int idx, const float* h_points, int
 
 int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_cell* h_queries, int n_queries, int k,
                         int lookup_mahalanobis, int use_intensity, int32_t* h_out) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !range_ok(fixed, fixed_idx, 1) || n_queries < 0 || k <= 0) return RANDT_ERR_INVALID;
   if (n_queries == 0) return RANDT_OK;
   if (!h_queries || !h_out) return RANDT_ERR_INVALID;
@@ -461,12 +488,14 @@ int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
 }
 
 int randt_maps_reindex(randt_maps* m, int first, int count) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, first, count)) return RANDT_ERR_INVALID;
   if (!m->v.grid) return randt_set_error(m->ctx, RANDT_ERR_INVALID, "maps batch has no index grid", hipSuccess);
   return launch_maps_reindex(m->ctx, m->v, first, count);
 }
 
 int randt_maps_transform(randt_maps* m, int first, int count, const double* h_pose4) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, first, count) || (count > 0 && !h_pose4)) return RANDT_ERR_INVALID;
   if (count == 0) return RANDT_OK;
   randt_ctx* ctx = m->ctx;
@@ -480,6 +509,7 @@ int randt_maps_transform(randt_maps* m, int first, int count, const double* h_po
 
 int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_first, int n_moving,
                      const double* h_pose4) {
+  DeviceGuard dev_guard__(fixed ? fixed->ctx : nullptr);
   if (!range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_first, n_moving) || (n_moving > 0 && !h_pose4) || !fixed->v.grid)
     return RANDT_ERR_INVALID;
   if (n_moving == 0) return RANDT_OK;
@@ -492,16 +522,45 @@ int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving,
   return randt_ctx_synchronize(ctx);
 }
 
+// The solve kernels run the reference's GNC / trust-region loops ON THE DEVICE (`do { ... mu /= divisor } while (mu > 1 /
+// sqrt(divisor))`, ndt_matcher.cpp:382-397,466-483): a divisor <= 1 or a non-finite scale that merely hangs a CPU thread
+// in the reference would hang a GPU queue here, so the ABI rejects such parameter sets before anything is enqueued.
+static int check_matcher_params(randt_ctx* ctx, const randt_matcher_params* mp) {
+  const char* bad = nullptr;
+  auto pos = [](double v) { return isfinite(v) && v > 0.0; };
+  if (mp->n_neighbours <= 0 || mp->n_neighbours > 64) bad = "n_neighbours must be in 1..64";
+  else if (!(isfinite(mp->gnc_divisor) && mp->gnc_divisor > 1.0)) bad = "gnc_divisor must be finite and > 1 (the GNC loop divides mu by it until mu <= 1/sqrt(divisor))";
+  else if (mp->gnc_steps < 1 || mp->gnc_steps > 64) bad = "gnc_steps must be in 1..64";
+  else if (mp->max_iterations < 0) bad = "max_iterations must be >= 0";
+  else if (mp->max_consecutive_invalid_steps < 1) bad = "max_consecutive_invalid_steps must be >= 1";
+  else if (!pos(mp->loss_scale)) bad = "loss_scale must be finite and > 0";
+  else if (!pos(mp->mu_scale)) bad = "mu_scale must be finite and > 0";
+  else if (!pos(mp->loss_weight)) bad = "loss_weight must be finite and > 0";
+  else if (!isfinite(mp->loss_alpha)) bad = "loss_alpha must be finite";
+  else if (!isfinite(mp->function_tolerance) || !isfinite(mp->gradient_tolerance) || !isfinite(mp->parameter_tolerance) ||
+           mp->function_tolerance < 0.0 || mp->gradient_tolerance < 0.0 || mp->parameter_tolerance < 0.0)
+    bad = "tolerances must be finite and >= 0";
+  else if (!pos(mp->initial_radius) || !pos(mp->max_radius) || !(isfinite(mp->min_radius) && mp->min_radius >= 0.0))
+    bad = "trust-region radii must be finite and positive";
+  else if (!(isfinite(mp->min_lm_diagonal) && mp->min_lm_diagonal >= 0.0) || !pos(mp->max_lm_diagonal) || mp->min_lm_diagonal > mp->max_lm_diagonal)
+    bad = "LM diagonal bounds";
+  else if (!isfinite(mp->min_relative_decrease)) bad = "min_relative_decrease";
+  else if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_AMBIENT4 && mp->parameterization != RANDT_PARAM_VECTOR)
+    bad = "unknown parameterization";
+  if (bad) return randt_set_error(ctx, RANDT_ERR_INVALID, bad, hipSuccess);
+  return RANDT_OK;
+}
+
 static int check_pairs(randt_ctx* ctx, const randt_maps* fixed, const randt_maps* moving, int moving_first, int n_pairs,
                        const randt_matcher_params* mp) {
   if (!ctx || !fixed || !mp || n_pairs < 0 || !range_ok(moving, moving_first, n_pairs)) return RANDT_ERR_INVALID;
-  if (mp->n_neighbours <= 0 || mp->n_neighbours > 64) return RANDT_ERR_INVALID;
-  return RANDT_OK;
+  return check_matcher_params(ctx, mp);
 }
 
 int randt_associate_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx,
                               const randt_maps* moving, int moving_first, int n_pairs, const double* d_guess4,
                               const randt_matcher_params* mp, int32_t* d_corr) {
+  DeviceGuard dev_guard__(ctx);
   int rc = check_pairs(ctx, fixed, moving, moving_first, n_pairs, mp);
   if (rc) return rc;
   if (n_pairs == 0) return RANDT_OK;
@@ -513,6 +572,7 @@ int randt_associate_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int
 int randt_solve_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx, const randt_maps* moving,
                           int moving_first, int n_pairs, const int32_t* d_corr, const randt_matcher_params* mp,
                           double* d_pose4, randt_result* d_results) {
+  DeviceGuard dev_guard__(ctx);
   int rc = check_pairs(ctx, fixed, moving, moving_first, n_pairs, mp);
   if (rc) return rc;
   if (n_pairs == 0) return RANDT_OK;
@@ -523,6 +583,7 @@ int randt_solve_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t
 int randt_register_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx,
                              const randt_maps* moving, int moving_first, int n_pairs, const randt_matcher_params* mp,
                              double* d_pose4, randt_result* d_results) {
+  DeviceGuard dev_guard__(ctx);
   int rc = check_pairs(ctx, fixed, moving, moving_first, n_pairs, mp);
   if (rc) return rc;
   if (n_pairs == 0) return RANDT_OK;
@@ -542,6 +603,7 @@ int randt_scan_register_batch_dev(randt_ctx* ctx, const float* d_points, int n_s
                                   const randt_cluster_params* cp, const randt_maps* fixed, const int32_t* d_fixed_idx,
                                   randt_maps* scan_maps, const randt_matcher_params* mp, double* d_pose4,
                                   randt_result* d_results) {
+  DeviceGuard dev_guard__(ctx);
   int rc = randt_ndt_build_batch_dev(ctx, d_points, n_scans, pitch_points, d_n_points, stride_floats, intensity_index, cp,
                                      scan_maps, 0);
   if (rc) return rc;
@@ -550,6 +612,7 @@ int randt_scan_register_batch_dev(randt_ctx* ctx, const float* d_points, int n_s
 
 int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
                         const randt_matcher_params* mp, double h_pose4[4], randt_result* h_result) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !h_pose4 || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1) || !mp) return RANDT_ERR_INVALID;
   // small staging block: [pose4 | result | fixed_idx]
   char* stage = nullptr;
@@ -583,9 +646,11 @@ int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
 int randt_eval_cost_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
                               const int32_t* d_corr, const randt_matcher_params* mp, double scale, const double* d_poses4,
                               int n_poses, double* d_cost, int32_t* d_n_res) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !mp || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1) || n_poses < 0) return RANDT_ERR_INVALID;
   if (n_poses == 0) return RANDT_OK;
-  if (!d_corr || !d_poses4 || !d_cost || mp->n_neighbours <= 0) return RANDT_ERR_INVALID;
+  if (!d_corr || !d_poses4 || !d_cost || mp->n_neighbours <= 0 || !isfinite(mp->loss_alpha) || !(isfinite(scale) && scale > 0.0))
+    return RANDT_ERR_INVALID;
   return launch_eval_cost(ctx, fixed->v, fixed_idx, moving->v, moving_idx, d_corr, mp->n_neighbours, mp->use_intensity, scale,
                           mp->loss_alpha, d_poses4, n_poses, d_cost, d_n_res);
 }
@@ -593,6 +658,7 @@ int randt_eval_cost_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed
 int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed_first, int fixed_count,
                                   const int32_t* d_fixed_idx, const randt_maps* moving, int moving_first, int n_pairs,
                                   const double* d_pose4, double* d_out, double* d_terms) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !range_ok(fixed, fixed_first, fixed_count) || fixed_count < 1 || n_pairs < 0 || !range_ok(moving, moving_first, n_pairs))
     return RANDT_ERR_INVALID;
   if (n_pairs == 0) return RANDT_OK;
@@ -606,6 +672,7 @@ int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int f
 
 int randt_cs_divergence(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
                         const double* h_pose4, double* out, double* h_terms) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !out || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1)) return RANDT_ERR_INVALID;
   // device scratch of this call: pose | fixed index | result | terms (kept apart from the workspace the batch entry uses)
   char* d_blk = nullptr;
@@ -634,6 +701,7 @@ int randt_cs_divergence(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
 int randt_sc_make_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int points_pitch, const int32_t* d_n_points,
                             int stride_floats, int intensity_index, const randt_sc_params* p, double* d_desc, double* d_ring_keys,
                             double* d_sector_keys) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !p || n_scans < 0 || points_pitch <= 0 || stride_floats < 3 || intensity_index < 0 || intensity_index >= stride_floats)
     return RANDT_ERR_INVALID;
   if (n_scans == 0) return RANDT_OK;
@@ -645,6 +713,7 @@ int randt_sc_make_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, 
 int randt_sc_detect_batch_dev(randt_ctx* ctx, const randt_sc_params* p, const double* d_desc, const double* d_ring_keys,
                               const double* d_pos, const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries,
                               int32_t* d_loop_id, float* d_yaw, double* d_min_dist) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !p || n_db < 0 || n_queries < 0) return RANDT_ERR_INVALID;
   if (n_queries == 0) return RANDT_OK;
   if (!d_desc || !d_ring_keys || !d_pos || !d_dist || !d_loop_id || !d_yaw) return RANDT_ERR_INVALID;
@@ -689,6 +758,7 @@ int sc_db_reserve(randt_sc_db* db, int want) {
 }  // namespace
 
 int randt_sc_db_create(randt_ctx* ctx, const randt_sc_params* p, int initial_capacity, randt_sc_db** out) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !p || !out || p->num_ring < 1 || p->num_sector < 1) return RANDT_ERR_INVALID;
   randt_sc_db* db = new randt_sc_db();
   db->ctx = ctx;
@@ -710,6 +780,7 @@ int randt_sc_db_create(randt_ctx* ctx, const randt_sc_params* p, int initial_cap
 }
 
 void randt_sc_db_destroy(randt_sc_db* db) {
+  DeviceGuard dev_guard__(db ? db->ctx : nullptr);
   if (!db) return;
   for (double* p : {db->desc, db->ring, db->sector, db->pos, db->dist})
     if (p) (void)hipFree(p);
@@ -721,6 +792,7 @@ int randt_sc_db_size(const randt_sc_db* db) { return db ? db->n : 0; }
 
 int randt_sc_db_append(randt_sc_db* db, const float* h_points, int n_points, int stride_floats, int intensity_index,
                        const double odom_position[2], double traversed_distance, int* node_id) {
+  DeviceGuard dev_guard__(db ? db->ctx : nullptr);
   if (!db || n_points < 0 || (n_points > 0 && !h_points) || !odom_position || stride_floats < 3 || intensity_index < 0 ||
       intensity_index >= stride_floats)
     return RANDT_ERR_INVALID;
@@ -748,6 +820,7 @@ int randt_sc_db_append(randt_sc_db* db, const float* h_points, int n_points, int
 }
 
 int randt_sc_db_detect(randt_sc_db* db, int node_id, int* loop_id, float* yaw_diff_rad, double* min_dist) {
+  DeviceGuard dev_guard__(db ? db->ctx : nullptr);
   if (!db || !loop_id || !yaw_diff_rad || node_id < 0 || node_id >= db->n) return RANDT_ERR_INVALID;
   randt_ctx* ctx = db->ctx;
   int rc = ensure_ws(ctx, sizeof(float) * (size_t)db->n + 256);
@@ -769,6 +842,7 @@ int randt_sc_db_detect(randt_sc_db* db, int node_id, int* loop_id, float* yaw_di
 }
 
 int randt_sc_db_download(const randt_sc_db* db, int node_id, double* h_desc, double* h_ring_key, double* h_sector_key) {
+  DeviceGuard dev_guard__(db ? db->ctx : nullptr);
   if (!db || node_id < 0 || node_id >= db->n) return RANDT_ERR_INVALID;
   randt_ctx* ctx = db->ctx;
   const size_t nd = (size_t)db->p.num_ring * db->p.num_sector;
@@ -787,6 +861,7 @@ int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans,
                                 int stride_floats, int intensity_index, const randt_filter_params* fp,
                                 float* d_out_points, int pitch_out, int32_t* d_out_counts, float* d_out_polar,
                                 float* d_peaks, int32_t* d_peak_counts, int32_t* d_status) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !fp || n_scans < 0 || n_azimuths <= 0 || n_bins <= 0 || stride_floats < 3 || intensity_index < 0 ||
       intensity_index >= stride_floats || pitch_out <= 0)
     return RANDT_ERR_INVALID;
@@ -813,7 +888,15 @@ void bnb_mul(const double* a, const double* b, double* out);
 int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_idx,
                         const randt_matcher_params* mp, const randt_bnb_params* bp, double scale, double swl, double swa,
                         double h_trans4[4], double* min_cost_out, int* n_evals) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !mp || !bp || !h_trans4 || !range_ok(fixed, fixed_idx, 1) || !range_ok(moving, moving_idx, 1)) return RANDT_ERR_INVALID;
+  // the reference's grid loops advance by these steps (`tx += initial_linear_step`, `a += angular_step`, :527-541,
+  // :584-600): a non-positive or non-finite step never terminates (and the node list grows until memory runs out)
+  if (!(isfinite(bp->csm_linear_step) && bp->csm_linear_step > 0.0) || !(isfinite(bp->csm_max_px_accurate_range) && bp->csm_max_px_accurate_range > 0.0) ||
+      bp->csm_n_iter < 1 || bp->csm_n_iter > 16 || !isfinite(swl) || !isfinite(swa) || !isfinite(bp->csm_window_linear) ||
+      !isfinite(bp->csm_window_angular) || !isfinite(bp->csm_cost_threshold) || !(isfinite(scale) && scale > 0.0) || !isfinite(mp->loss_alpha) ||
+      bp->csm_linear_step >= 2.0 * bp->csm_max_px_accurate_range /* acos argument < -1: angular step NaN */)
+    return randt_set_error(ctx, RANDT_ERR_INVALID, "correlative search: steps / ranges must be finite and positive, csm_n_iter in 1..16", hipSuccess);
   swl = fmin(swl, bp->csm_window_linear);   // ndt_matcher.cpp:505-506
   swa = fmin(swa, bp->csm_window_angular);
   const int k = 4;                          // addNDTFactor(..., 4), :520
@@ -900,7 +983,11 @@ int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
                 float key[9];
                 key_of(nd.pose, key);
                 bool found = false;
-                for (size_t t = 0; t + 9 <= keys.size() && !found; t += 9) found = memcmp(&keys[t], key, sizeof(key)) == 0;
+                for (size_t t = 0; t + 9 <= keys.size() && !found; t += 9) {  // std::vector<float> ==: element-wise, -0.0f == 0.0f
+                  bool same = true;
+                  for (int c = 0; c < 9 && same; ++c) same = keys[t + c] == key[c];
+                  found = same;
+                }
                 if (!found) {
                   keys.insert(keys.end(), key, key + 9);
                   next_nodes.push_back(nd);
@@ -1000,11 +1087,18 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
                           const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
                           const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
                           double h_trans4[4], int* rejected, randt_result* h_result) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !fixed || !moving || !h_fixed_idx || !h_moving_idx || !h_states || !mp || !wp || !h_trans4) return RANDT_ERR_INVALID;
   const int S = n_states - 1;
   if (S < 1 || S > 3 || n_fixed < 1 || n_fixed > 2) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..3 optimised states, 1..2 fixed maps", hipSuccess);
   if (mp->parameterization != RANDT_PARAM_MANIFOLD) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window solve implements the manifold configuration", hipSuccess);
   if (mp->n_neighbours <= 0 || mp->n_neighbours > 8) return RANDT_ERR_INVALID;
+  {
+    const int prc = check_matcher_params(ctx, mp);
+    if (prc) return prc;
+    if (!(isfinite(wp->ndt_weight) && wp->ndt_weight > 0.0) || !isfinite(wp->weight_imu) || !isfinite(wp->weight_imu_bias))
+      return randt_set_error(ctx, RANDT_ERR_INVALID, "window weights must be finite (ndt_weight > 0)", hipSuccess);
+  }
   for (int f = 0; f < n_fixed; ++f)
     if (!range_ok(fixed, h_fixed_idx[f], 1)) return RANDT_ERR_INVALID;
   for (int j = 0; j < S; ++j)

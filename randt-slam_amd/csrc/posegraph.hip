@@ -695,6 +695,7 @@ void randt_pg_params_default(randt_pg_params* p) {
 int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int n_edges, const int32_t* h_id_begin,
                                          const int32_t* h_id_end, const double* h_meas, const double* h_sqrt_info,
                                          int max_update_index, const randt_pg_params* opt, randt_pg_result* out) {
+  DeviceGuard dev_guard__(ctx);
   if (!ctx || !opt || n_poses <= 0 || n_edges < 0 || !h_poses) return RANDT_ERR_INVALID;
   if (n_edges > 0 && (!h_id_begin || !h_id_end || !h_meas || !h_sqrt_info)) return RANDT_ERR_INVALID;
   if (out) {

@@ -64,6 +64,23 @@ int randt_set_error(randt_ctx* ctx, int status, const char* what, hipError_t e);
     if (e__ != hipSuccess) return randt_set_error((ctx), RANDT_ERR_HIP, #call, e__); \
   } while (0)
 
+// Makes the context's device current for the duration of an entry point and restores the caller's afterwards: a process
+// (or thread) may hold contexts on several GPUs, and the caller's current device may have been changed behind our back
+// (e.g. torch.cuda.set_device).  Allocations and launches of a context always land on ITS device.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const randt_ctx* ctx) {
+    if (!ctx) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // launchers implemented in the kernel TUs
 int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points,
                      int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map);

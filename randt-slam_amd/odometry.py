@@ -43,9 +43,18 @@ class HipBackend:
         self.free_subs = list(range(submap_slots))
         self.dev = torch.device("cuda", ctx.device)
 
+    def _take(self, pool, name, knob):
+        """Next free slot of a pool.  Slam keeps every keyframe scan and every finished submap referenced for loop
+        closure (like scans_ / submaps_ of the reference's LocalFuser), so a SLAM run needs scan_slots >= number of
+        keyframes + window and submap_slots >= number of submaps + 2."""
+        if not pool:
+            raise host.RandtError(3, "HipBackend", "%s slot pool exhausted: every slot is still referenced; create the backend "
+                                  "with a larger %s" % (name, knob))
+        return pool.pop(0)
+
     # ---- scans
     def build_scan(self, points):
-        idx = self.free_scans.pop(0)
+        idx = self._take(self.free_scans, "scan", "scan_slots")
         pts = points if hasattr(points, "data_ptr") else self.torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(self.dev)
         host.ndt_build_batch(self.ctx, pts.reshape(1, pts.shape[-2], pts.shape[-1]), self.clu, self.scans, first_map=idx)
         return idx
@@ -60,7 +69,7 @@ class HipBackend:
             self._f_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         raw = raw if hasattr(raw, "data_ptr") else torch.from_numpy(np.ascontiguousarray(raw, dtype=np.float32)).to(self.dev)
         host.filter_scan_batch(self.ctx, raw.reshape(1, *raw.shape[-3:]), filter_params, self._f_out, self._f_cnt, self._f_status)
-        idx = self.free_scans.pop(0)
+        idx = self._take(self.free_scans, "scan", "scan_slots")
         host.ndt_build_batch(self.ctx, self._f_out, self.clu, self.scans, first_map=idx, n_points=self._f_cnt)
         return idx
 
@@ -74,7 +83,7 @@ class HipBackend:
 
     # ---- submaps
     def new_submap(self):
-        idx = self.free_subs.pop(0)
+        idx = self._take(self.free_subs, "submap", "submap_slots")
         self.subs.clear(idx, 1)
         return idx
 
@@ -90,7 +99,7 @@ class HipBackend:
     def copy_transformed(self, src_idx, pose4, reindex=False):
         """_last_submap_transformed = _current_submap; .transformMap(pose) (local_fuser.cpp:44-46).  reindex: also rebuild
         the index grid (the reference leaves it stale)."""
-        dst = self.free_subs.pop(0)
+        dst = self._take(self.free_subs, "submap", "submap_slots")
         self.subs.copy_from(self.subs, dst_first=dst, src_first=src_idx, count=1)
         self.subs.transform(dst, np.asarray(pose4, dtype=np.float64).reshape(1, 4))
         if reindex:

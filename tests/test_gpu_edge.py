@@ -332,3 +332,51 @@ def test_solve_workgroup_grouping_does_not_change_results(env, monkeypatch):
         for rpb in ("2", "4", "8"):
             p, r = outs[(rpb, n_pairs)]
             assert np.array_equal(p, p1) and np.array_equal(r, r1), (rpb, n_pairs)
+
+
+def test_parameter_sets_that_would_hang_the_device_are_rejected(env):
+    """The GNC / trust-region loops run on the device: a divisor <= 1, non-positive scales or non-finite tolerances are
+    refused with RANDT_ERR_INVALID before anything is enqueued, and the context stays usable."""
+    torch, dev, ctx = env
+    mapp = R.indoor_map_params()
+    maps = R.Maps(ctx, 2, mapp, 512, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(np.stack([_scan(1200), _scan(1201)])).to(dev), R.indoor_cluster_params(), maps)
+    pose = torch.from_numpy(np.array([[1.0, 0.0, 0.0, 0.0]])).to(dev)
+    fidx = torch.zeros(1, dtype=torch.int32, device=dev)
+    res = torch.zeros((1, 64), dtype=torch.uint8, device=dev)
+    bad_sets = [dict(gnc_divisor=1.0), dict(gnc_divisor=0.5), dict(gnc_divisor=float("nan")), dict(gnc_steps=0), dict(max_iterations=-1),
+                dict(loss_scale=0.0), dict(mu_scale=0.0), dict(mu_scale=float("inf")), dict(loss_weight=-1.0), dict(function_tolerance=float("nan")),
+                dict(initial_radius=0.0), dict(loss_alpha=float("nan")), dict(parameterization=7), dict(max_consecutive_invalid_steps=0)]
+    for over in bad_sets:
+        mp = R.default_matcher_params(**over)
+        with pytest.raises(R.RandtError) as e:
+            R.register_batch(ctx, maps, fidx, maps, 1, 1, mp, pose, res)
+        assert e.value.status == 1, over
+    # window entry point: same gate
+    st = np.array([R.make_state([1, 0, 0, 0]), R.make_state([1, 0, 0.1, 0], stamp=0.25)], dtype=R.STATE_DTYPE)
+    with pytest.raises(R.RandtError) as e:
+        R.register_window(ctx, maps, [0], maps, [1], st, R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_divisor=0.9),
+                          R.window_params(), [1, 0, 0, 0])
+    assert e.value.status == 1 and "gnc_divisor" in str(e.value)
+    # correlative search: a zero / negative step would never terminate on the host
+    for over in (dict(linear_step=0.0), dict(linear_step=-0.4), dict(n_iter=0), dict(max_px_accurate_range=0.0), dict(linear_step=float("nan"))):
+        with pytest.raises(R.RandtError) as e:
+            host.search_global(ctx, maps, 0, maps, 1, R.default_matcher_params(), host.bnb_params(**over), [1, 0, 0, 0])
+        assert e.value.status == 1, over
+    # still alive
+    R.register_batch(ctx, maps, fidx, maps, 1, 1, R.default_matcher_params(), pose, res)
+    ctx.synchronize()
+    assert np.isfinite(pose.cpu().numpy()).all()
+
+
+def test_slot_pool_exhaustion_is_a_descriptive_error(env):
+    from randt_slam_amd import odometry
+
+    torch, dev, ctx = env
+    be = odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params(), scan_slots=2, submap_slots=1)
+    s = _scan(1300)
+    be.build_scan(s)
+    be.build_scan(s)
+    with pytest.raises(R.RandtError) as e:
+        be.build_scan(s)
+    assert "scan slot pool exhausted" in str(e.value) and "scan_slots" in str(e.value)

@@ -80,9 +80,9 @@ def test_predict_state_matches_oracle(built):
             assert np.allclose(a[f], b[f], rtol=0, atol=1e-15), f
 
 
-def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True):
+def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=None):
     torch, ctx = drive["torch"], drive["ctx"]
-    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3, **(mp_over or {}))
     wp = R.window_params(use_imu=use_imu, const_vel=const_vel)
     op, owp = to_oracle_params(mp), to_oracle_wp(wp)
     truth, dt = drive["truth"], drive["dt"]

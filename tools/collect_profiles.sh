@@ -1,0 +1,37 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the evidence behind bench.py's `roofline` line.
+#   tools/collect_profiles.sh TAG [extra bench args]
+# writes under gpurun_out/TAG/:
+#   bench.json                 the default bench line (un-profiled)
+#   stats/                     rocprofv3 --kernel-trace --stats of the same default command
+#   single/                    the same, one stream (clean per-kernel durations)
+#   pmc_<set>/                 one rocprofv3 --pmc pass per counter set (kernel-trace only; never with sys/hip traces)
+# Summaries to commit are produced afterwards (on either side) by tools/pmc_summary.py.
+set -u
+TAG=${1:-r02}
+shift || true
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+HEAD_ONLY="--odometry-scans 0 --polar-scans 0 --slam-scans 0 --polar-odometry-scans 0 --no-cpu-baseline"
+
+python bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -c 600 "$OUT/bench.json"; echo
+
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run --output-format csv -- python bench.py "$@" > "$OUT/stats_bench.json" 2> "$OUT/stats.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/single" -o run --output-format csv -- python bench.py --streams 1 --steps 300 $HEAD_ONLY "$@" > "$OUT/single_bench.json" 2> "$OUT/single.err"
+
+# SQ: 8 slots per pass; TCC: FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+declare -A SETS
+SETS[sq_a]="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES"
+SETS[sq_b]="SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+SETS[sq_c]="SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_BUSY_CYCLES"
+SETS[fetch]="FETCH_SIZE GRBM_GUI_ACTIVE"
+SETS[write]="WRITE_SIZE"
+for s in sq_a sq_b sq_c fetch write; do
+  rocprofv3 --kernel-trace --pmc ${SETS[$s]} -d "$OUT/pmc_$s" -o run --output-format csv -- \
+    python bench.py --streams 1 --steps 24 --warmup 2 $HEAD_ONLY "$@" > "$OUT/pmc_$s.json" 2> "$OUT/pmc_$s.err"
+  ls "$OUT/pmc_$s" | head -3
+done
+find "$OUT" -name '*agent_info.csv' -delete
+du -sh "$OUT"
