@@ -1,20 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- NDT registrations/sec on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic input: BASELINE config 4's batch
-of 512 independent registrations (8 submaps x 64 scans; 2000-point radar scans vs 100x100-slot
-0.5 m submaps, indoor parameter set), each registration = NDT build from the raw points +
-association against its submap + the full GNC / Levenberg-Marquardt solve, all on the GPU through
-the C ABI of librandt_hip.so.  Inputs are resident in HBM before the timed region starts.
+A "step" is one pass of the hot path over one batch of synthetic input: BASELINE config 4's batch of 512 independent
+registrations (8 submaps x 64 scans; 2000-point radar scans vs 100x100-slot 0.5 m submaps, indoor parameter set), each
+registration = NDT build from the raw points + association against its submap + the full GNC / Levenberg-Marquardt
+solve, all on the GPU through the C ABI of librandt_hip.so.  Inputs are resident in HBM before the timed region starts.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): independent registrations shard
-with no data-path collective -- every rank processes its own 512-registration batch per step
-("weak" scaling).  The submap tables are built once on rank 0 and broadcast over RCCL at set-up.
+Timed region: at least --steps steps AND at least --min-seconds of wall time (a 20-step region is 1.7 ms: clocks have
+not settled); the JSON reports the number of steps actually timed ("steps") next to the requested minimum.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU; "nccl" = RCCL over xGMI).  Independent registrations
+shard with no data-path collective; the only collectives are the set-up broadcast of the submap tables and the result
+gather.  Two regions are timed at N > 1:
+  * weak   (the headline `value`): every rank processes its own 512-registration batch per step;
+  * strong (`strong_scaling`): BASELINE config 4 as written -- ONE batch of 512 (seeds 1000..1511) split contiguously,
+    rank r runs [r*512/N, (r+1)*512/N), results all-gathered and checked bit-identical to the unsharded batch.
+
+Roofline: this path is not HBM-bound (counter traffic is ~10x below the dense-table byte model) but VALU-issue bound
+(fp64 vector instructions, no MFMA: J^T J is a reduction, not a GEMM).  `roofline` therefore prices the dominant kernel
+against the VALU issue rate: counted instructions per launch (rocprofv3 SQ counters, profiles/*_sq_summary.csv) x
+measured issue cycles per instruction class (tools/valu_rate_probe.hip) / the launch duration measured here with HIP
+events, over 1024 SIMDs x 2.4 GHz.  The SURVEY byte model and the counter traffic are kept as labelled secondaries.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import csv
+import glob
 import json
+import math
 import os
 import sys
 import time
@@ -28,9 +42,10 @@ N_SUBMAPS, SCANS_PER_SUBMAP, N_KEYFRAMES = 8, 64, 34
 N_POINTS, N_SLOTS = 2000, 100 * 100
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # vector fp64 (half the 157.3 TF fp32 vector rate)
-# HBM bytes of one 512-registration step measured with PMC counters (profiles/r01_pmc_summary.csv):
-# FETCH_SIZE KB x2 (gfx950 correction) of k_ndt_build + k_associate + k_solve, plus their WRITE_SIZE KB
-PMC_TRAFFIC_BYTES_PER_STEP = int(((8156.6 + 2082.4 + 1835.4) * 2 + (1834.9 + 609.2 + 48.0)) * 1024)  # profiles/r01_f_pmc_summary.csv
+N_SIMDS, CLOCK_GHZ = 1024, 2.4          # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip table)
+VALU_PEAK = N_SIMDS * CLOCK_GHZ         # G SIMD-cycles/s of VALU issue
+SAT_COPIES = 8                          # chip-filling launch of the roofline section: 8 copies of the batch = 4096 registrations
+HOT_KERNELS = ("k_ndt_build<true>", "k_associate<false>", "k_solve<3,1,64,true,4>")
 
 
 def algorithmic_bytes(n_points, n_slots, m_cells, k):
@@ -39,145 +54,66 @@ def algorithmic_bytes(n_points, n_slots, m_cells, k):
     return n_points * 16 + n_slots * 48 + n_slots * 4 + m_cells * 48 * 2 + m_cells * k * 4 + 64
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch-scale", type=int, default=1,
-                    help="diagnostic: registrations per step = 512 x this (the headline workload is 1)")
-    ap.add_argument("--only", choices=["build", "associate", "solve"], default=None,
-                    help="diagnostic: time ONE stage alone at saturation (the printed value is then not the headline metric)")
-    ap.add_argument("--streams", type=int, default=16, help="in-flight batches: step i runs on HIP stream i %% streams "
-                    "(GPU_MAX_HW_QUEUES is raised to match unless already set: HIP maps streams onto 4 hardware queues by default)")
-    ap.add_argument("--odometry-scans", type=int, default=200, help="BASELINE config 3 side measurement (0 = skip)")
-    ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
-    ap.add_argument("--slam-scans", type=int, default=300,
-                    help="side measurement: whole SLAM call pattern (odometry + loop closure + pose graph) on a two-lap drive (0 = skip)")
-    ap.add_argument("--polar-odometry-scans", type=int, default=60,
-                    help="BASELINE config 5 side measurement: full local-fuser loop on raw polar scans (0 = skip)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock budget of the CPU baseline leg")
-    args = ap.parse_args()
+def load_counters():
+    """Latest committed profiles/r*_sq_summary.csv (tools/pmc_summary.py): per-launch SQ / TCC counters of the three hot
+    kernels at the 512-registration launch.  Returns ({kernel: row dict}, file name) or ({}, None)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_summary.csv")))
+    if not files:
+        return {}, None
+    rows = {}
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"] in HOT_KERNELS and int(r["dispatches"]) >= 8 and r["kernel"] not in rows:
+            rows[r["kernel"]] = {k: (float(v) if v not in ("", None) and k != "kernel" else v) for k, v in r.items()}
+    return rows, os.path.relpath(files[-1], ROOT)
 
-    # in-flight batches need their own hardware queues to overlap (must be set before the HIP runtime starts)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(32, args.streams))))
-    import torch
-    import torch.distributed as dist
 
-    import randt_slam_amd as R
-    from randt_slam_amd import synth
+class Batch:
+    """One batch of registrations resident in HBM + the per-stream working sets of the three launches."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev and os.environ.get("RANDT_BENCH_BACKEND") != "gloo":
-        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, n_dev))
-    local_rank = local_rank % max(1, n_dev)   # only differs in the single-GPU gloo logic test
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        # "nccl" IS RCCL on ROCm.  RANDT_BENCH_BACKEND=gloo exists only to exercise the multi-rank control
-        # flow on a box with fewer GPUs than ranks (tests); it is never used for reported numbers.
-        backend = os.environ.get("RANDT_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
+    def __init__(self, R, torch, ctxs, submaps_v, mapp, clu, mp, points, fixed_idx, guess4, scan_cap=512):
+        self.R, self.torch, self.ctxs, self.submaps_v, self.clu, self.mp = R, torch, ctxs, submaps_v, clu, mp
+        self.points, self.fixed_idx, self.guess4 = points, fixed_idx, guess4
+        self.B = int(points.shape[0])
+        n, k, dev = len(ctxs), mp.n_neighbours, points.device
+        self.poses = [guess4.clone() for _ in range(n)]
+        self.results = [torch.zeros((self.B, 64), dtype=torch.uint8, device=dev) for _ in range(n)]
+        self.corrs = [torch.full((self.B, scan_cap, k), -1, dtype=torch.int32, device=dev) for _ in range(n)]
+        self.scan_maps = [R.Maps(ctxs[i], self.B, mapp, scan_cap, with_grid=False) for i in range(n)]
 
-    # One randt context per HIP stream: consecutive steps (independent batches) alternate streams so
-    # that the latency-bound tail of one batch's solve overlaps the next batch's build / association.
-    n_streams = max(1, args.streams)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
-    ctxs = [R.Context(local_rank, st.cuda_stream) for st in streams]
-    stream, ctx = streams[0], ctxs[0]
-    mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
-    mp = R.default_matcher_params()
-    k = mp.n_neighbours
-    scans_per_submap = SCANS_PER_SUBMAP * max(1, args.batch_scale)
-    B = N_SUBMAPS * scans_per_submap
-    scan_cap = 512
-
-    # ---------------- set-up (untimed): synthetic world, scans, submaps ---------------------------
-    prob = synth.make_batch_problem(N_SUBMAPS, scans_per_submap, N_KEYFRAMES, scan_seed0=1000 + 100000 * rank,
-                                    guess_seed0=2000 + 100000 * rank)
-    # submap tables live in torch-owned HBM so that RCCL can broadcast them
-    cb, nb, gb = R.Maps.storage_bytes(N_SUBMAPS, mapp, N_SLOTS)
-    t_cells = torch.zeros(cb, dtype=torch.uint8, device=dev)
-    t_counts = torch.zeros(N_SUBMAPS, dtype=torch.int32, device=dev)
-    t_grid = torch.zeros(gb // 4, dtype=torch.int32, device=dev)
-    submaps = R.Maps(ctx, N_SUBMAPS, mapp, N_SLOTS, storage=(t_cells, t_counts, t_grid))
-    if rank == 0:
-        for j, sm in enumerate(prob["submaps"]):
-            kf = torch.from_numpy(np.stack(sm["kf_scans"])).to(dev)
-            tmp = R.Maps(ctx, kf.shape[0], mapp, scan_cap, with_grid=False)
-            R.ndt_build_batch(ctx, kf, clu, tmp)
-            submaps.merge(j, tmp, 0, synth.pose3_to_pose4(sm["kf_rel"]))  # rolling-submap path (a9 + a18)
-            tmp.close()
-    ctx.synchronize()
-    if world > 1:
-        # the only collective: submap cell tables + index grids from the owner rank, once per submap epoch
-        for t in (t_cells, t_counts, t_grid):
-            dist.broadcast(t, src=0)
-        torch.cuda.synchronize()
-
-    points = torch.from_numpy(prob["scans"]).to(dev)                       # (B, 2000, 4) f32, 16 B / point
-    fixed_idx = torch.from_numpy(prob["submap_of"]).to(dev)
-    guess4 = torch.from_numpy(synth.pose3_to_pose4(prob["guess"])).to(dev)
-    # per-stream working set (outputs + intermediates); inputs and submaps are shared read-only
-    poses = [guess4.clone() for _ in range(n_streams)]
-    resultss = [torch.zeros((B, 64), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
-    corrs = [torch.full((B, scan_cap, k), -1, dtype=torch.int32, device=dev) for _ in range(n_streams)]
-    submaps_v = [submaps] + [R.Maps(ctxs[i], N_SUBMAPS, mapp, N_SLOTS, storage=(t_cells, t_counts, t_grid), clear=False)
-                             for i in range(1, n_streams)]
-    scan_mapss = [R.Maps(ctxs[i], B, mapp, scan_cap, with_grid=False) for i in range(n_streams)]
-    # the initial guess is an input and the solve updates it in place (Sophus::SE2d& trans): every timed step gets
-    # its own 16 KB copy of the guesses, resident before the timed region starts, instead of a reset copy per step
-    step_pose = [guess4.clone() for _ in range(args.steps)]
-    pose, results, scan_maps = step_pose[0], resultss[0], scan_mapss[0]
-    torch.cuda.synchronize()
-
-    def step(i, events=None):
-        j = i % n_streams
-        st, cx = streams[j], ctxs[j]
-        if events is None:
-            with torch.cuda.stream(st):
-                poses[j].copy_(guess4)                         # warm-up: reuse the per-stream buffer
-            pose_j = poses[j]
-        else:
-            pose_j = step_pose[i]
-        only = args.only if events is not None else None        # warm-up always runs the full path
+    def step(self, j, stream, pose, events=None, only=None):
+        """Enqueue build -> associate -> solve of the whole batch on stream slot j (asynchronous)."""
+        R, cx = self.R, self.ctxs[j]
         if events is not None:
-            events[0].record(st)
+            events[0].record(stream)
         if only in (None, "build"):
-            R.ndt_build_batch(cx, points, clu, scan_mapss[j])
+            R.ndt_build_batch(cx, self.points, self.clu, self.scan_maps[j])
         if events is not None:
-            events[1].record(st)
+            events[1].record(stream)
         if only in (None, "associate"):
-            R.associate_batch(cx, submaps_v[j], fixed_idx, scan_mapss[j], 0, B, pose_j, mp, corrs[j])
+            R.associate_batch(cx, self.submaps_v[j], self.fixed_idx, self.scan_maps[j], 0, self.B, pose, self.mp, self.corrs[j])
         if events is not None:
-            events[2].record(st)
+            events[2].record(stream)
         if only in (None, "solve"):
-            R.solve_batch(cx, submaps_v[j], fixed_idx, scan_mapss[j], 0, B, corrs[j], mp, pose_j, resultss[j])
+            R.solve_batch(cx, self.submaps_v[j], self.fixed_idx, self.scan_maps[j], 0, self.B, self.corrs[j], self.mp, pose, self.results[j])
         if events is not None:
-            events[3].record(st)
+            events[3].record(stream)
 
-    for i in range(args.warmup * n_streams):
-        step(i)
+
+def timed_region(torch, dist, world, dev, batch, streams, n_steps, only=None):
+    """EXACTLY n_steps steps between barrier + synchronize on both sides; MAX over ranks.  The initial guess is an input
+    and the solve updates it in place (Sophus::SE2d& trans): every step gets its own copy, resident beforehand."""
+    n_streams = len(streams)
+    step_pose = [batch.guess4.clone() for _ in range(n_steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_steps)]
     torch.cuda.synchronize()
-
-    # ---------------- timed region -----------------------------------------------------------------
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(s, ev[s])
-    t_enqueued = time.perf_counter() - t0
+    for s in range(n_steps):
+        j = s % n_streams
+        batch.step(j, streams[j], step_pose[s], ev[s], only)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -186,27 +122,191 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    stage_ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(3)] for s in range(n_steps)]).mean(axis=0)
+    return elapsed, t_enq, stage_ms, step_pose[0]
 
-    stage_ms = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(3)] for s in range(args.steps)]).mean(axis=0)
+
+def warm_up(torch, batch, streams, n):
+    for i in range(n):
+        j = i % len(streams)
+        with torch.cuda.stream(streams[j]):
+            batch.poses[j].copy_(batch.guess4)
+        batch.step(j, streams[j], batch.poses[j])
+    torch.cuda.synchronize()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000, help="minimum number of timed steps")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--min-seconds", type=float, default=0.3, help="the timed region also lasts at least this long")
+    ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
+                    help="multi-GPU regions to time (the headline value is the weak one unless only strong is asked for)")
+    ap.add_argument("--batch-scale", type=int, default=1,
+                    help="diagnostic: registrations per step = 512 x this (the headline workload is 1)")
+    ap.add_argument("--only", choices=["build", "associate", "solve"], default=None,
+                    help="diagnostic: time ONE stage alone at saturation (the printed value is then not the headline metric)")
+    ap.add_argument("--streams", type=int, default=16, help="in-flight batches: step i runs on HIP stream i %% streams "
+                    "(GPU_MAX_HW_QUEUES is raised to match unless already set: HIP maps streams onto 4 hardware queues by default)")
+    ap.add_argument("--odometry-scans", type=int, default=1000, help="BASELINE config 3 side measurement (0 = skip)")
+    ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
+    ap.add_argument("--slam-scans", type=int, default=300,
+                    help="side measurement: whole SLAM call pattern (odometry + loop closure + pose graph) on a two-lap drive (0 = skip)")
+    ap.add_argument("--polar-odometry-scans", type=int, default=60,
+                    help="BASELINE config 5 side measurement: full local-fuser loop on raw polar scans (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-sections", action="store_true", help="skip the single-stream / chip-filling-launch sections")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock budget of each CPU baseline leg")
+    args = ap.parse_args()
+
+    # in-flight batches need their own hardware queues to overlap (must be set before the HIP runtime starts)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(32, args.streams))))
+    import torch
+    import torch.distributed as dist
+
+    import randt_slam_amd as R
+    from randt_slam_amd import shard, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get("RANDT_BENCH_BACKEND", "nccl")
+    if local_rank >= n_dev and backend != "gloo":
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, n_dev))
+    local_rank = local_rank % max(1, n_dev)   # only differs in the single-GPU gloo logic test
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        # "nccl" IS RCCL on ROCm.  RANDT_BENCH_BACKEND=gloo exists only to exercise the multi-rank control flow on a box
+        # with fewer GPUs than ranks (tests); it is never used for reported numbers.
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    via_cpu = world > 1 and backend != "nccl"
+
+    # One randt context per HIP stream: consecutive steps (independent batches) alternate streams so
+    # that the latency-bound tail of one batch's solve overlaps the next batch's build / association.
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
+    ctxs = [R.Context(local_rank, st.cuda_stream) for st in streams]
+    ctx = ctxs[0]
+    mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
+    mp = R.default_matcher_params()
+    k = mp.n_neighbours
+    scans_per_submap = SCANS_PER_SUBMAP * max(1, args.batch_scale)
+    B = N_SUBMAPS * scans_per_submap
+
+    # ---------------- set-up (untimed): synthetic world, scans, submaps ---------------------------
+    # base problem = BASELINE config 4 (seeds 1000...): every rank generates it (deterministic); the submap tables are
+    # BUILT on rank 0 only and broadcast (RCCL), like a deployment where one rank owns the submap epoch
+    base = synth.make_batch_problem(N_SUBMAPS, scans_per_submap, N_KEYFRAMES)
+    cb, nb, gb = R.Maps.storage_bytes(N_SUBMAPS, mapp, N_SLOTS)
+    t_cells = torch.zeros(cb, dtype=torch.uint8, device=dev)       # torch-owned HBM so that RCCL can broadcast the tables
+    t_counts = torch.zeros(N_SUBMAPS, dtype=torch.int32, device=dev)
+    t_grid = torch.zeros(gb // 4, dtype=torch.int32, device=dev)
+    submaps = R.Maps(ctx, N_SUBMAPS, mapp, N_SLOTS, storage=(t_cells, t_counts, t_grid))
+    if rank == 0:
+        for j, sm in enumerate(base["submaps"]):
+            kf = torch.from_numpy(np.stack(sm["kf_scans"])).to(dev)
+            tmp = R.Maps(ctx, kf.shape[0], mapp, 512, with_grid=False)
+            R.ndt_build_batch(ctx, kf, clu, tmp)
+            submaps.merge(j, tmp, 0, synth.pose3_to_pose4(sm["kf_rel"]))  # rolling-submap path (a9 + a18)
+            tmp.close()
+    ctx.synchronize()
+    t_bcast = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        if via_cpu:
+            for t in (t_cells, t_counts, t_grid):
+                h = t.cpu()
+                dist.broadcast(h, src=0)
+                t.copy_(h)
+        else:
+            shard.broadcast_submap_tables((t_cells, t_counts, t_grid), src=0)   # the only set-up collective
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+    submaps_v = [submaps] + [R.Maps(ctxs[i], N_SUBMAPS, mapp, N_SLOTS, storage=(t_cells, t_counts, t_grid), clear=False)
+                             for i in range(1, n_streams)]
+
+    def to_dev(prob, lo=0, hi=None):
+        hi = len(prob["scans"]) if hi is None else hi
+        return (torch.from_numpy(prob["scans"][lo:hi]).to(dev), torch.from_numpy(prob["submap_of"][lo:hi]).to(dev),
+                torch.from_numpy(synth.pose3_to_pose4(prob["guess"][lo:hi])).to(dev))
+
+    # weak region: rank r > 0 registers its OWN 512 scans (other seeds) against the same submaps
+    if rank == 0 or args.scaling == "strong":
+        weak_prob = base
+    else:
+        weak_prob = synth.make_batch_problem(N_SUBMAPS, scans_per_submap, N_KEYFRAMES, scan_seed0=1000 + 100000 * rank,
+                                             guess_seed0=2000 + 100000 * rank)
+    full = Batch(R, torch, ctxs, submaps_v, mapp, clu, mp, *to_dev(weak_prob))
+    warm_up(torch, full, streams, args.warmup * n_streams)
+
+    # ---------------- timed region (weak = the headline) --------------------------------------------
+    # the region is re-run with more steps until it lasts --min-seconds (the LAST region is the reported one; `elapsed` is
+    # already the maximum over ranks, so every rank takes the same decision)
+    def region(batch):
+        n = args.steps
+        for _ in range(6):
+            r = timed_region(torch, dist, world, dev, batch, streams, n, args.only)
+            if r[0] >= args.min_seconds:
+                break
+            n = int(math.ceil(n * max(1.5, 1.25 * args.min_seconds / max(r[0], 1e-9))))
+        return (n,) + r
+
+    out = {}
+    if args.scaling != "strong" or world == 1:
+        n_steps, elapsed, t_enqueued, stage_ms, pose0 = region(full)
+        value = B * n_steps * world / elapsed
+        scaling = "weak"
+    strong = None
+    if world > 1 and args.scaling in ("strong", "both"):
+        lo, hi = shard.shard_range(B, world, rank)
+        part = Batch(R, torch, ctxs, submaps_v, mapp, clu, mp, *to_dev(base, lo, hi))
+        warm_up(torch, part, streams, 2 * n_streams)
+        s_steps, s_elapsed, s_enq, s_stage, s_pose0 = region(part)
+        # result gather (all-gather of 32-B poses + 64-B records) and the bit-identity check against the unsharded batch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lp, lr = (s_pose0.cpu(), part.results[0].cpu()) if via_cpu else (s_pose0, part.results[0])
+        all_pose = shard.gather_results(lp)
+        all_res = shard.gather_results(lr)
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - t0
+        strong = {"value": B * s_steps / s_elapsed, "unit": "registrations/s", "scaling": "strong", "steps": s_steps,
+                  "ms_per_step": s_elapsed / s_steps * 1e3, "registrations_per_gpu_per_step": hi - lo,
+                  "workload": "ONE 512-registration batch (seeds 1000..1511) split contiguously over %d GPUs" % world,
+                  "stage_ms": {"ndt_build": float(s_stage[0]), "associate": float(s_stage[1]), "solve": float(s_stage[2])},
+                  "result_gather_ms": t_gather * 1e3, "submap_broadcast_ms": t_bcast * 1e3,
+                  "submap_broadcast_bytes": int(cb + nb + gb)}
+        if rank == 0:
+            ref = Batch(R, torch, ctxs[:1], submaps_v[:1], mapp, clu, mp, *to_dev(base))
+            rp = ref.guess4.clone()
+            ref.step(0, streams[0], rp)
+            torch.cuda.synchronize()
+            strong["poses_bit_identical_to_unsharded"] = bool(torch.equal(all_pose.cpu(), rp.cpu()) and
+                                                              torch.equal(all_res.cpu(), ref.results[0].cpu()))
+        if args.scaling == "strong":
+            n_steps, elapsed, t_enqueued, stage_ms, pose0, value, scaling = s_steps, s_elapsed, s_enq, s_stage, s_pose0, strong["value"], "strong"
 
     if rank == 0:
-        res = results.cpu().numpy().view(R.RESULT_DTYPE).reshape(-1)
-        counts = scan_maps.counts()
-        m_mean = float(counts.mean())
+        res = full.results[0].cpu().numpy().view(R.RESULT_DTYPE).reshape(-1)
+        m_mean = float(full.scan_maps[0].counts().mean())
         n_res_mean = float(res["n_residuals"].mean())
-        evals_mean = float(res["n_evals"].mean())
-        value = B * args.steps * world / elapsed
-        path_ms = float(stage_ms.sum())
         b_alg = algorithmic_bytes(N_POINTS, N_SLOTS, m_mean, k)
-        achieved_gbs = b_alg * B / (path_ms * 1e-3) / 1e9
-        solve_gbs = b_alg * B / (float(stage_ms[2]) * 1e-3) / 1e9
-        # fp64 work of the solve kernel: SURVEY 8(d) F_alg = C * (E_J*370 + E_c*250); every pass here is a
-        # Jacobian pass except the raw-residual one
-        flops = n_res_mean * ((evals_mean - 1) * 370 + 250) * B
+        counters, counters_file = load_counters()
         out = {
-            "metric": "ndt_registrations_per_sec" if args.only is None and args.batch_scale == 1 else "DIAGNOSTIC_only=%s_batch_scale=%d" % (args.only, args.batch_scale), "value": value, "unit": "registrations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "ndt_registrations_per_sec" if args.only is None and args.batch_scale == 1 else "DIAGNOSTIC_only=%s_batch_scale=%d" % (args.only, args.batch_scale),
+            "value": value, "unit": "registrations/s",
+            "n_gpus": world, "steps": n_steps, "steps_requested": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / n_steps * 1e3, "timed_region_s": elapsed, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "BASELINE config 4 batch: 512 independent registrations per GPU per step "
@@ -216,38 +316,19 @@ def main():
                 "parameterization": "ambient4 (reference loop-closure behaviour)", "gnc_steps": mp.gnc_steps,
                 "streams": n_streams,
                 "mean_scan_cells": m_mean, "mean_residuals": n_res_mean, "mean_lm_iterations": float(res["iterations"].mean()),
+                "mean_passes": float(res["n_evals"].mean()),
             },
-            "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
-            "stage_ms": {"ndt_build": float(stage_ms[0]), "associate": float(stage_ms[1]), "solve": float(stage_ms[2])},
-            "roofline": {
-                # dominant kernel = k_solve; achieved = SURVEY 8(d) algorithmic bytes per registration x the 512
-                # registrations one launch processes / that kernel's average launch duration (HIP events on its stream)
-                "bound": "hbm", "achieved": solve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": solve_gbs / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES_PER_STEP,
-                "kernel": "k_solve<3,1,64,true,4> (dominant; four registrations = four wavefronts per workgroup); k_ndt_build and k_associate run once per step as well",
-                "algorithmic_bytes_per_registration": b_alg, "registrations_per_launch": B,
-                "avg_launch_ms": {"k_ndt_build": float(stage_ms[0]), "k_associate": float(stage_ms[1]), "k_solve": float(stage_ms[2])},
-                "all_three_kernels": {"achieved": achieved_gbs, "frac": achieved_gbs / HBM_PEAK_GBS},
-                "path_effective": {"achieved": value / world * b_alg / 1e9, "frac": value / world * b_alg / 1e9 / HBM_PEAK_GBS,
-                                   "note": "SURVEY 8(d) definition: registrations/s x algorithmic bytes (batches overlap on %d streams)" % n_streams},
-                "traffic_note": "HBM bytes per step (the three launches) from separate rocprofv3 --pmc passes, FETCH_SIZE x2 "
-                                "(gfx950 correction, calibrated on k_ndt_build / k_filter_peaks whose byte counts are known) + "
-                                "WRITE_SIZE, profiles/r01_f_pmc_summary.csv; ~10x BELOW the algorithmic bytes because the compact "
-                                "cell tables never touch the empty slots of the dense submap grid",
-                "note": "path is fp64-VALU / iteration-latency bound (SURVEY 8(d)); see roofline_fp64",
-            },
-            "roofline_fp64": {
-                "bound": "fp64_valu", "kernel": "k_solve", "achieved": flops / (float(stage_ms[2]) * 1e-3) / 1e12,
-                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / (float(stage_ms[2]) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                "note": "per launch: useful fp64 flops of one 512-registration solve / its duration while %d batches share the chip" % n_streams,
-                # whole-path figure: the solve's useful flops per registration x registrations/s of one GPU
-                "path_effective": {"achieved": flops / B * (value / world) / 1e12,
-                                   "frac": flops / B * (value / world) / 1e12 / FP64_PEAK_TFLOPS},
-            },
+            "host_enqueue_ms_per_step": t_enqueued / n_steps * 1e3,
+            "stage_ms": {"ndt_build": float(stage_ms[0]), "associate": float(stage_ms[1]), "solve": float(stage_ms[2]),
+                         "note": "HIP-event residency of each launch while %d batches share the chip (not a per-step cost)" % n_streams},
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
+        if world == 1 and not args.no_roofline_sections and args.only is None and args.batch_scale == 1:
+            out.update(roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file,
+                                         b_alg, value, elapsed / n_steps))
         if not args.no_cpu_baseline and world == 1:
-            out.update(cpu_baseline(prob, mp, pose.cpu().numpy(), args.cpu_seconds))
+            out.update(cpu_baseline(weak_prob, mp, pose0.cpu().numpy(), args.cpu_seconds))
         if args.odometry_scans > 0 and world == 1:
             out["config3_streaming_odometry"] = streaming_odometry(ctx, args.odometry_scans, not args.no_cpu_baseline)
         if args.polar_scans > 0 and world == 1:
@@ -260,6 +341,105 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file, b_alg, value, s_per_step):
+    """Clean (non-overlapped) measurements behind the `roofline` object, all with HIP events on the launch stream:
+      single_batch      ONE 512-registration batch at a time on one stream: latency, rate, per-kernel durations;
+      chip-filling      the dominant kernel (k_solve) with SAT_COPIES copies of the batch = 4096 registrations in ONE
+                        launch, one stream: the launch fills the chip by itself, so its duration is a per-launch cost and
+                        the rocprofv3 kernel trace of the same command shows the same number."""
+    st, B = streams[0], full.B
+    # ---- single batch, single stream
+    reps = 200
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    poses = [full.guess4.clone() for _ in range(reps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        full.step(0, st, poses[i], ev[i])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sb = np.array([[ev[s][i].elapsed_time(ev[s][i + 1]) for i in range(3)] for s in range(reps)]).mean(axis=0) * 1e3   # us
+    lat = np.array([ev[s][0].elapsed_time(ev[s][3]) for s in range(reps)]).mean() * 1e3
+    single = {"streams": 1, "registrations_per_launch": B, "value": B * reps / el, "unit": "registrations/s",
+              "batch_latency_us": float(lat),
+              "kernel_us": {"k_ndt_build": float(sb[0]), "k_associate": float(sb[1]), "k_solve": float(sb[2])},
+              "note": "one 512-registration batch alone (a loop-closure burst): 512 solve wavefronts cannot fill 1024 SIMDs"}
+    # ---- chip-filling launch of the dominant kernel
+    rep = lambda t: t.repeat(*([SAT_COPIES] + [1] * (t.dim() - 1))).contiguous()
+    big = Batch(R, torch, ctxs[:1], submaps_v[:1], mapp, clu, mp, rep(full.points), rep(full.fixed_idx), rep(full.guess4))
+    big.step(0, st, big.poses[0])                       # build + associate (+ a warm-up solve) once
+    n_l = 20
+    bp = [big.guess4.clone() for _ in range(n_l)]
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_l)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_l)]
+    e_b = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    torch.cuda.synchronize()
+    for i in range(n_l):
+        e0[i].record(st)
+        R.solve_batch(ctxs[0], submaps_v[0], big.fixed_idx, big.scan_maps[0], 0, big.B, big.corrs[0], mp, bp[i], big.results[0])
+        e1[i].record(st)
+    e_b[0].record(st)
+    R.ndt_build_batch(ctxs[0], big.points, clu, big.scan_maps[0])
+    e_b[1].record(st)
+    R.associate_batch(ctxs[0], submaps_v[0], big.fixed_idx, big.scan_maps[0], 0, big.B, big.guess4, mp, big.corrs[0])
+    e_b[2].record(st)
+    torch.cuda.synchronize()
+    sat_us = float(np.mean([e0[i].elapsed_time(e1[i]) for i in range(n_l)]) * 1e3)
+    sat_build_us, sat_assoc_us = e_b[0].elapsed_time(e_b[1]) * 1e3, e_b[1].elapsed_time(e_b[2]) * 1e3
+
+    ks = counters.get("k_solve<3,1,64,true,4>")
+    roof = {"bound": "valu_issue", "unit": "G SIMD-cycles/s", "peak": VALU_PEAK,
+            "peak_note": "%d SIMDs x %.1f GHz max clock; one wave64 VALU instruction occupies its SIMD's issue port for the cycles "
+                         "listed in cycle_costs (tools/valu_rate_probe.hip; under sustained VALU load the chip clocks 1.6-1.85 GHz, "
+                         "so 100 %% of this peak is not reachable)" % (N_SIMDS, CLOCK_GHZ),
+            "kernel": "k_solve<3,1,64,true,4> (dominant: 62 % of the path's VALU issue cycles)",
+            "launch": "%d registrations (%d copies of the 512 batch) in ONE launch, one stream, nothing else running" % (big.B, SAT_COPIES),
+            "avg_launch_us": sat_us, "achieved": None, "frac": None, "traffic": None, "counters": counters_file}
+    out = {"roofline": roof, "single_batch": single}
+    if ks is not None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_summary import VALU_COST
+
+        cyc = {n: counters[n]["valu_issue_cycles"] for n in counters}            # per 512-registration launch
+        cyc_l = ks["valu_issue_cycles"] * SAT_COPIES
+        roof.update({
+            "valu_issue_cycles_per_launch": cyc_l,
+            "achieved": cyc_l / sat_us * 1e-3, "frac": cyc_l / sat_us * 1e-3 / VALU_PEAK,
+            "cycle_costs": VALU_COST,
+            "counted_per_512_launch": {c: ks[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
+                                                          "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_ACTIVE_INST_VALU") if c in ks},
+            # HBM bytes per launch from the TCC counters: FETCH_SIZE KB x2 (gfx950 correction) + WRITE_SIZE KB
+            "traffic": int((2.0 * ks.get("FETCH_SIZE", 0.0) + ks.get("WRITE_SIZE", 0.0)) * 1024 * SAT_COPIES),
+            "traffic_note": "PMC bytes of one launch (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, scaled from the 512-registration "
+                            "launch); ~10x below the SURVEY byte model: the path is not HBM-bound",
+            "instructions_per_registration": ks["SQ_INSTS_VALU"] / 512.0,
+            "single_stream_512_launch": {"avg_launch_us": float(sb[2]), "frac": ks["valu_issue_cycles"] / float(sb[2]) * 1e-3 / VALU_PEAK,
+                                         "note": "512 wavefronts on 1024 SIMDs: at most half the chip, one wavefront per SIMD"},
+        })
+        if all(n in cyc for n in HOT_KERNELS):
+            tot = sum(cyc[n] for n in HOT_KERNELS)
+            roof["path"] = {
+                "valu_issue_cycles_per_step": tot, "by_kernel": {n: cyc[n] for n in HOT_KERNELS},
+                "achieved": tot / (s_per_step * 1e6) * 1e-3, "frac": tot / (s_per_step * 1e6) * 1e-3 / VALU_PEAK,
+                "note": "all three launches of a step / ms_per_step of the 16-stream headline region (throughput, no residency involved)",
+                "chip_filling_launch_us": {"k_ndt_build": sat_build_us, "k_associate": sat_assoc_us, "k_solve": sat_us,
+                                           "registrations": big.B},
+            }
+        flops = ks["fp64_flops"]
+        out["roofline_fp64"] = {"bound": "fp64_valu", "kernel": "k_solve", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+                                "achieved": flops * SAT_COPIES / sat_us * 1e-6, "frac": flops * SAT_COPIES / sat_us * 1e-6 / FP64_PEAK_TFLOPS,
+                                "flops_per_registration": flops / 512.0,
+                                "note": "EXECUTED fp64 flops from SQ_INSTS_VALU_{FMA x2, MUL, ADD, TRANS}_F64 x 64 lanes (redundant all-lane "
+                                        "LM algebra included), chip-filling launch"}
+    out["roofline_hbm_secondary"] = {
+        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_registration": b_alg,
+        "path_effective": {"achieved": value * b_alg / 1e9, "frac": value * b_alg / 1e9 / HBM_PEAK_GBS},
+        "note": "SURVEY 8(d) byte model (counts the dense 480 KB submap table once per registration) x registrations/s; kept for "
+                "continuity with round 1 -- the compact cell tables make the real traffic ~10x smaller, see roofline.traffic"}
+    big.scan_maps[0].close()
+    return out
 
 
 def polar_filter(ctx, n_scans):
@@ -480,6 +660,13 @@ def cpu_baseline(prob, mp, gpu_pose, budget_s):
                                                      ip["max_range"], n_threads=cores)
         t_total += time.perf_counter() - t0
         done += B
+    # single-thread leg: the first 64 registrations of the batch, repeated until the budget is spent
+    n1, done1, t1 = min(B, 64), 0, 0.0
+    while t1 < budget_s:
+        t0 = time.perf_counter()
+        po.register_batch(prob["scans"][:n1], fixed, prob["submap_of"][:n1], op, g4[:n1], ip["n_clusters"], ip["max_range"], n_threads=1)
+        t1 += time.perf_counter() - t0
+        done1 += n1
     err_t = float(np.abs(gpu_pose[:, 2:] - poses[:, 2:]).max())
     dth = np.arctan2(gpu_pose[:, 1], gpu_pose[:, 0]) - np.arctan2(poses[:, 1], poses[:, 0])
     err_r = float(np.abs((dth + np.pi) % (2 * np.pi) - np.pi).max())
@@ -487,6 +674,8 @@ def cpu_baseline(prob, mp, gpu_pose, budget_s):
         "cpu_baseline": {
             "value": done / t_total, "unit": "registrations/s", "cores": cores, "kind": "port",
             "sample": "%d passes of the same 512-registration batch through the OpenMP CPU oracle (%.1f s wall, %d threads)" % (done // B, t_total, cores),
+            "single_thread": {"value": done1 / t1, "unit": "registrations/s", "cores": 1,
+                              "sample": "%d passes of the batch's first %d registrations, 1 thread (%.1f s wall)" % (done1 // n1, n1, t1)},
         },
         "pose_err_vs_oracle": {"max_abs_translation_m": err_t, "max_abs_rotation_rad": err_r, "tolerance": [1e-4, 1e-4]},
     }

@@ -340,8 +340,13 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
 // RPB > 1 (BLOCK = 64 only): RPB independent registrations per workgroup, one per wavefront -- nothing is shared between
 // them (no workgroup barrier); the point is placement: the dispatcher spreads the wavefronts of ONE workgroup over the four
 // SIMDs of a CU, which it does not do for single-wavefront workgroups arriving from many queues.
+#ifdef RANDT_SOLVE_WPE  // experiment knob (tools/ab_build.sh): force this many wavefronts per SIMD
+#define RANDT_SOLVE_OCC __attribute__((amdgpu_waves_per_eu(RANDT_SOLVE_WPE, RANDT_SOLVE_WPE)))
+#else
+#define RANDT_SOLVE_OCC
+#endif
 template <int D, int PARAM, int BLOCK, bool AM2, int RPB>
-__global__ __launch_bounds__(BLOCK* RPB) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
+__global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
                                                       int moving_first, const int32_t* __restrict__ corr, SolveParams P,
                                                       double* __restrict__ pose4, randt_result* __restrict__ results,
                                                       double* trace, int trace_len, int n_total) {

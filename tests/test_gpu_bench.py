@@ -22,14 +22,21 @@ def _last_json(out):
 
 def test_bench_single_gpu_contract():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--odometry-scans", "8", "--polar-scans", "2",
-                        "--cpu-seconds", "0.5"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--cpu-seconds", "0.5", "--min-seconds", "0.1", "--slam-scans", "0", "--polar-odometry-scans", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     d = _last_json(r.stdout)
     for k in REQUIRED + ["cpu_baseline"]:
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["n_gpus"] == 1 and d["steps_requested"] == 4 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["steps"] >= 4 and d["timed_region_s"] >= 0.1                            # --min-seconds 0.1 below
+    assert abs(d["ms_per_step"] * d["steps"] * 1e-3 - d["timed_region_s"]) < 1e-9
     assert d["value"] > 1e5 and "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["traffic"] > 0
+    assert rf["bound"] == "valu_issue" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["traffic"] > 0
+    assert 0.0 < rf["frac"] < 1.0 and 0.0 < rf["path"]["frac"] < 1.0
+    # the line's frac follows from the committed counter summary: cycles per launch / measured launch duration / peak
+    assert abs(rf["valu_issue_cycles_per_launch"] / rf["avg_launch_us"] * 1e-3 / rf["peak"] - rf["frac"]) < 1e-12
+    assert d["single_batch"]["value"] > 1e5 and d["single_batch"]["batch_latency_us"] > 10
+    assert d["cpu_baseline"]["single_thread"]["cores"] == 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["pose_err_vs_oracle"]["max_abs_translation_m"] <= 1e-4 and d["pose_err_vs_oracle"]["max_abs_rotation_rad"] <= 1e-4
 
@@ -38,7 +45,23 @@ def test_bench_two_ranks_control_flow():
     env = dict(os.environ, RANDT_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
-           "--odometry-scans", "0", "--polar-scans", "0", "--streams", "2"]   # two processes share ONE GPU here
+           "--odometry-scans", "0", "--polar-scans", "0", "--streams", "2", "--min-seconds", "0.05"]   # two processes share ONE GPU here
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["value"] > 1e5
+    assert d["n_gpus"] == 2 and d["value"] > 1e5 and d["scaling"] == "weak"
+    # config 4 as BASELINE states it: ONE 512 batch split over the ranks, results gathered, identical to the unsharded run
+    ss = d["strong_scaling"]
+    assert ss["registrations_per_gpu_per_step"] == 256 and ss["value"] > 1e5 and ss["poses_bit_identical_to_unsharded"] is True
+
+
+def test_bench_two_ranks_rccl():
+    """The same over RCCL (backend "nccl") when the box has two GPUs (the driver's multi-GPU node; skipped on a 1-GPU box)."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", "bench.py", "--gpus", "2", "--steps", "50", "--warmup", "2", "--min-seconds", "0.05"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["strong_scaling"]["poses_bit_identical_to_unsharded"] is True

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Developer A/B hook: build a VARIANT of librandt_hip.so into build/ab/NAME/ (git-ignored, travels with gpurun) with extra
+# compiler flags, to be selected at run time with RANDT_LIB=build/ab/NAME/librandt_hip.so.
+#   tools/ab_build.sh NAME "-DSOME_KNOB=3" [file.hip ...]      (default: all translation units)
+set -e
+NAME=$1; EXTRA=$2; shift 2 || true
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+SRC=$ROOT/randt-slam_amd/csrc
+OUT=$ROOT/build/ab/$NAME
+mkdir -p "$OUT"
+COMMON="$EXTRA -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$SRC -Wall -Wno-unused-function -Wno-pass-failed"
+pids=()
+for f in api ndt_build associate solve window filter csdiv scancontext posegraph; do
+  exact=""
+  case $f in ndt_build|associate|filter|csdiv|scancontext) exact="-ffp-contract=off";; esac
+  /opt/rocm/bin/hipcc $COMMON $exact -c "$SRC/$f.hip" -o "$OUT/$f.o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/librandt_hip.so" "$OUT"/*.o
+echo "$OUT/librandt_hip.so"

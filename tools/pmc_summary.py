@@ -1,27 +1,107 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection CSVs (one counter per pass) into one small table:
-mean counter value per kernel dispatch shape.  Usage: pmc_summary.py OUT.csv COUNTER=path.csv ..."""
+"""Summarise one tools/collect_profiles.sh run (gpurun_out/TAG/) into the small CSVs that get committed under profiles/:
+
+  pmc_summary.py gpurun_out/TAG profiles/rNN_x
+    -> profiles/rNN_x_sq_summary.csv         mean counter value per dispatch of every randt kernel (kernel, grid, workgroup),
+                                             all counters of all --pmc passes side by side, plus the derived columns
+                                             valu_issue_cycles (see VALU_COST) and fp64_flops, plus that kernel's average
+                                             duration in the un-profiled single-stream kernel trace of the same run
+    -> profiles/rNN_x_kernel_stats.csv        rocprofv3 --kernel-trace --stats of the DEFAULT bench command
+    -> profiles/rNN_x_single_stream_kernel_stats.csv   the same with one stream (clean, non-overlapped durations)
+    -> profiles/rNN_x_durations_by_grid.csv   per (kernel, grid size) average duration of both traces
+
+FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports them; FETCH_SIZE is NOT doubled here (the gfx950 x2 correction of
+MI355X_MICROARCH.md is applied where the number is used, bench.py and DESIGN.md, so that this file stays raw).
+"""
 import collections
 import csv
+import glob
+import os
 import re
+import shutil
 import sys
 
-out = sys.argv[1]
-table = collections.defaultdict(dict)
-for arg in sys.argv[2:]:
-    counter, path = arg.split("=", 1)
+# SIMD-cycles one wave-instruction occupies the VALU issue port, measured at saturation with tools/valu_rate_probe.hip
+# (profiles/r02_valu_rate_probe.csv, s_memtime ticks per wave-instruction, 4 wavefronts per SIMD, 8 independent chains):
+# v_fma/mul/add_f64 3.33, v_rcp/rsq_f64 12.55, 64-bit integer 3.33, fp32 / int32 / cvt / moves 2.0-2.1, v_rcp_f32 6.3.
+# "other" = SQ_INSTS_VALU minus every counted class (moves, compares, selects, DPP, readlane): priced at the cheapest
+# class, 2.0 (DPP moves cost 3.4 and lane reads 6.2, so this is a LOWER bound of the issue cycles).
+VALU_COST = {"F64": 3.33, "TRANS_F64": 12.55, "INT64": 3.33, "F32": 2.0, "TRANS_F32": 6.3, "INT32": 2.0, "CVT": 2.0, "OTHER": 2.0}
+
+
+def valu_issue_cycles(c):
+    """Counter dict of one dispatch -> (issue cycles, fp64 flops).  Needs the sq_a and sq_c counter sets."""
+    g = lambda k: c.get(k, 0.0)
+    f64 = g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64")
+    t64 = g("SQ_INSTS_VALU_TRANS_F64")
+    f32 = g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32")
+    t32 = g("SQ_INSTS_VALU_TRANS_F32")
+    i32, i64, cvt = g("SQ_INSTS_VALU_INT32"), g("SQ_INSTS_VALU_INT64"), g("SQ_INSTS_VALU_CVT")
+    other = max(0.0, g("SQ_INSTS_VALU") - f64 - t64 - f32 - t32 - i32 - i64 - cvt)
+    cyc = (f64 * VALU_COST["F64"] + t64 * VALU_COST["TRANS_F64"] + i64 * VALU_COST["INT64"] + f32 * VALU_COST["F32"] +
+           t32 * VALU_COST["TRANS_F32"] + i32 * VALU_COST["INT32"] + cvt * VALU_COST["CVT"] + other * VALU_COST["OTHER"])
+    flops = 64.0 * (2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64") + t64)
+    return cyc, flops
+
+
+def kname(full):
+    m = re.search(r"(k_[a-z_0-9]+(?:<[^>]*>)?)", full)
+    return m.group(1).replace(" ", "") if m else None
+
+
+def trace_durations(path):
     agg = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return agg
     for r in csv.DictReader(open(path)):
-        m = re.search(r"(k_[a-z_0-9]+(?:<[^>]*>)?)", r["Kernel_Name"])
-        name = m.group(1) if m else r["Kernel_Name"].split("(")[0][-48:]
-        agg[(name, int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        table[k][counter] = (len(v), sum(v) / len(v))
-counters = [a.split("=", 1)[0] for a in sys.argv[2:]]
-with open(out, "w", newline="") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "grid_size", "workgroup_size", "dispatches"] + [c + "_mean_KB" for c in counters])
-    for k, d in sorted(table.items(), key=lambda kv: -max(x[1] for x in kv[1].values())):
-        n = max(x[0] for x in d.values())
-        w.writerow([k[0], k[1], k[2], n] + ["%.1f" % d[c][1] if c in d else "" for c in counters])
-print(open(out).read())
+        n = kname(r["Kernel_Name"])
+        if n:
+            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
+            agg[(n, grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return agg
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    table = collections.defaultdict(lambda: collections.defaultdict(list))
+    order = []
+    for path in sorted(glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv"))):
+        for r in csv.DictReader(open(path)):
+            n = kname(r["Kernel_Name"])
+            if not n:
+                continue
+            key = (n, int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+            table[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] not in order:
+                order.append(r["Counter_Name"])
+            table[key]["__vgpr"] = [int(r["VGPR_Count"])]
+            table[key]["__lds"] = [int(r["LDS_Block_Size"])]
+    single = trace_durations(os.path.join(src, "single", "run_kernel_trace.csv"))
+    default = trace_durations(os.path.join(src, "stats", "run_kernel_trace.csv"))
+    with open(dst + "_sq_summary.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_size", "workgroup_size", "dispatches", "rocprof_vgpr_count", "lds_bytes"] + order +
+                   ["valu_issue_cycles", "fp64_flops", "single_stream_avg_us", "single_stream_launches"])
+        for key, d in sorted(table.items(), key=lambda kv: -sum(kv[1].get("SQ_INSTS_VALU", [0]))):
+            mean = {c: sum(v) / len(v) for c, v in d.items() if not c.startswith("__")}
+            cyc, fl = valu_issue_cycles(mean)
+            dur = single.get((key[0], key[1]), [])
+            w.writerow([key[0], key[1], key[2], max(len(v) for c, v in d.items() if not c.startswith("__")), d["__vgpr"][0], d["__lds"][0]] +
+                       ["%.1f" % mean[c] if c in mean else "" for c in order] +
+                       ["%.0f" % cyc, "%.0f" % fl, "%.2f" % (sum(dur) / len(dur) / 1e3) if dur else "", len(dur)])
+    with open(dst + "_durations_by_grid.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["trace", "kernel", "grid_size", "launches", "avg_us", "min_us", "max_us"])
+        for label, agg in (("default_16_streams", default), ("single_stream", single)):
+            for (n, grid), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+                w.writerow([label, n, grid, len(v), "%.2f" % (sum(v) / len(v) / 1e3), "%.2f" % (min(v) / 1e3), "%.2f" % (max(v) / 1e3)])
+    for a, b in (("stats/run_kernel_stats.csv", "_kernel_stats.csv"), ("single/run_kernel_stats.csv", "_single_stream_kernel_stats.csv"),
+                 ("stats_bench.json", "_default_bench_profiled.json"), ("bench.json", "_default_bench.json"),
+                 ("single_bench.json", "_single_stream_bench.json"), ("valu_rate_probe.csv", "_valu_rate_probe.csv")):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copy(os.path.join(src, a), dst + b)
+    print(open(dst + "_sq_summary.csv").read()[:6000])
+
+
+if __name__ == "__main__":
+    main()
