@@ -5,26 +5,32 @@
 // (src/ndt_representation/ndt_map.cpp:101-175) and Cell::mahalanobisSquaredIntensity
 // (src/ndt_representation/ndt_cell.cpp:172-176).
 //
-// One workgroup (512 threads) per (scan, submap) pair, four phases per chunk of 64 moving cells so
-// that every global-memory round trip is taken once by all lanes together instead of once per cell:
+// One workgroup (256 threads) per (scan, submap) pair, phases per chunk of 64 moving cells so that every
+// global-memory round trip is taken once by all lanes together instead of once per cell, and so that the per-cell
+// logic runs one THREAD per cell (64 cells per wave-instruction) instead of one wavefront per cell:
 //   P0  a ring-major table of the (2R+1)^2 window offsets is built; optionally (RANDT_ASSOC_STAGE_GRID=1) the
 //       submap's dense int32 index grid (40 KB for the 100x100 indoor map) is staged into LDS with 16-byte
 //       loads -- by default it is gathered from L2, which is as fast and leaves the LDS to co-running kernels;
 //   P1  one thread per moving cell: 48-byte record from HBM/L2, fp32 transform by the initial guess
 //       (reference operation order), centre slot; query cells parked in LDS;
-//   P2  one wavefront per moving cell: lanes cover the window ring by ring (the first 64 slots are gathered one
-//       cell ahead), two ballots per 64 slots give the occupied / in-range masks, LANE r evaluates radius r from
-//       them and one more ballot picks the reference's termination radius; occupied slots are compacted into
-//       a candidate list;
+//   P1b one wavefront per moving cell, lanes over the 64 innermost window slots (radii 0..3; a window row is one
+//       contiguous run of the index grid): every cell's gather is in flight at once, the slot contents land in LDS;
+//   P2a one thread per cell: occupied / in-range bit masks of its 64 slots, the reference's termination radius
+//       from popcounts of mask prefixes (the window is enumerated ring-major, so "radius <= r" is a prefix), the
+//       occupied slots of the final window copied out as the candidate list;
+//   P2b cells not settled within radius 3 (sparse neighbourhoods) and maps narrower than the window: one
+//       wavefront per cell, ballots over the outer rings (the round-1 path);
 //   P3  one thread per (cell, candidate): gather the fixed cell's 48-byte record (L2), fp32
 //       Mahalanobis / Euclidean distance in Eigen's operation order;
-//   P4  one 16-lane group per cell: k rounds of an unsigned 64-bit min over sortable (distance, compact index)
-//       keys with in-row DPP = the order std::sort produces on std::pair<double,size_t>.
+//   P4  one thread per cell: insertion of sortable 64-bit (distance, compact index) keys into a k-entry sorted
+//       list = the order std::sort produces on std::pair<double,size_t>.
 #include "cell_math.h"
 
 using namespace randt_dev;
 
-#define ASSOC_BLOCK 512
+#ifndef ASSOC_BLOCK
+#define ASSOC_BLOCK 256
+#endif
 #define ASSOC_WAVES (ASSOC_BLOCK / 64)
 #define ASSOC_MAX_R 7    // window <= 15x15 = 225 slots = 4 lane passes
 #define ASSOC_PASSES 4
@@ -33,6 +39,7 @@ using namespace randt_dev;
 #endif
 #define ASSOC_CH_LOG2 (ASSOC_CH == 128 ? 7 : 6)
 #define ASSOC_CAND 64    // candidates per cell: <= (k-1) + 8R = 63 for k <= 8, R <= 7
+#define ASSOC_CS 65      // LDS stride of a cell's candidate / slot row (odd: thread-per-cell accesses are conflict-free)
 #define ASSOC_QS 11      // LDS stride of a query record (odd => conflict-free)
 
 #ifdef RANDT_TIMING
@@ -117,8 +124,11 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
   float* qrec = reinterpret_cast<float*>(wtab + 256);       // [CH][QS]: mean3, cov6, centre(bits), pad
   int32_t* clen = reinterpret_cast<int32_t*>(qrec + ASSOC_CH * ASSOC_QS + 1);  // [CH]
   int32_t* cpref = clen + ASSOC_CH;                         // [CH + 1]
-  int32_t* cand = cpref + ASSOC_CH + 4;                     // [CH][CAND]
-  float* cdist = reinterpret_cast<float*>(cand + ASSOC_CH * ASSOC_CAND);  // [CH][CAND]
+  int32_t* cand = cpref + ASSOC_CH + 4;                     // [CH][CS]
+  float* cdist = reinterpret_cast<float*>(cand + ASSOC_CH * ASSOC_CS);  // [CH][CS]
+  int32_t* p0tab = reinterpret_cast<int32_t*>(cdist);       // [CH][CS] window slots 0..63 of every cell (dead before P3 writes cdist)
+  unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cdist + ASSOC_CH * ASSOC_CS);  // [CH][2] occupied / in-range bits
+  int32_t* ulist = reinterpret_cast<int32_t*>(pmask + 2 * ASSOC_CH);                                // [CH + 1] cells left to P2b, count last
 
   const int R = fixed.rmax - 1 > 0 ? fixed.rmax - 1 : 0;  // last radius the reference evaluates
   const int side = 2 * R + 1, nwin = side * side;
@@ -170,33 +180,102 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     }
     __syncthreads();
 
-    ASSOC_TICK(1);
-    // ---- P2: window scan (LDS only), one wavefront per moving cell.
-    // Reference loop (ndt_map.cpp:101-152): evaluate radius 0, 1, ... until enough targets (nt >= k) or
-    // enough adjacent slots (nadj >= n_slots) were seen or the radius reaches rmax.  The window is
-    // enumerated ring-major, so "everything up to radius r" is a prefix of (2r+1)^2 entries: 64 lanes
-    // fetch a pass of the window, two ballots give its occupied / in-range masks, and LANE r evaluates
-    // radius r from those masks -- the termination radius is one more ballot instead of a scalar loop.
-    // pass 0 (the 64 innermost window slots) of a cell's index-grid gather; issued one cell ahead so that its
-    // L2 latency is hidden behind the previous cell's ballots
-    const int lane_i = (wtab[lane] >> 8) - 128, lane_j = (wtab[lane] & 255) - 128;
-    auto fetch_pass0 = [&](int cc) -> int32_t {
-      int32_t ci = -2;  // -2: not a valid window slot, -1: empty slot
-      if (lane < nwin) {
-        const uint32_t ctr = __float_as_uint(qrec[cc * ASSOC_QS + 9]);
-        const uint32_t ni = ctr + (uint32_t)lane_i + (uint32_t)lane_j * (uint32_t)fixed.size_x;
-        if (ni < (uint32_t)n_slots) {
-          ci = grid[ni];
-          if (ci < -1) ci = -1;
+    // ---- P1b: slots 0..63 of every cell's window (one wavefront per cell; all gathers of the chunk in flight together)
+    {
+      const int lane_i = (wtab[lane] >> 8) - 128, lane_j = (wtab[lane] & 255) - 128;
+      constexpr int PER_WAVE = ASSOC_CH / ASSOC_WAVES;
+      int32_t civ[PER_WAVE];
+#pragma unroll
+      for (int t = 0; t < PER_WAVE; ++t) {  // every request of this wavefront's cells first ...
+        const int cc = wave + t * ASSOC_WAVES;
+        int32_t ci = -2;  // -2: not a valid window slot, -1: empty slot
+        if (cc < nch && lane < nwin) {
+          const uint32_t ctr = __float_as_uint(qrec[cc * ASSOC_QS + 9]);
+          const uint32_t ni = ctr + (uint32_t)lane_i + (uint32_t)lane_j * (uint32_t)fixed.size_x;
+          if (ni < (uint32_t)n_slots) ci = grid[ni];
+        }
+        civ[t] = ci;
+      }
+#pragma unroll
+      for (int t = 0; t < PER_WAVE; ++t) {  // ... then the slot contents and their occupied / in-range bit masks into LDS
+        const int cc = wave + t * ASSOC_WAVES;
+        if (cc < nch) {  // wave-uniform
+          int32_t ci = civ[t];
+          if (ci < -1 && lane < nwin) {
+            const uint32_t ctr = __float_as_uint(qrec[cc * ASSOC_QS + 9]);
+            const uint32_t ni = ctr + (uint32_t)lane_i + (uint32_t)lane_j * (uint32_t)fixed.size_x;
+            ci = ni < (uint32_t)n_slots ? -1 : -2;  // a stored index below -1 counts as an empty slot
+          }
+          p0tab[cc * ASSOC_CS + lane] = ci;
+          const unsigned long long o = __ballot(ci >= 0), v = __ballot(ci >= -1);
+          if (lane == 0) {
+            pmask[2 * cc] = o;
+            pmask[2 * cc + 1] = v;
+          }
         }
       }
-      return ci;
-    };
-    int32_t ci_next = wave < nch ? fetch_pass0(wave) : -2;
-    for (int c = wave; c < nch; c += ASSOC_WAVES) {
+    }
+    __syncthreads();
+    ASSOC_TICK(1);
+    // ---- P2a: one thread per cell.  Reference loop (ndt_map.cpp:101-152): evaluate radius 0, 1, ... until enough
+    // targets (nt >= k) or enough adjacent slots (nadj >= n_slots) were seen or the radius reaches rmax.  Ring-major
+    // enumeration makes "everything up to radius r" the first (2r+1)^2 slots, so nt / nadj are popcounts of mask prefixes.
+    if (wave == 0) {
+      const int c = lane;
+      int len = -1;  // -1: not settled here (P2b)
+      if (c < nch && !need_dup) {
+        const int32_t* row = p0tab + c * ASSOC_CS;
+        const unsigned long long occ = pmask[2 * c], val = pmask[2 * c + 1];
+        const int r_hi = R < 3 ? R : 3;  // radii completely inside the 64 slots
+        int rstar = -1;
+        for (int r = 0; r <= r_hi && rstar < 0; ++r) {
+          const unsigned long long pm = prefix_mask((2 * r + 1) * (2 * r + 1));
+          const int nt = __popcll(occ & pm), nadj = __popcll(val & pm);
+          if (!(nt < k && nadj < n_slots)) rstar = r;
+        }
+        if (rstar < 0 && r_hi == R) rstar = R;  // "if (r >= rmax) break" after the last radius
+        if (rstar >= 0) {
+          unsigned long long m = occ & prefix_mask((2 * rstar + 1) * (2 * rstar + 1));
+          len = 0;
+          while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            cand[c * ASSOC_CS + len] = row[b];
+            ++len;
+          }
+        }
+      }
+      if (c < nch) clen[c] = len;
+      // the cells left open, compacted so that P2b spreads them evenly over the wavefronts
+      const bool open = c < nch && len < 0;
+      const unsigned long long om = __ballot(open);
+      if (open) ulist[__popcll(om & prefix_mask(lane))] = c;
+      if (lane == 0) ulist[ASSOC_CH] = __popcll(om);
+    }
+    __syncthreads();
+    // ---- P2b: the cells P2a left open, one wavefront per cell (outer rings / wrapping windows)
+    const int n_open = ulist[ASSOC_CH];
+    for (int u = wave; u < n_open; u += ASSOC_WAVES) {
+      const int c = ulist[u];
       const uint32_t center = __float_as_uint(qrec[c * ASSOC_QS + 9]);
-      const int32_t ci_pass0 = ci_next;
-      if (c + ASSOC_WAVES < nch) ci_next = fetch_pass0(c + ASSOC_WAVES);
+      const int32_t ci_pass0 = p0tab[c * ASSOC_CS + lane];
+      // the outer rings' slots, all requested before the first one is looked at (one L2 round trip per cell, not per pass)
+      int32_t ci_outer[ASSOC_PASSES];
+#pragma unroll
+      for (int p = 1; p < ASSOC_PASSES; ++p) {
+        const int r_first = p == 1 ? 4 : (p == 2 ? 6 : 7);
+        const int w = p * 64 + lane;
+        int32_t ci = -2;
+        if (!need_dup && r_first <= R && w < nwin) {
+          const int packed = wtab[w];
+          const uint32_t ni = center + (uint32_t)((packed >> 8) - 128) + (uint32_t)((packed & 255) - 128) * (uint32_t)fixed.size_x;
+          if (ni < (uint32_t)n_slots) {
+            ci = grid[ni];
+            if (ci < -1) ci = -1;
+          }
+        }
+        ci_outer[p] = ci;
+      }
       int32_t cidx[ASSOC_PASSES];
       unsigned long long occ[ASSOC_PASSES], val[ASSOC_PASSES];
       int rstar = -1;
@@ -211,18 +290,8 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
           const int r_first = p == 0 ? 0 : (p == 1 ? 4 : (p == 2 ? 6 : 7));
           if (rstar < 0 && r_first <= R) {
             const int w = p * 64 + lane;
-            int32_t ci = -2;
-            if (p == 0) {
-              ci = ci_pass0;
-            } else if (w < nwin) {
-              const int packed = wtab[w];
-              const int i = (packed >> 8) - 128, j = (packed & 255) - 128;
-              const uint32_t ni = center + (uint32_t)i + (uint32_t)j * (uint32_t)fixed.size_x;
-              if (ni < (uint32_t)n_slots) {
-                ci = grid[ni];
-                if (ci < -1) ci = -1;
-              }
-            }
+            const int32_t ci = p == 0 ? ci_pass0 : ci_outer[p];
+            (void)w;
             cidx[p] = ci;
             occ[p] = __ballot(ci >= 0);
             val[p] = __ballot(ci >= -1);
@@ -248,7 +317,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
             const bool in = cidx[p] >= 0 && (p * 64 + lane) < need;
             const unsigned long long m = __ballot(in);
             const int pos = base + __popcll(m & prefix_mask(lane));
-            if (in && pos < ASSOC_CAND) cand[c * ASSOC_CAND + pos] = cidx[p];
+            if (in && pos < ASSOC_CAND) cand[c * ASSOC_CS + pos] = cidx[p];
             base += __popcll(m);
           }
         }
@@ -311,7 +380,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
             const bool in = cidx[p] >= 0 && (p * 64 + lane) < need && !window_dup(wi[p], wj[p], rstar, fixed.size_x);
             const unsigned long long m = __ballot(in);
             const int pos = base + __popcll(m & prefix_mask(lane));
-            if (in && pos < ASSOC_CAND) cand[c * ASSOC_CAND + pos] = cidx[p];
+            if (in && pos < ASSOC_CAND) cand[c * ASSOC_CS + pos] = cidx[p];
             base += __popcll(m);
           }
         }
@@ -349,7 +418,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
         }
       }
       const int c = lo, jj = p - cpref[lo];
-      const int32_t fi_raw = cand[c * ASSOC_CAND + jj];
+      const int32_t fi_raw = cand[c * ASSOC_CS + jj];
       const int32_t fi = fi_raw < fixed.cap ? fi_raw : fixed.cap - 1;
       const randt_cell f = load_cell(fcells + fi);
       const float* o = qrec + c * ASSOC_QS;
@@ -364,44 +433,38 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
         const float dx = o[0] - f.mean[0], dy = o[1] - f.mean[1];
         d = sqrtf(dx * dx + dy * dy);
       }
-      cdist[c * ASSOC_CAND + jj] = d;
+      cdist[c * ASSOC_CS + jj] = d;
     }
     __syncthreads();
 
     ASSOC_TICK(4);
-    // ---- P4: top-k per cell by (dist, idx), one 16-lane group per cell.  A candidate is ONE sortable 64-bit key
-    // (order-preserving image of the float distance, then the compact index), so a selection round is an unsigned
-    // 64-bit min over the group: four DPP steps inside the 16-lane row, no LDS shuffles, no branches.
-    {
-      const int grp = tid >> 4, gl = tid & 15;
+    // ---- P4: top-k per cell by (dist, idx), one thread per cell.  A candidate is ONE sortable 64-bit key (order-preserving
+    // image of the float distance, then the compact index); the k smallest keys are kept in a sorted register list by
+    // compare-and-swap insertion = the first k entries of std::sort on std::pair<double,size_t>.
+    if (tid < nch) {
+      const int c = tid;
       constexpr unsigned long long EMPTY = ~0ull;
-      for (int c = grp; c < nch; c += ASSOC_BLOCK / 16) {
-        const int n = clen[c];
-        unsigned long long key[4];
+      const int n = clen[c];
+      unsigned long long best[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int jj = gl + 16 * s;
-          key[s] = EMPTY;
-          if (jj < n) {
-            const uint32_t u = __float_as_uint(cdist[c * ASSOC_CAND + jj] + 0.0f);  // -0 -> +0
-            const uint32_t ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // numeric order as unsigned order
-            key[s] = ((unsigned long long)ord << 32) | (uint32_t)cand[c * ASSOC_CAND + jj];
+      for (int s2 = 0; s2 < 8; ++s2) best[s2] = EMPTY;
+      for (int jj = 0; jj < n; ++jj) {
+        const uint32_t u = __float_as_uint(cdist[c * ASSOC_CS + jj] + 0.0f);  // -0 -> +0
+        const uint32_t ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // numeric order as unsigned order
+        unsigned long long key = ((unsigned long long)ord << 32) | (uint32_t)cand[c * ASSOC_CS + jj];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          if (s2 < k) {  // uniform
+            if (key == best[s2]) key = EMPTY;  // a repeated (distance, index) pair counts once
+            const unsigned long long lo = key < best[s2] ? key : best[s2];
+            key = key < best[s2] ? best[s2] : key;
+            best[s2] = lo;
           }
         }
-        for (int kk = 0; kk < k; ++kk) {
-          unsigned long long b = key[0];
-#pragma unroll
-          for (int s = 1; s < 4; ++s) b = key[s] < b ? key[s] : b;
-          b = min_u64_dpp<0xB1>(b);   // quad_perm [1,0,3,2]
-          b = min_u64_dpp<0x4E>(b);   // quad_perm [2,3,0,1]
-          b = min_u64_dpp<0x141>(b);  // row_half_mirror
-          b = min_u64_dpp<0x140>(b);  // row_mirror: every lane of the 16-lane row holds the minimum
-          if (gl == 0) out[(size_t)(c0 + c) * k + kk] = b == EMPTY ? -1 : (int32_t)(uint32_t)b;
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            if (key[s] == b) key[s] = EMPTY;
-        }
       }
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2)
+        if (s2 < k) out[(size_t)(c0 + c) * k + s2] = best[s2] == EMPTY ? -1 : (int32_t)(uint32_t)best[s2];
     }
     ASSOC_TICK(5);
   }
@@ -409,7 +472,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
 
 size_t assoc_lds_bytes(int n_slots, bool stage) {
   size_t words = (stage ? ((n_slots + 3) & ~3) : 0) + 256 + (ASSOC_CH * ASSOC_QS + 1) + ASSOC_CH + (ASSOC_CH + 4) +
-                 2 * ASSOC_CH * ASSOC_CAND;
+                 2 * ASSOC_CH * ASSOC_CS + 4 * ASSOC_CH + ASSOC_CH + 4;
   return words * 4 + 64;
 }
 
