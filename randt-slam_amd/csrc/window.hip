@@ -58,10 +58,15 @@ __device__ __forceinline__ void so2_normalize(double& c, double& s) {
   c = c * inv;
   s = s * inv;
 }
-__device__ __forceinline__ void se2_exp(const double* xi, double* out) {
+// raw_sc (nullable): sin / cos of theta as sincos() returned them (before the SO2 normalisation)
+__device__ __forceinline__ void se2_exp(const double* xi, double* out, double* raw_sc = nullptr) {
   const double theta = xi[2];
   double c, s;
   sincos(theta, &s, &c);
+  if (raw_sc) {
+    raw_sc[0] = s;
+    raw_sc[1] = c;
+  }
   so2_normalize(c, s);
   double sbt, omcbt;
   if (fabs(theta) < 1e-10) {
@@ -126,8 +131,8 @@ __device__ __forceinline__ void se2_log(const double* p, double* xi) {
 __device__ void motion_factor(const double* x0, const double* x1, double raw_dt, double* r, double* Ju /* LDS 8x16 */) {
   const double dt = raw_dt > 0.2 ? raw_dt : 0.2;  // predictSE2 clamp (:73)
   const double xi[3] = {x0[4] * dt + 0.5 * dt * x0[7], x0[5] * dt + 0.5 * dt * x0[8], x0[6] * dt};
-  double e[4], pred[4], pinv[4], E[4], lg[3];
-  se2_exp(xi, e);
+  double e[4], pred[4], pinv[4], E[4], lg[3], sc_w[2];
+  se2_exp(xi, e, sc_w);  // sin / cos of xi[2] are needed again for d exp / d xi below
   se2_mul(x0, e, pred);
   se2_inv(pred, pinv);
   se2_mul(pinv, x1, E);
@@ -148,12 +153,12 @@ __device__ void motion_factor(const double* x0, const double* x1, double raw_dt,
     h = 1.0 - phi * phi / 12.0;
     dh = -phi / 6.0;
   } else {
+    // cot(phi/2) = (1 + cos phi) / sin phi and 1 / sin^2(phi/2) = 2 (1 + cos phi) / sin^2 phi from the unit complex
+    // (cE, sE) of E itself (phi = atan2(sE, cE)): no second sincos; 1 + cos phi has no cancellation for |phi| < pi
     const double half = 0.5 * phi;
-    double sh, ch;
-    sincos(half, &sh, &ch);
-    const double ish = fast_rcp(sh), cot = ch * ish;
+    const double isn = fast_rcp(sE), cot = (1.0 + cE) * isn;
     h = half * cot;
-    dh = 0.5 * cot - 0.5 * half * (ish * ish);
+    dh = 0.5 * cot - half * (cot * isn);
   }
   const double Vi00 = h, Vi01 = 0.5 * phi, Vi10 = -0.5 * phi, Vi11 = h;
   const double dVt0 = dh * tEx + 0.5 * tEy, dVt1 = -0.5 * tEx + dh * tEy;
@@ -175,8 +180,7 @@ __device__ void motion_factor(const double* x0, const double* x1, double raw_dt,
     db = 0.5 - w * w / 8.0;
   } else {
     const double w = xi[2];
-    double s, c;
-    sincos(w, &s, &c);
+    const double s = sc_w[0], c = sc_w[1];
     const double iw = fast_rcp(w), iw2 = iw * iw;
     a = s * iw;
     b = (1.0 - c) * iw;
@@ -418,7 +422,9 @@ __device__ __forceinline__ void pose_T(const double* xp, double T[3][3]) {
 }
 
 // J^T J and J^T r at xs[buf] from the factor blocks in LDS and the per-state NDT base sums.
-__device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* base /* S*10 */) {
+// have_sigma: the Jacobi scaling of this solve is known (every assembly but the first of a solve): the scaled copies
+// Hs / gs are written in the same pass instead of by wavefront 0 afterwards.
+__device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* base /* S*10 */, bool have_sigma) {
   const int n = W.n_tan, tid = threadIdx.x;
   for (int e = tid; e < n * n; e += WIN_BLOCK) {
     const int a = e / n, b = e % n;
@@ -449,6 +455,7 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* ba
       h += v;
     }
     sh.H[a * n + b] = h;
+    if (have_sigma) sh.Hs[a * n + b] = h * sh.sigma[a] * sh.sigma[b];
   }
   if (tid < n) {
     const int a = tid;
@@ -473,6 +480,7 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* ba
       g += T[ia][0] * B[1] + T[ia][1] * B[2] + T[ia][2] * B[3];
     }
     sh.g[a] = g;
+    if (have_sigma) sh.gs[a] = g * sh.sigma[a];
   }
   __syncthreads();
 }
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       }
       if (res.gnc_solves == 0) res.initial_cost = cost;
       summary_min = cost;
-      assemble(W, sh, p, sh.base[p]);
+      assemble(W, sh, p, sh.base[p], false);
       WT(3);
       bool first = true, need_scale = true;
       double x_norm = 0.0;
@@ -671,12 +679,10 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         // ---- (wave 0) Jacobi scaling of the freshly assembled system, gradient test
         if (need_scale) {
           if (wave == 0) {
-            if (first) {
+            if (first) {  // later assemblies of this solve write Hs / gs themselves
               if (lane < n) sh.sigma[lane] = 1.0 / (1.0 + sqrt(sh.H[lane * n + lane]));
               wave_fence();
-            }
-            // all 64 lanes over the n^2 entries; (row, column) of entry e advance incrementally (no division)
-            {
+              // all 64 lanes over the n^2 entries; (row, column) of entry e advance incrementally (no division)
               int ei = ent_i0, ej = ent_j0;
               for (int e = lane; e < n * n; e += 64) {
                 sh.Hs[e] = sh.H[e] * sh.sigma[ei] * sh.sigma[ej];
@@ -687,8 +693,8 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
                   ++ei;
                 }
               }
+              if (lane < n) sh.gs[lane] = sh.g[lane] * sh.sigma[lane];
             }
-            if (lane < n) sh.gs[lane] = sh.g[lane] * sh.sigma[lane];
             // gradient tolerance: ||x - Plus(x, -g)||_inf <= gtol
             double gm = lane < n ? fabs(sh.g[lane]) : 0.0;
             gm = wave_max(gm);
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           p = 1 - p;
           cost = cand_cost;
           WT(6);
-          assemble(W, sh, p, sh.base[p]);
+          assemble(W, sh, p, sh.base[p], true);
           WT(3);
           need_scale = true;
           step_ok = true;

@@ -153,6 +153,21 @@ int main() {
     printf("%s,%s,%.2f,%.3f,%.3f,%.3f,%.1f\n", probes[p].name, probes[p].cls, us, 2.0 * us / t_ref, us * 1e-6 * 2.4e9 / instr_per_simd,
            h[1] / instr_per_simd, h[1] / us);
   }
+  // shader clock seen by a nearly idle chip: ONE workgroup (the fixed-lag window solve is such a launch)
+  for (int rep = 0; rep < 3; ++rep) {
+    hipLaunchKernelGGL(k_fma_f64, dim3(1), block, 0, 0, d_out, 1.5);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(k_fma_f64, dim3(1), block, 0, 0, d_out, 1.5);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    double h[2] = {0, 0};
+    CHECK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
+    printf("single_workgroup_v_fma_f64,us_per_launch %.2f,ticks_per_wave_instr %.3f (1 wave per SIMD),ticks_per_us %.1f\n", ms * 1e3 / 20,
+           h[1] / ((double)ITERS * CHAINS), h[1] / (ms * 1e3 / 20));
+  }
   (void)simds;
   return 0;
 }
