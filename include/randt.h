@@ -232,6 +232,22 @@ int randt_maps_insert_cells(randt_maps* m, int idx, const randt_cell* h_cells, i
 int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_cell* h_queries, int n_queries,
                         int k, int lookup_mahalanobis, int use_intensity, int32_t* h_out);
 
+/* Single cells (the mutators of rc::navigation::ndt::Cell, for callers that edit cells one by one; host buffers, a tiny
+ * launch and a synchronisation each -- same device arithmetic as the batched kernels):
+ *  - randt_cell_add_points: Cell::addPointCloud + updateCell (ndt_cell.cpp:25-114) on a cell that may already hold a
+ *    distribution (n > 0: the recursive update :84-89, then the regularisation :102-112 again).  *accepted = 1 if the
+ *    points were taken (n + n_points > min_points_per_cell); Cell::addPoint + updateCell is the same call per batch.
+ *  - randt_cells_merge: Cell::operator+= (ndt_cell.h:133-142), h_acc[i] += h_other[i].
+ *  - randt_cells_transform: Cell::transformCell (ndt_cell.cpp:117-123) of every cell by one pose.
+ *  - randt_cells_mahalanobis: h_out[i] = h_self[i].mahalanobisSquaredIntensity(h_subtrahend[i]) (use_intensity = 1,
+ *    ndt_cell.cpp:165-169) or .mahalanobisSquared (0, :158-162); fp32 like the reference, returned as double. */
+int randt_cell_add_points(randt_ctx* ctx, randt_cell* h_cell, const float* h_points, int n_points, int stride_floats,
+                          int intensity_index, int min_points_per_cell, int* accepted);
+int randt_cells_merge(randt_ctx* ctx, randt_cell* h_acc, const randt_cell* h_other, int n);
+int randt_cells_transform(randt_ctx* ctx, randt_cell* h_cells, int n, const double h_pose4[4]);
+int randt_cells_mahalanobis(randt_ctx* ctx, const randt_cell* h_self, const randt_cell* h_subtrahend, int n, int use_intensity,
+                            double* h_out);
+
 /* ------------------------------------------------------------------ association (a7,a8,a10) -- */
 /* Association half of Matcher::addNDTFactor (ndt_matcher.cpp:200-215,249-253) with
  * Map::getClosestCells / getAdjacentIndizes (ndt_map.cpp:101-175) and

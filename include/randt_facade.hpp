@@ -90,11 +90,34 @@ struct NDTMatcherParameters {
   bool use_analytic_expressions_for_optimization = false;
 };
 
+// Error policy of the facade.  The reference never throws and has no status codes: void / double returns, a warning on
+// std::cout, "keep the previous value" on failure.  kKeepPrevious (default) reproduces that: a failing ABI
+// call prints a warning, leaves the object as it was and records the status in last_status(); kThrow raises
+// std::runtime_error instead (what the tests of this repository use to see failures).
+enum class ErrorPolicy { kKeepPrevious, kThrow };
+inline ErrorPolicy& error_policy() {
+  static ErrorPolicy p = ErrorPolicy::kKeepPrevious;
+  return p;
+}
+inline int& last_status() {
+  static thread_local int s = RANDT_OK;
+  return s;
+}
+// returns true if the call succeeded
+inline bool facade_check(int rc, const char* what, randt_ctx* ctx) {
+  last_status() = rc;
+  if (rc == RANDT_OK) return true;
+  const std::string msg = std::string(what) + ": " + randt_status_string(rc) + " (" + (ctx ? randt_last_error(ctx) : "") + ")";
+  if (error_policy() == ErrorPolicy::kThrow) throw std::runtime_error(msg);
+  std::cout << "WARNING: " << msg << " -- previous value kept\n";
+  return false;
+}
+
 class Context {
  public:
   explicit Context(int device = 0, void* stream = nullptr) {
-    int rc = randt_ctx_create(device, stream, &ctx_);
-    if (rc != RANDT_OK) throw std::runtime_error(std::string("randt_ctx_create: ") + randt_status_string(rc));
+    // without a device every later call on this context fails with a status (there is no CPU fallback)
+    facade_check(randt_ctx_create(device, stream, &ctx_), "randt_ctx_create", nullptr);
   }
   ~Context() { randt_ctx_destroy(ctx_); }
   Context(const Context&) = delete;
@@ -105,16 +128,88 @@ class Context {
   randt_ctx* ctx_ = nullptr;
 };
 
-// Read-only host copy of one cell: the getters of rc::navigation::ndt::Cell (ndt_cell.h:39-121).
+// Host copy of one cell = rc::navigation::ndt::Cell (ndt_cell.h:16-170): getters on the record, mutators through the
+// ABI (the arithmetic runs on the device, randt_cell_add_points / randt_cells_{merge,transform,mahalanobis}).
+// A cell without a context can be read but not modified.
 class Cell {
  public:
   Cell() = default;
   explicit Cell(const randt_cell& c) : c_(c) {}
+  Cell(const randt_cell& c, std::shared_ptr<Context> ctx, int min_points_per_cell = 0)
+      : c_(c), ctx_(std::move(ctx)), min_points_(min_points_per_cell) {}
+
+  // void initialize(const int& min_points_per_cell, const NDTCellParameters& params) (ndt_cell.cpp:7-11); use_pndt is
+  // false in every shipped configuration and not built
+  void initialize(std::shared_ptr<Context> ctx, const int& min_points_per_cell) {
+    ctx_ = std::move(ctx);
+    min_points_ = min_points_per_cell;
+    c_ = randt_cell{};
+    pending_.clear();
+  }
+  // void addPoint(const pcl::PointXYZI& point, const std::pair<double, double>& angle_dist) (ndt_cell.cpp:19-23): queued
+  // until updateCell, like points_to_add_
+  void addPoint(float x, float y, float intensity) {
+    pending_.insert(pending_.end(), {x, y, 0.0f, intensity});
+  }
+  // bool addPointCloud(const pcl::PointCloud<pcl::PointXYZI>&, ...) (ndt_cell.cpp:25-34): points = n x stride floats
+  bool addPointCloud(const float* points, int n, int stride, int intensity_index) {
+    if (static_cast<long long>(c_.n) + static_cast<long long>(pending_.size() / 4) + n <= static_cast<long long>(min_points_)) return false;
+    for (int i = 0; i < n; ++i) addPoint(points[i * stride], points[i * stride + 1], points[i * stride + intensity_index]);
+    updateCell();  // "use recursive update equation"
+    return true;
+  }
+  // void updateCell(void) (ndt_cell.cpp:36-114)
+  void updateCell() {
+    if (pending_.empty() || !ctx_) return;
+    randt_cell next = c_;
+    int accepted = 0;
+    if (facade_check(randt_cell_add_points(ctx_->get(), &next, pending_.data(), static_cast<int>(pending_.size() / 4), 4, 3,
+                                           min_points_, &accepted), "randt_cell_add_points", ctx_->get()) && accepted) {
+      c_ = next;
+      pending_.clear();  // points_to_add_.clear(); below the gate the points stay queued, like in the reference
+    }
+  }
+  // void clearCell(void)
+  void clearCell() {
+    c_ = randt_cell{};
+    pending_.clear();
+  }
+  // void transformCell(const Eigen::Affine2f& trans) (ndt_cell.cpp:117-123)
+  void transformCell(const SE2d& trans) {
+    if (!ctx_) return;
+    randt_cell next = c_;
+    if (facade_check(randt_cells_transform(ctx_->get(), &next, 1, trans.data()), "randt_cells_transform", ctx_->get())) c_ = next;
+  }
+  // the per-cell point cloud only feeds the OGM (out of scope): the statistics move exactly as in transformCell
+  void transformCellWithPointCloud(const SE2d& trans) { transformCell(trans); }
+  // Cell& operator+=(const Cell& m_cell) (ndt_cell.h:133-142)
+  Cell& operator+=(const Cell& m_cell) {
+    if (!ctx_) return *this;
+    randt_cell next = c_;
+    if (facade_check(randt_cells_merge(ctx_->get(), &next, &m_cell.c_, 1), "randt_cells_merge", ctx_->get())) c_ = next;
+    return *this;
+  }
+  // double mahalanobisSquared(const Cell& subtrahend) const / mahalanobisSquaredIntensity (ndt_cell.cpp:158-169)
+  double mahalanobisSquared(const Cell& subtrahend) const { return mahalanobis(subtrahend, 0); }
+  double mahalanobisSquaredIntensity(const Cell& subtrahend) const { return mahalanobis(subtrahend, 1); }
+
   Vector2f getMean() const { return {c_.mean[0], c_.mean[1]}; }
+  void getMean(Vector2f& mean) const { mean = getMean(); }
   Vector3f getIntensityMean() const { return {c_.mean[0], c_.mean[1], c_.mean[2]}; }
+  void getIntensityMean(Vector3f& mean) const { mean = getIntensityMean(); }
   Matrix2f getCov() const { return {c_.cov[0], c_.cov[1], c_.cov[1], c_.cov[3]}; }
+  void getCov(Matrix2f& cov) const { cov = getCov(); }
   Matrix3f getIntensityCov() const {
     return {c_.cov[0], c_.cov[1], c_.cov[2], c_.cov[1], c_.cov[3], c_.cov[4], c_.cov[2], c_.cov[4], c_.cov[5]};
+  }
+  void getIntensityCov(Matrix3f& cov) const { cov = getIntensityCov(); }
+  void getMeanAndCov(Vector2f& mean, Matrix2f& cov) const {
+    mean = getMean();
+    cov = getCov();
+  }
+  void getIntensityMeanAndCov(Vector3f& mean, Matrix3f& cov) const {
+    mean = getIntensityMean();
+    cov = getIntensityCov();
   }
   double getMeanIntensity() const { return c_.mean[2]; }
   double getMaxIntensity() const { return c_.max_intensity; }
@@ -122,7 +217,16 @@ class Cell {
   const randt_cell& raw() const { return c_; }
 
  private:
+  double mahalanobis(const Cell& subtrahend, int use_intensity) const {
+    double out = 0.0;
+    if (!ctx_) return out;
+    facade_check(randt_cells_mahalanobis(ctx_->get(), &c_, &subtrahend.c_, 1, use_intensity, &out), "randt_cells_mahalanobis", ctx_->get());
+    return out;
+  }
   randt_cell c_{};
+  std::shared_ptr<Context> ctx_;
+  int min_points_ = 0;
+  std::vector<float> pending_;  // points_to_add_ as packed x y z I
 };
 
 // rc::navigation::ndt::State (include/ndt_slam/trajectory_representation.h:12-22)
@@ -232,7 +336,7 @@ class Map {
     check(randt_maps_download(m_, 0, raw.data(), cap_, &n, nullptr), "randt_maps_download");
     std::vector<Cell> out;
     out.reserve(n);
-    for (int i = 0; i < n && i < cap_; ++i) out.emplace_back(raw[i]);
+    for (int i = 0; i < n && i < cap_; ++i) out.emplace_back(raw[i], ctx_, params_.min_points_per_cell);
     return out;
   }
 
@@ -303,11 +407,7 @@ class Map {
     if (m_) randt_maps_destroy(m_);
     m_ = nullptr;
   }
-  void check(int rc, const char* what) const {
-    if (rc != RANDT_OK)
-      throw std::runtime_error(std::string(what) + ": " + randt_status_string(rc) + " (" +
-                               (ctx_ ? randt_last_error(ctx_->get()) : "") + ")");
-  }
+  bool check(int rc, const char* what) const { return facade_check(rc, what, ctx_ ? ctx_->get() : nullptr); }
   void closest(const randt_cell& q, int n_neighbours, int mahalanobis, std::vector<size_t>& indizes) const {
     if (n_neighbours <= 0) return;
     std::vector<int32_t> out(static_cast<size_t>(n_neighbours), -1);
@@ -319,6 +419,33 @@ class Map {
   randt_map_params params_{};
   int cap_ = 0;
   randt_maps* m_ = nullptr;
+};
+
+// rc::navigation::ndt::HierarchicalMap, the NDT side only (include/ndt_representation/ndt_hierarchical_map.h): the OGM
+// ray tracing is outside this path, so the class is the pass-through LocalFuser uses to fill a scan's NDT map
+// (ndt_hierarchical_map.cpp:28-33 addClusters -> Map::insertCluster per cluster; :35-37 getMap; clear / transform).
+class HierarchicalMap {
+ public:
+  void initialize(std::shared_ptr<Context> ctx, const NDTMapParameters& p, double center_x, double center_y, int cell_capacity = 0) {
+    ndt_map_.initialize(std::move(ctx), p, center_x, center_y, cell_capacity);
+  }
+  // void addClusters(const std::vector<pcl::PointCloud<pcl::PointXYZI>>& clusters, ...): cluster c = points
+  // [offsets[c], offsets[c+1]) of one n x stride array, inserted in order like the reference's loop
+  void addClusters(const float* points, const std::vector<int>& offsets, int stride, int intensity_index) {
+    for (size_t c = 0; c + 1 < offsets.size(); ++c)
+      ndt_map_.insertCluster(points + static_cast<size_t>(offsets[c]) * stride, offsets[c + 1] - offsets[c], stride, intensity_index);
+  }
+  // the whole filtered scan at once (clustering on the device): what RadarPreprocessor::processScan + addClusters amount to
+  void addScan(const float* points, int n, int stride, int intensity_index, const RadarPreprocessorParameters& rp) {
+    ndt_map_.addScan(points, n, stride, intensity_index, rp);
+  }
+  const Map& getMap() const { return ndt_map_; }
+  Map& getMap() { return ndt_map_; }
+  void clear() { ndt_map_.clear(); }
+  void transformMap(const SE2d& trans) { ndt_map_.transformMapWithPointCloud(trans); }
+
+ private:
+  Map ndt_map_;
 };
 
 // rc::navigation::ndt::Matcher, pair-registration part.
@@ -352,10 +479,7 @@ class Matcher {
     randt_result r{};
     int rc = randt_register_pair(old_ndt.context()->get(), old_ndt.handle(), 0, new_ndt.handle(), 0, &mp, trans.data(), &r);
     if (stats) *stats = r;
-    if (rc != RANDT_OK) {
-      std::cout << "WARNING: registration failed: " << randt_status_string(rc) << std::endl;
-      return 0.0;
-    }
+    if (!facade_check(rc, "randt_register_pair", old_ndt.context()->get())) return 0.0;  // trans untouched: outputs are written on success only
     if (r.n_residuals == 0) std::cout << "WARNING: NO RESIDUALS ADDED!" << std::endl;
     return r.cost;
   }
@@ -489,7 +613,7 @@ class SCManager {
     randt_sc_db_destroy(db_);
     db_ = nullptr;
     const int rc = randt_sc_db_create(ctx_->get(), &p, 256, &db_);
-    if (rc != RANDT_OK) throw std::runtime_error(std::string("randt_sc_db_create: ") + randt_status_string(rc));
+    facade_check(rc, "randt_sc_db_create", ctx_->get());
   }
 
   // void makeAndSaveScancontextAndKeys(pcl::PointCloud<SCPointType>::Ptr scan, Eigen::Vector2d& odom_position,
@@ -497,7 +621,7 @@ class SCManager {
   void makeAndSaveScancontextAndKeys(const float* points, int n, int stride, int intensity_index,
                                      const std::array<double, 2>& odom_position, const double& traversed_distance) {
     const int rc = randt_sc_db_append(db_, points, n, stride, intensity_index, odom_position.data(), traversed_distance, nullptr);
-    if (rc != RANDT_OK) throw std::runtime_error(std::string("randt_sc_db_append: ") + randt_status_string(rc));
+    facade_check(rc, "randt_sc_db_append", ctx_ ? ctx_->get() : nullptr);
   }
 
   // std::pair<int, float> detectLoopClosureID(int node_id): nearest node index or -1, relative yaw  (:261-341)
@@ -505,7 +629,7 @@ class SCManager {
     int loop_id = -1;
     float yaw = 0.f;
     const int rc = randt_sc_db_detect(db_, node_id, &loop_id, &yaw, nullptr);
-    if (rc != RANDT_OK) throw std::runtime_error(std::string("randt_sc_db_detect: ") + randt_status_string(rc));
+    if (!facade_check(rc, "randt_sc_db_detect", ctx_ ? ctx_->get() : nullptr)) return {-1, 0.f};  // "no loop found"
     return {loop_id, yaw};
   }
 

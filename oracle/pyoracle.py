@@ -135,6 +135,10 @@ def lib():
     L.orc_cell_from_points.restype = C.c_int
     L.orc_cell_from_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_cell_merge.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_cell_update.restype = C.c_int
+    L.orc_cell_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_cell_mahalanobis.restype = C.c_double
+    L.orc_cell_mahalanobis.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.orc_pose_to_affine_f.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_cell_transform.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_map_transform.argtypes = [P(OrcMap), C.c_void_p]
@@ -285,6 +289,20 @@ def cell_from_points(pts, min_points=5, ioff=3):
     cell = np.zeros(1, dtype=CELL_DTYPE)
     ok = lib().orc_cell_from_points(_ptr(cell), _ptr(pts), None, pts.shape[0], pts.shape[1], ioff, min_points)
     return bool(ok), cell[0]
+
+
+def cell_update(cell, pts, min_points=5, ioff=3):
+    """Cell::addPointCloud + updateCell on a cell that may already be filled; returns (accepted, cell)."""
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    c = np.array([cell], dtype=CELL_DTYPE)
+    ok = lib().orc_cell_update(_ptr(c), _ptr(pts), pts.shape[0], pts.shape[1], ioff, min_points)
+    return bool(ok), c[0]
+
+
+def cell_mahalanobis(a, b, use_intensity=True):
+    """a.mahalanobisSquared(b) / a.mahalanobisSquaredIntensity(b)"""
+    x, y = np.array([a], dtype=CELL_DTYPE), np.array([b], dtype=CELL_DTYPE)
+    return float(lib().orc_cell_mahalanobis(_ptr(x), _ptr(y), int(use_intensity)))
 
 
 def cell_merge(dst, src):

@@ -208,6 +208,58 @@ int orc_cell_from_points(orc_cell* c, const float* pts, const int32_t* idx, int 
   return 1;
 }
 
+/* Cell::addPointCloud + updateCell on a cell that may already hold a distribution (ndt_cell.cpp:25-34,36-114): batch
+ * statistics as in orc_cell_from_points (unregularised), then the recursive update of :84-89 when n_points_ > 0 -- the
+ * same formula as operator+= -- and the regularisation of :102-112 on the result.  Returns 1 if the points were taken
+ * (n_points_ + size > min_points_per_cell_), 0 if the cell is left untouched. */
+int orc_cell_update(orc_cell* c, const float* pts, int k, int stride, int ioff, int min_points) {
+  if (!((long long)c->n + (long long)k > (long long)min_points) || k <= 0) return 0;
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+  double maxi = (double)c->max_intensity;
+  for (int j = 0; j < k; ++j) {
+    const float* p = pts + (size_t)j * stride;
+    m0 += p[0];
+    m1 += p[1];
+    m2 += p[ioff];
+    if ((double)p[ioff] > maxi) maxi = (double)p[ioff];
+  }
+  float nf = (float)(double)(uint32_t)k;
+  m0 = m0 / nf;
+  m1 = m1 / nf;
+  m2 = m2 / nf;
+  float c00 = 0.f, c11 = 0.f, c22 = 0.f, c01 = 0.f, c02 = 0.f, c12 = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const float* p = pts + (size_t)j * stride;
+    float d0 = p[0] - m0, d1 = p[1] - m1, d2 = p[ioff] - m2;
+    c00 += (d0 * d0);
+    c11 += (d1 * d1);
+    c22 += (d2 * d2);
+    c01 += (d0 * d1);
+    c02 += (d0 * d2);
+    c12 += (d1 * d2);
+  }
+  orc_cell add;
+  memset(&add, 0, sizeof(add));
+  add.mean[0] = m0;
+  add.mean[1] = m1;
+  add.mean[2] = m2;
+  add.cov[0] = c00 / nf;
+  add.cov[1] = c01 / nf;
+  add.cov[2] = c02 / nf;
+  add.cov[3] = c11 / nf;
+  add.cov[4] = c12 / nf;
+  add.cov[5] = c22 / nf;
+  add.n = (uint32_t)k;
+  if (c->n > 0) {
+    orc_cell_merge(c, &add); /* :84-89, unsigned (n*m)/(n+m) like operator+= */
+  } else {
+    *c = add;
+  }
+  c->max_intensity = (float)maxi;
+  cell_regularize(c);
+  return 1;
+}
+
 /* Cell::operator+=, ndt_cell.h:133-142 (note the integer division (n*m)/(n+m)). */
 void orc_cell_merge(orc_cell* dst, const orc_cell* src) {
   uint32_t n = dst->n;
@@ -331,6 +383,20 @@ void orc_map_merge(orc_map* fixed, const orc_map* moving) {
 }
 
 /* ============================================================ association ================= */
+static float mahalanobis3f(const orc_cell* q, const orc_cell* f);
+
+/* Cell::mahalanobisSquared (ndt_cell.cpp:158-162, Eigen 2x2 inverse = adjugate * (1/det)) and
+ * Cell::mahalanobisSquaredIntensity (:165-169) of `self` against `subtrahend`, fp32 like the reference, returned as double. */
+double orc_cell_mahalanobis(const orc_cell* self, const orc_cell* subtrahend, int use_intensity) {
+  if (use_intensity) return (double)mahalanobis3f(self, subtrahend);
+  float s00 = subtrahend->cov[0] + self->cov[0], s01 = subtrahend->cov[1] + self->cov[1], s11 = subtrahend->cov[3] + self->cov[3];
+  float mu0 = subtrahend->mean[0] - self->mean[0], mu1 = subtrahend->mean[1] - self->mean[1];
+  float det = s00 * s11 - s01 * s01;
+  float invdet = 1.0f / det;
+  float i00 = s11 * invdet, i01 = -s01 * invdet, i10 = -s01 * invdet, i11 = s00 * invdet;
+  float r0 = mu0 * i00 + mu1 * i10, r1 = mu0 * i01 + mu1 * i11;
+  return (double)(r0 * mu0 + r1 * mu1);
+}
 
 /* Eigen 3.3 Matrix3f::inverse() (cofactor formulation) followed by mu^T * inv * mu, all fp32;
  * Cell::mahalanobisSquaredIntensity, ndt_cell.cpp:172-176.  q = query (transformed moving) cell,

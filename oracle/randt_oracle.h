@@ -74,6 +74,10 @@ int orc_cell_from_points(orc_cell* c, const float* pts, const int32_t* idx, int 
                          int ioff, int min_points);
 /* ndt_cell.h:133-142 */
 void orc_cell_merge(orc_cell* dst, const orc_cell* src);
+/* Cell::addPointCloud + updateCell incl. the recursive update of an already filled cell (ndt_cell.cpp:25-114) */
+int orc_cell_update(orc_cell* c, const float* pts, int k, int stride, int ioff, int min_points);
+/* Cell::mahalanobisSquared / mahalanobisSquaredIntensity (ndt_cell.cpp:158-169) */
+double orc_cell_mahalanobis(const orc_cell* self, const orc_cell* subtrahend, int use_intensity);
 /* Sophus SE2d::cast<float>() -> Eigen::Affine2f, as used at ndt_matcher.cpp:208, local_fuser.cpp:175 */
 void orc_pose_to_affine_f(const double pose4[4], float aff[4]);
 /* ndt_cell.cpp:117-123 */

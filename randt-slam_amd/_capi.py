@@ -126,6 +126,10 @@ SYMBOLS = {
     "randt_maps_insert_cluster": (_I, [_V, _I, _V, _I, _I, _I, _P(_I)]),
     "randt_maps_insert_cells": (_I, [_V, _I, _V, _I, _I]),
     "randt_closest_cells": (_I, [_V, _V, _I, _V, _I, _I, _I, _I, _V]),
+    "randt_cell_add_points": (_I, [_V, _V, _V, _I, _I, _I, _I, _P(_I)]),
+    "randt_cells_merge": (_I, [_V, _V, _V, _I]),
+    "randt_cells_transform": (_I, [_V, _V, _I, _V]),
+    "randt_cells_mahalanobis": (_I, [_V, _V, _V, _I, _I, _V]),
     "randt_associate_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _V, _P(MatcherParams), _V]),
     "randt_solve_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _V, _P(MatcherParams), _V, _V]),
     "randt_register_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _P(MatcherParams), _V, _V]),

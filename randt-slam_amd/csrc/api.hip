@@ -487,6 +487,75 @@ int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   return rc;
 }
 
+// ---------------------------------------------------------------- single cells (facade Cell mutators) ---------
+namespace {
+// stage n cells (and optionally n more) in the workspace, run one cell kernel, read back what it produced
+int cells_roundtrip(randt_ctx* ctx, int op, randt_cell* h_a, const randt_cell* h_b, int n, const double* h_pose4, double* h_out) {
+  const size_t cb = sizeof(randt_cell) * (size_t)n;
+  const size_t off_b = (cb + 255) & ~(size_t)255, off_pose = off_b + ((cb + 255) & ~(size_t)255), off_out = off_pose + 256;
+  int rc = ensure_ws(ctx, off_out + sizeof(double) * (size_t)n + 256);
+  if (rc) return rc;
+  char* ws = (char*)ctx->ws;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws, h_a, cb, hipMemcpyHostToDevice, ctx->stream));
+  if (h_b) RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_b, h_b, cb, hipMemcpyHostToDevice, ctx->stream));
+  if (h_pose4) RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_pose, h_pose4, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_cells_op(ctx, op, (randt_cell*)ws, (const randt_cell*)(ws + off_b), n, (const double*)(ws + off_pose), (double*)(ws + off_out));
+  if (rc) return rc;
+  if (h_out) RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_out, ws + off_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  else RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_a, ws, cb, hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RANDT_OK;
+}
+}  // namespace
+
+int randt_cells_merge(randt_ctx* ctx, randt_cell* h_acc, const randt_cell* h_other, int n) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx || n < 0 || (n > 0 && (!h_acc || !h_other))) return RANDT_ERR_INVALID;
+  if (n == 0) return RANDT_OK;
+  return cells_roundtrip(ctx, 0, h_acc, h_other, n, nullptr, nullptr);
+}
+
+int randt_cells_transform(randt_ctx* ctx, randt_cell* h_cells, int n, const double h_pose4[4]) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx || n < 0 || !h_pose4 || (n > 0 && !h_cells)) return RANDT_ERR_INVALID;
+  if (n == 0) return RANDT_OK;
+  return cells_roundtrip(ctx, 1, h_cells, nullptr, n, h_pose4, nullptr);
+}
+
+int randt_cells_mahalanobis(randt_ctx* ctx, const randt_cell* h_self, const randt_cell* h_subtrahend, int n, int use_intensity,
+                            double* h_out) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx || n < 0 || (n > 0 && (!h_self || !h_subtrahend || !h_out))) return RANDT_ERR_INVALID;
+  if (n == 0) return RANDT_OK;
+  return cells_roundtrip(ctx, use_intensity ? 2 : 3, const_cast<randt_cell*>(h_self), h_subtrahend, n, nullptr, h_out);
+}
+
+int randt_cell_add_points(randt_ctx* ctx, randt_cell* h_cell, const float* h_points, int n_points, int stride_floats,
+                          int intensity_index, int min_points_per_cell, int* accepted) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx || !h_cell || n_points < 0 || (n_points > 0 && !h_points) || stride_floats < 3 || intensity_index < 0 ||
+      intensity_index >= stride_floats)
+    return RANDT_ERR_INVALID;
+  if (accepted) *accepted = 0;
+  if (n_points == 0) return RANDT_OK;
+  const size_t pb = sizeof(float) * (size_t)n_points * stride_floats;
+  const size_t off_cell = (pb + 255) & ~(size_t)255, off_acc = off_cell + 256;
+  int rc = ensure_ws(ctx, off_acc + 64);
+  if (rc) return rc;
+  char* ws = (char*)ctx->ws;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws, h_points, pb, hipMemcpyHostToDevice, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_cell, h_cell, sizeof(randt_cell), hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_cell_update(ctx, (randt_cell*)(ws + off_cell), (const float*)ws, n_points, stride_floats, intensity_index, min_points_per_cell,
+                          (int32_t*)(ws + off_acc));
+  if (rc) return rc;
+  int32_t acc = 0;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_cell, ws + off_cell, sizeof(randt_cell), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&acc, ws + off_acc, sizeof(acc), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (accepted) *accepted = acc;
+  return RANDT_OK;
+}
+
 int randt_maps_reindex(randt_maps* m, int first, int count) {
   DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, first, count)) return RANDT_ERR_INVALID;

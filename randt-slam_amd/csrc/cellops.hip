@@ -1,0 +1,117 @@
+// Cell-level operations of the reference's Cell class, for callers that edit single cells through the facade
+// (compiled with -ffp-contract=off, see cell_math.h).  Convenience paths: the batched map kernels are the hot path.
+//
+// Replaces (paths relative to /root/reference/ros/ndt_radar_slam/):
+//   src/ndt_representation/ndt_cell.cpp:25-114        Cell::addPointCloud / updateCell incl. the recursive update (:84-89)
+//   src/ndt_representation/ndt_cell.cpp:117-123       Cell::transformCell
+//   src/ndt_representation/ndt_cell.cpp:158-169       Cell::mahalanobisSquared / mahalanobisSquaredIntensity
+//   include/ndt_representation/ndt_cell.h:133-142     Cell::operator+=
+#include "cell_math.h"
+
+using namespace randt_dev;
+
+namespace {
+
+// Cell::mahalanobisSquared (ndt_cell.cpp:158-162): Eigen's 2x2 inverse is the adjugate times 1 / det; mu^T * inv first.
+__device__ __forceinline__ float mahalanobis2f(const randt_cell& self, const randt_cell& sub) {
+  const float s00 = sub.cov[0] + self.cov[0], s01 = sub.cov[1] + self.cov[1], s11 = sub.cov[3] + self.cov[3];
+  const float mu0 = sub.mean[0] - self.mean[0], mu1 = sub.mean[1] - self.mean[1];
+  const float det = s00 * s11 - s01 * s01;
+  const float invdet = 1.0f / det;
+  const float i00 = s11 * invdet, i01 = -s01 * invdet, i10 = -s01 * invdet, i11 = s00 * invdet;
+  const float r0 = mu0 * i00 + mu1 * i10, r1 = mu0 * i01 + mu1 * i11;
+  return r0 * mu0 + r1 * mu1;
+}
+
+// op 0: a[i] += b[i] (operator+=); 1: a[i] transformed by pose; 2 / 3: out[i] = a[i].mahalanobisSquared{Intensity,}(b[i])
+__global__ __launch_bounds__(64) void k_cells_op(int op, randt_cell* a, const randt_cell* b, int n, const double* pose4, double* out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  randt_cell x = load_cell(a + i);
+  if (op == 0) {
+    cell_merge(x, load_cell(b + i));
+    store_cell(a + i, x);
+  } else if (op == 1) {
+    float aff[4];
+    pose_to_affine_f(pose4, aff);
+    cell_transform(x, aff);
+    store_cell(a + i, x);
+  } else if (op == 2) {
+    out[i] = (double)mahalanobis3f(x, load_cell(b + i));
+  } else {
+    out[i] = (double)mahalanobis2f(x, load_cell(b + i));
+  }
+}
+
+// Cell::addPointCloud (ndt_cell.cpp:25-34) + updateCell (:36-114) for ONE cell that may already hold a distribution.
+// Strictly sequential fp32 sums in point order (one lane): the reference's arithmetic spelled out.
+__global__ __launch_bounds__(64) void k_cell_update(randt_cell* cell, const float* pts, int k, int stride, int ioff, int min_points,
+                                                   int32_t* accepted) {
+  if (threadIdx.x != 0) return;
+  randt_cell c = load_cell(cell);
+  if (!((long long)c.n + (long long)k > (long long)min_points) || k <= 0) {
+    *accepted = 0;
+    return;
+  }
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, maxi = c.max_intensity;
+  for (int j = 0; j < k; ++j) {
+    const float* p = pts + (size_t)j * stride;
+    m0 += p[0];
+    m1 += p[1];
+    m2 += p[ioff];
+    maxi = p[ioff] > maxi ? p[ioff] : maxi;
+  }
+  const float nf = (float)(uint32_t)k;
+  m0 = m0 / nf;
+  m1 = m1 / nf;
+  m2 = m2 / nf;
+  float c00 = 0.f, c11 = 0.f, c22 = 0.f, c01 = 0.f, c02 = 0.f, c12 = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const float* p = pts + (size_t)j * stride;
+    const float d0 = p[0] - m0, d1 = p[1] - m1, d2 = p[ioff] - m2;
+    c00 += (d0 * d0);
+    c11 += (d1 * d1);
+    c22 += (d2 * d2);
+    c01 += (d0 * d1);
+    c02 += (d0 * d2);
+    c12 += (d1 * d2);
+  }
+  randt_cell add;
+  add.mean[0] = m0;
+  add.mean[1] = m1;
+  add.mean[2] = m2;
+  add.cov[0] = c00 / nf;
+  add.cov[1] = c01 / nf;
+  add.cov[2] = c02 / nf;
+  add.cov[3] = c11 / nf;
+  add.cov[4] = c12 / nf;
+  add.cov[5] = c22 / nf;
+  add.n = (uint32_t)k;
+  add.max_intensity = 0.f;
+  add.reserved = 0;
+  if (c.n > 0) {
+    cell_merge(c, add);  // the recursive update (:84-89) is operator+='s formula
+  } else {
+    c = add;
+  }
+  c.max_intensity = maxi;
+  cell_regularize(c);
+  store_cell(cell, c);
+  *accepted = 1;
+}
+
+}  // namespace
+
+int launch_cells_op(randt_ctx* ctx, int op, randt_cell* d_a, const randt_cell* d_b, int n, const double* d_pose4, double* d_out) {
+  if (n <= 0) return RANDT_OK;
+  hipLaunchKernelGGL(k_cells_op, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, op, d_a, d_b, n, d_pose4, d_out);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
+
+int launch_cell_update(randt_ctx* ctx, randt_cell* d_cell, const float* d_pts, int k, int stride, int ioff, int min_points,
+                       int32_t* d_accepted) {
+  hipLaunchKernelGGL(k_cell_update, dim3(1), dim3(64), 0, ctx->stream, d_cell, d_pts, k, stride, ioff, min_points, d_accepted);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}

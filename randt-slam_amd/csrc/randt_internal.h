@@ -127,6 +127,10 @@ int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_d
                      const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries, float* d_ws, int32_t* d_loop_id,
                      float* d_yaw, double* d_min_dist);
 
+int launch_cells_op(randt_ctx* ctx, int op, randt_cell* d_a, const randt_cell* d_b, int n, const double* d_pose4, double* d_out);
+int launch_cell_update(randt_ctx* ctx, randt_cell* d_cell, const float* d_pts, int k, int stride, int ioff, int min_points,
+                       int32_t* d_accepted);
+
 int launch_eval_cost(randt_ctx* ctx, const MapView& fixed, int fmap, const MapView& moving, int mmap, const int32_t* d_corr, int k,
                      int use_intensity, double scale, double alpha, const double* d_poses4, int n_poses, double* d_cost,
                      int32_t* d_n_res);

@@ -221,6 +221,45 @@ class Maps:
         return a.value, b.value, c.value
 
 
+# ------------------------------------------------------------------ single cells (Cell mutators) ----
+def cell_add_points(ctx, cell, points, min_points_per_cell=5, intensity_index=None):
+    """Cell::addPointCloud + updateCell on one cell (CELL_DTYPE scalar; n = 0: empty).  Returns (accepted, cell)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    stride = int(pts.shape[1])
+    ioff = (3 if stride == 4 else 4) if intensity_index is None else intensity_index
+    c = np.array([cell], dtype=CELL_DTYPE)
+    acc = C.c_int(0)
+    ctx._check(ctx._lib.randt_cell_add_points(ctx._h, _dptr(c), _dptr(pts), len(pts), stride, ioff, int(min_points_per_cell), C.byref(acc)),
+               "randt_cell_add_points")
+    return bool(acc.value), c[0]
+
+
+def cells_merge(ctx, acc, other):
+    """Cell::operator+= elementwise; returns the merged cells."""
+    a = np.array(acc, dtype=CELL_DTYPE).reshape(-1).copy()
+    b = np.ascontiguousarray(np.array(other, dtype=CELL_DTYPE).reshape(-1))
+    ctx._check(ctx._lib.randt_cells_merge(ctx._h, _dptr(a), _dptr(b), len(a)), "randt_cells_merge")
+    return a
+
+
+def cells_transform(ctx, cells, pose4):
+    """Cell::transformCell of every cell by one pose."""
+    a = np.array(cells, dtype=CELL_DTYPE).reshape(-1).copy()
+    p = np.ascontiguousarray(pose4, dtype=np.float64)
+    ctx._check(ctx._lib.randt_cells_transform(ctx._h, _dptr(a), len(a), _dptr(p)), "randt_cells_transform")
+    return a
+
+
+def cells_mahalanobis(ctx, self_cells, subtrahend_cells, use_intensity=True):
+    """self.mahalanobisSquaredIntensity(subtrahend) (or mahalanobisSquared) elementwise, as float64."""
+    a = np.ascontiguousarray(np.array(self_cells, dtype=CELL_DTYPE).reshape(-1))
+    b = np.ascontiguousarray(np.array(subtrahend_cells, dtype=CELL_DTYPE).reshape(-1))
+    out = np.zeros(len(a))
+    ctx._check(ctx._lib.randt_cells_mahalanobis(ctx._h, _dptr(a), _dptr(b), len(a), 1 if use_intensity else 0, _dptr(out)),
+               "randt_cells_mahalanobis")
+    return out
+
+
 def _shape3(points):
     if hasattr(points, "shape") and len(points.shape) == 3:
         return int(points.shape[0]), int(points.shape[1]), int(points.shape[2])

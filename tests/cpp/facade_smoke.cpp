@@ -9,12 +9,20 @@
 
 int main() {
   using namespace randt;
-  std::shared_ptr<Context> ctx;
-  try {
-    ctx = std::make_shared<Context>(0);
-  } catch (const std::exception& e) {
-    std::printf("no device: %s\n", e.what());
-    return 3;
+  // default error policy = the reference's: nothing throws, a failing call warns on std::cout and keeps the previous
+  // value, the status is available from last_status()
+  std::shared_ptr<Context> ctx = std::make_shared<Context>(0);
+  if (!ctx->get()) {
+    std::printf("no device: %s\n", randt_status_string(last_status()));
+    // ... and with the throwing policy the same failure is an exception
+    error_policy() = ErrorPolicy::kThrow;
+    bool thrown = false;
+    try {
+      Context c2(0);
+    } catch (const std::exception&) {
+      thrown = true;
+    }
+    return thrown ? 3 : 5;
   }
   // scene: 40 tight blobs on a ring; "submap" scan at identity, "query" scan seen from (0.3, -0.2, 0.1 rad)
   std::mt19937 rng(7);
@@ -172,6 +180,57 @@ int main() {
     edit_ok = cells.size() == 2 && grid.at(idx0) == 0 && near_pt.size() == 2 && near_pt[0] == 1 && near_cell.size() == 1 &&
               near_cell[0] == 0 && pos == 2 && m.get_n_cells() == 3;
   }
+  // Cell mutators through the facade (ndt_cell.h:24-154) and the never-throw behaviour
+  bool cell_ok = true;
+  {
+    std::vector<float> a, b;
+    for (int i = 0; i < 24; ++i) a.insert(a.end(), {2.0f + 0.02f * (i % 6), 1.0f + 0.03f * (i / 6), 0.f, 30.f + (i % 7)});
+    for (int i = 0; i < 12; ++i) b.insert(b.end(), {2.3f + 0.015f * (i % 4), 1.1f + 0.02f * (i / 4), 0.f, 50.f + (i % 3)});
+    Cell c1, c2, c3;
+    c1.initialize(ctx, mp.min_points_per_cell);
+    c2.initialize(ctx, mp.min_points_per_cell);
+    c3.initialize(ctx, mp.min_points_per_cell);
+    const bool few = c1.addPointCloud(a.data(), 4, 4, 3);            // 4 points: below the gate, nothing happens
+    const bool t1 = c1.addPointCloud(a.data(), 24, 4, 3);
+    const bool t2 = c2.addPointCloud(b.data(), 12, 4, 3);
+    for (int i = 0; i < 24; ++i) c3.addPoint(a[4 * i], a[4 * i + 1], a[4 * i + 3]);
+    c3.updateCell();                                                  // addPoint ... updateCell == addPointCloud
+    const bool same = c3.getNumCells() == 24 && c3.getMean() == c1.getMean() && c3.getIntensityCov() == c1.getIntensityCov();
+    const double d3 = c1.mahalanobisSquaredIntensity(c2), d3r = c2.mahalanobisSquaredIntensity(c1), d2 = c1.mahalanobisSquared(c2);
+    Cell sum = c1;
+    sum += c2;                                                        // operator+=
+    Cell rec = c1;
+    rec.addPointCloud(b.data(), 12, 4, 3);                            // recursive update of a filled cell (+ regularisation)
+    Cell moved = c1;
+    moved.transformCell(SE2d(0.5, 1.0, -2.0));
+    const auto m0 = c1.getMean(), m1 = moved.getMean();
+    const double ex = std::cos(0.5) * m0[0] - std::sin(0.5) * m0[1] + 1.0, ey = std::sin(0.5) * m0[0] + std::cos(0.5) * m0[1] - 2.0;
+    std::printf("cells: n %zu + %zu -> %zu (recursive %zu), d3 %.4f (%.4f reversed) d2 %.4f, moved mean (%.4f, %.4f)\n", c1.getNumCells(),
+                c2.getNumCells(), sum.getNumCells(), rec.getNumCells(), d3, d3r, d2, m1[0], m1[1]);
+    cell_ok = !few && t1 && t2 && same && c1.getNumCells() == 24 && sum.getNumCells() == 36 && rec.getNumCells() == 36 && d3 > 0 &&
+              std::fabs(d3 - d3r) < 1e-3 * d3 && d2 > 0 && std::fabs(m1[0] - ex) < 1e-4 && std::fabs(m1[1] - ey) < 1e-4 &&
+              sum.getMean()[0] > m0[0] && sum.getMean()[0] < c2.getMean()[0] && moved.getNumCells() == 24;
+    // never-throw: a registration with an impossible parameter set warns and leaves the pose as it was
+    Matcher bad;
+    NDTMatcherParameters bp = prm;
+    bp.gnc_control_parameter_divisor = 0.5;                           // would hang the device loop: rejected by the ABI
+    bad.initialize(bp);
+    SE2d keep2(0.3, 4.0, 5.0);
+    bad.estimateLoopConstraint(keep2, submap, scan_b, 2, true, 1.5);
+    Map tiny;
+    tiny.initialize(ctx, mp, 0.0, 0.0, 1);
+    tiny.insertCluster(a.data(), 24, 4, 3);
+    tiny.insertCluster(b.data(), 12, 4, 3);                           // capacity exhausted: warning, map unchanged, no exception
+    cell_ok = cell_ok && keep2.d[2] == 4.0 && keep2.d[3] == 5.0 && tiny.get_n_cells() == 1 && last_status() == RANDT_OK;
+    // HierarchicalMap pass-through: cluster by cluster == what insertCluster builds
+    HierarchicalMap hm;
+    hm.initialize(ctx, mp, 0.0, 0.0, 16);
+    std::vector<float> both(a);
+    both.insert(both.end(), b.begin(), b.end());
+    hm.addClusters(both.data(), {0, 24, 36}, 4, 3);
+    const auto hc = hm.getMap().getCells();
+    cell_ok = cell_ok && hc.size() == 2 && hc[0].getMean() == c1.getMean() && hc[1].getIntensityCov() == c2.getIntensityCov();
+  }
   // pose-graph back end through the GlobalFuser mirror: a drifting square drive closed by one loop constraint
   bool pg_ok = true;
   {
@@ -215,5 +274,5 @@ int main() {
     pg_ok = e1 < 0.1 * e0 && nodes.at(0).pos[0] == 0.0 && nodes.at(0).pos[1] == 0.0 &&
             std::fabs(nodes.at(n - 1).pose.d[2] - after[0]) < 1e-12;
   }
-  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok && edit_ok) ? 0 : 2;
+  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok && edit_ok && cell_ok) ? 0 : 2;
 }
