@@ -16,6 +16,8 @@
 // bins and cluster bounds live in LDS as well, so the only HBM traffic is N*16 B in, M*48 B + grid out.  fp32
 // sums run in the reference's sequential point order (one lane per accumulator chain, eight lanes per
 // cluster) so the cell statistics are bit-identical to the CPU path.
+#include <vector>
+
 #include "cell_math.h"
 
 using namespace randt_dev;
@@ -635,7 +637,33 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
                      int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map) {
   if (n_scans <= 0) return RANDT_OK;
   const int npad = (pitch + 63) & ~63;
-  if (pitch > 7168) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel (max 7168 points)", hipSuccess);
+  if (pitch > 7168 || ctx->build_tiled) {
+    // scans beyond one workgroup's LDS: multi-workgroup stable counting sort in global memory (ndt_build_big.hip)
+    if ((long long)pitch > (1ll << 26)) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large (max 2^26 points)", hipSuccess);
+    const size_t want = ndt_build_big_ws_bytes(n_scans, pitch);
+    if (want > ctx->build_ws_bytes) {
+      if (ctx->build_ws) {
+        RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        RANDT_HIP_CHECK(ctx, hipFree(ctx->build_ws));
+        ctx->build_ws = nullptr;
+        ctx->build_ws_bytes = 0;
+      }
+      RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->build_ws, want));
+      ctx->build_ws_bytes = want;
+    }
+    int rc = launch_ndt_build_big(ctx, d_points, n_scans, pitch, d_n_points, stride, ioff, cp, out, first_map, ctx->build_ws);
+    if (rc) return rc;
+    // The tiled path keeps <= 8192 label bins per tile.  A scan whose labels span more (points many times max_range away
+    // from the sensor) cannot be sorted by it: that is reported here, which costs this path one synchronisation.
+    std::vector<int32_t> st((size_t)4 * n_scans);
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(st.data(), ctx->build_ws, sizeof(int32_t) * 4 * n_scans, hipMemcpyDeviceToHost, ctx->stream));
+    RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < n_scans; ++s)
+      if (st[4 * (size_t)s + 2] != 0)
+        return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan above 7168 points whose cluster labels span more than 8192 values "
+                               "(points far outside max_range): not supported by the tiled build", hipSuccess);
+    return RANDT_OK;
+  }
   // Grid::cluster (grid.cpp:8-9)
   const int row_size = (int)sqrt((double)cp->n_clusters);
   const float resolution = cp->max_range * 2 / (float)row_size;

@@ -40,6 +40,7 @@ struct randt_ctx {
   int solve_rpb = 4;         // independent registrations (one wavefront each) per workgroup in the pair solve: 1, 2, 4, 8
                              // (RANDT_SOLVE_RPB).  4 = one per SIMD of a CU: +9 % end to end over single-wavefront workgroups,
                              // which the dispatcher places unevenly when they arrive from 16 queues
+  int build_tiled = 0;       // RANDT_BUILD_TILED=1: every scan through the multi-workgroup build (normally only > 7168 points)
   int assoc_stage_grid = 0;  // 1: stage the fixed map's index grid in LDS; 0: gather it from L2 (same speed alone, but 36 KB instead of 76 KB of LDS leaves room for co-running build workgroups: +2 % end to end)
 };
 
@@ -84,6 +85,9 @@ struct DeviceGuard {
 // launchers implemented in the kernel TUs
 int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points,
                      int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map);
+size_t ndt_build_big_ws_bytes(int n_scans, int pitch);
+int launch_ndt_build_big(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride,
+                         int ioff, const randt_cluster_params* cp, const MapView& out, int first_map, void* d_ws);
 int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count, const double* d_pose4);
 int launch_maps_reindex(randt_ctx* ctx, const MapView& m, int first, int count);
 int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,

@@ -62,19 +62,16 @@ def test_pcl_stride_and_host_entry_point(env):
     assert cells_equal(a, om.cells()) and cells_equal(b, om.cells()) and np.array_equal(ga, gb)
 
 
-def test_maximum_scan_size_and_too_large(env):
+def test_largest_one_workgroup_scans(env):
     torch, dev, ctx = env
     maps = R.Maps(ctx, 1, R.indoor_map_params(), 2048, with_grid=True)
-    for n in (4096, 7168):                                      # 7168 = the LDS build kernel's maximum
+    for n in (4096, 7168):                                      # 7168 = the one-workgroup (LDS) build kernel's maximum
         big = np.concatenate([_scan(1002 + i) for i in range(4)])[:n]
         R.ndt_build_batch(ctx, torch.from_numpy(big[None]).to(dev), R.indoor_cluster_params(), maps)
         cells, grid = maps.download(0)
         om = oracle_scan_map(big, cap=2048)
         assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
-    huge = torch.zeros((1, 9000, 4), dtype=torch.float32, device=dev)
-    with pytest.raises(R.RandtError) as e:
-        R.ndt_build_batch(ctx, huge, R.indoor_cluster_params(), maps)
-    assert e.value.status == R._capi.ERR_UNSUPPORTED           # loud, not a silent fallback
+    # larger scans take the multi-workgroup path: tests/test_gpu_big_scans.py
 
 
 def test_out_of_range_points_take_the_fallback_sort(env):

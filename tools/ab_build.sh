@@ -10,9 +10,9 @@ OUT=$ROOT/build/ab/$NAME
 mkdir -p "$OUT"
 COMMON="$EXTRA -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$SRC -Wall -Wno-unused-function -Wno-pass-failed"
 pids=()
-for f in api ndt_build associate solve window filter csdiv scancontext posegraph cellops; do
+for f in api ndt_build associate solve window filter csdiv scancontext posegraph cellops ndt_build_big; do
   exact=""
-  case $f in ndt_build|associate|filter|csdiv|scancontext|cellops) exact="-ffp-contract=off";; esac
+  case $f in ndt_build|associate|filter|csdiv|scancontext|cellops|ndt_build_big) exact="-ffp-contract=off";; esac
   /opt/rocm/bin/hipcc $COMMON $exact -c "$SRC/$f.hip" -o "$OUT/$f.o" &
   pids+=($!)
 done
