@@ -341,13 +341,18 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
 // RPB > 1 (BLOCK = 64 only): RPB independent registrations per workgroup, one per wavefront -- nothing is shared between
 // them (no workgroup barrier); the point is placement: the dispatcher spreads the wavefronts of ONE workgroup over the four
 // SIMDs of a CU, which it does not do for single-wavefront workgroups arriving from many queues.
-#ifdef RANDT_SOLVE_WPE  // experiment knob (tools/ab_build.sh): force this many wavefronts per SIMD
-#define RANDT_SOLVE_OCC __attribute__((amdgpu_waves_per_eu(RANDT_SOLVE_WPE, RANDT_SOLVE_WPE)))
+// Wavefronts per SIMD.  The closed-form-loss kernels (AM2) are pinned to THREE (<= 168 registers): with the cold solver
+// state in LDS they need ~190, and squeezed to 168 the compiler parks ~20 dwords in scratch, one access of which sits in
+// the residual loop -- measured -12 % per chip-filling solve launch against two wavefronts per SIMD (a lone wavefront is
+// VALU-active about half the time; the third fills the gaps).  Four per SIMD (128 registers) spill 70 dwords and lose.
+// The general-alpha kernels carry pow() and stay at two.  RANDT_SOLVE_WPE: experiment knob (tools/ab_build.sh).
+#ifdef RANDT_SOLVE_WPE
+#define RANDT_SOLVE_OCC(AM2) __attribute__((amdgpu_waves_per_eu(RANDT_SOLVE_WPE, RANDT_SOLVE_WPE)))
 #else
-#define RANDT_SOLVE_OCC
+#define RANDT_SOLVE_OCC(AM2) __attribute__((amdgpu_waves_per_eu((AM2) ? 3 : 2, (AM2) ? 3 : 2)))
 #endif
 template <int D, int PARAM, int BLOCK, bool AM2, int RPB>
-__global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
+__global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
                                                       int moving_first, const int32_t* __restrict__ corr, SolveParams P,
                                                       double* __restrict__ pose4, randt_result* __restrict__ results,
                                                       double* trace, int trace_len, int n_total) {
@@ -357,6 +362,10 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
   __shared__ double red_all[RPB][2 * WAVES * 12];
   __shared__ int s_count_all[RPB][WAVES];
   __shared__ unsigned s_pairs_all[RPB][PAIR_CAP];
+  // Solver state that is not touched while a residual pass runs lives in LDS (one copy per registration, written by one
+  // lane, read back with uniform addresses): best point, Jacobi scaling and its products, LM diagonal, scaled gradient /
+  // J^T J.  That takes ~70 registers out of the pass and lets a third wavefront share the SIMD.
+  __shared__ double cold_all[RPB * WAVES][56];  // one copy per WAVEFRONT: the two wavefronts of BLOCK = 128 run the solver redundantly and are only synchronised inside a pass
 
   const int sub = RPB > 1 ? (int)(threadIdx.x >> 6) : 0;
   const int tid = RPB > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -365,6 +374,10 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
   double* red = red_all[sub];
   int* s_count = s_count_all[sub];
   unsigned* s_pairs = s_pairs_all[sub];
+  double* const cold = cold_all[RPB > 1 ? sub : (int)(threadIdx.x >> 6)];
+  const bool w0 = (threadIdx.x & 63) == 0;  // the lane that writes the LDS-resident state
+#define RANDT_COLD_SET(ref, val) do { const double v__ = (val); if (w0) (ref) = v__; } while (0)
+#define RANDT_COLD_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
   const int fmap = fixed_idx ? fixed_idx[pair] : 0;
   const int mmap = moving_first + pair;
   const int k = P.k;
@@ -439,18 +452,29 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
   res.status = 0;
   res.reserved[0] = res.reserved[1] = 0;
 
-  double x[4], best[4];
+  double* const best = cold;     // [4]
+  double* const x = cold + 36;   // [4] current point
+  double* const cand = cold + 40;  // [4] candidate point
+  double& minimum_cost = cold[44];
+  double& summary_min = cold[45];
+  double& x_norm = cold[46];
   {
     const double p0 = pose4[4 * (size_t)pair + 0], p1 = pose4[4 * (size_t)pair + 1];
     const double p2 = pose4[4 * (size_t)pair + 2], p3 = pose4[4 * (size_t)pair + 3];
+    double x0[4];
     if (PARAM == RANDT_PARAM_VECTOR) {
-      x[0] = p2; x[1] = p3; x[2] = atan2(p1, p0); x[3] = 0.0;  // trans.log()(2), ndt_matcher.cpp:439
+      x0[0] = p2; x0[1] = p3; x0[2] = atan2(p1, p0); x0[3] = 0.0;  // trans.log()(2), ndt_matcher.cpp:439
     } else {
-      x[0] = p0; x[1] = p1; x[2] = p2; x[3] = p3;
+      x0[0] = p0; x0[1] = p1; x0[2] = p2; x0[3] = p3;
     }
-  }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) best[i] = x[i];
+    for (int i = 0; i < 4; ++i) {
+      RANDT_COLD_SET(x[i], x0[i]);
+      RANDT_COLD_SET(best[i], x0[i]);
+    }
+    RANDT_COLD_SET(summary_min, 0.0);
+  }
+  RANDT_COLD_SYNC();
 
   if (n_res == 0) {
     // "WARNING: NO RESIDUALS ADDED!" (ndt_matcher.cpp:454-456): pose unchanged
@@ -469,7 +493,6 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
   gnc_mu = fmin(gnc_mu, pow(P.gnc_div, (double)(P.gnc_steps - 1)));
   res.mu0 = gnc_mu;
   int term = RANDT_TERM_FAILURE;
-  double summary_min = 0.0;
   if (!ok) res.status = 2;
 
   if (ok) {
@@ -477,18 +500,24 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
       gnc_mu = fmax(gnc_mu, 1.0);
       L = make_loss(P.loss_a, P.alpha, gnc_mu, P.weight);
       // ================= one ceres::Solve (TrustRegionMinimizer::Minimize) =================
-      double sigma[NT], diag[NT], step[NT], delta[NT], cand[4];
+      double step[NT], delta[NT];
       constexpr int NS = NT * (NT + 1) / 2;
-      double gs[NT], Hs[NS];  // Jacobi-scaled gradient / J^T J (packed lower) at the current point
-      double g[NT], H[NS], ss[NS];
+      double* const sigma = cold + 4;  // [NT]
+      double* const diag = cold + 8;   // [NT]
+      double* const gs = cold + 12;    // [NT]  Jacobi-scaled gradient / J^T J (packed lower) at the current point
+      double* const Hs = cold + 16;    // [NS]
+      double* const ss = cold + 26;    // [NS]
+      double g[NT], H[NS];
       double radius = P.r0, decrease = 2.0;
       bool reuse = false, step_ok = true;
       int num_invalid = 0, iteration = 0;
-      double minimum_cost = DBL_MAX;
+      RANDT_COLD_SET(minimum_cost, DBL_MAX);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[i] = best[i];
-      double x_norm = ambient_norm<PARAM>(x);
+      for (int i = 0; i < 4; ++i) RANDT_COLD_SET(x[i], best[i]);
+      RANDT_COLD_SET(x_norm, ambient_norm<PARAM>(best));
+      RANDT_COLD_SYNC();
       const bool e_ok = eval_pass<D, PARAM, 1, BLOCK, AM2>(S, x, L, cur, red, parity, tid);
+      asm volatile("" ::: "memory");
       res.n_evals++;
       res.iterations++;
       if (!e_ok) {
@@ -499,18 +528,24 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
       }
       double cost = cur.v[0];
       if (res.gnc_solves == 0) res.initial_cost = cost;
-      summary_min = cost;
+      RANDT_COLD_SET(summary_min, cost);
       to_param<PARAM, NT>(cur, x, g, H);
+      {
+        double sg[NT];
 #pragma unroll
-      for (int i = 0; i < NT; ++i) sigma[i] = 1.0 / (1.0 + sqrt(H[sym(i, i)]));  // jacobi scaling, fixed per solve
+        for (int i = 0; i < NT; ++i) sg[i] = 1.0 / (1.0 + sqrt(H[sym(i, i)]));  // jacobi scaling, fixed per solve
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        gs[i] = g[i] * sigma[i];
+        for (int i = 0; i < NT; ++i) {
+          RANDT_COLD_SET(sigma[i], sg[i]);
+          RANDT_COLD_SET(gs[i], g[i] * sg[i]);
 #pragma unroll
-        for (int j = 0; j <= i; ++j) {
-          ss[sym(i, j)] = sigma[i] * sigma[j];
-          Hs[sym(i, j)] = H[sym(i, j)] * ss[sym(i, j)];
+          for (int j = 0; j <= i; ++j) {
+            const double sij = sg[i] * sg[j];
+            RANDT_COLD_SET(ss[sym(i, j)], sij);
+            RANDT_COLD_SET(Hs[sym(i, j)], H[sym(i, j)] * sij);
+          }
         }
+        RANDT_COLD_SYNC();
       }
       bool gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
       trace_push(tr, trace_len, cost, radius, 0);
@@ -518,9 +553,10 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
       for (;;) {
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
         if (step_ok && uni(cost < minimum_cost)) {
-          minimum_cost = cost;
+          RANDT_COLD_SET(minimum_cost, cost);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) best[i] = x[i];
+          for (int i = 0; i < 4; ++i) RANDT_COLD_SET(best[i], x[i]);
+          RANDT_COLD_SYNC();
         }
         if (iteration >= P.max_it) { term = RANDT_TERM_NO_CONVERGENCE; break; }
         if (step_ok && gconv) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
@@ -532,7 +568,8 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
         double A[NS];
         if (!reuse) {
 #pragma unroll
-          for (int i = 0; i < NT; ++i) diag[i] = fmin(fmax(Hs[sym(i, i)], P.dmin), P.dmax);
+          for (int i = 0; i < NT; ++i) RANDT_COLD_SET(diag[i], fmin(fmax(Hs[sym(i, i)], P.dmin), P.dmax));
+          RANDT_COLD_SYNC();
         }
         const double inv_radius = fast_rcp(radius);
 #pragma unroll
@@ -564,17 +601,25 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
           decrease *= 2.0;
           reuse = true;
           step_ok = false;
-          summary_min = fmin(summary_min, cost);
+          RANDT_COLD_SET(summary_min, fmin(summary_min, cost));
+          RANDT_COLD_SYNC();
           trace_push(tr, trace_len, cost, radius, 3);
           continue;
         }
         num_invalid = 0;
 #pragma unroll
         for (int i = 0; i < NT; ++i) delta[i] = step[i] * sigma[i];
-        plus<PARAM>(x, delta, cand);
+        {
+          double cnew[4];
+          plus<PARAM>(x, delta, cnew);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) RANDT_COLD_SET(cand[i], cnew[i]);
+          RANDT_COLD_SYNC();
+        }
 
         // ---- candidate cost (+ speculative gradient / J^T J)
         const bool c_ok = eval_pass<D, PARAM, 1, BLOCK, AM2>(S, cand, L, cnd, red, parity, tid);
+        asm volatile("" ::: "memory");  // the LDS-resident state is re-read after the pass, not carried through it in registers
         res.n_evals++;
         const double cand_cost = c_ok ? cnd.v[0] : DBL_MAX;
 
@@ -594,14 +639,16 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
         if (uni(rel > P.min_rel)) {
           // ---- HandleSuccessfulStep
 #pragma unroll
-          for (int i = 0; i < 4; ++i) x[i] = cand[i];
-          x_norm = ambient_norm<PARAM>(x);
+          for (int i = 0; i < 4; ++i) RANDT_COLD_SET(x[i], cand[i]);
+          RANDT_COLD_SET(x_norm, ambient_norm<PARAM>(cand));
+          RANDT_COLD_SYNC();
           cost = cand_cost;
           to_param<PARAM, NT>(cnd, x, g, H);
 #pragma unroll
-          for (int i = 0; i < NT; ++i) gs[i] = g[i] * sigma[i];
+          for (int i = 0; i < NT; ++i) RANDT_COLD_SET(gs[i], g[i] * sigma[i]);
 #pragma unroll
-          for (int i = 0; i < NS; ++i) Hs[i] = H[i] * ss[i];
+          for (int i = 0; i < NS; ++i) RANDT_COLD_SET(Hs[i], H[i] * ss[i]);
+          RANDT_COLD_SYNC();
           gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
           step_ok = true;
           const double t = 2.0 * rel - 1.0;
@@ -609,14 +656,16 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC void k_solve(MapView fi
           radius = fmin(P.rmax, radius);
           decrease = 2.0;
           reuse = false;
-          summary_min = fmin(summary_min, cost);
+          RANDT_COLD_SET(summary_min, fmin(summary_min, cost));
+          RANDT_COLD_SYNC();
           trace_push(tr, trace_len, cost, radius, 1);
         } else {
           step_ok = false;
           radius = radius * fast_rcp(decrease);  // decrease is a power of two: exact
           decrease *= 2.0;
           reuse = true;
-          summary_min = fmin(summary_min, cand_cost);
+          RANDT_COLD_SET(summary_min, fmin(summary_min, cand_cost));
+          RANDT_COLD_SYNC();
           trace_push(tr, trace_len, cand_cost, radius, 2);
         }
       }
