@@ -70,6 +70,46 @@ __global__ void k_clear(MapView v, int first, int count) {
   }
 }
 
+// Self-test behind randt_ctx::lds_atomics_lane_ordered: 64 lanes add to LDS words in several collision patterns (all on one
+// word, groups of 2..32 neighbours, strided groups, a second instruction on top of the first) and every lane checks that the
+// value it got back equals the number of LOWER lanes of its group (plus the group's earlier total).  out[0] = 1 if all hold.
+__global__ void k_lds_atomic_order_probe(int32_t* out) {
+  __shared__ unsigned long long w[64];
+  const int lane = threadIdx.x;
+  int ok = 1;
+  for (int pattern = 0; pattern < 8; ++pattern) {
+    w[lane] = 0ull;
+    __syncthreads();
+    int grp, rank, size;
+    if (pattern < 6) {  // contiguous groups of 64, 32, 16, 8, 4, 2 lanes
+      size = 64 >> pattern;
+      grp = lane / size;
+      rank = lane % size;
+    } else if (pattern == 6) {  // interleaved: lanes with equal (lane % 8) collide
+      size = 8;
+      grp = lane % 8;
+      rank = lane / 8;
+    } else {  // irregular group sizes 1, 2, 3, ...
+      int start = 0, g = 0;
+      while (start + g + 1 <= lane) {
+        start += g + 1;
+        ++g;
+      }
+      grp = g;
+      rank = lane - start;
+      size = g + 1;
+      if (start + size > 64) size = 64 - start;
+    }
+    for (int rep = 0; rep < 3; ++rep) {  // a wavefront's LDS operations complete in program order
+      const unsigned long long old = atomicAdd(&w[grp], 1ull << 16);
+      if ((int)(old >> 16) != rep * size + rank) ok = 0;
+    }
+    __syncthreads();
+  }
+  const unsigned long long all = __ballot(ok != 0);
+  if (lane == 0) out[0] = all == ~0ull ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -145,9 +185,30 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
   }
   if (const char* e = getenv("RANDT_ASSOC_STAGE_GRID")) ctx->assoc_stage_grid = atoi(e) ? 1 : 0;
   if (const char* e = getenv("RANDT_BUILD_TILED")) ctx->build_tiled = atoi(e) ? 1 : 0;
+  {
+    // does this device serve colliding LDS atomics in lane order?  (one 64-thread launch; if the probe cannot run or says
+    // no, the build kernels keep the ballot ranking, which assumes nothing)
+    int32_t* d_flag = nullptr;
+    int32_t h_flag = 0;
+    if (hipMalloc(&d_flag, sizeof(int32_t)) == hipSuccess) {
+      bool good = true;
+      for (int rep = 0; rep < 4 && good; ++rep) {
+        hipLaunchKernelGGL(k_lds_atomic_order_probe, dim3(1), dim3(64), 0, ctx->stream, d_flag);
+        good = hipMemcpyAsync(&h_flag, d_flag, sizeof(h_flag), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+               hipStreamSynchronize(ctx->stream) == hipSuccess && h_flag == 1;
+      }
+      ctx->lds_atomics_lane_ordered = good ? 1 : 0;
+      (void)hipFree(d_flag);
+    }
+    (void)hipGetLastError();
+    if (const char* e = getenv("RANDT_BUILD_ATOMIC_RANK")) ctx->lds_atomics_lane_ordered = (atoi(e) && ctx->lds_atomics_lane_ordered) ? 1 : 0;
+  }
   *out = ctx;
   return RANDT_OK;
 }
+
+// debug / test hook (not part of the ABI): did the LDS atomic ordering self-test pass on this context's device?
+int randt_debug_lds_atomics_lane_ordered(const randt_ctx* ctx) { return ctx ? ctx->lds_atomics_lane_ordered : 0; }
 
 int randt_ctx_destroy(randt_ctx* ctx) {
   if (!ctx) return RANDT_OK;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
                                                            const int32_t* __restrict__ n_pts_arr, int stride,
                                                            int ioff, int row_size, float resolution, MapView out,
                                                            int first_map, int npad, int nb_cap, int aux_bytes,
-                                                           int32_t* __restrict__ fallback_ws) {
+                                                           int32_t* __restrict__ fallback_ws, int lane_ordered_atomics) {
   constexpr int PPT = 8;
   constexpr bool KEEP = REG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -265,26 +265,42 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     const int nbits = nb > 1 ? 32 - __clz(nb - 1) : 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int sh = 16 * wave;
+    if (lane_ordered_atomics) {
+      // The LDS serves the lanes of one atomic instruction that hit the same address in ascending lane order (checked on
+      // this device when the context was created, randt_ctx_create): the value a lane gets back IS its rank among the
+      // lanes of the step with its label plus what earlier steps of this wavefront added -- one returning atomic per point
+      // instead of a ballot per label bit; a wavefront's LDS operations execute in program order, so the steps stay ordered.
 #pragma unroll 8
-    for (int j = 0; j < nsteps; ++j) {
-      const int i = w_beg + 64 * j + lane;
-      const bool valid = i < w_end;
-      const int b = (valid ? RANDT_PL(j, i) : 0) - lmin;
-      unsigned long long mask = __ballot(valid);  // lanes of this step with my label
-      if (mask == 0ull) break;                    // wave-uniform: this quarter is exhausted
-      for (int bit = 0; bit < nbits; ++bit) {
-        const bool one = (b >> bit) & 1;
-        const unsigned long long m = __ballot(valid && one);
-        mask &= one ? m : ~m;
+      for (int j = 0; j < nsteps; ++j) {
+        const int i = w_beg + 64 * j + lane;
+        if (i < w_end) {
+          const int b = RANDT_PL(j, i) - lmin;
+          const unsigned long long old = atomicAdd(&bins[b], 1ull << sh);
+          RANDT_PL(j, i) = b | ((int)((old >> sh) & 0xffff) << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
+        }
       }
-      int field = 0;
-      const int leader = __ffsll((long long)mask) - 1;
-      if (valid && lane == leader) {
-        const unsigned long long old = atomicAdd(&bins[b], (unsigned long long)__popcll(mask) << sh);
-        field = (int)((old >> sh) & 0xffff);
+    } else {
+#pragma unroll 8
+      for (int j = 0; j < nsteps; ++j) {
+        const int i = w_beg + 64 * j + lane;
+        const bool valid = i < w_end;
+        const int b = (valid ? RANDT_PL(j, i) : 0) - lmin;
+        unsigned long long mask = __ballot(valid);  // lanes of this step with my label
+        if (mask == 0ull) break;                    // wave-uniform: this quarter is exhausted
+        for (int bit = 0; bit < nbits; ++bit) {
+          const bool one = (b >> bit) & 1;
+          const unsigned long long m = __ballot(valid && one);
+          mask &= one ? m : ~m;
+        }
+        int field = 0;
+        const int leader = __ffsll((long long)mask) - 1;
+        if (valid && lane == leader) {
+          const unsigned long long old = atomicAdd(&bins[b], (unsigned long long)__popcll(mask) << sh);
+          field = (int)((old >> sh) & 0xffff);
+        }
+        field = __shfl(field, valid ? leader : lane, 64);
+        if (valid) RANDT_PL(j, i) = b | ((field + __popcll(mask & lt)) << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
       }
-      field = __shfl(field, valid ? leader : lane, 64);
-      if (valid) RANDT_PL(j, i) = b | ((field + __popcll(mask & lt)) << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
     }
     __syncthreads();
     RANDT_TICK(3);
@@ -720,7 +736,8 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<REG>),                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
     hipLaunchKernelGGL((k_ndt_build<REG>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,            \
-                       d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux, d_fallback);            \
+                       d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux, d_fallback,            \
+                       ctx->lds_atomics_lane_ordered);                                                                      \
   } while (0)
   if (reg) RANDT_BUILD_LAUNCH(true);
   else RANDT_BUILD_LAUNCH(false);

@@ -46,6 +46,7 @@ struct BigArgs {
   float* sy;
   float* si;
   int npad;
+  int lane_ordered_atomics;  // randt_ctx::lds_atomics_lane_ordered
 };
 
 __device__ __forceinline__ int32_t big_label(float x, float y, int row_size, float resolution) {
@@ -116,30 +117,45 @@ __global__ __launch_bounds__(BIG_BLOCK) void k_big_count(BigArgs A) {
   const int nbits = nb > 1 ? 32 - __clz(nb - 1) : 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int sh = 16 * wave;
-  for (int j = 0; j < BIG_PPT; ++j) {
-    const int i = w_beg + 64 * j + lane;
-    const bool valid = i < w_end;
-    int b = 0;
-    if (valid) {
-      float x, y, in;
-      fetch_point(A, sp, i, x, y, in);
-      b = big_label(x, y, A.row_size, A.resolution) - lmin;
+  if (A.lane_ordered_atomics) {
+    // colliding LDS atomics of one instruction are served in lane order on this device (self-test at context creation):
+    // the returned count is the rank (see k_ndt_build)
+    for (int j = 0; j < BIG_PPT; ++j) {
+      const int i = w_beg + 64 * j + lane;
+      if (i < w_end) {
+        float x, y, in;
+        fetch_point(A, sp, i, x, y, in);
+        const int b = big_label(x, y, A.row_size, A.resolution) - lmin;
+        const unsigned long long old = atomicAdd(&bins[b], 1ull << sh);
+        pw[i] = (uint32_t)b | ((uint32_t)((old >> sh) & 0xffff) << 16);
+      }
     }
-    unsigned long long mask = __ballot(valid);  // lanes of this step with my label
-    if (mask == 0ull) break;                    // wave-uniform: this quarter is exhausted
-    for (int bit = 0; bit < nbits; ++bit) {
-      const bool one = (b >> bit) & 1;
-      const unsigned long long m = __ballot(valid && one);
-      mask &= one ? m : ~m;
+  } else {
+    for (int j = 0; j < BIG_PPT; ++j) {
+      const int i = w_beg + 64 * j + lane;
+      const bool valid = i < w_end;
+      int b = 0;
+      if (valid) {
+        float x, y, in;
+        fetch_point(A, sp, i, x, y, in);
+        b = big_label(x, y, A.row_size, A.resolution) - lmin;
+      }
+      unsigned long long mask = __ballot(valid);  // lanes of this step with my label
+      if (mask == 0ull) break;                    // wave-uniform: this quarter is exhausted
+      for (int bit = 0; bit < nbits; ++bit) {
+        const bool one = (b >> bit) & 1;
+        const unsigned long long m = __ballot(valid && one);
+        mask &= one ? m : ~m;
+      }
+      int field = 0;
+      const int leader = __ffsll((long long)mask) - 1;
+      if (valid && lane == leader) {
+        const unsigned long long old = atomicAdd(&bins[b], (unsigned long long)__popcll(mask) << sh);
+        field = (int)((old >> sh) & 0xffff);
+      }
+      field = __shfl(field, valid ? leader : lane, 64);
+      if (valid) pw[i] = (uint32_t)b | ((uint32_t)(field + __popcll(mask & lt)) << 16);  // bin | rank inside (bin, wave)
     }
-    int field = 0;
-    const int leader = __ffsll((long long)mask) - 1;
-    if (valid && lane == leader) {
-      const unsigned long long old = atomicAdd(&bins[b], (unsigned long long)__popcll(mask) << sh);
-      field = (int)((old >> sh) & 0xffff);
-    }
-    field = __shfl(field, valid ? leader : lane, 64);
-    if (valid) pw[i] = (uint32_t)b | ((uint32_t)(field + __popcll(mask & lt)) << 16);  // bin | rank inside (bin, wave)
   }
   __syncthreads();
   unsigned long long* h = A.hist + ((size_t)scan * A.n_tiles + tile) * BIG_NB_MAX;
@@ -382,6 +398,7 @@ int launch_ndt_build_big(randt_ctx* ctx, const float* d_points, int n_scans, int
   A.n_tiles = (pitch + BIG_TILE - 1) / BIG_TILE;
   A.first_map = first_map;
   A.npad = (pitch + 63) & ~63;
+  A.lane_ordered_atomics = ctx->lds_atomics_lane_ordered;
   char* w = (char*)d_ws;
   auto take = [&](size_t bytes) {
     char* p = w;

@@ -40,6 +40,8 @@ struct randt_ctx {
   int solve_rpb = 4;         // independent registrations (one wavefront each) per workgroup in the pair solve: 1, 2, 4, 8
                              // (RANDT_SOLVE_RPB).  4 = one per SIMD of a CU: +9 % end to end over single-wavefront workgroups,
                              // which the dispatcher places unevenly when they arrive from 16 queues
+  int lds_atomics_lane_ordered = 0;  // device self-test at context creation (api.hip): same-address LDS atomics of one instruction
+                                     // are served in ascending lane order -> the build kernels rank points with one atomic each
   int build_tiled = 0;       // RANDT_BUILD_TILED=1: every scan through the multi-workgroup build (normally only > 7168 points)
   int assoc_stage_grid = 0;  // 1: stage the fixed map's index grid in LDS; 0: gather it from L2 (same speed alone, but 36 KB instead of 76 KB of LDS leaves room for co-running build workgroups: +2 % end to end)
 };
