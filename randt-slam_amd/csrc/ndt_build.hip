@@ -463,7 +463,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     for (int j = s; j < e; ++j) {
       const float v = p1[j];
       acc += v;
-      accm = v > accm ? v : accm;
+      accm = fmaxf(accm, v);  // std::max(max_intensity_, intensity): one v_max_f32 (NaN-free data; +0 start)
     }
     if (r0 == 0) RANDT_TICK(10);
     const float nf = (float)(uint32_t)k;

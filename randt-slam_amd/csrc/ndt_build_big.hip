@@ -277,7 +277,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void k_big_stats(BigArgs A, MapView out)
     for (int j = s; j < e; ++j) {
       const float v = p1[j];
       acc += v;
-      accm = v > accm ? v : accm;
+      accm = fmaxf(accm, v);
     }
     const float nf = (float)(uint32_t)k;
     const float mean = acc / nf;
