@@ -61,8 +61,9 @@ def load_counters():
     if not files:
         return {}, None
     rows = {}
+    want_wgs = {"k_ndt_build<true>": 512, "k_associate<false>": 512, "k_solve<3,1,64,true,4>": 128}   # workgroups of a 512-registration launch
     for r in csv.DictReader(open(files[-1])):
-        if r["kernel"] in HOT_KERNELS and int(r["dispatches"]) >= 8 and r["kernel"] not in rows:
+        if r["kernel"] in HOT_KERNELS and r["kernel"] not in rows and int(r["grid_size"]) == want_wgs[r["kernel"]] * int(r["workgroup_size"]):
             rows[r["kernel"]] = {k: (float(v) if v not in ("", None) and k != "kernel" else v) for k, v in r.items()}
     return rows, os.path.relpath(files[-1], ROOT)
 
