@@ -158,14 +158,23 @@ __device__ __forceinline__ double residual_sq(const float4* mrec, const float4* 
 // Jacobian row jb / r, added to the ten base sums acc = {cost, J^T r (3), upper J^T J (6)}.
 template <bool AM2>
 __device__ __forceinline__ void accumulate_residual(const Loss& L, double sq, const double* jb, double* acc) {
-  double rs;  // residual and Jacobian scale of the corrector (equal for a scalar residual when rho'' <= 0)
-  double js;
+  // With r = sqrt(sq) and the true Jacobian row J = jb / r: the corrected residual is rs * r and the corrected row
+  // js * J, so  J^T r += (js rs) jb  and  J^T J += (js^2 / sq) jb jb^T  -- no square root.
+  // sq == 0: autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545); zero row instead (branch-free: jb is
+  // exactly zero when sq is, so clamping the divisor suffices; 1e-280 keeps weight / clamp finite for any sane weight).
+  double jr, h;
   if (AM2) {
-    // alpha = -2: rho' = w / u^2 > 0, rho'' < 0 always => corrector is sqrt(rho') = sqrt(w) / u
-    const double iu = fast_rcp(sq * L.ts + 1.0);
+    // alpha = -2: rho' = w / u^2 > 0, rho'' < 0 always => corrector is sqrt(rho') = sqrt(w) / u, rs = js.
+    // ONE reciprocal serves 1 / u and 1 / sq: rP = 1 / (u^2 sq)  ->  h = w rP,  js rs = w / u^2 = h sq,  1 / u = rP u sq.
+    const double u = fma(sq, L.ts, 1.0);
+    const double sqc = fmax(sq, 1e-280);
+    const double rP = fast_rcp((u * u) * sqc);
+    h = L.weight * rP;
+    jr = h * sqc;
+    const double iu = (rP * u) * sqc;
     acc[0] += L.half_w_pre * (iu - 1.);
-    rs = js = L.sqrt_w * iu;
   } else {
+    double rs, js;  // residual and Jacobian scale of the corrector (equal for a scalar residual when rho'' <= 0)
     double r0, r1, r2;
     loss_eval(L, sq, r0, r1, r2);
     acc[0] += 0.5 * r0;
@@ -178,13 +187,9 @@ __device__ __forceinline__ void accumulate_residual(const Loss& L, double sq, co
       rs = sqrt_rho1 / (1 - al);
       js = sqrt_rho1 * (1.0 - al);  // J - (alpha/sq) r r^T J for a scalar residual
     }
+    jr = js * rs;
+    h = js * js * fast_rcp(fmax(sq, 1e-280));
   }
-  // With r = sqrt(sq) and the true Jacobian row J = jb / r: the corrected residual is rs * r and the
-  // corrected row js * J, so  J^T r += (js rs) jb  and  J^T J += (js^2 / sq) jb jb^T  -- no square root.
-  // sq == 0: autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545); zero row instead.
-  // (branch-free: jb is exactly zero when sq is, so clamping the reciprocal's argument suffices)
-  const double jr = js * rs;
-  const double h = js * js * fast_rcp(fmax(sq, DBL_MIN));
   const double h0 = h * jb[0], h1 = h * jb[1], h2 = h * jb[2];
   acc[1] += jr * jb[0];
   acc[2] += jr * jb[1];
