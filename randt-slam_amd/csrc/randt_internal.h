@@ -56,6 +56,7 @@ struct randt_maps {
 // Parameters of the solve kernel (POD copy of randt_matcher_params + derived values).
 struct SolveParams {
   double loss_a, mu_scale, alpha, weight, gnc_div;
+  double mu_cap, mu_stop;  // gnc_div^(gnc_steps - 1) and 1 / sqrt(gnc_div) (ndt_matcher.cpp:388-397,475-483), formed once on the host
   double ftol, gtol, ptol, r0, rmax, rmin, min_rel, dmin, dmax;
   int32_t gnc_steps, max_it, k, max_invalid;
 };

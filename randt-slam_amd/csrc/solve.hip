@@ -484,13 +484,13 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
   }
 
   // ---- raw residuals at the initial point -> gnc_mu (ndt_matcher.cpp:466-476)
-  Loss L = make_loss(P.loss_a, P.alpha, 1.0, P.weight);
+  Loss L = AM2 ? make_loss_am2(P.loss_a, 1.0, P.weight) : make_loss(P.loss_a, P.alpha, 1.0, P.weight);
   Base cur, cnd;
   bool ok = eval_pass<D, PARAM, 0, BLOCK, AM2>(S, x, L, cur, red, parity, tid);
   const double raw_max = cur.v[0];
   res.n_evals++;
   double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
-  gnc_mu = fmin(gnc_mu, pow(P.gnc_div, (double)(P.gnc_steps - 1)));
+  gnc_mu = fmin(gnc_mu, P.mu_cap);
   res.mu0 = gnc_mu;
   int term = RANDT_TERM_FAILURE;
   if (!ok) res.status = 2;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
   if (ok) {
     do {
       gnc_mu = fmax(gnc_mu, 1.0);
-      L = make_loss(P.loss_a, P.alpha, gnc_mu, P.weight);
+      L = AM2 ? make_loss_am2(P.loss_a, gnc_mu, P.weight) : make_loss(P.loss_a, P.alpha, gnc_mu, P.weight);
       // ================= one ceres::Solve (TrustRegionMinimizer::Minimize) =================
       double step[NT], delta[NT];
       constexpr int NS = NT * (NT + 1) / 2;
@@ -533,7 +533,10 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
       {
         double sg[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) sg[i] = 1.0 / (1.0 + sqrt(H[sym(i, i)]));  // jacobi scaling, fixed per solve
+        for (int i = 0; i < NT; ++i) {  // jacobi scaling 1 / (1 + sqrt(H_ii)), fixed per solve; Newton-refined rsqrt / rcp (~1 ulp:
+          const double hii = H[sym(i, i)];  // the scaling is a change of variables, exact arithmetic does not see it)
+          sg[i] = fast_rcp(1.0 + (hii > 0.0 ? hii * fast_rsqrt(hii) : 0.0));
+        }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
           RANDT_COLD_SET(sigma[i], sg[i]);
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
       }
       res.gnc_solves++;
       gnc_mu /= P.gnc_div;
-    } while (uni(gnc_mu > 1.0 / sqrt(P.gnc_div)));
+    } while (uni(gnc_mu > P.mu_stop));
   }
 
   res.termination = term;
@@ -773,6 +776,8 @@ int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_id
   P.alpha = mp->loss_alpha;
   P.weight = mp->loss_weight;
   P.gnc_div = mp->gnc_divisor;
+  P.mu_cap = pow(mp->gnc_divisor, (double)(mp->gnc_steps - 1));
+  P.mu_stop = 1.0 / sqrt(mp->gnc_divisor);
   P.ftol = mp->function_tolerance;
   P.gtol = mp->gradient_tolerance;
   P.ptol = mp->parameter_tolerance;

@@ -52,6 +52,20 @@ __device__ __forceinline__ Loss make_loss(double a, double alpha, double mu, dou
   return L;
 }
 
+// The same for the shipped shape alpha = -2, only what the closed-form corrector reads: factor = 4, exponent = -1,
+// pre = -2 b, ts = 1 / (2 b): one division instead of four and a square root (once per GNC step, but on every lane).
+__device__ __forceinline__ Loss make_loss_am2(double a, double mu, double weight) {
+  Loss L;
+  L.alpha = -2.0;
+  L.b = mu * a * a;
+  L.c = L.factor = L.exponent = L.pre = L.sqrt_w = 0.0;
+  L.ts = 0.5 * (1.0 / L.b);  // 2 c / factor with c = 1 / b correctly rounded, like make_loss (the long Oxford GNC schedule is sensitive to its last bit)
+  L.weight = weight;
+  L.half_w_pre = -weight * L.b;
+  L.mode = 2;
+  return L;
+}
+
 // BarronLoss::Evaluate (ceres_loss_functions.cpp:19-39) x ScaledLoss, general branches
 __device__ __forceinline__ void loss_eval(const Loss& L, double s, double& r0, double& r1, double& r2) {
   if (L.mode == 0) {

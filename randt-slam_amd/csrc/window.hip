@@ -624,7 +624,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
 
   // ---- raw NDT residuals -> gnc_mu (ndt_matcher.cpp:382-389)
   const double weight = n_cells > 0 ? W.ndt_weight / (double)(n_cells * W.k) : 0.0;
-  Loss L = make_loss(P.loss_a, P.alpha, 1.0, weight);
+  Loss L = AM2 ? make_loss_am2(P.loss_a, 1.0, weight) : make_loss(P.loss_a, P.alpha, 1.0, weight);
   double raw_max = 0.0;
   bool ok = true;
   if (n_res > 0) {
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
     __syncthreads();
   }
   double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
-  gnc_mu = fmin(gnc_mu, pow(P.gnc_div, (double)(P.gnc_steps - 1)));
+  gnc_mu = fmin(gnc_mu, P.mu_cap);
   res.mu0 = gnc_mu;
   int term = RANDT_TERM_FAILURE;
   double summary_min = 0.0;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   if (ok) {
     do {
       gnc_mu = fmax(gnc_mu, 1.0);
-      L = make_loss(P.loss_a, P.alpha, gnc_mu, weight);
+      L = AM2 ? make_loss_am2(P.loss_a, gnc_mu, weight) : make_loss(P.loss_a, P.alpha, gnc_mu, weight);
       // ================= one ceres::Solve =================
       double radius = P.r0, decrease = 2.0;
       bool reuse = false, step_ok = true;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       }
       res.gnc_solves++;
       gnc_mu /= P.gnc_div;
-    } while (uni(gnc_mu > 1.0 / sqrt(P.gnc_div)));
+    } while (uni(gnc_mu > P.mu_stop));
   }
   __syncthreads();
   for (int e = tid; e < (S + 1) * ST_STRIDE; e += WIN_BLOCK) states[e] = sh.xs[p][e / ST_STRIDE][e % ST_STRIDE];
@@ -900,6 +900,8 @@ int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& mov
   P.alpha = mp->loss_alpha;
   P.weight = mp->loss_weight;
   P.gnc_div = mp->gnc_divisor;
+  P.mu_cap = pow(mp->gnc_divisor, (double)(mp->gnc_steps - 1));
+  P.mu_stop = 1.0 / sqrt(mp->gnc_divisor);
   P.ftol = mp->function_tolerance;
   P.gtol = mp->gradient_tolerance;
   P.ptol = mp->parameter_tolerance;

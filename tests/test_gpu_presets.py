@@ -50,7 +50,7 @@ def osub(built):
     return [oracle_submap(sm) for sm in problem()["submaps"]]
 
 
-def _check(pose, res, trace, ref, B):
+def _check(pose, res, trace, ref, B, radius_rtol=1e-8):
     for i in range(B):
         p4, cost, st = ref[i]
         assert abs(pose[i, 2] - p4[2]) <= POSE_TOL_T and abs(pose[i, 3] - p4[3]) <= POSE_TOL_T
@@ -67,7 +67,7 @@ def _check(pose, res, trace, ref, B):
             assert n == len(st["trace_cost"])
             t = trace[i, 1: 1 + 3 * n].reshape(n, 3)
             assert np.allclose(t[:, 0], st["trace_cost"], rtol=1e-8)
-            assert np.allclose(t[:, 1], st["trace_radius"], rtol=1e-8)
+            assert np.allclose(t[:, 1], st["trace_radius"], rtol=radius_rtol)
             assert np.array_equal(t[:, 2].astype(int), st["trace_flag"])
 
 
@@ -242,7 +242,9 @@ def test_oxford_geometry_loop_closure_refinement(built):
     # needs 160+ LM iterations along a flat valley of the un-manifolded 4-parameter problem, where the perturbed oracle
     # lands 6e-5 away from the oracle) only have to meet the north_star tolerance and the oracle's cost.
     idx = [i for i in range(B) if stable[i]]
-    _check(pose[idx], res[idx], trace[idx], [ref[i] for i in idx], len(idx))
+    # radii to 1e-6: a trust-region radius is a function of cost DIFFERENCES (rel = cost change / model change), which late in
+    # a ten-step schedule are 1e-6 of the cost -- costs that agree to 1e-14 give radii that agree to ~1e-8 at best
+    _check(pose[idx], res[idx], trace[idx], [ref[i] for i in idx], len(idx), radius_rtol=1e-6)
     for i in range(B):
         if stable[i]:
             continue
