@@ -32,7 +32,6 @@
 #include "solve_math.h"
 
 #include <float.h>
-#include <stdlib.h>
 
 using namespace randt_solve;
 
@@ -737,8 +736,7 @@ __global__ __launch_bounds__(64) void k_eval_cost(MapView fixed, int fmap, MapVi
 template <int D, int PARAM, int BLOCK, bool AM2, int RPB = 1>
 int launch_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
                int n_pairs, const int32_t* d_corr, const SolveParams& P, double* d_pose4, randt_result* d_results) {
-  static const int lds_pad = getenv("RANDT_SOLVE_LDS_PAD") ? atoi(getenv("RANDT_SOLVE_LDS_PAD")) : 0;  // experiment: caps workgroups per CU
-  hipLaunchKernelGGL((k_solve<D, PARAM, BLOCK, AM2, RPB>), dim3((n_pairs + RPB - 1) / RPB), dim3(BLOCK * RPB), lds_pad, ctx->stream, fixed,
+  hipLaunchKernelGGL((k_solve<D, PARAM, BLOCK, AM2, RPB>), dim3((n_pairs + RPB - 1) / RPB), dim3(BLOCK * RPB), 0, ctx->stream, fixed,
                      d_fixed_idx, moving, moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len, n_pairs);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
