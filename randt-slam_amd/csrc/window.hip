@@ -8,11 +8,12 @@
 //   include/ndt_registration/ceres_residuals.h:520-552    NDTFrameToMapIntensityFactorResidualSE2 (and the 2-D form)
 //   Ceres 2.1.0 trust-region LM / Sophus 1.22.10 SE(2) manifold (un-vendored), as in solve.hip.
 //
-// One 256-thread workgroup owns one window problem (<= 3 optimised states, <= 2 fixed maps, 21-32
+// One 512-thread workgroup owns one window problem (<= 3 optimised states, <= 2 fixed maps, 21-32
 // tangent dimensions) and runs the whole GNC x LM loop without host round trips:
-//   * NDT terms: one wavefront per (state, fixed map) term streams that term's correspondence slots, cell
-//     records read in place from L1/L2, ten fp64 base sums per term (one lane-swap reduction), combined per
-//     state in term order;
+//   * NDT terms: six wavefronts share the (state, fixed map) terms (a term is split over 6 / 3 / 2 wavefronts when there
+//     are 1 / 2 / 3 of them) and stream their correspondence slots, cell records read in place from L1/L2, ten fp64 base
+//     sums per wavefront (one lane-swap reduction), combined per state in wavefront order; a seventh wavefront evaluates
+//     the motion / IMU factors meanwhile; every wavefront fetches its term's map / count / pointers ONCE per solve;
 //   * motion / IMU factors: one lane per factor evaluates residual + analytic Jacobian (right
 //     perturbations, verified against finite differences in tests/test_oracle_window.py), all lanes
 //     apply the 8x8 square-root information;
@@ -43,8 +44,9 @@ extern "C" int randt_debug_win_timing(long long* out) {
 #define WT_FLUSH do {} while (0)
 #endif
 
-#define WIN_BLOCK 256
-#define WIN_WAVES 4
+#define WIN_BLOCK 512
+#define WIN_WAVES 8
+#define WIN_NDT_WAVES 6  // wavefronts that stream NDT slots during a pass (wavefront 6: motion / IMU factors)
 #define WIN_NMAX 32  // tangent dimensions
 #define WIN_SMAX 3   // optimised states
 
@@ -274,6 +276,7 @@ struct Shared {
   int lcol[WIN_SMAX][WIN_NMAX];   // tangent column -> local column of motion factor f (-1 none)
   int lcol2[WIN_SMAX][WIN_NMAX];  // ... of IMU factor f
   int pose_of[WIN_NMAX];          // tangent column -> state whose pose block holds it (-1 none)
+  int wave_state[WIN_WAVES];      // state of the NDT term wavefront w streams (-1: none)
 };
 
 // Unweighted motion / IMU factors at xs[buf], one lane per factor (called by ONE wavefront).
@@ -296,46 +299,52 @@ __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
   }
 }
 
+// What a wavefront needs to stream its share of ONE NDT term, fetched once per kernel (the window descriptor lives in
+// device memory: re-reading term -> map -> cell count through three dependent global loads cost every pass ~1.5 us).
+struct TermShare {
+  const float4* mov;
+  const float4* fix;
+  const int32_t* pc;
+  int state, n_slots, first, stride, k, active;
+  unsigned kmagic;
+  int wpt;
+};
+
 // NDT pass over every term at the states in xs[buf].  MODE 0: max raw residual -> out[0];
 // MODE 1: ten base sums per state -> out[(j-1)*10 ..].
-// In MODE 1 wavefront 3 evaluates the motion / IMU factors of the same point while wavefronts 0-2
+// In MODE 1 wavefront 6 evaluates the motion / IMU factors of the same point while wavefronts 0-5
 // stream the NDT slots (the factors are a ~2000-instruction serial chain: hidden behind the pass).
 template <int D, int MODE, bool AM2>
-__device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const int32_t* __restrict__ corr,
+__device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const TermShare& T,
                          const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw) {
-  // One wavefront per NDT term (state x fixed map), round robin: a term's ~M k slots are a handful of trips for
-  // 64 lanes, its ten base sums need ONE ten-value wave reduction and no cross-wave combine.  MODE 1: wavefront 3
-  // evaluates the motion / IMU factors meanwhile.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool factor_wave = MODE == 1 && wave == 3;
+  const bool factor_wave = MODE == 1 && wave == WIN_NDT_WAVES;
   if (factor_wave) factors_unweighted(W, shw, buf);
-  const int n_ndt_waves = MODE == 1 ? 3 : WIN_WAVES;
-  double* r = shw.red[parity][0];  // [6 terms][10] | [64 + wave] bad | [72 + wave] max
+  // Six NDT wavefronts share the <= 6 terms: with 1 / 2 / 3 terms every term is split over 6 / 3 / 2 wavefronts (a
+  // wavefront takes every wpt-th 64-slot trip of its term), otherwise one wavefront per term.  Each wavefront reduces its
+  // own ten base sums; the per-state combine below adds the parts in wavefront order.
+  double* r = shw.red[parity][0];  // [8 wavefronts][10] | [96 + wave] bad | [104 + wave] max
   parity ^= 1;
   double mx = -DBL_MAX;
   int bad = 0;
-  if (!factor_wave) {
-    for (int t = wave; t < W.n_terms; t += n_ndt_waves) {
-      const int j = W.term_state[t];
-      const double* xp = sh.xs[buf][j];
+  if (T.active) {
+    {
+      const double* xp = sh.xs[buf][T.state];
       const double inv = fast_rsqrt(xp[0] * xp[0] + xp[1] * xp[1]);
       const double c = xp[0] * inv, s = xp[1] * inv, tx = xp[2], ty = xp[3];
       const Rot rot = make_rot(c, s);
-      const int mmap = W.term_moving[t], fmap = W.term_fixed[t];
-      int M = moving.counts[mmap];
-      M = M > moving.cap ? moving.cap : M;
-      const float4* mov = reinterpret_cast<const float4*>(moving.cells + (size_t)mmap * moving.cap);
-      const float4* fix = reinterpret_cast<const float4*>(fixed.cells + (size_t)fmap * fixed.cap);
-      const int32_t* pc = corr + (size_t)t * moving.cap * W.k;
-      const int n_slots = M * W.k;
-      const unsigned kmagic = W.k > 1 ? (unsigned)((0x100000000ull + (unsigned)W.k - 1) / (unsigned)W.k) : 0u;
+      const float4* mov = T.mov;
+      const float4* fix = T.fix;
+      const int32_t* pc = T.pc;
+      const int n_slots = T.n_slots;
+      const unsigned kmagic = T.kmagic;
       double a10[10];
 #pragma unroll
       for (int i = 0; i < 10; ++i) a10[i] = 0.0;
-      for (int slot = lane; slot < n_slots; slot += 64) {
+      for (int slot = lane + T.first; slot < n_slots; slot += T.stride) {
         const int ci = pc[slot];
         if (ci < 0 || ci >= fixed.cap) continue;
-        const unsigned mi = W.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, kmagic);  // slot / k
+        const unsigned mi = T.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, kmagic);  // slot / k
         const float4* mv = mov + (size_t)mi * 3;
         const float4* fv = fix + (size_t)ci * 3;
         double jb[3];
@@ -348,7 +357,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
         wave_sum10(a10);
         if (lane == 0) {
 #pragma unroll
-          for (int i = 0; i < 10; ++i) r[t * 10 + i] = a10[i];
+          for (int i = 0; i < 10; ++i) r[wave * 10 + i] = a10[i];
         }
       }
     }
@@ -356,15 +365,15 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
   double badf = wave_any(bad != 0);
   if (MODE == 0) mx = wave_max(mx);
   if (lane == 0) {
-    r[64 + wave] = badf;
-    r[72 + wave] = mx;
+    r[96 + wave] = badf;
+    r[104 + wave] = mx;
   }
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < WIN_WAVES; ++w) badf = r[64 + w] > badf ? r[64 + w] : badf;
+  for (int w = 0; w < WIN_WAVES; ++w) badf = r[96 + w] > badf ? r[96 + w] : badf;
   if (MODE == 0) {
 #pragma unroll
-    for (int w = 0; w < WIN_WAVES; ++w) mx = r[72 + w] > mx ? r[72 + w] : mx;
+    for (int w = 0; w < WIN_WAVES; ++w) mx = r[104 + w] > mx ? r[104 + w] : mx;
     if (threadIdx.x == 0) out[0] = mx > 0.0 ? sqrt(mx) : 0.0;
     __syncthreads();
     return uni(badf == 0.0);
@@ -373,8 +382,8 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
   if (threadIdx.x < WIN_SMAX * 10) {
     const int jj = (int)threadIdx.x / 10 + 1, i = (int)threadIdx.x % 10;
     double a = 0.0;
-    for (int t = 0; t < W.n_terms; ++t)
-      if (W.term_state[t] == jj) a += r[t * 10 + i];
+    for (int w = 0; w < WIN_NDT_WAVES; ++w)
+      if (sh.wave_state[w] == jj) a += r[w * 10 + i];
     out[threadIdx.x] = a;
   }
   return uni(badf == 0.0);
@@ -583,6 +592,34 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   }
   __syncthreads();
 
+  // this wavefront's share of the NDT terms (fixed for the whole solve)
+  TermShare T;
+  {
+    T.wpt = W.n_terms <= 3 && W.n_terms > 0 ? WIN_NDT_WAVES / W.n_terms : 1;
+    const int t = wave < WIN_NDT_WAVES ? wave / T.wpt : -1;
+    T.active = (t >= 0 && t < W.n_terms) ? 1 : 0;
+    T.k = W.k;
+    T.kmagic = W.k > 1 ? (unsigned)((0x100000000ull + (unsigned)W.k - 1) / (unsigned)W.k) : 0u;
+    T.first = 64 * (wave < WIN_NDT_WAVES ? wave % T.wpt : 0);
+    T.stride = 64 * T.wpt;
+    T.state = 0;
+    T.n_slots = 0;
+    T.mov = T.fix = nullptr;
+    T.pc = nullptr;
+    if (T.active) {
+      const int mmap = W.term_moving[t], fmap = W.term_fixed[t];
+      int M = moving.counts[mmap];
+      M = M > moving.cap ? moving.cap : M;
+      T.state = W.term_state[t];
+      T.n_slots = M * W.k;
+      T.mov = reinterpret_cast<const float4*>(moving.cells + (size_t)mmap * moving.cap);
+      T.fix = reinterpret_cast<const float4*>(fixed.cells + (size_t)fmap * fixed.cap);
+      T.pc = corr + (size_t)t * moving.cap * W.k;
+    }
+    if (lane == 0) sh.wave_state[wave] = T.active ? T.state : -1;
+  }
+  __syncthreads();
+
   // number of NDT residual blocks and of moving cells
   int n_res = 0;
   for (int t = 0; t < W.n_terms; ++t) {
@@ -598,7 +635,10 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
     double v = wave_sum((double)n_res);
     if (lane == 0) sh.red[0][wave][33] = v;
     __syncthreads();
-    n_res = (int)(sh.red[0][0][33] + sh.red[0][1][33] + sh.red[0][2][33] + sh.red[0][3][33]);
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < WIN_WAVES; ++w) tot += sh.red[0][w][33];
+    n_res = (int)tot;
     __syncthreads();
   }
   int n_cells = 0;  // sum over optimised states (ndt_matcher.cpp:367)
@@ -628,7 +668,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   double raw_max = 0.0;
   bool ok = true;
   if (n_res > 0) {
-    ok = ndt_pass<D, 0, AM2>(fixed, moving, W, corr, sh, 0, L, sh.base[0], parity, sh);
+    ok = ndt_pass<D, 0, AM2>(fixed, moving, W, T, sh, 0, L, sh.base[0], parity, sh);
     raw_max = sh.base[0][0];
     res.n_evals++;
     __syncthreads();
@@ -652,7 +692,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       bool reuse = false, step_ok = true;
       int num_invalid = 0, iteration = 0;
       double minimum_cost = DBL_MAX;
-      bool e_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, corr, sh, p, L, sh.base[p], parity, sh);
+      bool e_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, p, L, sh.base[p], parity, sh);
       WT(1);
       double fcost = factors_weight(W, sh, p);  // its barrier also publishes sh.base[p]
       WT(2);
@@ -834,7 +874,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         num_invalid = 0;
 
         // ---- candidate: factors + NDT terms with Jacobians (speculative)
-        const bool c_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, corr, sh, 1 - p, L, sh.base[1 - p], parity, sh);
+        const bool c_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, 1 - p, L, sh.base[1 - p], parity, sh);
         WT(1);
         const double cf = factors_weight(W, sh, 1 - p);
         WT(2);
