@@ -215,6 +215,7 @@ int randt_ctx_destroy(randt_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->build_ws) (void)hipFree(ctx->build_ws);
   if (ctx->small) (void)hipFree(ctx->small);
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   delete ctx;
   return RANDT_OK;
 }
@@ -1277,28 +1278,34 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
       h_idx[RANDT_WIN_MAX_TERMS + q] = h_moving_idx[j - 1];
       memcpy(h_guess + 4 * q, h_states[j].pose, sizeof(double) * 4);  // association at the state's own pose (:364)
     }
-  // workspace: corr | states | guess | idx | result
+  // workspace: corr | [ states | guess | idx | result | descriptor ]  -- the bracketed span is ONE host image, staged in
+  // pinned memory and moved with one copy per direction (five small pageable copies cost ~40 us per scan)
   const size_t corr_bytes = sizeof(int32_t) * (size_t)W.n_terms * moving->v.cap * k;
   const size_t off_states = (corr_bytes + 255) & ~(size_t)255;
   const size_t off_guess = off_states + sizeof(double) * 10 * RANDT_WIN_MAX_STATES;
   const size_t off_idx = off_guess + sizeof(h_guess);
   const size_t off_res = off_idx + sizeof(h_idx) + 64;
   const size_t off_desc = (off_res + sizeof(randt_result) + 64 + 255) & ~(size_t)255;
+  const size_t span = off_desc + sizeof(WinDesc) - off_states;
   int rc = ensure_ws(ctx, off_desc + sizeof(WinDesc) + 64);
   if (rc) return rc;
+  if (!ctx->h_pin) RANDT_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pin, 8192, hipHostMallocDefault));
+  if (span > 4096) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window staging image too large", hipSuccess);
   char* ws = (char*)ctx->ws;
-  double h_packed[10 * RANDT_WIN_MAX_STATES];
+  char* img = (char*)ctx->h_pin;           // upload image; the download lands at img + 4096
+  memset(img, 0, span);
+  double* h_packed = reinterpret_cast<double*>(img);
   for (int j = 0; j <= S; ++j) {
     double* o = h_packed + 10 * j;
     memcpy(o, h_states[j].pose, sizeof(double) * 4);
     o[4] = h_states[j].lin_vel[0]; o[5] = h_states[j].lin_vel[1]; o[6] = h_states[j].rot_vel;
     o[7] = h_states[j].lin_acc[0]; o[8] = h_states[j].lin_acc[1]; o[9] = h_states[j].imu_bias;
   }
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_states, h_packed, sizeof(double) * 10 * (S + 1), hipMemcpyHostToDevice, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_guess, h_guess, sizeof(h_guess), hipMemcpyHostToDevice, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_idx, h_idx, sizeof(h_idx), hipMemcpyHostToDevice, ctx->stream));
+  memcpy(img + (off_guess - off_states), h_guess, sizeof(h_guess));
+  memcpy(img + (off_idx - off_states), h_idx, sizeof(h_idx));
   // the window descriptor is indexed dynamically by the kernel: it lives in device memory, not in kernel arguments
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_desc, &W, sizeof(W), hipMemcpyHostToDevice, ctx->stream));
+  memcpy(img + (off_desc - off_states), &W, sizeof(W));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_states, img, span, hipMemcpyHostToDevice, ctx->stream));
   const int32_t* d_fidx = (const int32_t*)(ws + off_idx);
   const int32_t* d_midx = d_fidx + RANDT_WIN_MAX_TERMS;
   rc = launch_associate(ctx, fixed->v, d_fidx, moving->v, 0, W.n_terms, (const double*)(ws + off_guess), k, mp->lookup_mahalanobis,
@@ -1307,9 +1314,12 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   rc = launch_solve_window(ctx, fixed->v, moving->v, W, (const WinDesc*)(ws + off_desc), (const int32_t*)ws, mp, (double*)(ws + off_states), (randt_result*)(ws + off_res));
   if (rc) return rc;
   randt_result r;
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_packed, ws + off_states, sizeof(double) * 10 * (S + 1), hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&r, ws + off_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  char* back = img + 4096;
+  const size_t back_span = off_res + sizeof(randt_result) - off_states;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(back, ws + off_states, back_span, hipMemcpyDeviceToHost, ctx->stream));
   RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(&r, back + (off_res - off_states), sizeof(r));
+  h_packed = reinterpret_cast<double*>(back);
   for (int j = 0; j <= S; ++j) {
     const double* o = h_packed + 10 * j;
     memcpy(h_states[j].pose, o, sizeof(double) * 4);

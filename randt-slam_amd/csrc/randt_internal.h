@@ -29,6 +29,7 @@ struct randt_ctx {
   // scratch (grown on demand, never inside a timed region after warm-up)
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  void* h_pin = nullptr;     // 8 KB of pinned host memory: staging image of the synchronous host-level entries (one copy per direction)
   void* small = nullptr;     // 4 KB of device scratch for the synchronous host-level conveniences (lazily allocated)
   void* build_ws = nullptr;  // label scratch of k_ndt_build's fallback sort (its own buffer: callers stage points in ws)
   size_t build_ws_bytes = 0;
