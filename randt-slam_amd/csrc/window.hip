@@ -37,7 +37,7 @@ extern "C" int randt_debug_win_timing(long long* out) {
 }
 #define WT_DECL long long wt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wt_last = wall_clock64();
 #define WT(slot) do { const long long now_ = wall_clock64(); wt_acc[slot] += now_ - wt_last; wt_last = now_; } while (0)
-#define WT_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) g_randt_win_timing[i_] = wt_acc[i_]; } while (0)
+#define WT_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 13; ++i_) g_randt_win_timing[i_] = wt_acc[i_]; } while (0)
 #else
 #define WT_DECL
 #define WT(slot) do {} while (0)
@@ -139,6 +139,9 @@ __device__ void motion_factor(const double* x0, const double* x1, double raw_dt,
   se2_inv(pred, pinv);
   se2_mul(pinv, x1, E);
   se2_log(E, lg);
+#ifdef RANDT_TIMING
+  if (threadIdx.x == 64 * WIN_NDT_WAVES) atomicAdd((unsigned long long*)&g_randt_win_timing[15], (unsigned long long)wall_clock64());
+#endif
   r[0] = lg[0];
   r[1] = lg[1];
   r[2] = lg[2];
@@ -284,6 +287,9 @@ __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
   const int lane = threadIdx.x & 63;
   for (int e = lane; e < W.S * 128; e += 64) (&sh.Ju[0][0])[e] = 0.0;  // all lanes clear the Jacobian blocks
   wave_fence();
+#ifdef RANDT_TIMING
+  if (threadIdx.x == 64 * WIN_NDT_WAVES) atomicAdd((unsigned long long*)&g_randt_win_timing[15], (unsigned long long)(-wall_clock64()));
+#endif
   if (lane < W.S) {
     const int f = lane;  // factor between states f and f+1
     double r[8];
@@ -319,7 +325,13 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
                          const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool factor_wave = MODE == 1 && wave == WIN_NDT_WAVES;
+#ifdef RANDT_TIMING
+  const long long wt_t0 = wall_clock64();
+#endif
   if (factor_wave) factors_unweighted(W, shw, buf);
+#ifdef RANDT_TIMING
+  if (factor_wave && lane == 0) atomicAdd((unsigned long long*)&g_randt_win_timing[13], (unsigned long long)(wall_clock64() - wt_t0));
+#endif
   // Six NDT wavefronts share the <= 6 terms: with 1 / 2 / 3 terms every term is split over 6 / 3 / 2 wavefronts (a
   // wavefront takes every wpt-th 64-slot trip of its term), otherwise one wavefront per term.  Each wavefront reduces its
   // own ten base sums; the per-state combine below adds the parts in wavefront order.
@@ -362,6 +374,9 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
       }
     }
   }
+#ifdef RANDT_TIMING
+  if (MODE == 1 && wave == 0 && lane == 0) atomicAdd((unsigned long long*)&g_randt_win_timing[14], (unsigned long long)(wall_clock64() - wt_t0));
+#endif
   double badf = wave_any(bad != 0);
   if (MODE == 0) mx = wave_max(mx);
   if (lane == 0) {
@@ -716,68 +731,68 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       trace_push(tr, trace_len, cost, radius, 0);
 
       for (;;) {
-        // ---- (wave 0) Jacobi scaling of the freshly assembled system, gradient test
-        if (need_scale) {
-          if (wave == 0) {
-            if (first) {  // later assemblies of this solve write Hs / gs themselves
-              if (lane < n) sh.sigma[lane] = 1.0 / (1.0 + sqrt(sh.H[lane * n + lane]));
-              wave_fence();
-              // all 64 lanes over the n^2 entries; (row, column) of entry e advance incrementally (no division)
-              int ei = ent_i0, ej = ent_j0;
-              for (int e = lane; e < n * n; e += 64) {
-                sh.Hs[e] = sh.H[e] * sh.sigma[ei] * sh.sigma[ej];
-                ei += ent_di;
-                ej += ent_dj;
-                if (ej >= n) {
-                  ej -= n;
-                  ++ei;
-                }
+        // ---- Two wavefronts share the serial part of an iteration.  Wavefront 0: Jacobi scaling (first assembly of a solve
+        // only; later assemblies write Hs / gs themselves), the damped solve, Plus and the step norm.  Wavefront 1, at the
+        // same time: the gradient test and ||x|| of a freshly accepted point, then -- once the step is published --
+        // the model cost change.  The gradient / radius stopping tests are therefore evaluated AFTER the solve has been
+        // started (their operands arrive with the barrier that publishes the step); a stop discards that work and takes
+        // back the iteration count, so the decision sequence is the reference's (max iterations, gradient, radius).
+        if (need_scale && wave == 1) {
+          // gradient tolerance: ||x - Plus(x, -g)||_inf <= gtol
+          double gm = lane < n ? fabs(sh.g[lane]) : 0.0;
+          gm = wave_max(gm);
+          double gconv = 0.0;
+          // the displacement of Plus(x, -g) is >= 0.4 max|g_i| (|omega| <= pi): exact test only for tiny gradients
+          if (uni(!(0.4 * gm > P.gtol && gm < 3.0))) {
+            plus_states(W, sh, p, 1 - p, sh.g, -1.0, lane);  // the candidate buffer is dead until the step below is taken
+            wave_fence();
+            double m = 0.0;
+            if (lane <= S) {
+              for (int e = 0; e < ST_STRIDE; ++e) {
+                const double d = fabs(sh.xs[p][lane][e] - sh.xs[1 - p][lane][e]);
+                m = d > m ? d : m;
               }
-              if (lane < n) sh.gs[lane] = sh.g[lane] * sh.sigma[lane];
             }
-            // gradient tolerance: ||x - Plus(x, -g)||_inf <= gtol
-            double gm = lane < n ? fabs(sh.g[lane]) : 0.0;
-            gm = wave_max(gm);
-            double gconv = 0.0;
-            // the displacement of Plus(x, -g) is >= 0.4 max|g_i| (|omega| <= pi): exact test only for tiny gradients
-            if (uni(!(0.4 * gm > P.gtol && gm < 3.0))) {
-              wave_fence();
-              plus_states(W, sh, p, 1 - p, sh.g, -1.0, lane);
-              wave_fence();
-              double m = 0.0;
-              if (lane <= S) {
-                for (int e = 0; e < ST_STRIDE; ++e) {
-                  const double d = fabs(sh.xs[p][lane][e] - sh.xs[1 - p][lane][e]);
-                  m = d > m ? d : m;
-                }
-              }
-              m = wave_max(m);
-              gconv = m <= P.gtol ? 1.0 : 0.0;
-            }
-            const double xn = ambient_sq(W, sh, p, -1, lane);
-            if (lane == 0) {
-              sh.scal[4] = gconv;
-              sh.scal[2] = sqrt(xn);
+            m = wave_max(m);
+            gconv = m <= P.gtol ? 1.0 : 0.0;
+          }
+          const double xn = ambient_sq(W, sh, p, -1, lane);
+          if (lane == 0) {
+            sh.scal[4] = gconv;
+            sh.scal[2] = sqrt(xn);
+          }
+        }
+        if (need_scale && first && wave == 0) {
+          if (lane < n) sh.sigma[lane] = 1.0 / (1.0 + sqrt(sh.H[lane * n + lane]));
+          wave_fence();
+          // all 64 lanes over the n^2 entries; (row, column) of entry e advance incrementally (no division)
+          int ei = ent_i0, ej = ent_j0;
+          for (int e = lane; e < n * n; e += 64) {
+            sh.Hs[e] = sh.H[e] * sh.sigma[ei] * sh.sigma[ej];
+            ei += ent_di;
+            ej += ent_dj;
+            if (ej >= n) {
+              ej -= n;
+              ++ei;
             }
           }
-          __syncthreads();
-          x_norm = sh.scal[2];
+          if (lane < n) sh.gs[lane] = sh.g[lane] * sh.sigma[lane];
+          wave_fence();
+        }
+        if (need_scale) {
           need_scale = false;
           first = false;
           WT(4);
         }
-        const bool gconv = uni(sh.scal[4] != 0.0);
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
         // (Ceres copies x to the user parameters after successful steps that lower the minimum cost;
         //  accepted steps are monotone here, so the current buffer p always is that point.)
         if (step_ok && uni(cost < minimum_cost)) minimum_cost = cost;
         if (iteration >= P.max_it) { term = RANDT_TERM_NO_CONVERGENCE; break; }
-        if (step_ok && gconv) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
-        if (uni(radius <= P.rmin)) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
         ++iteration;
         res.iterations++;
 
-        // ---- (wave 0) LevenbergMarquardtStrategy::ComputeStep: damped normal equations, LDL^T in LDS
+        // ---- (wave 0) LevenbergMarquardtStrategy::ComputeStep: damped normal equations
         if (wave == 0) {
           if (!reuse && lane < n) sh.diag[lane] = fmin(fmax(sh.Hs[lane * n + lane], P.dmin), P.dmax);
           wave_fence();
@@ -822,38 +837,40 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
             RANDT_GJ_STEPS(8)
             RANDT_GJ_STEPS(4)
 #undef RANDT_GJ_STEPS
-            if (lane < n) sh.step[lane] = b * fast_rcp(dg);
+            // scaled step (negated: Ceres solves for -step), its finiteness, the unscaled delta
+            const double st = lane < n ? -(b * fast_rcp(dg)) : 0.0;
+            const double fin = 1.0 - wave_any(!isfinite(st));
+            if (lane < n) {
+              sh.step[lane] = st;
+              sh.delta[lane] = st * sh.sigma[lane];
+            }
+            if (lane == 0) sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
           }
-          wave_fence();
           WT(9);
-          double fin = 1.0;
-          if (lane < n) {
-            if (!isfinite(sh.step[lane])) fin = 0.0;
-            sh.step[lane] = -sh.step[lane];
-          }
-          fin = 1.0 - wave_any(fin == 0.0);
-          wave_fence();
+        }
+        __syncthreads();  // publishes: step / delta / scal[3] (wave 0), gradient test and ||x|| (wave 1), Hs / gs of a first assembly
+        x_norm = sh.scal[2];
+        if (step_ok && uni(sh.scal[4] != 0.0)) { res.iterations--; term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
+        if (uni(radius <= P.rmin)) { res.iterations--; term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
+        if (wave == 1) {
           // model_cost_change = -(step.gs + step^T Hs step / 2)
           double t = 0.0;
           if (lane < n) {
             double hs = 0.0;
+#pragma unroll 8
             for (int b = 0; b < n; ++b) hs += sh.Hs[b * n + lane] * sh.step[b];  // symmetric: column read, conflict-free
             t = sh.step[lane] * (sh.gs[lane] + 0.5 * hs);
-            sh.delta[lane] = sh.step[lane] * sh.sigma[lane];
           }
           const double mcc = -wave_sum(t);
-          wave_fence();
+          if (lane == 0) sh.scal[0] = mcc;
+        } else if (wave == 0) {
           WT(10);
           plus_states(W, sh, p, 1 - p, sh.delta, 1.0, lane);
           wave_fence();
           WT(11);
           const double sn2 = ambient_sq(W, sh, p, 1 - p, lane);
           WT(12);
-          if (lane == 0) {
-            sh.scal[0] = mcc;
-            sh.scal[1] = sn2;
-            sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
-          }
+          if (lane == 0) sh.scal[1] = sn2;
         }
         __syncthreads();
         WT(5);

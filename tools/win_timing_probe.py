@@ -13,8 +13,9 @@ odo = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor
 names = ["setup+raw", "ndt_pass(+factors)", "factors_weight", "assemble", "scale/grad", "LM rest+barrier", "decide", "tail", "LM:buildA", "LM:eliminate", "LM:mcc", "LM:plus", "LM:ambient"]
 for i in range(40):
     odo.process_scan(d[i], i * dt)
-    if i in (10, 20, 39):
+    if i in (20, 38, 39):
         out = (C.c_longlong * 16)()
         lib.randt_debug_win_timing(out)
         t = np.array(out[:13]) * 0.01
+        print("   cumulative over all scans so far (take deltas): factor wavefront %.1f us (of it exp..log chain %.1f us), NDT wavefront 0 %.1f us" % (out[13] * 0.01, out[15] * 0.01, out[14] * 0.01))
         print("scan", i, "iters", int(odo.last_result["iterations"]), "total %.1f us" % t.sum(), {n: round(v, 1) for n, v in zip(names, t)})
