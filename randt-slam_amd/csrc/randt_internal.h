@@ -123,7 +123,7 @@ int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_id
 
 int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az, int n_bins, int stride, int ioff,
                        const randt_filter_params* fp, float* d_out_pts, int pitch_out, int32_t* d_out_counts, float* d_polar,
-                       float* d_peaks, int32_t* d_peak_counts, int32_t* d_status, void* d_scratch);
+                       float* d_peaks, int32_t* d_peak_counts, int32_t* d_status, void* d_scratch /* n_scans * n_az * 32 B */);
 
 int launch_cs_divergence(randt_ctx* ctx, const MapView& fixed, int fixed_first, int fixed_count, const int32_t* d_fixed_idx,
                          const MapView& moving, int moving_first, int n_pairs, const double* d_pose4, double* d_partial,
