@@ -25,7 +25,7 @@
 // Measured alternatives (16 scans per launch, 307 MB): emission fused into the row kernel behind a device-scope ticket
 // 130 us (every row workgroup then ends with a store acknowledgement and a returning atomic under full read load);
 // a second register set holding the workgroup's next row (191 registers, two workgroups per CU) 93 us; this version
-// (128 registers, four per CU) 72 us; squeezed to 96 / 80 registers by the compiler (spills) 84 / 104 us.
+// (128 registers, four per CU) 72 us; the same with non-temporal row loads (the run expansion then misses L2) 100 us; squeezed to 96 / 80 registers by the compiler (spills) 84 / 104 us.
 #include "randt_internal.h"
 
 #include <math.h>
