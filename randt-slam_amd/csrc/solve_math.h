@@ -219,8 +219,10 @@ __device__ __forceinline__ void accumulate_residual(const Loss& L, double sq, co
 // ---------------------------------------------------------------- reductions -------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  // every control used here is a full permutation inside a row, so all lanes are written: no "old" value to set up
+  // (update_dpp with old = 0 costs a v_mov per half in front of every DPP move)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_f64(double v, int l) {
