@@ -114,3 +114,69 @@ def test_hip_filter_flags_unorganised_input(built):
     host.filter_scan_batch(ctx, torch.from_numpy(raw[None]).to(dev), host.filter_params(), out, counts, status)
     ctx.synchronize()
     assert status.item() == 1                              # loud, never a silently different result
+
+
+def _run_hip_filter(ctx, dev, scans, fp, intensity_index=None, pitch=4096):
+    import torch
+
+    n_scans, n_az = scans.shape[:2]
+    out = torch.zeros((n_scans, pitch, 4), dtype=torch.float32, device=dev)
+    polar = torch.zeros((n_scans, pitch, 2), dtype=torch.float32, device=dev)
+    peaks = torch.zeros((n_scans, n_az, 3), dtype=torch.float32, device=dev)
+    counts = torch.zeros(n_scans, dtype=torch.int32, device=dev)
+    pcounts = torch.zeros(n_scans, dtype=torch.int32, device=dev)
+    status = torch.zeros(n_scans, dtype=torch.int32, device=dev)
+    host.filter_scan_batch(ctx, torch.from_numpy(scans).to(dev), fp, out, counts, status, polar, peaks, pcounts,
+                           intensity_index=intensity_index)
+    ctx.synchronize()
+    return out.cpu().numpy(), polar.cpu().numpy(), peaks.cpu().numpy(), counts.cpu().numpy(), pcounts.cpu().numpy(), status.cpu().numpy()
+
+
+def _check_against_oracle(res, scans_xyzi, ofp):
+    out, polar, peaks, counts, pcounts, status = res
+    assert status.tolist() == [0] * len(scans_xyzi)
+    for s in range(len(scans_xyzi)):
+        cnt, pts, pol, pk = po.filter_scan(scans_xyzi[s].reshape(-1, 4), ofp)
+        assert counts[s] == cnt and pcounts[s] == len(pk), s
+        assert np.array_equal(out[s, :cnt].view(np.uint32), pts.view(np.uint32)), s
+        assert np.array_equal(polar[s, :cnt, 1], pol[:, 1]), s
+        g = peaks[s, :len(pk)]
+        assert np.array_equal(g[:, 1:], pk[:, 1:]) and np.allclose(g[:, 0], pk[:, 0], atol=1e-6), s
+
+
+@pytest.mark.gpu
+def test_hip_filter_many_scans_several_rows_per_workgroup(built):
+    """More azimuth rows in one launch than row workgroups fit on the chip: every workgroup walks several rows
+    (the launcher sizes the grid by occupancy), and the per-scan emission still sees every row record."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    n_scans = 150                                           # x 12 rows = 1800 rows > 4 workgroups x 256 CUs
+    scans = np.stack([small_polar(100 + s, empty_rows=((0,) if s % 7 == 0 else (5, 6) if s % 5 == 0 else ()))[0]
+                      for s in range(n_scans)])
+    res = _run_hip_filter(ctx, dev, scans, host.filter_params())
+    _check_against_oracle(res, scans, po.filter_params())
+    # the same batch again through the same context: nothing carried over between launches
+    res2 = _run_hip_filter(ctx, dev, scans, host.filter_params())
+    assert all(np.array_equal(a, b) for a, b in zip(res, res2))
+
+
+@pytest.mark.gpu
+def test_hip_filter_pcl_stride_and_long_rows(built):
+    """The two row-kernel paths beside the packed one-shot fetch: (a) PCL's 32-byte PointXYZI layout (8 floats, intensity at
+    float 4); (b) packed rows longer than 12 x 256 bins (streamed in the loop)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    scans = np.stack([small_polar(300 + s)[0] for s in range(3)])            # (3, 12, 80, 4) x y z I
+    pcl = np.zeros(scans.shape[:3] + (8,), dtype=np.float32)
+    pcl[..., :3] = scans[..., :3]
+    pcl[..., 3] = 1.0                                                        # PCL's padding float
+    pcl[..., 4] = scans[..., 3]
+    res = _run_hip_filter(ctx, dev, pcl, host.filter_params(), intensity_index=4)
+    _check_against_oracle(res, scans, po.filter_params())
+    long_rows = np.stack([small_polar(400 + s, n_az=6, n_bins=3500)[0] for s in range(2)])
+    res = _run_hip_filter(ctx, dev, long_rows, host.filter_params(), pitch=8192)
+    _check_against_oracle(res, long_rows, po.filter_params())
