@@ -105,6 +105,7 @@ struct Stage {
   const int* corr;        // [M*k] compact fixed index or -1
   const unsigned* pairs;  // LDS: compacted valid correspondences, or nullptr (then the raw slots are walked)
   int n_pairs;
+  int pack16;             // pairs hold (3 * moving index) << 16 | 3 * fixed index (both record offsets in float4 units < 2^16)
   int n_slots, k, fixed_cap;
   unsigned kmagic;        // ceil(2^32 / k): slot / k == umulhi(slot, kmagic) for slot < 2^32 / k (k >= 2)
 };
@@ -135,20 +136,29 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   for (int i = 0; i < 10; ++i) acc[i] = 0.0;
   double mx = -DBL_MAX;
   int bad = 0;
-  // one residual; mi / ci = moving / fixed compact cell index
-  auto one = [&](unsigned mi, unsigned ci) {
-    const float4* mv = S.mov + (size_t)mi * 3;
-    const float4* fv = S.fix + (size_t)ci * 3;
+  // one residual; mv / fv = moving / fixed cell record
+  auto one_rec = [&](const float4* mv, const float4* fv) {
     double jb[3];
     const double sq = residual_sq<D, MODE == 1>(mv, fv, rot, tx, ty, jb);
-    if (!isfinite(sq)) bad = 1;
+    // closed-form loss: a non-finite residual makes the cost sum non-finite (u or 1 / (u^2 s) is NaN / 0 x inf), which the
+    // caller tests after the reduction -- no per-residual class test in the hot loop
+    if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
     if (MODE == 0) {
       mx = sq > mx ? sq : mx;
     } else {
       accumulate_residual<AM2>(L, sq, jb, acc);
     }
   };
-  if (S.n_pairs > 0) {  // scalar: the dense list in LDS
+  auto one = [&](unsigned mi, unsigned ci) { one_rec(S.mov + (size_t)mi * 3, S.fix + (size_t)ci * 3); };
+  if (S.n_pairs > 0 && S.pack16) {  // scalar: the dense list in LDS, record BYTE offsets two shifts / masks away
+    // (32-bit offsets against the uniform table bases: the loads take the scalar-base addressing form, no 64-bit adds)
+    const char* mb = reinterpret_cast<const char*>(S.mov);
+    const char* fb = reinterpret_cast<const char*>(S.fix);
+    for (int e = tid; e < S.n_pairs; e += BLOCK) {
+      const unsigned u = S.pairs[e];
+      one_rec(reinterpret_cast<const float4*>(mb + ((u >> 12) & 0xffff0u)), reinterpret_cast<const float4*>(fb + ((u << 4) & 0xffff0u)));
+    }
+  } else if (S.n_pairs > 0) {
     for (int e = tid; e < S.n_pairs; e += BLOCK) {
       const unsigned u = S.pairs[e];
       one(u >> PAIR_SHIFT, u & PAIR_MASK);
@@ -384,14 +394,23 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
   M = M > moving.cap ? moving.cap : M;
 
   Stage S;
-  S.mov = reinterpret_cast<const float4*>(moving.cells + (size_t)mmap * moving.cap);
-  S.fix = reinterpret_cast<const float4*>(fixed.cells + (size_t)fmap * fixed.cap);
+  {
+    // the table bases are the same in every lane of the wavefront: say so (scalar element offsets from the kernel-argument
+    // pointers, which keeps them global-address-space pointers), so that record loads can use base + 32-bit offset addressing
+    auto uniform_off = [](size_t v) {
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+      return (size_t)(((unsigned long long)hi << 32) | lo);
+    };
+    S.mov = reinterpret_cast<const float4*>(moving.cells + uniform_off((size_t)mmap * moving.cap));
+    S.fix = reinterpret_cast<const float4*>(fixed.cells + uniform_off((size_t)fmap * fixed.cap));
+  }
   S.corr = corr + (size_t)pair * moving.cap * k;
   S.n_slots = M * k;
   S.k = k;
   S.fixed_cap = fixed.cap;
   S.pairs = nullptr;
   S.n_pairs = 0;
+  S.pack16 = (3 * fixed.cap <= 65536 && 3 * M <= 65536) ? 1 : 0;
   S.kmagic = k > 1 ? (unsigned)((0x100000000ull + (unsigned)k - 1) / (unsigned)k) : 0u;
 
   // number of residual blocks (addNDTFactor, ndt_matcher.cpp:217-246)
@@ -425,7 +444,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
         if (valid) {
           const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
           const unsigned mi = k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, S.kmagic);
-          s_pairs[n_out + rank] = (mi << PAIR_SHIFT) | (unsigned)cr;
+          s_pairs[n_out + rank] = S.pack16 ? ((3u * mi) << 16) | (3u * (unsigned)cr) : (mi << PAIR_SHIFT) | (unsigned)cr;
         }
         n_out += __popcll(mask);
       }

@@ -361,7 +361,9 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
         const float4* fv = fix + (size_t)ci * 3;
         double jb[3];
         const double sq = residual_sq<D, MODE == 1>(mv, fv, rot, tx, ty, jb);
-        if (!isfinite(sq)) bad = 1;
+        // closed-form loss: a non-finite residual makes the cost sum non-finite (u or 1 / (u^2 s) is NaN / 0 x inf), which the
+        // caller tests after the reduction -- no per-residual class test in the hot loop
+        if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
         if (MODE == 0) mx = sq > mx ? sq : mx;
         else accumulate_residual<AM2>(L, sq, jb, a10);
       }
