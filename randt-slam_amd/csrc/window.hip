@@ -261,12 +261,62 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+
+// ---------------------------------------------------------------- banded block elimination ------
+// The damped normal equations of the window are BLOCK TRIDIAGONAL in the state order (motion / IMU factors couple
+// neighbouring states only, NDT terms are unary).  With every state's tangent block padded to 8 rows, block step b works on
+// the 16 x 16 band [state b, state b + 1] inside ONE 16-lane DPP row (lane = row, register = column): the pivot row is
+// broadcast by the DPP row_newbcast modifier of v_fmac_f64 itself (the only DPP control the 64-bit ALU accepts on
+// gfx90a+), so an update costs ONE instruction instead of two v_readlane + one FMA.  DPP row b of the wavefront holds block
+// step b (all four load their originals at once); the Schur-updated rows of state b + 1 move on through LDS.
+template <int L>
+__device__ __forceinline__ double bcast16(double v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + L, 0xf, 0xf, true);  // v_mov_b64_dpp row_newbcast:L
+}
+// d += (lane L of d's 16-lane row) * m.  Hazard (VALU write of the DPP source within 2 wait states) is the caller's: the
+// updates of one pivot step write distinct registers, an s_nop leads each step.
+template <int L>
+__device__ __forceinline__ void fmac_bcast(double& d, double m) {
+  asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(m), "n"(L));
+}
+// Gauss-Jordan step on pivot JJ of the band's first block: every other lane of the row (rows above, below and of the next
+// state) subtracts its multiple of the pivot row from columns JJ+1 .. W-1 and the right-hand side.
+template <int JJ, int W>
+__device__ __forceinline__ void band_pivot(double (&C)[16], double& B, double& RD, int l) {
+  const double rpb = fast_rcp(bcast16<JJ>(C[JJ]));
+  const bool me = l == JJ;
+  RD = me ? rpb : RD;
+  const double cm = me ? 0.0 : C[JJ];
+  const double nf = -(cm * rpb);
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int k = JJ + 1; k < W; ++k) fmac_bcast<JJ>(C[k], nf);
+  fmac_bcast<JJ>(B, nf);
+}
+template <int W>
+__device__ __forceinline__ void band_block(double (&C)[16], double& B, double& RD, int l) {
+  band_pivot<0, W>(C, B, RD, l);
+  band_pivot<1, W>(C, B, RD, l);
+  band_pivot<2, W>(C, B, RD, l);
+  band_pivot<3, W>(C, B, RD, l);
+  band_pivot<4, W>(C, B, RD, l);
+  band_pivot<5, W>(C, B, RD, l);
+  band_pivot<6, W>(C, B, RD, l);
+  band_pivot<7, W>(C, B, RD, l);
+}
+
 struct Shared {
   double xs[2][WIN_SMAX + 1][ST_STRIDE];  // states: buffer p = current, 1-p = candidate
-  double Ju[WIN_SMAX][128];               // unweighted motion Jacobians (scratch)
-  double ru[WIN_SMAX][8];
-  double Jf[2][WIN_SMAX][128];            // weighted motion Jacobians at current / candidate
+  double Ju[2][WIN_SMAX][128];            // unweighted motion Jacobians at current / candidate (zeroed ONCE: a factor always
+                                          // writes the same entries)
+  double ru[2][WIN_SMAX][8];
+  double Jf[2][WIN_SMAX][128];            // weighted motion Jacobians (only when the square-root information is not diagonal)
   double rf[2][WIN_SMAX][8];
+  double fc[2][WIN_SMAX];                 // 1/2 |weighted residual|^2 of factor f (diagonal case: summed by the factor's own lane)
+  unsigned short tri[WIN_NMAX * (WIN_NMAX + 1) / 2];  // upper-triangle entry e -> a | b << 8 (a <= b)
+  int sw_first[WIN_SMAX + 1], sw_cnt[WIN_SMAX + 1];   // wavefronts that stream the NDT terms of state j: [first, first + cnt)
+  double d2[8];                           // squared diagonal of the square-root information
+  int sq_diag;                            // it IS diagonal (shipped configurations): weighting folded into the assembly
   double J2[2][WIN_SMAX][16];             // IMU factors
   double r2[2][WIN_SMAX][2];
   double H[WIN_NMAX * WIN_NMAX];
@@ -275,33 +325,43 @@ struct Shared {
   double g[WIN_NMAX], gs[WIN_NMAX], sigma[WIN_NMAX], diag[WIN_NMAX], step[WIN_NMAX], delta[WIN_NMAX], col[WIN_NMAX];
   double red[2][WIN_WAVES][34];
   double scal[8];  // 0 mcc, 1 sn2, 2 x_norm, 3 solved, 4 gconv
-  double base[2][WIN_SMAX * 10];  // NDT base sums at current / candidate point (uniform values)
   int lcol[WIN_SMAX][WIN_NMAX];   // tangent column -> local column of motion factor f (-1 none)
   int lcol2[WIN_SMAX][WIN_NMAX];  // ... of IMU factor f
   int pose_of[WIN_NMAX];          // tangent column -> state whose pose block holds it (-1 none)
   int wave_state[WIN_WAVES];      // state of the NDT term wavefront w streams (-1: none)
+  // banded block solve (band_solve below): per-lane LDS byte offsets of the 16 band columns + right-hand side, the lane's
+  // tangent row (-1: padding), damped diagonal, constants 0 / 1 for padding entries, hand-over buffers between block steps
+  int boff[18][64];
+  double dd[WIN_NMAX];
+  double cst[2];
+  double xfer[8][10];
+  double xsol[8];
+  int band_ok;
 };
 
 // Unweighted motion / IMU factors at xs[buf], one lane per factor (called by ONE wavefront).
 __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
   const int lane = threadIdx.x & 63;
-  for (int e = lane; e < W.S * 128; e += 64) (&sh.Ju[0][0])[e] = 0.0;  // all lanes clear the Jacobian blocks
-  wave_fence();
 #ifdef RANDT_TIMING
   if (threadIdx.x == 64 * WIN_NDT_WAVES) atomicAdd((unsigned long long*)&g_randt_win_timing[15], (unsigned long long)(-wall_clock64()));
 #endif
   if (lane < W.S) {
     const int f = lane;  // factor between states f and f+1
     double r[8];
-    motion_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], r, sh.Ju[f]);
+    motion_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], r, sh.Ju[buf][f]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sh.ru[f][i] = r[i];
+    for (int i = 0; i < 8; ++i) sh.ru[buf][f][i] = r[i];
+    double c = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c += 0.5 * sh.d2[i] * (r[i] * r[i]);
     if (W.use_imu) {
       double r2[2];
       imu_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], W.imu[f], W.w_imu, W.w_bias, r2, sh.J2[buf][f]);
       sh.r2[buf][f][0] = r2[0];
       sh.r2[buf][f][1] = r2[1];
+      c += 0.5 * r2[0] * r2[0] + 0.5 * r2[1] * r2[1];
     }
+    sh.fc[buf][f] = c;
   }
 }
 
@@ -316,13 +376,21 @@ struct TermShare {
   int wpt;
 };
 
+// Base sum i of state jj from the per-wavefront partial sums of a pass (wavefront order: fixed association).
+__device__ __forceinline__ double state_sum(const Shared& sh, const double* r, int jj, int i) {
+  double a = 0.0;
+  const int w0 = sh.sw_first[jj], w1 = w0 + sh.sw_cnt[jj];
+  for (int w = w0; w < w1; ++w) a += r[w * 10 + i];
+  return a;
+}
+
 // NDT pass over every term at the states in xs[buf].  MODE 0: max raw residual -> out[0];
-// MODE 1: ten base sums per state -> out[(j-1)*10 ..].
+// MODE 1: ten base sums per wavefront -> rsum[w * 10 ..] (state_sum() combines them per state).
 // In MODE 1 wavefront 6 evaluates the motion / IMU factors of the same point while wavefronts 0-5
 // stream the NDT slots (the factors are a ~2000-instruction serial chain: hidden behind the pass).
 template <int D, int MODE, bool AM2>
 __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const TermShare& T,
-                         const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw) {
+                         const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw, const double*& rsum) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool factor_wave = MODE == 1 && wave == WIN_NDT_WAVES;
 #ifdef RANDT_TIMING
@@ -336,6 +404,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
   // wavefront takes every wpt-th 64-slot trip of its term), otherwise one wavefront per term.  Each wavefront reduces its
   // own ten base sums; the per-state combine below adds the parts in wavefront order.
   double* r = shw.red[parity][0];  // [8 wavefronts][10] | [96 + wave] bad | [104 + wave] max
+  rsum = r;
   parity ^= 1;
   double mx = -DBL_MAX;
   int bad = 0;
@@ -395,39 +464,36 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
     __syncthreads();
     return uni(badf == 0.0);
   }
-  // per-state sums in term order, one thread per sum; published by the caller's next barrier
-  if (threadIdx.x < WIN_SMAX * 10) {
-    const int jj = (int)threadIdx.x / 10 + 1, i = (int)threadIdx.x % 10;
-    double a = 0.0;
-    for (int w = 0; w < WIN_NDT_WAVES; ++w)
-      if (sh.wave_state[w] == jj) a += r[w * 10 + i];
-    out[threadIdx.x] = a;
-  }
   return uni(badf == 0.0);
 }
 
 // Weighting half of the factor evaluation (the unweighted residuals / Jacobians were produced by
-// factors_unweighted on wavefront 3 during the NDT pass, whose barrier published them):
-// residuals_map.applyOnTheLeft(sqrtI_), one thread per entry.  Returns sum of 1/2 r^2 over the
-// factor residuals (identical in every thread).  One barrier.
+// factors_unweighted on the factor wavefront during the NDT pass, whose barrier published them):
+// residuals_map.applyOnTheLeft(sqrtI_).  Returns sum of 1/2 r^2 over the factor residuals (identical in every thread).
+// Diagonal square-root information (every shipped configuration): nothing is materialised -- the assembly applies
+// d_i^2 itself -- and there is no barrier; otherwise one thread per entry forms sqrtI * J, one barrier.
 __device__ double factors_weight(const WinDesc& W, Shared& sh, int buf) {
   const int tid = threadIdx.x;
+  double cost = 0.0;
+  if (sh.sq_diag) {
+    for (int f = 0; f < W.S; ++f) cost += sh.fc[buf][f];
+    return cost;
+  }
   for (int e = tid; e < W.S * 128; e += WIN_BLOCK) {
     const int f = e >> 7, i = (e & 127) >> 4, c = e & 15;
     double a = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a += W.sqrtI[i * 8 + k] * sh.Ju[f][k * 16 + c];
+    for (int k = 0; k < 8; ++k) a += W.sqrtI[i * 8 + k] * sh.Ju[buf][f][k * 16 + c];
     sh.Jf[buf][f][i * 16 + c] = a;
   }
   if (tid < W.S * 8) {
     const int f = tid >> 3, i = tid & 7;
     double a = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a += W.sqrtI[i * 8 + k] * sh.ru[f][k];
+    for (int k = 0; k < 8; ++k) a += W.sqrtI[i * 8 + k] * sh.ru[buf][f][k];
     sh.rf[buf][f][i] = a;
   }
   __syncthreads();
-  double cost = 0.0;
   for (int f = 0; f < W.S; ++f) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) cost += 0.5 * sh.rf[buf][f][i] * sh.rf[buf][f][i];
@@ -450,16 +516,26 @@ __device__ __forceinline__ void pose_T(const double* xp, double T[3][3]) {
 // J^T J and J^T r at xs[buf] from the factor blocks in LDS and the per-state NDT base sums.
 // have_sigma: the Jacobi scaling of this solve is known (every assembly but the first of a solve): the scaled copies
 // Hs / gs are written in the same pass instead of by wavefront 0 afterwards.
-__device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* base /* S*10 */, bool have_sigma) {
+__device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* rsum /* per-wavefront base sums of the pass */,
+                         bool have_sigma) {
   const int n = W.n_tan, tid = threadIdx.x;
-  for (int e = tid; e < n * n; e += WIN_BLOCK) {
-    const int a = e / n, b = e % n;
+  const bool dg = sh.sq_diag != 0;
+  const double(*J)[128] = dg ? sh.Ju[buf] : sh.Jf[buf];
+  const double(*rr)[8] = dg ? sh.ru[buf] : sh.rf[buf];
+  // upper triangle only (n (n + 1) / 2 <= 528 entries: one round), mirrored on the way out
+  for (int e = tid; e < n * (n + 1) / 2; e += WIN_BLOCK) {
+    const int ab = sh.tri[e], a = ab & 255, b = ab >> 8;
     double h = 0.0;
     for (int f = 0; f < W.S; ++f) {
       const int la = sh.lcol[f][a], lb = sh.lcol[f][b];
       if (la >= 0 && lb >= 0) {
+        if (dg) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h += sh.Jf[buf][f][i * 16 + la] * sh.Jf[buf][f][i * 16 + lb];
+          for (int i = 0; i < 8; ++i) h += sh.d2[i] * (J[f][i * 16 + la] * J[f][i * 16 + lb]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) h += J[f][i * 16 + la] * J[f][i * 16 + lb];
+        }
       }
       if (W.use_imu) {
         const int ma = sh.lcol2[f][a], mb = sh.lcol2[f][b];
@@ -470,7 +546,9 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* ba
     if (j >= 0 && sh.pose_of[b] == j) {
       double T[3][3];
       pose_T(sh.xs[buf][j], T);
-      const double* B = base + (j - 1) * 10;
+      double B[10];
+#pragma unroll
+      for (int i = 4; i < 10; ++i) B[i] = state_sum(sh, rsum, j, i);
       const double G[3][3] = {{B[4], B[5], B[6]}, {B[5], B[7], B[8]}, {B[6], B[8], B[9]}};
       const int ia = a - W.off_tan[j][0], ib = b - W.off_tan[j][0];
       double v = 0.0;
@@ -481,16 +559,26 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* ba
       h += v;
     }
     sh.H[a * n + b] = h;
-    if (have_sigma) sh.Hs[a * n + b] = h * sh.sigma[a] * sh.sigma[b];
+    sh.H[b * n + a] = h;
+    if (have_sigma) {
+      const double hs = h * sh.sigma[a] * sh.sigma[b];
+      sh.Hs[a * n + b] = hs;
+      sh.Hs[b * n + a] = hs;
+    }
   }
-  if (tid < n) {
-    const int a = tid;
+  if (tid >= WIN_BLOCK - n) {  // the gradient on the block's last threads (idle above unless n = 32)
+    const int a = tid - (WIN_BLOCK - n);
     double g = 0.0;
     for (int f = 0; f < W.S; ++f) {
       const int la = sh.lcol[f][a];
       if (la >= 0) {
+        if (dg) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g += sh.Jf[buf][f][i * 16 + la] * sh.rf[buf][f][i];
+          for (int i = 0; i < 8; ++i) g += sh.d2[i] * (J[f][i * 16 + la] * rr[f][i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) g += J[f][i * 16 + la] * rr[f][i];
+        }
       }
       if (W.use_imu) {
         const int ma = sh.lcol2[f][a];
@@ -501,9 +589,8 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* ba
     if (j >= 0) {
       double T[3][3];
       pose_T(sh.xs[buf][j], T);
-      const double* B = base + (j - 1) * 10;
       const int ia = a - W.off_tan[j][0];
-      g += T[ia][0] * B[1] + T[ia][1] * B[2] + T[ia][2] * B[3];
+      g += T[ia][0] * state_sum(sh, rsum, j, 1) + T[ia][1] * state_sum(sh, rsum, j, 2) + T[ia][2] * state_sum(sh, rsum, j, 3);
     }
     sh.g[a] = g;
     if (have_sigma) sh.gs[a] = g * sh.sigma[a];
@@ -607,6 +694,53 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       if (W.off_tan[j][0] >= 0)
         for (int e = 0; e < 3; ++e) sh.pose_of[W.off_tan[j][0] + e] = j;
   }
+  if (tid < 64) {
+    // band layout of the block solve: DPP row br = block step br, lane l of it = row l of the band [state br, state br + 1]
+    auto bstart = [&](int j) { return j > S ? n : (W.off_tan[j][0] >= 0 ? W.off_tan[j][0] : W.off_tan[j][1]); };
+    auto tix = [&](int blk, int m) {
+      if (blk > S) return -1;
+      const int st = bstart(blk);
+      return m < bstart(blk + 1) - st ? st + m : -1;
+    };
+    auto off_of = [&](const double* q) { return (int)(reinterpret_cast<const char*>(q) - reinterpret_cast<const char*>(&sh)); };
+    const int br = tid >> 4, l = tid & 15;
+    const int rb = br + (l >> 3), rm = l & 7, trow = tix(rb, rm);
+    for (int k = 0; k < 16; ++k) {
+      const int cb = br + (k >> 3), cm = k & 7, tc = tix(cb, cm);
+      int off;
+      if (trow >= 0 && tc >= 0) off = trow == tc ? off_of(&sh.dd[trow]) : off_of(&sh.Hs[tc * n + trow]);
+      else off = off_of(&sh.cst[(rb == cb && rm == cm) ? 1 : 0]);
+      sh.boff[k][tid] = off;
+    }
+    sh.boff[16][tid] = trow >= 0 ? off_of(&sh.gs[trow]) : off_of(&sh.cst[0]);
+    sh.boff[17][tid] = (l < 8 && br <= S) ? trow : -1;
+    if (tid == 0) {
+      int okb = 1;
+      for (int j = 0; j <= S; ++j) okb &= (bstart(j + 1) - bstart(j) <= 8) ? 1 : 0;
+#ifdef RANDT_WIN_NO_BAND
+      okb = 0;
+#endif
+      sh.band_ok = okb;
+      sh.cst[0] = 0.0;
+      sh.cst[1] = 1.0;
+      int dgl = 1;
+      for (int i = 0; i < 8; ++i)
+        for (int k = 0; k < 8; ++k)
+          if (i != k && W.sqrtI[i * 8 + k] != 0.0) dgl = 0;
+#ifdef RANDT_WIN_NO_DIAG
+      dgl = 0;
+#endif
+      sh.sq_diag = dgl;
+      for (int i = 0; i < 8; ++i) sh.d2[i] = W.sqrtI[i * 8 + i] * W.sqrtI[i * 8 + i];
+    }
+  }
+  for (int e = tid; e < 2 * WIN_SMAX * 128; e += WIN_BLOCK) (&sh.Ju[0][0][0])[e] = 0.0;  // once: see Shared::Ju
+  for (int e = tid; e < n * (n + 1) / 2; e += WIN_BLOCK) {
+    // row a of the upper triangle starts at a n - a (a - 1) / 2
+    int a = 0;
+    while (a + 1 < n && (a + 1) * n - (a + 1) * a / 2 <= e) ++a;
+    sh.tri[e] = (unsigned short)(a | ((a + (e - (a * n - a * (a - 1) / 2))) << 8));
+  }
   __syncthreads();
 
   // this wavefront's share of the NDT terms (fixed for the whole solve)
@@ -636,6 +770,18 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
     if (lane == 0) sh.wave_state[wave] = T.active ? T.state : -1;
   }
   __syncthreads();
+  if (tid <= WIN_SMAX) {
+    int first = 0, cnt = 0;
+    for (int w = WIN_NDT_WAVES - 1; w >= 0; --w)
+      if (sh.wave_state[w] == tid && tid >= 1) {
+        first = w;
+        ++cnt;
+      }
+    sh.sw_first[tid] = first;
+    sh.sw_cnt[tid] = cnt;
+  }
+  __syncthreads();
+  const bool band_ok = __builtin_amdgcn_readfirstlane(sh.band_ok) != 0;
 
   // number of NDT residual blocks and of moving cells
   int n_res = 0;
@@ -685,8 +831,9 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   double raw_max = 0.0;
   bool ok = true;
   if (n_res > 0) {
-    ok = ndt_pass<D, 0, AM2>(fixed, moving, W, T, sh, 0, L, sh.base[0], parity, sh);
-    raw_max = sh.base[0][0];
+    const double* unused;
+    ok = ndt_pass<D, 0, AM2>(fixed, moving, W, T, sh, 0, L, &sh.scal[7], parity, sh, unused);
+    raw_max = sh.scal[7];
     res.n_evals++;
     __syncthreads();
   }
@@ -709,15 +856,16 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       bool reuse = false, step_ok = true;
       int num_invalid = 0, iteration = 0;
       double minimum_cost = DBL_MAX;
-      bool e_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, p, L, sh.base[p], parity, sh);
+      const double* rs_cur;  // per-wavefront NDT base sums at the current point
+      bool e_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, p, L, nullptr, parity, sh, rs_cur);
       WT(1);
-      double fcost = factors_weight(W, sh, p);  // its barrier also publishes sh.base[p]
+      double fcost = factors_weight(W, sh, p);
       WT(2);
       res.n_evals++;
       res.iterations++;
       double cost = fcost;
 #pragma unroll
-      for (int j = 0; j < WIN_SMAX; ++j) cost += sh.base[p][j * 10];
+      for (int j = 0; j < WIN_SMAX; ++j) cost += state_sum(sh, rs_cur, j + 1, 0);
       if (uni(!e_ok || !isfinite(cost))) {
         term = RANDT_TERM_FAILURE;
         res.status = 2;
@@ -726,7 +874,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       }
       if (res.gnc_solves == 0) res.initial_cost = cost;
       summary_min = cost;
-      assemble(W, sh, p, sh.base[p], false);
+      assemble(W, sh, p, rs_cur, false);
       WT(3);
       bool first = true, need_scale = true;
       double x_norm = 0.0;
@@ -807,7 +955,68 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           // pivot.  Eliminating above the pivot as well leaves a diagonal system -- no back substitution, no LDS
           // round trips, no barriers; the j loop stays rolled (~130 instructions per step).
           double okf = 1.0;
-          {
+          if (band_ok) {
+            // ---- banded block Gauss-Jordan with DPP broadcasts (see band_pivot above)
+            if (lane < n) sh.dd[lane] = sh.Hs[lane * n + lane] + sh.diag[lane] * inv_radius;
+            wave_fence();
+            const char* const sbase = reinterpret_cast<const char*>(&sh);
+            double C[16], B;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) C[k] = *reinterpret_cast<const double*>(sbase + sh.boff[k][lane]);
+            B = *reinterpret_cast<const double*>(sbase + sh.boff[16][lane]);
+            const int trow = sh.boff[17][lane];
+            const int l = lane & 15, br = lane >> 4;
+            double RD = 0.0, X = 0.0;
+#pragma nounroll
+            for (int b = 0; b <= S; ++b) {
+              if (br == b) {
+                if (b > 0 && l < 8) {  // rows of state b as block step b - 1 left them
+#pragma unroll
+                  for (int k = 0; k < 8; ++k) C[k] = sh.xfer[l][k];
+                  B = sh.xfer[l][8];
+                }
+                asm volatile("s_nop 4");
+                if (b < S) {
+                  band_block<16>(C, B, RD, l);
+                  if (l >= 8) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) sh.xfer[l - 8][k] = C[8 + k];
+                    sh.xfer[l - 8][8] = B;
+                  }
+                } else {
+                  band_block<8>(C, B, RD, l);  // last state: nothing behind it
+                }
+              }
+              wave_fence();
+            }
+            // rows of state b: diagonal in their own columns now; x_b = (B - U x_{b+1}) / d, last state first
+#pragma nounroll
+            for (int b = S; b >= 0; --b) {
+              if (br == b) {
+                double a0 = B, a1 = 0.0;
+                if (b < S) {
+#pragma unroll
+                  for (int m = 0; m < 8; m += 2) {
+                    a0 = fma(-C[8 + m], sh.xsol[m], a0);
+                    a1 = fma(-C[9 + m], sh.xsol[m + 1], a1);
+                  }
+                }
+                X = (a0 + a1) * RD;
+              }
+              wave_fence();  // every read of the next state's solution precedes its overwrite
+              if (br == b && l < 8) sh.xsol[l] = X;
+              wave_fence();
+            }
+            const bool real = trow >= 0;
+            const double st = -X;
+            okf = wave_any(real && !(RD > 0.0)) != 0.0 ? 0.0 : 1.0;
+            const double fin = 1.0 - wave_any(real && !isfinite(st));
+            if (real) {
+              sh.step[trow] = st;
+              sh.delta[trow] = st * sh.sigma[trow];
+            }
+            if (lane == 0) sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
+          } else {
             // row i of the damped matrix straight into registers: Hs is symmetric, so lane i reads COLUMN i
             // (consecutive lanes -> consecutive words, no bank conflicts); (sqrt(D^2 / radius))^2 on the diagonal
             double row[WIN_NMAX], b = lane < n ? sh.gs[lane] : 0.0, dg = 1.0;
@@ -893,14 +1102,15 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         num_invalid = 0;
 
         // ---- candidate: factors + NDT terms with Jacobians (speculative)
-        const bool c_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, 1 - p, L, sh.base[1 - p], parity, sh);
+        const double* rs_cand;
+        const bool c_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, 1 - p, L, nullptr, parity, sh, rs_cand);
         WT(1);
         const double cf = factors_weight(W, sh, 1 - p);
         WT(2);
         res.n_evals++;
         double cand_cost = cf;
 #pragma unroll
-        for (int j = 0; j < WIN_SMAX; ++j) cand_cost += sh.base[1 - p][j * 10];
+        for (int j = 0; j < WIN_SMAX; ++j) cand_cost += state_sum(sh, rs_cand, j + 1, 0);
         const bool cfin = uni(c_ok && isfinite(cand_cost));
         if (!cfin) cand_cost = DBL_MAX;
 
@@ -915,7 +1125,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           p = 1 - p;
           cost = cand_cost;
           WT(6);
-          assemble(W, sh, p, sh.base[p], true);
+          assemble(W, sh, p, rs_cand, true);
           WT(3);
           need_scale = true;
           step_ok = true;
