@@ -60,11 +60,41 @@ __device__ __forceinline__ void so2_normalize(double& c, double& s) {
   c = c * inv;
   s = s * inv;
 }
+// Small-argument sin / cos / atan2 for the serial chains of this kernel (motion factor, Plus): ONE lane pays ~16 cycles per
+// dependent fp64 operation and ocml's sincos / atan2 are ~40 operations deep.  Taylor polynomials in Estrin form (depth 6),
+// error <= 2.2e-16 relative on |x| <= 0.5 (sin, cos) and |t| <= 0.125 (atan) -- the rotation between two radar scans;
+// ocml beyond (uniform branch).  The reference calls libm here; all three are 1-ulp functions.
+__device__ __forceinline__ double estrin8(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7,
+                                          double z, double z2, double z4) {
+  return fma(z4, fma(z2, fma(c7, z, c6), fma(c5, z, c4)), fma(z2, fma(c3, z, c2), fma(c1, z, c0)));
+}
+__device__ __forceinline__ void sincos_small(double x, double* sp, double* cp) {
+  if (uni(!(fabs(x) <= 0.5))) {
+    sincos(x, sp, cp);
+    return;
+  }
+  const double z = x * x, z2 = z * z, z4 = z2 * z2;
+  const double ps = estrin8(-0.16666666666666666, 0.008333333333333333, -0.0001984126984126984, 2.7557319223985893e-06,
+                            -2.505210838544172e-08, 1.6059043836821613e-10, -7.647163731819816e-13, 2.8114572543455206e-15, z, z2, z4);
+  const double pc = estrin8(-0.5, 0.041666666666666664, -0.001388888888888889, 2.48015873015873e-05, -2.755731922398589e-07,
+                            2.08767569878681e-09, -1.1470745597729725e-11, 4.779477332387385e-14, z, z2, z4);
+  *sp = fma(x * z, ps, x);
+  *cp = fma(z, pc, 1.0);
+}
+__device__ __forceinline__ double atan2_small(double y, double x) {
+  if (uni(!(x > 0.0 && fabs(y) <= 0.125 * x))) return atan2(y, x);
+  const double t = y * fast_rcp(x);
+  const double z = t * t, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+  const double p = fma(z8, fma(0.047619047619047616, z, -0.05263157894736842),
+                       estrin8(-0.3333333333333333, 0.2, -0.14285714285714285, 0.1111111111111111, -0.09090909090909091,
+                               0.07692307692307693, -0.06666666666666667, 0.058823529411764705, z, z2, z4));
+  return fma(t * z, p, t);
+}
 // raw_sc (nullable): sin / cos of theta as sincos() returned them (before the SO2 normalisation)
 __device__ __forceinline__ void se2_exp(const double* xi, double* out, double* raw_sc = nullptr) {
   const double theta = xi[2];
   double c, s;
-  sincos(theta, &s, &c);
+  sincos_small(theta, &s, &c);
   if (raw_sc) {
     raw_sc[0] = s;
     raw_sc[1] = c;
@@ -111,7 +141,7 @@ __device__ __forceinline__ void se2_inv(const double* a, double* out) {
   out[3] = s * tx + c * ty;
 }
 __device__ __forceinline__ void se2_log(const double* p, double* xi) {
-  const double theta = atan2(p[1], p[0]);
+  const double theta = atan2_small(p[1], p[0]);
   const double half = 0.5 * theta;
   const double rm1 = p[0] - 1.0;
   double hbt;
@@ -337,6 +367,7 @@ struct Shared {
   double xfer[8][10];
   double xsol[8];
   int band_ok;
+  Loss loss;  // robust loss of the running GNC step (uniform; in LDS so that it does not occupy ~20 registers across the solve)
 };
 
 // Unweighted motion / IMU factors at xs[buf], one lane per factor (called by ONE wavefront).
@@ -374,7 +405,11 @@ struct TermShare {
   int state, n_slots, first, stride, k, active;
   unsigned kmagic;
   int wpt;
+  int ci0[4];  // correspondences of this lane's first three trips (the association is frozen for the whole solve)
 };
+#ifndef WIN_TRIP_GROUP
+#define WIN_TRIP_GROUP 1
+#endif
 
 // Base sum i of state jj from the per-wavefront partial sums of a pass (wavefront order: fixed association).
 __device__ __forceinline__ double state_sum(const Shared& sh, const double* r, int jj, int i) {
@@ -384,19 +419,28 @@ __device__ __forceinline__ double state_sum(const Shared& sh, const double* r, i
   return a;
 }
 
+__device__ double ambient_sq(const WinDesc& W, const Shared& sh, int a, int b, int lane);
+
 // NDT pass over every term at the states in xs[buf].  MODE 0: max raw residual -> out[0];
 // MODE 1: ten base sums per wavefront -> rsum[w * 10 ..] (state_sum() combines them per state).
 // In MODE 1 wavefront 6 evaluates the motion / IMU factors of the same point while wavefronts 0-5
 // stream the NDT slots (the factors are a ~2000-instruction serial chain: hidden behind the pass).
 template <int D, int MODE, bool AM2>
 __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const TermShare& T,
-                         const Shared& sh, int buf, const Loss& L, double* out, int& parity, Shared& shw, const double*& rsum) {
+                         const Shared& sh, int buf, const Loss& Lsh, double* out, int& parity, Shared& shw, const double*& rsum,
+                         int step_from = -1) {
+  const Loss L = Lsh;  // LDS -> registers for the duration of the pass
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool factor_wave = MODE == 1 && wave == WIN_NDT_WAVES;
 #ifdef RANDT_TIMING
   const long long wt_t0 = wall_clock64();
 #endif
   if (factor_wave) factors_unweighted(W, shw, buf);
+  // candidate evaluation: the idle last wavefront takes ||x_candidate - x||^2 (parameter-tolerance test) off wavefront 0
+  if (MODE == 1 && step_from >= 0 && wave == WIN_WAVES - 1) {
+    const double sn2 = ambient_sq(W, sh, step_from, buf, lane);
+    if (lane == 0) shw.scal[1] = sn2;
+  }
 #ifdef RANDT_TIMING
   if (factor_wave && lane == 0) atomicAdd((unsigned long long*)&g_randt_win_timing[13], (unsigned long long)(wall_clock64() - wt_t0));
 #endif
@@ -422,19 +466,43 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
       double a10[10];
 #pragma unroll
       for (int i = 0; i < 10; ++i) a10[i] = 0.0;
-      for (int slot = lane + T.first; slot < n_slots; slot += T.stride) {
-        const int ci = pc[slot];
-        if (ci < 0 || ci >= fixed.cap) continue;
-        const unsigned mi = T.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, kmagic);  // slot / k
-        const float4* mv = mov + (size_t)mi * 3;
-        const float4* fv = fix + (size_t)ci * 3;
-        double jb[3];
-        const double sq = residual_sq<D, MODE == 1>(mv, fv, rot, tx, ty, jb);
-        // closed-form loss: a non-finite residual makes the cost sum non-finite (u or 1 / (u^2 s) is NaN / 0 x inf), which the
-        // caller tests after the reduction -- no per-residual class test in the hot loop
-        if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
-        if (MODE == 0) mx = sq > mx ? sq : mx;
-        else accumulate_residual<AM2>(L, sq, jb, a10);
+      // A lone workgroup has nothing to hide memory latency behind: a trip used to be index load -> record loads ->
+      // arithmetic, two exposed L2 round trips each.  Trips are taken three at a time: the indices of the first group
+      // are kept in registers for the whole solve, and all 18 record loads of a group are in flight before the first
+      // residual is evaluated.
+      for (int s0 = T.first, grp = 0; s0 < n_slots; s0 += WIN_TRIP_GROUP * T.stride, ++grp) {
+        int ci[WIN_TRIP_GROUP];
+        bool val[WIN_TRIP_GROUP];
+#pragma unroll
+        for (int t = 0; t < WIN_TRIP_GROUP; ++t) {
+          const int slot = s0 + t * T.stride + lane;
+          ci[t] = grp == 0 ? T.ci0[t] : (slot < n_slots ? pc[slot] : -1);
+          val[t] = ci[t] >= 0 && ci[t] < fixed.cap;
+        }
+        float4 mrec[WIN_TRIP_GROUP][3], frec[WIN_TRIP_GROUP][3];
+#pragma unroll
+        for (int t = 0; t < WIN_TRIP_GROUP; ++t) {
+          const int slot = s0 + t * T.stride + lane;
+          const unsigned mi = T.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, kmagic);  // slot / k
+          const float4* mv = mov + (size_t)(val[t] ? mi : 0u) * 3;
+          const float4* fv = fix + (size_t)(val[t] ? ci[t] : 0) * 3;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            mrec[t][q] = mv[q];
+            frec[t][q] = fv[q];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < WIN_TRIP_GROUP; ++t) {
+          if (!val[t]) continue;
+          double jb[3];
+          const double sq = residual_sq<D, MODE == 1>(mrec[t], frec[t], rot, tx, ty, jb);
+          // closed-form loss: a non-finite residual makes the cost sum non-finite (u or 1 / (u^2 s) is NaN / 0 x inf), which the
+          // caller tests after the reduction -- no per-residual class test in the hot loop
+          if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
+          if (MODE == 0) mx = sq > mx ? sq : mx;
+          else accumulate_residual<AM2>(L, sq, jb, a10);
+        }
       }
       if (MODE == 1) {
         wave_sum10(a10);
@@ -651,6 +719,57 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
   }
 }
 
+// Dense fallback of the damped solve (windows whose state blocks exceed 8 tangent dimensions, i.e. with the IMU bias):
+// Gauss-Jordan elimination entirely in registers.  Lane i keeps row i of A and gs_i; after every step all rows are shifted
+// left by one column, so the pivot column is ALWAYS register 0 and no register is indexed dynamically: step j broadcasts
+// lane j's row with v_readlane (the lane select may be a loop variable), every other lane subtracts its multiple of it, and
+// lane j parks its pivot.  Eliminating above the pivot as well leaves a diagonal system -- no back substitution, no LDS round
+// trips, no barriers; the j loop stays rolled.  Kept out of line: its 32 row registers must not set the kernel's budget.
+__device__ __noinline__ void gj_dense_solve(Shared& sh, int n, double inv_radius, int lane) {
+  double okf = 1.0;
+  {
+    // row i of the damped matrix straight into registers: Hs is symmetric, so lane i reads COLUMN i
+    // (consecutive lanes -> consecutive words, no bank conflicts); (sqrt(D^2 / radius))^2 on the diagonal
+    double row[WIN_NMAX], b = lane < n ? sh.gs[lane] : 0.0, dg = 1.0;
+    const double damp = lane < n ? sh.diag[lane] * inv_radius : 0.0;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < WIN_NMAX; ++k) {
+      row[k] = (lane < n && k < n) ? sh.Hs[k * n + lane] : 0.0;
+      if (k == lane) row[k] += damp;
+    }
+    // at step j only the first n - j columns are still live: eight rolled loops of width 32, 28, ... 4
+    int j = 0;
+#define RANDT_GJ_STEPS(WIDTH)                                                                          \
+  for (; j < n && n - j > (WIDTH) - 4; ++j) {                                                         \
+    const double pj = readlane_f64(row[0], j);                                                        \
+    if (!(pj > 0.0)) okf = 0.0;                                                                       \
+    if (lane == j) dg = pj;                                                                           \
+    const double f = lane != j ? row[0] * fast_rcp(pj) : 0.0; /* lane j: f = 0, its row only shifts */ \
+    b = fma(-f, readlane_f64(b, j), b);                                                               \
+    _Pragma("clang loop unroll(full)") for (int k = 1; k < (WIDTH); ++k)                              \
+        row[k - 1] = fma(-f, readlane_f64(row[k], j), row[k]);                                        \
+    row[(WIDTH) - 1] = 0.0;                                                                           \
+  }
+    RANDT_GJ_STEPS(32)
+    RANDT_GJ_STEPS(28)
+    RANDT_GJ_STEPS(24)
+    RANDT_GJ_STEPS(20)
+    RANDT_GJ_STEPS(16)
+    RANDT_GJ_STEPS(12)
+    RANDT_GJ_STEPS(8)
+    RANDT_GJ_STEPS(4)
+#undef RANDT_GJ_STEPS
+    // scaled step (negated: Ceres solves for -step), its finiteness, the unscaled delta
+    const double st = lane < n ? -(b * fast_rcp(dg)) : 0.0;
+    const double fin = 1.0 - wave_any(!isfinite(st));
+    if (lane < n) {
+      sh.step[lane] = st;
+      sh.delta[lane] = st * sh.sigma[lane];
+    }
+    if (lane == 0) sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
+  }
+}
+
 // AM2: Barron shape exactly -2 (the shipped configurations): closed-form loss, no pow() in the kernel
 template <int D, bool AM2>
 __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapView moving, const WinDesc* __restrict__ Wp,
@@ -767,6 +886,11 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       T.fix = reinterpret_cast<const float4*>(fixed.cells + (size_t)fmap * fixed.cap);
       T.pc = corr + (size_t)t * moving.cap * W.k;
     }
+#pragma unroll
+    for (int q = 0; q < WIN_TRIP_GROUP; ++q) {
+      const int slot = T.first + q * T.stride + lane;
+      T.ci0[q] = (T.active && slot < T.n_slots) ? T.pc[slot] : -1;
+    }
     if (lane == 0) sh.wave_state[wave] = T.active ? T.state : -1;
   }
   __syncthreads();
@@ -827,12 +951,12 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
 
   // ---- raw NDT residuals -> gnc_mu (ndt_matcher.cpp:382-389)
   const double weight = n_cells > 0 ? W.ndt_weight / (double)(n_cells * W.k) : 0.0;
-  Loss L = AM2 ? make_loss_am2(P.loss_a, 1.0, weight) : make_loss(P.loss_a, P.alpha, 1.0, weight);
+  if (tid == 0) sh.loss = AM2 ? make_loss_am2(P.loss_a, 1.0, weight) : make_loss(P.loss_a, P.alpha, 1.0, weight);
   double raw_max = 0.0;
   bool ok = true;
   if (n_res > 0) {
     const double* unused;
-    ok = ndt_pass<D, 0, AM2>(fixed, moving, W, T, sh, 0, L, &sh.scal[7], parity, sh, unused);
+    ok = ndt_pass<D, 0, AM2>(fixed, moving, W, T, sh, 0, sh.loss, &sh.scal[7], parity, sh, unused);
     raw_max = sh.scal[7];
     res.n_evals++;
     __syncthreads();
@@ -850,14 +974,16 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   if (ok) {
     do {
       gnc_mu = fmax(gnc_mu, 1.0);
-      L = AM2 ? make_loss_am2(P.loss_a, gnc_mu, weight) : make_loss(P.loss_a, P.alpha, gnc_mu, weight);
+      __syncthreads();  // every pass of the previous step has read its loss
+      if (tid == 0) sh.loss = AM2 ? make_loss_am2(P.loss_a, gnc_mu, weight) : make_loss(P.loss_a, P.alpha, gnc_mu, weight);
+      __syncthreads();
       // ================= one ceres::Solve =================
       double radius = P.r0, decrease = 2.0;
       bool reuse = false, step_ok = true;
       int num_invalid = 0, iteration = 0;
       double minimum_cost = DBL_MAX;
       const double* rs_cur;  // per-wavefront NDT base sums at the current point
-      bool e_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, p, L, nullptr, parity, sh, rs_cur);
+      bool e_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, p, sh.loss, nullptr, parity, sh, rs_cur);
       WT(1);
       double fcost = factors_weight(W, sh, p);
       WT(2);
@@ -944,27 +1070,37 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
 
         // ---- (wave 0) LevenbergMarquardtStrategy::ComputeStep: damped normal equations
         if (wave == 0) {
-          if (!reuse && lane < n) sh.diag[lane] = fmin(fmax(sh.Hs[lane * n + lane], P.dmin), P.dmax);
-          wave_fence();
           const double inv_radius = fast_rcp(radius);
+          // the band solve's per-lane offsets do not depend on anything below: requested ahead of the fence
+          int boffv[18];
+#ifdef RANDT_WIN_PREFETCH_BOFF
+          if (band_ok) {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) boffv[k] = sh.boff[k][lane];
+          }
+#endif
+          if (lane < n) {
+            // LM diagonal (kept while steps are rejected) and the damped diagonal in one go
+            const double hd = sh.Hs[lane * n + lane];
+            const double dgv = reuse ? sh.diag[lane] : fmin(fmax(hd, P.dmin), P.dmax);
+            if (!reuse) sh.diag[lane] = dgv;
+            sh.dd[lane] = hd + dgv * inv_radius;
+          }
+          wave_fence();
           WT(8);
-          // SPD solve A y = gs by Gauss-Jordan elimination entirely in registers.  Lane i keeps row i of A and
-          // gs_i; after every step all rows are shifted left by one column, so the pivot column is ALWAYS register
-          // 0 and no register is indexed dynamically: step j broadcasts lane j's row with v_readlane (the lane
-          // select may be a loop variable), every other lane subtracts its multiple of it, and lane j parks its
-          // pivot.  Eliminating above the pivot as well leaves a diagonal system -- no back substitution, no LDS
-          // round trips, no barriers; the j loop stays rolled (~130 instructions per step).
           double okf = 1.0;
           if (band_ok) {
             // ---- banded block Gauss-Jordan with DPP broadcasts (see band_pivot above)
-            if (lane < n) sh.dd[lane] = sh.Hs[lane * n + lane] + sh.diag[lane] * inv_radius;
-            wave_fence();
             const char* const sbase = reinterpret_cast<const char*>(&sh);
+#ifndef RANDT_WIN_PREFETCH_BOFF
+#pragma unroll
+            for (int k = 0; k < 18; ++k) boffv[k] = sh.boff[k][lane];
+#endif
             double C[16], B;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) C[k] = *reinterpret_cast<const double*>(sbase + sh.boff[k][lane]);
-            B = *reinterpret_cast<const double*>(sbase + sh.boff[16][lane]);
-            const int trow = sh.boff[17][lane];
+            for (int k = 0; k < 16; ++k) C[k] = *reinterpret_cast<const double*>(sbase + boffv[k]);
+            B = *reinterpret_cast<const double*>(sbase + boffv[16]);
+            const int trow = boffv[17];
             const int l = lane & 15, br = lane >> 4;
             double RD = 0.0, X = 0.0;
 #pragma nounroll
@@ -989,23 +1125,22 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
               }
               wave_fence();
             }
-            // rows of state b: diagonal in their own columns now; x_b = (B - U x_{b+1}) / d, last state first
+            // rows of state b: diagonal in their own columns now; x_b = (B - U x_{b+1}) / d, last state first.  The next
+            // state's solution sits in lanes 0..7 of the next DPP row: eight uniform values, fetched with v_readlane
+            // (no LDS round trip on this dependent chain).
 #pragma nounroll
             for (int b = S; b >= 0; --b) {
-              if (br == b) {
-                double a0 = B, a1 = 0.0;
-                if (b < S) {
+              double a0 = B, a1 = 0.0;
+              if (b < S) {
+                const int src = 16 * (b + 1);
 #pragma unroll
-                  for (int m = 0; m < 8; m += 2) {
-                    a0 = fma(-C[8 + m], sh.xsol[m], a0);
-                    a1 = fma(-C[9 + m], sh.xsol[m + 1], a1);
-                  }
+                for (int m = 0; m < 8; m += 2) {
+                  a0 = fma(-C[8 + m], readlane_f64(X, src + m), a0);
+                  a1 = fma(-C[9 + m], readlane_f64(X, src + m + 1), a1);
                 }
-                X = (a0 + a1) * RD;
               }
-              wave_fence();  // every read of the next state's solution precedes its overwrite
-              if (br == b && l < 8) sh.xsol[l] = X;
-              wave_fence();
+              const double xb = (a0 + a1) * RD;
+              X = br == b ? xb : X;
             }
             const bool real = trow >= 0;
             const double st = -X;
@@ -1017,45 +1152,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
             }
             if (lane == 0) sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
           } else {
-            // row i of the damped matrix straight into registers: Hs is symmetric, so lane i reads COLUMN i
-            // (consecutive lanes -> consecutive words, no bank conflicts); (sqrt(D^2 / radius))^2 on the diagonal
-            double row[WIN_NMAX], b = lane < n ? sh.gs[lane] : 0.0, dg = 1.0;
-            const double damp = lane < n ? sh.diag[lane] * inv_radius : 0.0;
-#pragma clang loop unroll(full)
-            for (int k = 0; k < WIN_NMAX; ++k) {
-              row[k] = (lane < n && k < n) ? sh.Hs[k * n + lane] : 0.0;
-              if (k == lane) row[k] += damp;
-            }
-            // at step j only the first n - j columns are still live: eight rolled loops of width 32, 28, ... 4
-            int j = 0;
-#define RANDT_GJ_STEPS(WIDTH)                                                                          \
-  for (; j < n && n - j > (WIDTH) - 4; ++j) {                                                         \
-    const double pj = readlane_f64(row[0], j);                                                        \
-    if (!(pj > 0.0)) okf = 0.0;                                                                       \
-    if (lane == j) dg = pj;                                                                           \
-    const double f = lane != j ? row[0] * fast_rcp(pj) : 0.0; /* lane j: f = 0, its row only shifts */ \
-    b = fma(-f, readlane_f64(b, j), b);                                                               \
-    _Pragma("clang loop unroll(full)") for (int k = 1; k < (WIDTH); ++k)                              \
-        row[k - 1] = fma(-f, readlane_f64(row[k], j), row[k]);                                        \
-    row[(WIDTH) - 1] = 0.0;                                                                           \
-  }
-            RANDT_GJ_STEPS(32)
-            RANDT_GJ_STEPS(28)
-            RANDT_GJ_STEPS(24)
-            RANDT_GJ_STEPS(20)
-            RANDT_GJ_STEPS(16)
-            RANDT_GJ_STEPS(12)
-            RANDT_GJ_STEPS(8)
-            RANDT_GJ_STEPS(4)
-#undef RANDT_GJ_STEPS
-            // scaled step (negated: Ceres solves for -step), its finiteness, the unscaled delta
-            const double st = lane < n ? -(b * fast_rcp(dg)) : 0.0;
-            const double fin = 1.0 - wave_any(!isfinite(st));
-            if (lane < n) {
-              sh.step[lane] = st;
-              sh.delta[lane] = st * sh.sigma[lane];
-            }
-            if (lane == 0) sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
+            gj_dense_solve(sh, n, inv_radius, lane);
           }
           WT(9);
         }
@@ -1077,16 +1174,12 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         } else if (wave == 0) {
           WT(10);
           plus_states(W, sh, p, 1 - p, sh.delta, 1.0, lane);
-          wave_fence();
           WT(11);
-          const double sn2 = ambient_sq(W, sh, p, 1 - p, lane);
-          WT(12);
-          if (lane == 0) sh.scal[1] = sn2;
         }
         __syncthreads();
         WT(5);
         reuse = true;
-        const double mcc = sh.scal[0], sn2 = sh.scal[1];
+        const double mcc = sh.scal[0];
         const bool valid = uni(sh.scal[3] != 0.0 && mcc > 0.0);
         if (!valid) {
           // ---- HandleInvalidStep
@@ -1103,7 +1196,8 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
 
         // ---- candidate: factors + NDT terms with Jacobians (speculative)
         const double* rs_cand;
-        const bool c_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, 1 - p, L, nullptr, parity, sh, rs_cand);
+        const bool c_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, 1 - p, sh.loss, nullptr, parity, sh, rs_cand, p);
+        const double sn2 = sh.scal[1];
         WT(1);
         const double cf = factors_weight(W, sh, 1 - p);
         WT(2);
