@@ -198,6 +198,17 @@ int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans
 /* Host convenience for one scan (copies the points, synchronises). */
 int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int stride_floats,
                     int intensity_index, const randt_cluster_params* cp, randt_maps* out, int map_idx);
+/* The same with pNDT cells: Cell::updateCell's `params_.use_pndt` branch (ndt_cell.cpp:67-82, 102; NDTCellParameters
+ * {beam_cov, use_pndt}, ndt_slam_parameters.h:12-15; false in every shipped configuration).  d_polar:
+ * [n_scans][pitch_points][2] floats = (angle, range) of every point -- what RadarPreprocessor::filterScan emits beside the
+ * cloud (radar_preprocessor.cpp:116; randt_filter_scan_batch_dev's d_polar) and labelClouds deals out per cluster
+ * (:164-167); beam_cov9: row-major 3x3 sensor covariance (angle, range, intensity), host memory.  Every point adds
+ * J beam_cov J^T with J = d(x, y, i) / d(angle, range, i); the cell covariance is the sample covariance plus the mean of
+ * those, and the eigenvalue regularisation is skipped.  Always the multi-workgroup (tiled) build; fp32, parity with the
+ * oracle to rounding of sin / cos (spec decision 10). */
+int randt_ndt_build_pndt_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
+                                   const int32_t* d_n_points, int stride_floats, int intensity_index, const float* d_polar,
+                                   const float* beam_cov9, const randt_cluster_params* cp, randt_maps* out, int first_map);
 
 /* ------------------------------------------------------------------ transform / merge (a9,a18) */
 /* Map::transformMap (ndt_map.cpp:177-182, Cell::transformCell ndt_cell.cpp:117-123); like the

@@ -262,9 +262,19 @@ class Map:
         lib().orc_map_copy(m._p, self._p)
         return m
 
-    def build(self, pts, n_clusters, max_range, ioff=3):
+    def build(self, pts, n_clusters, max_range, ioff=3, polar=None, beam_cov=None):
+        """polar ([n, 2] angle / range) + beam_cov (3x3): the pNDT cells of ndt_cell.cpp:67-82 (use_pndt)."""
         pts = np.ascontiguousarray(pts, dtype=np.float32)
-        return lib().orc_ndt_build(self._p, _ptr(pts), pts.shape[0], pts.shape[1], ioff, int(n_clusters), float(max_range))
+        if polar is None:
+            return lib().orc_ndt_build(self._p, _ptr(pts), pts.shape[0], pts.shape[1], ioff, int(n_clusters), float(max_range))
+        polar = np.ascontiguousarray(polar, dtype=np.float32)
+        beam = np.ascontiguousarray(beam_cov, dtype=np.float32).reshape(9)
+        assert polar.shape == (pts.shape[0], 2)
+        L = lib()
+        L.orc_ndt_build_pndt.restype = C.c_int
+        L.orc_ndt_build_pndt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        return L.orc_ndt_build_pndt(self._p, _ptr(pts), pts.shape[0], pts.shape[1], ioff, int(n_clusters), float(max_range),
+                                    _ptr(polar), _ptr(beam))
 
     def transform(self, pose4):
         aff = pose_to_affine_f(pose4)

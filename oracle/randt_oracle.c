@@ -163,10 +163,26 @@ static void cell_regularize(orc_cell* c) {
   c->cov[5] = (float)((double)c->cov[5] + 0.000001); /* new_cov_(2,2) += 0.000001 (double literal) */
 }
 
+int orc_cell_from_points_pndt(orc_cell* c, const float* pts, const int32_t* idx, int k, int stride, int ioff, int min_points,
+                              const float* polar, const float* beam);
+
 /* Cell::addPointCloud + updateCell (first-fill branch), ndt_cell.cpp:25-65,90-94,102-112.
  * idx may be NULL (points 0..k-1).  Returns 1 if accepted. */
 int orc_cell_from_points(orc_cell* c, const float* pts, const int32_t* idx, int k, int stride,
                          int ioff, int min_points) {
+  return orc_cell_from_points_pndt(c, pts, idx, k, stride, ioff, min_points, NULL, NULL);
+}
+
+/* The same with the pNDT branch of updateCell (ndt_cell.cpp:67-82, use_pndt = true; false in every shipped configuration,
+ * "hard to tune, better not touch it"): every point adds J * beam_cov * J^T, J = d(x, y, i) / d(angle, range, i) at its
+ * polar coordinates; the mean of those is added to the sample covariance and the regularisation of :102-112 is skipped.
+ * polar (NULL = plain NDT): (angle, range) per point, indexed like pts; beam: row-major 3x3 (NDTCellParameters::beam_cov).
+ * SPEC DECISIONS: Eigen's 3x3 float products as ((a0 b0 + a1 b1) + a2 b2) with (J * S) evaluated first, like transformCell;
+ * std::sin / std::cos of the float angle are taken in double and rounded once (glibc's sinf is an IFUNC whose FMA and
+ * non-FMA variants differ in the last bit, so the reference itself is not reproducible across CPUs here); the six upper
+ * entries are kept. */
+int orc_cell_from_points_pndt(orc_cell* c, const float* pts, const int32_t* idx, int k, int stride,
+                              int ioff, int min_points, const float* polar, const float* beam) {
   memset(c, 0, sizeof(*c));
   if (!((long long)k > (long long)min_points)) return 0; /* n_points_(0) + size > min_points_per_cell_ */
   float m0 = 0.f, m1 = 0.f, m2 = 0.f;
@@ -204,6 +220,27 @@ int orc_cell_from_points(orc_cell* c, const float* pts, const int32_t* idx, int 
   c->cov[5] = c22 / nf;
   c->n = (uint32_t)k;
   c->max_intensity = (float)maxi;
+  if (polar && beam) {
+    float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    for (int j = 0; j < k; ++j) {
+      const size_t id = (size_t)(idx ? idx[j] : j);
+      const float a = polar[2 * id], r = polar[2 * id + 1];
+      const float sn = (float)sin((double)a), cs = (float)cos((double)a);
+      const float J[3][3] = {{-r * sn, cs, 0.f}, {r * cs, sn, 0.f}, {0.f, 0.f, 1.f}};
+      float JS[3][3];
+      for (int i = 0; i < 3; ++i)
+        for (int q = 0; q < 3; ++q) JS[i][q] = (J[i][0] * beam[0 * 3 + q] + J[i][1] * beam[1 * 3 + q]) + J[i][2] * beam[2 * 3 + q];
+      for (int i = 0; i < 3; ++i)
+        for (int q = i; q < 3; ++q) acc[i][q] = acc[i][q] + ((JS[i][0] * J[q][0] + JS[i][1] * J[q][1]) + JS[i][2] * J[q][2]);
+    }
+    c->cov[0] = c->cov[0] + acc[0][0] / nf;
+    c->cov[1] = c->cov[1] + acc[0][1] / nf;
+    c->cov[2] = c->cov[2] + acc[0][2] / nf;
+    c->cov[3] = c->cov[3] + acc[1][1] / nf;
+    c->cov[4] = c->cov[4] + acc[1][2] / nf;
+    c->cov[5] = c->cov[5] + acc[2][2] / nf;
+    return 1; /* :102: no regularisation with use_pndt */
+  }
   cell_regularize(c); /* use_pndt = false in every shipped config */
   return 1;
 }
@@ -328,11 +365,21 @@ static int cmp_lbl_idx(const void* a, const void* b) {
   return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
 }
 
+int orc_ndt_build_pndt(orc_map* m, const float* pts, int n, int stride, int ioff, int n_clusters, float max_range,
+                       const float* polar, const float* beam);
+
 /* processScan's cluster + labelClouds (radar_preprocessor.cpp:34-37,151-169): clusters in ascending
  * label order, points inside a cluster in input order; then addClusters -> insertCluster
  * (ndt_hierarchical_map.cpp:28-33, ndt_map.cpp:238-245). */
 int orc_ndt_build(orc_map* m, const float* pts, int n, int stride, int ioff, int n_clusters,
                   float max_range) {
+  return orc_ndt_build_pndt(m, pts, n, stride, ioff, n_clusters, max_range, NULL, NULL);
+}
+
+/* polar / beam: see orc_cell_from_points_pndt (labelClouds hands every cluster its polar points in the same order,
+ * radar_preprocessor.cpp:164-167). */
+int orc_ndt_build_pndt(orc_map* m, const float* pts, int n, int stride, int ioff, int n_clusters,
+                       float max_range, const float* polar, const float* beam) {
   if (n <= 0) return 0;
   int32_t* labels = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
   lbl_idx* li = (lbl_idx*)malloc(sizeof(lbl_idx) * (size_t)n);
@@ -347,7 +394,7 @@ int orc_ndt_build(orc_map* m, const float* pts, int n, int stride, int ioff, int
     int end = start + 1;
     while (end < n && li[end].label == li[start].label) ++end;
     orc_cell c;
-    if (orc_cell_from_points(&c, pts, idx + start, end - start, stride, ioff, m->min_points)) {
+    if (orc_cell_from_points_pndt(&c, pts, idx + start, end - start, stride, ioff, m->min_points, polar, beam)) {
       uint32_t slot = orc_map_coord_to_index(m, c.mean[0], c.mean[1]);
       if (slot < n_slots && m->n_cells < m->cap) {
         m->grid[slot] = m->n_cells; /* later cluster overwrites the slot, both cells stay (quirk A.7-5) */

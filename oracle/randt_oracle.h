@@ -69,9 +69,13 @@ void orc_grid_labels(const float* pts, int n, int stride, int ioff, int n_cluste
 /* radar_preprocessor.cpp:151-169 + ndt_hierarchical_map.cpp:28-33 + ndt_map.cpp:238-245 + ndt_cell.cpp:25-114 */
 int orc_ndt_build(orc_map* m, const float* pts, int n, int stride, int ioff, int n_clusters,
                   float max_range);
+int orc_ndt_build_pndt(orc_map* m, const float* pts, int n, int stride, int ioff, int n_clusters, float max_range,
+                       const float* polar, const float* beam);
 /* ndt_cell.cpp:36-114 (first-fill branch + regularisation) for one cluster of k points */
 int orc_cell_from_points(orc_cell* c, const float* pts, const int32_t* idx, int k, int stride,
                          int ioff, int min_points);
+int orc_cell_from_points_pndt(orc_cell* c, const float* pts, const int32_t* idx, int k, int stride, int ioff, int min_points,
+                              const float* polar /* (angle, range) per point or NULL */, const float* beam /* 3x3 row-major */);
 /* ndt_cell.h:133-142 */
 void orc_cell_merge(orc_cell* dst, const orc_cell* src);
 /* Cell::addPointCloud + updateCell incl. the recursive update of an already filled cell (ndt_cell.cpp:25-114) */

@@ -9,13 +9,13 @@ from . import _capi, synth  # noqa: F401
 from ._capi import (CELL_DTYPE, RESULT_DTYPE, PARAM_AMBIENT4, PARAM_MANIFOLD, PARAM_VECTOR,  # noqa: F401
                     STATE_DTYPE, ClusterParams, MapParams, MatcherParams, WindowParams)
 from .host import (Context, Maps, RandtError, associate_batch, default_matcher_params, indoor_cluster_params,  # noqa: F401
-                   indoor_map_params, make_state, ndt_build_batch, predict_state, register_batch, register_window,
+                   indoor_map_params, make_state, ndt_build_batch, ndt_build_pndt_batch, predict_state, register_batch, register_window,
                    scan_register_batch, solve_batch, window_params)
 
 __all__ = [
     "Context", "Maps", "RandtError", "MapParams", "ClusterParams", "MatcherParams", "CELL_DTYPE", "RESULT_DTYPE",
     "PARAM_MANIFOLD", "PARAM_AMBIENT4", "PARAM_VECTOR", "default_matcher_params", "indoor_map_params",
-    "indoor_cluster_params", "ndt_build_batch", "associate_batch", "solve_batch", "register_batch",
+    "indoor_cluster_params", "ndt_build_batch", "ndt_build_pndt_batch", "associate_batch", "solve_batch", "register_batch",
     "scan_register_batch", "synth", "STATE_DTYPE", "WindowParams", "make_state", "window_params", "predict_state",
     "register_window",
 ]

@@ -120,6 +120,7 @@ SYMBOLS = {
     "randt_maps_copy": (_I, [_V, _I, _V, _I, _I]),
     "randt_ndt_build_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ClusterParams), _V, _I]),
     "randt_ndt_build": (_I, [_V, _V, _I, _I, _I, _P(ClusterParams), _V, _I]),
+    "randt_ndt_build_pndt_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _V, _V, _P(ClusterParams), _V, _I]),
     "randt_maps_transform": (_I, [_V, _I, _I, _V]),
     "randt_maps_merge": (_I, [_V, _I, _V, _I, _I, _V]),
     "randt_maps_reindex": (_I, [_V, _I, _I]),

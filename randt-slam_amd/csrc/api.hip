@@ -428,6 +428,23 @@ int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans
   return launch_ndt_build(ctx, d_points, n_scans, pitch_points, d_n_points, stride_floats, intensity_index, cp, out->v, first_map);
 }
 
+int randt_ndt_build_pndt_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
+                                   const int32_t* d_n_points, int stride_floats, int intensity_index, const float* d_polar,
+                                   const float* beam_cov9, const randt_cluster_params* cp, randt_maps* out, int first_map) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx || !cp || !range_ok(out, first_map, n_scans < 0 ? 0 : n_scans) || n_scans < 0 || pitch_points < 0 ||
+      stride_floats < 3 || intensity_index < 0 || intensity_index >= stride_floats || cp->n_clusters <= 0 ||
+      !(cp->max_range > 0.f) || !beam_cov9)
+    return RANDT_ERR_INVALID;
+  for (int i = 0; i < 9; ++i)
+    if (!isfinite(beam_cov9[i])) return randt_set_error(ctx, RANDT_ERR_INVALID, "beam_cov must be finite", hipSuccess);
+  if (n_scans == 0) return RANDT_OK;
+  if ((!d_points || !d_polar) && pitch_points > 0) return RANDT_ERR_INVALID;
+  if (pitch_points == 0) return randt_maps_clear(out, first_map, n_scans);
+  return launch_ndt_build(ctx, d_points, n_scans, pitch_points, d_n_points, stride_floats, intensity_index, cp, out->v, first_map,
+                          d_polar, beam_cov9);
+}
+
 int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int stride_floats, int intensity_index,
                     const randt_cluster_params* cp, randt_maps* out, int map_idx) {
   DeviceGuard dev_guard__(ctx);

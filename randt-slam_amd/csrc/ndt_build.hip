@@ -650,13 +650,14 @@ __global__ __launch_bounds__(256) void k_maps_merge(MapView fixed, int fixed_idx
 }  // namespace
 
 int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points,
-                     int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map) {
+                     int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map, const float* d_polar,
+                     const float* beam_cov9) {
   if (n_scans <= 0) return RANDT_OK;
   const int npad = (pitch + 63) & ~63;
-  if (pitch > 7168 || ctx->build_tiled) {
+  if (pitch > 7168 || ctx->build_tiled || d_polar) {  // pNDT cells: always the tiled path (its statistics kernel carries the option)
     // scans beyond one workgroup's LDS: multi-workgroup stable counting sort in global memory (ndt_build_big.hip)
     if ((long long)pitch > (1ll << 26)) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large (max 2^26 points)", hipSuccess);
-    const size_t want = ndt_build_big_ws_bytes(n_scans, pitch);
+    const size_t want = ndt_build_big_ws_bytes(n_scans, pitch, d_polar ? 1 : 0);
     if (want > ctx->build_ws_bytes) {
       if (ctx->build_ws) {
         RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -667,7 +668,7 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
       RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->build_ws, want));
       ctx->build_ws_bytes = want;
     }
-    int rc = launch_ndt_build_big(ctx, d_points, n_scans, pitch, d_n_points, stride, ioff, cp, out, first_map, ctx->build_ws);
+    int rc = launch_ndt_build_big(ctx, d_points, n_scans, pitch, d_n_points, stride, ioff, cp, out, first_map, ctx->build_ws, d_polar, beam_cov9);
     if (rc) return rc;
     // The tiled path keeps <= 8192 label bins per tile.  A scan whose labels span more (points many times max_range away
     // from the sensor) cannot be sorted by it: that is reported here, which costs this path one synchronisation.

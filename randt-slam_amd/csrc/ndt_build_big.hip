@@ -47,6 +47,11 @@ struct BigArgs {
   float* si;
   int npad;
   int lane_ordered_atomics;  // randt_ctx::lds_atomics_lane_ordered
+  // pNDT (Cell::updateCell with use_pndt, ndt_cell.cpp:67-82): polar coordinates of the points, sorted like sx / sy / si
+  const float* polar;    // [n_scans][pitch][2] (angle, range) or nullptr
+  float* sa;             // [n_scans][npad] x 2
+  float* sr;
+  float beam[9];         // NDTCellParameters::beam_cov, row-major
 };
 
 __device__ __forceinline__ int32_t big_label(float x, float y, int row_size, float resolution) {
@@ -237,6 +242,11 @@ __global__ __launch_bounds__(BIG_BLOCK) void k_big_scatter(BigArgs A) {
       sx[pos] = x;
       sy[pos] = y;
       si[pos] = in;
+      if (A.polar) {
+        const float* pp = A.polar + ((size_t)scan * A.pitch + i) * 2;
+        A.sa[(size_t)scan * A.npad + pos] = pp[0];
+        A.sr[(size_t)scan * A.npad + pos] = pp[1];
+      }
     }
   }
 }
@@ -290,7 +300,26 @@ __global__ __launch_bounds__(BIG_BLOCK) void k_big_stats(BigArgs A, MapView out)
       const float da = pa[j] - ma, db = pb[j] - mb;
       cacc += (da * db);
     }
-    const float cv = cacc / nf;
+    float cv = cacc / nf;
+    if (A.polar) {
+      // pNDT: lane g accumulates entry (ia, ib) of sum_j J_j S J_j^T in point order, J = d(x, y, i) / d(angle, range, i)
+      // (ndt_cell.cpp:68-80); products as ((a0 b0 + a1 b1) + a2 b2) with (J S) first, sin / cos in double rounded once
+      // (spec decision 10)
+      const float* sa = A.sa + (size_t)scan * A.npad;
+      const float* sr = A.sr + (size_t)scan * A.npad;
+      float pacc = 0.f;
+      for (int j = s; j < e; ++j) {
+        const float a = sa[j], r = sr[j];
+        const float sn = (float)sin((double)a), cs = (float)cos((double)a);
+        const float Ja0 = ia == 0 ? -r * sn : (ia == 1 ? r * cs : 0.f), Ja1 = ia == 0 ? cs : (ia == 1 ? sn : 0.f), Ja2 = ia == 2 ? 1.f : 0.f;
+        const float Jb0 = ib == 0 ? -r * sn : (ib == 1 ? r * cs : 0.f), Jb1 = ib == 0 ? cs : (ib == 1 ? sn : 0.f), Jb2 = ib == 2 ? 1.f : 0.f;
+        const float JS0 = (Ja0 * A.beam[0] + Ja1 * A.beam[3]) + Ja2 * A.beam[6];
+        const float JS1 = (Ja0 * A.beam[1] + Ja1 * A.beam[4]) + Ja2 * A.beam[7];
+        const float JS2 = (Ja0 * A.beam[2] + Ja1 * A.beam[5]) + Ja2 * A.beam[8];
+        pacc = pacc + ((JS0 * Jb0 + JS1 * Jb1) + JS2 * Jb2);
+      }
+      cv = cv + pacc / nf;
+    }
     const float c00 = __shfl(cv, gbase + 0, 64), c11 = __shfl(cv, gbase + 1, 64), c22 = __shfl(cv, gbase + 2, 64);
     const float c01 = __shfl(cv, gbase + 3, 64), c02 = __shfl(cv, gbase + 4, 64), c12 = __shfl(cv, gbase + 5, 64);
     if (g == 0 && k > 0) {
@@ -307,7 +336,7 @@ __global__ __launch_bounds__(BIG_BLOCK) void k_big_stats(BigArgs A, MapView out)
       cell.n = (uint32_t)k;
       cell.max_intensity = maxi;
       cell.reserved = 0;
-      cell_regularize(cell);
+      if (!A.polar) cell_regularize(cell);  // ndt_cell.cpp:102: not with use_pndt
       const uint32_t slot = coord_to_index(out, cell.mean[0], cell.mean[1]);
       if (slot < (uint32_t)out.n_slots) {  // reference: vector::at throws otherwise
         if (target < (uint32_t)out.cap) {
@@ -377,17 +406,22 @@ __global__ void k_big_init(int32_t* range, int n_scans) {
 }  // namespace
 
 // Workspace bytes of the tiled path for a batch.
-size_t ndt_build_big_ws_bytes(int n_scans, int pitch) {
+size_t ndt_build_big_ws_bytes(int n_scans, int pitch, int with_polar) {
   const size_t npad = ((size_t)pitch + 63) & ~(size_t)63;
   const size_t n_tiles = ((size_t)pitch + BIG_TILE - 1) / BIG_TILE;
-  size_t per = 16 + npad * 4 + n_tiles * BIG_NB_MAX * 8 + n_tiles * BIG_NB_MAX * 4 + (BIG_NB_MAX + 1) * 4 + BIG_NB_MAX * 4 + npad * 12;
+  size_t per = 16 + npad * 4 + n_tiles * BIG_NB_MAX * 8 + n_tiles * BIG_NB_MAX * 4 + (BIG_NB_MAX + 1) * 4 + BIG_NB_MAX * 4 + npad * 12 +
+               (with_polar ? npad * 8 + 512 : 0);
   per = (per + 255) & ~(size_t)255;
   return per * n_scans + 4096;
 }
 
 int launch_ndt_build_big(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride,
-                         int ioff, const randt_cluster_params* cp, const MapView& out, int first_map, void* d_ws) {
+                         int ioff, const randt_cluster_params* cp, const MapView& out, int first_map, void* d_ws, const float* d_polar,
+                         const float* beam_cov9) {
   BigArgs A;
+  A.polar = d_polar;
+  A.sa = A.sr = nullptr;
+  for (int i = 0; i < 9; ++i) A.beam[i] = (d_polar && beam_cov9) ? beam_cov9[i] : 0.f;
   A.pts = d_points;
   A.n_pts_arr = d_n_points;
   A.pitch = pitch;
@@ -414,6 +448,10 @@ int launch_ndt_build_big(randt_ctx* ctx, const float* d_points, int n_scans, int
   A.sx = (float*)take(sizeof(float) * (size_t)A.npad * n_scans);
   A.sy = (float*)take(sizeof(float) * (size_t)A.npad * n_scans);
   A.si = (float*)take(sizeof(float) * (size_t)A.npad * n_scans);
+  if (d_polar) {
+    A.sa = (float*)take(sizeof(float) * (size_t)A.npad * n_scans);
+    A.sr = (float*)take(sizeof(float) * (size_t)A.npad * n_scans);
+  }
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(k_big_init, dim3((n_scans + 255) / 256), dim3(256), 0, st, A.range, n_scans);
   const dim3 tiles(A.n_tiles, n_scans);

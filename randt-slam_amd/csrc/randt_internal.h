@@ -88,10 +88,12 @@ struct DeviceGuard {
 
 // launchers implemented in the kernel TUs
 int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points,
-                     int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map);
-size_t ndt_build_big_ws_bytes(int n_scans, int pitch);
+                     int stride, int ioff, const randt_cluster_params* cp, const MapView& out, int first_map, const float* d_polar = nullptr,
+                     const float* beam_cov9 = nullptr);
+size_t ndt_build_big_ws_bytes(int n_scans, int pitch, int with_polar = 0);
 int launch_ndt_build_big(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride,
-                         int ioff, const randt_cluster_params* cp, const MapView& out, int first_map, void* d_ws);
+                         int ioff, const randt_cluster_params* cp, const MapView& out, int first_map, void* d_ws, const float* d_polar = nullptr,
+                         const float* beam_cov9 = nullptr);
 int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count, const double* d_pose4);
 int launch_maps_reindex(randt_ctx* ctx, const MapView& m, int first, int count);
 int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,

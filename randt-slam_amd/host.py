@@ -274,6 +274,20 @@ def ndt_build_batch(ctx, points, cluster, out_maps, first_map=0, n_points=None, 
                                                   out_maps._h, first_map), "randt_ndt_build_batch_dev")
 
 
+def ndt_build_pndt_batch(ctx, points, polar, beam_cov, cluster, out_maps, first_map=0, n_points=None, intensity_index=None):
+    """randt_ndt_build_pndt_batch_dev: pNDT cells (Cell::updateCell with use_pndt).  points: (B, N, S) float32 and polar:
+    (B, N, 2) float32 (angle, range) on the device; beam_cov: 3x3 (host)."""
+    import numpy as np
+
+    B, N, S = _shape3(points)
+    assert tuple(polar.shape) == (B, N, 2) and polar.is_contiguous()
+    ioff = (3 if S == 4 else 4) if intensity_index is None else intensity_index
+    beam = np.ascontiguousarray(np.asarray(beam_cov, dtype=np.float32).reshape(9))
+    ctx._check(ctx._lib.randt_ndt_build_pndt_batch_dev(ctx._h, _dptr(points), B, N, _dptr(n_points), S, ioff, _dptr(polar),
+                                                       beam.ctypes.data_as(C.c_void_p), C.byref(cluster), out_maps._h, first_map),
+               "randt_ndt_build_pndt_batch_dev")
+
+
 def associate_batch(ctx, fixed, fixed_idx, moving, moving_first, n_pairs, guess4, mp, corr):
     ctx._check(ctx._lib.randt_associate_batch_dev(ctx._h, fixed._h, _dptr(fixed_idx), moving._h, moving_first, n_pairs,
                                                   _dptr(guess4), C.byref(mp), _dptr(corr)), "randt_associate_batch_dev")
