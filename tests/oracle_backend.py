@@ -7,18 +7,20 @@ from util import IP
 
 
 class OracleBackend:
-    def __init__(self, scan_capacity=512):
+    def __init__(self, scan_capacity=512, params=None):
         self.scan_capacity = scan_capacity
+        self.ip = dict(IP) if params is None else dict(params)   # map / clustering parameter set (default: indoor preset)
         self.scans, self.subs = {}, {}
         self._next = 0
 
     def _map(self, cap=None):
-        return po.Map(IP["size_x"], IP["size_y"], IP["resolution"], (0, 0), IP["max_neighbour_dist"], IP["min_points_per_cell"], cap)
+        ip = self.ip
+        return po.Map(ip["size_x"], ip["size_y"], ip["resolution"], (0, 0), ip["max_neighbour_dist"], ip["min_points_per_cell"], cap)
 
     def build_scan(self, points):
         m = self._map(self.scan_capacity)
         pts = np.ascontiguousarray(points, dtype=np.float32)
-        m.build(pts, IP["n_clusters"], IP["max_range"], ioff=3 if pts.shape[1] == 4 else 4)
+        m.build(pts, self.ip["n_clusters"], self.ip["max_range"], ioff=3 if pts.shape[1] == 4 else 4)
         self._next += 1
         self.scans[self._next] = m
         return self._next

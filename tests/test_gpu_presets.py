@@ -254,3 +254,48 @@ def test_oxford_geometry_loop_closure_refinement(built):
         assert abs((dth + np.pi) % (2 * np.pi) - np.pi) <= POSE_TOL_R
         assert np.isclose(res["cost"][i], cost, rtol=1e-6) and res["n_residuals"][i] == st["n_residuals"]
     assert max(n_solves) >= 5          # the long GNC schedule really ran
+
+
+def test_oxford_preset_odometry_drive_end_to_end(built):
+    """parameters_oxford.yaml through the whole `processScan` call pattern on the device (not only the pair solve above): 3.5 m
+    cells on the 400 x 400 map, 10 m search window, min 10 points per cell, two neighbours, constant-velocity fixed-lag window
+    with covariance_scaling_factor 0.01 x motion_sqrtI diag(1, 1, 10, 1, 3, 0.1, 20, 60), ndt_weight 5000, GNC 2 steps / divisor
+    1.1 at scale 1, rejection gate 5 m / 2 rad, every second scan a keyframe, 20-state submaps with 10 states of overlap
+    (`config/parameters_oxford.yaml:41-47,52-57,59-87`) -- the synthetic world blown up by 7 and driven at 7 x the speed.  Pose
+    by pose against the same loop on the oracle, and against the truth."""
+    import torch
+    from oracle_backend import OracleBackend
+    from randt_slam_amd import odometry
+
+    ox = OXFORD
+    mapp, clu, n_clusters = _oxford_maps()
+    world = synth.make_world()
+    n_scans, dt = 56, 0.25
+    traj = synth.make_trajectory(3300, n_scans, step=0.25)
+    scans = [_scale_scan(synth.make_scan(world, traj[i], 14000 + i)) for i in range(n_scans)]
+    truth = traj.copy()
+    truth[:, :2] *= SCALE
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=2, gnc_divisor=1.1, loss_scale=1.0, mu_scale=1.0,
+                                  n_neighbours=ox["k"])
+    wp = R.window_params(motion_sqrtI_diag=(1, 1, 10, 1, 3, 0.1, 20, 60), covariance_scaling_factor=0.01, ndt_weight=5000.0,
+                         reject_t=5.0, reject_r=2.0, smoothing_steps=3, const_vel=1)
+    drive = dict(insertion_step=2, submap_size_poses=20, submap_overlap=10)
+    oip = dict(size_x=ox["size"], size_y=ox["size"], resolution=ox["resolution"], max_neighbour_dist=ox["max_neighbour"],
+               min_points_per_cell=ox["min_points"], n_clusters=n_clusters, max_range=ox["max_range"])
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    gpu = odometry.Odometry(odometry.HipBackend(ctx, mapp, clu), mp, wp, drive)
+    cpu = odometry.Odometry(OracleBackend(params=oip), mp, wp, drive)
+    origin_inv = synth.se2_inv3(truth[0])
+    worst_t = worst_r = 0.0
+    for i in range(n_scans):
+        pg = gpu.process_scan(scans[i], i * dt)
+        pc = cpu.process_scan(scans[i], i * dt)
+        worst_t = max(worst_t, np.abs(pg[2:] - pc[2:]).max())
+        worst_r = max(worst_r, abs(synth.wrap_angle(np.arctan2(pg[1], pg[0]) - np.arctan2(pc[1], pc[0]))))
+        assert worst_t <= POSE_TOL_T and worst_r <= POSE_TOL_R, (i, pg, pc)
+        rel = synth.se2_mul3(origin_inv, truth[i])
+        est = synth.pose4_to_pose3(pg)
+        assert np.all(np.abs(est[:2] - rel[:2]) < 0.25 * SCALE) and abs(synth.wrap_angle(est[2] - rel[2])) < 0.08, (i, est, rel)
+    assert gpu.n_finished_submaps == cpu.n_finished_submaps >= 2           # roll-overs with overlap happened
+    assert gpu.n_registrations == cpu.n_registrations and gpu.n_rejected == cpu.n_rejected
+    print("oxford preset drive: max deviation GPU vs oracle %.3e m, %.3e rad; %d submaps" % (worst_t, worst_r, gpu.n_finished_submaps))
