@@ -303,36 +303,88 @@ template <int L>
 __device__ __forceinline__ double bcast16(double v) {
   return __builtin_amdgcn_update_dpp(v, v, 0x150 + L, 0xf, 0xf, true);  // v_mov_b64_dpp row_newbcast:L
 }
-// d += (lane L of d's 16-lane row) * m.  Hazard (VALU write of the DPP source within 2 wait states) is the caller's: the
-// updates of one pivot step write distinct registers, an s_nop leads each step.
-template <int L>
-__device__ __forceinline__ void fmac_bcast(double& d, double m) {
-  asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(m), "n"(L));
+// One pivot step as ONE assembly block.  Updates: d += (lane JJ of d's 16-lane row) * m for the NC live columns behind the
+// pivot and the right-hand side -- v_fmac_f64 with the DPP row_newbcast modifier, which the compiler cannot emit (its DPP
+// combiner leaves 64-bit operations alone).  LA (look-ahead): the reciprocal of the NEXT pivot (hardware seed + two Newton
+// steps on its broadcast value, out in rpn) is woven between the updates, right behind the update of its column, so the
+// dependent rcp -> fma -> fma -> fma -> fma chain runs in the shadow of the other columns' updates instead of in front of
+// them.  Inline assembly is opaque to the compiler's hazard recogniser; the block keeps the gfx9 rules itself: 2 wait
+// states between a VALU write and a DPP read of the same register (updates write distinct registers; a leading s_nop
+// covers whatever the compiler placed in front), 1 wait state behind v_rcp_f64.  tools/check_dpp_hazards.py verifies
+// the built object.  (The case table is generated: operands 0 .. NC = C[JJ+1 .. JJ+NC], B.)
+template <int JJ, int NC, bool LA>
+__device__ __forceinline__ void pivot_group(double (&C)[16], double& B, double nf, double& rpn) {
+  [[maybe_unused]] double t0, t1 = 0.0, t2;
+  if constexpr (LA == true && NC == 1) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\ts_nop 0\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]" : "+v"(C[JJ + 1]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 2) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\ts_nop 0\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 3) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\ts_nop 0\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 4) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 5) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 6) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64 %[t1], %[t1], %[t2]" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 7) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 8) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 9) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 10) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 11) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 12) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %12, %12, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(C[JJ + 12]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 13) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %12, %12, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %13, %13, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(C[JJ + 12]), "+v"(C[JJ + 13]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 14) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %12, %12, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %13, %13, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %14, %14, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(C[JJ + 12]), "+v"(C[JJ + 13]), "+v"(C[JJ + 14]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == true && NC == 15) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %[t0], %0 row_newbcast:%[l1] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_rcp_f64 %[t1], %[t0]\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fma_f64 %[t2], -%[t0], %[t1], 1.0\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %12, %12, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %[t1], %[t1], %[t2]\n\tv_fmac_f64_dpp %13, %13, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %14, %14, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %15, %15, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(C[JJ + 12]), "+v"(C[JJ + 13]), "+v"(C[JJ + 14]), "+v"(C[JJ + 15]), "+v"(B), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2) : [m] "v"(nf), [l] "n"(JJ), [l1] "n"(JJ + 1));
+  if constexpr (LA == false && NC == 0) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 1) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 2) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 3) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 4) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 5) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 6) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 7) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 8) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 9) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 10) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 11) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 12) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %12, %12, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(C[JJ + 12]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 13) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %12, %12, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %13, %13, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(C[JJ + 12]), "+v"(C[JJ + 13]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 14) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %12, %12, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %13, %13, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %14, %14, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(C[JJ + 12]), "+v"(C[JJ + 13]), "+v"(C[JJ + 14]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA == false && NC == 15) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %2, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %4, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %5, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %6, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %7, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %8, %8, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %9, %9, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %10, %10, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %11, %11, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %12, %12, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %13, %13, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %14, %14, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %15, %15, %[m] row_newbcast:%[l] row_mask:0xf bank_mask:0xf" : "+v"(C[JJ + 1]), "+v"(C[JJ + 2]), "+v"(C[JJ + 3]), "+v"(C[JJ + 4]), "+v"(C[JJ + 5]), "+v"(C[JJ + 6]), "+v"(C[JJ + 7]), "+v"(C[JJ + 8]), "+v"(C[JJ + 9]), "+v"(C[JJ + 10]), "+v"(C[JJ + 11]), "+v"(C[JJ + 12]), "+v"(C[JJ + 13]), "+v"(C[JJ + 14]), "+v"(C[JJ + 15]), "+v"(B) : [m] "v"(nf), [l] "n"(JJ));
+  if constexpr (LA) rpn = t1;
 }
 // Gauss-Jordan step on pivot JJ of the band's first block: every other lane of the row (rows above, below and of the next
-// state) subtracts its multiple of the pivot row from columns JJ+1 .. W-1 and the right-hand side.
-template <int JJ, int W>
-__device__ __forceinline__ void band_pivot(double (&C)[16], double& B, double& RD, int l) {
-  const double rpb = fast_rcp(bcast16<JJ>(C[JJ]));
+// state) subtracts its multiple of the pivot row from columns JJ+1 .. W-1 and the right-hand side.  rpb: reciprocal of the
+// pivot, same in every lane of the row (in); of the next pivot (out, LA).
+template <int JJ, int W, bool LA>
+__device__ __forceinline__ void band_pivot(double (&C)[16], double& B, double& RD, int l, double& rpb) {
   const bool me = l == JJ;
   RD = me ? rpb : RD;
   const double cm = me ? 0.0 : C[JJ];
   const double nf = -(cm * rpb);
-  asm volatile("s_nop 1");
-#pragma unroll
-  for (int k = JJ + 1; k < W; ++k) fmac_bcast<JJ>(C[k], nf);
-  fmac_bcast<JJ>(B, nf);
+  pivot_group<JJ, W - 1 - JJ, LA>(C, B, nf, rpb);
+}
+// sz (uniform): tangent dimensions of the block's state; the padding rows behind them are identity rows nobody couples to,
+// their pivot steps are skipped (constant-velocity windows: 3 + 6 + 6 + 6 of 4 x 8)
+// SZ: tangent dimensions of the block's state, compile-time for the shipped layouts (constant velocity 3 | 6 6 6, constant
+// acceleration 5 | 8 8 8): straight-line code -- with run-time skips the register allocator shuffled the live columns
+// through copies at every join.  The padding rows behind SZ are identity rows nobody couples to; their pivot steps are skipped.
+template <int W, int SZ>
+__device__ __forceinline__ void band_block_n(double (&C)[16], double& B, double& RD, int l) {
+  double rpb = fast_rcp(bcast16<0>(C[0]));
+  band_pivot<0, W, (SZ > 1)>(C, B, RD, l, rpb);
+  if constexpr (SZ > 1) band_pivot<1, W, (SZ > 2)>(C, B, RD, l, rpb);
+  if constexpr (SZ > 2) band_pivot<2, W, (SZ > 3)>(C, B, RD, l, rpb);
+  if constexpr (SZ > 3) band_pivot<3, W, (SZ > 4)>(C, B, RD, l, rpb);
+  if constexpr (SZ > 4) band_pivot<4, W, (SZ > 5)>(C, B, RD, l, rpb);
+  if constexpr (SZ > 5) band_pivot<5, W, (SZ > 6)>(C, B, RD, l, rpb);
+  if constexpr (SZ > 6) band_pivot<6, W, (SZ > 7)>(C, B, RD, l, rpb);
+  if constexpr (SZ > 7) band_pivot<7, W, false>(C, B, RD, l, rpb);
 }
 template <int W>
-__device__ __forceinline__ void band_block(double (&C)[16], double& B, double& RD, int l) {
-  band_pivot<0, W>(C, B, RD, l);
-  band_pivot<1, W>(C, B, RD, l);
-  band_pivot<2, W>(C, B, RD, l);
-  band_pivot<3, W>(C, B, RD, l);
-  band_pivot<4, W>(C, B, RD, l);
-  band_pivot<5, W>(C, B, RD, l);
-  band_pivot<6, W>(C, B, RD, l);
-  band_pivot<7, W>(C, B, RD, l);
+__device__ __forceinline__ void band_block(double (&C)[16], double& B, double& RD, int l, int sz) {
+  switch (sz) {  // uniform
+    case 3: band_block_n<W, 3>(C, B, RD, l); break;
+    case 5: band_block_n<W, 5>(C, B, RD, l); break;
+    case 6: band_block_n<W, 6>(C, B, RD, l); break;
+    case 7: band_block_n<W, 7>(C, B, RD, l); break;
+    default: band_block_n<W, 8>(C, B, RD, l); break;  // any other size <= 8: identity padding pivots are harmless
+  }
 }
 
 struct Shared {
@@ -365,7 +417,7 @@ struct Shared {
   double dd[WIN_NMAX];
   double cst[2];
   double xfer[8][10];
-  double xsol[8];
+  int bsize[WIN_SMAX + 1];  // tangent dimensions of state b
   int band_ok;
   Loss loss;  // robust loss of the running GNC step (uniform; in LDS so that it does not occupy ~20 registers across the solve)
 };
@@ -835,7 +887,10 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
     sh.boff[17][tid] = (l < 8 && br <= S) ? trow : -1;
     if (tid == 0) {
       int okb = 1;
-      for (int j = 0; j <= S; ++j) okb &= (bstart(j + 1) - bstart(j) <= 8) ? 1 : 0;
+      for (int j = 0; j <= S; ++j) {
+        okb &= (bstart(j + 1) - bstart(j) <= 8) ? 1 : 0;
+        sh.bsize[j] = bstart(j + 1) - bstart(j);
+      }
 #ifdef RANDT_WIN_NO_BAND
       okb = 0;
 #endif
@@ -1089,6 +1144,11 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           wave_fence();
           WT(8);
           double okf = 1.0;
+#ifndef RANDT_WIN_REPEAT_SOLVE
+#define RANDT_WIN_REPEAT_SOLVE 1  // > 1: cost probe (the solve is idempotent: same inputs, same outputs)
+#endif
+#pragma nounroll
+          for (int rpt = 0; rpt < RANDT_WIN_REPEAT_SOLVE; ++rpt)
           if (band_ok) {
             // ---- banded block Gauss-Jordan with DPP broadcasts (see band_pivot above)
             const char* const sbase = reinterpret_cast<const char*>(&sh);
@@ -1103,8 +1163,10 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
             const int trow = boffv[17];
             const int l = lane & 15, br = lane >> 4;
             double RD = 0.0, X = 0.0;
+
 #pragma nounroll
             for (int b = 0; b <= S; ++b) {
+              const int bsz = __builtin_amdgcn_readfirstlane(sh.bsize[b]);
               if (br == b) {
                 if (b > 0 && l < 8) {  // rows of state b as block step b - 1 left them
 #pragma unroll
@@ -1113,14 +1175,14 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
                 }
                 asm volatile("s_nop 4");
                 if (b < S) {
-                  band_block<16>(C, B, RD, l);
+                  band_block<16>(C, B, RD, l, bsz);
                   if (l >= 8) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) sh.xfer[l - 8][k] = C[8 + k];
                     sh.xfer[l - 8][8] = B;
                   }
                 } else {
-                  band_block<8>(C, B, RD, l);  // last state: nothing behind it
+                  band_block<8>(C, B, RD, l, bsz);  // last state: nothing behind it
                 }
               }
               wave_fence();

@@ -3,7 +3,7 @@
 
 The fused `v_fmac_f64_dpp` updates are inline assembly, which the compiler's hazard recogniser cannot see into: on gfx9 a
 VALU write of a VGPR must be followed by 2 wait states before a DPP instruction reads it.  This script disassembles the
-object and verifies, for every v_fmac_f64_dpp, that none of the instructions within the two preceding wait states writes
+object and verifies, for every 64-bit DPP instruction, that none of the instructions within the two preceding wait states writes
 its DPP source registers.  Usage: tools/check_dpp_hazards.py [path/to/window.o]; exit code 1 on a violation."""
 import os
 import re
@@ -42,11 +42,11 @@ def check(text):
         ins.append(line)
     n_dpp, bad = 0, []
     for i, line in enumerate(ins):
-        if not line.startswith("v_fmac_f64_dpp"):
+        if not line.startswith(("v_fmac_f64_dpp", "v_mov_b64_dpp")):
             continue
         n_dpp += 1
         ops = [t.strip() for t in line.split(None, 1)[1].split(",")]
-        src = regs(ops[1].split()[0])
+        src = regs(ops[1].split()[0])   # the DPP operand is src0
         wait, j = 0, i - 1
         while wait < 2 and j >= 0:
             p = ins[j]
@@ -65,7 +65,7 @@ def check(text):
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "randt-slam_amd", "csrc", "window.o")
     n, bad = check(disassemble(lib))
-    print("%d v_fmac_f64_dpp instructions, %d hazard violations" % (n, len(bad)))
+    print("%d 64-bit DPP instructions (v_fmac_f64_dpp / v_mov_b64_dpp), %d hazard violations" % (n, len(bad)))
     for a, b in bad:
         print("  ", a, "->", b)
     sys.exit(1 if bad or n == 0 else 0)

@@ -87,6 +87,11 @@ KERNEL_D(k_rcp_f64, "v_rcp_f64 %0, %0")
 KERNEL_D(k_rsq_f64, "v_rsq_f64 %0, %0")
 KERNEL_D(k_lshl_b64, "v_lshlrev_b64 %0, 1, %0")
 KERNEL_CVT(k_cvt_f64_f32, "v_cvt_f64_f32 %0, %1")
+// 64-bit ALU with the DPP row_newbcast modifier (gfx90a+: the only DPP control the DP ALU takes) -- the window solve's
+// pivot-row broadcast (csrc/window.hip, pivot_group)
+KERNEL_D(k_fmac_f64, "v_fmac_f64 %0, %1, %2")
+KERNEL_D(k_fmac_f64_dpp, "v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf")
+KERNEL_D(k_mov_b64_dpp, "v_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf")
 
 __global__ __launch_bounds__(256) void k_readlane(double* out, double seed) {
   float a = (float)seed + threadIdx.x;
@@ -126,6 +131,8 @@ int main() {
       {"v_readlane_b32", k_readlane, "move"}, {"v_fma_f64", k_fma_f64, "fp64"},        {"v_mul_f64", k_mul_f64, "fp64"},
       {"v_add_f64", k_add_f64, "fp64"},       {"v_max_f64", k_max_f64, "fp64"},        {"v_rcp_f64", k_rcp_f64, "trans_f64"},
       {"v_rsq_f64", k_rsq_f64, "trans_f64"},  {"v_lshlrev_b64", k_lshl_b64, "int64"},  {"v_cvt_f64_f32", k_cvt_f64_f32, "cvt"},
+      {"v_fmac_f64", k_fmac_f64, "fp64"},     {"v_fmac_f64_dpp(row_newbcast)", k_fmac_f64_dpp, "fp64_dpp"},
+      {"v_mov_b64_dpp(row_newbcast)", k_mov_b64_dpp, "move64_dpp"},
   };
   const int n = sizeof(probes) / sizeof(probes[0]);
   hipEvent_t e0, e1;
@@ -167,6 +174,22 @@ int main() {
     CHECK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
     printf("single_workgroup_v_fma_f64,us_per_launch %.2f,ticks_per_wave_instr %.3f (1 wave per SIMD),ticks_per_us %.1f\n", ms * 1e3 / 20,
            h[1] / ((double)ITERS * CHAINS), h[1] / (ms * 1e3 / 20));
+  }
+  // the same instruction kinds issued by ONE wavefront on an otherwise idle chip (8 independent chains): what the serial
+  // phases of the window solve pay per instruction
+  printf("lone_wavefront: instruction,ticks_per_wave_instr,ticks_per_us\n");
+  for (int p = 0; p < n; ++p) {
+    hipLaunchKernelGGL(probes[p].k, dim3(1), dim3(64), 0, 0, d_out, 1.5);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(probes[p].k, dim3(1), dim3(64), 0, 0, d_out, 1.5);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    double h[2] = {0, 0};
+    CHECK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
+    printf("lone_wavefront: %s,%.3f,%.1f\n", probes[p].name, h[1] / ((double)ITERS * CHAINS), h[1] / (ms * 1e3));
   }
   (void)simds;
   return 0;
