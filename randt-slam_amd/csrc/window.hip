@@ -519,16 +519,19 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
 #pragma unroll
       for (int i = 0; i < 10; ++i) a10[i] = 0.0;
       // A lone workgroup has nothing to hide memory latency behind: a trip used to be index load -> record loads ->
-      // arithmetic, two exposed L2 round trips each.  Trips are taken three at a time: the indices of the first group
-      // are kept in registers for the whole solve, and all 18 record loads of a group are in flight before the first
-      // residual is evaluated.
+      // arithmetic, two exposed L2 round trips each.  The correspondences of a lane's first three trips are kept in
+      // registers for the whole solve (the association is frozen); WIN_TRIP_GROUP > 1 additionally puts the record loads of
+      // several trips in flight together (measured: the registers that costs lose more elsewhere -- the NDT wavefronts,
+      // ~2.1 us per pass, are the pass's critical path, the factor wavefront needs ~1.7 us; software-pipelining the
+      // next trip's records behind the current residual spilled and lost 2 %).
       for (int s0 = T.first, grp = 0; s0 < n_slots; s0 += WIN_TRIP_GROUP * T.stride, ++grp) {
         int ci[WIN_TRIP_GROUP];
         bool val[WIN_TRIP_GROUP];
 #pragma unroll
         for (int t = 0; t < WIN_TRIP_GROUP; ++t) {
           const int slot = s0 + t * T.stride + lane;
-          ci[t] = grp == 0 ? T.ci0[t] : (slot < n_slots ? pc[slot] : -1);
+          const int tix = grp * WIN_TRIP_GROUP + t;  // trip number of this wavefront
+          ci[t] = tix < 3 ? (tix == 0 ? T.ci0[0] : (tix == 1 ? T.ci0[1] : T.ci0[2])) : (slot < n_slots ? pc[slot] : -1);
           val[t] = ci[t] >= 0 && ci[t] < fixed.cap;
         }
         float4 mrec[WIN_TRIP_GROUP][3], frec[WIN_TRIP_GROUP][3];
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       T.pc = corr + (size_t)t * moving.cap * W.k;
     }
 #pragma unroll
-    for (int q = 0; q < WIN_TRIP_GROUP; ++q) {
+    for (int q = 0; q < 3; ++q) {
       const int slot = T.first + q * T.stride + lane;
       T.ci0[q] = (T.active && slot < T.n_slots) ? T.pc[slot] : -1;
     }
