@@ -156,7 +156,10 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
   float aff[4];
   pose_to_affine_f(guess4 + 4 * (size_t)pair, aff);
 
-  for (int c0 = 0; c0 < M; c0 += ASSOC_CH) {
+  // chunks are independent (a moving cell's correspondences depend on nothing but the pair's pose): a small batch spreads
+  // the chunks of a pair over gridDim.y workgroups (a lone pair of 75 cells = two chunks used to cost 37 us of latency in
+  // front of every fixed-lag window solve)
+  for (int c0 = (int)blockIdx.y * ASSOC_CH; c0 < M; c0 += (int)gridDim.y * ASSOC_CH) {
     const int nch = M - c0 < ASSOC_CH ? M - c0 : ASSOC_CH;
     __syncthreads();  // previous chunk fully consumed (also orders P0 before first use)
     ASSOC_TICK(0);
@@ -491,15 +494,22 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   const int full = (use_intensity && lookup_mahalanobis) ? 1 : 0;
   const bool stage = ctx->assoc_stage_grid && assoc_lds_bytes(fixed.n_slots, true) <= (size_t)ctx->lds_limit / 2;
   const size_t lds = assoc_lds_bytes(fixed.n_slots, stage);
+  // small batches: one workgroup per (pair, chunk); large ones fill the chip by pairs alone
+  int split = 1;
+  if (n_pairs <= 64) {
+    split = (moving.cap + ASSOC_CH - 1) / ASSOC_CH;
+    if (split > 8) split = 8;
+    if (split < 1) split = 1;
+  }
   if (stage) {
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_associate<true>, dim3(n_pairs), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
+    hipLaunchKernelGGL(k_associate<true>, dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
                        moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr);
   } else {
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_associate<false>, dim3(n_pairs), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
+    hipLaunchKernelGGL(k_associate<false>, dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
                        moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr);
   }
   RANDT_HIP_CHECK(ctx, hipGetLastError());
