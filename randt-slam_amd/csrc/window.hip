@@ -49,6 +49,9 @@ extern "C" int randt_debug_win_timing(long long* out) {
 #define WIN_NDT_WAVES 6  // wavefronts that stream NDT slots during a pass (wavefront 6: motion / IMU factors)
 #define WIN_NMAX 32  // tangent dimensions
 #define WIN_SMAX 3   // optimised states
+#ifndef WIN_LEVELS
+#define WIN_LEVELS 6  // damped solves taken at once, one wavefront each: the running radius and the next five a rejection chain visits (<= 6: wavefronts 0..5)
+#endif
 
 using namespace randt_solve;
 
@@ -402,9 +405,10 @@ struct Shared {
   double J2[2][WIN_SMAX][16];             // IMU factors
   double r2[2][WIN_SMAX][2];
   double H[WIN_NMAX * WIN_NMAX];
-  double A[WIN_NMAX * WIN_NMAX];
   double Hs[WIN_NMAX * WIN_NMAX];
-  double g[WIN_NMAX], gs[WIN_NMAX], sigma[WIN_NMAX], diag[WIN_NMAX], step[WIN_NMAX], delta[WIN_NMAX], col[WIN_NMAX];
+  double g[WIN_NMAX], gs[WIN_NMAX], sigma[WIN_NMAX], diag[WIN_NMAX];
+  double step[WIN_LEVELS][WIN_NMAX], delta[WIN_LEVELS][WIN_NMAX];  // level q: the step for the radius after q rejections (band_solve)
+  double solved[WIN_LEVELS];                    // the solve succeeded (pivots positive, step finite)
   double red[2][WIN_WAVES][34];
   double scal[8];  // 0 mcc, 1 sn2, 2 x_norm, 3 solved, 4 gconv
   int lcol[WIN_SMAX][WIN_NMAX];   // tangent column -> local column of motion factor f (-1 none)
@@ -413,10 +417,10 @@ struct Shared {
   int wave_state[WIN_WAVES];      // state of the NDT term wavefront w streams (-1: none)
   // banded block solve (band_solve below): per-lane LDS byte offsets of the 16 band columns + right-hand side, the lane's
   // tangent row (-1: padding), damped diagonal, constants 0 / 1 for padding entries, hand-over buffers between block steps
-  int boff[18][64];
-  double dd[WIN_NMAX];
+  int boff[18][64];      // bit 0 set: the entry is the row's damped diagonal, in dd[level]
+  double dd[WIN_LEVELS][WIN_NMAX];
   double cst[2];
-  double xfer[8][10];
+  double xfer[WIN_LEVELS][8][10];
   int bsize[WIN_SMAX + 1];  // tangent dimensions of state b
   int band_ok;
   Loss loss;  // robust loss of the running GNC step (uniform; in LDS so that it does not occupy ~20 registers across the solve)
@@ -640,7 +644,7 @@ __device__ __forceinline__ void pose_T(const double* xp, double T[3][3]) {
 // have_sigma: the Jacobi scaling of this solve is known (every assembly but the first of a solve): the scaled copies
 // Hs / gs are written in the same pass instead of by wavefront 0 afterwards.
 __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* rsum /* per-wavefront base sums of the pass */,
-                         bool have_sigma) {
+                         bool have_sigma, double dmin, double dmax) {
   const int n = W.n_tan, tid = threadIdx.x;
   const bool dg = sh.sq_diag != 0;
   const double(*J)[128] = dg ? sh.Ju[buf] : sh.Jf[buf];
@@ -687,6 +691,7 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* rs
       const double hs = h * sh.sigma[a] * sh.sigma[b];
       sh.Hs[a * n + b] = hs;
       sh.Hs[b * n + a] = hs;
+      if (a == b) sh.diag[a] = fmin(fmax(hs, dmin), dmax);  // LM diagonal of the new point
     }
   }
   if (tid >= WIN_BLOCK - n) {  // the gradient on the block's last threads (idle above unless n = 32)
@@ -774,6 +779,86 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
   }
 }
 
+// The damped solve (H_s + D / radius) y = g_s by the banded block Gauss-Jordan (band_pivot above), one wavefront per LEVEL:
+// level 0 is the radius of the running iteration, level q the radius q rejections later (radius / decrease, decrease doubling).
+// A rejected -- or invalid -- step changes nothing but the radius, and with Ceres' default initial radius of 1e4 more than half
+// of all iterations of these windows are rejections (the first five of every GNC step): wavefronts 0..5 are idle during the
+// solve anyway, so the next radii cost (almost) no time and the following rejected iterations start from a finished step.  Own scratch per level; results in step[q] / delta[q] / solved[q].
+__device__ __forceinline__ void band_solve(Shared& sh, int n, int S, int lane, double inv_radius, int Q) {
+  if (lane < n) sh.dd[Q][lane] = sh.Hs[lane * n + lane] + sh.diag[lane] * inv_radius;
+  wave_fence();
+  double okf = 1.0;
+  {
+            // ---- banded block Gauss-Jordan with DPP broadcasts (see band_pivot above)
+            const char* const sbase = reinterpret_cast<const char*>(&sh);
+            int boffv[18];
+#pragma unroll
+            for (int k = 0; k < 18; ++k) boffv[k] = sh.boff[k][lane];
+            {
+              const int dshift = Q * (int)sizeof(sh.dd[0]) - 1;  // flagged entries: this level's damped diagonal
+#pragma unroll
+              for (int k = 0; k < 16; ++k) boffv[k] += (boffv[k] & 1) ? dshift : 0;
+            }
+            double C[16], B;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) C[k] = *reinterpret_cast<const double*>(sbase + boffv[k]);
+            B = *reinterpret_cast<const double*>(sbase + boffv[16]);
+            const int trow = boffv[17];
+            const int l = lane & 15, br = lane >> 4;
+            double RD = 0.0, X = 0.0;
+
+#pragma nounroll
+            for (int b = 0; b <= S; ++b) {
+              const int bsz = __builtin_amdgcn_readfirstlane(sh.bsize[b]);
+              if (br == b) {
+                if (b > 0 && l < 8) {  // rows of state b as block step b - 1 left them
+#pragma unroll
+                  for (int k = 0; k < 8; ++k) C[k] = sh.xfer[Q][l][k];
+                  B = sh.xfer[Q][l][8];
+                }
+                asm volatile("s_nop 4");
+                if (b < S) {
+                  band_block<16>(C, B, RD, l, bsz);
+                  if (l >= 8) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) sh.xfer[Q][l - 8][k] = C[8 + k];
+                    sh.xfer[Q][l - 8][8] = B;
+                  }
+                } else {
+                  band_block<8>(C, B, RD, l, bsz);  // last state: nothing behind it
+                }
+              }
+              wave_fence();
+            }
+            // rows of state b: diagonal in their own columns now; x_b = (B - U x_{b+1}) / d, last state first.  The next
+            // state's solution sits in lanes 0..7 of the next DPP row: eight uniform values, fetched with v_readlane
+            // (no LDS round trip on this dependent chain).
+#pragma nounroll
+            for (int b = S; b >= 0; --b) {
+              double a0 = B, a1 = 0.0;
+              if (b < S) {
+                const int src = 16 * (b + 1);
+#pragma unroll
+                for (int m = 0; m < 8; m += 2) {
+                  a0 = fma(-C[8 + m], readlane_f64(X, src + m), a0);
+                  a1 = fma(-C[9 + m], readlane_f64(X, src + m + 1), a1);
+                }
+              }
+              const double xb = (a0 + a1) * RD;
+              X = br == b ? xb : X;
+            }
+            const bool real = trow >= 0;
+            const double st = -X;
+            okf = wave_any(real && !(RD > 0.0)) != 0.0 ? 0.0 : 1.0;
+            const double fin = 1.0 - wave_any(real && !isfinite(st));
+            if (real) {
+              sh.step[Q][trow] = st;
+              sh.delta[Q][trow] = st * sh.sigma[trow];
+            }
+            if (lane == 0) sh.solved[Q] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
+  }
+}
+
 // Dense fallback of the damped solve (windows whose state blocks exceed 8 tangent dimensions, i.e. with the IMU bias):
 // Gauss-Jordan elimination entirely in registers.  Lane i keeps row i of A and gs_i; after every step all rows are shifted
 // left by one column, so the pivot column is ALWAYS register 0 and no register is indexed dynamically: step j broadcasts
@@ -818,10 +903,10 @@ __device__ __noinline__ void gj_dense_solve(Shared& sh, int n, double inv_radius
     const double st = lane < n ? -(b * fast_rcp(dg)) : 0.0;
     const double fin = 1.0 - wave_any(!isfinite(st));
     if (lane < n) {
-      sh.step[lane] = st;
-      sh.delta[lane] = st * sh.sigma[lane];
+      sh.step[0][lane] = st;
+      sh.delta[0][lane] = st * sh.sigma[lane];
     }
-    if (lane == 0) sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
+    if (lane == 0) sh.solved[0] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
   }
 }
 
@@ -882,7 +967,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
     for (int k = 0; k < 16; ++k) {
       const int cb = br + (k >> 3), cm = k & 7, tc = tix(cb, cm);
       int off;
-      if (trow >= 0 && tc >= 0) off = trow == tc ? off_of(&sh.dd[trow]) : off_of(&sh.Hs[tc * n + trow]);
+      if (trow >= 0 && tc >= 0) off = trow == tc ? (off_of(&sh.dd[0][trow]) | 1) : off_of(&sh.Hs[tc * n + trow]);
       else off = off_of(&sh.cst[(rb == cb && rm == cm) ? 1 : 0]);
       sh.boff[k][tid] = off;
     }
@@ -1037,7 +1122,8 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       __syncthreads();
       // ================= one ceres::Solve =================
       double radius = P.r0, decrease = 2.0;
-      bool reuse = false, step_ok = true;
+      bool step_ok = true;
+      int lvl = 0, n_lvl = 0;  // damped solves in stock: level lvl of n_lvl is the running radius
       int num_invalid = 0, iteration = 0;
       double minimum_cost = DBL_MAX;
       const double* rs_cur;  // per-wavefront NDT base sums at the current point
@@ -1058,7 +1144,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       }
       if (res.gnc_solves == 0) res.initial_cost = cost;
       summary_min = cost;
-      assemble(W, sh, p, rs_cur, false);
+      assemble(W, sh, p, rs_cur, false, P.dmin, P.dmax);
       WT(3);
       bool first = true, need_scale = true;
       double x_norm = 0.0;
@@ -1112,7 +1198,11 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           }
           if (lane < n) sh.gs[lane] = sh.g[lane] * sh.sigma[lane];
           wave_fence();
+          // LM diagonal: a function of the scaled J^T J alone (Ceres keeps it across rejected steps -- the same values)
+          if (lane < n) sh.diag[lane] = fmin(fmax(sh.Hs[lane * n + lane], P.dmin), P.dmax);
+          wave_fence();
         }
+        if (need_scale && first) __syncthreads();  // first assembly of a solve: wavefront 0 scaled it; wavefronts 1..3 solve from it too
         if (need_scale) {
           need_scale = false;
           first = false;
@@ -1126,101 +1216,40 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         ++iteration;
         res.iterations++;
 
-        // ---- (wave 0) LevenbergMarquardtStrategy::ComputeStep: damped normal equations
-        if (wave == 0) {
-          const double inv_radius = fast_rcp(radius);
-          // the band solve's per-lane offsets do not depend on anything below: requested ahead of the fence
-          int boffv[18];
-#ifdef RANDT_WIN_PREFETCH_BOFF
-          if (band_ok) {
-#pragma unroll
-            for (int k = 0; k < 18; ++k) boffv[k] = sh.boff[k][lane];
-          }
+        // ---- LevenbergMarquardtStrategy::ComputeStep: damped normal equations -- for this radius and, at no extra time, for
+        // the radii the next rejections lead to (band_solve).  Skipped while such a level is still in stock.
+        if (lvl >= n_lvl) {
+          lvl = 0;
+          // Several wavefronts solving at once run measurably slower than one alone (config 3: always six levels 2.5 % worse
+          // than this policy), so the stock is only laid in where rejections come in chains: at the first iteration of a solve
+          // (Ceres' initial radius 1e4 is shrunk five times before the first step of every GNC step is accepted) and after a
+          // rejection; behind an accepted step the next one is usually accepted too and the wavefront solves alone.
+          n_lvl = (band_ok && (iteration <= 1 || !step_ok)) ? WIN_LEVELS : 1;
+#ifdef RANDT_WIN_NO_SPEC
+          n_lvl = 1;
 #endif
-          if (lane < n) {
-            // LM diagonal (kept while steps are rejected) and the damped diagonal in one go
-            const double hd = sh.Hs[lane * n + lane];
-            const double dgv = reuse ? sh.diag[lane] : fmin(fmax(hd, P.dmin), P.dmax);
-            if (!reuse) sh.diag[lane] = dgv;
-            sh.dd[lane] = hd + dgv * inv_radius;
-          }
-          wave_fence();
-          WT(8);
-          double okf = 1.0;
+          if (wave < n_lvl) {
+            double rr = radius, dc = decrease;  // the reference's update, replayed: radius /= decrease; decrease *= 2
+            for (int q = 0; q < wave; ++q) {
+              rr = rr / dc;
+              dc *= 2.0;
+            }
+            const double inv_radius = fast_rcp(rr);
+            WT(8);
 #ifndef RANDT_WIN_REPEAT_SOLVE
 #define RANDT_WIN_REPEAT_SOLVE 1  // > 1: cost probe (the solve is idempotent: same inputs, same outputs)
 #endif
 #pragma nounroll
-          for (int rpt = 0; rpt < RANDT_WIN_REPEAT_SOLVE; ++rpt)
-          if (band_ok) {
-            // ---- banded block Gauss-Jordan with DPP broadcasts (see band_pivot above)
-            const char* const sbase = reinterpret_cast<const char*>(&sh);
-#ifndef RANDT_WIN_PREFETCH_BOFF
-#pragma unroll
-            for (int k = 0; k < 18; ++k) boffv[k] = sh.boff[k][lane];
-#endif
-            double C[16], B;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) C[k] = *reinterpret_cast<const double*>(sbase + boffv[k]);
-            B = *reinterpret_cast<const double*>(sbase + boffv[16]);
-            const int trow = boffv[17];
-            const int l = lane & 15, br = lane >> 4;
-            double RD = 0.0, X = 0.0;
-
-#pragma nounroll
-            for (int b = 0; b <= S; ++b) {
-              const int bsz = __builtin_amdgcn_readfirstlane(sh.bsize[b]);
-              if (br == b) {
-                if (b > 0 && l < 8) {  // rows of state b as block step b - 1 left them
-#pragma unroll
-                  for (int k = 0; k < 8; ++k) C[k] = sh.xfer[l][k];
-                  B = sh.xfer[l][8];
-                }
-                asm volatile("s_nop 4");
-                if (b < S) {
-                  band_block<16>(C, B, RD, l, bsz);
-                  if (l >= 8) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) sh.xfer[l - 8][k] = C[8 + k];
-                    sh.xfer[l - 8][8] = B;
-                  }
-                } else {
-                  band_block<8>(C, B, RD, l, bsz);  // last state: nothing behind it
-                }
-              }
-              wave_fence();
+            for (int rpt = 0; rpt < RANDT_WIN_REPEAT_SOLVE; ++rpt)
+            if (band_ok) {
+              band_solve(sh, n, S, lane, inv_radius, wave);
+            } else {
+              gj_dense_solve(sh, n, inv_radius, lane);
             }
-            // rows of state b: diagonal in their own columns now; x_b = (B - U x_{b+1}) / d, last state first.  The next
-            // state's solution sits in lanes 0..7 of the next DPP row: eight uniform values, fetched with v_readlane
-            // (no LDS round trip on this dependent chain).
-#pragma nounroll
-            for (int b = S; b >= 0; --b) {
-              double a0 = B, a1 = 0.0;
-              if (b < S) {
-                const int src = 16 * (b + 1);
-#pragma unroll
-                for (int m = 0; m < 8; m += 2) {
-                  a0 = fma(-C[8 + m], readlane_f64(X, src + m), a0);
-                  a1 = fma(-C[9 + m], readlane_f64(X, src + m + 1), a1);
-                }
-              }
-              const double xb = (a0 + a1) * RD;
-              X = br == b ? xb : X;
-            }
-            const bool real = trow >= 0;
-            const double st = -X;
-            okf = wave_any(real && !(RD > 0.0)) != 0.0 ? 0.0 : 1.0;
-            const double fin = 1.0 - wave_any(real && !isfinite(st));
-            if (real) {
-              sh.step[trow] = st;
-              sh.delta[trow] = st * sh.sigma[trow];
-            }
-            if (lane == 0) sh.scal[3] = (okf != 0.0 && fin != 0.0) ? 1.0 : 0.0;
-          } else {
-            gj_dense_solve(sh, n, inv_radius, lane);
+            WT(9);
           }
-          WT(9);
         }
+        const int cs = lvl;
         __syncthreads();  // publishes: step / delta / scal[3] (wave 0), gradient test and ||x|| (wave 1), Hs / gs of a first assembly
         x_norm = sh.scal[2];
         if (step_ok && uni(sh.scal[4] != 0.0)) { res.iterations--; term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
@@ -1231,27 +1260,27 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           if (lane < n) {
             double hs = 0.0;
 #pragma unroll 8
-            for (int b = 0; b < n; ++b) hs += sh.Hs[b * n + lane] * sh.step[b];  // symmetric: column read, conflict-free
-            t = sh.step[lane] * (sh.gs[lane] + 0.5 * hs);
+            for (int b = 0; b < n; ++b) hs += sh.Hs[b * n + lane] * sh.step[cs][b];  // symmetric: column read, conflict-free
+            t = sh.step[cs][lane] * (sh.gs[lane] + 0.5 * hs);
           }
           const double mcc = -wave_sum(t);
           if (lane == 0) sh.scal[0] = mcc;
         } else if (wave == 0) {
           WT(10);
-          plus_states(W, sh, p, 1 - p, sh.delta, 1.0, lane);
+          plus_states(W, sh, p, 1 - p, sh.delta[cs], 1.0, lane);
           WT(11);
         }
         __syncthreads();
         WT(5);
-        reuse = true;
         const double mcc = sh.scal[0];
-        const bool valid = uni(sh.scal[3] != 0.0 && mcc > 0.0);
+        const bool valid = uni(sh.solved[cs] != 0.0 && mcc > 0.0);
         if (!valid) {
           // ---- HandleInvalidStep
           if (++num_invalid >= P.max_invalid) { term = RANDT_TERM_FAILURE; break; }
           radius = radius / decrease;
           decrease *= 2.0;
           step_ok = false;
+          ++lvl;  // an invalid step shrinks the radius like a rejection: the next level is that radius
           summary_min = fmin(summary_min, cost);
           trace_push(tr, trace_len, cost, radius, 3);
           __syncthreads();
@@ -1284,7 +1313,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           p = 1 - p;
           cost = cand_cost;
           WT(6);
-          assemble(W, sh, p, rs_cand, true);
+          assemble(W, sh, p, rs_cand, true, P.dmin, P.dmax);
           WT(3);
           need_scale = true;
           step_ok = true;
@@ -1292,13 +1321,14 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
           radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
           radius = fmin(P.rmax, radius);
           decrease = 2.0;
-          reuse = false;
+          n_lvl = 0;  // new point, new normal equations
           summary_min = fmin(summary_min, cost);
           trace_push(tr, trace_len, cost, radius, 1);
         } else {
           step_ok = false;
           radius = radius / decrease;
           decrease *= 2.0;
+          ++lvl;  // the step for exactly this radius may already be solved
           summary_min = fmin(summary_min, cand_cost);
           trace_push(tr, trace_len, cand_cost, radius, 2);
           __syncthreads();
