@@ -46,7 +46,19 @@ extern "C" int randt_debug_win_timing(long long* out) {
 
 #define WIN_BLOCK 512
 #define WIN_WAVES 8
-#define WIN_NDT_WAVES 6  // wavefronts that stream NDT slots during a pass (wavefront 6: motion / IMU factors)
+#define WIN_NDT_WAVES 6  // wavefronts that stream NDT slots during a pass
+// Roles of the eight wavefronts in a pass.  Wavefronts w and w + 4 share a SIMD, and with three terms a term's first share
+// has three 64-slot trips, its second two: the heavy shares go to wavefronts 0, 1, 3, their SIMD partners 4, 5, 7 take the
+// light ones, and SIMD 2 holds the factor wavefront (6) next to the one (2) that only takes the step norm.
+#define WIN_FACTOR_WAVE 6
+#define WIN_SPARE_WAVE 2
+__device__ __forceinline__ int ndt_share_of_wave(int wave) {  // 0..5 = share (term = share / wpt, part = share % wpt), -1: none
+#ifdef RANDT_WIN_PLAIN_ROLES
+  return wave == 7 ? 5 : (wave == 2 ? -1 : (wave < 2 ? wave : (wave < 6 ? wave - 1 : -1)));  // 0 1 . 2 3 4 F 5
+#else
+  return wave == 0 ? 0 : (wave == 4 ? 1 : (wave == 1 ? 2 : (wave == 5 ? 3 : (wave == 3 ? 4 : (wave == 7 ? 5 : -1)))));
+#endif
+}
 #define WIN_NMAX 32  // tangent dimensions
 #define WIN_SMAX 3   // optimised states
 #ifndef WIN_LEVELS
@@ -173,7 +185,7 @@ __device__ void motion_factor(const double* x0, const double* x1, double raw_dt,
   se2_mul(pinv, x1, E);
   se2_log(E, lg);
 #ifdef RANDT_TIMING
-  if (threadIdx.x == 64 * WIN_NDT_WAVES) atomicAdd((unsigned long long*)&g_randt_win_timing[15], (unsigned long long)wall_clock64());
+  if (threadIdx.x == 64 * WIN_FACTOR_WAVE) atomicAdd((unsigned long long*)&g_randt_win_timing[15], (unsigned long long)wall_clock64());
 #endif
   r[0] = lg[0];
   r[1] = lg[1];
@@ -399,7 +411,7 @@ struct Shared {
   double rf[2][WIN_SMAX][8];
   double fc[2][WIN_SMAX];                 // 1/2 |weighted residual|^2 of factor f (diagonal case: summed by the factor's own lane)
   unsigned short tri[WIN_NMAX * (WIN_NMAX + 1) / 2];  // upper-triangle entry e -> a | b << 8 (a <= b)
-  int sw_first[WIN_SMAX + 1], sw_cnt[WIN_SMAX + 1];   // wavefronts that stream the NDT terms of state j: [first, first + cnt)
+  int sw_first[WIN_SMAX + 1], sw_cnt[WIN_SMAX + 1];   // shares (ndt_share_of_wave) that stream the NDT terms of state j: [first, first + cnt)
   double d2[8];                           // squared diagonal of the square-root information
   int sq_diag;                            // it IS diagonal (shipped configurations): weighting folded into the assembly
   double J2[2][WIN_SMAX][16];             // IMU factors
@@ -414,7 +426,7 @@ struct Shared {
   int lcol[WIN_SMAX][WIN_NMAX];   // tangent column -> local column of motion factor f (-1 none)
   int lcol2[WIN_SMAX][WIN_NMAX];  // ... of IMU factor f
   int pose_of[WIN_NMAX];          // tangent column -> state whose pose block holds it (-1 none)
-  int wave_state[WIN_WAVES];      // state of the NDT term wavefront w streams (-1: none)
+  int wave_state[WIN_WAVES];      // state of the NDT term share s streams (-1: none)
   // banded block solve (band_solve below): per-lane LDS byte offsets of the 16 band columns + right-hand side, the lane's
   // tangent row (-1: padding), damped diagonal, constants 0 / 1 for padding entries, hand-over buffers between block steps
   int boff[18][64];      // bit 0 set: the entry is the row's damped diagonal, in dd[level]
@@ -430,7 +442,7 @@ struct Shared {
 __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
   const int lane = threadIdx.x & 63;
 #ifdef RANDT_TIMING
-  if (threadIdx.x == 64 * WIN_NDT_WAVES) atomicAdd((unsigned long long*)&g_randt_win_timing[15], (unsigned long long)(-wall_clock64()));
+  if (threadIdx.x == 64 * WIN_FACTOR_WAVE) atomicAdd((unsigned long long*)&g_randt_win_timing[15], (unsigned long long)(-wall_clock64()));
 #endif
   if (lane < W.S) {
     const int f = lane;  // factor between states f and f+1
@@ -460,7 +472,7 @@ struct TermShare {
   const int32_t* pc;
   int state, n_slots, first, stride, k, active;
   unsigned kmagic;
-  int wpt;
+  int wpt, share;
   int ci0[4];  // correspondences of this lane's first three trips (the association is frozen for the whole solve)
 };
 #ifndef WIN_TRIP_GROUP
@@ -487,13 +499,13 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
                          int step_from = -1) {
   const Loss L = Lsh;  // LDS -> registers for the duration of the pass
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool factor_wave = MODE == 1 && wave == WIN_NDT_WAVES;
+  const bool factor_wave = MODE == 1 && wave == WIN_FACTOR_WAVE;
 #ifdef RANDT_TIMING
   const long long wt_t0 = wall_clock64();
 #endif
   if (factor_wave) factors_unweighted(W, shw, buf);
   // candidate evaluation: the idle last wavefront takes ||x_candidate - x||^2 (parameter-tolerance test) off wavefront 0
-  if (MODE == 1 && step_from >= 0 && wave == WIN_WAVES - 1) {
+  if (MODE == 1 && step_from >= 0 && wave == WIN_SPARE_WAVE) {
     const double sn2 = ambient_sq(W, sh, step_from, buf, lane);
     if (lane == 0) shw.scal[1] = sn2;
   }
@@ -567,7 +579,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
         wave_sum10(a10);
         if (lane == 0) {
 #pragma unroll
-          for (int i = 0; i < 10; ++i) r[wave * 10 + i] = a10[i];
+          for (int i = 0; i < 10; ++i) r[T.share * 10 + i] = a10[i];
         }
       }
     }
@@ -1009,11 +1021,12 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   TermShare T;
   {
     T.wpt = W.n_terms <= 3 && W.n_terms > 0 ? WIN_NDT_WAVES / W.n_terms : 1;
-    const int t = wave < WIN_NDT_WAVES ? wave / T.wpt : -1;
+    T.share = ndt_share_of_wave(wave);
+    const int t = T.share >= 0 ? T.share / T.wpt : -1;
     T.active = (t >= 0 && t < W.n_terms) ? 1 : 0;
     T.k = W.k;
     T.kmagic = W.k > 1 ? (unsigned)((0x100000000ull + (unsigned)W.k - 1) / (unsigned)W.k) : 0u;
-    T.first = 64 * (wave < WIN_NDT_WAVES ? wave % T.wpt : 0);
+    T.first = 64 * (T.share >= 0 ? T.share % T.wpt : 0);
     T.stride = 64 * T.wpt;
     T.state = 0;
     T.n_slots = 0;
@@ -1034,7 +1047,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       const int slot = T.first + q * T.stride + lane;
       T.ci0[q] = (T.active && slot < T.n_slots) ? T.pc[slot] : -1;
     }
-    if (lane == 0) sh.wave_state[wave] = T.active ? T.state : -1;
+    if (lane == 0 && T.share >= 0) sh.wave_state[T.share] = T.active ? T.state : -1;
   }
   __syncthreads();
   if (tid <= WIN_SMAX) {
