@@ -434,6 +434,7 @@ struct Shared {
   double cst[2];
   double xfer[WIN_LEVELS][8][10];
   int bsize[WIN_SMAX + 1];  // tangent dimensions of state b
+  int off_tan[RANDT_WIN_MAX_STATES][5], off_amb[RANDT_WIN_MAX_STATES][5];  // WinDesc's, for the lane-indexed readers (Plus, step norms, assembly)
   int band_ok;
   Loss loss;  // robust loss of the running GNC step (uniform; in LDS so that it does not occupy ~20 registers across the solve)
 };
@@ -689,7 +690,7 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* rs
 #pragma unroll
       for (int i = 4; i < 10; ++i) B[i] = state_sum(sh, rsum, j, i);
       const double G[3][3] = {{B[4], B[5], B[6]}, {B[5], B[7], B[8]}, {B[6], B[8], B[9]}};
-      const int ia = a - W.off_tan[j][0], ib = b - W.off_tan[j][0];
+      const int ia = a - sh.off_tan[j][0], ib = b - sh.off_tan[j][0];
       double v = 0.0;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
@@ -729,7 +730,7 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* rs
     if (j >= 0) {
       double T[3][3];
       pose_T(sh.xs[buf][j], T);
-      const int ia = a - W.off_tan[j][0];
+      const int ia = a - sh.off_tan[j][0];
       g += T[ia][0] * state_sum(sh, rsum, j, 1) + T[ia][1] * state_sum(sh, rsum, j, 2) + T[ia][2] * state_sum(sh, rsum, j, 3);
     }
     sh.g[a] = g;
@@ -744,8 +745,8 @@ __device__ void plus_states(const WinDesc& W, Shared& sh, int src, int dst, cons
     const int j = lane;
     const double* x = sh.xs[src][j];
     double* y = sh.xs[dst][j];
-    if (W.off_tan[j][0] >= 0) {
-      const double d[3] = {sign * vec[W.off_tan[j][0]], sign * vec[W.off_tan[j][0] + 1], sign * vec[W.off_tan[j][0] + 2]};
+    if (sh.off_tan[j][0] >= 0) {
+      const double d[3] = {sign * vec[sh.off_tan[j][0]], sign * vec[sh.off_tan[j][0] + 1], sign * vec[sh.off_tan[j][0] + 2]};
       double e[4];
       se2_exp(d, e);
       se2_mul(x, e, y);
@@ -753,12 +754,12 @@ __device__ void plus_states(const WinDesc& W, Shared& sh, int src, int dst, cons
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = x[i];
     }
-    y[4] = x[4] + (W.off_tan[j][1] >= 0 ? sign * vec[W.off_tan[j][1]] : 0.0);
-    y[5] = x[5] + (W.off_tan[j][1] >= 0 ? sign * vec[W.off_tan[j][1] + 1] : 0.0);
-    y[6] = x[6] + (W.off_tan[j][2] >= 0 ? sign * vec[W.off_tan[j][2]] : 0.0);
-    y[7] = x[7] + (W.off_tan[j][3] >= 0 ? sign * vec[W.off_tan[j][3]] : 0.0);
-    y[8] = x[8] + (W.off_tan[j][3] >= 0 ? sign * vec[W.off_tan[j][3] + 1] : 0.0);
-    y[9] = x[9] + (W.off_tan[j][4] >= 0 ? sign * vec[W.off_tan[j][4]] : 0.0);
+    y[4] = x[4] + (sh.off_tan[j][1] >= 0 ? sign * vec[sh.off_tan[j][1]] : 0.0);
+    y[5] = x[5] + (sh.off_tan[j][1] >= 0 ? sign * vec[sh.off_tan[j][1] + 1] : 0.0);
+    y[6] = x[6] + (sh.off_tan[j][2] >= 0 ? sign * vec[sh.off_tan[j][2]] : 0.0);
+    y[7] = x[7] + (sh.off_tan[j][3] >= 0 ? sign * vec[sh.off_tan[j][3]] : 0.0);
+    y[8] = x[8] + (sh.off_tan[j][3] >= 0 ? sign * vec[sh.off_tan[j][3] + 1] : 0.0);
+    y[9] = x[9] + (sh.off_tan[j][4] >= 0 ? sign * vec[sh.off_tan[j][4]] : 0.0);
   }
 }
 
@@ -770,7 +771,7 @@ __device__ double ambient_sq(const WinDesc& W, const Shared& sh, int a, int b, i
     const int lo[5] = {0, 4, 6, 7, 9}, sz[5] = {4, 2, 1, 2, 1};
 #pragma unroll
     for (int blk = 0; blk < 5; ++blk)
-      if (W.off_amb[j][blk] >= 0)
+      if (sh.off_amb[j][blk] >= 0)
         for (int e = 0; e < sz[blk]; ++e) {
           const double d = sh.xs[a][j][lo[blk] + e] - (b >= 0 ? sh.xs[b][j][lo[blk] + e] : 0.0);
           v += d * d;
@@ -948,6 +949,10 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
     sh.lcol2[e / WIN_NMAX][e % WIN_NMAX] = -1;
   }
   if (tid < WIN_NMAX) sh.pose_of[tid] = -1;
+  if (tid < RANDT_WIN_MAX_STATES * 5) {
+    sh.off_tan[tid / 5][tid % 5] = W.off_tan[tid / 5][tid % 5];
+    sh.off_amb[tid / 5][tid % 5] = W.off_amb[tid / 5][tid % 5];
+  }
   __syncthreads();
   if (tid == 0) {
     const int sz[4] = {3, 2, 1, 2}, lbase[4] = {0, 3, 5, 6};
