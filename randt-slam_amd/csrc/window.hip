@@ -436,6 +436,11 @@ struct Shared {
   int bsize[WIN_SMAX + 1];  // tangent dimensions of state b
   int off_tan[RANDT_WIN_MAX_STATES][5], off_amb[RANDT_WIN_MAX_STATES][5];  // WinDesc's, for the lane-indexed readers (Plus, step norms, assembly)
   int band_ok;
+  // The cell records of every lane's first three NDT trips, staged once per solve (the association is frozen): a lone
+  // workgroup has nothing to hide the L2 latency of the record gathers behind, and they sit on the pass's critical path
+  // three times per pass.  [share][trip][group][lane]: moving record floats 0-3, 4-7, fixed 0-3, 4-7, (moving 8, fixed 8, -, -).
+  // gfx950 lets one workgroup declare all 160 KiB of the CU's LDS.
+  float4 recs[WIN_NDT_WAVES][3][5][64];
   Loss loss;  // robust loss of the running GNC step (uniform; in LDS so that it does not occupy ~20 registers across the solve)
 };
 
@@ -556,12 +561,24 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
         for (int t = 0; t < WIN_TRIP_GROUP; ++t) {
           const int slot = s0 + t * T.stride + lane;
           const unsigned mi = T.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, kmagic);  // slot / k
-          const float4* mv = mov + (size_t)(val[t] ? mi : 0u) * 3;
-          const float4* fv = fix + (size_t)(val[t] ? ci[t] : 0) * 3;
+          const int tix2 = grp * WIN_TRIP_GROUP + t;
+          if (tix2 < 3) {  // staged in LDS at the start of the solve (uniform branch)
+            const float4 (*rc)[64] = sh.recs[T.share][tix2];
+            mrec[t][0] = rc[0][lane];
+            mrec[t][1] = rc[1][lane];
+            frec[t][0] = rc[2][lane];
+            frec[t][1] = rc[3][lane];
+            const float4 tail = rc[4][lane];
+            mrec[t][2] = make_float4(tail.x, 0.f, 0.f, 0.f);
+            frec[t][2] = make_float4(tail.y, 0.f, 0.f, 0.f);
+          } else {
+            const float4* mv = mov + (size_t)(val[t] ? mi : 0u) * 3;
+            const float4* fv = fix + (size_t)(val[t] ? ci[t] : 0) * 3;
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            mrec[t][q] = mv[q];
-            frec[t][q] = fv[q];
+            for (int q = 0; q < 3; ++q) {
+              mrec[t][q] = mv[q];
+              frec[t][q] = fv[q];
+            }
           }
         }
 #pragma unroll
@@ -1051,6 +1068,17 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
     for (int q = 0; q < 3; ++q) {
       const int slot = T.first + q * T.stride + lane;
       T.ci0[q] = (T.active && slot < T.n_slots) ? T.pc[slot] : -1;
+      if (T.share >= 0 && T.ci0[q] >= 0 && T.ci0[q] < fixed.cap) {
+        const unsigned mi = T.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, T.kmagic);  // slot / k
+        const float4* mv = T.mov + (size_t)mi * 3;
+        const float4* fv = T.fix + (size_t)T.ci0[q] * 3;
+        const float4 m0 = mv[0], m1 = mv[1], m2 = mv[2], f0 = fv[0], f1 = fv[1], f2 = fv[2];
+        sh.recs[T.share][q][0][lane] = m0;
+        sh.recs[T.share][q][1][lane] = m1;
+        sh.recs[T.share][q][2][lane] = f0;
+        sh.recs[T.share][q][3][lane] = f1;
+        sh.recs[T.share][q][4][lane] = make_float4(m2.x, f2.x, 0.f, 0.f);
+      }
     }
     if (lane == 0 && T.share >= 0) sh.wave_state[T.share] = T.active ? T.state : -1;
   }
