@@ -103,7 +103,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
                                                            MapView moving, int moving_first,
                                                            const int32_t* __restrict__ moving_idx,
                                                            const double* __restrict__ guess4, int k, int metric_mahal,
-                                                           int transform_full, int32_t* __restrict__ corr) {
+                                                           int transform_full, int32_t* __restrict__ corr, int ch /* cells per chunk <= ASSOC_CH */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pair = blockIdx.x;
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
   // chunks are independent (a moving cell's correspondences depend on nothing but the pair's pose): a small batch spreads
   // the chunks of a pair over gridDim.y workgroups (a lone pair of 75 cells = two chunks used to cost 37 us of latency in
   // front of every fixed-lag window solve)
-  for (int c0 = (int)blockIdx.y * ASSOC_CH; c0 < M; c0 += (int)gridDim.y * ASSOC_CH) {
-    const int nch = M - c0 < ASSOC_CH ? M - c0 : ASSOC_CH;
+  for (int c0 = (int)blockIdx.y * ch; c0 < M; c0 += (int)gridDim.y * ch) {
+    const int nch = M - c0 < ch ? M - c0 : ch;
     __syncthreads();  // previous chunk fully consumed (also orders P0 before first use)
     ASSOC_TICK(0);
 
@@ -495,22 +495,25 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   const bool stage = ctx->assoc_stage_grid && assoc_lds_bytes(fixed.n_slots, true) <= (size_t)ctx->lds_limit / 2;
   const size_t lds = assoc_lds_bytes(fixed.n_slots, stage);
   // small batches: one workgroup per (pair, chunk); large ones fill the chip by pairs alone
-  int split = 1;
+  // (a handful of pairs -- the terms of a fixed-lag window -- in chunks of 16 cells: the wavefront-per-cell phases of a
+  // chunk are serial rounds, and the launch is all latency)
+  int split = 1, ch = ASSOC_CH;
   if (n_pairs <= 64) {
-    split = (moving.cap + ASSOC_CH - 1) / ASSOC_CH;
-    if (split > 8) split = 8;
+    ch = n_pairs <= 8 ? 16 : ASSOC_CH;
+    split = (moving.cap + ch - 1) / ch;
+    if (split > 32) split = 32;
     if (split < 1) split = 1;
   }
   if (stage) {
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_associate<true>, dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
-                       moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr);
+                       moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, ch);
   } else {
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_associate<false>, dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
-                       moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr);
+                       moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, ch);
   }
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
