@@ -499,9 +499,12 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   // chunk are serial rounds, and the launch is all latency)
   int split = 1, ch = ASSOC_CH;
   if (n_pairs <= 64) {
-    ch = n_pairs <= 8 ? 16 : ASSOC_CH;
+#ifndef RANDT_ASSOC_SMALL_CH
+#define RANDT_ASSOC_SMALL_CH 16
+#endif
+    ch = n_pairs <= 8 ? RANDT_ASSOC_SMALL_CH : ASSOC_CH;
     split = (moving.cap + ch - 1) / ch;
-    if (split > 32) split = 32;
+    if (split > 64) split = 64;
     if (split < 1) split = 1;
   }
   if (stage) {
