@@ -10,20 +10,24 @@
 //
 // One 512-thread workgroup owns one window problem (<= 3 optimised states, <= 2 fixed maps, 21-32
 // tangent dimensions) and runs the whole GNC x LM loop without host round trips:
-//   * NDT terms: six wavefronts share the (state, fixed map) terms (a term is split over 6 / 3 / 2 wavefronts when there
-//     are 1 / 2 / 3 of them) and stream their correspondence slots, cell records read in place from L1/L2, ten fp64 base
-//     sums per wavefront (one lane-swap reduction), combined per state in wavefront order; a seventh wavefront evaluates
-//     the motion / IMU factors meanwhile; every wavefront fetches its term's map / count / pointers ONCE per solve;
-//   * motion / IMU factors: one lane per factor evaluates residual + analytic Jacobian (right
-//     perturbations, verified against finite differences in tests/test_oracle_window.py), all lanes
-//     apply the 8x8 square-root information;
-//   * J^T J / J^T r: one thread per matrix entry gathers the factor blocks and the per-state
-//     3x3 NDT blocks (T G T^T with Sophus' PlusJacobian) into LDS;
-//   * Jacobi scaling, LM damping, the dense n x n solve (Gauss-Jordan in registers: lane = row, pivot rows
-//     broadcast with v_readlane, rows shifted so that the pivot column is always register 0), model-cost
-//     change, Plus on every manifold block and the step norms run on wavefront 0;
-//   * convergence tests / accept-reject / radius update are evaluated redundantly by every lane
-//     from broadcast scalars (uniform control flow).
+//   * NDT terms: six wavefronts share the (state, fixed map) terms (a term is split over 6 / 3 / 2 of them when there are
+//     1 / 2 / 3 terms); the cell records of a lane's first three 64-slot trips are staged in LDS once per solve (the
+//     association is frozen; the kernel declares 141 KB of the CU's 160 KB), ten fp64 base sums per wavefront (one lane-swap
+//     reduction), combined per state in share order.  Wavefronts w and w + 4 share a SIMD: the heavy shares sit on 0, 1, 3,
+//     the light ones on their partners 4, 5, 7, and SIMD 2 holds the factor wavefront (6) and the spare one (2: step norm);
+//   * motion / IMU factors: one lane per factor evaluates residual + analytic Jacobian (right perturbations, verified
+//     against finite differences in tests/test_oracle_window.py) with small-argument sin / cos / atan2; a diagonal
+//     square-root information (every shipped configuration) is applied by the assembly itself, a full one by all threads;
+//   * J^T J / J^T r: one thread per entry of the upper triangle gathers the factor blocks and the per-state 3x3 NDT blocks
+//     (T G T^T with Sophus' PlusJacobian) into LDS, mirrored on the way out, with the scaled copy and the LM diagonal;
+//   * the damped solve: banded block Gauss-Jordan, the band [state b, state b + 1] in one 16-lane DPP row, pivot rows
+//     broadcast by v_fmac_f64's row_newbcast modifier (pivot_group: one assembly block per pivot step with the next
+//     pivot's reciprocal woven in).  Rejections come in chains -- the reference keeps Ceres' initial radius of 1e4, which
+//     costs five rejected candidates at the start of EVERY GNC stage -- so wavefronts 0..5 solve the running radius and the
+//     next five at once when such a chain is due (band_solve levels); windows with a 9-dimensional state block (IMU bias)
+//     take the dense register Gauss-Jordan (gj_dense_solve);
+//   * model-cost change (wavefront 1), Plus on every manifold block (wavefront 0), convergence tests / accept-reject /
+//     radius update redundantly by every lane from broadcast scalars (uniform control flow).
 // The candidate point is evaluated with its Jacobians so that an accepted step costs one pass.
 #include <float.h>
 
