@@ -23,8 +23,8 @@
 //   * the damped solve: banded block Gauss-Jordan, the band [state b, state b + 1] in one 16-lane DPP row, pivot rows
 //     broadcast by v_fmac_f64's row_newbcast modifier (pivot_group: one assembly block per pivot step with the next
 //     pivot's reciprocal woven in).  Rejections come in chains -- the reference keeps Ceres' initial radius of 1e4, which
-//     costs five rejected candidates at the start of EVERY GNC stage -- so wavefronts 0..5 solve the running radius and the
-//     next five at once when such a chain is due (band_solve levels); windows with a 9-dimensional state block (IMU bias)
+//     costs five rejected candidates at the start of EVERY GNC stage -- so wavefronts 0..6 solve the running radius and the
+//     next six at once when such a chain is due (band_solve levels); windows with a 9-dimensional state block (IMU bias)
 //     take the dense register Gauss-Jordan (gj_dense_solve);
 //   * model-cost change (wavefront 1), Plus on every manifold block (wavefront 0), convergence tests / accept-reject /
 //     radius update redundantly by every lane from broadcast scalars (uniform control flow).
@@ -66,7 +66,8 @@ __device__ __forceinline__ int ndt_share_of_wave(int wave) {  // 0..5 = share (t
 #define WIN_NMAX 32  // tangent dimensions
 #define WIN_SMAX 3   // optimised states
 #ifndef WIN_LEVELS
-#define WIN_LEVELS 6  // damped solves taken at once, one wavefront each: the running radius and the next five a rejection chain visits (<= 6: wavefronts 0..5)
+#define WIN_LEVELS 7  // damped solves taken at once, one wavefront each (<= 8): the running radius and the next six a rejection chain
+                      // visits -- chains of five or six rejections and the accepted step behind them (5 / 6 / 7 / 8 measured: 7)
 #endif
 
 using namespace randt_solve;
@@ -816,7 +817,7 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, double cost,
 // The damped solve (H_s + D / radius) y = g_s by the banded block Gauss-Jordan (band_pivot above), one wavefront per LEVEL:
 // level 0 is the radius of the running iteration, level q the radius q rejections later (radius / decrease, decrease doubling).
 // A rejected -- or invalid -- step changes nothing but the radius, and with Ceres' default initial radius of 1e4 more than half
-// of all iterations of these windows are rejections (the first five of every GNC step): wavefronts 0..5 are idle during the
+// of all iterations of these windows are rejections (the first five of every GNC step): wavefronts 0..6 are idle during the
 // solve anyway, so the next radii cost (almost) no time and the following rejected iterations start from a finished step.  Own scratch per level; results in step[q] / delta[q] / solved[q].
 __device__ __forceinline__ void band_solve(Shared& sh, int n, int S, int lane, double inv_radius, int Q) {
   if (lane < n) sh.dd[Q][lane] = sh.Hs[lane * n + lane] + sh.diag[lane] * inv_radius;
@@ -1270,7 +1271,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
         // the radii the next rejections lead to (band_solve).  Skipped while such a level is still in stock.
         if (lvl >= n_lvl) {
           lvl = 0;
-          // Several wavefronts solving at once run measurably slower than one alone (config 3: always six levels 2.5 % worse
+          // Several wavefronts solving at once run measurably slower than one alone (config 3: always all levels 2.5 % worse
           // than this policy), so the stock is only laid in where rejections come in chains: at the first iteration of a solve
           // (Ceres' initial radius 1e4 is shrunk five times before the first step of every GNC step is accepted) and after a
           // rejection; behind an accepted step the next one is usually accepted too and the wavefront solves alone.
