@@ -449,6 +449,66 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
                               const int32_t* h_id_end, const double* h_meas, const double* h_sqrt_info,
                               int max_update_index, const randt_pg_params* p, randt_pg_result* out);
 
+/* ------------------------------------------------------------------ multi-GPU group (8e) ----- */
+/* Independent scan-to-submap registrations -- the loop-closure candidates LocalFuser::detectLoopClosures hands to
+ * Matcher::estimateLoopConstraint one by one (src/local_fuser/local_fuser.cpp:329-339, 370-397), a submap batch, a BNB
+ * pose grid -- share nothing but the read-only fixed maps, so a batch splits contiguously over the GPUs of a node with
+ * NO data-path collective.  A group owns one context (and stream) per member GPU and the only two exchanges the path
+ * has: a broadcast of map tables (cells + counts + index grid, 520 KB per indoor submap) from the member that built
+ * them, once per submap epoch, and a gather of the 32-byte poses / 64-byte result records.  Transport: RCCL over xGMI
+ * (ncclBroadcast; librccl is opened at run time, it is not a link-time dependency of this library) or -- one process
+ * only -- hipMemcpyPeerAsync fan-out, which also serves "virtual ranks" that share one device (tests, a 1-GPU box).
+ *
+ * Two ways to form a group:
+ *   - ONE process drives n devices (the reference's single-process node): randt_group_create(devices, n, ...);
+ *     members are ranks 0..n-1, all local.
+ *   - one process per GPU (torch.distributed / MPI launchers): rank 0 calls randt_group_unique_id, the launcher ships the
+ *     128 bytes to every rank, every rank calls randt_group_create_rank; each process then holds ONE local member.
+ * Per-member arguments below are arrays with one entry per LOCAL member (n_local; 1 in the one-process-per-GPU mode),
+ * e.g. `randt_maps* const* maps`: maps[i] lives on member i's device, created on randt_group_ctx(g, i).
+ * Member r of a world of G owns items [lo, hi) = randt_shard_range(n, G, r): contiguous, remainders to the low ranks. */
+typedef struct randt_group randt_group;
+enum { RANDT_TRANSPORT_AUTO = 0, RANDT_TRANSPORT_PEER = 1, RANDT_TRANSPORT_RCCL = 2 };
+#define RANDT_UNIQUE_ID_BYTES 128
+void randt_shard_range(int n_items, int world, int rank, int* lo, int* hi);
+/* devices[i] = HIP device of member i (repeats allowed with the PEER transport); streams (nullable, or entries NULL):
+ * a hipStream_t per member to enqueue on, otherwise the group creates its own non-blocking streams.
+ * AUTO = RCCL when n > 1, all devices are distinct and librccl can be opened, PEER otherwise. */
+int randt_group_create(const int* devices, int n, void* const* streams, int transport, randt_group** out);
+int randt_group_unique_id(void* out128);
+int randt_group_create_rank(int device, void* stream, int rank, int world, const void* unique_id128, randt_group** out);
+int randt_group_destroy(randt_group* g);
+int randt_group_info(const randt_group* g, int* world, int* n_local, int* first_rank, int* transport);
+randt_ctx* randt_group_ctx(randt_group* g, int local_member);
+const char* randt_group_last_error(const randt_group* g);
+int randt_group_synchronize(randt_group* g);
+/* Cells, counts and index grids of maps [first, first + count) of every member's batch := those of rank `root`'s batch
+ * (all batches must have the same geometry).  Asynchronous on the members' streams. */
+int randt_group_broadcast_maps(randt_group* g, randt_maps* const* maps, int first, int count, int root);
+/* Rows [lo_r, hi_r) = randt_shard_range(n_rows, world, r) of d_rows[member r] -> the same rows of every member's buffer
+ * (each buffer holds n_rows rows of row_bytes bytes): the gather of per-registration outputs.  Asynchronous. */
+int randt_group_allgather_rows(randt_group* g, void* const* d_rows, int n_rows, size_t row_bytes);
+/* Matcher::estimateLoopConstraint (ndt_matcher.cpp:426-493) for a batch SHARDED over the group: member r runs pairs
+ * [lo_r, hi_r) of the batch exactly like randt_register_batch_dev / randt_scan_register_batch_dev would (same kernels,
+ * bit-identical results), on its own device and stream.  Every member's arrays describe the WHOLE batch (n_pairs /
+ * n_scans entries; a member reads only its own rows: moving maps [lo_r, hi_r) of moving[r], d_fixed_idx[r][lo_r..],
+ * d_pose4[r][4 lo_r ..]); scan_maps[r] is a workspace of >= hi_r - lo_r maps.  gather != 0: poses and results are
+ * all-gathered afterwards, so every member holds the full batch's outputs.  Asynchronous. */
+int randt_group_register_batch_dev(randt_group* g, randt_maps* const* fixed, const int32_t* const* d_fixed_idx,
+                                   randt_maps* const* moving, int n_pairs, const randt_matcher_params* mp,
+                                   double* const* d_pose4, randt_result* const* d_results, int gather);
+int randt_group_scan_register_batch_dev(randt_group* g, const float* const* d_points, int n_scans, int pitch_points,
+                                        const int32_t* const* d_n_points /* nullable */, int stride_floats, int intensity_index,
+                                        const randt_cluster_params* cp, randt_maps* const* fixed,
+                                        const int32_t* const* d_fixed_idx, randt_maps* const* scan_maps,
+                                        const randt_matcher_params* mp, double* const* d_pose4,
+                                        randt_result* const* d_results, int gather);
+/* Host convenience (synchronous) for a caller that holds poses on the host, like LocalFuser does: the same sharded
+ * registration of pre-built moving maps; h_fixed_idx[p] selects pair p's fixed map, h_pose4 in: guesses, out: refined
+ * poses, h_results (nullable) out -- identical on every rank on return. */
+int randt_group_register_pairs(randt_group* g, randt_maps* const* fixed, const int32_t* h_fixed_idx, randt_maps* const* moving,
+                               int n_pairs, const randt_matcher_params* mp, double* h_pose4, randt_result* h_results);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,7 +158,7 @@ def lib():
     L.orc_register_batch.restype = C.c_int
     L.orc_register_batch.argtypes = [
         C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
-        P(MatcherParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+        P(MatcherParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
     ]
     for name in ("orc_se2_exp", "orc_se2_log", "orc_se2_inv"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
@@ -384,7 +384,7 @@ def register_pair(fixed, moving, params, pose4):
     return rc, p, cost.value, stats_to_dict(st)
 
 
-def register_batch(pts, fixed_maps, fixed_idx, params, guess4, n_clusters, max_range, ioff=3, n_threads=0):
+def register_batch(pts, fixed_maps, fixed_idx, params, guess4, n_clusters, max_range, ioff=3, n_threads=0, want_stats=False):
     """pts: (B, n, stride) float32.  Returns poses (B,4), cost (B,), iters (B,)."""
     pts = np.ascontiguousarray(pts, dtype=np.float32)
     B, n, stride = pts.shape
@@ -394,10 +394,13 @@ def register_batch(pts, fixed_maps, fixed_idx, params, guess4, n_clusters, max_r
     poses = np.zeros((B, 4))
     cost = np.zeros(B)
     iters = np.zeros(B, dtype=np.int32)
+    stats = np.zeros((B, 4), dtype=np.int32) if want_stats else None
     fail = lib().orc_register_batch(
         B, _ptr(pts), n, stride, ioff, int(n_clusters), float(max_range), C.cast(arr, C.c_void_p), _ptr(fixed_idx),
-        C.byref(params), _ptr(guess4), _ptr(poses), _ptr(cost), _ptr(iters), int(n_threads),
+        C.byref(params), _ptr(guess4), _ptr(poses), _ptr(cost), _ptr(iters), int(n_threads), _ptr(stats) if want_stats else None,
     )
+    if want_stats:   # columns: n_residuals, n_solves, termination, passes
+        return fail, poses, cost, iters, stats
     return fail, poses, cost, iters
 
 

@@ -1310,7 +1310,7 @@ int orc_register_pair(const orc_map* fixed, const orc_map* moving, const orc_mat
 int orc_register_batch(int B, const float* pts, int n, int stride, int ioff, int n_clusters,
                        float max_range, orc_map* const* fixed_maps, const int32_t* fixed_idx,
                        const orc_matcher_params* p, const double* guess4, double* pose4_out,
-                       double* cost_out, int32_t* iters_out, int n_threads) {
+                       double* cost_out, int32_t* iters_out, int n_threads, int32_t* stats_out) {
   int fail = 0;
 #ifdef _OPENMP
   if (n_threads <= 0) n_threads = omp_get_max_threads();
@@ -1332,6 +1332,12 @@ int orc_register_batch(int B, const float* pts, int n, int stride, int ioff, int
     memcpy(pose4_out + (size_t)b * 4, p4, sizeof(p4));
     if (cost_out) cost_out[b] = cost;
     if (iters_out) iters_out[b] = st->n_iterations;
+    if (stats_out) { /* [B][4]: residual blocks, GNC solves, termination of the last solve, passes (cost + Jacobian evaluations) */
+      stats_out[4 * b + 0] = st->n_residuals;
+      stats_out[4 * b + 1] = st->n_solves;
+      stats_out[4 * b + 2] = st->termination;
+      stats_out[4 * b + 3] = st->n_jac_evals + st->n_cost_evals;
+    }
     free(st);
     orc_map_destroy(scan);
   }

@@ -177,7 +177,8 @@ int orc_register_pair(const orc_map* fixed, const orc_map* moving, const orc_mat
 int orc_register_batch(int B, const float* pts, int n, int stride, int ioff, int n_clusters,
                        float max_range, orc_map* const* fixed_maps, const int32_t* fixed_idx,
                        const orc_matcher_params* p, const double* guess4, double* pose4_out,
-                       double* cost_out, int32_t* iters_out, int n_threads);
+                       double* cost_out, int32_t* iters_out, int n_threads,
+                       int32_t* stats_out /* nullable, [B][4]: n_residuals, n_solves, termination, passes */);
 
 /* ---------------------------------------------------------------- fixed-lag window (a16/a17) */
 

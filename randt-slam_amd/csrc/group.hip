@@ -1,0 +1,533 @@
+// Multi-GPU group of the C ABI (include/randt.h, "multi-GPU group"): one context + stream per member GPU, contiguous
+// sharding of independent registrations, and the only two exchanges the path has -- broadcast of map tables, gather of
+// result rows -- over RCCL (xGMI) or, inside one process, peer copies.
+//
+// The reference has no counterpart (single process, one CPU thread pool: SURVEY 2.2); the caller this serves is
+// LocalFuser::detectLoopClosures (src/local_fuser/local_fuser.cpp:329-339, 370-397), whose candidates are independent
+// Matcher::estimateLoopConstraint calls (src/ndt_registration/ndt_matcher.cpp:426-493 holds no cross-call state).
+//
+// RCCL is opened at run time (dlopen): librandt_hip.so keeps no link-time dependency on it, single-GPU callers never
+// load it, and inside a PyTorch process the copy torch already mapped is reused instead of a second one.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <new>
+#include <set>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "randt_internal.h"
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;
+};
+
+// one attempt per process; thread-safe by C++11 static initialisation
+const Rccl& rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+      x.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);  // already mapped (e.g. by PyTorch)?
+      if (x.handle) break;
+    }
+    for (int i = 0; !x.handle && i < 4; ++i) x.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!x.handle) {
+      const char* e = dlerror();
+      x.why = std::string("librccl could not be opened: ") + (e ? e : "?");
+      return x;
+    }
+    bool ok = true;
+    auto sym = [&](const char* n) {
+      void* p = dlsym(x.handle, n);
+      if (!p) {
+        ok = false;
+        x.why = std::string("librccl lacks ") + n;
+      }
+      return p;
+    };
+    x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+    x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+    x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
+    x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+    x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
+    x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+    x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+    x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) x.handle = nullptr;
+    return x;
+  }();
+  return r;
+}
+
+}  // namespace
+
+struct randt_group {
+  int world = 1, n_local = 1, first_rank = 0;
+  int transport = RANDT_TRANSPORT_PEER;
+  std::vector<randt_ctx*> ctx;           // one per local member
+  std::vector<hipStream_t> own_stream;   // streams created here (nullptr where the caller's is used)
+  std::vector<ncclComm_t> comm;          // RCCL transport
+  std::vector<hipEvent_t> ev;            // PEER transport: "member i's stream has reached this point"
+  std::vector<hipEvent_t> ev_done;       // PEER transport: "member i's copies of this exchange are enqueued behind this"
+  std::vector<void*> stage;              // randt_group_register_pairs: per-member device staging block
+  std::vector<size_t> stage_bytes;
+  std::string last_error;
+};
+
+namespace {
+
+int gerr(randt_group* g, int status, const std::string& what) {
+  if (g) g->last_error = what;
+  return status;
+}
+int gerr_hip(randt_group* g, const char* what, hipError_t e) {
+  return gerr(g, RANDT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+int gerr_nccl(randt_group* g, const char* what, ncclResult_t r) {
+  const Rccl& R = rccl();
+  return gerr(g, RANDT_ERR_HIP, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));
+}
+int gerr_member(randt_group* g, int i, int rc, const char* what) {
+  return gerr(g, rc, std::string(what) + " (member " + std::to_string(i) + "): " + randt_last_error(g->ctx[i]));
+}
+#define G_HIP(g, call)                                      \
+  do {                                                      \
+    hipError_t e__ = (call);                                \
+    if (e__ != hipSuccess) return gerr_hip((g), #call, e__); \
+  } while (0)
+#define G_NCCL(g, call)                                        \
+  do {                                                         \
+    ncclResult_t r__ = (call);                                 \
+    if (r__ != ncclSuccess) return gerr_nccl((g), #call, r__); \
+  } while (0)
+
+struct DevSwitch {  // like DeviceGuard, for a bare device index
+  int prev = -1;
+  explicit DevSwitch(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DevSwitch() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int make_members(randt_group* g, const int* devices, int n, void* const* streams) {
+  for (int i = 0; i < n; ++i) {
+    hipStream_t st = streams ? (hipStream_t)streams[i] : nullptr;
+    hipStream_t own = nullptr;
+    DevSwitch sw(devices[i]);
+    if (!st) {
+      G_HIP(g, hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+      st = own;
+    }
+    randt_ctx* c = nullptr;
+    const int rc = randt_ctx_create(devices[i], st, &c);
+    if (rc) {
+      if (own) (void)hipStreamDestroy(own);
+      return gerr(g, rc, "randt_ctx_create failed for device " + std::to_string(devices[i]));
+    }
+    hipEvent_t ev = nullptr, ev2 = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev2, hipEventDisableTiming);
+    g->ctx.push_back(c);
+    g->own_stream.push_back(own);
+    g->ev.push_back(ev);
+    g->ev_done.push_back(ev2);
+    g->stage.push_back(nullptr);
+    g->stage_bytes.push_back(0);
+    if (e != hipSuccess) return gerr_hip(g, "hipEventCreateWithFlags", e);
+  }
+  return RANDT_OK;
+}
+
+bool same_geometry(const randt_maps* a, const randt_maps* b) {
+  return a->v.n_maps == b->v.n_maps && a->v.cap == b->v.cap && a->v.n_slots == b->v.n_slots && (a->v.grid != nullptr) == (b->v.grid != nullptr);
+}
+
+// PEER transport: copy `bytes` from member src's buffer to member dst's, ordered after everything enqueued on src's
+// stream so far (event ev[src] must have been recorded there) and enqueued on dst's stream.
+int peer_copy(randt_group* g, int dst, void* d_dst, int src, const void* d_src, size_t bytes) {
+  if (bytes == 0) return RANDT_OK;
+  randt_ctx *cd = g->ctx[dst], *cs = g->ctx[src];
+  DevSwitch sw(cd->device);
+  G_HIP(g, hipStreamWaitEvent(cd->stream, g->ev[src], 0));
+  if (cd->device == cs->device)
+    G_HIP(g, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, cd->stream));
+  else
+    G_HIP(g, hipMemcpyPeerAsync(d_dst, cd->device, d_src, cs->device, bytes, cd->stream));
+  return RANDT_OK;
+}
+
+int record_all(randt_group* g) {
+  for (int i = 0; i < g->n_local; ++i) {
+    DevSwitch sw(g->ctx[i]->device);
+    G_HIP(g, hipEventRecord(g->ev[i], g->ctx[i]->stream));
+  }
+  return RANDT_OK;
+}
+
+// PEER transport, end of an exchange: no member's stream runs ahead of the copies that READ its buffers (a member that
+// started its next batch would overwrite rows another member is still fetching) -- RCCL gives the same ordering by
+// enqueueing the collective on every participant's stream.
+int peer_fence(randt_group* g) {
+  for (int i = 0; i < g->n_local; ++i) {
+    DevSwitch sw(g->ctx[i]->device);
+    G_HIP(g, hipEventRecord(g->ev_done[i], g->ctx[i]->stream));
+  }
+  for (int j = 0; j < g->n_local; ++j) {
+    DevSwitch sw(g->ctx[j]->device);
+    for (int i = 0; i < g->n_local; ++i)
+      if (i != j) G_HIP(g, hipStreamWaitEvent(g->ctx[j]->stream, g->ev_done[i], 0));
+  }
+  return RANDT_OK;
+}
+
+// one table of every member := root's (RCCL: one broadcast per local member inside the caller's group call)
+int bcast_table(randt_group* g, void* const* ptr, size_t bytes, int root) {
+  if (bytes == 0) return RANDT_OK;
+  if (g->transport == RANDT_TRANSPORT_RCCL) {
+    const Rccl& R = rccl();
+    for (int i = 0; i < g->n_local; ++i) {
+      DevSwitch sw(g->ctx[i]->device);
+      G_NCCL(g, R.Broadcast(ptr[i], ptr[i], bytes, ncclChar, root, g->comm[i], g->ctx[i]->stream));
+    }
+    return RANDT_OK;
+  }
+  for (int i = 0; i < g->n_local; ++i) {
+    if (i == root) continue;
+    const int rc = peer_copy(g, i, ptr[i], root, ptr[root], bytes);
+    if (rc) return rc;
+  }
+  return RANDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void randt_shard_range(int n_items, int world, int rank, int* lo, int* hi) {
+  if (world < 1) world = 1;
+  if (n_items < 0) n_items = 0;
+  const int base = n_items / world, rem = n_items % world;
+  const int l = rank * base + (rank < rem ? rank : rem);
+  if (lo) *lo = l;
+  if (hi) *hi = l + base + (rank < rem ? 1 : 0);
+}
+
+const char* randt_group_last_error(const randt_group* g) { return g ? g->last_error.c_str() : ""; }
+
+int randt_group_destroy(randt_group* g) {
+  if (!g) return RANDT_OK;
+  for (size_t i = 0; i < g->ctx.size(); ++i) {
+    DevSwitch sw(g->ctx[i]->device);
+    (void)hipStreamSynchronize(g->ctx[i]->stream);
+    if (i < g->comm.size() && g->comm[i] && rccl().CommDestroy) (void)rccl().CommDestroy(g->comm[i]);
+    if (g->stage[i]) (void)hipFree(g->stage[i]);
+    if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+    if (g->ev_done[i]) (void)hipEventDestroy(g->ev_done[i]);
+    (void)randt_ctx_destroy(g->ctx[i]);
+    if (g->own_stream[i]) (void)hipStreamDestroy(g->own_stream[i]);
+  }
+  delete g;
+  return RANDT_OK;
+}
+
+int randt_group_create(const int* devices, int n, void* const* streams, int transport, randt_group** out) {
+  if (!out) return RANDT_ERR_INVALID;
+  *out = nullptr;
+  if (!devices || n < 1 || n > 64 || transport < RANDT_TRANSPORT_AUTO || transport > RANDT_TRANSPORT_RCCL) return RANDT_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RANDT_ERR_NODEVICE;
+  std::set<int> distinct;
+  for (int i = 0; i < n; ++i) {
+    if (devices[i] < 0 || devices[i] >= n_dev) return RANDT_ERR_INVALID;
+    distinct.insert(devices[i]);
+  }
+  const bool all_distinct = (int)distinct.size() == n;
+  if (transport == RANDT_TRANSPORT_AUTO) transport = (n > 1 && all_distinct && rccl().handle) ? RANDT_TRANSPORT_RCCL : RANDT_TRANSPORT_PEER;
+  if (transport == RANDT_TRANSPORT_RCCL && !all_distinct) return RANDT_ERR_INVALID;  // RCCL refuses two ranks on one device
+  randt_group* g = new (std::nothrow) randt_group();
+  if (!g) return RANDT_ERR_NOMEM;
+  g->world = g->n_local = n;
+  g->first_rank = 0;
+  g->transport = transport;
+  int rc = make_members(g, devices, n, streams);
+  if (!rc && transport == RANDT_TRANSPORT_RCCL) {
+    const Rccl& R = rccl();
+    if (!R.handle) {
+      rc = gerr(g, RANDT_ERR_UNSUPPORTED, R.why);
+    } else {
+      g->comm.assign(n, nullptr);
+      const ncclResult_t r = R.CommInitAll(g->comm.data(), n, devices);
+      if (r != ncclSuccess) rc = gerr_nccl(g, "ncclCommInitAll", r);
+    }
+  }
+  if (!rc && transport == RANDT_TRANSPORT_PEER) {
+    // peer access between distinct member devices (already-enabled is fine; where the fabric offers none the runtime stages
+    // hipMemcpyPeerAsync through the host -- slower, still correct)
+    for (int a : distinct)
+      for (int b : distinct) {
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+          DevSwitch sw(a);
+          (void)hipDeviceEnablePeerAccess(b, 0);
+          (void)hipGetLastError();
+        }
+      }
+  }
+  if (rc) {
+    // keep the message for the caller? there is no object to ask once destroyed: statuses are all the caller gets here
+    randt_group_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return RANDT_OK;
+}
+
+int randt_group_unique_id(void* out128) {
+  if (!out128) return RANDT_ERR_INVALID;
+  const Rccl& R = rccl();
+  if (!R.handle) return RANDT_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  if (R.GetUniqueId(&id) != ncclSuccess) return RANDT_ERR_HIP;
+  static_assert(sizeof(id) == RANDT_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+  memcpy(out128, &id, sizeof(id));
+  return RANDT_OK;
+}
+
+int randt_group_create_rank(int device, void* stream, int rank, int world, const void* unique_id128, randt_group** out) {
+  if (!out) return RANDT_ERR_INVALID;
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !unique_id128)) return RANDT_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RANDT_ERR_NODEVICE;
+  if (device < 0 || device >= n_dev) return RANDT_ERR_INVALID;
+  randt_group* g = new (std::nothrow) randt_group();
+  if (!g) return RANDT_ERR_NOMEM;
+  g->world = world;
+  g->n_local = 1;
+  g->first_rank = rank;
+  g->transport = (world > 1 || unique_id128) ? RANDT_TRANSPORT_RCCL : RANDT_TRANSPORT_PEER;
+  void* st[1] = {stream};
+  int rc = make_members(g, &device, 1, st);
+  if (!rc && g->transport == RANDT_TRANSPORT_RCCL) {
+    const Rccl& R = rccl();
+    if (!R.handle) {
+      rc = gerr(g, RANDT_ERR_UNSUPPORTED, R.why);
+    } else {
+      ncclUniqueId id;
+      memcpy(&id, unique_id128, sizeof(id));
+      g->comm.assign(1, nullptr);
+      DevSwitch sw(device);
+      const ncclResult_t r = R.CommInitRank(&g->comm[0], world, id, rank);
+      if (r != ncclSuccess) rc = gerr_nccl(g, "ncclCommInitRank", r);
+    }
+  }
+  if (rc) {
+    randt_group_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return RANDT_OK;
+}
+
+int randt_group_info(const randt_group* g, int* world, int* n_local, int* first_rank, int* transport) {
+  if (!g) return RANDT_ERR_INVALID;
+  if (world) *world = g->world;
+  if (n_local) *n_local = g->n_local;
+  if (first_rank) *first_rank = g->first_rank;
+  if (transport) *transport = g->transport;
+  return RANDT_OK;
+}
+
+randt_ctx* randt_group_ctx(randt_group* g, int local_member) {
+  return (g && local_member >= 0 && local_member < g->n_local) ? g->ctx[local_member] : nullptr;
+}
+
+int randt_group_synchronize(randt_group* g) {
+  if (!g) return RANDT_ERR_INVALID;
+  for (int i = 0; i < g->n_local; ++i) {
+    DevSwitch sw(g->ctx[i]->device);
+    G_HIP(g, hipStreamSynchronize(g->ctx[i]->stream));
+  }
+  return RANDT_OK;
+}
+
+int randt_group_broadcast_maps(randt_group* g, randt_maps* const* maps, int first, int count, int root) {
+  if (!g || !maps || root < 0 || root >= g->world || first < 0 || count < 0) return RANDT_ERR_INVALID;
+  for (int i = 0; i < g->n_local; ++i) {
+    if (!maps[i] || maps[i]->ctx != g->ctx[i]) return gerr(g, RANDT_ERR_INVALID, "maps[i] must be created on randt_group_ctx(g, i)");
+    if (!same_geometry(maps[i], maps[0]) || first + count > maps[i]->v.n_maps) return gerr(g, RANDT_ERR_INVALID, "map batches of a group must share one geometry");
+  }
+  if (count == 0 || g->world == 1) return RANDT_OK;
+  const MapView& v0 = maps[0]->v;
+  const size_t cell_b = sizeof(randt_cell) * (size_t)v0.cap * count, cnt_b = sizeof(int32_t) * (size_t)count;
+  const size_t grid_b = v0.grid ? sizeof(int32_t) * (size_t)v0.n_slots * count : 0;
+  std::vector<void*> pc(g->n_local), pn(g->n_local), pg(g->n_local);
+  for (int i = 0; i < g->n_local; ++i) {
+    const MapView& v = maps[i]->v;
+    pc[i] = v.cells + (size_t)first * v.cap;
+    pn[i] = v.counts + first;
+    pg[i] = v.grid ? v.grid + (size_t)first * v.n_slots : nullptr;
+  }
+  int rc = RANDT_OK;
+  if (g->transport == RANDT_TRANSPORT_RCCL) {
+    const Rccl& R = rccl();
+    G_NCCL(g, R.GroupStart());
+    rc = bcast_table(g, pc.data(), cell_b, root);
+    if (!rc) rc = bcast_table(g, pn.data(), cnt_b, root);
+    if (!rc) rc = bcast_table(g, pg.data(), grid_b, root);
+    const ncclResult_t r = R.GroupEnd();
+    if (!rc && r != ncclSuccess) rc = gerr_nccl(g, "ncclGroupEnd", r);
+    return rc;
+  }
+  rc = record_all(g);
+  if (!rc) rc = bcast_table(g, pc.data(), cell_b, root);
+  if (!rc) rc = bcast_table(g, pn.data(), cnt_b, root);
+  if (!rc) rc = bcast_table(g, pg.data(), grid_b, root);
+  if (!rc) rc = peer_fence(g);
+  return rc;
+}
+
+int randt_group_allgather_rows(randt_group* g, void* const* d_rows, int n_rows, size_t row_bytes) {
+  if (!g || !d_rows || n_rows < 0) return RANDT_ERR_INVALID;
+  if (n_rows == 0 || row_bytes == 0 || g->world == 1) return RANDT_OK;
+  for (int i = 0; i < g->n_local; ++i)
+    if (!d_rows[i]) return RANDT_ERR_INVALID;
+  if (g->transport == RANDT_TRANSPORT_RCCL) {
+    // one in-place broadcast per owner rank, all inside one group call (shards may differ by a row, which an all-gather's
+    // equal-count contract would need padding for)
+    const Rccl& R = rccl();
+    G_NCCL(g, R.GroupStart());
+    int rc = RANDT_OK;
+    for (int r = 0; r < g->world && !rc; ++r) {
+      int lo, hi;
+      randt_shard_range(n_rows, g->world, r, &lo, &hi);
+      if (hi == lo) continue;
+      for (int i = 0; i < g->n_local && !rc; ++i) {
+        DevSwitch sw(g->ctx[i]->device);
+        char* p = static_cast<char*>(d_rows[i]) + (size_t)lo * row_bytes;
+        const ncclResult_t q = R.Broadcast(p, p, (size_t)(hi - lo) * row_bytes, ncclChar, r, g->comm[i], g->ctx[i]->stream);
+        if (q != ncclSuccess) rc = gerr_nccl(g, "ncclBroadcast", q);
+      }
+    }
+    const ncclResult_t e = R.GroupEnd();
+    if (!rc && e != ncclSuccess) rc = gerr_nccl(g, "ncclGroupEnd", e);
+    return rc;
+  }
+  int rc = record_all(g);
+  for (int src = 0; src < g->n_local && !rc; ++src) {
+    int lo, hi;
+    randt_shard_range(n_rows, g->world, src, &lo, &hi);
+    const size_t off = (size_t)lo * row_bytes, bytes = (size_t)(hi - lo) * row_bytes;
+    for (int dst = 0; dst < g->n_local && !rc; ++dst)
+      if (dst != src) rc = peer_copy(g, dst, static_cast<char*>(d_rows[dst]) + off, src, static_cast<const char*>(d_rows[src]) + off, bytes);
+  }
+  if (!rc) rc = peer_fence(g);
+  return rc;
+}
+
+int randt_group_register_batch_dev(randt_group* g, randt_maps* const* fixed, const int32_t* const* d_fixed_idx,
+                                   randt_maps* const* moving, int n_pairs, const randt_matcher_params* mp,
+                                   double* const* d_pose4, randt_result* const* d_results, int gather) {
+  if (!g || !fixed || !moving || !mp || !d_pose4 || !d_results || n_pairs < 0) return RANDT_ERR_INVALID;
+  for (int i = 0; i < g->n_local; ++i) {
+    if (!fixed[i] || !moving[i] || !d_pose4[i] || !d_results[i]) return RANDT_ERR_INVALID;
+    int lo, hi;
+    randt_shard_range(n_pairs, g->world, g->first_rank + i, &lo, &hi);
+    if (hi == lo) continue;
+    const int rc = randt_register_batch_dev(g->ctx[i], fixed[i], (d_fixed_idx && d_fixed_idx[i]) ? d_fixed_idx[i] + lo : nullptr, moving[i], lo,
+                                            hi - lo, mp, d_pose4[i] + 4 * (size_t)lo, d_results[i] + lo);
+    if (rc) return gerr_member(g, i, rc, "randt_register_batch_dev");
+  }
+  if (!gather) return RANDT_OK;
+  int rc = randt_group_allgather_rows(g, reinterpret_cast<void* const*>(d_pose4), n_pairs, sizeof(double) * 4);
+  if (!rc) rc = randt_group_allgather_rows(g, reinterpret_cast<void* const*>(d_results), n_pairs, sizeof(randt_result));
+  return rc;
+}
+
+int randt_group_scan_register_batch_dev(randt_group* g, const float* const* d_points, int n_scans, int pitch_points,
+                                        const int32_t* const* d_n_points, int stride_floats, int intensity_index,
+                                        const randt_cluster_params* cp, randt_maps* const* fixed,
+                                        const int32_t* const* d_fixed_idx, randt_maps* const* scan_maps,
+                                        const randt_matcher_params* mp, double* const* d_pose4,
+                                        randt_result* const* d_results, int gather) {
+  if (!g || !d_points || !fixed || !scan_maps || !mp || !cp || !d_pose4 || !d_results || n_scans < 0 || pitch_points < 0 || stride_floats < 3)
+    return RANDT_ERR_INVALID;
+  for (int i = 0; i < g->n_local; ++i) {
+    if (!fixed[i] || !scan_maps[i] || !d_pose4[i] || !d_results[i] || (!d_points[i] && pitch_points > 0)) return RANDT_ERR_INVALID;
+    int lo, hi;
+    randt_shard_range(n_scans, g->world, g->first_rank + i, &lo, &hi);
+    if (hi == lo) continue;
+    const int rc = randt_scan_register_batch_dev(
+        g->ctx[i], d_points[i] + (size_t)lo * pitch_points * stride_floats, hi - lo, pitch_points,
+        (d_n_points && d_n_points[i]) ? d_n_points[i] + lo : nullptr, stride_floats, intensity_index, cp, fixed[i],
+        (d_fixed_idx && d_fixed_idx[i]) ? d_fixed_idx[i] + lo : nullptr, scan_maps[i], mp, d_pose4[i] + 4 * (size_t)lo, d_results[i] + lo);
+    if (rc) return gerr_member(g, i, rc, "randt_scan_register_batch_dev");
+  }
+  if (!gather) return RANDT_OK;
+  int rc = randt_group_allgather_rows(g, reinterpret_cast<void* const*>(d_pose4), n_scans, sizeof(double) * 4);
+  if (!rc) rc = randt_group_allgather_rows(g, reinterpret_cast<void* const*>(d_results), n_scans, sizeof(randt_result));
+  return rc;
+}
+
+int randt_group_register_pairs(randt_group* g, randt_maps* const* fixed, const int32_t* h_fixed_idx, randt_maps* const* moving,
+                               int n_pairs, const randt_matcher_params* mp, double* h_pose4, randt_result* h_results) {
+  if (!g || !fixed || !moving || !mp || n_pairs < 0 || (n_pairs > 0 && (!h_pose4 || !h_fixed_idx))) return RANDT_ERR_INVALID;
+  if (n_pairs == 0) return RANDT_OK;
+  // per-member staging block: [pose4 | results | fixed_idx] for the whole batch (100 bytes per pair)
+  const size_t pose_b = sizeof(double) * 4 * (size_t)n_pairs, res_b = sizeof(randt_result) * (size_t)n_pairs;
+  const size_t idx_b = sizeof(int32_t) * (size_t)n_pairs, need = pose_b + res_b + idx_b + 256;
+  std::vector<double*> dp(g->n_local);
+  std::vector<randt_result*> dr(g->n_local);
+  std::vector<const int32_t*> di(g->n_local);
+  for (int i = 0; i < g->n_local; ++i) {
+    randt_ctx* c = g->ctx[i];
+    DevSwitch sw(c->device);
+    if (g->stage_bytes[i] < need) {
+      G_HIP(g, hipStreamSynchronize(c->stream));
+      if (g->stage[i]) (void)hipFree(g->stage[i]);
+      g->stage[i] = nullptr;
+      g->stage_bytes[i] = 0;
+      G_HIP(g, hipMalloc(&g->stage[i], need + need / 2));
+      g->stage_bytes[i] = need + need / 2;
+    }
+    char* b = static_cast<char*>(g->stage[i]);
+    dp[i] = reinterpret_cast<double*>(b);
+    dr[i] = reinterpret_cast<randt_result*>(b + pose_b);
+    di[i] = reinterpret_cast<const int32_t*>(b + pose_b + res_b);
+    G_HIP(g, hipMemcpyAsync(dp[i], h_pose4, pose_b, hipMemcpyHostToDevice, c->stream));
+    G_HIP(g, hipMemsetAsync(dr[i], 0, res_b, c->stream));
+    G_HIP(g, hipMemcpyAsync(b + pose_b + res_b, h_fixed_idx, idx_b, hipMemcpyHostToDevice, c->stream));
+  }
+  int rc = randt_group_register_batch_dev(g, fixed, di.data(), moving, n_pairs, mp, dp.data(), dr.data(), 1);
+  if (rc) {
+    (void)randt_group_synchronize(g);
+    return rc;
+  }
+  randt_ctx* c0 = g->ctx[0];
+  {
+    DevSwitch sw(c0->device);
+    G_HIP(g, hipMemcpyAsync(h_pose4, dp[0], pose_b, hipMemcpyDeviceToHost, c0->stream));
+    if (h_results) G_HIP(g, hipMemcpyAsync(h_results, dr[0], res_b, hipMemcpyDeviceToHost, c0->stream));
+  }
+  return randt_group_synchronize(g);
+}
+
+}  // extern "C"

@@ -333,8 +333,8 @@ __device__ __forceinline__ bool gradient_converged(const double* x, const double
   return uni(m <= gtol);
 }
 
-__device__ __forceinline__ void trace_push(double* tr, int max_len, double cost, double radius, int flag) {
-  if (tr && threadIdx.x == 0) {  // (tracing is a single-registration-per-workgroup feature)
+__device__ __forceinline__ void trace_push(double* tr, int max_len, int tid, double cost, double radius, int flag) {
+  if (tr && tid == 0) {  // thread 0 of the registration (RPB > 1: lane 0 of its wavefront)
     const int n = (int)tr[0];
     if (3 * (n + 1) + 1 <= max_len) {
       tr[1 + 3 * n + 0] = cost;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
         RANDT_COLD_SYNC();
       }
       bool gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
-      trace_push(tr, trace_len, cost, radius, 0);
+      trace_push(tr, trace_len, tid, cost, radius, 0);
 
       for (;;) {
         // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
           step_ok = false;
           RANDT_COLD_SET(summary_min, fmin(summary_min, cost));
           RANDT_COLD_SYNC();
-          trace_push(tr, trace_len, cost, radius, 3);
+          trace_push(tr, trace_len, tid, cost, radius, 3);
           continue;
         }
         num_invalid = 0;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
           reuse = false;
           RANDT_COLD_SET(summary_min, fmin(summary_min, cost));
           RANDT_COLD_SYNC();
-          trace_push(tr, trace_len, cost, radius, 1);
+          trace_push(tr, trace_len, tid, cost, radius, 1);
         } else {
           step_ok = false;
           radius = radius * fast_rcp(decrease);  // decrease is a power of two: exact
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
           reuse = true;
           RANDT_COLD_SET(summary_min, fmin(summary_min, cand_cost));
           RANDT_COLD_SYNC();
-          trace_push(tr, trace_len, cand_cost, radius, 2);
+          trace_push(tr, trace_len, tid, cand_cost, radius, 2);
         }
       }
       res.gnc_solves++;
@@ -767,7 +767,7 @@ int launch_one(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx,
 #define RANDT_CFG(BB, AA) \
   return launch_cfg<D, PARAM, BB, AA>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results)
   const bool am2 = P.alpha == -2.0;
-  if (block == 64 && am2 && !ctx->d_trace && ctx->solve_rpb > 1) {
+  if (block == 64 && am2 && ctx->solve_rpb > 1) {
     if (ctx->solve_rpb == 2)
       return launch_cfg<D, PARAM, 64, true, 2>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results);
     if (ctx->solve_rpb == 8)
