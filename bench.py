@@ -48,6 +48,27 @@ SAT_COPIES = 8                          # chip-filling launch of the roofline se
 HOT_KERNELS = ("k_ndt_build<true>", "k_associate<false>", "k_solve<3,1,64,true,4>")
 
 
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes of this pool show
+    256 logical CPUs behind a 16-CPU quota: 128 OpenMP threads there are 16 cores' worth of time slices)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(p)
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:  # noqa: BLE001
+            pass
+    eff = n if quota is None else max(1, min(n, int(quota)))
+    return eff, n, quota
+
+
 def algorithmic_bytes(n_points, n_slots, m_cells, k):
     """bytes one registration must move (points in, dense submap table + index grid,
     scan cells out + back in, correspondences, pose/stat out)."""
@@ -66,6 +87,32 @@ def load_counters():
         if r["kernel"] in HOT_KERNELS and r["kernel"] not in rows and int(r["grid_size"]) == want_wgs[r["kernel"]] * int(r["workgroup_size"]):
             rows[r["kernel"]] = {k: (float(v) if v not in ("", None) and k != "kernel" else v) for k, v in r.items()}
     return rows, os.path.relpath(files[-1], ROOT)
+
+
+class GroupBatch:
+    """BASELINE config 4 as written -- ONE batch split over the GPUs of the node -- through the C ABI's multi-GPU group
+    (randt_group_scan_register_batch_dev): every rank holds the full input arrays, runs its contiguous shard (NDT build ->
+    associate -> solve) and the poses / result records are gathered over RCCL, per step, on the group's stream."""
+
+    def __init__(self, R, torch, grp, submaps_g, mapp, clu, mp, points, fixed_idx, guess4, scan_cap=512):
+        self.grp, self.submaps_g, self.clu, self.mp = grp, submaps_g, clu, mp
+        self.points, self.fixed_idx, self.guess4 = points, fixed_idx, guess4
+        self.B = int(points.shape[0])
+        lo, hi = R.shard_range(self.B, grp.world, grp.first_rank)
+        self.lo, self.hi = lo, hi
+        self.poses = [guess4.clone()]
+        self.results = [torch.zeros((self.B, 64), dtype=torch.uint8, device=points.device)]
+        self.ws = R.Maps(grp.ctxs[0], max(1, hi - lo), mapp, scan_cap, with_grid=False)
+
+    def step(self, j, stream, pose, events=None, only=None):
+        if events is not None:
+            events[0].record(stream)
+            events[1].record(stream)
+            events[2].record(stream)
+        self.grp.scan_register_batch([self.points], self.clu, [self.submaps_g], [self.fixed_idx], [self.ws], self.mp, [pose], [self.results[0]],
+                                     gather=True)
+        if events is not None:
+            events[3].record(stream)
 
 
 class Batch:
@@ -231,7 +278,25 @@ def main():
             tmp.close()
     ctx.synchronize()
     t_bcast = 0.0
+    grp = submaps_g = None
     if world > 1:
+        if not via_cpu:
+            # the multi-GPU group of the C ABI (csrc/group.hip): RCCL opened and driven by librandt_hip.so itself; torch.distributed
+            # only ships the 128-byte communicator id.  The group enqueues on this rank's first stream.
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.from_numpy(R.group_unique_id()))
+            dist.broadcast(uid, src=0)
+            try:
+                grp = R.Group(device=local_rank, rank=rank, world=world, unique_id=uid.cpu().numpy(), stream=streams[0].cuda_stream)
+                submaps_g = R.Maps(grp.ctxs[0], N_SUBMAPS, mapp, N_SLOTS, storage=(t_cells, t_counts, t_grid), clear=False)
+            except Exception as e:  # noqa: BLE001 -- every rank must take the same path: agree below
+                sys.stderr.write("rank %d: randt_group unavailable (%s); falling back to torch.distributed for the exchanges\n" % (rank, e))
+                grp = None
+            ok = torch.tensor([1 if grp is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                grp = submaps_g = None
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -240,8 +305,11 @@ def main():
                 h = t.cpu()
                 dist.broadcast(h, src=0)
                 t.copy_(h)
+        elif grp is None:
+            shard.broadcast_submap_tables((t_cells, t_counts, t_grid), src=0)
         else:
-            shard.broadcast_submap_tables((t_cells, t_counts, t_grid), src=0)   # the only set-up collective
+            grp.broadcast_maps([submaps_g], root=0)                              # the only set-up collective (ncclBroadcast x 3)
+            grp.synchronize()
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
     submaps_v = [submaps] + [R.Maps(ctxs[i], N_SUBMAPS, mapp, N_SLOTS, storage=(t_cells, t_counts, t_grid), clear=False)
@@ -264,10 +332,10 @@ def main():
     # ---------------- timed region (weak = the headline) --------------------------------------------
     # the region is re-run with more steps until it lasts --min-seconds (the LAST region is the reported one; `elapsed` is
     # already the maximum over ranks, so every rank takes the same decision)
-    def region(batch):
+    def region(batch, use_streams=None):
         n = args.steps
         for _ in range(6):
-            r = timed_region(torch, dist, world, dev, batch, streams, n, args.only)
+            r = timed_region(torch, dist, world, dev, batch, use_streams or streams, n, args.only)
             if r[0] >= args.min_seconds:
                 break
             n = int(math.ceil(n * max(1.5, 1.25 * args.min_seconds / max(r[0], 1e-9))))
@@ -281,22 +349,32 @@ def main():
     strong = None
     if world > 1 and args.scaling in ("strong", "both"):
         lo, hi = shard.shard_range(B, world, rank)
-        part = Batch(R, torch, ctxs, submaps_v, mapp, clu, mp, *to_dev(base, lo, hi))
-        warm_up(torch, part, streams, 2 * n_streams)
-        s_steps, s_elapsed, s_enq, s_stage, s_pose0 = region(part)
-        # result gather (all-gather of 32-B poses + 64-B records) and the bit-identity check against the unsharded batch
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        lp, lr = (s_pose0.cpu(), part.results[0].cpu()) if via_cpu else (s_pose0, part.results[0])
-        all_pose = shard.gather_results(lp)
-        all_res = shard.gather_results(lr)
-        torch.cuda.synchronize()
-        t_gather = time.perf_counter() - t0
+        if grp is not None:
+            # through the C ABI: shard + kernels + RCCL gather of poses / records inside every step
+            part = GroupBatch(R, torch, grp, submaps_g, mapp, clu, mp, *to_dev(base))
+            warm_up(torch, part, streams[:1], 4)
+            s_steps, s_elapsed, s_enq, s_stage, s_pose0 = region(part, streams[:1])
+            all_pose, all_res, t_gather = s_pose0, part.results[0], None
+            how = "randt_group_scan_register_batch_dev (C ABI, RCCL gather inside every step, one stream)"
+        else:
+            part = Batch(R, torch, ctxs, submaps_v, mapp, clu, mp, *to_dev(base, lo, hi))
+            warm_up(torch, part, streams, 2 * n_streams)
+            s_steps, s_elapsed, s_enq, s_stage, s_pose0 = region(part)
+            # result gather (all-gather of 32-B poses + 64-B records) and the bit-identity check against the unsharded batch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lp, lr = (s_pose0.cpu(), part.results[0].cpu()) if via_cpu else (s_pose0, part.results[0])
+            all_pose = shard.gather_results(lp)
+            all_res = shard.gather_results(lr)
+            torch.cuda.synchronize()
+            t_gather = time.perf_counter() - t0
+            how = "per-rank randt_scan_register_batch_dev, gather through torch.distributed (gloo control-flow test only)"
         strong = {"value": B * s_steps / s_elapsed, "unit": "registrations/s", "scaling": "strong", "steps": s_steps,
                   "ms_per_step": s_elapsed / s_steps * 1e3, "registrations_per_gpu_per_step": hi - lo,
                   "workload": "ONE 512-registration batch (seeds 1000..1511) split contiguously over %d GPUs" % world,
+                  "entry": how,
                   "stage_ms": {"ndt_build": float(s_stage[0]), "associate": float(s_stage[1]), "solve": float(s_stage[2])},
-                  "result_gather_ms": t_gather * 1e3, "submap_broadcast_ms": t_bcast * 1e3,
+                  "result_gather_ms": None if t_gather is None else t_gather * 1e3, "submap_broadcast_ms": t_bcast * 1e3,
                   "submap_broadcast_bytes": int(cb + nb + gb)}
         if rank == 0:
             ref = Batch(R, torch, ctxs[:1], submaps_v[:1], mapp, clu, mp, *to_dev(base))
@@ -675,7 +753,8 @@ def cpu_baseline(prob, mp, gpu_pose, budget_s):
         if name != "reserved":
             setattr(op, name, getattr(mp, name))
     g4 = synth.pose3_to_pose4(prob["guess"])
-    cores = po.num_threads()
+    eff, logical, quota = effective_cpus()
+    cores = max(1, min(po.num_threads(), eff))     # one OpenMP thread per CPU the cgroup really grants
     B = len(prob["scans"])
     done, t_total, poses = 0, 0.0, None
     while t_total < budget_s:
@@ -697,7 +776,9 @@ def cpu_baseline(prob, mp, gpu_pose, budget_s):
     return {
         "cpu_baseline": {
             "value": done / t_total, "unit": "registrations/s", "cores": cores, "kind": "port",
-            "sample": "%d passes of the same 512-registration batch through the OpenMP CPU oracle (%.1f s wall, %d threads)" % (done // B, t_total, cores),
+            "host_logical_cpus": logical, "cgroup_cpu_quota": quota,
+            "sample": "%d passes of the same 512-registration batch through the OpenMP CPU oracle (%.1f s wall, %d threads = the CPUs "
+                      "the container's cgroup quota grants; the host shows %d logical CPUs)" % (done // B, t_total, cores, logical),
             "single_thread": {"value": done1 / t1, "unit": "registrations/s", "cores": 1,
                               "sample": "%d passes of the batch's first %d registrations, 1 thread (%.1f s wall)" % (done1 // n1, n1, t1)},
         },

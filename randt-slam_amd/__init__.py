@@ -8,7 +8,7 @@ through the shared library and fails loudly when it (or a GPU) is missing.
 from . import _capi, synth  # noqa: F401
 from ._capi import (CELL_DTYPE, RESULT_DTYPE, PARAM_AMBIENT4, PARAM_MANIFOLD, PARAM_VECTOR,  # noqa: F401
                     STATE_DTYPE, ClusterParams, MapParams, MatcherParams, WindowParams)
-from .host import (Context, Maps, RandtError, associate_batch, default_matcher_params, indoor_cluster_params,  # noqa: F401
+from .host import (Context, Group, Maps, RandtError, group_unique_id, shard_range, associate_batch, default_matcher_params, indoor_cluster_params,  # noqa: F401
                    indoor_map_params, make_state, ndt_build_batch, ndt_build_pndt_batch, predict_state, register_batch, register_window,
                    scan_register_batch, solve_batch, window_params)
 
@@ -17,5 +17,5 @@ __all__ = [
     "PARAM_MANIFOLD", "PARAM_AMBIENT4", "PARAM_VECTOR", "default_matcher_params", "indoor_map_params",
     "indoor_cluster_params", "ndt_build_batch", "ndt_build_pndt_batch", "associate_batch", "solve_batch", "register_batch",
     "scan_register_batch", "synth", "STATE_DTYPE", "WindowParams", "make_state", "window_params", "predict_state",
-    "register_window",
+    "register_window", "Group", "group_unique_id", "shard_range",
 ]

@@ -154,7 +154,25 @@ SYMBOLS = {
     "randt_pose_graph_optimize": (_I, [_V, _I, _V, _I, _V, _V, _V, _V, _I, _P(PgParams), _P(PgResult)]),
     "randt_predict_state": (_I, [_V, C.c_double, _V]),
     "randt_register_window": (_I, [_V, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _P(_I), _V]),
+    # multi-GPU group
+    "randt_shard_range": (None, [_I, _I, _I, _P(_I), _P(_I)]),
+    "randt_group_create": (_I, [_P(_I), _I, _P(_V), _I, _P(_V)]),
+    "randt_group_unique_id": (_I, [_V]),
+    "randt_group_create_rank": (_I, [_I, _V, _I, _I, _V, _P(_V)]),
+    "randt_group_destroy": (_I, [_V]),
+    "randt_group_info": (_I, [_V, _P(_I), _P(_I), _P(_I), _P(_I)]),
+    "randt_group_ctx": (_V, [_V, _I]),
+    "randt_group_last_error": (C.c_char_p, [_V]),
+    "randt_group_synchronize": (_I, [_V]),
+    "randt_group_broadcast_maps": (_I, [_V, _P(_V), _I, _I, _I]),
+    "randt_group_allgather_rows": (_I, [_V, _P(_V), _I, C.c_size_t]),
+    "randt_group_register_batch_dev": (_I, [_V, _P(_V), _P(_V), _P(_V), _I, _P(MatcherParams), _P(_V), _P(_V), _I]),
+    "randt_group_scan_register_batch_dev": (_I, [_V, _P(_V), _I, _I, _P(_V), _I, _I, _P(ClusterParams), _P(_V), _P(_V), _P(_V),
+                                                 _P(MatcherParams), _P(_V), _P(_V), _I]),
+    "randt_group_register_pairs": (_I, [_V, _P(_V), _V, _P(_V), _I, _P(MatcherParams), _V, _V]),
 }
+TRANSPORT_AUTO, TRANSPORT_PEER, TRANSPORT_RCCL = 0, 1, 2
+UNIQUE_ID_BYTES = 128
 
 _lib = None
 

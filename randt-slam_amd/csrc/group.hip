@@ -375,7 +375,7 @@ int randt_group_broadcast_maps(randt_group* g, randt_maps* const* maps, int firs
     if (!maps[i] || maps[i]->ctx != g->ctx[i]) return gerr(g, RANDT_ERR_INVALID, "maps[i] must be created on randt_group_ctx(g, i)");
     if (!same_geometry(maps[i], maps[0]) || first + count > maps[i]->v.n_maps) return gerr(g, RANDT_ERR_INVALID, "map batches of a group must share one geometry");
   }
-  if (count == 0 || g->world == 1) return RANDT_OK;
+  if (count == 0 || (g->world == 1 && g->transport != RANDT_TRANSPORT_RCCL)) return RANDT_OK;  // (a one-rank RCCL group still makes the calls)
   const MapView& v0 = maps[0]->v;
   const size_t cell_b = sizeof(randt_cell) * (size_t)v0.cap * count, cnt_b = sizeof(int32_t) * (size_t)count;
   const size_t grid_b = v0.grid ? sizeof(int32_t) * (size_t)v0.n_slots * count : 0;
@@ -407,7 +407,7 @@ int randt_group_broadcast_maps(randt_group* g, randt_maps* const* maps, int firs
 
 int randt_group_allgather_rows(randt_group* g, void* const* d_rows, int n_rows, size_t row_bytes) {
   if (!g || !d_rows || n_rows < 0) return RANDT_ERR_INVALID;
-  if (n_rows == 0 || row_bytes == 0 || g->world == 1) return RANDT_OK;
+  if (n_rows == 0 || row_bytes == 0 || (g->world == 1 && g->transport != RANDT_TRANSPORT_RCCL)) return RANDT_OK;
   for (int i = 0; i < g->n_local; ++i)
     if (!d_rows[i]) return RANDT_ERR_INVALID;
   if (g->transport == RANDT_TRANSPORT_RCCL) {

@@ -88,9 +88,20 @@ class Context:
     def set_trace(self, d_trace, max_len):
         self._check(self._lib.randt_ctx_set_trace(self._h, _dptr(d_trace), int(max_len)), "randt_ctx_set_trace")
 
+    @classmethod
+    def _borrowed(cls, handle, device):
+        """A context owned by someone else (a Group member): same calls, never destroyed from here."""
+        self = cls.__new__(cls)
+        self._lib = _capi.load()
+        self._h = C.c_void_p(handle)
+        self.device = device
+        self._borrow = True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.randt_ctx_destroy(self._h)
+            if not getattr(self, "_borrow", False):
+                self._lib.randt_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -545,3 +556,117 @@ def search_global(ctx, fixed, fixed_idx, moving, moving_idx, mp, bp, trans4, sca
                                             float(window_linear), float(window_angular), _dptr(t), C.byref(mc), C.byref(ne)),
                "randt_search_global")
     return mc.value, t, ne.value
+
+
+# ------------------------------------------------------------------ multi-GPU group ----
+def shard_range(n_items, world, rank):
+    """randt_shard_range: contiguous split, remainders to the low ranks."""
+    lo, hi = C.c_int(0), C.c_int(0)
+    _capi.load().randt_shard_range(int(n_items), int(world), int(rank), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def group_unique_id():
+    """randt_group_unique_id: 128 bytes rank 0 hands to every rank (as a numpy uint8 array)."""
+    buf = np.zeros(_capi.UNIQUE_ID_BYTES, dtype=np.uint8)
+    rc = _capi.load().randt_group_unique_id(_dptr(buf))
+    if rc:
+        raise RandtError(rc, "randt_group_unique_id")
+    return buf
+
+
+class Group:
+    """randt_group: one context + stream per member GPU, map broadcast, sharded registration, row gather.
+
+    Group(devices=[0, 1, ...])                       one process drives the listed devices (repeats = virtual ranks)
+    Group(device=d, rank=r, world=G, unique_id=u)    one process per GPU (u from group_unique_id() on rank 0)
+    Per-member arguments are lists with one entry per LOCAL member."""
+
+    def __init__(self, devices=None, streams=None, transport=_capi.TRANSPORT_AUTO, device=None, rank=None, world=None, unique_id=None,
+                 stream=None):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        if devices is not None:
+            n = len(devices)
+            devs = (C.c_int * n)(*[int(d) for d in devices])
+            sts = None if streams is None else (C.c_void_p * n)(*[C.c_void_p(s) if s else None for s in streams])
+            rc = self._lib.randt_group_create(devs, n, sts, int(transport), C.byref(h))
+            where = "randt_group_create"
+        else:
+            uid = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
+            rc = self._lib.randt_group_create_rank(int(device), C.c_void_p(stream) if stream else None, int(rank), int(world), _dptr(uid),
+                                                   C.byref(h))
+            where = "randt_group_create_rank"
+        if rc:
+            raise RandtError(rc, where)
+        self._h = h
+        w, nl, fr, tr = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self._lib.randt_group_info(self._h, C.byref(w), C.byref(nl), C.byref(fr), C.byref(tr))
+        self.world, self.n_local, self.first_rank, self.transport = w.value, nl.value, fr.value, tr.value
+        dl = list(devices) if devices is not None else [device]
+        self.ctxs = [Context._borrowed(self._lib.randt_group_ctx(self._h, i), dl[i]) for i in range(self.n_local)]
+
+    def _check(self, rc, where):
+        if rc:
+            raise RandtError(rc, where, self._lib.randt_group_last_error(self._h).decode())
+
+    def _arr(self, xs, handle=False):
+        """Per-member pointer array (None entries allowed)."""
+        if xs is None:
+            return None
+        assert len(xs) == self.n_local, "one entry per local member"
+        vals = []
+        for x in xs:
+            if x is None:
+                vals.append(None)
+            elif handle:
+                vals.append(x._h)
+            else:
+                vals.append(_dptr(x))
+        return (C.c_void_p * self.n_local)(*vals)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for c in self.ctxs:
+                c._h = None
+            self._lib.randt_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._lib.randt_group_synchronize(self._h), "randt_group_synchronize")
+
+    def broadcast_maps(self, maps, first=0, count=None, root=0):
+        count = maps[0].n_maps - first if count is None else count
+        self._check(self._lib.randt_group_broadcast_maps(self._h, self._arr(maps, True), first, count, root), "randt_group_broadcast_maps")
+
+    def allgather_rows(self, bufs, n_rows, row_bytes):
+        self._check(self._lib.randt_group_allgather_rows(self._h, self._arr(bufs), int(n_rows), int(row_bytes)), "randt_group_allgather_rows")
+
+    def register_batch(self, fixed, fixed_idx, moving, n_pairs, mp, pose4, results, gather=True):
+        self._check(self._lib.randt_group_register_batch_dev(self._h, self._arr(fixed, True), self._arr(fixed_idx), self._arr(moving, True),
+                                                             int(n_pairs), C.byref(mp), self._arr(pose4), self._arr(results), int(bool(gather))),
+                    "randt_group_register_batch_dev")
+
+    def scan_register_batch(self, points, cluster, fixed, fixed_idx, scan_maps, mp, pose4, results, gather=True, n_points=None,
+                            intensity_index=None):
+        B, N, S = _shape3(points[0])
+        ioff = (3 if S == 4 else 4) if intensity_index is None else intensity_index
+        self._check(self._lib.randt_group_scan_register_batch_dev(
+            self._h, self._arr(points), B, N, self._arr(n_points), S, ioff, C.byref(cluster), self._arr(fixed, True), self._arr(fixed_idx),
+            self._arr(scan_maps, True), C.byref(mp), self._arr(pose4), self._arr(results), int(bool(gather))),
+            "randt_group_scan_register_batch_dev")
+
+    def register_pairs(self, fixed, fixed_idx, moving, mp, pose4):
+        """Host convenience: returns (poses (n,4) float64, results (n,) RESULT_DTYPE)."""
+        p = np.array(pose4, dtype=np.float64).reshape(-1, 4).copy()
+        fi = np.ascontiguousarray(fixed_idx, dtype=np.int32)
+        res = np.zeros(len(p), dtype=RESULT_DTYPE)
+        self._check(self._lib.randt_group_register_pairs(self._h, self._arr(fixed, True), _dptr(fi), self._arr(moving, True), len(p), C.byref(mp),
+                                                         _dptr(p), _dptr(res)), "randt_group_register_pairs")
+        return p, res

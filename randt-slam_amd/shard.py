@@ -3,18 +3,21 @@
 Pair registrations share nothing but the read-only submap tables, so a batch splits contiguously
 across ranks with no data-path collective.  The only exchanges are (a) a broadcast of the submap
 cell tables + index grids from the owner rank, once per submap epoch, and (b) an all-gather of the
-small per-registration results.  Both go through torch.distributed: backend "nccl" (= RCCL over
-xGMI) on the GPU box, "gloo" in the CPU tests.
+small per-registration results.  The product path for both is the C ABI's randt_group_* (csrc/group.hip: RCCL opened
+by the library itself, or peer copies inside one process; host.Group binds it).  The torch.distributed helpers below
+remain for launch-time plumbing (shipping the RCCL unique id) and for the gloo control-flow tests on boxes with fewer
+GPUs than ranks.
 """
 import torch
 import torch.distributed as dist
 
 
 def shard_range(n_items, world_size, rank):
-    """Contiguous split: rank r gets [r*B/G, (r+1)*B/G) (uneven remainders go to the low ranks)."""
-    base, rem = divmod(int(n_items), int(world_size))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous split: rank r gets [r*B/G, (r+1)*B/G) (uneven remainders go to the low ranks) -- randt_shard_range of the
+    C ABI, the split randt_group_* uses."""
+    from .host import shard_range as _abi
+
+    return _abi(n_items, world_size, rank)
 
 
 def broadcast_submap_tables(tables, src=0, group=None):

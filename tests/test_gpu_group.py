@@ -1,0 +1,154 @@
+"""-m gpu: the multi-GPU group of the C ABI (randt_group_*, csrc/group.hip) -- sharding, map broadcast, result gather.
+
+On a one-GPU box the members are "virtual ranks" (several contexts + streams on device 0, peer-copy transport): the
+control flow, the sharding and the exchanges are the real ones, and the results must be bit-identical to one context
+running the whole batch.  RCCL itself is exercised with a one-rank communicator (dlopen, ncclCommInitRank,
+ncclBroadcast in a group call) and, where the box has >= 2 GPUs, with a real two-device group."""
+import numpy as np
+import pytest
+
+import randt_slam_amd as R
+from randt_slam_amd import _capi, synth
+from util import GpuRig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def base(built):
+    import torch
+
+    prob = synth.make_batch_problem(4, 33, 20)          # 132 registrations: uneven shards at G = 8
+    rig = GpuRig(prob)
+    rig.build_submaps()
+    mp = R.default_matcher_params()
+    g4 = synth.pose3_to_pose4(prob["guess"])
+    pose = torch.from_numpy(g4.copy()).to(rig.dev)
+    res = torch.zeros((rig.B, 64), dtype=torch.uint8, device=rig.dev)
+    ws = R.Maps(rig.ctx, rig.B, rig.mapp, rig.scan_cap, with_grid=False)
+    R.scan_register_batch(rig.ctx, rig.points, rig.clu, rig.submaps, rig.fixed_idx, ws, mp, pose, res)
+    rig.ctx.synchronize()
+    return prob, rig, mp, g4, pose.cpu().numpy(), res.cpu().numpy()
+
+
+def _replicas(grp, rig, torch, g4, root_maps=None):
+    """Per-member device state of a sharded batch: submap batch (empty unless this member is the root), full point / index /
+    guess arrays, workspace scan maps, outputs."""
+    n_slots = rig.mapp.size_x * rig.mapp.size_y
+    devs = [torch.device("cuda", c.device) for c in grp.ctxs]
+    subs = [R.Maps(c, rig.n_sub, rig.mapp, n_slots, with_grid=True) for c in grp.ctxs]
+    pts = [rig.points.to(d).clone() for d in devs]
+    fidx = [rig.fixed_idx.to(d).clone() for d in devs]
+    pose = [torch.from_numpy(g4.copy()).to(d) for d in devs]
+    res = [torch.zeros((rig.B, 64), dtype=torch.uint8, device=d) for d in devs]
+    ws = [R.Maps(c, rig.B, rig.mapp, rig.scan_cap, with_grid=False) for c in grp.ctxs]
+    return subs, pts, fidx, pose, res, ws
+
+
+@pytest.mark.parametrize("G", [1, 2, 4, 8])
+def test_virtual_rank_group_bit_identical_to_one_context(base, G):
+    import torch
+
+    prob, rig, mp, g4, ref_pose, ref_res = base
+    grp = R.Group(devices=[0] * G)
+    assert (grp.world, grp.n_local, grp.first_rank, grp.transport) == (G, G, 0, _capi.TRANSPORT_PEER)
+    subs, pts, fidx, pose, res, ws = _replicas(grp, rig, torch, g4)
+    # the root (member G - 1, to make it interesting) owns the submap epoch: it gets the tables, everyone else has empty maps
+    root = G - 1
+    subs[root].copy_from(rig.submaps)
+    torch.cuda.synchronize()
+    grp.broadcast_maps(subs, root=root)
+    grp.synchronize()
+    for m in subs:
+        for j in range(rig.n_sub):
+            c0, g0 = rig.submaps.download(j)
+            c1, g1 = m.download(j)
+            assert np.array_equal(c0.view(np.uint8), c1.view(np.uint8)) and np.array_equal(g0, g1)
+    grp.scan_register_batch(pts, rig.clu, subs, fidx, ws, mp, pose, res, gather=True)
+    grp.synchronize()
+    for i in range(G):      # every member holds the whole batch's outputs
+        assert np.array_equal(pose[i].cpu().numpy(), ref_pose), i
+        assert np.array_equal(res[i].cpu().numpy(), ref_res), i
+    # without the gather a member holds exactly its own rows
+    pose2 = [torch.from_numpy(g4.copy()).to(rig.dev) for _ in range(G)]
+    grp.scan_register_batch(pts, rig.clu, subs, fidx, ws, mp, pose2, res, gather=False)
+    grp.synchronize()
+    for i in range(G):
+        lo, hi = R.shard_range(rig.B, G, i)
+        got = pose2[i].cpu().numpy()
+        assert np.array_equal(got[lo:hi], ref_pose[lo:hi])
+        mask = np.ones(rig.B, bool)
+        mask[lo:hi] = False
+        assert np.array_equal(got[mask], g4[mask])
+    grp.close()
+
+
+def test_group_register_pairs_host_entry(base):
+    """randt_group_register_pairs: host poses in / out (what LocalFuser::detectLoopClosures holds), pre-built moving maps."""
+    import torch
+
+    prob, rig, mp, g4, ref_pose, ref_res = base
+    G = 3
+    grp = R.Group(devices=[0] * G)
+    subs, pts, fidx, pose, res, ws = _replicas(grp, rig, torch, g4)
+    subs[0].copy_from(rig.submaps)
+    # moving maps: built once on member 0, broadcast like any other map batch
+    R.ndt_build_batch(grp.ctxs[0], pts[0], rig.clu, ws[0])
+    grp.broadcast_maps(subs, root=0)
+    grp.broadcast_maps(ws, root=0)
+    p, r = grp.register_pairs(subs, prob["submap_of"], ws, mp, g4)
+    assert np.array_equal(p, ref_pose)
+    assert np.array_equal(r.view(np.uint8).reshape(rig.B, 64), ref_res)
+    grp.close()
+
+
+def test_rccl_transport_one_rank(base):
+    """The RCCL code path on a single GPU: unique id, ncclCommInitRank (world 1), in-place broadcasts inside a group call."""
+    import torch
+
+    prob, rig, mp, g4, ref_pose, ref_res = base
+    uid = R.group_unique_id()
+    assert uid.shape == (128,) and uid.any()
+    grp = R.Group(device=0, rank=0, world=1, unique_id=uid)
+    assert grp.transport == _capi.TRANSPORT_RCCL and grp.n_local == 1
+    subs, pts, fidx, pose, res, ws = _replicas(grp, rig, torch, g4)
+    subs[0].copy_from(rig.submaps)
+    torch.cuda.synchronize()
+    grp.broadcast_maps(subs, root=0)
+    grp.scan_register_batch(pts, rig.clu, subs, fidx, ws, mp, pose, res, gather=True)
+    grp.synchronize()
+    assert np.array_equal(pose[0].cpu().numpy(), ref_pose) and np.array_equal(res[0].cpu().numpy(), ref_res)
+    grp.close()
+
+
+def test_rccl_two_devices_one_process(base):
+    """ONE process driving two GPUs over RCCL (ncclCommInitAll): the reference's single-process node.  Needs >= 2 GPUs."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    prob, rig, mp, g4, ref_pose, ref_res = base
+    for transport in (_capi.TRANSPORT_RCCL, _capi.TRANSPORT_PEER):
+        grp = R.Group(devices=[0, 1], transport=transport)
+        subs, pts, fidx, pose, res, ws = _replicas(grp, rig, torch, g4)
+        subs[0].copy_from(rig.submaps)
+        torch.cuda.synchronize()
+        grp.broadcast_maps(subs, root=0)
+        grp.scan_register_batch(pts, rig.clu, subs, fidx, ws, mp, pose, res, gather=True)
+        grp.synchronize()
+        for i in range(2):
+            assert np.array_equal(pose[i].cpu().numpy(), ref_pose) and np.array_equal(res[i].cpu().numpy(), ref_res)
+        grp.close()
+
+
+def test_group_argument_checks(base):
+    prob, rig, mp, g4, _, _ = base
+    with pytest.raises(R.RandtError):
+        R.Group(devices=[0, 0], transport=_capi.TRANSPORT_RCCL)      # RCCL refuses two ranks on one device
+    with pytest.raises(R.RandtError):
+        R.Group(devices=[99])
+    grp = R.Group(devices=[0, 0])
+    foreign = R.Maps(rig.ctx, 1, rig.mapp, 16, with_grid=True)           # not created on the members' contexts
+    with pytest.raises(R.RandtError):
+        grp.broadcast_maps([foreign, foreign])
+    grp.close()
