@@ -397,6 +397,11 @@ int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans,
 /* Matcher::predictTransform, optimize_on_manifold branch (ndt_matcher.cpp:22-59) with predictSE2
  * (ceres_residuals.h:62-83): constant-velocity prediction of the next state.  Host-side O(1) math. */
 int randt_predict_state(const randt_state* last, double stamp, randt_state* next);
+/* The same for either state representation: RANDT_PARAM_MANIFOLD = predictSE2 (what randt_predict_state does),
+ * RANDT_PARAM_VECTOR = the (pos[2], rot) form `predict` (ceres_residuals.h:25-55, 91-123) that Matcher::predictTransform
+ * takes when optimize_on_manifold is false (ndt_matcher.cpp:27-41): mid-point heading, NormalizeAngle'd rotation,
+ * pose = Sophus::SE2d(rot, pos). */
+int randt_predict_state_param(const randt_state* last, double stamp, int parameterization, randt_state* next);
 /* Matcher::estimateTransformCeres (ndt_matcher.cpp:322-424): fixed-lag smoother over n_states = S+1
  * states (oldest first; its pose is held constant), S <= 3.  Per state j = 1..S: MotionModelFactorSE2 to
  * its predecessor (ceres_residuals.h:621-679), optional RotationalResidualSE2 (:338-370, h_imu[j-1]),

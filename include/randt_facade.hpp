@@ -19,7 +19,9 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <deque>
 #include <iostream>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <memory>
@@ -79,15 +81,33 @@ struct RadarPreprocessorParameters {
   int n_clusters = 2304;  // (2*max_range/resolution)^2, ndt_slam.cpp:691
   double max_range = 12.0;
 };
+// rc::navigation::ndt::NDTMatcherParameters (include/ndt_slam/ndt_slam_parameters.h:52-84), every member under its
+// reference name; motion_sqrtI is the 8 x 8 matrix row-major.  Defaults = config/parameters_indoor.yaml:24-39 +
+// config/ndt_radar_slam_base_parameters.yaml:21-48 (the reference struct itself has no defaults: readParameters fills it).
 struct NDTMatcherParameters {
+  std::array<double, 64> motion_sqrtI = [] {
+    std::array<double, 64> m{};
+    const double d[8] = {1, 1, 1, 1, 3, 0.1, 20, 60};  // base yaml :36-43
+    for (int i = 0; i < 8; ++i) m[i * 8 + i] = d[i];
+    return m;
+  }();
+  double covariance_scaling_factor = 25.0;
+  double weight_kinematics = 1.0;  // unused by the reference as well
+  double weight_imu = 64.0, weight_imu_bias = 6.0e5, initial_imu_bias = 0.0;
   int gnc_steps = 3;
+  int smoothing_steps = 3;
   double loss_function_convexity = -2.0, loss_function_scale = 1.5, gnc_control_parameter_divisor = 1.3;
   int max_iteration = 200;
-  int smoothing_steps = 3;
+  double pose_reject_translation = 2.0, pose_reject_rotation = 2.0;
   int n_results_kd_lookup = 4;
   double ndt_weight = 5.0e4;
-  bool use_intensity_as_dimension = true, optimize_on_manifold = true, lookup_mahalanobis = true;
   bool use_analytic_expressions_for_optimization = false;
+  bool use_intensity_as_dimension = true, use_constant_velocity_model = true, optimize_on_manifold = true, lookup_mahalanobis = true;
+  bool use_imu = false;  // indoor preset: true; the IMU increments then come through predictTransform's initial_angle_guess
+  double csm_window_linear = 4.5, csm_window_angular = 0.45, csm_linear_step = 0.4, csm_cost_threshold = 0.82;
+  double csm_max_px_accurate_range = 4.0;
+  bool csm_ignore_overlap = false;
+  int csm_n_iter = 2;
 };
 
 // Error policy of the facade.  The reference never throws and has no status codes: void / double returns, a warning on
@@ -103,10 +123,20 @@ inline int& last_status() {
   static thread_local int s = RANDT_OK;
   return s;
 }
+// The first failure since clear_errors() (last_status() is overwritten by the next successful call): a caller that cannot
+// check after every call -- the reference's call sites check nothing -- reads this once per scan.
+inline int& first_error() {
+  static thread_local int s = RANDT_OK;
+  return s;
+}
+inline void clear_errors() { last_status() = first_error() = RANDT_OK; }
+// what a failed call returns where the reference returns a scalar (a cost, a divergence): never a plausible value
+inline double failed_value() { return std::numeric_limits<double>::quiet_NaN(); }
 // returns true if the call succeeded
 inline bool facade_check(int rc, const char* what, randt_ctx* ctx) {
   last_status() = rc;
   if (rc == RANDT_OK) return true;
+  if (first_error() == RANDT_OK) first_error() = rc;
   const std::string msg = std::string(what) + ": " + randt_status_string(rc) + " (" + (ctx ? randt_last_error(ctx) : "") + ")";
   if (error_policy() == ErrorPolicy::kThrow) throw std::runtime_error(msg);
   std::cout << "WARNING: " << msg << " -- previous value kept\n";
@@ -394,12 +424,15 @@ class Map {
   // (the moving map already transformed by the caller, like local_fuser.cpp:338-339)
   double calculateCSDivergence(const Map& m_map) const {
     double v = 0.0;
-    check(randt_cs_divergence(ctx_->get(), m_, 0, m_map.m_, 0, nullptr, &v, nullptr), "randt_cs_divergence");
+    if (!check(randt_cs_divergence(ctx_->get(), m_, 0, m_map.m_, 0, nullptr, &v, nullptr), "randt_cs_divergence"))
+      return failed_value();  // NaN: "identical maps" (0) would pass a loop-closure gate
     return v;
   }
 
   randt_maps* handle() const { return m_; }
   const std::shared_ptr<Context>& context() const { return ctx_; }
+  const randt_map_params& params() const { return params_; }
+  int capacity() const { return cap_; }
 
  private:
   void create() { check(randt_maps_create(ctx_->get(), 1, &params_, cap_, 1, &m_), "randt_maps_create"); }
@@ -448,10 +481,37 @@ class HierarchicalMap {
   Map ndt_map_;
 };
 
-// rc::navigation::ndt::Matcher, pair-registration part.
+// Several GPUs behind one caller: the C ABI's multi-GPU group (randt_group_*, csrc/group.hip) for the batched loop
+// registration below.  devices = HIP device indices of the members (member 0 must be the device the facade Maps live
+// on; a repeated index gives "virtual ranks" that share one GPU).
+class DeviceGroup {
+ public:
+  explicit DeviceGroup(const std::vector<int>& devices, int transport = RANDT_TRANSPORT_AUTO) {
+    facade_check(randt_group_create(devices.data(), static_cast<int>(devices.size()), nullptr, transport, &g_), "randt_group_create", nullptr);
+    if (g_) randt_group_info(g_, &world_, &n_local_, nullptr, &transport_);
+  }
+  ~DeviceGroup() { randt_group_destroy(g_); }
+  DeviceGroup(const DeviceGroup&) = delete;
+  DeviceGroup& operator=(const DeviceGroup&) = delete;
+  randt_group* get() const { return g_; }
+  int size() const { return world_; }
+  int transport() const { return transport_; }
+
+ private:
+  randt_group* g_ = nullptr;
+  int world_ = 0, n_local_ = 0, transport_ = 0;
+};
+
+// rc::navigation::ndt::Matcher (include/ndt_registration/ndt_matcher.h:46-87): the public methods under the reference's
+// signatures (Sophus::SE2d -> SE2d, Eigen -> std::array); everything numeric goes through the C ABI.
 class Matcher {
  public:
-  // Matcher::initialize (ndt_matcher.cpp:7-16)
+  Matcher() = default;
+  Matcher(const Matcher&) = delete;
+  Matcher& operator=(const Matcher&) = delete;
+  ~Matcher() { release_stage(); }
+
+  // void Matcher::initialize(NDTMatcherParameters parameters)                          (ndt_matcher.cpp:7-16)
   void initialize(const NDTMatcherParameters& parameters) { parameters_ = parameters; }
 
   // double Matcher::estimateLoopConstraint(Sophus::SE2d& trans, const Map& old_ndt, Map& new_ndt,
@@ -461,33 +521,101 @@ class Matcher {
   double estimateLoopConstraint(SE2d& trans, const Map& old_ndt, Map& new_ndt, int max_gnc_steps,
                                 bool use_intensity_as_dimension, double scale, randt_result* stats = nullptr) const {
     randt_matcher_params mp;
-    randt_matcher_params_default(&mp);
-    mp.loss_scale = scale;                              // BarronLoss(scale, ...)            (:479)
-    mp.mu_scale = parameters_.loss_function_scale;      // gnc_mu uses the odometry scale    (:475)
-    mp.loss_alpha = parameters_.loss_function_convexity;
-    mp.loss_weight = 1.0;                               // ScaledLoss(..., 1, ...)          (:479)
-    mp.gnc_divisor = parameters_.gnc_control_parameter_divisor;
-    mp.gnc_steps = max_gnc_steps;
-    mp.max_iterations = parameters_.max_iteration;
-    mp.n_neighbours = parameters_.n_results_kd_lookup;
-    mp.lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
-    mp.use_intensity = use_intensity_as_dimension ? 1 : 0;
-    // optimize_on_manifold = true: the residuals hang on an un-manifolded 4-vector
-    mp.parameterization = (parameters_.optimize_on_manifold && !parameters_.use_analytic_expressions_for_optimization)
-                              ? RANDT_PARAM_AMBIENT4
-                              : RANDT_PARAM_VECTOR;
+    if (!loop_params(max_gnc_steps, use_intensity_as_dimension, scale, &mp, old_ndt.context()->get())) return failed_value();
     randt_result r{};
     int rc = randt_register_pair(old_ndt.context()->get(), old_ndt.handle(), 0, new_ndt.handle(), 0, &mp, trans.data(), &r);
     if (stats) *stats = r;
-    if (!facade_check(rc, "randt_register_pair", old_ndt.context()->get())) return 0.0;  // trans untouched: outputs are written on success only
+    if (!facade_check(rc, "randt_register_pair", old_ndt.context()->get())) return failed_value();  // trans untouched: outputs are written on success only
     if (r.n_residuals == 0) std::cout << "WARNING: NO RESIDUALS ADDED!" << std::endl;
     return r.cost;
+  }
+
+  // NOT in the reference (its detectLoopClosures registers the candidates one by one, local_fuser.cpp:329-339,370-397):
+  // the same call for a batch of independent candidates, sharded over the GPUs of `group`.  Pair p registers
+  // *moving_ndts[p] against *fixed_ndts[fixed_of_pair[p]] from trans[p] (in/out).  The maps are staged into one batch
+  // per member GPU and broadcast (RCCL / peer copies), every member registers its contiguous share, the poses come
+  // back to the caller; results are bit-identical to estimateLoopConstraint pair by pair.  Returns the costs.
+  std::vector<double> estimateLoopConstraintBatch(DeviceGroup& group, std::vector<SE2d>& trans, const std::vector<const Map*>& fixed_ndts,
+                                                  const std::vector<int>& fixed_of_pair, const std::vector<const Map*>& moving_ndts,
+                                                  int max_gnc_steps, bool use_intensity_as_dimension, double scale,
+                                                  std::vector<randt_result>* stats = nullptr) const {
+    const int n_pairs = static_cast<int>(moving_ndts.size()), n_fixed = static_cast<int>(fixed_ndts.size());
+    std::vector<double> cost(static_cast<size_t>(n_pairs), failed_value());
+    randt_group* g = group.get();
+    randt_matcher_params mp;
+    if (!g || n_pairs == 0 || n_fixed == 0 || static_cast<int>(trans.size()) != n_pairs || static_cast<int>(fixed_of_pair.size()) != n_pairs) {
+      facade_check(RANDT_ERR_INVALID, "estimateLoopConstraintBatch: group / argument sizes", nullptr);
+      return cost;
+    }
+    if (!loop_params(max_gnc_steps, use_intensity_as_dimension, scale, &mp, randt_group_ctx(g, 0))) return cost;
+    int world = 0, n_local = 0;
+    randt_group_info(g, &world, &n_local, nullptr, nullptr);
+    int fcap = 1, mcap = 1;
+    for (const Map* m : fixed_ndts) fcap = std::max(fcap, m->capacity());
+    for (const Map* m : moving_ndts) mcap = std::max(mcap, m->capacity());
+    std::vector<randt_maps*> fb(static_cast<size_t>(n_local), nullptr), mb(static_cast<size_t>(n_local), nullptr);
+    auto cleanup = [&] {
+      randt_group_synchronize(g);
+      for (randt_maps* m : fb) randt_maps_destroy(m);
+      for (randt_maps* m : mb) randt_maps_destroy(m);
+    };
+    int rc = RANDT_OK;
+    for (int i = 0; i < n_local && !rc; ++i) {
+      rc = randt_maps_create(randt_group_ctx(g, i), n_fixed, &fixed_ndts[0]->params(), fcap, 1, &fb[i]);
+      if (!rc) rc = randt_maps_create(randt_group_ctx(g, i), n_pairs, &moving_ndts[0]->params(), mcap, 0, &mb[i]);
+    }
+    // stage on member 0 (the facade Maps' device), then one broadcast per batch
+    for (int f = 0; f < n_fixed && !rc; ++f) {
+      randt_ctx_synchronize(fixed_ndts[f]->context()->get());
+      rc = randt_maps_copy(fb[0], f, fixed_ndts[f]->handle(), 0, 1);
+    }
+    for (int p = 0; p < n_pairs && !rc; ++p) {
+      randt_ctx_synchronize(moving_ndts[p]->context()->get());
+      rc = randt_maps_copy(mb[0], p, moving_ndts[p]->handle(), 0, 1);
+    }
+    if (!rc) rc = randt_group_broadcast_maps(g, fb.data(), 0, n_fixed, 0);
+    if (!rc) rc = randt_group_broadcast_maps(g, mb.data(), 0, n_pairs, 0);
+    std::vector<double> pose(4 * static_cast<size_t>(n_pairs));
+    std::vector<randt_result> res(static_cast<size_t>(n_pairs));
+    std::vector<int32_t> fidx(fixed_of_pair.begin(), fixed_of_pair.end());
+    for (int p = 0; p < n_pairs; ++p) std::copy(trans[p].d, trans[p].d + 4, pose.begin() + 4 * p);
+    if (!rc) rc = randt_group_register_pairs(g, fb.data(), fidx.data(), mb.data(), n_pairs, &mp, pose.data(), res.data());
+    if (rc != RANDT_OK) {
+      std::cout << "WARNING: batched loop registration failed: " << randt_group_last_error(g) << std::endl;
+      facade_check(rc, "estimateLoopConstraintBatch", randt_group_ctx(g, 0));
+      cleanup();
+      return cost;
+    }
+    for (int p = 0; p < n_pairs; ++p) {
+      if (res[p].n_residuals == 0) {
+        std::cout << "WARNING: NO RESIDUALS ADDED!" << std::endl;  // pose untouched, like the single call
+      }
+      std::copy(pose.begin() + 4 * p, pose.begin() + 4 * p + 4, trans[p].d);
+      cost[p] = res[p].cost;
+    }
+    if (stats) *stats = res;
+    cleanup();
+    last_status() = RANDT_OK;
+    return cost;
   }
 
   // double Matcher::estimateTransformGlobalBNB(Sophus::SE2d& trans, const Map& fixed_ndt, Map& moving_ndt,
   //   bool use_intensity_as_dimension, double scale, double search_window_size_linear,
   //   double search_window_size_angular)                                       (ndt_matcher.cpp:495-608)
-  // csm: the csm_* members of NDTMatcherParameters (ndt_slam_parameters.h:76-83).
+  // The csm_* members come from the parameters given to initialize(), like in the reference.
+  double estimateTransformGlobalBNB(SE2d& trans, const Map& fixed_ndt, Map& moving_ndt, bool use_intensity_as_dimension, double scale,
+                                    double search_window_size_linear, double search_window_size_angular) const {
+    randt_bnb_params csm{};
+    csm.csm_window_linear = parameters_.csm_window_linear;
+    csm.csm_window_angular = parameters_.csm_window_angular;
+    csm.csm_linear_step = parameters_.csm_linear_step;
+    csm.csm_cost_threshold = parameters_.csm_cost_threshold;
+    csm.csm_max_px_accurate_range = parameters_.csm_max_px_accurate_range;
+    csm.csm_n_iter = parameters_.csm_n_iter;
+    return estimateTransformGlobalBNB(trans, fixed_ndt, moving_ndt, use_intensity_as_dimension, scale, search_window_size_linear,
+                                      search_window_size_angular, csm);
+  }
+  // the same with explicit csm_* values (not a reference signature)
   double estimateTransformGlobalBNB(SE2d& trans, const Map& fixed_ndt, Map& moving_ndt, bool use_intensity_as_dimension, double scale,
                                     double search_window_size_linear, double search_window_size_angular,
                                     const randt_bnb_params& csm) const {
@@ -496,10 +624,11 @@ class Matcher {
     mp.loss_alpha = parameters_.loss_function_convexity;
     mp.lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
     mp.use_intensity = use_intensity_as_dimension ? 1 : 0;
+    if (refuse_analytic(fixed_ndt.context()->get())) return failed_value();
     double min_cost = 0.0;
     const int rc = randt_search_global(fixed_ndt.context()->get(), fixed_ndt.handle(), 0, moving_ndt.handle(), 0, &mp, &csm, scale,
                                        search_window_size_linear, search_window_size_angular, trans.data(), &min_cost, nullptr);
-    if (rc != RANDT_OK) std::cout << "WARNING: global search failed: " << randt_status_string(rc) << std::endl;
+    if (!facade_check(rc, "randt_search_global", fixed_ndt.context()->get())) return failed_value();
     return min_cost;
   }
 
@@ -507,10 +636,12 @@ class Matcher {
 
   // void Matcher::predictTransform(const double& initial_angle_guess, const double& stamp,
   //                                std::vector<State>& trajectory)            (ndt_matcher.cpp:22-59)
+  // optimize_on_manifold = false (or the analytic flag) takes the reference's vector-form `predict` (:27-41).
   void predictTransform(const double& initial_angle_guess, const double& stamp, std::vector<State>& trajectory) {
     if (trajectory.empty()) return;
     randt_state last = toAbi(trajectory.back()), next;
-    randt_predict_state(&last, stamp, &next);
+    const bool vec = parameters_.use_analytic_expressions_for_optimization || !parameters_.optimize_on_manifold;
+    randt_predict_state_param(&last, stamp, vec ? RANDT_PARAM_VECTOR : RANDT_PARAM_MANIFOLD, &next);
     trajectory.push_back(fromAbi(next));
     imu_constraints_.push_back(initial_angle_guess);
   }
@@ -518,14 +649,47 @@ class Matcher {
   // void Matcher::estimateTransformCeres(Sophus::SE2d& trans, std::vector<State>& trajectory,
   //      const double& initial_angle_guess, const double& stamp, const std::deque<Map>& fixed_ndts,
   //      const std::deque<Map>& moving_ndts)                                   (ndt_matcher.cpp:322-424)
-  // The maps of one call must live in the same device batch: pass the MapBatch that owns them and
-  // their slot indices (a std::deque<Map> of the reference becomes a vector of slots).
+  // THE REFERENCE SIGNATURE.  The window's maps (<= 2 fixed, the newest smoothing_steps moving ones) are copied on the
+  // device into two internal batches (Map is one device-resident map; the window kernel wants its maps side by side);
+  // every window parameter comes from initialize(), like in the reference.
+  void estimateTransformCeres(SE2d& trans, std::vector<State>& trajectory, const double& initial_angle_guess, const double& stamp,
+                              const std::deque<Map>& fixed_ndts, const std::deque<Map>& moving_ndts, randt_result* stats = nullptr) {
+    if (trajectory.size() < 2 || fixed_ndts.empty() || moving_ndts.empty()) return;
+    const size_t S = std::min(trajectory.size() - 1, static_cast<size_t>(parameters_.smoothing_steps));  // :343
+    if (moving_ndts.size() < S) {
+      facade_check(RANDT_ERR_INVALID, "estimateTransformCeres: fewer moving maps than window states", nullptr);
+      return;
+    }
+    const std::shared_ptr<Context>& ctx = fixed_ndts.front().context();
+    const int nf = static_cast<int>(fixed_ndts.size());
+    int fcap = 1, mcap = 1;
+    for (const Map& m : fixed_ndts) fcap = std::max(fcap, m.capacity());
+    for (size_t i = 1; i <= S; ++i) mcap = std::max(mcap, moving_ndts.end()[-static_cast<long>(i)].capacity());
+    if (!ensure_stage(ctx, fixed_ndts.front().params(), fcap, nf, moving_ndts.back().params(), mcap, static_cast<int>(S))) return;
+    std::vector<int32_t> fslots, mslots;
+    int rc = RANDT_OK;
+    for (int f = 0; f < nf && !rc; ++f) {
+      rc = randt_maps_copy(stage_fixed_, f, fixed_ndts[f].handle(), 0, 1);
+      fslots.push_back(f);
+    }
+    for (size_t i = S; i >= 1 && !rc; --i) {  // moving_ndts.end()[-i], i = S..1 -> slots 0..S-1 (oldest first)
+      rc = randt_maps_copy(stage_moving_, static_cast<int>(S - i), moving_ndts.end()[-static_cast<long>(i)].handle(), 0, 1);
+      mslots.push_back(static_cast<int32_t>(S - i));
+    }
+    if (!facade_check(rc, "randt_maps_copy (window staging)", ctx->get())) return;
+    estimateTransformCeres(trans, trajectory, initial_angle_guess, stamp, stage_fixed_, fslots, stage_moving_, mslots, ctx->get(), window_params(),
+                           stats);
+  }
+
+  // The same on maps that already live side by side in device batches (no staging copies): slots of `fixed_batch` /
+  // `moving_batch` instead of deques (moving_slots: the scan window, oldest first).  Not a reference signature.
   void estimateTransformCeres(SE2d& trans, std::vector<State>& trajectory, const double& /*initial_angle_guess*/,
                               const double& /*stamp*/, randt_maps* fixed_batch, const std::vector<int32_t>& fixed_slots,
                               randt_maps* moving_batch, const std::vector<int32_t>& moving_slots, randt_ctx* ctx,
                               const randt_window_params& wp, randt_result* stats = nullptr) {
     if (trajectory.size() < 2) return;
-    const size_t S = std::min(trajectory.size() - 1, static_cast<size_t>(parameters_.smoothing_steps));  // :343
+    const size_t S = std::min(trajectory.size() - 1, static_cast<size_t>(wp.smoothing_steps > 0 ? wp.smoothing_steps : parameters_.smoothing_steps));  // :343
+    if (refuse_analytic(ctx)) return;
     randt_matcher_params mp;
     randt_matcher_params_default(&mp);
     mp.loss_scale = mp.mu_scale = parameters_.loss_function_scale;
@@ -536,7 +700,8 @@ class Matcher {
     mp.n_neighbours = parameters_.n_results_kd_lookup;
     mp.lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
     mp.use_intensity = parameters_.use_intensity_as_dimension ? 1 : 0;
-    mp.parameterization = RANDT_PARAM_MANIFOLD;
+    // optimize_on_manifold: false -> the (pos[2], rot) problem of ndt_matcher.cpp:290-313,330-335
+    mp.parameterization = parameters_.optimize_on_manifold ? RANDT_PARAM_MANIFOLD : RANDT_PARAM_VECTOR;
     std::vector<randt_state> st(S + 1);
     for (size_t j = 0; j <= S; ++j) st[j] = toAbi(trajectory.end()[-(long)(S + 1) + (long)j]);
     std::vector<int32_t> mv(moving_slots.end() - (long)S, moving_slots.end());  // moving_ndts.end()[-i], i = S..1
@@ -548,11 +713,23 @@ class Matcher {
     int rc = randt_register_window(ctx, fixed_batch, fixed_slots.data(), (int)fixed_slots.size(), moving_batch, mv.data(), st.data(),
                                    (int)st.size(), imu.empty() ? nullptr : imu.data(), &mp, &wp, trans.data(), &rejected, &r);
     if (stats) *stats = r;
-    if (rc != RANDT_OK) {
-      std::cout << "WARNING: window registration failed: " << randt_status_string(rc) << std::endl;
-      return;
-    }
+    if (!facade_check(rc, "randt_register_window", ctx)) return;  // trajectory and trans as they were
     for (size_t j = 0; j <= S; ++j) trajectory.end()[-(long)(S + 1) + (long)j] = fromAbi(st[j]);
+  }
+
+  // randt_window_params from the parameters given to initialize() (ndt_matcher.cpp:99: covariance_scaling_factor * motion_sqrtI)
+  randt_window_params window_params() const {
+    randt_window_params wp{};
+    for (int i = 0; i < 64; ++i) wp.motion_sqrtI[i] = parameters_.covariance_scaling_factor * parameters_.motion_sqrtI[i];
+    wp.ndt_weight = parameters_.ndt_weight;
+    wp.weight_imu = parameters_.weight_imu;
+    wp.weight_imu_bias = parameters_.weight_imu_bias;
+    wp.pose_reject_translation = parameters_.pose_reject_translation;
+    wp.pose_reject_rotation = parameters_.pose_reject_rotation;
+    wp.smoothing_steps = parameters_.smoothing_steps;
+    wp.use_imu = parameters_.use_imu ? 1 : 0;
+    wp.use_constant_velocity_model = parameters_.use_constant_velocity_model ? 1 : 0;
+    return wp;
   }
 
   static randt_state toAbi(const State& s) {
@@ -573,8 +750,69 @@ class Matcher {
   }
 
  private:
+  // `use_analytic_expressions_for_optimization: true` selects the reference's hand-written functors
+  // (ceres_residuals.h:207-305), whose rotation Jacobian is wrong for theta != 0: their iterates are not
+  // reproduced here, and computing the autodiff answer instead would be a silent behaviour change -- so the call is
+  // refused (RANDT_ERR_UNSUPPORTED in last_status(), outputs untouched).  No shipped configuration sets the flag.
+  bool refuse_analytic(randt_ctx* ctx) const {
+    if (!parameters_.use_analytic_expressions_for_optimization) return false;
+    std::cout << "WARNING: use_analytic_expressions_for_optimization is not supported (the reference's analytic Jacobian is "
+                 "incorrect for rotated poses and is not reproduced); set it to false" << std::endl;
+    facade_check(RANDT_ERR_UNSUPPORTED, "use_analytic_expressions_for_optimization", ctx);
+    return true;
+  }
+  bool loop_params(int max_gnc_steps, bool use_intensity_as_dimension, double scale, randt_matcher_params* mp, randt_ctx* ctx) const {
+    if (refuse_analytic(ctx)) return false;
+    randt_matcher_params_default(mp);
+    mp->loss_scale = scale;                              // BarronLoss(scale, ...)            (:479)
+    mp->mu_scale = parameters_.loss_function_scale;      // gnc_mu uses the odometry scale    (:475)
+    mp->loss_alpha = parameters_.loss_function_convexity;
+    mp->loss_weight = 1.0;                               // ScaledLoss(..., 1, ...)          (:479)
+    mp->gnc_divisor = parameters_.gnc_control_parameter_divisor;
+    mp->gnc_steps = max_gnc_steps;
+    mp->max_iterations = parameters_.max_iteration;
+    mp->n_neighbours = parameters_.n_results_kd_lookup;
+    mp->lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
+    mp->use_intensity = use_intensity_as_dimension ? 1 : 0;
+    // optimize_on_manifold = true: the residuals hang on an un-manifolded 4-vector; false: (pos, rot)
+    mp->parameterization = parameters_.optimize_on_manifold ? RANDT_PARAM_AMBIENT4 : RANDT_PARAM_VECTOR;
+    return true;
+  }
+  // internal batches the deque overload of estimateTransformCeres copies the window's maps into
+  bool ensure_stage(const std::shared_ptr<Context>& ctx, const randt_map_params& fp, int fcap, int n_fixed, const randt_map_params& mpar,
+                    int mcap, int n_moving) {
+    auto fits = [](randt_maps* b, const randt_map_params& p, int cap_needed, int n) {
+      if (!b) return false;
+      int nm = 0, cap = 0, slots = 0;
+      randt_maps_info(b, &nm, &cap, &slots, nullptr);
+      return nm >= n && cap >= cap_needed && slots == p.size_x * p.size_y;
+    };
+    if (stage_ctx_ != ctx) release_stage();
+    int rc = RANDT_OK;
+    if (!fits(stage_fixed_, fp, fcap, n_fixed)) {
+      randt_maps_destroy(stage_fixed_);
+      stage_fixed_ = nullptr;
+      rc = randt_maps_create(ctx->get(), std::max(2, n_fixed), &fp, fcap, 1, &stage_fixed_);
+    }
+    if (!rc && !fits(stage_moving_, mpar, mcap, n_moving)) {
+      randt_maps_destroy(stage_moving_);
+      stage_moving_ = nullptr;
+      rc = randt_maps_create(ctx->get(), std::max(4, n_moving), &mpar, mcap, 0, &stage_moving_);
+    }
+    stage_ctx_ = ctx;
+    return facade_check(rc, "randt_maps_create (window staging)", ctx->get());
+  }
+  void release_stage() {
+    randt_maps_destroy(stage_fixed_);
+    randt_maps_destroy(stage_moving_);
+    stage_fixed_ = stage_moving_ = nullptr;
+    stage_ctx_.reset();
+  }
+
   NDTMatcherParameters parameters_;
   std::vector<double> imu_constraints_;
+  std::shared_ptr<Context> stage_ctx_;
+  randt_maps *stage_fixed_ = nullptr, *stage_moving_ = nullptr;
 };
 
 // rc::navigation::ndt::ScanContextParameters (include/ndt_slam/ndt_slam_parameters.h; ndt_slam.cpp:515-552)

@@ -153,6 +153,7 @@ SYMBOLS = {
     "randt_pg_params_default": (None, [_P(PgParams)]),
     "randt_pose_graph_optimize": (_I, [_V, _I, _V, _I, _V, _V, _V, _V, _I, _P(PgParams), _P(PgResult)]),
     "randt_predict_state": (_I, [_V, C.c_double, _V]),
+    "randt_predict_state_param": (_I, [_V, C.c_double, _I, _V]),
     "randt_register_window": (_I, [_V, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _P(_I), _V]),
     # multi-GPU group
     "randt_shard_range": (None, [_I, _I, _I, _P(_I), _P(_I)]),

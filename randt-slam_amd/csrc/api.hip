@@ -1232,6 +1232,43 @@ int randt_predict_state(const randt_state* last, double stamp, randt_state* next
   return RANDT_OK;
 }
 
+// NormalizeAngle (include/ndt_registration/state_manifold.h:17-23)
+static double h_normalize_angle(double a) { return a - 2.0 * M_PI * floor((a + M_PI) / (2.0 * M_PI)); }
+
+int randt_predict_state_param(const randt_state* last, double stamp, int parameterization, randt_state* next) {
+  if (!last || !next) return RANDT_ERR_INVALID;
+  if (parameterization == RANDT_PARAM_MANIFOLD) return randt_predict_state(last, stamp, next);
+  if (parameterization != RANDT_PARAM_VECTOR) return RANDT_ERR_INVALID;
+  // predict(...) with last_state.lin_acc = 0 (ndt_matcher.cpp:26-41; ceres_residuals.h:91-123)
+  const double raw_dt = stamp - last->stamp;
+  const double dt = raw_dt > 0.2 ? raw_dt : 0.2;
+  randt_state n;
+  memset(&n, 0, sizeof(n));
+  double new_rot = last->rot;
+  new_rot += dt * last->rot_vel;
+  new_rot = h_normalize_angle(new_rot);
+  const double rot = h_normalize_angle(last->rot + 0.5 * dt * last->rot_vel);
+  const double sy = sin(rot), cy = cos(rot);
+  const double half_dt2 = 0.5 * dt * dt;
+  const double delta_x = last->lin_vel[0] * dt + 0.0 * half_dt2;
+  const double delta_y = last->lin_vel[1] * dt + 0.0 * half_dt2;
+  n.pos[0] = last->pos[0] + (cy * delta_x - sy * delta_y);
+  n.pos[1] = last->pos[1] + (sy * delta_x + cy * delta_y);
+  n.rot = new_rot;
+  n.lin_vel[0] = last->lin_vel[0];
+  n.lin_vel[1] = last->lin_vel[1];
+  n.rot_vel = last->rot_vel;
+  // X_next_.pose = Sophus::SE2d(X_next_.rot, X_next_.pos) (:41): SO2(theta) = (cos, sin)
+  n.pose[0] = cos(new_rot);
+  n.pose[1] = sin(new_rot);
+  n.pose[2] = n.pos[0];
+  n.pose[3] = n.pos[1];
+  n.imu_bias = 0.0;
+  n.stamp = stamp;
+  *next = n;
+  return RANDT_OK;
+}
+
 int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
                           const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
                           const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,

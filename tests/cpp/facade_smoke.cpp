@@ -1,7 +1,9 @@
 // Exercises include/randt_facade.hpp the way LocalFuser::detectLoopClosures uses the reference
 // classes (local_fuser.cpp:329-339): build two NDT maps from point clouds, then
 // Matcher::estimateLoopConstraint.  Exit 0: pose recovered; 3: no GPU (expected on a CPU-only box).
+#include <cmath>
 #include <cstdio>
+#include <deque>
 #include <random>
 #include <vector>
 
@@ -70,35 +72,51 @@ int main() {
   SE2d keep(0.2, 1.0, 2.0);
   matcher.estimateLoopConstraint(keep, submap, empty, 2, true, 1.5);
   const bool kept = keep.d[2] == 1.0 && keep.d[3] == 2.0;
-  // fixed-lag odometry through the facade: predictTransform + estimateTransformCeres on a 3-scan drive
+  // fixed-lag odometry through the facade: predictTransform + estimateTransformCeres on a 3-scan drive, called with THE
+  // REFERENCE'S SIGNATURE (std::deque<Map> fixed / moving windows, all parameters from initialize()) like
+  // LocalFuser::processScan does (local_fuser.cpp:125-138), and -- same drive -- through the batch-slot variant
   bool win_ok = true;
   {
+    Map sub_w;
+    sub_w.initialize(ctx, mp, 0.0, 0.0);
+    sub_w.mergeMapCell(scan_a);
+    std::deque<Map> f_maps, map_window;
+    f_maps.push_back(sub_w);
+    std::vector<State> trajectory(1), trajectory_b(1);
+    trajectory[0].lin_vel = {0.8, 0.0};
+    trajectory_b[0].lin_vel = {0.8, 0.0};
+    Matcher mw, mb;
+    mw.initialize(prm);
+    mb.initialize(prm);
     randt_map_params rmp{mp.size_x, mp.size_y, mp.resolution, 0.0, 0.0, mp.max_neighbour_manhattan_distance, mp.min_points_per_cell, 0};
     randt_maps *fixed_batch = nullptr, *scan_batch = nullptr;
     if (randt_maps_create(ctx->get(), 1, &rmp, 10000, 1, &fixed_batch) || randt_maps_create(ctx->get(), 4, &rmp, 512, 0, &scan_batch)) return 4;
     randt_cluster_params cp{rp.n_clusters, (float)rp.max_range};
-    // submap = the blob scene at identity; scans seen from a sensor moving +0.25 m in x per step
     randt_ndt_build(ctx->get(), fixed_pts.data(), (int)fixed_pts.size() / 4, 4, 3, &cp, scan_batch, 0);
     const double id[4] = {1, 0, 0, 0};
     randt_maps_merge(fixed_batch, 0, scan_batch, 0, 1, id);
-    std::vector<State> trajectory(1);
-    trajectory[0].lin_vel = {0.8, 0.0};
-    randt_window_params wp{};
-    const double diag[8] = {1, 1, 1, 1, 3, 0.1, 20, 60};
-    for (int i = 0; i < 8; ++i) wp.motion_sqrtI[i * 8 + i] = 25.0 * diag[i];
-    wp.ndt_weight = 5.0e4; wp.pose_reject_translation = 2.0; wp.pose_reject_rotation = 2.0;
-    wp.smoothing_steps = 3; wp.use_constant_velocity_model = 1;
-    SE2d cur;
+    SE2d cur, cur_b;
     std::vector<int32_t> window;
-    for (int step = 1; step <= 3; ++step) {
-      std::vector<float> pts;
+    for (int step = 1; step <= 4; ++step) {
+      std::vector<float> pts;   // the blob scene seen from a sensor moving +0.25 m in x per step
       for (size_t p = 0; p < fixed_pts.size(); p += 4) pts.insert(pts.end(), {fixed_pts[p] - 0.25f * step, fixed_pts[p + 1], 0.f, fixed_pts[p + 3]});
-      randt_ndt_build(ctx->get(), pts.data(), (int)pts.size() / 4, 4, 3, &cp, scan_batch, step);
-      window.push_back(step);
-      matcher.predictTransform(0.0, 0.25 * step, trajectory);
-      matcher.estimateTransformCeres(cur, trajectory, 0.0, 0.25 * step, fixed_batch, {0}, scan_batch, window, ctx->get(), wp);
+      Map scan_w;
+      scan_w.initialize(ctx, mp, 0.0, 0.0, 512);
+      scan_w.addScan(pts.data(), (int)pts.size() / 4, 4, 3, rp);
+      map_window.push_back(scan_w);
+      const double stamp = 0.25 * step, yaw = 0.0;
+      mw.predictTransform(yaw, stamp, trajectory);
+      mw.estimateTransformCeres(cur, trajectory, yaw, stamp, f_maps, map_window);                 // reference signature
+      if ((int)map_window.size() >= prm.smoothing_steps) map_window.pop_front();                   // local_fuser.cpp:152-154
+      // batch-slot variant on the same data
+      randt_ndt_build(ctx->get(), pts.data(), (int)pts.size() / 4, 4, 3, &cp, scan_batch, step % 4);
+      window.push_back(step % 4);
+      mb.predictTransform(yaw, stamp, trajectory_b);
+      mb.estimateTransformCeres(cur_b, trajectory_b, yaw, stamp, fixed_batch, {0}, scan_batch, window, ctx->get(), mb.window_params());
+      if ((int)window.size() >= prm.smoothing_steps) window.erase(window.begin());
       std::printf("step %d pose %.4f %.4f %.4f vel %.3f\n", step, cur.d[2], cur.d[3], cur.angle(), trajectory.back().lin_vel[0]);
       win_ok = win_ok && std::fabs(cur.d[2] - 0.25 * step) < 0.03 && std::fabs(cur.d[3]) < 0.03 && std::fabs(cur.angle()) < 0.01;
+      win_ok = win_ok && cur.d[2] == cur_b.d[2] && cur.d[3] == cur_b.d[3] && cur.d[0] == cur_b.d[0];   // staging copies change nothing
     }
     randt_maps_destroy(fixed_batch);
     randt_maps_destroy(scan_batch);
@@ -128,9 +146,12 @@ int main() {
     Map off = fb;                                            // value copy, then transformMap like :338
     off.transformMap(SE2d(0.6, 1.5, -1.0));
     const double cs_bad = sub2.calculateCSDivergence(off);
-    randt_bnb_params csm{4.5, 0.45, 0.4, 1e9, 4.0, 2, 0};
+    Matcher csm_matcher;
+    NDTMatcherParameters csm_prm = prm;
+    csm_prm.csm_cost_threshold = 1e9;       // csm_* come from the parameters, like in the reference (ndt_slam_parameters.h:76-83)
+    csm_matcher.initialize(csm_prm);
     SE2d g(0.0, 0.0, 0.0);
-    const double bnb_cost = matcher.estimateTransformGlobalBNB(g, submap, scan_b, true, 1.5, 1.0, 0.3, csm);
+    const double bnb_cost = csm_matcher.estimateTransformGlobalBNB(g, submap, scan_b, true, 1.5, 1.0, 0.3);   // reference signature
     std::printf("cs divergence aligned %.4f vs displaced %.4f; global search -> %.3f %.3f %.3f (cost %.4f)\n", cs_good, cs_bad, g.d[2],
                 g.d[3], g.angle(), bnb_cost);
     // the correlative search is a coarse grid (0.1 m / finest level) over correspondences frozen at the guess
@@ -231,6 +252,40 @@ int main() {
     const auto hc = hm.getMap().getCells();
     cell_ok = cell_ok && hc.size() == 2 && hc[0].getMean() == c1.getMean() && hc[1].getIntensityCov() == c2.getIntensityCov();
   }
+  // batched loop registration over a group of (virtual) GPUs: bit-identical to the pair-by-pair calls
+  bool batch_ok = true;
+  {
+    const int n_cand = 7;
+    std::vector<SE2d> guess, single;
+    for (int p = 0; p < n_cand; ++p) guess.emplace_back(0.05 + 0.01 * p, 0.15 - 0.02 * p, -0.05 + 0.015 * p);
+    single = guess;
+    std::vector<double> single_cost;
+    for (int p = 0; p < n_cand; ++p) single_cost.push_back(matcher.estimateLoopConstraint(single[p], p % 2 ? copy : submap, scan_b, 2, true, 1.5));
+    for (int n_dev : {1, 3}) {
+      DeviceGroup grp(std::vector<int>(n_dev, 0));              // n_dev contexts on device 0: peer-copy transport
+      std::vector<SE2d> batch = guess;
+      std::vector<const Map*> fixed_list{&submap, &copy}, moving_list(n_cand, &scan_b);
+      std::vector<int> fixed_of(n_cand);
+      for (int p = 0; p < n_cand; ++p) fixed_of[p] = p % 2;
+      std::vector<randt_result> bst;
+      const std::vector<double> bc = matcher.estimateLoopConstraintBatch(grp, batch, fixed_list, fixed_of, moving_list, 2, true, 1.5, &bst);
+      for (int p = 0; p < n_cand; ++p)
+        batch_ok = batch_ok && bc[p] == single_cost[p] && batch[p].d[0] == single[p].d[0] && batch[p].d[1] == single[p].d[1] &&
+                   batch[p].d[2] == single[p].d[2] && batch[p].d[3] == single[p].d[3];
+      std::printf("group of %d: %d candidates, pose[6] %.5f %.5f (single %.5f %.5f), transport %d\n", grp.size(), n_cand, batch[6].d[2],
+                  batch[6].d[3], single[6].d[2], single[6].d[3], grp.transport());
+    }
+    // refusals instead of silent substitutions: the analytic functors are not reproduced
+    Matcher ana;
+    NDTMatcherParameters ap = prm;
+    ap.use_analytic_expressions_for_optimization = true;
+    ana.initialize(ap);
+    SE2d keep3(0.3, 4.0, 5.0);
+    clear_errors();
+    const double c = ana.estimateLoopConstraint(keep3, submap, scan_b, 2, true, 1.5);
+    batch_ok = batch_ok && std::isnan(c) && keep3.d[2] == 4.0 && last_status() == RANDT_ERR_UNSUPPORTED && first_error() == RANDT_ERR_UNSUPPORTED;
+    clear_errors();
+  }
   // pose-graph back end through the GlobalFuser mirror: a drifting square drive closed by one loop constraint
   bool pg_ok = true;
   {
@@ -274,5 +329,6 @@ int main() {
     pg_ok = e1 < 0.1 * e0 && nodes.at(0).pos[0] == 0.0 && nodes.at(0).pos[1] == 0.0 &&
             std::fabs(nodes.at(n - 1).pose.d[2] - after[0]) < 1e-12;
   }
-  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok && edit_ok && cell_ok) ? 0 : 2;
+  std::printf("checks: pair %d kept %d window %d sc %d gate %d pg %d edit %d cell %d batch %d\n", ok, kept, win_ok, sc_ok, gate_ok, pg_ok, edit_ok, cell_ok, batch_ok);
+  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok && edit_ok && cell_ok && batch_ok) ? 0 : 2;
 }
