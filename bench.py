@@ -254,6 +254,12 @@ def main():
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     ctxs = [R.Context(local_rank, st.cuda_stream) for st in streams]
     ctx = ctxs[0]
+    if n_streams > 1:
+        # several batches in flight: the chip is full, one wavefront per registration (the library's AUTO default would give a
+        # lone 512-registration batch eight wavefronts per registration -- right for the single_batch section below, which
+        # switches it back, and wrong here: 4.6 M instead of 9.0 M registrations/s)
+        for c in ctxs:
+            c.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
     mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
     mp = R.default_matcher_params()
     k = mp.n_neighbours
@@ -452,7 +458,8 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
                         launch, one stream: the launch fills the chip by itself, so its duration is a per-launch cost and
                         the rocprofv3 kernel trace of the same command shows the same number."""
     st, B = streams[0], full.B
-    # ---- single batch, single stream
+    # ---- single batch, single stream: the library's own choice of solve geometry (RANDT_SOLVE_AUTO)
+    ctxs[0].set_solve_mode(R._capi.SOLVE_AUTO)
     reps = 200
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     poses = [full.guess4.clone() for _ in range(reps)]
@@ -467,7 +474,23 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
     single = {"streams": 1, "registrations_per_launch": B, "value": B * reps / el, "unit": "registrations/s",
               "batch_latency_us": float(lat),
               "kernel_us": {"k_ndt_build": float(sb[0]), "k_associate": float(sb[1]), "k_solve": float(sb[2])},
-              "note": "one 512-registration batch alone (a loop-closure burst): 512 solve wavefronts cannot fill 1024 SIMDs"}
+              "note": "one 512-registration batch alone (a loop-closure burst), solve geometry chosen by the library "
+                      "(RANDT_SOLVE_AUTO: eight wavefronts per registration at this size)"}
+    # the per-GPU share of an 8-GPU split of the same batch: 64 registrations alone on the device
+    sub = Batch(R, torch, ctxs[:1], submaps_v[:1], mapp, clu, mp, full.points[:64].contiguous(), full.fixed_idx[:64].contiguous(),
+                full.guess4[:64].contiguous())
+    ev64 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    p64 = [sub.guess4.clone() for _ in range(reps)]
+    for i in range(3):
+        sub.step(0, st, sub.poses[0])
+    torch.cuda.synchronize()
+    for i in range(reps):
+        sub.step(0, st, p64[i], ev64[i])
+    torch.cuda.synchronize()
+    sb64 = np.array([[ev64[s][i].elapsed_time(ev64[s][i + 1]) for i in range(3)] for s in range(reps)]).mean(axis=0) * 1e3
+    single["batch_of_64"] = {"batch_latency_us": float(np.array([ev64[s][0].elapsed_time(ev64[s][3]) for s in range(reps)]).mean() * 1e3),
+                             "kernel_us": {"k_ndt_build": float(sb64[0]), "k_associate": float(sb64[1]), "k_solve": float(sb64[2])}}
+    sub.scan_maps[0].close()
     # ---- chip-filling launch of the dominant kernel
     rep = lambda t: t.repeat(*([SAT_COPIES] + [1] * (t.dim() - 1))).contiguous()
     big = Batch(R, torch, ctxs[:1], submaps_v[:1], mapp, clu, mp, rep(full.points), rep(full.fixed_idx), rep(full.guess4))
@@ -541,6 +564,8 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
         "note": "SURVEY 8(d) byte model (counts the dense 480 KB submap table once per registration) x registrations/s; kept for "
                 "continuity with round 1 -- the compact cell tables make the real traffic ~10x smaller, see roofline.traffic"}
     big.scan_maps[0].close()
+    if len(ctxs) > 1:
+        ctxs[0].set_solve_mode(R._capi.SOLVE_THROUGHPUT)
     return out
 
 

@@ -158,6 +158,16 @@ int randt_ctx_synchronize(randt_ctx* ctx);
 /* Debug/parity hook: when set, each solve writes its per-iteration (cost, radius, flag) triplets
  * (max_len per registration; first double of each block = number written).  NULL disables. */
 int randt_ctx_set_trace(randt_ctx* ctx, double* d_trace, int max_len);
+/* How the pair solve lays a batch out on the device (results are bit-identical either way):
+ *   RANDT_SOLVE_AUTO (default)  chosen per launch from the batch size, assuming the device has nothing else to do: a batch
+ *                               too small to give every SIMD a registration of its own (<= 3 per compute unit: one
+ *                               loop-closure burst, the per-GPU share of a multi-GPU split) gets several wavefronts per
+ *                               registration, which shortens the batch's latency (512 registrations: 148 -> 117 us);
+ *   RANDT_SOLVE_THROUGHPUT      always one wavefront per registration: for callers that keep several batches in flight on
+ *                               several contexts / streams (bench.py's 16-stream region), where the chip is full anyway and
+ *                               helper wavefronts only take slots away from other batches. */
+enum { RANDT_SOLVE_AUTO = 0, RANDT_SOLVE_THROUGHPUT = 1 };
+int randt_ctx_set_solve_mode(randt_ctx* ctx, int mode);
 void randt_matcher_params_default(randt_matcher_params* p);
 
 /* ------------------------------------------------------------------ maps -------------------- */

@@ -105,6 +105,7 @@ SYMBOLS = {
     "randt_ctx_set_stream": (_I, [_V, _V]),
     "randt_ctx_synchronize": (_I, [_V]),
     "randt_ctx_set_trace": (_I, [_V, _V, _I]),
+    "randt_ctx_set_solve_mode": (_I, [_V, _I]),
     "randt_matcher_params_default": (None, [_P(MatcherParams)]),
     "randt_maps_create": (_I, [_V, _I, _P(MapParams), _I, _I, _P(_V)]),
     "randt_maps_create_external": (_I, [_V, _I, _P(MapParams), _I, _V, _V, _V, _P(_V)]),
@@ -173,6 +174,7 @@ SYMBOLS = {
     "randt_group_register_pairs": (_I, [_V, _P(_V), _V, _P(_V), _I, _P(MatcherParams), _V, _V]),
 }
 TRANSPORT_AUTO, TRANSPORT_PEER, TRANSPORT_RCCL = 0, 1, 2
+SOLVE_AUTO, SOLVE_THROUGHPUT = 0, 1
 UNIQUE_ID_BYTES = 128
 
 _lib = None

@@ -179,6 +179,14 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
     const int r = atoi(e);
     if (r == 1 || r == 2 || r == 4 || r == 8) ctx->solve_rpb = r;
   }
+  if (const char* e = getenv("RANDT_SOLVE_SPLIT")) {
+    const int w = atoi(e);
+    if (w >= 0 && w <= 8) ctx->solve_split = w;
+  }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
+  }
   if (const char* e = getenv("RANDT_SOLVE_BLOCK")) {
     int b = atoi(e);
     if (b == 64 || b == 128) ctx->solve_block = b;
@@ -245,6 +253,12 @@ int randt_ctx_set_trace(randt_ctx* ctx, double* d_trace, int max_len) {
   if (!ctx) return RANDT_ERR_INVALID;
   ctx->d_trace = d_trace;
   ctx->trace_len = d_trace ? max_len : 0;
+  return RANDT_OK;
+}
+
+int randt_ctx_set_solve_mode(randt_ctx* ctx, int mode) {
+  if (!ctx || (mode != RANDT_SOLVE_AUTO && mode != RANDT_SOLVE_THROUGHPUT)) return RANDT_ERR_INVALID;
+  ctx->solve_mode = mode;
   return RANDT_OK;
 }
 

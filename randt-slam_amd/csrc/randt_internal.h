@@ -41,6 +41,10 @@ struct randt_ctx {
   int solve_rpb = 4;         // independent registrations (one wavefront each) per workgroup in the pair solve: 1, 2, 4, 8
                              // (RANDT_SOLVE_RPB).  4 = one per SIMD of a CU: +9 % end to end over single-wavefront workgroups,
                              // which the dispatcher places unevenly when they arrive from 16 queues
+  int solve_split = -1;      // wavefronts per registration in the pair solve: -1 = chosen from the batch size (solve.hip, split_width),
+                             // 0 = never split, 2..8 = forced (RANDT_SOLVE_SPLIT; experiments)
+  int solve_mode = 0;        // RANDT_SOLVE_AUTO / RANDT_SOLVE_THROUGHPUT (randt_ctx_set_solve_mode)
+  int n_cus = 256;           // compute units of the context's device
   int lds_atomics_lane_ordered = 0;  // device self-test at context creation (api.hip): same-address LDS atomics of one instruction
                                      // are served in ascending lane order -> the build kernels rank points with one atomic each
   int build_tiled = 0;       // RANDT_BUILD_TILED=1: every scan through the multi-workgroup build (normally only > 7168 points)

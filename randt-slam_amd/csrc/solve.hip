@@ -215,6 +215,173 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   return uni(badf == 0.0 && isfinite(acc[0]));
 }
 
+// ---------------------------------------------------------------- split mode (small batches) ---
+// A batch that cannot fill the chip with one wavefront per registration (one 512-registration loop-closure burst is 512
+// wavefronts on 1024 SIMDs; an 8-GPU split of it leaves 64 per GPU) gives every registration W wavefronts on the SIMDs of
+// one CU.  Wavefront 0 runs the whole solver exactly as in the one-wavefront kernel; for every pass it publishes the
+// evaluation point, and wavefront w evaluates residual trip w (correspondences [64 w, 64 w + 64)) and hands the per-lane
+// TERMS (jr, h, jb, c -- solve_math.h) back through LDS.  Wavefront 0 adds them to its accumulators in trip order with
+// the same fused multiply-adds a lone wavefront would have executed, so the ten sums -- and everything after them -- are
+// bit-identical to the one-wavefront kernel; trips beyond W (n_res > 64 W) it evaluates itself.  A pass then costs one
+// trip + the combine instead of ceil(n_res / 64) trips.  The helpers keep their two cell records in registers for the
+// whole solve (the association is frozen) and sleep at the workgroup barrier while wavefront 0 does the solver algebra.
+constexpr int SPLIT_MAXW = 8;          // wavefronts per registration (workgroup of <= 512 threads)
+constexpr int SPLIT_PAIR_CAP = 2048;   // compacted correspondences per registration in split mode (launcher guarantees M k <= this)
+struct SplitReq {
+  double x[4];
+  Loss L;
+  int mode;  // 0: raw-residual maximum, 1: terms of the ten sums, -1: the solve is over
+  int pad;
+};
+
+template <int D, int PARAM>
+__device__ __forceinline__ void pass_pose(const double* x, double& c, double& s, double& tx, double& ty) {
+  if (PARAM == RANDT_PARAM_VECTOR) {
+    c = cos(x[2]);
+    s = sin(x[2]);
+    tx = x[0];
+    ty = x[1];
+  } else {
+    // R = AngleAxis(atan2(sp, cp)): cos/sin of the angle == normalised stored complex
+    const double inv = fast_rsqrt(x[0] * x[0] + x[1] * x[1]);
+    c = x[0] * inv;
+    s = x[1] * inv;
+    tx = x[2];
+    ty = x[3];
+  }
+}
+
+__device__ __forceinline__ void pair_records(const Stage& S, int e, const float4*& mv, const float4*& fv) {
+  const unsigned u = S.pairs[e];
+  if (S.pack16) {
+    mv = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.mov) + ((u >> 12) & 0xffff0u));
+    fv = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.fix) + ((u << 4) & 0xffff0u));
+  } else {
+    mv = S.mov + (size_t)(u >> PAIR_SHIFT) * 3;
+    fv = S.fix + (size_t)(u & PAIR_MASK) * 3;
+  }
+}
+
+// wavefront w >= 1 of a split-mode registration: serve trip w of every pass until the solve is over
+template <int D, int PARAM, bool AM2>
+__device__ __forceinline__ void split_helper(const Stage& S, const SplitReq* req, double* mine /* [64][6] */, int* bad_flag, int w, int lane) {
+  const int e = w * 64 + lane;
+  const bool active = e < S.n_pairs;
+  float4 ma, mb, mc4, fa, fb, fc4;
+  ma = mb = mc4 = fa = fb = fc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    const float4 *mv, *fv;
+    pair_records(S, e, mv, fv);
+    ma = mv[0]; mb = mv[1]; mc4 = mv[2];
+    fa = fv[0]; fb = fv[1]; fc4 = fv[2];
+  }
+  double2* out = reinterpret_cast<double2*>(mine + lane * 6);
+  for (;;) {
+    __syncthreads();  // A: the request is visible
+    const int mode = req->mode;
+    if (mode < 0) return;
+    double c, s, tx, ty;
+    pass_pose<D, PARAM>(req->x, c, s, tx, ty);
+    const Rot rot = make_rot(c, s);
+    double o0 = mode == 0 ? -DBL_MAX : 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0, o4 = 0.0, o5 = 0.0;
+    int bad = 0;
+    if (active) {
+      double jb[3];
+      const double sq = residual_sq_v<D, true>(ma, mb, mc4, fa, fb, fc4, rot, tx, ty, jb);
+      if (!(mode == 1 && AM2) && !isfinite(sq)) bad = 1;
+      if (mode == 0) {
+        o0 = sq;
+      } else {
+        Loss L;
+        if (AM2) {  // the closed form reads three members
+          L.ts = req->L.ts;
+          L.weight = req->L.weight;
+          L.half_w_pre = req->L.half_w_pre;
+        } else {
+          L = req->L;
+        }
+        double jr, h, cterm;
+        residual_terms<AM2>(L, sq, jr, h, cterm);
+        o0 = jr; o1 = h; o2 = jb[0]; o3 = jb[1]; o4 = jb[2]; o5 = cterm;
+      }
+    }
+    out[0] = make_double2(o0, o1);
+    out[1] = make_double2(o2, o3);
+    out[2] = make_double2(o4, o5);
+    const bool anybad = __ballot(bad != 0) != 0ull;
+    if (lane == 0) *bad_flag = anybad ? 1 : 0;
+    __syncthreads();  // B: the terms are visible
+  }
+}
+
+// wavefront 0's pass in split mode (same contract as eval_pass with one wavefront)
+template <int D, int PARAM, int MODE, bool AM2>
+__device__ __forceinline__ bool eval_pass_split(const Stage& S, const double* x, const Loss& L, Base& out, SplitReq* req, const double* part,
+                                                const int* bad_flags, int W, int lane) {
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) req->x[i] = x[i];
+    req->L = L;
+    req->mode = MODE;
+  }
+  __syncthreads();  // A
+  double c, s, tx, ty;
+  pass_pose<D, PARAM>(x, c, s, tx, ty);
+  const Rot rot = make_rot(c, s);
+  double acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+  double mx = -DBL_MAX;
+  int bad = 0;
+  auto one_rec = [&](const float4* mv, const float4* fv) {
+    double jb[3];
+    const double sq = residual_sq<D, MODE == 1>(mv, fv, rot, tx, ty, jb);
+    if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
+    if (MODE == 0) {
+      mx = sq > mx ? sq : mx;
+    } else {
+      accumulate_residual<AM2>(L, sq, jb, acc);
+    }
+  };
+  if (lane < S.n_pairs) {  // trip 0
+    const float4 *mv, *fv;
+    pair_records(S, lane, mv, fv);
+    one_rec(mv, fv);
+  }
+  __syncthreads();  // B
+  const int T = (S.n_pairs + 63) >> 6;
+  const int Tp = T < W ? T : W;
+  for (int w = 1; w < Tp; ++w) {  // trips 1 .. W-1 from the helpers, in trip order
+    const double2* p = reinterpret_cast<const double2*>(part + ((size_t)(w - 1) * 64 + lane) * 6);
+    const double2 a = p[0], b = p[1], d = p[2];
+    if (MODE == 0) {
+      mx = a.x > mx ? a.x : mx;
+    } else {
+      const double jb[3] = {b.x, b.y, d.x};
+      accumulate_terms<AM2>(L, a.x, a.y, jb, d.y, acc);
+    }
+    if (bad_flags[w] != 0) bad = 1;
+  }
+  for (int t = W; t < T; ++t) {  // what the helpers do not cover
+    const int e = t * 64 + lane;
+    if (e < S.n_pairs) {
+      const float4 *mv, *fv;
+      pair_records(S, e, mv, fv);
+      one_rec(mv, fv);
+    }
+  }
+  const double badf = wave_any(bad != 0);
+  if (MODE == 0) {
+    mx = wave_max(mx);
+    out.v[0] = mx > 0.0 ? sqrt(mx) : 0.0;
+    return uni(badf == 0.0);
+  }
+  wave_sum10(acc);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) out.v[i] = acc[i];
+  return uni(badf == 0.0 && isfinite(acc[0]));
+}
+
 // packed lower triangle: (i, j), i >= j  ->  i (i + 1) / 2 + j
 __device__ __forceinline__ constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
@@ -356,34 +523,46 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, int tid, dou
 // VALU-active about half the time; the third fills the gaps).  Four per SIMD (128 registers) spill 70 dwords and lose.
 // The general-alpha kernels carry pow() and stay at two.  RANDT_SOLVE_WPE: experiment knob (tools/ab_build.sh).
 #ifdef RANDT_SOLVE_WPE
-#define RANDT_SOLVE_OCC(AM2) __attribute__((amdgpu_waves_per_eu(RANDT_SOLVE_WPE, RANDT_SOLVE_WPE)))
+#define RANDT_SOLVE_OCC(AM2, SPLIT) __attribute__((amdgpu_waves_per_eu(RANDT_SOLVE_WPE, RANDT_SOLVE_WPE)))
 #else
-#define RANDT_SOLVE_OCC(AM2) __attribute__((amdgpu_waves_per_eu((AM2) ? 3 : 2, (AM2) ? 3 : 2)))
+#ifndef RANDT_SPLIT_WPE
+#define RANDT_SPLIT_WPE 4  // split mode: wavefront 0's pass holds ONE residual trip -> 127 registers (five spilled dwords), four per SIMD
 #endif
-template <int D, int PARAM, int BLOCK, bool AM2, int RPB>
-__global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
+#define RANDT_SOLVE_OCC(AM2, SPLIT) \
+  __attribute__((amdgpu_waves_per_eu((SPLIT) ? RANDT_SPLIT_WPE : ((AM2) ? 3 : 2), (SPLIT) ? RANDT_SPLIT_WPE : ((AM2) ? 3 : 2))))
+#endif
+template <int D, int PARAM, int BLOCK, bool AM2, int RPB, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_OCC(AM2, SPLIT) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
                                                       int moving_first, const int32_t* __restrict__ corr, SolveParams P,
                                                       double* __restrict__ pose4, randt_result* __restrict__ results,
                                                       double* trace, int trace_len, int n_total) {
   static_assert(RPB == 1 || BLOCK == 64, "several registrations per workgroup: one wavefront each");
+  static_assert(!SPLIT || (BLOCK == 64 && RPB == 1), "split mode: wavefront 0 is the one-wavefront solver, the others serve residual trips");
   constexpr int NT = PARAM == RANDT_PARAM_AMBIENT4 ? 4 : 3;
   constexpr int WAVES = BLOCK / 64;
+  constexpr int PCAP = SPLIT ? SPLIT_PAIR_CAP : PAIR_CAP;
   __shared__ double red_all[RPB][2 * WAVES * 12];
   __shared__ int s_count_all[RPB][WAVES];
-  __shared__ unsigned s_pairs_all[RPB][PAIR_CAP];
+  __shared__ unsigned s_pairs_all[RPB][PCAP];
+  // split mode: request block, the helpers' per-lane terms (six doubles per lane per helper), their bad-residual flags
+  __shared__ SplitReq s_req;
+  __shared__ __attribute__((aligned(16))) double s_part[SPLIT ? (SPLIT_MAXW - 1) * 64 * 6 : 2];
+  __shared__ int s_badflag[SPLIT_MAXW];
   // Solver state that is not touched while a residual pass runs lives in LDS (one copy per registration, written by one
   // lane, read back with uniform addresses): best point, Jacobi scaling and its products, LM diagonal, scaled gradient /
   // J^T J.  That takes ~70 registers out of the pass and lets a third wavefront share the SIMD.
   __shared__ double cold_all[RPB * WAVES][56];  // one copy per WAVEFRONT: the two wavefronts of BLOCK = 128 run the solver redundantly and are only synchronised inside a pass
 
   const int sub = RPB > 1 ? (int)(threadIdx.x >> 6) : 0;
-  const int tid = RPB > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int tid = (RPB > 1 || SPLIT) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int split_wave = SPLIT ? (int)(threadIdx.x >> 6) : 0;   // split mode: every wavefront runs the prologue below for itself
+  const int split_W = SPLIT ? (int)(blockDim.x >> 6) : 1;
   const int pair = blockIdx.x * RPB + sub;
   if (pair >= n_total) return;  // RPB > 1: a whole wavefront leaves; there is no workgroup barrier below in that mode
   double* red = red_all[sub];
   int* s_count = s_count_all[sub];
   unsigned* s_pairs = s_pairs_all[sub];
-  double* const cold = cold_all[RPB > 1 ? sub : (int)(threadIdx.x >> 6)];
+  double* const cold = cold_all[(RPB > 1 || SPLIT) ? sub : (int)(threadIdx.x >> 6)];
   const bool w0 = (threadIdx.x & 63) == 0;  // the lane that writes the LDS-resident state
 #define RANDT_COLD_SET(ref, val) do { const double v__ = (val); if (w0) (ref) = v__; } while (0)
 #define RANDT_COLD_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -433,8 +612,8 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
 
   // Compact the valid correspondences once (ascending slot order): every pass then walks a dense list,
   // ceil(n_res / BLOCK) trips per lane instead of ceil(M k / BLOCK), with no per-pass index arithmetic.
-  if (n_res > 0 && n_res <= PAIR_CAP && fixed.cap <= (int)PAIR_MASK + 1 && M <= (1 << (32 - PAIR_SHIFT))) {
-    if (tid < 64) {
+  if (n_res > 0 && n_res <= PCAP && fixed.cap <= (int)PAIR_MASK + 1 && M <= (1 << (32 - PAIR_SHIFT))) {
+    if (tid < 64 && split_wave == 0) {
       int n_out = 0;
       for (int base = 0; base < S.n_slots; base += 64) {
         const int slot = base + tid;
@@ -449,7 +628,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
         n_out += __popcll(mask);
       }
     }
-    if (WAVES > 1) {
+    if (WAVES > 1 || SPLIT) {
       __syncthreads();
     } else {  // the list is written and read by the same wavefront
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -460,7 +639,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
   }
 
   double* tr = trace ? trace + (size_t)pair * trace_len : nullptr;
-  if (tr && tid == 0) tr[0] = 0.0;
+  if (tr && tid == 0 && split_wave == 0) tr[0] = 0.0;
 
   randt_result res;
   res.cost = res.final_cost = res.initial_cost = res.mu0 = 0.0;
@@ -497,14 +676,27 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
   if (n_res == 0) {
     // "WARNING: NO RESIDUALS ADDED!" (ndt_matcher.cpp:454-456): pose unchanged
     res.status = 1;
-    if (tid == 0) results[pair] = res;
+    if (tid == 0 && split_wave == 0) results[pair] = res;
     return;
   }
+  if (SPLIT && S.n_pairs != n_res) {  // cannot happen (launch_one only takes split mode when M k <= SPLIT_PAIR_CAP etc.): fail loudly
+    res.status = 2;
+    res.termination = RANDT_TERM_FAILURE;
+    if (tid == 0 && split_wave == 0) results[pair] = res;
+    return;
+  }
+  if (SPLIT && split_wave != 0) {
+    split_helper<D, PARAM, AM2>(S, &s_req, s_part + (size_t)(split_wave - 1) * 64 * 6, &s_badflag[split_wave], split_wave, tid);
+    return;
+  }
+#define RANDT_EVAL(MODE, XP, OUT)                                                                                     \
+  (SPLIT ? eval_pass_split<D, PARAM, MODE, AM2>(S, XP, L, OUT, &s_req, s_part, s_badflag, split_W, tid) \
+         : eval_pass<D, PARAM, MODE, BLOCK, AM2>(S, XP, L, OUT, red, parity, tid))
 
   // ---- raw residuals at the initial point -> gnc_mu (ndt_matcher.cpp:466-476)
   Loss L = AM2 ? make_loss_am2(P.loss_a, 1.0, P.weight) : make_loss(P.loss_a, P.alpha, 1.0, P.weight);
   Base cur, cnd;
-  bool ok = eval_pass<D, PARAM, 0, BLOCK, AM2>(S, x, L, cur, red, parity, tid);
+  bool ok = RANDT_EVAL(0, x, cur);
   const double raw_max = cur.v[0];
   res.n_evals++;
   double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
@@ -534,7 +726,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
       for (int i = 0; i < 4; ++i) RANDT_COLD_SET(x[i], best[i]);
       RANDT_COLD_SET(x_norm, ambient_norm<PARAM>(best));
       RANDT_COLD_SYNC();
-      const bool e_ok = eval_pass<D, PARAM, 1, BLOCK, AM2>(S, x, L, cur, red, parity, tid);
+      const bool e_ok = RANDT_EVAL(1, x, cur);
       asm volatile("" ::: "memory");
       res.n_evals++;
       res.iterations++;
@@ -639,7 +831,7 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
         }
 
         // ---- candidate cost (+ speculative gradient / J^T J)
-        const bool c_ok = eval_pass<D, PARAM, 1, BLOCK, AM2>(S, cand, L, cnd, red, parity, tid);
+        const bool c_ok = RANDT_EVAL(1, cand, cnd);
         asm volatile("" ::: "memory");  // the LDS-resident state is re-read after the pass, not carried through it in registers
         res.n_evals++;
         const double cand_cost = c_ok ? cnd.v[0] : DBL_MAX;
@@ -695,6 +887,11 @@ __global__ __launch_bounds__(BLOCK* RPB) RANDT_SOLVE_OCC(AM2) void k_solve(MapVi
     } while (uni(gnc_mu > P.mu_stop));
   }
 
+#undef RANDT_EVAL
+  if (SPLIT) {  // the helpers leave at their next barrier
+    if (tid == 0) s_req.mode = -1;
+    __syncthreads();
+  }
   res.termination = term;
   res.final_cost = summary_min;
   res.cost = summary_min / (double)n_res;
@@ -761,12 +958,38 @@ int launch_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx,
   return RANDT_OK;
 }
 
+// Wavefronts per registration for a batch of n_pairs (0 = the one-wavefront kernel).  The split-mode kernels hold four
+// wavefronts per SIMD (16 slots per CU).  Only multiples of four are taken: a workgroup's wavefronts are dealt round-robin
+// over the CU's four SIMDs, so W = 8 packs two workgroups per CU as 4-4-4-4 whatever their start SIMD, whereas W = 6
+// (2-2-1-1) may not fit beside a resident one and then waits for a second round (measured on 512 registrations: W = 6 at
+// three wavefronts per SIMD 200 us, W = 4 133 us).  W = 8 while two registrations per CU cover the batch (512 on MI355X:
+// 117 us against 148 us for one wavefront each; 64 registrations: 97 against 128), W = 4 up to three per CU; beyond that
+// every SIMD has a registration of its own and splitting only adds barriers.  RANDT_SOLVE_SPLIT = 0 / 2..8 overrides
+// (experiments: tools/split_probe.py).
+int split_width(const randt_ctx* ctx, const MapView& fixed, const MapView& moving, int n_pairs, int k) {
+  if ((long long)moving.cap * k > SPLIT_PAIR_CAP || fixed.cap > (int)PAIR_MASK + 1 || moving.cap > (1 << (32 - PAIR_SHIFT))) return 0;
+  if (ctx->solve_split >= 0) return ctx->solve_split < 2 ? 0 : (ctx->solve_split > SPLIT_MAXW ? SPLIT_MAXW : ctx->solve_split);
+  if (ctx->solve_mode == RANDT_SOLVE_THROUGHPUT) return 0;
+  if (n_pairs <= 2 * ctx->n_cus) return 8;
+  if (n_pairs <= 3 * ctx->n_cus) return 4;
+  return 0;
+}
+
 template <int D, int PARAM>
 int launch_one(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
                int n_pairs, const int32_t* d_corr, const SolveParams& P, double* d_pose4, randt_result* d_results, int block) {
 #define RANDT_CFG(BB, AA) \
   return launch_cfg<D, PARAM, BB, AA>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results)
   const bool am2 = P.alpha == -2.0;
+  if (block == 64 && am2) {
+    const int W = split_width(ctx, fixed, moving, n_pairs, P.k);
+    if (W >= 2) {
+      hipLaunchKernelGGL((k_solve<D, PARAM, 64, true, 1, true>), dim3(n_pairs), dim3(64 * W), 0, ctx->stream, fixed, d_fixed_idx, moving,
+                         moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len, n_pairs);
+      RANDT_HIP_CHECK(ctx, hipGetLastError());
+      return RANDT_OK;
+    }
+  }
   if (block == 64 && am2 && ctx->solve_rpb > 1) {
     if (ctx->solve_rpb == 2)
       return launch_cfg<D, PARAM, 64, true, 2>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_corr, P, d_pose4, d_results);

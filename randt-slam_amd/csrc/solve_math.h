@@ -112,10 +112,8 @@ __device__ __forceinline__ Rot make_rot(double c, double s) {
 }
 
 template <int D, bool WANT_JAC>
-__device__ __forceinline__ double residual_sq(const float4* mrec, const float4* frec, const Rot& R, double tx, double ty, double* jb) {
-  // 48-byte records as three 16-byte loads each (global: dwordx4, LDS: ds_read_b128, conflict-free at stride 48)
-  const float4 ma = mrec[0], mb = mrec[1], mc4 = mrec[2];
-  const float4 fa = frec[0], fb = frec[1], fc4 = frec[2];
+__device__ __forceinline__ double residual_sq_v(const float4 ma, const float4 mb, const float4 mc4, const float4 fa, const float4 fb,
+                                                const float4 fc4, const Rot& R, double tx, double ty, double* jb) {
   const float mv[9] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w, mc4.x};
   const float fv[9] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc4.x};
   const double c = R.c, s = R.s;
@@ -167,16 +165,26 @@ __device__ __forceinline__ double residual_sq(const float4* mrec, const float4* 
   }
   return ssq;
 }
+template <int D, bool WANT_JAC>
+__device__ __forceinline__ double residual_sq(const float4* mrec, const float4* frec, const Rot& R, double tx, double ty, double* jb) {
+  // 48-byte records as three 16-byte loads each (global: dwordx4, LDS: ds_read_b128, conflict-free at stride 48)
+  const float4 ma = mrec[0], mb = mrec[1], mc4 = mrec[2];
+  const float4 fa = frec[0], fb = frec[1], fc4 = frec[2];
+  return residual_sq_v<D, WANT_JAC>(ma, mb, mc4, fa, fb, fc4, R, tx, ty, jb);
+}
 
 // Loss + Ceres corrector (residual_block.cc / corrector.cc) of one scalar residual r = sqrt(sq) with base
 // Jacobian row jb / r, added to the ten base sums acc = {cost, J^T r (3), upper J^T J (6)}.
+// With r = sqrt(sq) and the true Jacobian row J = jb / r: the corrected residual is rs * r and the corrected row
+// js * J, so  J^T r += (js rs) jb  and  J^T J += (js^2 / sq) jb jb^T  -- no square root.
+// sq == 0: autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545); zero row instead (branch-free: jb is
+// exactly zero when sq is, so clamping the divisor suffices; 1e-280 keeps weight / clamp finite for any sane weight).
+// Two halves, so that a residual can be evaluated by one wavefront and accumulated by another (k_solve's split mode)
+// with the SAME roundings as when one lane does both: residual_terms yields (jr, h, c), accumulate_terms adds them with
+// explicit fused multiply-adds (nothing is left to the compiler's contraction choices).
+//   jr = js rs, h = js^2 / sq, c = the cost term's variable part (alpha = -2: 1/u - 1, added as half_w_pre * c; else rho / 2)
 template <bool AM2>
-__device__ __forceinline__ void accumulate_residual(const Loss& L, double sq, const double* jb, double* acc) {
-  // With r = sqrt(sq) and the true Jacobian row J = jb / r: the corrected residual is rs * r and the corrected row
-  // js * J, so  J^T r += (js rs) jb  and  J^T J += (js^2 / sq) jb jb^T  -- no square root.
-  // sq == 0: autodiff of sqrt(0) is singular in the reference (ceres_residuals.h:545); zero row instead (branch-free: jb is
-  // exactly zero when sq is, so clamping the divisor suffices; 1e-280 keeps weight / clamp finite for any sane weight).
-  double jr, h;
+__device__ __forceinline__ void residual_terms(const Loss& L, double sq, double& jr, double& h, double& c) {
   if (AM2) {
     // alpha = -2: rho' = w / u^2 > 0, rho'' < 0 always => corrector is sqrt(rho') = sqrt(w) / u, rs = js.
     // ONE reciprocal serves 1 / u and 1 / sq: rP = 1 / (u^2 sq)  ->  h = w rP,  js rs = w / u^2 = h sq,  1 / u = rP u sq.
@@ -186,12 +194,12 @@ __device__ __forceinline__ void accumulate_residual(const Loss& L, double sq, co
     h = L.weight * rP;
     jr = h * sqc;
     const double iu = (rP * u) * sqc;
-    acc[0] += L.half_w_pre * (iu - 1.);
+    c = iu - 1.;
   } else {
     double rs, js;  // residual and Jacobian scale of the corrector (equal for a scalar residual when rho'' <= 0)
     double r0, r1, r2;
     loss_eval(L, sq, r0, r1, r2);
-    acc[0] += 0.5 * r0;
+    c = 0.5 * r0;
     const double sqrt_rho1 = sqrt(r1);
     if (sq == 0.0 || r2 <= 0.0) {
       rs = js = sqrt_rho1;
@@ -204,16 +212,26 @@ __device__ __forceinline__ void accumulate_residual(const Loss& L, double sq, co
     jr = js * rs;
     h = js * js * fast_rcp(fmax(sq, 1e-280));
   }
+}
+template <bool AM2>
+__device__ __forceinline__ void accumulate_terms(const Loss& L, double jr, double h, const double* jb, double c, double* acc) {
+  acc[0] = AM2 ? fma(L.half_w_pre, c, acc[0]) : acc[0] + c;
   const double h0 = h * jb[0], h1 = h * jb[1], h2 = h * jb[2];
-  acc[1] += jr * jb[0];
-  acc[2] += jr * jb[1];
-  acc[3] += jr * jb[2];
-  acc[4] += h0 * jb[0];
-  acc[5] += h0 * jb[1];
-  acc[6] += h0 * jb[2];
-  acc[7] += h1 * jb[1];
-  acc[8] += h1 * jb[2];
-  acc[9] += h2 * jb[2];
+  acc[1] = fma(jr, jb[0], acc[1]);
+  acc[2] = fma(jr, jb[1], acc[2]);
+  acc[3] = fma(jr, jb[2], acc[3]);
+  acc[4] = fma(h0, jb[0], acc[4]);
+  acc[5] = fma(h0, jb[1], acc[5]);
+  acc[6] = fma(h0, jb[2], acc[6]);
+  acc[7] = fma(h1, jb[1], acc[7]);
+  acc[8] = fma(h1, jb[2], acc[8]);
+  acc[9] = fma(h2, jb[2], acc[9]);
+}
+template <bool AM2>
+__device__ __forceinline__ void accumulate_residual(const Loss& L, double sq, const double* jb, double* acc) {
+  double jr, h, c;
+  residual_terms<AM2>(L, sq, jr, h, c);
+  accumulate_terms<AM2>(L, jr, h, jb, c, acc);
 }
 
 // ---------------------------------------------------------------- reductions -------------------

@@ -85,6 +85,11 @@ class Context:
     def synchronize(self):
         self._check(self._lib.randt_ctx_synchronize(self._h), "randt_ctx_synchronize")
 
+    def set_solve_mode(self, mode):
+        """randt_ctx_set_solve_mode: _capi.SOLVE_AUTO (default: small batches get several wavefronts per registration) or
+        _capi.SOLVE_THROUGHPUT (always one wavefront each: several batches in flight on several contexts)."""
+        self._check(self._lib.randt_ctx_set_solve_mode(self._h, int(mode)), "randt_ctx_set_solve_mode")
+
     def set_trace(self, d_trace, max_len):
         self._check(self._lib.randt_ctx_set_trace(self._h, _dptr(d_trace), int(max_len)), "randt_ctx_set_trace")
 

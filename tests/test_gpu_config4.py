@@ -7,6 +7,7 @@
     same instantiation against the oracle's on a sample, and bit-identity with the one-registration-per-workgroup kernel.
 (c) the strong split of that batch over G = 2 / 4 / 8 "virtual ranks" on one GPU (contiguous `shard_range` pieces, one
     context + stream per piece) is bit-identical to the unsharded batch.
+(d) the solve geometries -- split mode at every width, four-per-workgroup, one-per-workgroup -- are bit-identical.
 """
 import os
 
@@ -84,26 +85,77 @@ def test_config4_full_batch_matches_oracle_on_every_registration(cfg4):
         assert np.array_equal(t[:, 2].astype(int), st["trace_flag"])
 
 
-def test_config4_rpb4_bit_identical_to_rpb1_including_traces(cfg4):
-    """The workgroup geometry is a placement decision, not an arithmetic one: results AND per-iteration traces of the
-    four-per-workgroup kernel equal those of the one-per-workgroup kernel bit for bit."""
+def _ctx_with(torch, env=None, mode=None):
+    """A context created under the given environment knobs (they are read at creation) / solve mode."""
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    if mode is not None:
+        ctx.set_solve_mode(mode)
+    return ctx
+
+
+def test_config4_solve_geometries_bit_identical_including_traces(cfg4):
+    """The solve geometry is a placement decision, not an arithmetic one.  The library's own choice for a lone
+    512-registration batch (RANDT_SOLVE_AUTO: split mode, eight wavefronts per registration), the throughput kernel bench.py's
+    16-stream region runs (one wavefront per registration, four registrations per workgroup) and the one-registration-per-
+    workgroup kernel give the same poses, result records AND per-iteration traces bit for bit."""
     prob, rig, _ = cfg4
     torch = rig.torch
     mp = R.default_matcher_params()
     g4 = synth.pose3_to_pose4(prob["guess"])
     TL = 3 * 400 + 1
-    p4w, r4w, t4w = _run(rig, rig.ctx, mp, rig.points, rig.fixed_idx, g4, TL)
-    old = os.environ.get("RANDT_SOLVE_RPB")
-    os.environ["RANDT_SOLVE_RPB"] = "1"
-    try:
-        ctx1 = R.Context(0, torch.cuda.current_stream().cuda_stream)
-    finally:
-        if old is None:
-            del os.environ["RANDT_SOLVE_RPB"]
-        else:
-            os.environ["RANDT_SOLVE_RPB"] = old
+    p_auto, r_auto, t_auto = _run(rig, rig.ctx, mp, rig.points, rig.fixed_idx, g4, TL)                   # AUTO -> split, W = 8
+    ctx_tp = _ctx_with(torch, mode=R._capi.SOLVE_THROUGHPUT)                                            # k_solve<..., RPB = 4>
+    p4w, r4w, t4w = _run(rig, ctx_tp, mp, rig.points, rig.fixed_idx, g4, TL)
+    ctx1 = _ctx_with(torch, env={"RANDT_SOLVE_RPB": "1"}, mode=R._capi.SOLVE_THROUGHPUT)                 # k_solve<..., RPB = 1>
     p1, r1, t1 = _run(rig, ctx1, mp, rig.points, rig.fixed_idx, g4, TL)
     assert np.array_equal(p4w, p1) and np.array_equal(r4w, r1) and np.array_equal(t4w, t1)
+    assert np.array_equal(p_auto, p1) and np.array_equal(r_auto, r1) and np.array_equal(t_auto, t1)
+
+
+@pytest.mark.parametrize("param", [R.PARAM_AMBIENT4, R.PARAM_MANIFOLD, R.PARAM_VECTOR])
+@pytest.mark.parametrize("intensity", [1, 0])
+def test_split_mode_bit_identical_for_every_instantiation(cfg4, param, intensity):
+    """Split mode (several wavefronts per registration) against the one-wavefront kernel for every parameterisation and
+    both residual dimensions, at the widths the library picks (8, 4) and at widths that leave trips to wavefront 0
+    (2, 3: n_res > 64 W for most registrations here) or do not divide the trips evenly (5, 7); batch sizes with a ragged end."""
+    prob, rig, _ = cfg4
+    torch = rig.torch
+    mp = R.default_matcher_params(parameterization=param, use_intensity=intensity)
+    g4 = synth.pose3_to_pose4(prob["guess"])
+    n = 70
+    pts, fidx = rig.points[:n].contiguous(), rig.fixed_idx[:n].contiguous()
+    ref = _run(rig, _ctx_with(torch, mode=R._capi.SOLVE_THROUGHPUT), mp, pts, fidx, g4[:n], 3 * 400 + 1)
+    assert (ref[1]["status"] == 0).all() and ref[1]["n_residuals"].max() > 64 * 5
+    for w in ("2", "3", "4", "5", "7", "8"):
+        got = _run(rig, _ctx_with(torch, env={"RANDT_SOLVE_SPLIT": w}), mp, pts, fidx, g4[:n], 3 * 400 + 1)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), w
+    auto = _run(rig, rig.ctx, mp, pts, fidx, g4[:n], 3 * 400 + 1)          # the library's choice
+    for a, b in zip(auto, ref):
+        assert np.array_equal(a, b)
+
+
+def test_split_mode_general_loss_shapes_fall_back_to_one_wavefront(cfg4):
+    """Only the closed-form (alpha = -2) kernels have a split instantiation; other Barron shapes run one wavefront per
+    registration whatever the batch size -- same results as in throughput mode."""
+    prob, rig, _ = cfg4
+    torch = rig.torch
+    mp = R.default_matcher_params(loss_alpha=-1.0)
+    g4 = synth.pose3_to_pose4(prob["guess"])
+    n = 24
+    pts, fidx = rig.points[:n].contiguous(), rig.fixed_idx[:n].contiguous()
+    a = _run(rig, rig.ctx, mp, pts, fidx, g4[:n])
+    b = _run(rig, _ctx_with(torch, mode=R._capi.SOLVE_THROUGHPUT), mp, pts, fidx, g4[:n])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
 @pytest.mark.parametrize("G", [2, 4, 8])

@@ -314,6 +314,7 @@ def test_solve_workgroup_grouping_does_not_change_results(env, monkeypatch):
     for rpb in ("1", "2", "4", "8"):
         monkeypatch.setenv("RANDT_SOLVE_RPB", rpb)
         rig = GpuRig(prob)                                   # the knob is read when the context is created
+        rig.ctx.set_solve_mode(R._capi.SOLVE_THROUGHPUT)     # one wavefront per registration (AUTO would split so small a batch)
         rig.build_submaps()
         rig.build_scans()
         for n_pairs in (1, 7, rig.B):
