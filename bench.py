@@ -44,8 +44,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # vector fp64 (half the 157.3 TF fp32 vector rate)
 N_SIMDS, CLOCK_GHZ = 1024, 2.4          # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip table)
 VALU_PEAK = N_SIMDS * CLOCK_GHZ         # G SIMD-cycles/s of VALU issue
-SAT_COPIES = 8                          # chip-filling launch of the roofline section: 8 copies of the batch = 4096 registrations
-HOT_KERNELS = ("k_ndt_build<true>", "k_associate<false>", "k_solve<3,1,64,true,4>")
+SAT_COPIES = 12                         # chip-filling launch of the roofline section: 12 copies of the batch = 6144 registrations =
+                                        # exactly two rounds of the 3072 resident wavefronts (3 per SIMD) of the one-wavefront solve kernel
+HOT_KERNELS = ("k_ndt_build<true>", "k_associate<false>", "k_solve<3,1,64,true,4,false>")
 
 
 def effective_cpus():
@@ -77,16 +78,26 @@ def algorithmic_bytes(n_points, n_slots, m_cells, k):
 
 def load_counters():
     """Latest committed profiles/r*_sq_summary.csv (tools/pmc_summary.py): per-launch SQ / TCC counters of the three hot
-    kernels at the 512-registration launch.  Returns ({kernel: row dict}, file name) or ({}, None)."""
+    kernels at the 512-registration launch.  Returns ({kernel: row dict}, file name, stale reason or None): counters stamped
+    with another fingerprint of the hot kernels' sources (tools/csrc_hash.py) than the code being benchmarked are REFUSED."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash
+
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_summary.csv")))
     if not files:
-        return {}, None
+        return {}, None, "no committed counter summary"
     rows = {}
-    want_wgs = {"k_ndt_build<true>": 512, "k_associate<false>": 512, "k_solve<3,1,64,true,4>": 128}   # workgroups of a 512-registration launch
+    want_wgs = {"k_ndt_build<true>": 512, "k_associate<false>": 512, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch
+    stamp = None
     for r in csv.DictReader(open(files[-1])):
+        stamp = r.get("csrc_hash", stamp)
         if r["kernel"] in HOT_KERNELS and r["kernel"] not in rows and int(r["grid_size"]) == want_wgs[r["kernel"]] * int(r["workgroup_size"]):
-            rows[r["kernel"]] = {k: (float(v) if v not in ("", None) and k != "kernel" else v) for k, v in r.items()}
-    return rows, os.path.relpath(files[-1], ROOT)
+            rows[r["kernel"]] = {k: (float(v) if v not in ("", None) and k not in ("kernel", "csrc_hash") else v) for k, v in r.items()}
+    rel = os.path.relpath(files[-1], ROOT)
+    now = csrc_hash()
+    if stamp != now:
+        return {}, rel, "counters in %s were taken from other kernel code (stamp %s, current sources %s): re-run tools/collect_profiles.sh" % (rel, stamp, now)
+    return rows, rel, None
 
 
 class GroupBatch:
@@ -206,6 +217,9 @@ def main():
                     help="diagnostic: time ONE stage alone at saturation (the printed value is then not the headline metric)")
     ap.add_argument("--streams", type=int, default=16, help="in-flight batches: step i runs on HIP stream i %% streams "
                     "(GPU_MAX_HW_QUEUES is raised to match unless already set: HIP maps streams onto 4 hardware queues by default)")
+    ap.add_argument("--solve-mode", choices=["default", "auto", "throughput"], default="default",
+                    help="pair-solve geometry of the timed region's contexts: throughput = one wavefront per registration, auto = the "
+                         "library's choice per launch (splits a lone small batch); default = throughput when several streams keep batches in flight")
     ap.add_argument("--odometry-scans", type=int, default=1000, help="BASELINE config 3 side measurement (0 = skip)")
     ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
     ap.add_argument("--slam-scans", type=int, default=300,
@@ -254,7 +268,8 @@ def main():
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     ctxs = [R.Context(local_rank, st.cuda_stream) for st in streams]
     ctx = ctxs[0]
-    if n_streams > 1:
+    throughput_mode = args.solve_mode == "throughput" or (args.solve_mode == "default" and n_streams > 1)
+    if throughput_mode:
         # several batches in flight: the chip is full, one wavefront per registration (the library's AUTO default would give a
         # lone 512-registration batch eight wavefronts per registration -- right for the single_batch section below, which
         # switches it back, and wrong here: 4.6 M instead of 9.0 M registrations/s)
@@ -397,7 +412,7 @@ def main():
         m_mean = float(full.scan_maps[0].counts().mean())
         n_res_mean = float(res["n_residuals"].mean())
         b_alg = algorithmic_bytes(N_POINTS, N_SLOTS, m_mean, k)
-        counters, counters_file = load_counters()
+        counters, counters_file, counters_stale = load_counters()
         out = {
             "metric": "ndt_registrations_per_sec" if args.only is None and args.batch_scale == 1 else "DIAGNOSTIC_only=%s_batch_scale=%d" % (args.only, args.batch_scale),
             "value": value, "unit": "registrations/s",
@@ -434,7 +449,7 @@ def main():
         if not args.no_roofline_sections and args.only is None and args.batch_scale == 1:
             # (at N > 1 too: rank 0 alone, the other ranks wait at the closing barrier; per-GPU figures)
             side(None, roofline_sections, R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file,
-                 b_alg, value / world, elapsed / n_steps)
+                 b_alg, value / world, elapsed / n_steps, counters_stale, throughput_mode)
         if not args.no_cpu_baseline and world == 1:
             side(None, cpu_baseline, weak_prob, mp, pose0.cpu().numpy(), args.cpu_seconds)
         if args.odometry_scans > 0 and world == 1:
@@ -451,7 +466,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file, b_alg, value, s_per_step):
+def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file, b_alg, value, s_per_step, counters_stale=None, throughput_mode=True):
     """Clean (non-overlapped) measurements behind the `roofline` object, all with HIP events on the launch stream:
       single_batch      ONE 512-registration batch at a time on one stream: latency, rate, per-kernel durations;
       chip-filling      the dominant kernel (k_solve) with SAT_COPIES copies of the batch = 4096 registrations in ONE
@@ -514,14 +529,16 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
     sat_us = float(np.mean([e0[i].elapsed_time(e1[i]) for i in range(n_l)]) * 1e3)
     sat_build_us, sat_assoc_us = e_b[0].elapsed_time(e_b[1]) * 1e3, e_b[1].elapsed_time(e_b[2]) * 1e3
 
-    ks = counters.get("k_solve<3,1,64,true,4>")
+    ks = counters.get("k_solve<3,1,64,true,4,false>")
     roof = {"bound": "valu_issue", "unit": "G SIMD-cycles/s", "peak": VALU_PEAK,
-            "peak_note": "%d SIMDs x %.1f GHz max clock; one wave64 VALU instruction occupies its SIMD's issue port for the cycles "
-                         "listed in cycle_costs (tools/valu_rate_probe.hip; under sustained VALU load the chip clocks 1.6-1.85 GHz, "
-                         "so 100 %% of this peak is not reachable)" % (N_SIMDS, CLOCK_GHZ),
-            "kernel": "k_solve<3,1,64,true,4> (dominant: 62 % of the path's VALU issue cycles)",
+            "peak_note": "%d SIMDs x %.1f GHz max clock; one wave64 VALU instruction occupies its SIMD's issue port for the spec "
+                         "cycles listed in cycle_costs (fp32-class 2, fp64 4 = the 78.6 TFLOP/s vector-fp64 rate, transcendental 8 / 16; "
+                         "tools/clock_probe.hip measures 0.88-0.97 of these rates at a 2.1-2.4 GHz shader clock)" % (N_SIMDS, CLOCK_GHZ),
+            "kernel": "k_solve<3,1,64,true,4,false> (dominant: 62 % of the path's VALU issue cycles)",
             "launch": "%d registrations (%d copies of the 512 batch) in ONE launch, one stream, nothing else running" % (big.B, SAT_COPIES),
             "avg_launch_us": sat_us, "achieved": None, "frac": None, "traffic": None, "counters": counters_file}
+    if counters_stale:
+        roof["counters_refused"] = counters_stale
     out = {"roofline": roof, "single_batch": single}
     if ks is not None:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -564,7 +581,7 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
         "note": "SURVEY 8(d) byte model (counts the dense 480 KB submap table once per registration) x registrations/s; kept for "
                 "continuity with round 1 -- the compact cell tables make the real traffic ~10x smaller, see roofline.traffic"}
     big.scan_maps[0].close()
-    if len(ctxs) > 1:
+    if throughput_mode:
         ctxs[0].set_solve_mode(R._capi.SOLVE_THROUGHPUT)
     return out
 

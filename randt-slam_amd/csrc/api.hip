@@ -70,44 +70,54 @@ __global__ void k_clear(MapView v, int first, int count) {
   }
 }
 
-// Self-test behind randt_ctx::lds_atomics_lane_ordered: 64 lanes add to LDS words in several collision patterns (all on one
-// word, groups of 2..32 neighbours, strided groups, a second instruction on top of the first) and every lane checks that the
-// value it got back equals the number of LOWER lanes of its group (plus the group's earlier total).  out[0] = 1 if all hold.
-__global__ void k_lds_atomic_order_probe(int32_t* out) {
+// Self-test behind randt_ctx::lds_atomics_lane_ordered, under the build kernel's own conditions: FOUR wavefronts of one
+// workgroup add to the SAME 64-bit LDS words at once, each in its own 16-bit field (k_ndt_build's (bin, wave) counters),
+// in several collision patterns (all lanes on one word, groups of 2..32 neighbours, strided groups, irregular group sizes),
+// three dependent rounds per pattern, 32 repetitions with the wavefronts deliberately out of step; every lane checks that the
+// value it got back equals the number of LOWER lanes of its group (plus its wavefront's earlier total).  out[0] = 1 if all
+// hold.  (The kernel that relies on the order also re-checks it on a sample in every launch: ndt_build.hip.)
+__global__ __launch_bounds__(256) void k_lds_atomic_order_probe(int32_t* out) {
   __shared__ unsigned long long w[64];
-  const int lane = threadIdx.x;
+  __shared__ int fails;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sh = 16 * wave;
+  if (threadIdx.x == 0) fails = 0;
   int ok = 1;
-  for (int pattern = 0; pattern < 8; ++pattern) {
-    w[lane] = 0ull;
-    __syncthreads();
-    int grp, rank, size;
-    if (pattern < 6) {  // contiguous groups of 64, 32, 16, 8, 4, 2 lanes
-      size = 64 >> pattern;
-      grp = lane / size;
-      rank = lane % size;
-    } else if (pattern == 6) {  // interleaved: lanes with equal (lane % 8) collide
-      size = 8;
-      grp = lane % 8;
-      rank = lane / 8;
-    } else {  // irregular group sizes 1, 2, 3, ...
-      int start = 0, g = 0;
-      while (start + g + 1 <= lane) {
-        start += g + 1;
-        ++g;
+  for (int rep = 0; rep < 32; ++rep) {
+    for (int pattern = 0; pattern < 8; ++pattern) {
+      if (threadIdx.x < 64) w[threadIdx.x] = 0ull;
+      __syncthreads();
+      int grp, rank, size;
+      if (pattern < 6) {  // contiguous groups of 64, 32, 16, 8, 4, 2 lanes
+        size = 64 >> pattern;
+        grp = lane / size;
+        rank = lane % size;
+      } else if (pattern == 6) {  // interleaved: lanes with equal (lane % 8) collide
+        size = 8;
+        grp = lane % 8;
+        rank = lane / 8;
+      } else {  // irregular group sizes 1, 2, 3, ...
+        int start = 0, g = 0;
+        while (start + g + 1 <= lane) {
+          start += g + 1;
+          ++g;
+        }
+        grp = g;
+        rank = lane - start;
+        size = g + 1;
+        if (start + size > 64) size = 64 - start;
       }
-      grp = g;
-      rank = lane - start;
-      size = g + 1;
-      if (start + size > 64) size = 64 - start;
+      for (int skew = 0; skew < ((wave * 7 + rep) & 15); ++skew) __builtin_amdgcn_s_sleep(1);  // the wavefronts arrive out of step
+      for (int round = 0; round < 3; ++round) {  // a wavefront's LDS operations complete in program order
+        const unsigned long long old = atomicAdd(&w[grp], 1ull << sh);
+        if ((int)((old >> sh) & 0xffff) != round * size + rank) ok = 0;
+      }
+      __syncthreads();
     }
-    for (int rep = 0; rep < 3; ++rep) {  // a wavefront's LDS operations complete in program order
-      const unsigned long long old = atomicAdd(&w[grp], 1ull << 16);
-      if ((int)(old >> 16) != rep * size + rank) ok = 0;
-    }
-    __syncthreads();
   }
-  const unsigned long long all = __ballot(ok != 0);
-  if (lane == 0) out[0] = all == ~0ull ? 1 : 0;
+  if (__ballot(ok != 0) != ~0ull && lane == 0) atomicAdd(&fails, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fails == 0 ? 1 : 0;
 }
 
 }  // namespace
@@ -201,7 +211,7 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
     if (hipMalloc(&d_flag, sizeof(int32_t)) == hipSuccess) {
       bool good = true;
       for (int rep = 0; rep < 4 && good; ++rep) {
-        hipLaunchKernelGGL(k_lds_atomic_order_probe, dim3(1), dim3(64), 0, ctx->stream, d_flag);
+        hipLaunchKernelGGL(k_lds_atomic_order_probe, dim3(1), dim3(256), 0, ctx->stream, d_flag);
         good = hipMemcpyAsync(&h_flag, d_flag, sizeof(h_flag), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                hipStreamSynchronize(ctx->stream) == hipSuccess && h_flag == 1;
       }
@@ -210,6 +220,17 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
     }
     (void)hipGetLastError();
     if (const char* e = getenv("RANDT_BUILD_ATOMIC_RANK")) ctx->lds_atomics_lane_ordered = (atoi(e) && ctx->lds_atomics_lane_ordered) ? 1 : 0;
+    if (const char* e = getenv("RANDT_DEBUG_FORCE_MISRANK")) ctx->debug_force_misrank = atoi(e) ? 1 : 0;
+    // the word the build kernel counts its in-kernel ranking fallbacks in: pinned host memory, read without a synchronisation
+    // in front of every build launch; without it the atomic ranking is not used at all
+    void* pin = nullptr;
+    if (hipHostMalloc(&pin, 64, hipHostMallocDefault) == hipSuccess && pin) {
+      memset(pin, 0, 64);
+      ctx->misrank_word = static_cast<int32_t*>(pin);
+    } else {
+      (void)hipGetLastError();
+      ctx->lds_atomics_lane_ordered = 0;
+    }
   }
   *out = ctx;
   return RANDT_OK;
@@ -217,6 +238,14 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
 
 // debug / test hook (not part of the ABI): did the LDS atomic ordering self-test pass on this context's device?
 int randt_debug_lds_atomics_lane_ordered(const randt_ctx* ctx) { return ctx ? ctx->lds_atomics_lane_ordered : 0; }
+// debug / test hook: workgroups of this context's NDT builds that found the atomic ranking out of order and re-ranked with
+// ballots (synchronises the stream)
+int randt_debug_build_rank_fallbacks(randt_ctx* ctx) {
+  if (!ctx) return 0;
+  DeviceGuard dev_guard__(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  return ctx->build_rank_fallbacks + (ctx->misrank_word ? *reinterpret_cast<volatile int32_t*>(ctx->misrank_word) * (ctx->lds_atomics_lane_ordered ? 1 : 0) : 0);
+}
 
 int randt_ctx_destroy(randt_ctx* ctx) {
   if (!ctx) return RANDT_OK;
@@ -224,6 +253,7 @@ int randt_ctx_destroy(randt_ctx* ctx) {
   if (ctx->build_ws) (void)hipFree(ctx->build_ws);
   if (ctx->small) (void)hipFree(ctx->small);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->misrank_word) (void)hipHostFree(ctx->misrank_word);
   delete ctx;
   return RANDT_OK;
 }

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
                                                            const int32_t* __restrict__ n_pts_arr, int stride,
                                                            int ioff, int row_size, float resolution, MapView out,
                                                            int first_map, int npad, int nb_cap, int aux_bytes,
-                                                           int32_t* __restrict__ fallback_ws, int lane_ordered_atomics) {
+                                                           int32_t* __restrict__ fallback_ws, int lane_ordered_atomics,
+                                                           int32_t* misrank_word) {
   constexpr int PPT = 8;
   constexpr bool KEEP = REG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     scratch[8 + wave] = lmin;
     scratch[12 + wave] = lmax;
   }
+  if (tid == 0) scratch[20] = 0;  // "the atomic ranking failed its order check" (set in the count phase below)
   __syncthreads();
   lmin = scratch[8];
   lmax = scratch[12];
@@ -265,26 +267,14 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     const int nbits = nb > 1 ? 32 - __clz(nb - 1) : 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int sh = 16 * wave;
-    if (lane_ordered_atomics) {
-      // The LDS serves the lanes of one atomic instruction that hit the same address in ascending lane order (checked on
-      // this device when the context was created, randt_ctx_create): the value a lane gets back IS its rank among the
-      // lanes of the step with its label plus what earlier steps of this wavefront added -- one returning atomic per point
-      // instead of a ballot per label bit; a wavefront's LDS operations execute in program order, so the steps stay ordered.
-#pragma unroll 8
-      for (int j = 0; j < nsteps; ++j) {
-        const int i = w_beg + 64 * j + lane;
-        if (i < w_end) {
-          const int b = RANDT_PL(j, i) - lmin;
-          const unsigned long long old = atomicAdd(&bins[b], 1ull << sh);
-          RANDT_PL(j, i) = b | ((int)((old >> sh) & 0xffff) << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
-        }
-      }
-    } else {
+    // rank by one ballot per label bit: assumes nothing about the hardware.  from_packed: the per-point word already holds
+    // bin | rank << 16 (redo behind a failed atomic ranking), otherwise the raw label
+    auto rank_by_ballots = [&](const bool from_packed) {
 #pragma unroll 8
       for (int j = 0; j < nsteps; ++j) {
         const int i = w_beg + 64 * j + lane;
         const bool valid = i < w_end;
-        const int b = (valid ? RANDT_PL(j, i) : 0) - lmin;
+        const int b = valid ? (from_packed ? (RANDT_PL(j, i) & 0xffff) : RANDT_PL(j, i) - lmin) : 0;
         unsigned long long mask = __ballot(valid);  // lanes of this step with my label
         if (mask == 0ull) break;                    // wave-uniform: this quarter is exhausted
         for (int bit = 0; bit < nbits; ++bit) {
@@ -301,6 +291,50 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
         field = __shfl(field, valid ? leader : lane, 64);
         if (valid) RANDT_PL(j, i) = b | ((field + __popcll(mask & lt)) << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
       }
+    };
+    if (lane_ordered_atomics) {
+      // The LDS serves the lanes of one atomic instruction that hit the same address in ascending lane order: the value a
+      // lane gets back IS its rank among the lanes of the step with its label plus what earlier steps of this wavefront
+      // added -- one returning atomic per point instead of a ballot per label bit; a wavefront's LDS operations execute in
+      // program order, so the steps stay ordered.  That serving order is observed, not documented, so it is CHECKED: at
+      // context creation under the real kernel's conditions (api.hip, k_lds_atomic_order_probe: four wavefronts on shared
+      // 64-bit bins) and here in every step of every launch on a sample -- the lanes that share the first active lane's bin
+      // must hold consecutive ranks in lane order (two ballots and a popcount).  A violation makes the WHOLE workgroup rank
+      // again with the ballots below (the sums stay bit-exact) and is reported to the host, which stops using the atomic
+      // ranking on this context (launch_ndt_build).  lane_ordered_atomics == 2: test hook, one rank of the sample is
+      // misread on purpose so that the fallback path runs.
+      int viol = 0;
+#pragma unroll 8
+      for (int j = 0; j < nsteps; ++j) {
+        const int i = w_beg + 64 * j + lane;
+        const bool valid = i < w_end;
+        int b = -1, rk = 0;
+        if (valid) {
+          b = RANDT_PL(j, i) - lmin;
+          const unsigned long long old = atomicAdd(&bins[b], 1ull << sh);
+          rk = (int)((old >> sh) & 0xffff);
+          RANDT_PL(j, i) = b | (rk << 16);  // bin (<= 16 bits, nb_cap < 65536) | rank
+        }
+        const unsigned long long act = __ballot(valid);
+        if (act == 0ull) break;  // wave-uniform: this quarter is exhausted
+        const int first = __ffsll((long long)act) - 1;
+        const int b0 = __shfl(b, first, 64), rk0 = __shfl(rk, first, 64);
+        const unsigned long long same = __ballot(valid && b == b0);
+        int seen = rk;
+        if (lane_ordered_atomics == 2 && __popcll(same & lt) == 1) seen ^= 1;  // test hook: the sample's second lane misreads
+        if (valid && b == b0 && seen != rk0 + __popcll(same & lt)) viol = 1;
+      }
+      if (__ballot(viol != 0) != 0ull && lane == 0) scratch[20] = 1;
+    } else {
+      rank_by_ballots(false);
+    }
+    __syncthreads();
+    if (lane_ordered_atomics && scratch[20] != 0) {  // uniform over the workgroup (read behind the barrier)
+      for (int b = tid; b < nb; b += BUILD_BLOCK) bins[b] = 0ull;
+      __syncthreads();
+      rank_by_ballots(true);
+      if (tid == 0 && misrank_word) __hip_atomic_fetch_add(misrank_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // pinned host word
+      __syncthreads();
     }
     __syncthreads();
     RANDT_TICK(3);
@@ -732,13 +766,22 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
     }
   }
   int32_t* d_fallback = reinterpret_cast<int32_t*>(ctx->build_ws);
+  // Atomic ranking (see k_ndt_build): every launch checks the serving order it relies on and falls back in-kernel; the
+  // workgroups that had to are counted in a host-visible word, read here without a synchronisation -- once it is non-zero the
+  // context ranks with ballots only.
+  if (ctx->lds_atomics_lane_ordered && ctx->misrank_word && *reinterpret_cast<volatile int32_t*>(ctx->misrank_word) != 0) {
+    ctx->build_rank_fallbacks += *reinterpret_cast<volatile int32_t*>(ctx->misrank_word);
+    ctx->lds_atomics_lane_ordered = 0;
+    ctx->last_error = "NDT build: the LDS atomic ranking failed its lane-order check on this device; ballot ranking from now on (results unaffected)";
+  }
+  const int rank_mode = ctx->lds_atomics_lane_ordered ? (ctx->debug_force_misrank ? 2 : 1) : 0;
 #define RANDT_BUILD_LAUNCH(REG)                                                                                            \
   do {                                                                                                                     \
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<REG>),                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
     hipLaunchKernelGGL((k_ndt_build<REG>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,            \
                        d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux, d_fallback,            \
-                       ctx->lds_atomics_lane_ordered);                                                                      \
+                       rank_mode, ctx->misrank_word);                                                                       \
   } while (0)
   if (reg) RANDT_BUILD_LAUNCH(true);
   else RANDT_BUILD_LAUNCH(false);

@@ -432,7 +432,9 @@ int launch_ndt_build_big(randt_ctx* ctx, const float* d_points, int n_scans, int
   A.n_tiles = (pitch + BIG_TILE - 1) / BIG_TILE;
   A.first_map = first_map;
   A.npad = (pitch + 63) & ~63;
-  A.lane_ordered_atomics = ctx->lds_atomics_lane_ordered;
+  // the tiled path (scans above 7168 points, pNDT cells: not the headline path) ranks with ballots unless asked otherwise: the atomic
+  // ranking's in-kernel order check and fallback live in k_ndt_build only
+  A.lane_ordered_atomics = (ctx->lds_atomics_lane_ordered && getenv("RANDT_BUILD_BIG_ATOMIC_RANK")) ? 1 : 0;
   char* w = (char*)d_ws;
   auto take = [&](size_t bytes) {
     char* p = w;

@@ -86,3 +86,15 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "randt_oracle" not in txt and "orc_" not in txt, f
+
+
+def test_committed_counters_belong_to_the_current_kernels():
+    """bench.py's roofline numerator comes from the newest profiles/r*_sq_summary.csv; its rows carry a fingerprint of the hot
+    kernels' sources (tools/csrc_hash.py) and bench.py refuses counters taken from other code -- so a kernel change without
+    tools/collect_profiles.sh + tools/pmc_summary.py fails HERE, on the CPU, before a stale number can be printed."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    rows, path, stale = bench.load_counters()
+    assert stale is None, stale
+    assert set(rows) == set(bench.HOT_KERNELS), (path, sorted(rows))

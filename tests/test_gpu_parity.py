@@ -189,3 +189,45 @@ def test_full_batch_size_independent_properties(built):
     err_r = np.abs(synth.wrap_angle(est[:, 2] - prob["truth"][:, 2]))
     assert np.median(err_t) < 0.02 and np.percentile(err_t, 95) < 0.1 and np.median(err_r) < 0.005
     assert (r1["status"] == 0).all() and (r1["termination"] >= 1).all() and (r1["termination"] <= 3).all()
+
+
+def test_atomic_ranking_is_checked_in_every_launch_and_falls_back(built, monkeypatch):
+    """k_ndt_build ranks points with one returning LDS atomic each, which is only right if colliding lanes are served in
+    lane order.  The kernel re-checks that on a sample in every launch; a violation makes the workgroup rank again with
+    ballots (bit-exact results) and the context stops using the atomic ranking.  RANDT_DEBUG_FORCE_MISRANK makes the check
+    fail on purpose: the fallback must engage, be reported, and leave the cell statistics bit-identical to the oracle."""
+    import ctypes as C
+
+    import torch
+
+    lib = R._capi.load()
+    lib.randt_debug_lds_atomics_lane_ordered.argtypes = [C.c_void_p]
+    lib.randt_debug_build_rank_fallbacks.argtypes = [C.c_void_p]
+    prob = problem()
+    dev = torch.device("cuda:0")
+    pts = torch.from_numpy(prob["scans"]).to(dev)
+    B = pts.shape[0]
+
+    def build_and_check(ctx):
+        maps = R.Maps(ctx, B, R.indoor_map_params(), 512, with_grid=True)
+        R.ndt_build_batch(ctx, pts, R.indoor_cluster_params(), maps)
+        ctx.synchronize()
+        for i in range(B):
+            om = oracle_scan_map(prob["scans"][i])
+            cells, grid = maps.download(i)
+            assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid()), i
+
+    healthy = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    assert lib.randt_debug_lds_atomics_lane_ordered(healthy._h) == 1          # the device passes the creation-time probe
+    build_and_check(healthy)
+    assert lib.randt_debug_build_rank_fallbacks(healthy._h) == 0              # ... and every in-launch check
+    monkeypatch.setenv("RANDT_DEBUG_FORCE_MISRANK", "1")
+    sick = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    monkeypatch.delenv("RANDT_DEBUG_FORCE_MISRANK")
+    build_and_check(sick)                                                      # re-ranked in-kernel: still bit-exact
+    n = lib.randt_debug_build_rank_fallbacks(sick._h)
+    assert n >= B                                                              # every workgroup took the fallback
+    build_and_check(sick)                                                      # the launcher has seen the report ...
+    assert lib.randt_debug_lds_atomics_lane_ordered(sick._h) == 0              # ... and switched the context to ballots
+    assert lib.randt_debug_build_rank_fallbacks(sick._h) == n                  # no further fallbacks: ballots from the start
+    assert "lane-order check" in lib.randt_last_error(sick._h).decode()

@@ -15,11 +15,14 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 HEAD_ONLY="--odometry-scans 0 --polar-scans 0 --slam-scans 0 --polar-odometry-scans 0 --no-cpu-baseline"
 
+# the cost table's evidence: issue rates and the shader clock, three time bases (tools/clock_probe.hip)
+hipcc --offload-arch=gfx950 -O2 tools/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe > "$OUT/clock_probe.csv" 2>&1
+
 python bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"; echo
 
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run --output-format csv -- python bench.py "$@" > "$OUT/stats_bench.json" 2> "$OUT/stats.err"
-rocprofv3 --kernel-trace --stats -d "$OUT/single" -o run --output-format csv -- python bench.py --streams 1 --steps 300 --min-seconds 0 $HEAD_ONLY "$@" > "$OUT/single_bench.json" 2> "$OUT/single.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/single" -o run --output-format csv -- python bench.py --streams 1 --solve-mode throughput --steps 300 --min-seconds 0 $HEAD_ONLY "$@" > "$OUT/single_bench.json" 2> "$OUT/single.err"
 
 # SQ: 8 slots per pass; TCC: FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md, rocprofv3 PMC slots)
 declare -A SETS
@@ -30,7 +33,7 @@ SETS[fetch]="FETCH_SIZE GRBM_GUI_ACTIVE"
 SETS[write]="WRITE_SIZE"
 for s in sq_a sq_b sq_c fetch write; do
   rocprofv3 --kernel-trace --pmc ${SETS[$s]} -d "$OUT/pmc_$s" -o run --output-format csv -- \
-    python bench.py --streams 1 --steps 24 --warmup 2 --min-seconds 0 $HEAD_ONLY "$@" > "$OUT/pmc_$s.json" 2> "$OUT/pmc_$s.err"
+    python bench.py --streams 1 --solve-mode throughput --steps 24 --warmup 2 --min-seconds 0 $HEAD_ONLY "$@" > "$OUT/pmc_$s.json" 2> "$OUT/pmc_$s.err"
   ls "$OUT/pmc_$s" | head -3
 done
 find "$OUT" -name '*agent_info.csv' -delete

@@ -21,12 +21,20 @@ import re
 import shutil
 import sys
 
-# SIMD-cycles one wave-instruction occupies the VALU issue port, measured at saturation with tools/valu_rate_probe.hip
-# (profiles/r02_valu_rate_probe.csv, s_memtime ticks per wave-instruction, 4 wavefronts per SIMD, 8 independent chains):
-# v_fma/mul/add_f64 3.33, v_rcp/rsq_f64 12.55, 64-bit integer 3.33, fp32 / int32 / cvt / moves 2.0-2.1, v_rcp_f32 6.3.
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_hash  # noqa: E402
+
+# SIMD-cycles one wave64 instruction occupies its SIMD's VALU issue port, from the chip's SPEC rates (MI355X_MICROARCH.md:
+# SIMD-32, fp32 FMA 157.3 TFLOP/s = 2 cycles per wave instruction; vector fp64 78.6 TFLOP/s = half rate = 4 cycles;
+# transcendentals quarter rate: 8 cycles fp32, 16 cycles fp64), confirmed by tools/clock_probe.hip
+# (profiles/r03_clock_probe.csv: at 8 wavefronts per SIMD the event-timed rates reach 0.88-0.97 of these, at a shader clock
+# of 2.1-2.4 GHz measured as d(s_memtime) / d(s_memrealtime)).  Round 2 priced fp64 at 3.33 "ticks" from
+# tools/valu_rate_probe.hip: that probe divided ONE wavefront's tick count by the instructions of the four wavefronts it
+# assumed co-resident for the whole loop, but a wavefront's loop lasts only ~75 % of the launch (dispatch ramp), so the
+# figure was 4.0 x 0.83 -- an artefact, as was the "1.56-1.85 GHz under load" clock derived the same way.
 # "other" = SQ_INSTS_VALU minus every counted class (moves, compares, selects, DPP, readlane): priced at the cheapest
-# class, 2.0 (DPP moves cost 3.4 and lane reads 6.2, so this is a LOWER bound of the issue cycles).
-VALU_COST = {"F64": 3.33, "TRANS_F64": 12.55, "INT64": 3.33, "F32": 2.0, "TRANS_F32": 6.3, "INT32": 2.0, "CVT": 2.0, "OTHER": 2.0}
+# class, 2 (a LOWER bound of the issue cycles).
+VALU_COST = {"F64": 4.0, "TRANS_F64": 16.0, "INT64": 4.0, "F32": 2.0, "TRANS_F32": 8.0, "INT32": 2.0, "CVT": 2.0, "OTHER": 2.0}
 
 
 def valu_issue_cycles(c):
@@ -80,15 +88,16 @@ def main():
     default = trace_durations(os.path.join(src, "stats", "run_kernel_trace.csv"))
     with open(dst + "_sq_summary.csv", "w", newline="") as f:
         w = csv.writer(f)
+        stamp = csrc_hash()   # the code these counters were taken from (bench.py refuses them for other code)
         w.writerow(["kernel", "grid_size", "workgroup_size", "dispatches", "rocprof_vgpr_count", "lds_bytes"] + order +
-                   ["valu_issue_cycles", "fp64_flops", "single_stream_avg_us", "single_stream_launches"])
+                   ["valu_issue_cycles", "fp64_flops", "single_stream_avg_us", "single_stream_launches", "csrc_hash"])
         for key, d in sorted(table.items(), key=lambda kv: -sum(kv[1].get("SQ_INSTS_VALU", [0]))):
             mean = {c: sum(v) / len(v) for c, v in d.items() if not c.startswith("__")}
             cyc, fl = valu_issue_cycles(mean)
             dur = single.get((key[0], key[1]), [])
             w.writerow([key[0], key[1], key[2], max(len(v) for c, v in d.items() if not c.startswith("__")), d["__vgpr"][0], d["__lds"][0]] +
                        ["%.1f" % mean[c] if c in mean else "" for c in order] +
-                       ["%.0f" % cyc, "%.0f" % fl, "%.2f" % (sum(dur) / len(dur) / 1e3) if dur else "", len(dur)])
+                       ["%.0f" % cyc, "%.0f" % fl, "%.2f" % (sum(dur) / len(dur) / 1e3) if dur else "", len(dur), stamp])
     with open(dst + "_durations_by_grid.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["trace", "kernel", "grid_size", "launches", "avg_us", "min_us", "max_us"])
@@ -97,7 +106,8 @@ def main():
                 w.writerow([label, n, grid, len(v), "%.2f" % (sum(v) / len(v) / 1e3), "%.2f" % (min(v) / 1e3), "%.2f" % (max(v) / 1e3)])
     for a, b in (("stats/run_kernel_stats.csv", "_kernel_stats.csv"), ("single/run_kernel_stats.csv", "_single_stream_kernel_stats.csv"),
                  ("stats_bench.json", "_default_bench_profiled.json"), ("bench.json", "_default_bench.json"),
-                 ("single_bench.json", "_single_stream_bench.json"), ("valu_rate_probe.csv", "_valu_rate_probe.csv")):
+                 ("single_bench.json", "_single_stream_bench.json"), ("valu_rate_probe.csv", "_valu_rate_probe.csv"),
+                 ("clock_probe.csv", "_clock_probe.csv")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), dst + b)
     print(open(dst + "_sq_summary.csv").read()[:6000])
