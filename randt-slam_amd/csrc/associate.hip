@@ -117,7 +117,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
   int M = moving.counts[mmap];
   M = M > moving.cap ? moving.cap : M;
 
-  // ---- LDS carve (all 4-byte types; offsets multiples of 16 bytes)
+  // ---- LDS carve (4-byte types; the 64-bit mask array is rounded up to an 8-byte boundary)
   int32_t* lgrid = reinterpret_cast<int32_t*>(smem);
   const int grid_words = STAGE_GRID ? ((n_slots + 3) & ~3) : 0;
   int32_t* wtab = lgrid + grid_words;                       // [256] packed (i+128) << 8 | (j+128)
@@ -127,7 +127,9 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
   int32_t* cand = cpref + ASSOC_CH + 4;                     // [CH][CS]
   float* cdist = reinterpret_cast<float*>(cand + ASSOC_CH * ASSOC_CS);  // [CH][CS]
   int32_t* p0tab = reinterpret_cast<int32_t*>(cdist);       // [CH][CS] window slots 0..63 of every cell (dead before P3 writes cdist)
-  unsigned long long* pmask = reinterpret_cast<unsigned long long*>(cdist + ASSOC_CH * ASSOC_CS);  // [CH][2] occupied / in-range bits
+  // [CH][2] occupied / in-range bits; CH * CS is odd, so the word offset is rounded up to an even one (8-byte aligned ds_read_b64)
+  unsigned long long* pmask = reinterpret_cast<unsigned long long*>(
+      smem + ((static_cast<size_t>(reinterpret_cast<char*>(cdist + ASSOC_CH * ASSOC_CS) - smem) + 7) & ~static_cast<size_t>(7)));
   int32_t* ulist = reinterpret_cast<int32_t*>(pmask + 2 * ASSOC_CH);                                // [CH + 1] cells left to P2b, count last
 
   const int R = fixed.rmax - 1 > 0 ? fixed.rmax - 1 : 0;  // last radius the reference evaluates
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
 
 size_t assoc_lds_bytes(int n_slots, bool stage) {
   size_t words = (stage ? ((n_slots + 3) & ~3) : 0) + 256 + (ASSOC_CH * ASSOC_QS + 1) + ASSOC_CH + (ASSOC_CH + 4) +
-                 2 * ASSOC_CH * ASSOC_CS + 4 * ASSOC_CH + ASSOC_CH + 4;
+                 2 * ASSOC_CH * ASSOC_CS + 2 /* pmask alignment */ + 4 * ASSOC_CH + ASSOC_CH + 4;
   return words * 4 + 64;
 }
 

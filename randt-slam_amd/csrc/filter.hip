@@ -452,7 +452,8 @@ int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az
   // holds (occupancy x CUs), each walking several rows with its next row's loads already in flight.
   int per_scan = n_az;
   {
-    static int resident = 0;  // per process: one device architecture (gfx950)
+    static int resident_of[64] = {0};  // resident workgroups per device (a process may hold contexts on several GPUs)
+    int& resident = resident_of[ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0];
     if (resident == 0) {
       int per_cu = 0, cus = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_filter_rows<true>, FILT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
