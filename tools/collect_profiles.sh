@@ -15,6 +15,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 HEAD_ONLY="--odometry-scans 0 --polar-scans 0 --slam-scans 0 --polar-odometry-scans 0 --no-cpu-baseline"
 
+python tools/csrc_hash.py > "$OUT/csrc_hash.txt"   # fingerprint of the kernels these counters belong to
 # the cost table's evidence: issue rates and the shader clock, three time bases (tools/clock_probe.hip)
 hipcc --offload-arch=gfx950 -O2 tools/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe > "$OUT/clock_probe.csv" 2>&1
 

@@ -88,7 +88,10 @@ def main():
     default = trace_durations(os.path.join(src, "stats", "run_kernel_trace.csv"))
     with open(dst + "_sq_summary.csv", "w", newline="") as f:
         w = csv.writer(f)
-        stamp = csrc_hash()   # the code these counters were taken from (bench.py refuses them for other code)
+        # the code these counters were taken from (bench.py refuses them for other code): recorded on the GPU box by
+        # collect_profiles.sh at collection time
+        hp = os.path.join(src, "csrc_hash.txt")
+        stamp = open(hp).read().strip() if os.path.exists(hp) else csrc_hash()
         w.writerow(["kernel", "grid_size", "workgroup_size", "dispatches", "rocprof_vgpr_count", "lds_bytes"] + order +
                    ["valu_issue_cycles", "fp64_flops", "single_stream_avg_us", "single_stream_launches", "csrc_hash"])
         for key, d in sorted(table.items(), key=lambda kv: -sum(kv[1].get("SQ_INSTS_VALU", [0]))):
