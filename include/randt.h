@@ -420,7 +420,11 @@ int randt_predict_state_param(const randt_state* last, double stamp, int paramet
  * pair registration; whole LM loop on the device.  h_states in/out (both pose representations are
  * synchronised on return, cf. local_fuser.cpp:141-150); h_trans4 in: prior pose for the rejection
  * gate (ndt_matcher.cpp:339-340,411-422), out: newest pose.  *rejected = 1 if the gate fired.
- * mp->parameterization must be RANDT_PARAM_MANIFOLD (the shipped configuration). */
+ * mp->parameterization: RANDT_PARAM_MANIFOLD (optimize_on_manifold: true, the shipped configuration: SE(2) pose blocks with
+ * Sophus' manifold, MotionModelFactorSE2 / RotationalResidualSE2) or RANDT_PARAM_VECTOR (optimize_on_manifold: false: parameter
+ * blocks pos[2] and rot[1] with plain addition, MotionModelFactor :554-619 / RotationalResidual :307-336 /
+ * NDTFrameToMap{,Intensity}FactorResidual :421-451,486-518; pos / rot of the states are the variables, the association still
+ * starts from the states' `pose` members like the reference's, ndt_matcher.cpp:364). */
 int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
                           const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
                           const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,

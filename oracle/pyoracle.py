@@ -183,6 +183,9 @@ def lib():
     L.orc_predict_state.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
     L.orc_motion_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_imu_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    L.orc_predict_state_vec.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+    L.orc_motion_residual_vec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_imu_residual_vec.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     L.orc_register_window.restype = C.c_int
     L.orc_register_window.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, P(MatcherParams),
                                       P(WindowParams), C.c_void_p, P(SolveStats)]
@@ -465,29 +468,30 @@ def window_params(motion_sqrtI_diag=(1, 1, 1, 1, 3, 0.1, 20, 60), covariance_sca
     return wp
 
 
-def predict_state(last, stamp):
+def predict_state(last, stamp, vector=False):
     a = np.array([last], dtype=STATE_DTYPE)
     out = np.zeros(1, dtype=STATE_DTYPE)
-    lib().orc_predict_state(_ptr(a), float(stamp), _ptr(out))
+    (lib().orc_predict_state_vec if vector else lib().orc_predict_state)(_ptr(a), float(stamp), _ptr(out))
     return out[0]
 
 
-def motion_residual(x0, x1, sqrtI, want_jac=True):
+def motion_residual(x0, x1, sqrtI, want_jac=True, vector=False):
     a = np.array([x0], dtype=STATE_DTYPE)
     b = np.array([x1], dtype=STATE_DTYPE)
     M = np.ascontiguousarray(sqrtI, dtype=np.float64).reshape(64)
     r = np.zeros(8)
     J = np.zeros((8, 16))
-    lib().orc_motion_residual(_ptr(a), _ptr(b), _ptr(M), _ptr(r), _ptr(J) if want_jac else None)
+    (lib().orc_motion_residual_vec if vector else lib().orc_motion_residual)(_ptr(a), _ptr(b), _ptr(M), _ptr(r), _ptr(J) if want_jac else None)
     return r, J
 
 
-def imu_residual(x0, x1, imu_rot, weight, bias_weight, want_jac=True):
+def imu_residual(x0, x1, imu_rot, weight, bias_weight, want_jac=True, vector=False):
     a = np.array([x0], dtype=STATE_DTYPE)
     b = np.array([x1], dtype=STATE_DTYPE)
     r = np.zeros(2)
     J = np.zeros((2, 8))
-    lib().orc_imu_residual(_ptr(a), _ptr(b), float(imu_rot), float(weight), float(bias_weight), _ptr(r), _ptr(J) if want_jac else None)
+    (lib().orc_imu_residual_vec if vector else lib().orc_imu_residual)(_ptr(a), _ptr(b), float(imu_rot), float(weight), float(bias_weight),
+                                                                       _ptr(r), _ptr(J) if want_jac else None)
     return r, J
 
 

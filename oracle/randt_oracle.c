@@ -1520,7 +1520,117 @@ void orc_imu_residual(const orc_state* x0, const orc_state* x1, double imu_rot, 
   }
 }
 
+/* NormalizeAngle (include/ndt_registration/state_manifold.h:17-23): into [-pi, pi) */
+static double normalize_angle(double a) { return a - 2.0 * M_PI * floor((a + M_PI) / (2.0 * M_PI)); }
+
+/* predict, (pos, rot) form (ceres_residuals.h:25-55 template / :91-123 double): mid-point heading, dt clamped to >= 0.2 */
+static void predict_vec(const double pos[2], double rot, const double v[2], double w, const double a[2], double raw_dt,
+                        double pos_out[2], double* rot_out, double v_out[2], double* w_out, double a_out[2], double* cy_out,
+                        double* sy_out, double delta_rot[2]) {
+  const double dt = raw_dt > 0.2 ? raw_dt : 0.2;
+  double new_rot = rot;
+  const double mid = normalize_angle(rot + 0.5 * dt * w);
+  new_rot += dt * w;
+  new_rot = normalize_angle(new_rot);
+  const double sy = sin(mid), cy = cos(mid);
+  const double delta_x = v[0] * dt + 0.5 * a[0] * dt * dt;
+  const double delta_y = v[1] * dt + 0.5 * a[1] * dt * dt;
+  const double dxr = cy * delta_x - sy * delta_y, dyr = sy * delta_x + cy * delta_y;
+  pos_out[0] = pos[0] + dxr;
+  pos_out[1] = pos[1] + dyr;
+  *rot_out = new_rot;
+  v_out[0] = v[0] + dt * a[0];
+  v_out[1] = v[1] + dt * a[1];
+  *w_out = w;
+  a_out[0] = a[0];
+  a_out[1] = a[1];
+  if (cy_out) *cy_out = cy;
+  if (sy_out) *sy_out = sy;
+  if (delta_rot) {
+    delta_rot[0] = dxr;
+    delta_rot[1] = dyr;
+  }
+}
+
+/* Matcher::predictTransform, the branch taken when optimize_on_manifold is false (ndt_matcher.cpp:27-41) */
+void orc_predict_state_vec(const orc_state* last, double stamp, orc_state* next) {
+  const double zero[2] = {0.0, 0.0}; /* last_state.lin_acc = Zero (:26) */
+  memset(next, 0, sizeof(*next));
+  predict_vec(last->pos, last->rot, last->lin_vel, last->rot_vel, zero, stamp - last->stamp, next->pos, &next->rot, next->lin_vel,
+              &next->rot_vel, next->lin_acc, NULL, NULL, NULL);
+  next->pose[0] = cos(next->rot); /* Sophus::SE2d(rot, pos) (:41) */
+  next->pose[1] = sin(next->rot);
+  next->pose[2] = next->pos[0];
+  next->pose[3] = next->pos[1];
+  next->imu_bias = 0.0;
+  next->stamp = stamp;
+}
+
+/* MotionModelFactor (ceres_residuals.h:554-619), parameter blocks pos(2) rot(1) lin_vel(2) rot_vel(1) lin_acc(2) of both
+ * states; J: 8 x 16, columns [X0: pos2 rot1 v2 w1 a2 | X1: the same] -- what Ceres' autodiff yields (NormalizeAngle has
+ * derivative 1: the floor() term is piecewise constant). */
+void orc_motion_residual_vec(const orc_state* x0, const orc_state* x1, const double* sqrtI, double* r8, double* J) {
+  const double raw_dt = x1->stamp - x0->stamp;
+  const double dt = raw_dt > 0.2 ? raw_dt : 0.2;
+  double pp[2], rp, vp[2], wp_, ap[2], cy, sy, dr[2];
+  predict_vec(x0->pos, x0->rot, x0->lin_vel, x0->rot_vel, x0->lin_acc, raw_dt, pp, &rp, vp, &wp_, ap, &cy, &sy, dr);
+  const double r[8] = {x1->pos[0] - pp[0], x1->pos[1] - pp[1], normalize_angle(x1->rot - rp), x1->lin_vel[0] - vp[0],
+                       x1->lin_vel[1] - vp[1], x1->rot_vel - wp_, x1->lin_acc[0] - ap[0], x1->lin_acc[1] - ap[1]};
+  double Jr[8][16];
+  memset(Jr, 0, sizeof(Jr));
+  if (J) {
+    const double h = 0.5 * dt * dt;
+    /* position rows: -d pos_pred */
+    Jr[0][0] = -1; Jr[1][1] = -1;
+    Jr[0][2] = dr[1];             Jr[1][2] = -dr[0];              /* d/d rot0: -(d R / d theta) delta = -(-dyr, dxr) */
+    Jr[0][3] = -cy * dt;          Jr[0][4] = sy * dt;
+    Jr[1][3] = -sy * dt;          Jr[1][4] = -cy * dt;
+    Jr[0][5] = dr[1] * 0.5 * dt;  Jr[1][5] = -dr[0] * 0.5 * dt;   /* heading at rot0 + dt w0 / 2 */
+    Jr[0][6] = -cy * h;           Jr[0][7] = sy * h;
+    Jr[1][6] = -sy * h;           Jr[1][7] = -cy * h;
+    Jr[0][8] = 1; Jr[1][9] = 1;
+    /* rotation row */
+    Jr[2][2] = -1; Jr[2][5] = -dt; Jr[2][10] = 1;
+    /* velocity / acceleration rows */
+    Jr[3][3] = -1; Jr[3][6] = -dt; Jr[3][11] = 1;
+    Jr[4][4] = -1; Jr[4][7] = -dt; Jr[4][12] = 1;
+    Jr[5][5] = -1; Jr[5][13] = 1;
+    Jr[6][6] = -1; Jr[6][14] = 1;
+    Jr[7][7] = -1; Jr[7][15] = 1;
+  }
+  for (int i = 0; i < 8; ++i) {
+    double acc = 0;
+    for (int k = 0; k < 8; ++k) acc += sqrtI[i * 8 + k] * r[k];
+    r8[i] = acc;
+  }
+  if (J)
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 16; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 8; ++k) acc += sqrtI[i * 8 + k] * Jr[k][j];
+        J[i * 16 + j] = acc;
+      }
+}
+
+/* RotationalResidual (ceres_residuals.h:307-336): blocks rot0, rot1, bias0, bias1; J: 2 x 8, columns as orc_imu_residual
+ * ([X0 pos2 rot1 | X1 pos2 rot1 | b0 | b1]). */
+void orc_imu_residual_vec(const orc_state* x0, const orc_state* x1, double imu_rot, double weight, double bias_weight, double* r2,
+                          double* J) {
+  const double raw_dt = x1->stamp - x0->stamp; /* dt_ is NOT clamped here (ndt_matcher.cpp:147) */
+  r2[0] = weight * (imu_rot - normalize_angle(x1->rot - x0->rot + x1->imu_bias * raw_dt));
+  r2[1] = bias_weight * (x1->imu_bias - x0->imu_bias);
+  if (J) {
+    memset(J, 0, sizeof(double) * 16);
+    J[0 * 8 + 2] = weight;
+    J[0 * 8 + 3 + 2] = -weight;
+    J[0 * 8 + 7] = -weight * raw_dt;
+    J[1 * 8 + 6] = -bias_weight;
+    J[1 * 8 + 7] = bias_weight;
+  }
+}
+
 typedef struct win_user {
+  int vec;                      /* (pos[2], rot) parameter blocks instead of the SE(2) manifold (optimize_on_manifold: false) */
   int S, F, d, k;               /* states 0..S (0 = oldest, pose constant), fixed maps */
   int const_vel, use_imu;
   orc_state base[8];            /* constant parts (stamps, oldest pose, constant blocks) */
@@ -1542,7 +1652,7 @@ static void win_layout(win_user* u) {
   int a = 0, t = 0;
   for (int j = 0; j <= u->S; ++j) {
     /* AddParameterBlock order: pose, lin_vel, rot_vel, lin_acc, [imu_bias] (ndt_matcher.cpp:290-320,146-181) */
-    if (j == 0) { u->off_amb[j][0] = u->off_tan[j][0] = -1; } else { u->off_amb[j][0] = a; u->off_tan[j][0] = t; a += 4; t += 3; }
+    if (j == 0) { u->off_amb[j][0] = u->off_tan[j][0] = -1; } else { u->off_amb[j][0] = a; u->off_tan[j][0] = t; a += u->vec ? 3 : 4; t += 3; }
     u->off_amb[j][1] = a; u->off_tan[j][1] = t; a += 2; t += 2;
     u->off_amb[j][2] = a; u->off_tan[j][2] = t; a += 1; t += 1;
     if (u->const_vel) { u->off_amb[j][3] = u->off_tan[j][3] = -1; } else { u->off_amb[j][3] = a; u->off_tan[j][3] = t; a += 2; t += 2; }
@@ -1555,7 +1665,15 @@ static void win_layout(win_user* u) {
 static void win_unpack(const win_user* u, const double* x, orc_state* st) {
   for (int j = 0; j <= u->S; ++j) {
     st[j] = u->base[j];
-    if (u->off_amb[j][0] >= 0) memcpy(st[j].pose, x + u->off_amb[j][0], sizeof(double) * 4);
+    if (u->off_amb[j][0] >= 0) {
+      if (u->vec) {
+        st[j].pos[0] = x[u->off_amb[j][0]];
+        st[j].pos[1] = x[u->off_amb[j][0] + 1];
+        st[j].rot = x[u->off_amb[j][0] + 2];
+      } else {
+        memcpy(st[j].pose, x + u->off_amb[j][0], sizeof(double) * 4);
+      }
+    }
     memcpy(st[j].lin_vel, x + u->off_amb[j][1], sizeof(double) * 2);
     st[j].rot_vel = x[u->off_amb[j][2]];
     if (u->off_amb[j][3] >= 0) memcpy(st[j].lin_acc, x + u->off_amb[j][3], sizeof(double) * 2);
@@ -1565,7 +1683,15 @@ static void win_unpack(const win_user* u, const double* x, orc_state* st) {
 
 static void win_pack(const win_user* u, const orc_state* st, double* x) {
   for (int j = 0; j <= u->S; ++j) {
-    if (u->off_amb[j][0] >= 0) memcpy(x + u->off_amb[j][0], st[j].pose, sizeof(double) * 4);
+    if (u->off_amb[j][0] >= 0) {
+      if (u->vec) {
+        x[u->off_amb[j][0]] = st[j].pos[0];
+        x[u->off_amb[j][0] + 1] = st[j].pos[1];
+        x[u->off_amb[j][0] + 2] = st[j].rot;
+      } else {
+        memcpy(x + u->off_amb[j][0], st[j].pose, sizeof(double) * 4);
+      }
+    }
     memcpy(x + u->off_amb[j][1], st[j].lin_vel, sizeof(double) * 2);
     x[u->off_amb[j][2]] = st[j].rot_vel;
     if (u->off_amb[j][3] >= 0) memcpy(x + u->off_amb[j][3], st[j].lin_acc, sizeof(double) * 2);
@@ -1576,7 +1702,9 @@ static void win_pack(const win_user* u, const orc_state* st, double* x) {
 static void win_plus(void* user, const double* x, const double* delta, double* xp) {
   const win_user* u = (const win_user*)user;
   for (int j = 0; j <= u->S; ++j) {
-    if (u->off_amb[j][0] >= 0) {
+    if (u->off_amb[j][0] >= 0 && u->vec) {
+      for (int e = 0; e < 3; ++e) xp[u->off_amb[j][0] + e] = x[u->off_amb[j][0] + e] + delta[u->off_tan[j][0] + e];
+    } else if (u->off_amb[j][0] >= 0) {
       double e[4];
       orc_se2_exp(delta + u->off_tan[j][0], e);
       orc_se2_mul(x + u->off_amb[j][0], e, xp + u->off_amb[j][0]);
@@ -1607,7 +1735,8 @@ static int win_eval(void* user, const double* x, double* cost, double* residuals
   if (jac) memset(jac, 0, sizeof(double) * (size_t)u->n_res * nt);
   for (int j = 1; j <= u->S; ++j) {
     double r8[8], J[8 * 16];
-    orc_motion_residual(&st[j - 1], &st[j], u->sqrtI, r8, jac ? J : NULL);
+    if (u->vec) orc_motion_residual_vec(&st[j - 1], &st[j], u->sqrtI, r8, jac ? J : NULL);
+    else orc_motion_residual(&st[j - 1], &st[j], u->sqrtI, r8, jac ? J : NULL);
     for (int i = 0; i < 8; ++i) {
       total += 0.5 * r8[i] * r8[i];
       if (residuals) residuals[row + i] = r8[i];
@@ -1626,7 +1755,8 @@ static int win_eval(void* user, const double* x, double* cost, double* residuals
     row += 8;
     if (u->use_imu) {
       double r2[2], J2[16];
-      orc_imu_residual(&st[j - 1], &st[j], u->imu[j - 1], u->weight_imu, u->weight_imu_bias, r2, jac ? J2 : NULL);
+      if (u->vec) orc_imu_residual_vec(&st[j - 1], &st[j], u->imu[j - 1], u->weight_imu, u->weight_imu_bias, r2, jac ? J2 : NULL);
+      else orc_imu_residual(&st[j - 1], &st[j], u->imu[j - 1], u->weight_imu, u->weight_imu_bias, r2, jac ? J2 : NULL);
       for (int i = 0; i < 2; ++i) {
         total += 0.5 * r2[i] * r2[i];
         if (residuals) residuals[row + i] = r2[i];
@@ -1643,8 +1773,10 @@ static int win_eval(void* user, const double* x, double* cost, double* residuals
     while (ndt_at < u->n_ndt && u->ndt_state[ndt_at] == j) {
       const int d = u->d;
       double jl[4];
-      double r = orc_ndt_residual(d, ORC_PARAM_MANIFOLD, st[j].pose, u->mm + (size_t)ndt_at * d, u->mc + (size_t)ndt_at * d * d,
-                                  u->fm + (size_t)ndt_at * d, u->fc + (size_t)ndt_at * d * d, jac ? jl : NULL);
+      /* vector form: NDTFrameToMap{,Intensity}FactorResidual on (pos, rot) (ceres_residuals.h:421-451, 486-518) */
+      const double pv[4] = {cos(st[j].rot), sin(st[j].rot), st[j].pos[0], st[j].pos[1]};
+      double r = orc_ndt_residual(d, u->vec ? ORC_PARAM_VECTOR : ORC_PARAM_MANIFOLD, u->vec ? pv : st[j].pose, u->mm + (size_t)ndt_at * d,
+                                  u->mc + (size_t)ndt_at * d * d, u->fm + (size_t)ndt_at * d, u->fc + (size_t)ndt_at * d * d, jac ? jl : NULL);
       if (!isfinite(r)) return 0;
       const double sq = r * r;
       double rs = 1.0, js = 1.0;
@@ -1692,6 +1824,8 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
 
   win_user u;
   memset(&u, 0, sizeof(u));
+  if (p->parameterization != ORC_PARAM_MANIFOLD && p->parameterization != ORC_PARAM_VECTOR) return -1;
+  u.vec = p->parameterization == ORC_PARAM_VECTOR;
   u.S = S; u.F = n_fixed; u.d = d; u.k = k;
   u.const_vel = wp->use_constant_velocity_model;
   u.use_imu = wp->use_imu && imu;
@@ -1794,11 +1928,18 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
   st->termination = term;
   st->final_cost = final_cost;
   win_unpack(&u, x, states);
-  /* both representations (ndt_matcher.cpp:403-406; local_fuser.cpp:141-150 does it for the whole window) */
+  /* both representations (ndt_matcher.cpp:399-406; local_fuser.cpp:141-150 does it for the whole window) */
   for (int j = 0; j <= S; ++j) {
-    states[j].pos[0] = states[j].pose[2];
-    states[j].pos[1] = states[j].pose[3];
-    states[j].rot = atan2(states[j].pose[1], states[j].pose[0]);
+    if (u.vec) { /* Sophus::SE2d(rot, pos) */
+      states[j].pose[0] = cos(states[j].rot);
+      states[j].pose[1] = sin(states[j].rot);
+      states[j].pose[2] = states[j].pos[0];
+      states[j].pose[3] = states[j].pos[1];
+    } else {
+      states[j].pos[0] = states[j].pose[2];
+      states[j].pos[1] = states[j].pose[3];
+      states[j].rot = atan2(states[j].pose[1], states[j].pose[0]);
+    }
   }
   int rejected = 0;
   {

@@ -203,6 +203,12 @@ typedef struct orc_window_params {
 
 /* Matcher::predictTransform, manifold branch (ndt_matcher.cpp:22-59) -> predictSE2 (ceres_residuals.h:62-83) */
 void orc_predict_state(const orc_state* last, double stamp, orc_state* next);
+/* ... and the (pos[2], rot) branch (optimize_on_manifold: false), ndt_matcher.cpp:27-41 with predict(), ceres_residuals.h:25-55 */
+void orc_predict_state_vec(const orc_state* last, double stamp, orc_state* next);
+/* MotionModelFactor / RotationalResidual on (pos, rot) blocks (ceres_residuals.h:554-619, 307-336); layouts as the SE2 forms */
+void orc_motion_residual_vec(const orc_state* x0, const orc_state* x1, const double* sqrtI, double* r8, double* J8x16);
+void orc_imu_residual_vec(const orc_state* x0, const orc_state* x1, double imu_rot, double weight, double bias_weight, double* r2,
+                          double* J2x8);
 /* MotionModelFactorSE2 (ceres_residuals.h:621-679): 8 residuals (already multiplied by sqrtI) and
  * the 8 x 16 row-major Jacobian w.r.t. tangent [X0: pose3 v2 w1 a2 | X1: pose3 v2 w1 a2]. */
 void orc_motion_residual(const orc_state* x0, const orc_state* x1, const double* sqrtI, double* r8, double* J8x16);

@@ -1325,7 +1325,9 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   if (!ctx || !fixed || !moving || !h_fixed_idx || !h_moving_idx || !h_states || !mp || !wp || !h_trans4) return RANDT_ERR_INVALID;
   const int S = n_states - 1;
   if (S < 1 || S > 3 || n_fixed < 1 || n_fixed > 2) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..3 optimised states, 1..2 fixed maps", hipSuccess);
-  if (mp->parameterization != RANDT_PARAM_MANIFOLD) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window solve implements the manifold configuration", hipSuccess);
+  if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_VECTOR)
+    return randt_set_error(ctx, RANDT_ERR_INVALID, "window solve: parameterization must be RANDT_PARAM_MANIFOLD or RANDT_PARAM_VECTOR", hipSuccess);
+  const bool vec = mp->parameterization == RANDT_PARAM_VECTOR;
   if (mp->n_neighbours <= 0 || mp->n_neighbours > 8) return RANDT_ERR_INVALID;
   {
     const int prc = check_matcher_params(ctx, mp);
@@ -1344,6 +1346,7 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   WinDesc W;
   memset(&W, 0, sizeof(W));
   W.S = S;
+  W.vec = vec ? 1 : 0;
   W.k = k;
   W.d3 = mp->use_intensity ? 1 : 0;
   W.const_vel = wp->use_constant_velocity_model ? 1 : 0;
@@ -1355,7 +1358,7 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   // tangent / ambient layout in Ceres' parameter-block order (ndt_matcher.cpp:290-320)
   int a = 0, t = 0;
   for (int j = 0; j <= S; ++j) {
-    if (j == 0) { W.off_amb[j][0] = W.off_tan[j][0] = -1; } else { W.off_amb[j][0] = a; W.off_tan[j][0] = t; a += 4; t += 3; }
+    if (j == 0) { W.off_amb[j][0] = W.off_tan[j][0] = -1; } else { W.off_amb[j][0] = a; W.off_tan[j][0] = t; a += vec ? 3 : 4; t += 3; }
     W.off_amb[j][1] = a; W.off_tan[j][1] = t; a += 2; t += 2;
     W.off_amb[j][2] = a; W.off_tan[j][2] = t; a += 1; t += 1;
     if (W.const_vel) { W.off_amb[j][3] = W.off_tan[j][3] = -1; } else { W.off_amb[j][3] = a; W.off_tan[j][3] = t; a += 2; t += 2; }
@@ -1384,7 +1387,7 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   // pinned memory and moved with one copy per direction (five small pageable copies cost ~40 us per scan)
   const size_t corr_bytes = sizeof(int32_t) * (size_t)W.n_terms * moving->v.cap * k;
   const size_t off_states = (corr_bytes + 255) & ~(size_t)255;
-  const size_t off_guess = off_states + sizeof(double) * 10 * RANDT_WIN_MAX_STATES;
+  const size_t off_guess = off_states + sizeof(double) * 12 * RANDT_WIN_MAX_STATES;
   const size_t off_idx = off_guess + sizeof(h_guess);
   const size_t off_res = off_idx + sizeof(h_idx) + 64;
   const size_t off_desc = (off_res + sizeof(randt_result) + 64 + 255) & ~(size_t)255;
@@ -1397,11 +1400,16 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   char* img = (char*)ctx->h_pin;           // upload image; the download lands at img + 4096
   memset(img, 0, span);
   double* h_packed = reinterpret_cast<double*>(img);
-  for (int j = 0; j <= S; ++j) {
-    double* o = h_packed + 10 * j;
-    memcpy(o, h_states[j].pose, sizeof(double) * 4);
+  for (int j = 0; j <= S; ++j) {  // 12 doubles per state (window.hip, ST_STRIDE)
+    double* o = h_packed + 12 * j;
+    if (vec) {  // the parameters are pos and rot; the pose slots carry cos / sin of rot for the NDT pass
+      o[0] = cos(h_states[j].rot); o[1] = sin(h_states[j].rot); o[2] = h_states[j].pos[0]; o[3] = h_states[j].pos[1];
+    } else {
+      memcpy(o, h_states[j].pose, sizeof(double) * 4);
+    }
     o[4] = h_states[j].lin_vel[0]; o[5] = h_states[j].lin_vel[1]; o[6] = h_states[j].rot_vel;
     o[7] = h_states[j].lin_acc[0]; o[8] = h_states[j].lin_acc[1]; o[9] = h_states[j].imu_bias;
+    o[10] = h_states[j].rot; o[11] = 0.0;
   }
   memcpy(img + (off_guess - off_states), h_guess, sizeof(h_guess));
   memcpy(img + (off_idx - off_states), h_idx, sizeof(h_idx));
@@ -1423,14 +1431,19 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   memcpy(&r, back + (off_res - off_states), sizeof(r));
   h_packed = reinterpret_cast<double*>(back);
   for (int j = 0; j <= S; ++j) {
-    const double* o = h_packed + 10 * j;
-    memcpy(h_states[j].pose, o, sizeof(double) * 4);
+    const double* o = h_packed + 12 * j;
     h_states[j].lin_vel[0] = o[4]; h_states[j].lin_vel[1] = o[5]; h_states[j].rot_vel = o[6];
     h_states[j].lin_acc[0] = o[7]; h_states[j].lin_acc[1] = o[8]; h_states[j].imu_bias = o[9];
-    // both pose representations (ndt_matcher.cpp:403-406, local_fuser.cpp:141-150)
+    // both pose representations (ndt_matcher.cpp:399-406, local_fuser.cpp:141-150)
     h_states[j].pos[0] = o[2];
     h_states[j].pos[1] = o[3];
-    h_states[j].rot = atan2(o[1], o[0]);
+    if (vec) {  // Sophus::SE2d(rot, pos)
+      h_states[j].rot = o[10];
+      h_states[j].pose[0] = cos(o[10]); h_states[j].pose[1] = sin(o[10]); h_states[j].pose[2] = o[2]; h_states[j].pose[3] = o[3];
+    } else {
+      memcpy(h_states[j].pose, o, sizeof(double) * 4);
+      h_states[j].rot = atan2(o[1], o[0]);
+    }
   }
   // rejection gate (ndt_matcher.cpp:411-422)
   int rej = 0;

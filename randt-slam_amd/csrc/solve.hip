@@ -110,13 +110,10 @@ struct Stage {
   unsigned kmagic;        // ceil(2^32 / k): slot / k == umulhi(slot, kmagic) for slot < 2^32 / k (k >= 2)
 };
 
-// Pass over all correspondence slots at ambient point x.  MODE 0: max raw residual (out.v[0]);
-// MODE 1: the ten base sums with loss + corrector (Ceres residual_block.cc / corrector.cc).
-// Returns false if any residual was non-finite.  red: [2][BLOCK/64][12] LDS, parity alternates per call.
-template <int D, int PARAM, int MODE, int BLOCK, bool AM2>
-__device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const Loss& L, Base& out, double* red, int& parity, int tid) {
-  constexpr int WAVES = BLOCK / 64;
-  double c, s, tx, ty;
+// cos / sin of the rotation and the translation of ambient point x (what a pass evaluates the residuals at)
+template <int D, int PARAM>
+__device__ __forceinline__ void pass_pose(const double* x, double& c, double& s, double& tx, double& ty) {
+#pragma clang fp contract(off)
   if (PARAM == RANDT_PARAM_VECTOR) {
     c = cos(x[2]);
     s = sin(x[2]);
@@ -124,12 +121,22 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     ty = x[1];
   } else {
     // R = AngleAxis(atan2(sp, cp)): cos/sin of the angle == normalised stored complex
-    const double inv = fast_rsqrt(x[0] * x[0] + x[1] * x[1]);
+    const double inv = fast_rsqrt(fma(x[0], x[0], x[1] * x[1]));
     c = x[0] * inv;
     s = x[1] * inv;
     tx = x[2];
     ty = x[3];
   }
+}
+
+// Pass over all correspondence slots at ambient point x.  MODE 0: max raw residual (out.v[0]);
+// MODE 1: the ten base sums with loss + corrector (Ceres residual_block.cc / corrector.cc).
+// Returns false if any residual was non-finite.  red: [2][BLOCK/64][12] LDS, parity alternates per call.
+template <int D, int PARAM, int MODE, int BLOCK, bool AM2>
+__device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const Loss& L, Base& out, double* red, int& parity, int tid) {
+  constexpr int WAVES = BLOCK / 64;
+  double c, s, tx, ty;
+  pass_pose<D, PARAM>(x, c, s, tx, ty);
   const Rot rot = make_rot(c, s);
   double acc[10];
 #pragma unroll
@@ -233,23 +240,6 @@ struct SplitReq {
   int mode;  // 0: raw-residual maximum, 1: terms of the ten sums, -1: the solve is over
   int pad;
 };
-
-template <int D, int PARAM>
-__device__ __forceinline__ void pass_pose(const double* x, double& c, double& s, double& tx, double& ty) {
-  if (PARAM == RANDT_PARAM_VECTOR) {
-    c = cos(x[2]);
-    s = sin(x[2]);
-    tx = x[0];
-    ty = x[1];
-  } else {
-    // R = AngleAxis(atan2(sp, cp)): cos/sin of the angle == normalised stored complex
-    const double inv = fast_rsqrt(x[0] * x[0] + x[1] * x[1]);
-    c = x[0] * inv;
-    s = x[1] * inv;
-    tx = x[2];
-    ty = x[3];
-  }
-}
 
 __device__ __forceinline__ void pair_records(const Stage& S, int e, const float4*& mv, const float4*& fv) {
   const unsigned u = S.pairs[e];

@@ -10,6 +10,7 @@ namespace randt_solve {
 // 1/x and 1/sqrt(x) to ~1 ulp: hardware seed (2^-23 relative) + two Newton-Raphson steps.  A correctly
 // rounded fp64 division costs ~25 instructions on gfx950, these 5 / 9.
 __device__ __forceinline__ double fast_rcp(double x) {
+#pragma clang fp contract(off)
   double y = __builtin_amdgcn_rcp(x);
   double e = fma(-x, y, 1.0);
   y = fma(y, e, y);
@@ -17,6 +18,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(y, e, y);
 }
 __device__ __forceinline__ double fast_rsqrt(double x) {
+#pragma clang fp contract(off)
   double y = __builtin_amdgcn_rsq(x);
   double e = fma(-x * y, y, 1.0);
   y = fma(0.5 * y, e, y);
@@ -100,6 +102,7 @@ struct Rot {
   double c, s, c2, s2, cs, cs2, c2ms2;
 };
 __device__ __forceinline__ Rot make_rot(double c, double s) {
+#pragma clang fp contract(off)
   Rot R;
   R.c = c;
   R.s = s;
@@ -114,6 +117,7 @@ __device__ __forceinline__ Rot make_rot(double c, double s) {
 template <int D, bool WANT_JAC>
 __device__ __forceinline__ double residual_sq_v(const float4 ma, const float4 mb, const float4 mc4, const float4 fa, const float4 fb,
                                                 const float4 fc4, const Rot& R, double tx, double ty, double* jb) {
+#pragma clang fp contract(off)
   const float mv[9] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w, mc4.x};
   const float fv[9] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc4.x};
   const double c = R.c, s = R.s;
@@ -126,6 +130,9 @@ __device__ __forceinline__ double residual_sq_v(const float4 ma, const float4 mb
   const double d1 = fma(s, m0, fma(c, m1, ty - (double)fv[1]));
   double q0, q1, q2 = 0.0, ssq;
   double cc = 0.0, e = 0.0;
+  // Every product-sum below is an explicit fma / mul / add under `fp contract(off)`: the same residual is evaluated by
+  // different wavefronts in different kernels (k_solve's split mode, the window solve) and must round identically everywhere
+  // -- the compiler's own contraction picks different fusions for the same expression in different surroundings.
   if (D == 3) {
     cc = mv[5];
     e = mv[7];
@@ -133,35 +140,35 @@ __device__ __forceinline__ double residual_sq_v(const float4 ma, const float4 mb
     const double C12 = fma(s, cc, fma(c, e, (double)fv[7]));
     const double C22 = (double)mv[8] + (double)fv[8];
     const double d2 = (double)mv[2] - (double)fv[2];
-    const double k00 = C11 * C22 - C12 * C12;
-    const double k01 = C12 * C02 - C01 * C22;
-    const double k02 = C01 * C12 - C11 * C02;
-    const double det = C00 * k00 + C01 * k01 + C02 * k02;
+    const double k00 = fma(C11, C22, -(C12 * C12));
+    const double k01 = fma(C12, C02, -(C01 * C22));
+    const double k02 = fma(C01, C12, -(C11 * C02));
+    const double det = fma(C02, k02, fma(C01, k01, C00 * k00));
     const double id = fast_rcp(det);
-    const double k11 = C00 * C22 - C02 * C02;
-    const double k12 = C02 * C01 - C00 * C12;
-    const double k22 = C00 * C11 - C01 * C01;
-    q0 = (k00 * d0 + k01 * d1 + k02 * d2) * id;
-    q1 = (k01 * d0 + k11 * d1 + k12 * d2) * id;
-    q2 = (k02 * d0 + k12 * d1 + k22 * d2) * id;
-    ssq = d0 * q0 + d1 * q1 + d2 * q2;
+    const double k11 = fma(C00, C22, -(C02 * C02));
+    const double k12 = fma(C02, C01, -(C00 * C12));
+    const double k22 = fma(C00, C11, -(C01 * C01));
+    q0 = fma(k02, d2, fma(k01, d1, k00 * d0)) * id;
+    q1 = fma(k12, d2, fma(k11, d1, k01 * d0)) * id;
+    q2 = fma(k22, d2, fma(k12, d1, k02 * d0)) * id;
+    ssq = fma(d2, q2, fma(d1, q1, d0 * q0));
   } else {
-    const double det = C00 * C11 - C01 * C01;
+    const double det = fma(C00, C11, -(C01 * C01));
     const double id = fast_rcp(det);
-    q0 = (C11 * d0 - C01 * d1) * id;
-    q1 = (-C01 * d0 + C00 * d1) * id;
-    ssq = d0 * q0 + d1 * q1;
+    q0 = fma(C11, d0, -(C01 * d1)) * id;
+    q1 = fma(C00, d1, -(C01 * d0)) * id;
+    ssq = fma(d1, q1, d0 * q0);
   }
   if (WANT_JAC) {
-    const double u0 = c * q0 + s * q1, u1 = -s * q0 + c * q1;
-    double Su0 = a * u0 + b * u1, Su1 = b * u0 + dd * u1;
+    const double u0 = fma(s, q1, c * q0), u1 = fma(c, q1, -(s * q0));
+    double Su0 = fma(b, u1, a * u0), Su1 = fma(dd, u1, b * u0);
     if (D == 3) {
-      Su0 += cc * q2;
-      Su1 += e * q2;
+      Su0 = fma(cc, q2, Su0);
+      Su1 = fma(e, q2, Su1);
     }
     jb[0] = q0;
     jb[1] = q1;
-    jb[2] = (u1 * m0 - u0 * m1) - (u1 * Su0 - u0 * Su1);
+    jb[2] = fma(u1, m0, -(u0 * m1)) - fma(u1, Su0, -(u0 * Su1));
   }
   return ssq;
 }
@@ -185,6 +192,7 @@ __device__ __forceinline__ double residual_sq(const float4* mrec, const float4* 
 //   jr = js rs, h = js^2 / sq, c = the cost term's variable part (alpha = -2: 1/u - 1, added as half_w_pre * c; else rho / 2)
 template <bool AM2>
 __device__ __forceinline__ void residual_terms(const Loss& L, double sq, double& jr, double& h, double& c) {
+#pragma clang fp contract(off)
   if (AM2) {
     // alpha = -2: rho' = w / u^2 > 0, rho'' < 0 always => corrector is sqrt(rho') = sqrt(w) / u, rs = js.
     // ONE reciprocal serves 1 / u and 1 / sq: rP = 1 / (u^2 sq)  ->  h = w rP,  js rs = w / u^2 = h sq,  1 / u = rP u sq.
@@ -193,8 +201,7 @@ __device__ __forceinline__ void residual_terms(const Loss& L, double sq, double&
     const double rP = fast_rcp((u * u) * sqc);
     h = L.weight * rP;
     jr = h * sqc;
-    const double iu = (rP * u) * sqc;
-    c = iu - 1.;
+    c = fma(rP * u, sqc, -1.0);  // 1 / u - 1
   } else {
     double rs, js;  // residual and Jacobian scale of the corrector (equal for a scalar residual when rho'' <= 0)
     double r0, r1, r2;
@@ -215,6 +222,7 @@ __device__ __forceinline__ void residual_terms(const Loss& L, double sq, double&
 }
 template <bool AM2>
 __device__ __forceinline__ void accumulate_terms(const Loss& L, double jr, double h, const double* jb, double c, double* acc) {
+#pragma clang fp contract(off)
   acc[0] = AM2 ? fma(L.half_w_pre, c, acc[0]) : acc[0] + c;
   const double h0 = h * jb[0], h1 = h * jb[1], h2 = h * jb[2];
   acc[1] = fma(jr, jb[0], acc[1]);

@@ -175,8 +175,10 @@ __device__ __forceinline__ void se2_log(const double* p, double* xi) {
   xi[2] = theta;
 }
 
-// state record in LDS: [0..3] pose, [4,5] lin_vel, [6] rot_vel, [7,8] lin_acc, [9] imu_bias
-#define ST_STRIDE 10
+// state record in LDS: [0..3] pose, [4,5] lin_vel, [6] rot_vel, [7,8] lin_acc, [9] imu_bias, [10] rot, [11] unused.
+// Vector parameterisation (optimize_on_manifold: false; parameter blocks pos[2], rot[1]): the parameters are [2], [3], [10],
+// and [0], [1] = cos / sin of [10] are kept up to date by Plus, so that the NDT pass reads one layout in both modes.
+#define ST_STRIDE 12
 
 // MotionModelFactorSE2 (ceres_residuals.h:621-679): UNWEIGHTED residual r[8] and Jacobian Ju[8][16]
 // w.r.t. tangent [X0: pose3 v2 w1 a2 | X1: pose3 v2 w1 a2] (right perturbations).
@@ -296,6 +298,64 @@ __device__ void imu_factor(const double* x0, const double* x1, double raw_dt, do
   se2_mul(inv0, M1, E);
   se2_log(E, lg);
   r[0] = w * (imu_rot - lg[2]);
+  r[1] = wb * (x1[9] - x0[9]);
+  for (int i = 0; i < 16; ++i) J[i] = 0.0;
+  J[2] = w;
+  J[3 + 2] = -w;
+  J[7] = -w * raw_dt;
+  J[8 + 6] = -wb;
+  J[8 + 7] = wb;
+}
+
+// NormalizeAngle (include/ndt_registration/state_manifold.h:17-23)
+__device__ __forceinline__ double normalize_angle(double a) {
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  return a - two_pi * floor((a + 3.14159265358979323846) / two_pi);
+}
+
+// MotionModelFactor (ceres_residuals.h:554-619) on the (pos, rot) blocks, with predict() (:25-55): UNWEIGHTED residual r[8]
+// and Jacobian Ju[8][16] w.r.t. [X0: pos2 rot1 v2 w1 a2 | X1: the same] (what Ceres' autodiff yields; NormalizeAngle has
+// derivative 1).  (Ju was zeroed by the whole wavefront once per kernel: a factor always writes the same entries.)
+__device__ void motion_factor_vec(const double* x0, const double* x1, double raw_dt, double* r, double* Ju /* LDS 8x16 */) {
+  const double dt = raw_dt > 0.2 ? raw_dt : 0.2;
+  const double mid = normalize_angle(x0[10] + 0.5 * dt * x0[6]);
+  double new_rot = x0[10];
+  new_rot += dt * x0[6];
+  new_rot = normalize_angle(new_rot);
+  double sy, cy;
+  sincos(mid, &sy, &cy);
+  const double half_dt2 = 0.5 * dt * dt;
+  const double delta_x = x0[4] * dt + 0.5 * x0[7] * dt * dt;
+  const double delta_y = x0[5] * dt + 0.5 * x0[8] * dt * dt;
+  const double dxr = cy * delta_x - sy * delta_y, dyr = sy * delta_x + cy * delta_y;
+  r[0] = x1[2] - (x0[2] + dxr);
+  r[1] = x1[3] - (x0[3] + dyr);
+  r[2] = normalize_angle(x1[10] - new_rot);
+  r[3] = x1[4] - (x0[4] + dt * x0[7]);
+  r[4] = x1[5] - (x0[5] + dt * x0[8]);
+  r[5] = x1[6] - x0[6];
+  r[6] = x1[7] - x0[7];
+  r[7] = x1[8] - x0[8];
+  Ju[0 * 16 + 0] = -1; Ju[1 * 16 + 1] = -1;
+  Ju[0 * 16 + 2] = dyr;               Ju[1 * 16 + 2] = -dxr;
+  Ju[0 * 16 + 3] = -cy * dt;          Ju[0 * 16 + 4] = sy * dt;
+  Ju[1 * 16 + 3] = -sy * dt;          Ju[1 * 16 + 4] = -cy * dt;
+  Ju[0 * 16 + 5] = dyr * 0.5 * dt;    Ju[1 * 16 + 5] = -dxr * 0.5 * dt;
+  Ju[0 * 16 + 6] = -cy * half_dt2;    Ju[0 * 16 + 7] = sy * half_dt2;
+  Ju[1 * 16 + 6] = -sy * half_dt2;    Ju[1 * 16 + 7] = -cy * half_dt2;
+  Ju[0 * 16 + 8] = 1; Ju[1 * 16 + 9] = 1;
+  Ju[2 * 16 + 2] = -1; Ju[2 * 16 + 5] = -dt; Ju[2 * 16 + 10] = 1;
+  Ju[3 * 16 + 3] = -1; Ju[3 * 16 + 6] = -dt; Ju[3 * 16 + 11] = 1;
+  Ju[4 * 16 + 4] = -1; Ju[4 * 16 + 7] = -dt; Ju[4 * 16 + 12] = 1;
+  Ju[5 * 16 + 5] = -1; Ju[5 * 16 + 13] = 1;
+  Ju[6 * 16 + 6] = -1; Ju[6 * 16 + 14] = 1;
+  Ju[7 * 16 + 7] = -1; Ju[7 * 16 + 15] = 1;
+}
+
+// RotationalResidual (ceres_residuals.h:307-336) on rot0, rot1, bias0, bias1; J as imu_factor's
+__device__ void imu_factor_vec(const double* x0, const double* x1, double raw_dt, double imu_rot, double w, double wb, double* r,
+                               double* J /* LDS 2x8 */) {
+  r[0] = w * (imu_rot - normalize_angle(x1[10] - x0[10] + x1[9] * raw_dt));
   r[1] = wb * (x1[9] - x0[9]);
   for (int i = 0; i < 16; ++i) J[i] = 0.0;
   J[2] = w;
@@ -458,7 +518,8 @@ __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
   if (lane < W.S) {
     const int f = lane;  // factor between states f and f+1
     double r[8];
-    motion_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], r, sh.Ju[buf][f]);
+    if (W.vec) motion_factor_vec(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], r, sh.Ju[buf][f]);
+    else motion_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], r, sh.Ju[buf][f]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) sh.ru[buf][f][i] = r[i];
     double c = 0.0;
@@ -466,7 +527,8 @@ __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
     for (int i = 0; i < 8; ++i) c += 0.5 * sh.d2[i] * (r[i] * r[i]);
     if (W.use_imu) {
       double r2[2];
-      imu_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], W.imu[f], W.w_imu, W.w_bias, r2, sh.J2[buf][f]);
+      if (W.vec) imu_factor_vec(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], W.imu[f], W.w_imu, W.w_bias, r2, sh.J2[buf][f]);
+      else imu_factor(sh.xs[buf][f], sh.xs[buf][f + 1], W.raw_dt[f + 1], W.imu[f], W.w_imu, W.w_bias, r2, sh.J2[buf][f]);
       sh.r2[buf][f][0] = r2[0];
       sh.r2[buf][f][1] = r2[1];
       c += 0.5 * r2[0] * r2[0] + 0.5 * r2[1] * r2[1];
@@ -666,7 +728,13 @@ __device__ double factors_weight(const WinDesc& W, Shared& sh, int buf) {
 
 // Entry (a, b) of T G T^T and entry a of T g_b for the manifold pose block of a state
 // (T rows: [cp, sp, 0], [-sp, cp, 0], [0, 0, kappa], see solve.hip::to_param).
-__device__ __forceinline__ void pose_T(const double* xp, double T[3][3]) {
+__device__ __forceinline__ void pose_T(const double* xp, double T[3][3], int vec) {
+  if (vec) {  // (pos, rot) blocks: the base Jacobian w.r.t. (tx, ty, theta) IS the block's Jacobian
+    T[0][0] = 1; T[0][1] = 0; T[0][2] = 0;
+    T[1][0] = 0; T[1][1] = 1; T[1][2] = 0;
+    T[2][0] = 0; T[2][1] = 0; T[2][2] = 1;
+    return;
+  }
   const double cp = xp[0], sp = xp[1];
   const double n2 = cp * cp + sp * sp;
   const double a = -sp / n2, b = cp / n2;
@@ -707,7 +775,7 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* rs
     const int j = sh.pose_of[a];
     if (j >= 0 && sh.pose_of[b] == j) {
       double T[3][3];
-      pose_T(sh.xs[buf][j], T);
+      pose_T(sh.xs[buf][j], T, W.vec);
       double B[10];
 #pragma unroll
       for (int i = 4; i < 10; ++i) B[i] = state_sum(sh, rsum, j, i);
@@ -751,7 +819,7 @@ __device__ void assemble(const WinDesc& W, Shared& sh, int buf, const double* rs
     const int j = sh.pose_of[a];
     if (j >= 0) {
       double T[3][3];
-      pose_T(sh.xs[buf][j], T);
+      pose_T(sh.xs[buf][j], T, W.vec);
       const int ia = a - sh.off_tan[j][0];
       g += T[ia][0] * state_sum(sh, rsum, j, 1) + T[ia][1] * state_sum(sh, rsum, j, 2) + T[ia][2] * state_sum(sh, rsum, j, 3);
     }
@@ -767,14 +835,25 @@ __device__ void plus_states(const WinDesc& W, Shared& sh, int src, int dst, cons
     const int j = lane;
     const double* x = sh.xs[src][j];
     double* y = sh.xs[dst][j];
-    if (sh.off_tan[j][0] >= 0) {
+    if (sh.off_tan[j][0] >= 0 && W.vec) {  // plain addition on pos and rot; cos / sin follow
+      y[2] = x[2] + sign * vec[sh.off_tan[j][0]];
+      y[3] = x[3] + sign * vec[sh.off_tan[j][0] + 1];
+      const double rot = x[10] + sign * vec[sh.off_tan[j][0] + 2];
+      y[10] = rot;
+      double sr, cr;
+      sincos(rot, &sr, &cr);
+      y[0] = cr;
+      y[1] = sr;
+    } else if (sh.off_tan[j][0] >= 0) {
       const double d[3] = {sign * vec[sh.off_tan[j][0]], sign * vec[sh.off_tan[j][0] + 1], sign * vec[sh.off_tan[j][0] + 2]};
       double e[4];
       se2_exp(d, e);
       se2_mul(x, e, y);
+      y[10] = x[10];
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = x[i];
+      y[10] = x[10];
     }
     y[4] = x[4] + (sh.off_tan[j][1] >= 0 ? sign * vec[sh.off_tan[j][1]] : 0.0);
     y[5] = x[5] + (sh.off_tan[j][1] >= 0 ? sign * vec[sh.off_tan[j][1] + 1] : 0.0);
@@ -793,11 +872,20 @@ __device__ double ambient_sq(const WinDesc& W, const Shared& sh, int a, int b, i
     const int lo[5] = {0, 4, 6, 7, 9}, sz[5] = {4, 2, 1, 2, 1};
 #pragma unroll
     for (int blk = 0; blk < 5; ++blk)
-      if (sh.off_amb[j][blk] >= 0)
+      if (sh.off_amb[j][blk] >= 0) {
+        if (blk == 0 && W.vec) {  // ambient elements of the (pos, rot) blocks
+          const int el[3] = {2, 3, 10};
+          for (int e = 0; e < 3; ++e) {
+            const double d = sh.xs[a][j][el[e]] - (b >= 0 ? sh.xs[b][j][el[e]] : 0.0);
+            v += d * d;
+          }
+          continue;
+        }
         for (int e = 0; e < sz[blk]; ++e) {
           const double d = sh.xs[a][j][lo[blk] + e] - (b >= 0 ? sh.xs[b][j][lo[blk] + e] : 0.0);
           v += d * d;
         }
+      }
   }
   return wave_sum(v);
 }
@@ -1219,7 +1307,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
             wave_fence();
             double m = 0.0;
             if (lane <= S) {
-              for (int e = 0; e < ST_STRIDE; ++e) {
+              for (int e = W.vec ? 2 : 0; e < ST_STRIDE - 1; ++e) {  // vector form: [0], [1] are cos / sin of the parameter [10]
                 const double d = fabs(sh.xs[p][lane][e] - sh.xs[1 - p][lane][e]);
                 m = d > m ? d : m;
               }

@@ -375,13 +375,14 @@ def window_params(motion_sqrtI_diag=(1, 1, 1, 1, 3, 0.1, 20, 60), covariance_sca
     return wp
 
 
-def predict_state(last, stamp):
-    """Matcher::predictTransform (constant-velocity prediction of the next State)."""
+def predict_state(last, stamp, parameterization=_capi.PARAM_MANIFOLD):
+    """Matcher::predictTransform (constant-velocity prediction of the next State); PARAM_VECTOR = the (pos, rot) form the
+    reference takes when optimize_on_manifold is false."""
     a = np.array([last], dtype=STATE_DTYPE)
     out = np.zeros(1, dtype=STATE_DTYPE)
-    rc = _capi.load().randt_predict_state(_dptr(a), float(stamp), _dptr(out))
+    rc = _capi.load().randt_predict_state_param(_dptr(a), float(stamp), int(parameterization), _dptr(out))
     if rc:
-        raise RandtError(rc, "randt_predict_state")
+        raise RandtError(rc, "randt_predict_state_param")
     return out[0]
 
 

@@ -118,8 +118,8 @@ class HipBackend:
         return dst
 
     # ---- matcher
-    def predict(self, state, stamp):
-        return host.predict_state(state, stamp)
+    def predict(self, state, stamp, vector=False):
+        return host.predict_state(state, stamp, host._capi.PARAM_VECTOR if vector else host._capi.PARAM_MANIFOLD)
 
     # ---- loop closure + back end (slam.py)
     def register_pair(self, sub_idx, scan_idx, mp, guess4):
@@ -164,6 +164,7 @@ class Odometry:
         self.submap_size_poses = p["submap_size_poses"]
         self.submap_overlap = p["submap_overlap"]
         self.fix_submap_handover = bool(p.get("fix_submap_handover", False))   # False = the reference's behaviour
+        self.vector = int(getattr(matcher_params, "parameterization", 0)) == 2     # optimize_on_manifold: false -> (pos, rot) blocks
         self.current_submap = backend.new_submap()
         self.last_submap_transformed = None
         self.trajectory = []                                          # list of STATE_DTYPE scalars
@@ -239,7 +240,7 @@ class Odometry:
     def _process(self, scan, stamp):
         b = self.b
         if b.submap_cells(self.current_submap) > 0:
-            self.trajectory.append(b.predict(self.trajectory[-1], stamp))                 # :125
+            self.trajectory.append(b.predict(self.trajectory[-1], stamp, self.vector))    # :125 (predict / predictSE2 by optimize_on_manifold)
             self.map_window.append(scan)                                                  # :130
             self._ref(scan)
             fixed = [self.current_submap]

@@ -113,8 +113,8 @@ class OracleBackend:
         self.subs[self._next] = m
         return self._next
 
-    def predict(self, state, stamp):
-        return po.predict_state(np.asarray(state).astype(po.STATE_DTYPE), stamp)
+    def predict(self, state, stamp, vector=False):
+        return po.predict_state(np.asarray(state).astype(po.STATE_DTYPE), stamp, vector=vector)
 
     def register_window(self, fixed_h, moving_h, states, mp, wp, trans4):
         from test_gpu_window import to_oracle_wp

@@ -80,9 +80,10 @@ def test_predict_state_matches_oracle(built):
             assert np.allclose(a[f], b[f], rtol=0, atol=1e-15), f
 
 
-def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=None):
+def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=None, param=R.PARAM_MANIFOLD):
     torch, ctx = drive["torch"], drive["ctx"]
-    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3, **(mp_over or {}))
+    vec = param == R.PARAM_VECTOR
+    mp = R.default_matcher_params(parameterization=param, gnc_steps=3, **(mp_over or {}))
     wp = R.window_params(use_imu=use_imu, const_vel=const_vel)
     op, owp = to_oracle_params(mp), to_oracle_wp(wp)
     truth, dt = drive["truth"], drive["dt"]
@@ -93,8 +94,10 @@ def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=Non
     imu_all = []
     dev_trace = torch.zeros(3 * 512 + 1, dtype=torch.float64, device="cuda:0")
     for i in range(1, len(truth)):
-        gs.append(R.predict_state(gs[-1], i * dt))
-        os_.append(po.predict_state(os_[-1], i * dt))
+        gs.append(R.predict_state(gs[-1], i * dt, param))
+        os_.append(po.predict_state(os_[-1], i * dt, vector=vec))
+        for f in gs[-1].dtype.names:
+            assert np.allclose(gs[-1][f], os_[-1][f], rtol=0, atol=1e-12), f
         imu_all.append(synth.wrap_angle(truth[i][2] - truth[i - 1][2]) + 0.002)
         S = min(len(gs) - 1, 3)
         win = list(range(i - S + 1, i + 1))                       # scan indices of the optimised states
@@ -116,6 +119,8 @@ def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=Non
             assert np.isclose(g_states[j]["rot_vel"], o_states[j]["rot_vel"], atol=1e-6)
             assert np.allclose(g_states[j]["lin_acc"], o_states[j]["lin_acc"], atol=1e-5)
             assert np.isclose(g_states[j]["imu_bias"], o_states[j]["imu_bias"], atol=1e-7)
+            g = g_states[j]   # both representations are in sync on return (local_fuser.cpp:141-150)
+            assert np.allclose(g["pose"], [np.cos(g["rot"]), np.sin(g["rot"]), g["pos"][0], g["pos"][1]], atol=1e-12)
         assert np.allclose(gtrans, otrans, atol=1e-7)
         assert g_res["n_residuals"] == o_st["n_residuals"] and g_res["gnc_solves"] == o_st["n_solves"]
         assert g_res["iterations"] == o_st["n_iterations"] and g_res["termination"] == o_st["termination"]
@@ -160,3 +165,64 @@ def test_window_rejection_gate(drive):
     states = np.array([prev, R.predict_state(prev, dt)], dtype=R.STATE_DTYPE)
     out, trans, rej, res = R.register_window(ctx, drive["sub"], [0], drive["smaps"], [1], states, mp, wp, synth.pose3_to_pose4(truth[0]))
     assert rej and np.array_equal(out[1]["pose"], out[0]["pose"]) and np.all(out[1]["lin_vel"] == 0) and np.array_equal(trans, out[0]["pose"])
+
+
+# ---- optimize_on_manifold: false -- parameter blocks pos[2], rot[1] (ndt_matcher.cpp:290-313, 330-335), MotionModelFactor /
+# RotationalResidual / NDTFrameToMap{,Intensity}FactorResidual on them, vector-form prediction
+def test_vector_predict_state_matches_oracle(built):
+    rng = np.random.default_rng(1)
+    for _ in range(10):
+        th = rng.uniform(-3, 3)
+        st = R.make_state([np.cos(th), np.sin(th), rng.normal(), rng.normal()], lin_vel=rng.normal(0, 1, 2), rot_vel=rng.normal(0, .5),
+                          lin_acc=rng.normal(0, 1, 2), imu_bias=0.1, stamp=5.0)
+        stamp = 5.0 + rng.choice([0.0, 0.1, 0.25, 1.0])
+        a = R.predict_state(st, stamp, R.PARAM_VECTOR)
+        b = po.predict_state(st.astype(po.STATE_DTYPE), stamp, vector=True)
+        for f in a.dtype.names:
+            assert np.allclose(a[f], b[f], rtol=0, atol=1e-15), f
+
+
+def test_vector_window_drive_matches_oracle(drive):
+    gs = _run_drive(drive, param=R.PARAM_VECTOR)
+    assert abs(np.hypot(*gs[-1]["lin_vel"]) - 1.0) < 0.15
+
+
+def test_vector_window_overlap_imu_and_constant_acceleration(drive):
+    _run_drive(drive, n_fixed=2, param=R.PARAM_VECTOR)
+    _run_drive(drive, use_imu=1, param=R.PARAM_VECTOR)
+    _run_drive(drive, const_vel=0, param=R.PARAM_VECTOR)
+
+
+def test_vector_window_two_dimensional_and_general_loss(drive):
+    _run_drive(drive, param=R.PARAM_VECTOR, mp_over=dict(use_intensity=0))
+    _run_drive(drive, param=R.PARAM_VECTOR, mp_over=dict(loss_alpha=-1.0))
+
+
+def test_vector_odometry_drive_matches_oracle_loop(built):
+    """The processScan call pattern with optimize_on_manifold: false end to end (vector prediction, vector window, keyframe
+    merges, a submap roll-over) against the same loop on the oracle."""
+    import torch
+
+    from randt_slam_amd import odometry
+    from oracle_backend import OracleBackend
+
+    world = synth.make_world()
+    n_scans, dt = 40, 0.25
+    traj = synth.make_trajectory(3200, n_scans, step=0.25)
+    scans = [synth.make_scan(world, traj[i], 9000 + i) for i in range(n_scans)]
+    small = dict(submap_size_poses=24, submap_overlap=8)
+    mp = R.default_matcher_params(parameterization=R.PARAM_VECTOR, gnc_steps=3)
+    wp = R.window_params()
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    gpu = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, wp, small)
+    cpu = odometry.Odometry(OracleBackend(), mp, wp, small)
+    assert gpu.vector and cpu.vector
+    origin_inv = synth.se2_inv3(traj[0])
+    for i in range(n_scans):
+        pg = gpu.process_scan(scans[i], i * dt)
+        pc = cpu.process_scan(scans[i], i * dt)
+        assert np.abs(pg[2:] - pc[2:]).max() <= 1e-4 and abs(synth.wrap_angle(np.arctan2(pg[1], pg[0]) - np.arctan2(pc[1], pc[0]))) <= 1e-4, (i, pg, pc)
+        rel = synth.se2_mul3(origin_inv, traj[i])
+        est = synth.pose4_to_pose3(pg)
+        assert np.all(np.abs(est[:2] - rel[:2]) < 0.25) and abs(synth.wrap_angle(est[2] - rel[2])) < 0.08, (i, est, rel)
+    assert gpu.n_finished_submaps == cpu.n_finished_submaps == 1 and gpu.n_rejected == cpu.n_rejected == 0

@@ -150,3 +150,118 @@ def test_rejection_gate(built):
     assert rc == 1                                           # "Rejected new estimated transform!"
     assert np.array_equal(out[1]["pose"], out[0]["pose"]) and np.all(out[1]["lin_vel"] == 0) and out[1]["rot_vel"] == 0
     assert np.array_equal(trans, out[0]["pose"])
+
+
+# ---------------------------------------------------------------- (pos[2], rot) parameterisation (optimize_on_manifold: false)
+def perturb_vec(st, blk, e, eps):
+    """perturb coordinate e of block blk of the vector representation (0: pos2 + rot1, 1 v2, 2 w1, 3 a2, 4 b1)."""
+    s = st.copy()
+    if blk == 0:
+        if e < 2:
+            s["pos"][e] += eps
+        else:
+            s["rot"] += eps
+    elif blk == 1:
+        s["lin_vel"][e] += eps
+    elif blk == 2:
+        s["rot_vel"] += eps
+    elif blk == 3:
+        s["lin_acc"][e] += eps
+    else:
+        s["imu_bias"] += eps
+    return s
+
+
+@pytest.mark.parametrize("dt", [0.25, 0.05, 1.0])
+def test_vector_motion_factor_jacobian_fd(built, dt):
+    """MotionModelFactor on (pos, rot) blocks (ceres_residuals.h:554-619): analytic Jacobian vs central differences, full
+    square-root information, rotations far from 0 (NormalizeAngle wraps)."""
+    rng = np.random.default_rng(int(dt * 100) + 7)
+    sqrtI = np.diag([1, 1, 1, 1, 3, 0.1, 20, 60.0]) * 25 + rng.normal(0, 0.1, (8, 8))
+    cols = [(0, 0, 0), (0, 0, 1), (0, 0, 2), (0, 1, 0), (0, 1, 1), (0, 2, 0), (0, 3, 0), (0, 3, 1),
+            (1, 0, 0), (1, 0, 1), (1, 0, 2), (1, 1, 0), (1, 1, 1), (1, 2, 0), (1, 3, 0), (1, 3, 1)]
+    for trial in range(5):
+        x0, x1 = rand_state(rng, 10.0), rand_state(rng, 10.0 + dt)
+        if trial == 3:
+            x0["rot"], x1["rot"] = 3.0, -3.1          # the difference wraps
+        r, J = po.motion_residual(x0, x1, sqrtI, vector=True)
+        eps = 1e-6
+        for c, (which, blk, e) in enumerate(cols):
+            a = (perturb_vec(x0, blk, e, eps), x1) if which == 0 else (x0, perturb_vec(x1, blk, e, eps))
+            b = (perturb_vec(x0, blk, e, -eps), x1) if which == 0 else (x0, perturb_vec(x1, blk, e, -eps))
+            fd = (po.motion_residual(*a, sqrtI, False, vector=True)[0] - po.motion_residual(*b, sqrtI, False, vector=True)[0]) / (2 * eps)
+            assert np.allclose(J[:, c], fd, rtol=2e-6, atol=2e-5), (trial, c, J[:, c], fd)
+    if dt >= 0.2:   # a perfect constant-velocity pair has zero residual
+        x0 = rand_state(rng, 0.0); x0["lin_acc"] = 0
+        x1 = po.predict_state(x0, dt, vector=True)
+        r, _ = po.motion_residual(x0, x1, sqrtI, vector=True)
+        assert np.allclose(r, 0, atol=1e-9)
+        assert np.allclose(x1["pose"], [np.cos(x1["rot"]), np.sin(x1["rot"]), *x1["pos"]])   # Sophus::SE2d(rot, pos)
+
+
+def test_vector_imu_factor_and_prediction(built):
+    rng = np.random.default_rng(11)
+    x0, x1 = rand_state(rng, 1.0), rand_state(rng, 1.25)
+    r, J = po.imu_residual(x0, x1, 0.03, 64.0, 6e5, vector=True)
+    eps = 1e-6
+    cols = [(0, 0, 0), (0, 0, 1), (0, 0, 2), (1, 0, 0), (1, 0, 1), (1, 0, 2), (0, 4, 0), (1, 4, 0)]
+    for c, (which, blk, e) in enumerate(cols):
+        a = (perturb_vec(x0, blk, e, eps), x1) if which == 0 else (x0, perturb_vec(x1, blk, e, eps))
+        b = (perturb_vec(x0, blk, e, -eps), x1) if which == 0 else (x0, perturb_vec(x1, blk, e, -eps))
+        fd = (po.imu_residual(*a, 0.03, 64.0, 6e5, False, vector=True)[0] - po.imu_residual(*b, 0.03, 64.0, 6e5, False, vector=True)[0]) / (2 * eps)
+        assert np.allclose(J[:, c], fd, rtol=1e-5, atol=1e-3), (c, J[:, c], fd)
+    # the two predictions differ only in the integration rule (mid-point heading vs SE(2) exponential): identical without rotation
+    s = po.make_state([np.cos(0.7), np.sin(0.7), 1.0, -2.0], lin_vel=(1.2, 0.1), rot_vel=0.0, stamp=0.0)
+    a, b = po.predict_state(s, 0.25), po.predict_state(s, 0.25, vector=True)
+    assert np.allclose(a["pose"], b["pose"], atol=1e-12) and np.allclose(a["pos"], b["pos"], atol=1e-12)
+    s["rot_vel"] = 0.4                     # with rotation: second-order difference only
+    a, b = po.predict_state(s, 0.25), po.predict_state(s, 0.25, vector=True)
+    assert np.abs(a["pos"] - b["pos"]).max() < 2e-4 and abs(a["rot"] - b["rot"]) < 1e-12
+    # dt clamp (:38) and zeroed acceleration (ndt_matcher.cpp:26) like the SE(2) form
+    s2 = po.make_state([1, 0, 0, 0], lin_vel=(1.0, 0.0), lin_acc=(5.0, 5.0), stamp=3.0)
+    p = po.predict_state(s2, 3.0, vector=True)
+    assert np.allclose(p["pos"], [0.2, 0]) and np.allclose(p["lin_vel"], [1, 0]) and np.allclose(p["lin_acc"], 0)
+
+
+def test_vector_window_reduces_to_the_vector_pair_problem(built):
+    """S = 1 and a null motion factor: the (pos, rot) window problem IS the vector pair problem (same traces)."""
+    sub, scans, truth, dt = _window_setup(n_scans=2)
+    g4 = synth.pose3_to_pose4(synth.perturb_pose(truth[1], 42, dt=0.1, dtheta_deg=1.0))
+    w = 5.0e4 / (scans[1].n_cells * 4)
+    prm = po.default_params(parameterization=po.PARAM_VECTOR, gnc_steps=3, loss_weight=w, parameter_tolerance=0.0)
+    rc, p_pair, cost, st_pair = po.register_pair(sub, scans[1], prm, g4)
+    wp = po.window_params(covariance_scaling_factor=0.0)
+    states = np.array([po.make_state(synth.pose3_to_pose4(truth[0]), stamp=0.0), po.make_state(g4, stamp=dt)], dtype=po.STATE_DTYPE)
+    rc, out, trans, st_win = po.register_window([sub], [scans[1]], states, prm, wp, g4)
+    assert rc == 0 and np.allclose(trans, p_pair, atol=1e-9)
+    assert np.allclose(st_win["trace_cost"], st_pair["trace_cost"], rtol=1e-9)
+    assert np.allclose(out[1]["pose"], [np.cos(out[1]["rot"]), np.sin(out[1]["rot"]), *out[1]["pos"]])
+
+
+def test_vector_window_drive_agrees_with_the_manifold_one(built):
+    """The same drive through both parameterisations: different iterates (Plus, prediction and motion residual differ at second
+    order), same optimum up to the solver's stopping tolerance, both near the truth."""
+    sub, scans, truth, dt = _window_setup()
+    wp = po.window_params()
+    v_true = np.array([0.25 / dt, 0.0])
+    finals = {}
+    for name, param, vec in (("manifold", po.PARAM_MANIFOLD, False), ("vector", po.PARAM_VECTOR, True)):
+        prm = po.default_params(parameterization=param, gnc_steps=3)
+        states = [po.make_state(synth.pose3_to_pose4(truth[0]), lin_vel=v_true * 0.8, rot_vel=0.0, stamp=0.0)]
+        window, trans = [], synth.pose3_to_pose4(truth[0])
+        for i in range(1, len(scans)):
+            states.append(po.predict_state(states[-1], i * dt, vector=vec))
+            window.append(scans[i])
+            S = min(len(states) - 1, 3)
+            rc, out, trans, st = po.register_window([sub], window[-S:], np.array(states[-S - 1:], dtype=po.STATE_DTYPE), prm, wp, trans)
+            assert rc == 0 and st["termination"] in (1, 2, 3)
+            for j in range(S + 1):
+                states[len(states) - S - 1 + j] = out[j]
+                o = out[j]
+                assert np.allclose(o["pose"], [np.cos(o["rot"]), np.sin(o["rot"]), *o["pos"]], atol=1e-12)   # both representations in sync
+            est = synth.pose4_to_pose3(trans)
+            assert np.all(np.abs(est[:2] - truth[i][:2]) < 0.08) and abs(synth.wrap_angle(est[2] - truth[i][2])) < 0.03, (name, i, est, truth[i])
+            if len(window) >= 3:
+                window.pop(0)
+        finals[name] = synth.pose4_to_pose3(trans)
+    assert np.abs(finals["manifold"] - finals["vector"]).max() < 5e-3
