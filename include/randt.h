@@ -68,7 +68,15 @@ typedef struct randt_cluster_params {
   float max_range;
 } randt_cluster_params;
 
-enum { RANDT_PARAM_MANIFOLD = 0, RANDT_PARAM_AMBIENT4 = 1, RANDT_PARAM_VECTOR = 2 };
+/* Parameter blocks the NDT residuals hang on (ndt_matcher.cpp:217-246, 290-313):
+ *   MANIFOLD  SE(2) pose with Sophus' manifold             (optimize_on_manifold: true; the window solve's default)
+ *   AMBIENT4  the un-manifolded [c, s, tx, ty] block estimateLoopConstraint really optimises in that configuration
+ *   VECTOR    pos[2] + rot[1], autodiff functors           (optimize_on_manifold: false)
+ *   ANALYTIC  pos[2] + rot[1] with the reference's hand-written functors NDTFrameToMap{,Intensity}FactorResidualAnalytic
+ *             (use_analytic_expressions_for_optimization: true; ceres_residuals.h:207-305).  Their rotation Jacobian is not the
+ *             derivative for theta != 0 and is reproduced as written, because Ceres iterates with exactly that
+ *             row; the analytic motion / IMU factors (:794-889, :372-419) have correct Jacobians = the VECTOR factors. */
+enum { RANDT_PARAM_MANIFOLD = 0, RANDT_PARAM_AMBIENT4 = 1, RANDT_PARAM_VECTOR = 2, RANDT_PARAM_ANALYTIC = 3 };
 
 enum {
   RANDT_TERM_NONE = 0,
@@ -420,7 +428,7 @@ int randt_predict_state_param(const randt_state* last, double stamp, int paramet
  * pair registration; whole LM loop on the device.  h_states in/out (both pose representations are
  * synchronised on return, cf. local_fuser.cpp:141-150); h_trans4 in: prior pose for the rejection
  * gate (ndt_matcher.cpp:339-340,411-422), out: newest pose.  *rejected = 1 if the gate fired.
- * mp->parameterization: RANDT_PARAM_MANIFOLD (optimize_on_manifold: true, the shipped configuration: SE(2) pose blocks with
+ * mp->parameterization (RANDT_PARAM_ANALYTIC = VECTOR with the analytic NDT functor): RANDT_PARAM_MANIFOLD (optimize_on_manifold: true, the shipped configuration: SE(2) pose blocks with
  * Sophus' manifold, MotionModelFactorSE2 / RotationalResidualSE2) or RANDT_PARAM_VECTOR (optimize_on_manifold: false: parameter
  * blocks pos[2] and rot[1] with plain addition, MotionModelFactor :554-619 / RotationalResidual :307-336 /
  * NDTFrameToMap{,Intensity}FactorResidual :421-451,486-518; pos / rot of the states are the variables, the association still

@@ -624,7 +624,6 @@ class Matcher {
     mp.loss_alpha = parameters_.loss_function_convexity;
     mp.lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
     mp.use_intensity = use_intensity_as_dimension ? 1 : 0;
-    if (refuse_analytic(fixed_ndt.context()->get())) return failed_value();
     double min_cost = 0.0;
     const int rc = randt_search_global(fixed_ndt.context()->get(), fixed_ndt.handle(), 0, moving_ndt.handle(), 0, &mp, &csm, scale,
                                        search_window_size_linear, search_window_size_angular, trans.data(), &min_cost, nullptr);
@@ -689,7 +688,6 @@ class Matcher {
                               const randt_window_params& wp, randt_result* stats = nullptr) {
     if (trajectory.size() < 2) return;
     const size_t S = std::min(trajectory.size() - 1, static_cast<size_t>(wp.smoothing_steps > 0 ? wp.smoothing_steps : parameters_.smoothing_steps));  // :343
-    if (refuse_analytic(ctx)) return;
     randt_matcher_params mp;
     randt_matcher_params_default(&mp);
     mp.loss_scale = mp.mu_scale = parameters_.loss_function_scale;
@@ -701,7 +699,7 @@ class Matcher {
     mp.lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
     mp.use_intensity = parameters_.use_intensity_as_dimension ? 1 : 0;
     // optimize_on_manifold: false -> the (pos[2], rot) problem of ndt_matcher.cpp:290-313,330-335
-    mp.parameterization = parameters_.optimize_on_manifold ? RANDT_PARAM_MANIFOLD : RANDT_PARAM_VECTOR;
+    mp.parameterization = analytic() ? RANDT_PARAM_ANALYTIC : (parameters_.optimize_on_manifold ? RANDT_PARAM_MANIFOLD : RANDT_PARAM_VECTOR);
     std::vector<randt_state> st(S + 1);
     for (size_t j = 0; j <= S; ++j) st[j] = toAbi(trajectory.end()[-(long)(S + 1) + (long)j]);
     std::vector<int32_t> mv(moving_slots.end() - (long)S, moving_slots.end());  // moving_ndts.end()[-i], i = S..1
@@ -751,18 +749,20 @@ class Matcher {
 
  private:
   // `use_analytic_expressions_for_optimization: true` selects the reference's hand-written functors
-  // (ceres_residuals.h:207-305), whose rotation Jacobian is wrong for theta != 0: their iterates are not
-  // reproduced here, and computing the autodiff answer instead would be a silent behaviour change -- so the call is
-  // refused (RANDT_ERR_UNSUPPORTED in last_status(), outputs untouched).  No shipped configuration sets the flag.
-  bool refuse_analytic(randt_ctx* ctx) const {
-    if (!parameters_.use_analytic_expressions_for_optimization) return false;
-    std::cout << "WARNING: use_analytic_expressions_for_optimization is not supported (the reference's analytic Jacobian is "
-                 "incorrect for rotated poses and is not reproduced); set it to false" << std::endl;
-    facade_check(RANDT_ERR_UNSUPPORTED, "use_analytic_expressions_for_optimization", ctx);
-    return true;
+  // (ceres_residuals.h:207-305, 372-419, 794-889) on (pos, rot) blocks whatever optimize_on_manifold says
+  // (ndt_matcher.cpp:225-231, 330-335).  The NDT functors' rotation Jacobian is not the derivative for theta != 0 (SURVEY
+  // a12); it is reproduced as written (RANDT_PARAM_ANALYTIC), because those are the iterates the reference takes.  A warning
+  // says so once per Matcher.
+  bool analytic() const {
+    if (parameters_.use_analytic_expressions_for_optimization && !warned_analytic_) {
+      std::cout << "WARNING: use_analytic_expressions_for_optimization: the reference's analytic NDT Jacobian is inexact for rotated "
+                   "poses; reproduced as written" << std::endl;
+      warned_analytic_ = true;
+    }
+    return parameters_.use_analytic_expressions_for_optimization;
   }
   bool loop_params(int max_gnc_steps, bool use_intensity_as_dimension, double scale, randt_matcher_params* mp, randt_ctx* ctx) const {
-    if (refuse_analytic(ctx)) return false;
+    (void)ctx;
     randt_matcher_params_default(mp);
     mp->loss_scale = scale;                              // BarronLoss(scale, ...)            (:479)
     mp->mu_scale = parameters_.loss_function_scale;      // gnc_mu uses the odometry scale    (:475)
@@ -774,8 +774,9 @@ class Matcher {
     mp->n_neighbours = parameters_.n_results_kd_lookup;
     mp->lookup_mahalanobis = parameters_.lookup_mahalanobis ? 1 : 0;
     mp->use_intensity = use_intensity_as_dimension ? 1 : 0;
-    // optimize_on_manifold = true: the residuals hang on an un-manifolded 4-vector; false: (pos, rot)
-    mp->parameterization = parameters_.optimize_on_manifold ? RANDT_PARAM_AMBIENT4 : RANDT_PARAM_VECTOR;
+    // optimize_on_manifold = true: the residuals hang on an un-manifolded 4-vector; false: (pos, rot); the analytic
+    // flag: (pos, rot) with the hand-written functors (ndt_matcher.cpp:428-433: no manifold either way)
+    mp->parameterization = analytic() ? RANDT_PARAM_ANALYTIC : (parameters_.optimize_on_manifold ? RANDT_PARAM_AMBIENT4 : RANDT_PARAM_VECTOR);
     return true;
   }
   // internal batches the deque overload of estimateTransformCeres copies the window's maps into
@@ -810,6 +811,7 @@ class Matcher {
   }
 
   NDTMatcherParameters parameters_;
+  mutable bool warned_analytic_ = false;
   std::vector<double> imu_constraints_;
   std::shared_ptr<Context> stage_ctx_;
   randt_maps *stage_fixed_ = nullptr, *stage_moving_ = nullptr;

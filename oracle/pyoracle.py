@@ -19,7 +19,7 @@ assert CELL_DTYPE.itemsize == 48
 
 TRACE_MAX = 4096
 
-PARAM_MANIFOLD, PARAM_AMBIENT4, PARAM_VECTOR = 0, 1, 2
+PARAM_MANIFOLD, PARAM_AMBIENT4, PARAM_VECTOR, PARAM_ANALYTIC = 0, 1, 2, 3
 LINSOLVE_QR, LINSOLVE_NORMAL = 0, 1
 
 

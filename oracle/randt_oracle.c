@@ -776,6 +776,15 @@ double orc_ndt_residual(int d, int parameterization, const double* pose4, const 
       jac[1] = dtheta * (cp / n2);
       jac[2] = q[0] / r;
       jac[3] = q[1] / r;
+    } else if (parameterization == ORC_PARAM_ANALYTIC) {
+      /* NDTFrameToMap{,Intensity}FactorResidualAnalytic (ceres_residuals.h:207-305), AS WRITTEN: the second term of the rotation
+       * Jacobian is  d^T C^-1 R Sm (R J) C^-1 d  (:245, :295) where  -d^T C^-1 (R J) Sm R^T C^-1 d  would be correct -- equal only
+       * at theta = 0.  With u = R^T q and w = R J q:  (u^T J m + (Sm u)^T w) / r.  Reproduced because
+       * use_analytic_expressions_for_optimization: true makes Ceres iterate with exactly this row. */
+      const double w0 = c * (-q[1]) - s * q[0], w1 = s * (-q[1]) + c * q[0];
+      jac[0] = q[0] / r;
+      jac[1] = q[1] / r;
+      jac[2] = ((u[1] * mm[0] - u[0] * mm[1]) + (Su0 * w0 + Su1 * w1)) / r;
     } else {
       jac[0] = q[0] / r;
       jac[1] = q[1] / r;
@@ -1082,7 +1091,7 @@ typedef struct pair_user {
 } pair_user;
 
 static void x_to_pose4(const pair_user* u, const double* x, double p4[4]) {
-  if (u->parameterization == ORC_PARAM_VECTOR) {
+  if (u->parameterization == ORC_PARAM_VECTOR || u->parameterization == ORC_PARAM_ANALYTIC) {
     /* NormalizeAngle(rot) then cos/sin: residual only depends on theta mod 2pi */
     p4[0] = cos(x[2]);
     p4[1] = sin(x[2]);
@@ -1241,11 +1250,12 @@ int orc_solve_pair(const orc_map* fixed, const orc_map* moving, const int32_t* c
   P.eval = pair_eval;
   P.plus = pair_plus;
   P.n_res = n;
-  P.n_ambient = (p->parameterization == ORC_PARAM_VECTOR) ? 3 : 4;
+  const int vec_like = p->parameterization == ORC_PARAM_VECTOR || p->parameterization == ORC_PARAM_ANALYTIC; /* (pos, rot) blocks */
+  P.n_ambient = vec_like ? 3 : 4;
   P.n_tangent = (p->parameterization == ORC_PARAM_AMBIENT4) ? 4 : 3;
 
   double x[4];
-  if (p->parameterization == ORC_PARAM_VECTOR) {
+  if (vec_like) {
     double xi[3];
     orc_se2_log(pose4, xi); /* two_representation_state.rot = trans.log()(2) (ndt_matcher.cpp:438-439) */
     x[0] = pose4[2]; x[1] = pose4[3]; x[2] = xi[2];
@@ -1282,7 +1292,7 @@ int orc_solve_pair(const orc_map* fixed, const orc_map* moving, const int32_t* c
     st->termination = term;
     st->final_cost = final_cost;
   }
-  if (p->parameterization == ORC_PARAM_VECTOR) {
+  if (vec_like) {
     /* Sophus::SE2d(rot, pos) (ndt_matcher.cpp:486) */
     double c = cos(x[2]), s = sin(x[2]);
     so2_normalize(&c, &s);
@@ -1631,6 +1641,7 @@ void orc_imu_residual_vec(const orc_state* x0, const orc_state* x1, double imu_r
 
 typedef struct win_user {
   int vec;                      /* (pos[2], rot) parameter blocks instead of the SE(2) manifold (optimize_on_manifold: false) */
+  int analytic;                 /* ... with the reference's hand-written NDT Jacobian (use_analytic_expressions_for_optimization) */
   int S, F, d, k;               /* states 0..S (0 = oldest, pose constant), fixed maps */
   int const_vel, use_imu;
   orc_state base[8];            /* constant parts (stamps, oldest pose, constant blocks) */
@@ -1775,7 +1786,7 @@ static int win_eval(void* user, const double* x, double* cost, double* residuals
       double jl[4];
       /* vector form: NDTFrameToMap{,Intensity}FactorResidual on (pos, rot) (ceres_residuals.h:421-451, 486-518) */
       const double pv[4] = {cos(st[j].rot), sin(st[j].rot), st[j].pos[0], st[j].pos[1]};
-      double r = orc_ndt_residual(d, u->vec ? ORC_PARAM_VECTOR : ORC_PARAM_MANIFOLD, u->vec ? pv : st[j].pose, u->mm + (size_t)ndt_at * d,
+      double r = orc_ndt_residual(d, u->vec ? (u->analytic ? ORC_PARAM_ANALYTIC : ORC_PARAM_VECTOR) : ORC_PARAM_MANIFOLD, u->vec ? pv : st[j].pose, u->mm + (size_t)ndt_at * d,
                                   u->mc + (size_t)ndt_at * d * d, u->fm + (size_t)ndt_at * d, u->fc + (size_t)ndt_at * d * d, jac ? jl : NULL);
       if (!isfinite(r)) return 0;
       const double sq = r * r;
@@ -1824,8 +1835,11 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
 
   win_user u;
   memset(&u, 0, sizeof(u));
-  if (p->parameterization != ORC_PARAM_MANIFOLD && p->parameterization != ORC_PARAM_VECTOR) return -1;
-  u.vec = p->parameterization == ORC_PARAM_VECTOR;
+  if (p->parameterization != ORC_PARAM_MANIFOLD && p->parameterization != ORC_PARAM_VECTOR && p->parameterization != ORC_PARAM_ANALYTIC) return -1;
+  u.vec = p->parameterization != ORC_PARAM_MANIFOLD;
+  /* use_analytic_expressions_for_optimization: MotionModelFactorAnalytic / RotationalResidualAnalytic (ceres_residuals.h:794-889,
+   * 372-419) are the vector factors with hand-written -- correct -- Jacobians; only the NDT functor's rotation column differs */
+  u.analytic = p->parameterization == ORC_PARAM_ANALYTIC;
   u.S = S; u.F = n_fixed; u.d = d; u.k = k;
   u.const_vel = wp->use_constant_velocity_model;
   u.use_imu = wp->use_imu && imu;

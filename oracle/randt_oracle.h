@@ -105,7 +105,7 @@ void orc_barron_scaled(double s, double scale_a, double alpha, double mu, double
 
 /* ---------------------------------------------------------------- registration ------------- */
 
-enum { ORC_PARAM_MANIFOLD = 0, ORC_PARAM_AMBIENT4 = 1, ORC_PARAM_VECTOR = 2 };
+enum { ORC_PARAM_MANIFOLD = 0, ORC_PARAM_AMBIENT4 = 1, ORC_PARAM_VECTOR = 2, ORC_PARAM_ANALYTIC = 3 /* VECTOR blocks + the reference's analytic NDT functors */ };
 enum { ORC_LINSOLVE_QR = 0, ORC_LINSOLVE_NORMAL = 1 };
 enum {
   ORC_TERM_CONVERGENCE_FUNCTION = 1,

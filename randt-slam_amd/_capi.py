@@ -22,7 +22,7 @@ RESULT_DTYPE = np.dtype(
 )
 assert CELL_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 64
 
-PARAM_MANIFOLD, PARAM_AMBIENT4, PARAM_VECTOR = 0, 1, 2
+PARAM_MANIFOLD, PARAM_AMBIENT4, PARAM_VECTOR, PARAM_ANALYTIC = 0, 1, 2, 3
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NODEVICE = range(6)
 
 

@@ -738,7 +738,8 @@ static int check_matcher_params(randt_ctx* ctx, const randt_matcher_params* mp) 
   else if (!(isfinite(mp->min_lm_diagonal) && mp->min_lm_diagonal >= 0.0) || !pos(mp->max_lm_diagonal) || mp->min_lm_diagonal > mp->max_lm_diagonal)
     bad = "LM diagonal bounds";
   else if (!isfinite(mp->min_relative_decrease)) bad = "min_relative_decrease";
-  else if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_AMBIENT4 && mp->parameterization != RANDT_PARAM_VECTOR)
+  else if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_AMBIENT4 && mp->parameterization != RANDT_PARAM_VECTOR &&
+           mp->parameterization != RANDT_PARAM_ANALYTIC)
     bad = "unknown parameterization";
   if (bad) return randt_set_error(ctx, RANDT_ERR_INVALID, bad, hipSuccess);
   return RANDT_OK;
@@ -1286,7 +1287,7 @@ static double h_normalize_angle(double a) { return a - 2.0 * M_PI * floor((a + M
 int randt_predict_state_param(const randt_state* last, double stamp, int parameterization, randt_state* next) {
   if (!last || !next) return RANDT_ERR_INVALID;
   if (parameterization == RANDT_PARAM_MANIFOLD) return randt_predict_state(last, stamp, next);
-  if (parameterization != RANDT_PARAM_VECTOR) return RANDT_ERR_INVALID;
+  if (parameterization != RANDT_PARAM_VECTOR && parameterization != RANDT_PARAM_ANALYTIC) return RANDT_ERR_INVALID;  // (pos, rot) forms
   // predict(...) with last_state.lin_acc = 0 (ndt_matcher.cpp:26-41; ceres_residuals.h:91-123)
   const double raw_dt = stamp - last->stamp;
   const double dt = raw_dt > 0.2 ? raw_dt : 0.2;
@@ -1325,9 +1326,9 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   if (!ctx || !fixed || !moving || !h_fixed_idx || !h_moving_idx || !h_states || !mp || !wp || !h_trans4) return RANDT_ERR_INVALID;
   const int S = n_states - 1;
   if (S < 1 || S > 3 || n_fixed < 1 || n_fixed > 2) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..3 optimised states, 1..2 fixed maps", hipSuccess);
-  if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_VECTOR)
-    return randt_set_error(ctx, RANDT_ERR_INVALID, "window solve: parameterization must be RANDT_PARAM_MANIFOLD or RANDT_PARAM_VECTOR", hipSuccess);
-  const bool vec = mp->parameterization == RANDT_PARAM_VECTOR;
+  if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_VECTOR && mp->parameterization != RANDT_PARAM_ANALYTIC)
+    return randt_set_error(ctx, RANDT_ERR_INVALID, "window solve: parameterization must be RANDT_PARAM_MANIFOLD, _VECTOR or _ANALYTIC", hipSuccess);
+  const bool vec = mp->parameterization != RANDT_PARAM_MANIFOLD;
   if (mp->n_neighbours <= 0 || mp->n_neighbours > 8) return RANDT_ERR_INVALID;
   {
     const int prc = check_matcher_params(ctx, mp);
@@ -1347,6 +1348,7 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   memset(&W, 0, sizeof(W));
   W.S = S;
   W.vec = vec ? 1 : 0;
+  W.pad_ = mp->parameterization == RANDT_PARAM_ANALYTIC ? 1 : 0;  // the NDT functor's analytic rotation Jacobian (launch_solve_window picks the instantiation)
   W.k = k;
   W.d3 = mp->use_intensity ? 1 : 0;
   W.const_vel = wp->use_constant_velocity_model ? 1 : 0;

@@ -116,7 +116,7 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
 #define RANDT_WIN_MAX_TERMS 6
 struct WinDesc {
   int S, n_terms, n_tan, n_amb, use_imu, const_vel, k, d3;
-  int vec, pad_;  // (pos[2], rot) parameter blocks instead of the SE(2) manifold (optimize_on_manifold: false)
+  int vec, pad_;  // vec: (pos[2], rot) parameter blocks instead of the SE(2) manifold (optimize_on_manifold: false); pad_: 1 = RANDT_PARAM_ANALYTIC
   int term_state[RANDT_WIN_MAX_TERMS], term_moving[RANDT_WIN_MAX_TERMS], term_fixed[RANDT_WIN_MAX_TERMS];
   int off_tan[RANDT_WIN_MAX_STATES][5], off_amb[RANDT_WIN_MAX_STATES][5];  // pose, v, w, a, b; -1 = constant
   double sqrtI[64];

@@ -94,6 +94,10 @@ __device__ __forceinline__ void plus(const double* x, const double* d, double* x
   }
 }
 
+// RANDT_PARAM_VECTOR and RANDT_PARAM_ANALYTIC optimise the same (pos[2], rot) blocks; ANALYTIC only swaps the NDT functor's
+// rotation Jacobian for the reference's hand-written one (solve_math.h, residual_sq_v)
+__device__ __forceinline__ constexpr bool vec_like(int param) { return param == RANDT_PARAM_VECTOR || param == RANDT_PARAM_ANALYTIC; }
+
 // valid correspondences of one registration, compacted once into LDS: (moving index << 21) | fixed index
 constexpr int PAIR_CAP = 1024;
 constexpr int PAIR_SHIFT = 21;
@@ -114,7 +118,7 @@ struct Stage {
 template <int D, int PARAM>
 __device__ __forceinline__ void pass_pose(const double* x, double& c, double& s, double& tx, double& ty) {
 #pragma clang fp contract(off)
-  if (PARAM == RANDT_PARAM_VECTOR) {
+  if (vec_like(PARAM)) {
     c = cos(x[2]);
     s = sin(x[2]);
     tx = x[0];
@@ -146,7 +150,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   // one residual; mv / fv = moving / fixed cell record
   auto one_rec = [&](const float4* mv, const float4* fv) {
     double jb[3];
-    const double sq = residual_sq<D, MODE == 1>(mv, fv, rot, tx, ty, jb);
+    const double sq = residual_sq<D, MODE == 1, PARAM == RANDT_PARAM_ANALYTIC>(mv, fv, rot, tx, ty, jb);
     // closed-form loss: a non-finite residual makes the cost sum non-finite (u or 1 / (u^2 s) is NaN / 0 x inf), which the
     // caller tests after the reduction -- no per-residual class test in the hot loop
     if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
@@ -277,7 +281,7 @@ __device__ __forceinline__ void split_helper(const Stage& S, const SplitReq* req
     int bad = 0;
     if (active) {
       double jb[3];
-      const double sq = residual_sq_v<D, true>(ma, mb, mc4, fa, fb, fc4, rot, tx, ty, jb);
+      const double sq = residual_sq_v<D, true, PARAM == RANDT_PARAM_ANALYTIC>(ma, mb, mc4, fa, fb, fc4, rot, tx, ty, jb);
       if (!(mode == 1 && AM2) && !isfinite(sq)) bad = 1;
       if (mode == 0) {
         o0 = sq;
@@ -325,7 +329,7 @@ __device__ __forceinline__ bool eval_pass_split(const Stage& S, const double* x,
   int bad = 0;
   auto one_rec = [&](const float4* mv, const float4* fv) {
     double jb[3];
-    const double sq = residual_sq<D, MODE == 1>(mv, fv, rot, tx, ty, jb);
+    const double sq = residual_sq<D, MODE == 1, PARAM == RANDT_PARAM_ANALYTIC>(mv, fv, rot, tx, ty, jb);
     if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
     if (MODE == 0) {
       mx = sq > mx ? sq : mx;
@@ -382,7 +386,7 @@ template <int PARAM, int NT>
 __device__ __forceinline__ void to_param(const Base& B, const double* x, double* g, double* H) {
   const double gb0 = B.v[1], gb1 = B.v[2], gb2 = B.v[3];
   const double G00 = B.v[4], G01 = B.v[5], G02 = B.v[6], G11 = B.v[7], G12 = B.v[8], G22 = B.v[9];
-  if (PARAM == RANDT_PARAM_VECTOR) {
+  if (vec_like(PARAM)) {
     g[0] = gb0; g[1] = gb1; g[2] = gb2;
     H[sym(0, 0)] = G00; H[sym(1, 0)] = G01; H[sym(1, 1)] = G11;
     H[sym(2, 0)] = G02; H[sym(2, 1)] = G12; H[sym(2, 2)] = G22;
@@ -461,7 +465,7 @@ __device__ __forceinline__ bool ldlt_solve(double* A, const double* g, double* y
 template <int PARAM>
 __device__ __forceinline__ double ambient_norm(const double* x) {
   double n = 0.0;
-  constexpr int NA = PARAM == RANDT_PARAM_VECTOR ? 3 : 4;
+  constexpr int NA = vec_like(PARAM) ? 3 : 4;
 #pragma unroll
   for (int i = 0; i < NA; ++i) n += x[i] * x[i];
   return n > 0.0 ? n * fast_rsqrt(n) : 0.0;  // sqrt to ~1 ulp without the IEEE sequence (only feeds the parameter-tolerance test)
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
     const double p0 = pose4[4 * (size_t)pair + 0], p1 = pose4[4 * (size_t)pair + 1];
     const double p2 = pose4[4 * (size_t)pair + 2], p3 = pose4[4 * (size_t)pair + 3];
     double x0[4];
-    if (PARAM == RANDT_PARAM_VECTOR) {
+    if (vec_like(PARAM)) {
       x0[0] = p2; x0[1] = p3; x0[2] = atan2(p1, p0); x0[3] = 0.0;  // trans.log()(2), ndt_matcher.cpp:439
     } else {
       x0[0] = p0; x0[1] = p1; x0[2] = p2; x0[3] = p3;
@@ -829,7 +833,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
         // ---- ParameterToleranceReached / FunctionToleranceReached (before accept/reject)
         double sn2 = 0.0;
         {
-          constexpr int NAmb = PARAM == RANDT_PARAM_VECTOR ? 3 : 4;
+          constexpr int NAmb = vec_like(PARAM) ? 3 : 4;
 #pragma unroll
           for (int i = 0; i < NAmb; ++i) sn2 += (x[i] - cand[i]) * (x[i] - cand[i]);
         }
@@ -887,7 +891,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
   res.cost = summary_min / (double)n_res;
   if (tid == 0) {
     double* po = pose4 + 4 * (size_t)pair;
-    if (PARAM == RANDT_PARAM_VECTOR) {
+    if (vec_like(PARAM)) {
       double c = cos(best[2]), s = sin(best[2]);  // Sophus::SE2d(rot, pos), ndt_matcher.cpp:486
       so2_normalize(c, s);
       po[0] = c; po[1] = s; po[2] = best[0]; po[3] = best[1];
@@ -1033,6 +1037,8 @@ int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_id
       if (d3) RANDT_DISPATCH(3, RANDT_PARAM_AMBIENT4); else RANDT_DISPATCH(2, RANDT_PARAM_AMBIENT4);
     case RANDT_PARAM_VECTOR:
       if (d3) RANDT_DISPATCH(3, RANDT_PARAM_VECTOR); else RANDT_DISPATCH(2, RANDT_PARAM_VECTOR);
+    case RANDT_PARAM_ANALYTIC:
+      if (d3) RANDT_DISPATCH(3, RANDT_PARAM_ANALYTIC); else RANDT_DISPATCH(2, RANDT_PARAM_ANALYTIC);
     default:
       return randt_set_error(ctx, RANDT_ERR_INVALID, "unknown parameterization", hipSuccess);
   }

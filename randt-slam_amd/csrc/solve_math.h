@@ -114,7 +114,10 @@ __device__ __forceinline__ Rot make_rot(double c, double s) {
   return R;
 }
 
-template <int D, bool WANT_JAC>
+// ANALYTIC: the rotation entry of jb is the one of the reference's hand-written functors (ceres_residuals.h:244-246, 294-296:
+// u^T J m + (Sm u)^T (R J q) -- equal to the derivative only at theta = 0, reproduced for
+// use_analytic_expressions_for_optimization: true, RANDT_PARAM_ANALYTIC).
+template <int D, bool WANT_JAC, bool ANALYTIC = false>
 __device__ __forceinline__ double residual_sq_v(const float4 ma, const float4 mb, const float4 mc4, const float4 fa, const float4 fb,
                                                 const float4 fc4, const Rot& R, double tx, double ty, double* jb) {
 #pragma clang fp contract(off)
@@ -168,16 +171,21 @@ __device__ __forceinline__ double residual_sq_v(const float4 ma, const float4 mb
     }
     jb[0] = q0;
     jb[1] = q1;
-    jb[2] = fma(u1, m0, -(u0 * m1)) - fma(u1, Su0, -(u0 * Su1));
+    if (ANALYTIC) {
+      const double w0 = -fma(c, q1, s * q0), w1 = fma(c, q0, -(s * q1));  // R J q
+      jb[2] = fma(u1, m0, -(u0 * m1)) + fma(Su0, w0, Su1 * w1);
+    } else {
+      jb[2] = fma(u1, m0, -(u0 * m1)) - fma(u1, Su0, -(u0 * Su1));
+    }
   }
   return ssq;
 }
-template <int D, bool WANT_JAC>
+template <int D, bool WANT_JAC, bool ANALYTIC = false>
 __device__ __forceinline__ double residual_sq(const float4* mrec, const float4* frec, const Rot& R, double tx, double ty, double* jb) {
   // 48-byte records as three 16-byte loads each (global: dwordx4, LDS: ds_read_b128, conflict-free at stride 48)
   const float4 ma = mrec[0], mb = mrec[1], mc4 = mrec[2];
   const float4 fa = frec[0], fb = frec[1], fc4 = frec[2];
-  return residual_sq_v<D, WANT_JAC>(ma, mb, mc4, fa, fb, fc4, R, tx, ty, jb);
+  return residual_sq_v<D, WANT_JAC, ANALYTIC>(ma, mb, mc4, fa, fb, fc4, R, tx, ty, jb);
 }
 
 // Loss + Ceres corrector (residual_block.cc / corrector.cc) of one scalar residual r = sqrt(sq) with base

@@ -566,7 +566,7 @@ __device__ double ambient_sq(const WinDesc& W, const Shared& sh, int a, int b, i
 // MODE 1: ten base sums per wavefront -> rsum[w * 10 ..] (state_sum() combines them per state).
 // In MODE 1 wavefront 6 evaluates the motion / IMU factors of the same point while wavefronts 0-5
 // stream the NDT slots (the factors are a ~2000-instruction serial chain: hidden behind the pass).
-template <int D, int MODE, bool AM2>
+template <int D, int MODE, bool AM2, bool ANALYTIC>
 __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const TermShare& T,
                          const Shared& sh, int buf, const Loss& Lsh, double* out, int& parity, Shared& shw, const double*& rsum,
                          int step_from = -1) {
@@ -652,7 +652,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
         for (int t = 0; t < WIN_TRIP_GROUP; ++t) {
           if (!val[t]) continue;
           double jb[3];
-          const double sq = residual_sq<D, MODE == 1>(mrec[t], frec[t], rot, tx, ty, jb);
+          const double sq = residual_sq<D, MODE == 1, ANALYTIC>(mrec[t], frec[t], rot, tx, ty, jb);
           // closed-form loss: a non-finite residual makes the cost sum non-finite (u or 1 / (u^2 s) is NaN / 0 x inf), which the
           // caller tests after the reduction -- no per-residual class test in the hot loop
           if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
@@ -1034,7 +1034,7 @@ __device__ __noinline__ void gj_dense_solve(Shared& sh, int n, double inv_radius
 }
 
 // AM2: Barron shape exactly -2 (the shipped configurations): closed-form loss, no pow() in the kernel
-template <int D, bool AM2>
+template <int D, bool AM2, bool ANALYTIC>
 __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapView moving, const WinDesc* __restrict__ Wp,
                                                             const int32_t* __restrict__ corr, SolveParams P,
                                                             double* __restrict__ states, randt_result* __restrict__ result,
@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
   bool ok = true;
   if (n_res > 0) {
     const double* unused;
-    ok = ndt_pass<D, 0, AM2>(fixed, moving, W, T, sh, 0, sh.loss, &sh.scal[7], parity, sh, unused);
+    ok = ndt_pass<D, 0, AM2, ANALYTIC>(fixed, moving, W, T, sh, 0, sh.loss, &sh.scal[7], parity, sh, unused);
     raw_max = sh.scal[7];
     res.n_evals++;
     __syncthreads();
@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
       int num_invalid = 0, iteration = 0;
       double minimum_cost = DBL_MAX;
       const double* rs_cur;  // per-wavefront NDT base sums at the current point
-      bool e_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, p, sh.loss, nullptr, parity, sh, rs_cur);
+      bool e_ok = ndt_pass<D, 1, AM2, ANALYTIC>(fixed, moving, W, T, sh, p, sh.loss, nullptr, parity, sh, rs_cur);
       WT(1);
       double fcost = factors_weight(W, sh, p);
       WT(2);
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
 
         // ---- candidate: factors + NDT terms with Jacobians (speculative)
         const double* rs_cand;
-        const bool c_ok = ndt_pass<D, 1, AM2>(fixed, moving, W, T, sh, 1 - p, sh.loss, nullptr, parity, sh, rs_cand, p);
+        const bool c_ok = ndt_pass<D, 1, AM2, ANALYTIC>(fixed, moving, W, T, sh, 1 - p, sh.loss, nullptr, parity, sh, rs_cand, p);
         const double sn2 = sh.scal[1];
         WT(1);
         const double cf = factors_weight(W, sh, 1 - p);
@@ -1514,14 +1514,20 @@ int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& mov
   P.max_invalid = mp->max_consecutive_invalid_steps;
   if (desc.n_tan > WIN_NMAX || desc.S > WIN_SMAX)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window too large for the device solver", hipSuccess);
-#define RANDT_WIN_LAUNCH(DD, AA)                                                                                          \
-  hipLaunchKernelGGL((k_solve_window<DD, AA>), dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
+#define RANDT_WIN_LAUNCH(DD, AA, NN)                                                                                       \
+  hipLaunchKernelGGL((k_solve_window<DD, AA, NN>), dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
                      d_states, d_result, ctx->d_trace, ctx->trace_len)
   const bool am2 = P.alpha == -2.0;
-  if (desc.d3) {
-    if (am2) RANDT_WIN_LAUNCH(3, true); else RANDT_WIN_LAUNCH(3, false);
+  if (desc.pad_) {  // RANDT_PARAM_ANALYTIC: the reference's hand-written NDT functor (never set by a shipped configuration)
+    if (desc.d3) {
+      if (am2) RANDT_WIN_LAUNCH(3, true, true); else RANDT_WIN_LAUNCH(3, false, true);
+    } else {
+      if (am2) RANDT_WIN_LAUNCH(2, true, true); else RANDT_WIN_LAUNCH(2, false, true);
+    }
+  } else if (desc.d3) {
+    if (am2) RANDT_WIN_LAUNCH(3, true, false); else RANDT_WIN_LAUNCH(3, false, false);
   } else {
-    if (am2) RANDT_WIN_LAUNCH(2, true); else RANDT_WIN_LAUNCH(2, false);
+    if (am2) RANDT_WIN_LAUNCH(2, true, false); else RANDT_WIN_LAUNCH(2, false, false);
   }
 #undef RANDT_WIN_LAUNCH
   RANDT_HIP_CHECK(ctx, hipGetLastError());

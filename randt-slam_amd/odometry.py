@@ -164,7 +164,7 @@ class Odometry:
         self.submap_size_poses = p["submap_size_poses"]
         self.submap_overlap = p["submap_overlap"]
         self.fix_submap_handover = bool(p.get("fix_submap_handover", False))   # False = the reference's behaviour
-        self.vector = int(getattr(matcher_params, "parameterization", 0)) == 2     # optimize_on_manifold: false -> (pos, rot) blocks
+        self.vector = int(getattr(matcher_params, "parameterization", 0)) in (2, 3)   # VECTOR / ANALYTIC: (pos, rot) blocks (optimize_on_manifold: false or the analytic flag)
         self.current_submap = backend.new_submap()
         self.last_submap_transformed = None
         self.trajectory = []                                          # list of STATE_DTYPE scalars

@@ -275,15 +275,27 @@ int main() {
       std::printf("group of %d: %d candidates, pose[6] %.5f %.5f (single %.5f %.5f), transport %d\n", grp.size(), n_cand, batch[6].d[2],
                   batch[6].d[3], single[6].d[2], single[6].d[3], grp.transport());
     }
-    // refusals instead of silent substitutions: the analytic functors are not reproduced
+    // use_analytic_expressions_for_optimization: true -> the reference's hand-written functors on (pos, rot) blocks
+    // (RANDT_PARAM_ANALYTIC: their inexact rotation Jacobian reproduced as written): converges next to the autodiff answer
     Matcher ana;
     NDTMatcherParameters ap = prm;
     ap.use_analytic_expressions_for_optimization = true;
     ana.initialize(ap);
-    SE2d keep3(0.3, 4.0, 5.0);
+    SE2d ta(0.05, 0.15, -0.05);
     clear_errors();
-    const double c = ana.estimateLoopConstraint(keep3, submap, scan_b, 2, true, 1.5);
-    batch_ok = batch_ok && std::isnan(c) && keep3.d[2] == 4.0 && last_status() == RANDT_ERR_UNSUPPORTED && first_error() == RANDT_ERR_UNSUPPORTED;
+    randt_result sa{};
+    const double c = ana.estimateLoopConstraint(ta, submap, scan_b, 2, true, 1.5, &sa);
+    std::printf("analytic functors: pose %.5f %.5f %.5f cost %.4f iterations %d\n", ta.d[2], ta.d[3], ta.angle(), c, sa.iterations);
+    batch_ok = batch_ok && std::isfinite(c) && first_error() == RANDT_OK && std::fabs(ta.d[2] - 0.3) < 0.02 && std::fabs(ta.d[3] + 0.2) < 0.02 &&
+               std::fabs(ta.angle() - 0.1) < 0.01 && std::fabs(ta.d[0] * ta.d[0] + ta.d[1] * ta.d[1] - 1.0) < 1e-12;
+    // a failing call: NaN, not a plausible cost; the first error stays readable
+    Matcher bad2;
+    NDTMatcherParameters bp2 = prm;
+    bp2.gnc_control_parameter_divisor = 1.0;
+    bad2.initialize(bp2);
+    SE2d keep3(0.3, 4.0, 5.0);
+    const double cb = bad2.estimateLoopConstraint(keep3, submap, scan_b, 2, true, 1.5);
+    batch_ok = batch_ok && std::isnan(cb) && keep3.d[2] == 4.0 && last_status() == RANDT_ERR_INVALID && first_error() == RANDT_ERR_INVALID;
     clear_errors();
   }
   // pose-graph back end through the GlobalFuser mirror: a drifting square drive closed by one loop constraint

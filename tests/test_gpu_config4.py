@@ -121,7 +121,7 @@ def test_config4_solve_geometries_bit_identical_including_traces(cfg4):
     assert np.array_equal(p_auto, p1) and np.array_equal(r_auto, r1) and np.array_equal(t_auto, t1)
 
 
-@pytest.mark.parametrize("param", [R.PARAM_AMBIENT4, R.PARAM_MANIFOLD, R.PARAM_VECTOR])
+@pytest.mark.parametrize("param", [R.PARAM_AMBIENT4, R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC])
 @pytest.mark.parametrize("intensity", [1, 0])
 def test_split_mode_bit_identical_for_every_instantiation(cfg4, param, intensity):
     """Split mode (several wavefronts per registration) against the one-wavefront kernel for every parameterisation and

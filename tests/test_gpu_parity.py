@@ -90,7 +90,7 @@ def _solve_both(rig, osub, mp, trace_len=3 * 512 + 1):
     return pose, res, trace, out
 
 
-@pytest.mark.parametrize("param", [R.PARAM_AMBIENT4, R.PARAM_MANIFOLD, R.PARAM_VECTOR])
+@pytest.mark.parametrize("param", [R.PARAM_AMBIENT4, R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC])
 @pytest.mark.parametrize("intensity", [1, 0])
 def test_solve_matches_oracle(rig, osub, param, intensity):
     mp = R.default_matcher_params(parameterization=param, use_intensity=intensity)

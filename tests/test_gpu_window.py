@@ -82,7 +82,7 @@ def test_predict_state_matches_oracle(built):
 
 def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=None, param=R.PARAM_MANIFOLD):
     torch, ctx = drive["torch"], drive["ctx"]
-    vec = param == R.PARAM_VECTOR
+    vec = param in (R.PARAM_VECTOR, R.PARAM_ANALYTIC)
     mp = R.default_matcher_params(parameterization=param, gnc_steps=3, **(mp_over or {}))
     wp = R.window_params(use_imu=use_imu, const_vel=const_vel)
     op, owp = to_oracle_params(mp), to_oracle_wp(wp)
@@ -94,7 +94,7 @@ def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=Non
     imu_all = []
     dev_trace = torch.zeros(3 * 512 + 1, dtype=torch.float64, device="cuda:0")
     for i in range(1, len(truth)):
-        gs.append(R.predict_state(gs[-1], i * dt, param))
+        gs.append(R.predict_state(gs[-1], i * dt, R.PARAM_VECTOR if vec else R.PARAM_MANIFOLD))
         os_.append(po.predict_state(os_[-1], i * dt, vector=vec))
         for f in gs[-1].dtype.names:   # predictions from states that agree to the solve's tolerance
             assert np.allclose(gs[-1][f], os_[-1][f], rtol=0, atol=1e-6), f
@@ -226,3 +226,11 @@ def test_vector_odometry_drive_matches_oracle_loop(built):
         est = synth.pose4_to_pose3(pg)
         assert np.all(np.abs(est[:2] - rel[:2]) < 0.25) and abs(synth.wrap_angle(est[2] - rel[2])) < 0.08, (i, est, rel)
     assert gpu.n_finished_submaps == cpu.n_finished_submaps == 1 and gpu.n_rejected == cpu.n_rejected == 0
+
+
+def test_analytic_functor_window_drive_matches_oracle(drive):
+    """use_analytic_expressions_for_optimization: true -- (pos, rot) blocks, vector motion / IMU factors (the analytic ones have
+    the same, correct, Jacobians) and the reference's hand-written NDT functor with its inexact rotation Jacobian, reproduced as
+    written: same iterates as the oracle's restatement of it, 3-D and 2-D."""
+    _run_drive(drive, param=R.PARAM_ANALYTIC)
+    _run_drive(drive, n_fixed=2, use_imu=1, param=R.PARAM_ANALYTIC, mp_over=dict(use_intensity=0))

@@ -23,7 +23,7 @@ def num_jac(d, param, pose4, mm, mc, fm, fc, eps=1e-6):
         for i in range(4):
             e = np.zeros(4); e[i] = eps
             J.append((r_at(pose4 + e) - r_at(pose4 - e)) / (2 * eps))
-    else:
+    else:   # (pos, rot) blocks: PARAM_VECTOR (and PARAM_ANALYTIC, whose RESIDUAL is the same)
         th = np.arctan2(pose4[1], pose4[0])
         def r3(x):
             return r_at(np.array([np.cos(x[2]), np.sin(x[2]), x[0], x[1]]))
@@ -105,3 +105,35 @@ def test_se2_restatement(built):
     xi = np.array([0.4, -1.1, 0.9])
     G = np.array([[0, -xi[2], xi[0]], [xi[2], 0, xi[1]], [0, 0, 0]])
     assert np.allclose(mat(po.se2_exp(xi)), expm(G), atol=1e-12)
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_analytic_functor_jacobian_is_the_reference_formula_not_the_derivative(built, d):
+    """`use_analytic_expressions_for_optimization: true` selects NDTFrameToMap{,Intensity}FactorResidualAnalytic
+    (ceres_residuals.h:207-305).  PARAM_ANALYTIC reproduces its Jacobian AS WRITTEN -- re-derived here with numpy matrices,
+    line by line from the functor's Evaluate() -- which equals the true derivative at theta = 0 and not elsewhere
+    (the second rotation term uses R Sm (R J) where -(R J) Sm R^T is required)."""
+    rng = np.random.default_rng(77 + d)
+    for theta in [0.0, 0.7, -2.5, 3.0]:
+        mm, fm = rng.normal(0, 2, d), rng.normal(0, 2, d)
+        mc, fc = rand_spd(rng, d, 0.3), rand_spd(rng, d, 0.3)
+        t2 = rng.normal(0, 1, 2)
+        pose4 = np.array([np.cos(theta), np.sin(theta), t2[0], t2[1]])
+        r, J = po.ndt_residual(d, po.PARAM_ANALYTIC, pose4, mm, mc, fm, fc)
+        # the functor, transcribed: rotation, rotation_derivative = rotation * [[0,-1],[1,0]] (embedded), mean_diff, cov_inv
+        rot = np.eye(d); rot[:2, :2] = [[np.cos(theta), -np.sin(theta)], [np.sin(theta), np.cos(theta)]]
+        G = np.zeros((d, d)); G[0, 1], G[1, 0] = -1.0, 1.0
+        rot_d = rot @ G
+        trans = np.zeros(d); trans[:2] = t2
+        md = rot @ mm + trans - fm
+        ci = np.linalg.inv(rot @ mc @ rot.T + fc)
+        res = np.sqrt(md @ ci @ md)
+        ex, ey = np.zeros(d), np.zeros(d); ex[0], ey[1] = 1.0, 1.0
+        Jref = np.array([md @ ci @ ex, md @ ci @ ey, md @ ci @ rot_d @ mm + md @ ci @ rot @ mc @ rot_d @ ci @ md]) / res
+        assert np.isclose(r, res, rtol=1e-12) and np.allclose(J, Jref, rtol=1e-10, atol=1e-12), (theta, J, Jref)
+        Jfd = num_jac(d, po.PARAM_VECTOR, pose4, mm, mc, fm, fc)
+        assert np.allclose(J[:2], Jfd[:2], rtol=1e-5, atol=1e-7)                 # the translation columns are right
+        if theta == 0.0:
+            assert np.isclose(J[2], Jfd[2], rtol=1e-5, atol=1e-7)                # the rotation column only at theta = 0
+        else:
+            assert abs(J[2] - Jfd[2]) > 1e-3 * max(1.0, abs(Jfd[2]))
