@@ -276,6 +276,10 @@ int randt_cells_merge(randt_ctx* ctx, randt_cell* h_acc, const randt_cell* h_oth
 int randt_cells_transform(randt_ctx* ctx, randt_cell* h_cells, int n, const double h_pose4[4]);
 int randt_cells_mahalanobis(randt_ctx* ctx, const randt_cell* h_self, const randt_cell* h_subtrahend, int n, int use_intensity,
                             double* h_out);
+/* The point half of Cell::transformCellWithPointCloud (ndt_cell.cpp:126-136): pcl::transformPointCloud of a cell's generating
+ * points (Cell::getPointCloud, ndt_cell.h:146-148) by the 2-D pose, fp32, in place; x at 0, y at 1, z at 2 of every point,
+ * the other floats (intensity) untouched.  The cell statistics move with randt_cells_transform. */
+int randt_points_transform(randt_ctx* ctx, float* h_points, int n_points, int stride_floats, const double h_pose4[4]);
 
 /* ------------------------------------------------------------------ association (a7,a8,a10) -- */
 /* Association half of Matcher::addNDTFactor (ndt_matcher.cpp:200-215,249-253) with

@@ -175,16 +175,21 @@ class Cell {
     min_points_ = min_points_per_cell;
     c_ = randt_cell{};
     pending_.clear();
+    pending_polar_.clear();
+    points_.clear();
+    polar_points_.clear();
   }
   // void addPoint(const pcl::PointXYZI& point, const std::pair<double, double>& angle_dist) (ndt_cell.cpp:19-23): queued
   // until updateCell, like points_to_add_
-  void addPoint(float x, float y, float intensity) {
+  void addPoint(float x, float y, float intensity, const std::pair<double, double>& angle_dist = {0.0, 0.0}) {
     pending_.insert(pending_.end(), {x, y, 0.0f, intensity});
+    pending_polar_.push_back(angle_dist);
   }
   // bool addPointCloud(const pcl::PointCloud<pcl::PointXYZI>&, ...) (ndt_cell.cpp:25-34): points = n x stride floats
-  bool addPointCloud(const float* points, int n, int stride, int intensity_index) {
+  bool addPointCloud(const float* points, int n, int stride, int intensity_index, const std::pair<double, double>* angle_dists = nullptr) {
     if (static_cast<long long>(c_.n) + static_cast<long long>(pending_.size() / 4) + n <= static_cast<long long>(min_points_)) return false;
-    for (int i = 0; i < n; ++i) addPoint(points[i * stride], points[i * stride + 1], points[i * stride + intensity_index]);
+    for (int i = 0; i < n; ++i)
+      addPoint(points[i * stride], points[i * stride + 1], points[i * stride + intensity_index], angle_dists ? angle_dists[i] : std::pair<double, double>{0.0, 0.0});
     updateCell();  // "use recursive update equation"
     return true;
   }
@@ -196,13 +201,20 @@ class Cell {
     if (facade_check(randt_cell_add_points(ctx_->get(), &next, pending_.data(), static_cast<int>(pending_.size() / 4), 4, 3,
                                            min_points_, &accepted), "randt_cell_add_points", ctx_->get()) && accepted) {
       c_ = next;
+      // points_ += points_to_add_; polar_points_.insert(...) (ndt_cell.cpp:95-98): the cell keeps the points it was made of
+      points_.insert(points_.end(), pending_.begin(), pending_.end());
+      polar_points_.insert(polar_points_.end(), pending_polar_.begin(), pending_polar_.end());
       pending_.clear();  // points_to_add_.clear(); below the gate the points stay queued, like in the reference
+      pending_polar_.clear();
     }
   }
   // void clearCell(void)
   void clearCell() {
     c_ = randt_cell{};
     pending_.clear();
+    pending_polar_.clear();
+    points_.clear();
+    polar_points_.clear();
   }
   // void transformCell(const Eigen::Affine2f& trans) (ndt_cell.cpp:117-123)
   void transformCell(const SE2d& trans) {
@@ -210,8 +222,25 @@ class Cell {
     randt_cell next = c_;
     if (facade_check(randt_cells_transform(ctx_->get(), &next, 1, trans.data()), "randt_cells_transform", ctx_->get())) c_ = next;
   }
-  // the per-cell point cloud only feeds the OGM (out of scope): the statistics move exactly as in transformCell
-  void transformCellWithPointCloud(const SE2d& trans) { transformCell(trans); }
+  // void transformCellWithPointCloud(const Eigen::Affine2f& trans) (ndt_cell.cpp:126-136): the statistics as in transformCell,
+  // the generating points through pcl::transformPointCloud's arithmetic on the device (randt_points_transform)
+  void transformCellWithPointCloud(const SE2d& trans) {
+    if (!ctx_) return;
+    randt_cell next = c_;
+    std::vector<float> moved = points_;
+    if (!facade_check(randt_cells_transform(ctx_->get(), &next, 1, trans.data()), "randt_cells_transform", ctx_->get())) return;
+    if (!moved.empty() &&
+        !facade_check(randt_points_transform(ctx_->get(), moved.data(), static_cast<int>(moved.size() / 4), 4, trans.data()), "randt_points_transform", ctx_->get()))
+      return;
+    c_ = next;
+    points_.swap(moved);
+  }
+  // const pcl::PointCloud<pcl::PointXYZI>& getPointCloud() const (ndt_cell.h:146-148): the points that contributed, packed
+  // x y z I (z = 0); cells handed out by Map::getCells() carry none (device maps keep statistics only; the reference's only
+  // reader is the dead Map::mergeMapPoints, ndt_map.cpp:209-236)
+  const std::vector<float>& getPointCloud() const { return points_; }
+  // const std::vector<std::pair<double, double>> getAngleDists() const (ndt_cell.h:152-154)
+  std::vector<std::pair<double, double>> getAngleDists() const { return polar_points_; }
   // Cell& operator+=(const Cell& m_cell) (ndt_cell.h:133-142)
   Cell& operator+=(const Cell& m_cell) {
     if (!ctx_) return *this;
@@ -257,6 +286,9 @@ class Cell {
   std::shared_ptr<Context> ctx_;
   int min_points_ = 0;
   std::vector<float> pending_;  // points_to_add_ as packed x y z I
+  std::vector<std::pair<double, double>> pending_polar_;  // polar_points_to_add_
+  std::vector<float> points_;   // points_ (ndt_cell.h:158)
+  std::vector<std::pair<double, double>> polar_points_;
 };
 
 // rc::navigation::ndt::State (include/ndt_slam/trajectory_representation.h:12-22)

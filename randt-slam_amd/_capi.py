@@ -132,6 +132,7 @@ SYMBOLS = {
     "randt_cells_merge": (_I, [_V, _V, _V, _I]),
     "randt_cells_transform": (_I, [_V, _V, _I, _V]),
     "randt_cells_mahalanobis": (_I, [_V, _V, _V, _I, _I, _V]),
+    "randt_points_transform": (_I, [_V, _V, _I, _I, _V]),
     "randt_associate_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _V, _P(MatcherParams), _V]),
     "randt_solve_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _V, _P(MatcherParams), _V, _V]),
     "randt_register_batch_dev": (_I, [_V, _V, _V, _V, _I, _I, _P(MatcherParams), _V, _V]),

@@ -646,6 +646,23 @@ int randt_cells_transform(randt_ctx* ctx, randt_cell* h_cells, int n, const doub
   return cells_roundtrip(ctx, 1, h_cells, nullptr, n, h_pose4, nullptr);
 }
 
+int randt_points_transform(randt_ctx* ctx, float* h_points, int n_points, int stride_floats, const double h_pose4[4]) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx || n_points < 0 || stride_floats < 3 || !h_pose4 || (n_points > 0 && !h_points)) return RANDT_ERR_INVALID;
+  if (n_points == 0) return RANDT_OK;
+  const size_t pb = sizeof(float) * (size_t)n_points * stride_floats, off_pose = (pb + 255) & ~(size_t)255;
+  int rc = ensure_ws(ctx, off_pose + 64);
+  if (rc) return rc;
+  char* ws = (char*)ctx->ws;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws, h_points, pb, hipMemcpyHostToDevice, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_pose, h_pose4, sizeof(double) * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_points_transform(ctx, (float*)ws, n_points, stride_floats, (const double*)(ws + off_pose));
+  if (rc) return rc;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_points, ws, pb, hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RANDT_OK;
+}
+
 int randt_cells_mahalanobis(randt_ctx* ctx, const randt_cell* h_self, const randt_cell* h_subtrahend, int n, int use_intensity,
                             double* h_out) {
   DeviceGuard dev_guard__(ctx);

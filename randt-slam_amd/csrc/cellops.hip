@@ -100,7 +100,28 @@ __global__ __launch_bounds__(64) void k_cell_update(randt_cell* cell, const floa
   *accepted = 1;
 }
 
+// Cell::transformCellWithPointCloud's second half (ndt_cell.cpp:131-135): pcl::transformPointCloud of the cell's points with
+// the Affine3f built from the 2-D pose (z row / column identity), fp32; intensity and z untouched.  PCL (un-vendored; 1.10 on
+// ROS noetic) evaluates a transformed coordinate as m0 x + (m1 y + (m2 z + m3)) in its SSE path -- SPEC DECISION: that order.
+__global__ __launch_bounds__(256) void k_points_transform(float* pts, int n, int stride, const double* pose4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float aff[4];
+  pose_to_affine_f(pose4, aff);  // c, s, tx, ty as float (Sophus::SE2d::cast<float>().matrix())
+  float* p = pts + (size_t)i * stride;
+  const float x = p[0], y = p[1], z = p[2];
+  p[0] = aff[0] * x + (-aff[1] * y + (0.0f * z + aff[2]));
+  p[1] = aff[1] * x + (aff[0] * y + (0.0f * z + aff[3]));
+}
+
 }  // namespace
+
+int launch_points_transform(randt_ctx* ctx, float* d_pts, int n, int stride, const double* d_pose4) {
+  if (n <= 0) return RANDT_OK;
+  hipLaunchKernelGGL(k_points_transform, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_pts, n, stride, d_pose4);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
 
 int launch_cells_op(randt_ctx* ctx, int op, randt_cell* d_a, const randt_cell* d_b, int n, const double* d_pose4, double* d_out) {
   if (n <= 0) return RANDT_OK;

@@ -145,6 +145,7 @@ int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_d
                      const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries, float* d_ws, int32_t* d_loop_id,
                      float* d_yaw, double* d_min_dist);
 
+int launch_points_transform(randt_ctx* ctx, float* d_pts, int n, int stride, const double* d_pose4);
 int launch_cells_op(randt_ctx* ctx, int op, randt_cell* d_a, const randt_cell* d_b, int n, const double* d_pose4, double* d_out);
 int launch_cell_update(randt_ctx* ctx, randt_cell* d_cell, const float* d_pts, int k, int stride, int ioff, int min_points,
                        int32_t* d_accepted);

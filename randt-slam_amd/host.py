@@ -266,6 +266,14 @@ def cells_transform(ctx, cells, pose4):
     return a
 
 
+def points_transform(ctx, points, pose4):
+    """The point half of Cell::transformCellWithPointCloud: (n, stride) float32 points moved by one pose (fp32, on the device)."""
+    a = np.ascontiguousarray(points, dtype=np.float32).copy()
+    p = np.ascontiguousarray(pose4, dtype=np.float64)
+    ctx._check(ctx._lib.randt_points_transform(ctx._h, _dptr(a), int(a.shape[0]), int(a.shape[1]), _dptr(p)), "randt_points_transform")
+    return a
+
+
 def cells_mahalanobis(ctx, self_cells, subtrahend_cells, use_intensity=True):
     """self.mahalanobisSquaredIntensity(subtrahend) (or mahalanobisSquared) elementwise, as float64."""
     a = np.ascontiguousarray(np.array(self_cells, dtype=CELL_DTYPE).reshape(-1))

@@ -224,13 +224,24 @@ int main() {
     rec.addPointCloud(b.data(), 12, 4, 3);                            // recursive update of a filled cell (+ regularisation)
     Cell moved = c1;
     moved.transformCell(SE2d(0.5, 1.0, -2.0));
+    // the generating points travel with transformCellWithPointCloud (getPointCloud / getAngleDists, ndt_cell.h:146-154)
+    Cell withpts = c1;
+    withpts.transformCellWithPointCloud(SE2d(0.5, 1.0, -2.0));
+    const auto& cloud0 = c1.getPointCloud();
+    const auto& cloud1 = withpts.getPointCloud();
+    bool cloud_ok = cloud0.size() == 24 * 4 && cloud1.size() == 24 * 4 && c1.getAngleDists().size() == 24 && withpts.getMean() == moved.getMean();
+    for (int i = 0; i < 24 && cloud_ok; ++i) {
+      const double px = std::cos(0.5) * cloud0[4 * i] - std::sin(0.5) * cloud0[4 * i + 1] + 1.0;
+      const double py = std::sin(0.5) * cloud0[4 * i] + std::cos(0.5) * cloud0[4 * i + 1] - 2.0;
+      cloud_ok = std::fabs(cloud1[4 * i] - px) < 1e-5 && std::fabs(cloud1[4 * i + 1] - py) < 1e-5 && cloud1[4 * i + 3] == cloud0[4 * i + 3];
+    }
     const auto m0 = c1.getMean(), m1 = moved.getMean();
     const double ex = std::cos(0.5) * m0[0] - std::sin(0.5) * m0[1] + 1.0, ey = std::sin(0.5) * m0[0] + std::cos(0.5) * m0[1] - 2.0;
     std::printf("cells: n %zu + %zu -> %zu (recursive %zu), d3 %.4f (%.4f reversed) d2 %.4f, moved mean (%.4f, %.4f)\n", c1.getNumCells(),
                 c2.getNumCells(), sum.getNumCells(), rec.getNumCells(), d3, d3r, d2, m1[0], m1[1]);
     cell_ok = !few && t1 && t2 && same && c1.getNumCells() == 24 && sum.getNumCells() == 36 && rec.getNumCells() == 36 && d3 > 0 &&
               std::fabs(d3 - d3r) < 1e-3 * d3 && d2 > 0 && std::fabs(m1[0] - ex) < 1e-4 && std::fabs(m1[1] - ey) < 1e-4 &&
-              sum.getMean()[0] > m0[0] && sum.getMean()[0] < c2.getMean()[0] && moved.getNumCells() == 24;
+              sum.getMean()[0] > m0[0] && sum.getMean()[0] < c2.getMean()[0] && moved.getNumCells() == 24 && cloud_ok;
     // never-throw: a registration with an impossible parameter set warns and leaves the pose as it was
     Matcher bad;
     NDTMatcherParameters bp = prm;
