@@ -1899,7 +1899,7 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
   P.n_ambient = u.n_amb;
   P.n_tangent = u.n_tan;
 
-  double x[64];
+  double x[8 * ORC_MAX_TANGENT]; /* ambient size: <= 5 + 10 S */
   win_pack(&u, states, x);
 
   /* raw NDT residuals -> gnc_mu (ndt_matcher.cpp:382-389) */

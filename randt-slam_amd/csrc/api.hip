@@ -221,6 +221,7 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
     (void)hipGetLastError();
     if (const char* e = getenv("RANDT_BUILD_ATOMIC_RANK")) ctx->lds_atomics_lane_ordered = (atoi(e) && ctx->lds_atomics_lane_ordered) ? 1 : 0;
     if (const char* e = getenv("RANDT_DEBUG_FORCE_MISRANK")) ctx->debug_force_misrank = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("RANDT_WINDOW_GENERAL")) ctx->window_general = atoi(e) ? 1 : 0;
     // the word the build kernel counts its in-kernel ranking fallbacks in: pinned host memory, read without a synchronisation
     // in front of every build launch; without it the atomic ranking is not used at all
     void* pin = nullptr;
@@ -1342,7 +1343,8 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   DeviceGuard dev_guard__(ctx);
   if (!ctx || !fixed || !moving || !h_fixed_idx || !h_moving_idx || !h_states || !mp || !wp || !h_trans4) return RANDT_ERR_INVALID;
   const int S = n_states - 1;
-  if (S < 1 || S > 3 || n_fixed < 1 || n_fixed > 2) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..3 optimised states, 1..2 fixed maps", hipSuccess);
+  if (S < 1 || S > RANDT_WIN_MAX_STATES - 1 || n_fixed < 1 || n_fixed > 2)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..7 optimised states, 1..2 fixed maps", hipSuccess);
   if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_VECTOR && mp->parameterization != RANDT_PARAM_ANALYTIC)
     return randt_set_error(ctx, RANDT_ERR_INVALID, "window solve: parameterization must be RANDT_PARAM_MANIFOLD, _VECTOR or _ANALYTIC", hipSuccess);
   const bool vec = mp->parameterization != RANDT_PARAM_MANIFOLD;

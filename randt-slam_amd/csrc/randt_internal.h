@@ -49,6 +49,7 @@ struct randt_ctx {
                                      // are served in ascending lane order -> the build kernels rank points with one atomic each
   int32_t* misrank_word = nullptr;   // pinned host word the build kernel counts its ranking fallbacks in (device-visible)
   int build_rank_fallbacks = 0;      // workgroups that re-ranked with ballots so far (randt_debug_build_rank_fallbacks)
+  int window_general = 0;            // RANDT_WINDOW_GENERAL=1: every window takes window_gen.hip (tests: the two kernels agree)
   int debug_force_misrank = 0;       // RANDT_DEBUG_FORCE_MISRANK=1: test hook, makes the in-kernel order check fail
   int build_tiled = 0;       // RANDT_BUILD_TILED=1: every scan through the multi-workgroup build (normally only > 7168 points)
   int assoc_stage_grid = 0;  // 1: stage the fixed map's index grid in LDS; 0: gather it from L2 (same speed alone, but 36 KB instead of 76 KB of LDS leaves room for co-running build workgroups: +2 % end to end)
@@ -112,8 +113,8 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
                      int use_intensity, int32_t* d_corr, const int32_t* d_moving_idx = nullptr);
 
 // fixed-lag window problem description (kernel argument, by value)
-#define RANDT_WIN_MAX_STATES 4
-#define RANDT_WIN_MAX_TERMS 6
+#define RANDT_WIN_MAX_STATES 8   // window_gen.hip: <= 7 optimised states + the constant one (window.hip takes <= 3 + 1)
+#define RANDT_WIN_MAX_TERMS 14   // (state, fixed map) NDT terms: 7 states x 2 fixed maps
 struct WinDesc {
   int S, n_terms, n_tan, n_amb, use_imu, const_vel, k, d3;
   int vec, pad_;  // vec: (pos[2], rot) parameter blocks instead of the SE(2) manifold (optimize_on_manifold: false); pad_: 1 = RANDT_PARAM_ANALYTIC
@@ -127,6 +128,9 @@ struct WinDesc {
 int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
                         const int32_t* d_corr, const randt_matcher_params* mp, double* d_states /* (S+1) x 10 */,
                         randt_result* d_result);
+// window_gen.hip: the general kernel (4..7 optimised states); launch_solve_window routes to it
+int launch_solve_window_gen(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
+                            const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result);
 int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
                  int moving_first, int n_pairs, const int32_t* d_corr, const randt_matcher_params* mp,
                  double* d_pose4, randt_result* d_results);

@@ -1146,8 +1146,9 @@ int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& mov
   P.max_it = mp->max_iterations;
   P.k = mp->n_neighbours;
   P.max_invalid = mp->max_consecutive_invalid_steps;
-  if (desc.n_tan > WIN_NMAX || desc.S > WIN_SMAX)
-    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window too large for the device solver", hipSuccess);
+  // more than three optimised states (no shipped configuration): the general kernel
+  if (desc.n_tan > WIN_NMAX || desc.S > WIN_SMAX || desc.n_terms > 6 || ctx->window_general)
+    return launch_solve_window_gen(ctx, fixed, moving, desc, d_desc, d_corr, P, d_states, d_result);
 #define RANDT_WIN_LAUNCH(DD, AA, NN)                                                                                       \
   hipLaunchKernelGGL((k_solve_window<DD, AA, NN>), dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
                      d_states, d_result, ctx->d_trace, ctx->trace_len)

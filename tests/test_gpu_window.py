@@ -24,9 +24,21 @@ def to_oracle_wp(wp):
     return o
 
 
-@pytest.fixture(scope="module")
-def drive(built):
+def _make_drive(env=None):
+    import os
+
     import torch
+
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)   # the environment knobs are read at creation
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
     world = synth.make_world()
     n_scans, dt = 8, 0.25
@@ -52,7 +64,6 @@ def drive(built):
     oscans = [oracle_scan_map(s) for s in scans]
     # device side
     dev = torch.device("cuda:0")
-    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
     mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
     sub = R.Maps(ctx, 2, mapp, 10000, with_grid=True)
     tmp = R.Maps(ctx, len(kf), mapp, 512, with_grid=False)
@@ -65,6 +76,17 @@ def drive(built):
     ctx.synchronize()
     assert cells_equal(sub.download(1)[0], osub2.cells())
     return dict(ctx=ctx, sub=sub, smaps=smaps, osub=osub, osub2=osub2, oscans=oscans, truth=rel[32:32 + n_scans], dt=dt, torch=torch)
+
+
+@pytest.fixture(scope="module")
+def drive(built):
+    return _make_drive()
+
+
+@pytest.fixture(scope="module")
+def drive_general(built):
+    """The same drive on a context whose windows ALL take the general kernel (window_gen.hip)."""
+    return _make_drive({"RANDT_WINDOW_GENERAL": "1"})
 
 
 def test_predict_state_matches_oracle(built):
@@ -80,7 +102,7 @@ def test_predict_state_matches_oracle(built):
             assert np.allclose(a[f], b[f], rtol=0, atol=1e-15), f
 
 
-def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=None, param=R.PARAM_MANIFOLD):
+def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=None, param=R.PARAM_MANIFOLD, lag=3):
     torch, ctx = drive["torch"], drive["ctx"]
     vec = param in (R.PARAM_VECTOR, R.PARAM_ANALYTIC)
     mp = R.default_matcher_params(parameterization=param, gnc_steps=3, **(mp_over or {}))
@@ -99,7 +121,7 @@ def _run_drive(drive, n_fixed=1, use_imu=0, const_vel=1, trace=True, mp_over=Non
         for f in gs[-1].dtype.names:   # predictions from states that agree to the solve's tolerance
             assert np.allclose(gs[-1][f], os_[-1][f], rtol=0, atol=1e-6), f
         imu_all.append(synth.wrap_angle(truth[i][2] - truth[i - 1][2]) + 0.002)
-        S = min(len(gs) - 1, 3)
+        S = min(len(gs) - 1, lag)                                 # ndt_matcher.cpp:343 smoothing_steps_iter
         win = list(range(i - S + 1, i + 1))                       # scan indices of the optimised states
         imu = np.array(imu_all[-S:]) if use_imu else None
         if trace:
@@ -154,6 +176,34 @@ def test_window_with_imu_factor(drive):
 
 def test_window_constant_acceleration_layout(drive):
     _run_drive(drive, const_vel=0)
+
+
+# ---- smoothing_steps > 3 (no shipped configuration; ndt_matcher.cpp:343 takes any lag): window_gen.hip
+@pytest.mark.parametrize("lag,kw", [
+    (4, dict()),
+    (5, dict(n_fixed=2)),
+    (7, dict(n_fixed=2, use_imu=1, const_vel=0)),               # the largest problem: 68 tangent dimensions, 14 NDT terms
+    (6, dict(param=R.PARAM_VECTOR, use_imu=1)),
+    (4, dict(param=R.PARAM_ANALYTIC, const_vel=0, mp_over=dict(use_intensity=0, loss_alpha=-1.0))),
+])
+def test_window_longer_lags_match_oracle(drive, lag, kw):
+    _run_drive(drive, lag=lag, **kw)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_fixed=2, use_imu=1, const_vel=0), dict(param=R.PARAM_VECTOR, n_fixed=2)])
+def test_general_window_kernel_on_three_state_windows(drive_general, kw):
+    """The general kernel on the windows the tuned kernel normally takes: same oracle, same assertions (decision trace included)."""
+    _run_drive(drive_general, **kw)
+
+
+def test_window_lag_beyond_the_device_solver_is_refused(drive):
+    ctx = drive["ctx"]
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    st = R.make_state(synth.pose3_to_pose4(drive["truth"][0]), stamp=0.0)
+    states = np.array([st] * 9, dtype=R.STATE_DTYPE)            # 8 optimised states
+    with pytest.raises(R.RandtError) as e:
+        R.register_window(ctx, drive["sub"], [0], drive["smaps"], list(range(8)), states, mp, R.window_params(), st["pose"])
+    assert e.value.status == 3 and "1..7 optimised states" in str(e.value)                 # RANDT_ERR_UNSUPPORTED
 
 
 def test_window_rejection_gate(drive):
