@@ -41,6 +41,31 @@ def test_streaming_odometry_matches_oracle_and_truth(built):
     print("max deviation GPU vs oracle over the drive: %.3e m, %.3e rad" % (worst_t, worst_r))
 
 
+def test_streaming_odometry_with_a_five_scan_lag_matches_oracle(built):
+    """smoothing_steps: 5 (the reference reads it unbounded, ndt_slam.cpp:576; insertion_delay follows, :580): the whole
+    LocalFuser loop on the general window kernel, incl. a roll-over with overlap (two fixed maps, ten NDT terms)."""
+    import torch
+
+    world = synth.make_world()
+    n_scans, dt = 40, 0.25
+    traj = synth.make_trajectory(3300, n_scans, step=0.25)
+    scans = [synth.make_scan(world, traj[i], 9500 + i) for i in range(n_scans)]
+    small = dict(submap_size_poses=24, submap_overlap=8, smoothing_steps=5)
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    wp = R.window_params()
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    gpu = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, wp, small)
+    cpu = odometry.Odometry(OracleBackend(), mp, wp, small)
+    assert gpu.insertion_delay == 6
+    for i in range(n_scans):
+        pg = gpu.process_scan(scans[i], i * dt)
+        pc = cpu.process_scan(scans[i], i * dt)
+        assert np.abs(pg[2:] - pc[2:]).max() <= 1e-4, (i, pg, pc)
+        assert abs(synth.wrap_angle(np.arctan2(pg[1], pg[0]) - np.arctan2(pc[1], pc[0]))) <= 1e-4, (i, pg, pc)
+    assert gpu.n_finished_submaps == cpu.n_finished_submaps == 1
+    assert gpu.n_registrations == cpu.n_registrations and gpu.n_rejected == cpu.n_rejected == 0
+
+
 def test_config5_polar_loop_matches_oracle(built):
     """BASELINE config 5: Oxford-shaped polar scans -> filterScan -> NDT -> fixed-lag odometry."""
     import torch
