@@ -161,6 +161,14 @@ class Context {
 // Host copy of one cell = rc::navigation::ndt::Cell (ndt_cell.h:16-170): getters on the record, mutators through the
 // ABI (the arithmetic runs on the device, randt_cell_add_points / randt_cells_{merge,transform,mahalanobis}).
 // A cell without a context can be read but not modified.
+// COST: every mutator / metric below is ONE device round trip + stream synchronisation (~15-20 us) for ONE cell -- right for
+// the reference's occasional single-cell uses, wrong for loops over a map's cells (NDTSlam::createVisualizationMsg style).
+// The batched forms of the same operations, one launch for any number of cells:
+//   transformCell x n          randt_cells_transform(ctx, cells, n, pose4)      or the whole map: Map::transformMap / randt_maps_transform
+//   operator+= x n             randt_cells_merge(ctx, dst, src, n)              or cell-by-grid-slot: Map::mergeMap / randt_maps_merge
+//   mahalanobisSquared x n     randt_cells_mahalanobis(ctx, a, b, n, out)
+//   addPointCloud per cell     a whole scan at once: Map::addClusters / randt_ndt_build_batch_dev (the hot path)
+//   transformCellWithPointCloud  randt_points_transform(ctx, points, n, stride, pose4) on any point set
 class Cell {
  public:
   Cell() = default;
