@@ -236,6 +236,16 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
 // bit-identical to the one-wavefront kernel; trips beyond W (n_res > 64 W) it evaluates itself.  A pass then costs one
 // trip + the combine instead of ceil(n_res / 64) trips.  The helpers keep their two cell records in registers for the
 // whole solve (the association is frozen) and sleep at the workgroup barrier while wavefront 0 does the solver algebra.
+#ifdef RANDT_SPLIT_TIMING  // developer probe (tools/ab_build.sh): where wavefront 0 of workgroup 0 spends a split-mode solve
+__device__ long long g_randt_split_timing[10];
+__shared__ long long s_split_tim[10];
+extern "C" int randt_debug_split_timing(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_randt_split_timing), sizeof(long long) * 10) == hipSuccess ? 0 : 2;
+}
+#define ST(slot) do { if ((threadIdx.x) == 0) { const long long n_ = clock64(); s_split_tim[slot] += n_ - s_split_tim[9]; s_split_tim[9] = n_; } } while (0)
+#else
+#define ST(slot) do {} while (0)
+#endif
 constexpr int SPLIT_MAXW = 8;          // wavefronts per registration (workgroup of <= 512 threads)
 constexpr int SPLIT_PAIR_CAP = 2048;   // compacted correspondences per registration in split mode (launcher guarantees M k <= this)
 struct SplitReq {
@@ -312,6 +322,7 @@ __device__ __forceinline__ void split_helper(const Stage& S, const SplitReq* req
 template <int D, int PARAM, int MODE, bool AM2>
 __device__ __forceinline__ bool eval_pass_split(const Stage& S, const double* x, const Loss& L, Base& out, SplitReq* req, const double* part,
                                                 const int* bad_flags, int W, int lane) {
+  ST(4);  // solver algebra since the previous pass
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) req->x[i] = x[i];
@@ -319,6 +330,7 @@ __device__ __forceinline__ bool eval_pass_split(const Stage& S, const double* x,
     req->mode = MODE;
   }
   __syncthreads();  // A
+  ST(0);
   double c, s, tx, ty;
   pass_pose<D, PARAM>(x, c, s, tx, ty);
   const Rot rot = make_rot(c, s);
@@ -342,7 +354,9 @@ __device__ __forceinline__ bool eval_pass_split(const Stage& S, const double* x,
     pair_records(S, lane, mv, fv);
     one_rec(mv, fv);
   }
+  ST(1);
   __syncthreads();  // B
+  ST(2);
   const int T = (S.n_pairs + 63) >> 6;
   const int Tp = T < W ? T : W;
   for (int w = 1; w < Tp; ++w) {  // trips 1 .. W-1 from the helpers, in trip order
@@ -373,6 +387,7 @@ __device__ __forceinline__ bool eval_pass_split(const Stage& S, const double* x,
   wave_sum10(acc);
 #pragma unroll
   for (int i = 0; i < 10; ++i) out.v[i] = acc[i];
+  ST(3);
   return uni(badf == 0.0 && isfinite(acc[0]));
 }
 
@@ -679,6 +694,12 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
     if (tid == 0 && split_wave == 0) results[pair] = res;
     return;
   }
+#ifdef RANDT_SPLIT_TIMING
+  if (SPLIT && threadIdx.x == 0) {
+    for (int i = 0; i < 9; ++i) s_split_tim[i] = 0;
+    s_split_tim[9] = clock64();
+  }
+#endif
   if (SPLIT && split_wave != 0) {
     split_helper<D, PARAM, AM2>(S, &s_req, s_part + (size_t)(split_wave - 1) * 64 * 6, &s_badflag[split_wave], split_wave, tid);
     return;
@@ -886,6 +907,13 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
     if (tid == 0) s_req.mode = -1;
     __syncthreads();
   }
+#ifdef RANDT_SPLIT_TIMING
+  if (SPLIT && blockIdx.x == 0 && threadIdx.x == 0) {
+    ST(4);
+    for (int i = 0; i < 9; ++i) g_randt_split_timing[i] = s_split_tim[i];
+    g_randt_split_timing[8] = res.n_evals;
+  }
+#endif
   res.termination = term;
   res.final_cost = summary_min;
   res.cost = summary_min / (double)n_res;
