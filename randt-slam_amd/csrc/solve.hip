@@ -725,23 +725,28 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
       gnc_mu = fmax(gnc_mu, 1.0);
       L = AM2 ? make_loss_am2(P.loss_a, gnc_mu, P.weight) : make_loss(P.loss_a, P.alpha, gnc_mu, P.weight);
       // ================= one ceres::Solve (TrustRegionMinimizer::Minimize) =================
+      // The LDS-resident state is moved in BULK: one group of reads in front of the step computation, one behind the pass,
+      // writes without a dependent read behind them -- a lone wavefront (split mode) otherwise pays an LDS round trip per
+      // statement group.  The arithmetic is statement for statement the reference's.
       double step[NT], delta[NT];
       constexpr int NS = NT * (NT + 1) / 2;
+      constexpr int NAmb = vec_like(PARAM) ? 3 : 4;
       double* const sigma = cold + 4;  // [NT]
-      double* const diag = cold + 8;   // [NT]
+      double* const diag = cold + 8;   // [NT]  LM diagonal of the current point (kept across rejected steps: reuse_diagonal)
       double* const gs = cold + 12;    // [NT]  Jacobi-scaled gradient / J^T J (packed lower) at the current point
       double* const Hs = cold + 16;    // [NS]
       double* const ss = cold + 26;    // [NS]
       double g[NT], H[NS];
       double radius = P.r0, decrease = 2.0;
-      bool reuse = false, step_ok = true;
+      bool step_ok = true;
       int num_invalid = 0, iteration = 0;
-      RANDT_COLD_SET(minimum_cost, DBL_MAX);
+      double x0[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) RANDT_COLD_SET(x[i], best[i]);
-      RANDT_COLD_SET(x_norm, ambient_norm<PARAM>(best));
-      RANDT_COLD_SYNC();
-      const bool e_ok = RANDT_EVAL(1, x, cur);
+      for (int i = 0; i < 4; ++i) x0[i] = best[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) RANDT_COLD_SET(x[i], x0[i]);
+      RANDT_COLD_SET(x_norm, ambient_norm<PARAM>(x0));
+      const bool e_ok = RANDT_EVAL(1, x0, cur);
       asm volatile("" ::: "memory");
       res.n_evals++;
       res.iterations++;
@@ -753,9 +758,12 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
       }
       double cost = cur.v[0];
       if (res.gnc_solves == 0) res.initial_cost = cost;
-      RANDT_COLD_SET(summary_min, cost);
-      to_param<PARAM, NT>(cur, x, g, H);
+      bool gconv;
       {
+        double xr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[i] = x[i];
+        to_param<PARAM, NT>(cur, xr, g, H);
         double sg[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {  // jacobi scaling 1 / (1 + sqrt(H_ii)), fixed per solve; Newton-refined rsqrt / rcp (~1 ulp:
@@ -769,23 +777,25 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
 #pragma unroll
           for (int j = 0; j <= i; ++j) {
             const double sij = sg[i] * sg[j];
+            const double hs = H[sym(i, j)] * sij;
             RANDT_COLD_SET(ss[sym(i, j)], sij);
-            RANDT_COLD_SET(Hs[sym(i, j)], H[sym(i, j)] * sij);
+            RANDT_COLD_SET(Hs[sym(i, j)], hs);
+            if (i == j) RANDT_COLD_SET(diag[i], fmin(fmax(hs, P.dmin), P.dmax));  // LevenbergMarquardtStrategy: clamp of the scaled J^T J diagonal
           }
         }
+        gconv = gradient_converged<PARAM, NT>(xr, g, P.gtol);
+        // FinalizeIterationAndCheckIfMinimizerCanContinue of iteration zero: the starting point is the best one so far
+        RANDT_COLD_SET(minimum_cost, cost);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RANDT_COLD_SET(best[i], xr[i]);
+        RANDT_COLD_SET(summary_min, cost);
         RANDT_COLD_SYNC();
       }
-      bool gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
       trace_push(tr, trace_len, tid, cost, radius, 0);
 
       for (;;) {
-        // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
-        if (step_ok && uni(cost < minimum_cost)) {
-          RANDT_COLD_SET(minimum_cost, cost);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) RANDT_COLD_SET(best[i], x[i]);
-          RANDT_COLD_SYNC();
-        }
+        // ---- FinalizeIterationAndCheckIfMinimizerCanContinue (the copy of an improved point to the user parameters happens
+        // where the point is accepted: nothing can leave the loop between there and here)
         if (iteration >= P.max_it) { term = RANDT_TERM_NO_CONVERGENCE; break; }
         if (step_ok && gconv) { term = RANDT_TERM_CONVERGENCE_GRADIENT; break; }
         if (uni(radius <= P.rmin)) { term = RANDT_TERM_CONVERGENCE_RADIUS; break; }
@@ -793,32 +803,36 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
         res.iterations++;
 
         // ---- LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled normal equations
-        double A[NS];
-        if (!reuse) {
+        double A[NS], Hr[NS], gr[NT], dg[NT], sg[NT], xr[4];
 #pragma unroll
-          for (int i = 0; i < NT; ++i) RANDT_COLD_SET(diag[i], fmin(fmax(Hs[sym(i, i)], P.dmin), P.dmax));
-          RANDT_COLD_SYNC();
+        for (int i = 0; i < NS; ++i) Hr[i] = Hs[i];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          gr[i] = gs[i];
+          dg[i] = diag[i];
+          sg[i] = sigma[i];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[i] = x[i];
         const double inv_radius = fast_rcp(radius);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) A[i] = Hs[i];
+        for (int i = 0; i < NS; ++i) A[i] = Hr[i];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) A[sym(i, i)] += diag[i] * inv_radius;  // (sqrt(D^2 / radius))^2
-        bool solved = ldlt_solve<NT>(A, gs, step);
+        for (int i = 0; i < NT; ++i) A[sym(i, i)] += dg[i] * inv_radius;  // (sqrt(D^2 / radius))^2
+        bool solved = ldlt_solve<NT>(A, gr, step);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
           if (!isfinite(step[i])) solved = false;
           step[i] = -step[i];
         }
-        reuse = true;
         // model_cost_change = -(J step)^T (r + J step / 2) = -(step.g + step^T H step / 2)
         double mcc = 0.0;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
           double hs = 0.0;
 #pragma unroll
-          for (int j = 0; j < NT; ++j) hs += Hs[sym(i, j)] * step[j];
-          mcc += step[i] * (gs[i] + 0.5 * hs);
+          for (int j = 0; j < NT; ++j) hs += Hr[sym(i, j)] * step[j];
+          mcc += step[i] * (gr[i] + 0.5 * hs);
         }
         mcc = -mcc;
         const bool valid = uni(solved && mcc > 0.0);
@@ -827,7 +841,6 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
           if (++num_invalid >= P.max_invalid) { term = RANDT_TERM_FAILURE; break; }
           radius = radius * fast_rcp(decrease);  // decrease is a power of two: exact
           decrease *= 2.0;
-          reuse = true;
           step_ok = false;
           RANDT_COLD_SET(summary_min, fmin(summary_min, cost));
           RANDT_COLD_SYNC();
@@ -836,29 +849,38 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
         }
         num_invalid = 0;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) delta[i] = step[i] * sigma[i];
-        {
-          double cnew[4];
-          plus<PARAM>(x, delta, cnew);
+        for (int i = 0; i < NT; ++i) delta[i] = step[i] * sg[i];
+        double cnew[4];
+        plus<PARAM>(xr, delta, cnew);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) RANDT_COLD_SET(cand[i], cnew[i]);
-          RANDT_COLD_SYNC();
-        }
+        for (int i = 0; i < 4; ++i) RANDT_COLD_SET(cand[i], cnew[i]);
+        RANDT_COLD_SYNC();
 
-        // ---- candidate cost (+ speculative gradient / J^T J)
-        const bool c_ok = RANDT_EVAL(1, cand, cnd);
+        // ---- candidate cost (+ speculative gradient / J^T J); the pass takes the point from registers
+        const bool c_ok = RANDT_EVAL(1, cnew, cnd);
         asm volatile("" ::: "memory");  // the LDS-resident state is re-read after the pass, not carried through it in registers
         res.n_evals++;
         const double cand_cost = c_ok ? cnd.v[0] : DBL_MAX;
 
+        // ---- behind the pass: one group of reads
+        double xc[4], cc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xc[i] = x[i];
+          cc[i] = cand[i];
+        }
+        const double xn_cur = x_norm, smin = summary_min, mincost = minimum_cost;
+        double sgn[NT], ssn[NS];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) sgn[i] = sigma[i];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) ssn[i] = ss[i];
+
         // ---- ParameterToleranceReached / FunctionToleranceReached (before accept/reject)
         double sn2 = 0.0;
-        {
-          constexpr int NAmb = vec_like(PARAM) ? 3 : 4;
 #pragma unroll
-          for (int i = 0; i < NAmb; ++i) sn2 += (x[i] - cand[i]) * (x[i] - cand[i]);
-        }
-        const double ptol_abs = P.ptol * (x_norm + P.ptol);
+        for (int i = 0; i < NAmb; ++i) sn2 += (xc[i] - cc[i]) * (xc[i] - cc[i]);
+        const double ptol_abs = P.ptol * (xn_cur + P.ptol);
         if (uni(sn2 <= ptol_abs * ptol_abs)) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
         const double cost_change = cost - cand_cost;
         if (uni(fabs(cost_change) <= P.ftol * cost)) { term = RANDT_TERM_CONVERGENCE_FUNCTION; break; }
@@ -867,32 +889,40 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
         if (uni(rel > P.min_rel)) {
           // ---- HandleSuccessfulStep
 #pragma unroll
-          for (int i = 0; i < 4; ++i) RANDT_COLD_SET(x[i], cand[i]);
-          RANDT_COLD_SET(x_norm, ambient_norm<PARAM>(cand));
-          RANDT_COLD_SYNC();
+          for (int i = 0; i < 4; ++i) RANDT_COLD_SET(x[i], cc[i]);
+          RANDT_COLD_SET(x_norm, ambient_norm<PARAM>(cc));
           cost = cand_cost;
-          to_param<PARAM, NT>(cnd, x, g, H);
+          to_param<PARAM, NT>(cnd, cc, g, H);
 #pragma unroll
-          for (int i = 0; i < NT; ++i) RANDT_COLD_SET(gs[i], g[i] * sigma[i]);
+          for (int i = 0; i < NT; ++i) RANDT_COLD_SET(gs[i], g[i] * sgn[i]);
 #pragma unroll
-          for (int i = 0; i < NS; ++i) RANDT_COLD_SET(Hs[i], H[i] * ss[i]);
-          RANDT_COLD_SYNC();
-          gconv = gradient_converged<PARAM, NT>(x, g, P.gtol);
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+              const double hs = H[sym(i, j)] * ssn[sym(i, j)];
+              RANDT_COLD_SET(Hs[sym(i, j)], hs);
+              if (i == j) RANDT_COLD_SET(diag[i], fmin(fmax(hs, P.dmin), P.dmax));  // the LM diagonal of the new point
+            }
+          gconv = gradient_converged<PARAM, NT>(cc, g, P.gtol);
           step_ok = true;
           const double t = 2.0 * rel - 1.0;
           radius = radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - t * t * t));
           radius = fmin(P.rmax, radius);
           decrease = 2.0;
-          reuse = false;
-          RANDT_COLD_SET(summary_min, fmin(summary_min, cost));
+          // FinalizeIteration...: x is copied to the user parameters when the accepted point lowers the minimum cost
+          if (uni(cost < mincost)) {
+            RANDT_COLD_SET(minimum_cost, cost);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) RANDT_COLD_SET(best[i], cc[i]);
+          }
+          RANDT_COLD_SET(summary_min, fmin(smin, cost));
           RANDT_COLD_SYNC();
           trace_push(tr, trace_len, tid, cost, radius, 1);
         } else {
           step_ok = false;
           radius = radius * fast_rcp(decrease);  // decrease is a power of two: exact
           decrease *= 2.0;
-          reuse = true;
-          RANDT_COLD_SET(summary_min, fmin(summary_min, cand_cost));
+          RANDT_COLD_SET(summary_min, fmin(smin, cand_cost));
           RANDT_COLD_SYNC();
           trace_push(tr, trace_len, tid, cand_cost, radius, 2);
         }
