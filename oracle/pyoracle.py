@@ -223,7 +223,7 @@ class Map:
             raise MemoryError
 
     def __del__(self):
-        if getattr(self, "_p", None):
+        if getattr(self, "_p", None) and lib is not None:   # at interpreter shutdown the module globals may be gone already
             lib().orc_map_destroy(self._p)
             self._p = None
 

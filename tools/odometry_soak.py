@@ -21,10 +21,13 @@ for d in (range(n_drives) if os.environ.get('SOAK_DRIVE') is None else [int(os.e
     traj = synth.make_trajectory(5000 + d, n_scans, step=float(rng.choice([0.15, 0.25, 0.4])))
     scans = [synth.make_scan(world, traj[i], 40000 + 1000 * d + i) for i in range(n_scans)]
     small = dict(submap_size_poses=int(rng.choice([24, 40])), submap_overlap=8)
+    if os.environ.get("SOAK_LAGS") == "1":   # lags beyond the shipped 3: the general window kernel (window_gen.hip)
+        small["smoothing_steps"] = int(rng.choice([3, 4, 5, 6, 7]))
+    param = R.PARAM_MANIFOLD if os.environ.get("SOAK_PARAMS") != "1" else int(rng.choice([R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC]))
     # (the harness feeds no gyro increments, so the IMU factor stays off: with use_imu = 1 and all-zero measurements the
     #  problem contradicts itself, costs are ~1e5 and last-bit differences amplify by 1e4 per scan -- chaos, not parity)
     use_imu, const_vel = 0, int(rng.random() < 0.6)
-    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    mp = R.default_matcher_params(parameterization=param, gnc_steps=3)
     wp = R.window_params(use_imu=use_imu, const_vel=const_vel)
     gpu = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, wp, small)
     cpu = odometry.Odometry(OracleBackend(), mp, wp, small)
@@ -44,5 +47,5 @@ for d in (range(n_drives) if os.environ.get('SOAK_DRIVE') is None else [int(os.e
                   gpu.last_result["termination"] if gpu.last_result is not None else None, getattr(cpu, "last_result", None)))
         worst_t = max(worst_t, dt_)
         worst_r = max(worst_r, abs(synth.wrap_angle(np.arctan2(pg[1], pg[0]) - np.arctan2(pc[1], pc[0]))))
-    print("drive %d: %d scans, imu %d const_vel %d, submaps %d/%d, rejected %d/%d, worst GPU-vs-oracle %.3e m %.3e rad | oracle vs one-ulp-perturbed oracle %.3e m"
-          % (d, n_scans, use_imu, const_vel, gpu.n_finished_submaps, cpu.n_finished_submaps, gpu.n_rejected, cpu.n_rejected, worst_t, worst_r, worst_self))
+    print("drive %d: %d scans, lag %d param %d, imu %d const_vel %d, submaps %d/%d, rejected %d/%d, worst GPU-vs-oracle %.3e m %.3e rad | oracle vs one-ulp-perturbed oracle %.3e m"
+          % (d, n_scans, gpu.smoothing_steps, param, use_imu, const_vel, gpu.n_finished_submaps, cpu.n_finished_submaps, gpu.n_rejected, cpu.n_rejected, worst_t, worst_r, worst_self))

@@ -66,7 +66,7 @@ for case in range(n_cases):
         continue
     k = int(rng.choice([1, 3, 4, 6]))
     mp = R.default_matcher_params(n_neighbours=k, lookup_mahalanobis=int(rng.random() < 0.7), use_intensity=int(rng.random() < 0.7),
-                                  parameterization=int(rng.choice([R.PARAM_AMBIENT4, R.PARAM_MANIFOLD, R.PARAM_VECTOR])),
+                                  parameterization=int(rng.choice([R.PARAM_AMBIENT4, R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC])),
                                   gnc_steps=int(rng.choice([1, 2, 3])))
     rel = synth.se2_mul3(synth.se2_inv3(pose), dpose)
     g4 = synth.pose3_to_pose4(rel + np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(-0.04, 0.04)]))
