@@ -87,3 +87,85 @@ def test_k4_numpy_float32_cell_statistics(env):
             assert np.array_equal(cells["cov"][:, e].view(np.uint32), ref["cov"][:, e].view(np.uint32)), e
         got = np.stack([np.stack([cells["cov"][:, 0], cells["cov"][:, 1]], 1), np.stack([cells["cov"][:, 1], cells["cov"][:, 3]], 1)], 1)
         assert np.allclose(got.astype(np.float64), d["k4_xy_ref"][s][:n], rtol=2e-5, atol=1e-9)
+
+
+# ---- K9: the fixed-lag window path against an answer known by construction (no solver, no oracle).  The moving maps are
+# the fixed cells carried EXACTLY through the inverse poses of a constant-velocity chain X_j = predict(X_{j-1}); at that chain
+# every NDT residual and every motion residual is zero, so it is THE minimiser of the window objective.  Started from
+# perturbed poses and velocities, the window solve has to come back to it: checks the association in front of the window, the
+# NDT terms, the motion factors' zero set against randt_predict_state_param, Plus on every block and the LM loop -- for the
+# tuned three-state kernel, the general kernel (lags > 3, and three-state windows routed to it) and all three block layouts.
+def _lattice_cells(rng, pose3_list):
+    cell = R.CELL_DTYPE
+    xs, ys = np.meshgrid(np.arange(-7.0, 7.1, 2.0), np.arange(-5.0, 5.1, 2.0))
+    n = xs.size
+    fc = np.zeros(n, dtype=cell)
+    S_all = []
+    for i, (x, y) in enumerate(zip(xs.ravel(), ys.ravel())):
+        A = rng.normal(0, 1, (3, 3)) * [0.1, 0.1, 2.0]
+        S = A @ A.T + np.diag([1e-3, 1e-3, 1e-1])
+        S_all.append(S)
+        fc[i]["mean"] = [x + rng.uniform(-0.2, 0.2), y + rng.uniform(-0.2, 0.2), rng.uniform(20, 80)]
+        fc[i]["cov"] = [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]]
+        fc[i]["n"] = 10
+    moving = []
+    for p in pose3_list:
+        Rm = np.array([[np.cos(p[2]), -np.sin(p[2]), 0], [np.sin(p[2]), np.cos(p[2]), 0], [0, 0, 1]])
+        t = np.array([p[0], p[1], 0.0])
+        mc = np.zeros(n, dtype=cell)
+        for i in range(n):
+            mc[i]["mean"] = Rm.T @ (fc[i]["mean"].astype(np.float64) - t)
+            Sm = Rm.T @ S_all[i] @ Rm
+            mc[i]["cov"] = [Sm[0, 0], Sm[0, 1], Sm[0, 2], Sm[1, 1], Sm[1, 2], Sm[2, 2]]
+            mc[i]["n"] = 10
+        moving.append(mc)
+    return fc, moving
+
+
+@pytest.mark.parametrize("param", [R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC])
+@pytest.mark.parametrize("lag,general", [(1, False), (3, False), (3, True), (5, False), (7, False)])
+def test_k9_zero_noise_window_returns_the_constant_velocity_chain(built, param, lag, general):
+    import torch
+
+    old = os.environ.get("RANDT_WINDOW_GENERAL")
+    if general:
+        os.environ["RANDT_WINDOW_GENERAL"] = "1"
+    try:
+        ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    finally:
+        if general:
+            if old is None:
+                del os.environ["RANDT_WINDOW_GENERAL"]
+            else:
+                os.environ["RANDT_WINDOW_GENERAL"] = old
+    rng = np.random.default_rng(99 + lag)
+    pform = R.PARAM_MANIFOLD if param == R.PARAM_MANIFOLD else R.PARAM_VECTOR
+    dt = 0.25
+    chain = [R.make_state(synth.pose3_to_pose4(np.array([0.3, -0.2, 0.1])), lin_vel=(0.8, 0.1), rot_vel=0.2, stamp=0.0)]
+    for j in range(1, lag + 1):
+        chain.append(R.predict_state(chain[-1], j * dt, pform))
+    truth3 = [synth.pose4_to_pose3(np.array(s["pose"])) for s in chain]
+    fc, moving = _lattice_cells(rng, truth3[1:])
+    mapp = R.indoor_map_params()
+    fm = R.Maps(ctx, 1, mapp, 64, with_grid=True)
+    fm.upload(0, fc)
+    fm.reindex()
+    mm = R.Maps(ctx, lag, mapp, 64, with_grid=False)
+    for j in range(lag):
+        mm.upload(j, moving[j])
+    # start: every optimised state off its true pose and velocity
+    states = [chain[0]]
+    for j in range(1, lag + 1):
+        p = truth3[j] + np.array([0.08, -0.05, 0.02]) * (1 if j % 2 else -1)
+        states.append(R.make_state(synth.pose3_to_pose4(p), lin_vel=(0.9, 0.05), rot_vel=0.25, stamp=j * dt))
+    mp = R.default_matcher_params(parameterization=param, n_neighbours=1, gnc_steps=2, function_tolerance=1e-14, parameter_tolerance=1e-13)
+    out, trans, rej, res = R.register_window(ctx, fm, [0], mm, list(range(lag)), np.array(states, dtype=R.STATE_DTYPE), mp, R.window_params(),
+                                             states[-1]["pose"])
+    assert not rej and res["status"] == 0 and res["n_residuals"] == lag * len(fc)
+    for j in range(1, lag + 1):
+        e = synth.pose4_to_pose3(np.array(out[j]["pose"])) - truth3[j]
+        e[2] = (e[2] + np.pi) % (2 * np.pi) - np.pi
+        # cells are float32 (means ~10 m: 1e-6 m quantisation); the objective is zero at the chain up to that
+        assert np.abs(e[:2]).max() < 2e-5 and abs(e[2]) < 2e-6, (j, e)
+        assert np.allclose(out[j]["lin_vel"], chain[0]["lin_vel"], atol=2e-4) and abs(out[j]["rot_vel"] - chain[0]["rot_vel"]) < 2e-4, (j, out[j])
+    assert res["final_cost"] < 1e-3
