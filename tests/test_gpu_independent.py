@@ -123,8 +123,11 @@ def _lattice_cells(rng, pose3_list):
 
 
 @pytest.mark.parametrize("param", [R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC])
-@pytest.mark.parametrize("lag,general", [(1, False), (3, False), (3, True), (5, False), (7, False)])
-def test_k9_zero_noise_window_returns_the_constant_velocity_chain(built, param, lag, general):
+@pytest.mark.parametrize("lag,general,full", [(1, False, False), (3, False, False), (3, True, False), (5, False, False), (7, False, False),
+                                              (3, False, True), (6, False, True)])
+def test_k9_zero_noise_window_returns_the_constant_velocity_chain(built, param, lag, general, full):
+    """full: constant-acceleration layout (acceleration blocks, zero along the chain) + the IMU factor fed with the chain's own
+    heading increments (bias zero): still an exact zero of every residual."""
     import torch
 
     old = os.environ.get("RANDT_WINDOW_GENERAL")
@@ -159,8 +162,10 @@ def test_k9_zero_noise_window_returns_the_constant_velocity_chain(built, param, 
         p = truth3[j] + np.array([0.08, -0.05, 0.02]) * (1 if j % 2 else -1)
         states.append(R.make_state(synth.pose3_to_pose4(p), lin_vel=(0.9, 0.05), rot_vel=0.25, stamp=j * dt))
     mp = R.default_matcher_params(parameterization=param, n_neighbours=1, gnc_steps=2, function_tolerance=1e-14, parameter_tolerance=1e-13)
-    out, trans, rej, res = R.register_window(ctx, fm, [0], mm, list(range(lag)), np.array(states, dtype=R.STATE_DTYPE), mp, R.window_params(),
-                                             states[-1]["pose"])
+    wp = R.window_params(use_imu=1, const_vel=0) if full else R.window_params()
+    imu = np.array([synth.wrap_angle(truth3[j][2] - truth3[j - 1][2]) for j in range(1, lag + 1)]) if full else None
+    out, trans, rej, res = R.register_window(ctx, fm, [0], mm, list(range(lag)), np.array(states, dtype=R.STATE_DTYPE), mp, wp,
+                                             states[-1]["pose"], imu)
     assert not rej and res["status"] == 0 and res["n_residuals"] == lag * len(fc)
     for j in range(1, lag + 1):
         e = synth.pose4_to_pose3(np.array(out[j]["pose"])) - truth3[j]
@@ -168,4 +173,6 @@ def test_k9_zero_noise_window_returns_the_constant_velocity_chain(built, param, 
         # cells are float32 (means ~10 m: 1e-6 m quantisation); the objective is zero at the chain up to that
         assert np.abs(e[:2]).max() < 2e-5 and abs(e[2]) < 2e-6, (j, e)
         assert np.allclose(out[j]["lin_vel"], chain[0]["lin_vel"], atol=2e-4) and abs(out[j]["rot_vel"] - chain[0]["rot_vel"]) < 2e-4, (j, out[j])
+        if full:
+            assert np.abs(out[j]["lin_acc"]).max() < 2e-3 and abs(out[j]["imu_bias"]) < 1e-6, (j, out[j])
     assert res["final_cost"] < 1e-3
