@@ -203,6 +203,9 @@ def warm_up(torch, batch, streams, n):
     torch.cuda.synchronize()
 
 
+_HUNG_THREADS = []   # watchdog victims (a collective that never returned): the process leaves through os._exit
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,10 +311,31 @@ def main():
             if rank == 0:
                 uid.copy_(torch.from_numpy(R.group_unique_id()))
             dist.broadcast(uid, src=0)
+            # ncclCommInitRank is a collective: should it ever hang (a rank that could not open librccl, a bootstrap socket
+            # that does not connect) the bench must still produce its line -- the creation runs under a watchdog, a rank that
+            # gives up says so and all ranks agree on the fallback below.
+            import threading
+            box = {}
+
+            def _make_group():
+                try:
+                    box["grp"] = R.Group(device=local_rank, rank=rank, world=world, unique_id=uid_host, stream=streams[0].cuda_stream)
+                except Exception as e:  # noqa: BLE001 -- every rank must take the same path: agree below
+                    box["err"] = e
+
+            uid_host = uid.cpu().numpy()
+            th = threading.Thread(target=_make_group, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("RANDT_BENCH_GROUP_TIMEOUT", "120")))
+            if th.is_alive():
+                box["err"] = "no answer from randt_group_create_rank within the watchdog time"
+                _HUNG_THREADS.append(th)
             try:
-                grp = R.Group(device=local_rank, rank=rank, world=world, unique_id=uid.cpu().numpy(), stream=streams[0].cuda_stream)
+                if "err" in box:
+                    raise RuntimeError(box["err"])
+                grp = box["grp"]
                 submaps_g = R.Maps(grp.ctxs[0], N_SUBMAPS, mapp, N_SLOTS, storage=(t_cells, t_counts, t_grid), clear=False)
-            except Exception as e:  # noqa: BLE001 -- every rank must take the same path: agree below
+            except Exception as e:  # noqa: BLE001
                 sys.stderr.write("rank %d: randt_group unavailable (%s); falling back to torch.distributed for the exchanges\n" % (rank, e))
                 grp = None
             ok = torch.tensor([1 if grp is not None else 0], dtype=torch.int32, device=dev)
@@ -830,3 +854,7 @@ def cpu_baseline(prob, mp, gpu_pose, budget_s):
 
 if __name__ == "__main__":
     main()
+    if _HUNG_THREADS:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
