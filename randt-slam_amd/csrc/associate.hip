@@ -500,7 +500,10 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   // (a handful of pairs -- the terms of a fixed-lag window -- in chunks of 16 cells: the wavefront-per-cell phases of a
   // chunk are serial rounds, and the launch is all latency)
   int split = 1, ch = ASSOC_CH;
-  if (n_pairs <= 64) {
+  // (a lone batch of up to two pairs per CU -- the size at which the solve takes its split geometry -- is latency too, unless
+  // the caller keeps several batches in flight: RANDT_SOLVE_THROUGHPUT)
+  const bool lone = ctx->solve_mode != RANDT_SOLVE_THROUGHPUT && n_pairs <= 2 * ctx->n_cus;
+  if (n_pairs <= 64 || lone) {
 #ifndef RANDT_ASSOC_SMALL_CH
 #define RANDT_ASSOC_SMALL_CH 16
 #endif

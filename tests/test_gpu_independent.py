@@ -176,3 +176,168 @@ def test_k9_zero_noise_window_returns_the_constant_velocity_chain(built, param, 
         if full:
             assert np.abs(out[j]["lin_acc"]).max() < 2e-3 and abs(out[j]["imu_bias"]) < 1e-6, (j, out[j])
     assert res["final_cost"] < 1e-3
+
+
+# ---- K5 on the device: k_associate against a brute-force numpy enumeration of Map::getClosestCells / getAdjacentIndizes
+# (ndt_map.cpp:101-175: the square window grown ring by ring around the query's slot until k occupied slots are inside or
+# the radius limit is hit, uint32 slot arithmetic without a row-wrap guard, candidates ranked by the fp32 metric), written
+# from the reference's definition in this file -- the oracle is not involved.
+def _brute_closest(cells, grid, size, res, offset, max_dist, q_mean, q_cov, k, metric):
+    F = np.float32
+    n_slots = size * size
+    mx = int((np.float64(q_mean[0]) - offset) / res) & 0xFFFFFFFF
+    my = int((np.float64(q_mean[1]) - offset) / res) & 0xFFFFFFFF
+    center = (my * size + mx) & 0xFFFFFFFF
+    rmax = int(max_dist / res)
+    targets, nadj, radius = [], 0, 0
+    while len(targets) < k and nadj < n_slots:
+        targets, seen = [], []
+        for i in range(-radius, radius + 1):
+            for j in range(-radius, radius + 1):
+                ni = (center + i + j * size) & 0xFFFFFFFF
+                if ni < n_slots and ni not in seen:
+                    seen.append(ni)
+        nadj = len(seen)
+        for ni in seen:
+            ci = grid[ni]
+            if ci >= 0:
+                f = cells[ci]
+                if metric:
+                    S = np.zeros((3, 3))
+                    for e, (a, b) in enumerate([(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]):
+                        S[a, b] = S[b, a] = np.float64(F(f["cov"][e]) + F(q_cov[e]))
+                    mu = (f["mean"].astype(F) - q_mean.astype(F)).astype(np.float64)
+                    d = float(mu @ np.linalg.inv(S) @ mu)
+                else:
+                    d = float(np.hypot(F(q_mean[0]) - F(f["mean"][0]), F(q_mean[1]) - F(f["mean"][1])))
+                targets.append((d, int(ci)))
+        radius += 1
+        if radius >= rmax:
+            break
+    targets.sort()
+    return targets[:k]
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_k5_association_vs_numpy_brute_force(env, metric, seed):
+    torch, dev, ctx, _ = env
+    F = np.float32
+    rng = np.random.default_rng(500 + seed)
+    size, res, max_dist, n_cells, k = 40, 0.5, 4.0, 300, 4
+    offset = -size / 2.0 * res
+    cells = np.zeros(n_cells, dtype=R.CELL_DTYPE)
+    grid = np.full(size * size, -1, dtype=np.int32)
+    for i, s in enumerate(rng.choice(size * size, n_cells, replace=False)):
+        my, mx = divmod(int(s), size)
+        cells[i]["mean"] = [(mx + rng.uniform(.1, .9)) * res + offset, (my + rng.uniform(.1, .9)) * res + offset, rng.uniform(20, 80)]
+        A = rng.normal(0, 1, (3, 3)) * [0.1, 0.1, 3.0]
+        S = A @ A.T + np.diag([1e-3, 1e-3, 1e-2])
+        cells[i]["cov"] = [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]]
+        cells[i]["n"] = 10
+        grid[s] = i
+    n_q = 100
+    mc = np.zeros(n_q, dtype=R.CELL_DTYPE)
+    for i in range(n_q):
+        lim = 11.0 if i % 5 else 9.9          # some queries near / beyond the map edge (row wrap, out-of-range centres)
+        mc[i]["mean"] = [rng.uniform(-lim, lim), rng.uniform(-lim, lim), rng.uniform(20, 80)]
+        A = rng.normal(0, 1, (3, 3)) * [0.1, 0.1, 3.0]
+        S = A @ A.T + np.diag([1e-3, 1e-3, 1e-2])
+        mc[i]["cov"] = [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]]
+        mc[i]["n"] = 8
+    mapp = R.MapParams(size, size, res, 0.0, 0.0, max_dist, 5, 0)
+    fm = R.Maps(ctx, 1, mapp, n_cells, with_grid=True)
+    fm.upload(0, cells, grid)
+    mm = R.Maps(ctx, 1, mapp, 128, with_grid=False)
+    mm.upload(0, mc)
+    th = 0.1
+    pose4 = np.array([[np.cos(th), np.sin(th), 0.3, -0.2]])
+    mp = R.default_matcher_params(n_neighbours=k, lookup_mahalanobis=metric, use_intensity=1)
+    corr = torch.full((1, 128, k), -7, dtype=torch.int32, device=dev)
+    R.associate_batch(ctx, fm, torch.zeros(1, dtype=torch.int32, device=dev), mm, 0, 1, torch.from_numpy(pose4).to(dev), mp, corr)
+    ctx.synchronize()
+    got_all = corr.cpu().numpy()[0]
+    # the query as the reference forms it: float affine of the guess (transformMap / transformCell, ndt_matcher.cpp:203-209)
+    c, s, tx, ty = F(np.cos(th)), F(np.sin(th)), F(0.3), F(-0.2)
+    Rm = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    mism = 0
+    for i in range(n_q):
+        x, y = F(mc[i]["mean"][0]), F(mc[i]["mean"][1])
+        qm = np.array([(c * x - s * y) + tx, (s * x + c * y) + ty, mc[i]["mean"][2]], dtype=F)
+        cv = mc[i]["cov"].astype(np.float64)
+        Sq = Rm @ np.array([[cv[0], cv[1], cv[2]], [cv[1], cv[3], cv[4]], [cv[2], cv[4], cv[5]]]) @ Rm.T
+        qc = np.array([Sq[0, 0], Sq[0, 1], Sq[0, 2], Sq[1, 1], Sq[1, 2], Sq[2, 2]], dtype=F)
+        ref = _brute_closest(cells, grid, size, res, offset, max_dist, qm, qc, k, metric)
+        got = [int(v) for v in got_all[i] if v >= 0]
+        assert len(got) == len(ref), (i, got, ref)
+        if got != [r[1] for r in ref]:
+            mism += 1                        # fp32 (device) against fp64 (brute force) distances: near-ties may swap, nothing else
+            assert sorted(got) == sorted(r[1] for r in ref) or len(ref) == k, (i, got, ref)
+    assert mism <= 3, mism
+
+
+# ---- f-2 on the device: Map::calculateCSDivergence (ndt_map.cpp:36-99) against the definition evaluated in numpy float64
+# (pair term 0.5 / sqrt(pi^2 det(Sf + Sq)) exp(-d^T (Sf + Sq)^-1 d / 2); a map's own term sums sqrt(det(S^-1)) / (2 pi) and
+# twice the pair terms with every EARLIER cell, over the cells whose det(S) >= 1e-5; CS = -log I + log(F) / 2 + log(M) / 2).
+def test_cs_divergence_vs_numpy_definition(env):
+    from randt_slam_amd import host
+
+    torch, dev, ctx, _ = env
+    rng = np.random.default_rng(77)
+
+    def rand_cells(n, centres=None):
+        c = np.zeros(n, dtype=R.CELL_DTYPE)
+        for i in range(n):
+            base = np.array([rng.uniform(-8, 8), rng.uniform(-8, 8), rng.uniform(20, 80)]) if centres is None else \
+                centres[i % len(centres)] + np.array([rng.uniform(-.3, .3), rng.uniform(-.3, .3), rng.uniform(-3, 3)])
+            A = rng.normal(0, 1, (3, 3)) * [0.15, 0.15, 2.0]
+            S = A @ A.T + np.diag([1e-3 if i % 7 else 1e-5, 1e-3 if i % 7 else 1e-5, 1e-2 if i % 7 else 1e-4])
+            if i % 7 == 0:
+                S *= 1e-2                                   # a few nearly degenerate cells: the det(S) < 1e-5 gate
+            c[i]["mean"], c[i]["cov"], c[i]["n"] = base, [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]], 9
+        return c
+
+    fc = rand_cells(60)
+    mc = rand_cells(50, centres=[f["mean"].astype(np.float64) for f in fc])
+
+    def full(c):
+        c = c.astype(np.float64)
+        return np.array([[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]])
+
+    def pair(a, b):
+        S = full(a["cov"]) + full(b["cov"])
+        d = a["mean"].astype(np.float64) - b["mean"].astype(np.float64)
+        return 0.5 / np.sqrt(np.pi ** 2 * np.linalg.det(S)) * np.exp(-0.5 * d @ np.linalg.solve(S, d))
+
+    def own(cells):
+        t = 0.0
+        for i, a in enumerate(cells):
+            det = np.linalg.det(full(a["cov"]))
+            assert abs(det / 1e-5 - 1.0) > 0.05            # no cell sits on the gate, where fp32 and fp64 could disagree
+            if det < 1e-5:
+                continue
+            t += np.sqrt(np.linalg.det(np.linalg.inv(full(a["cov"])))) / (2 * np.pi)
+            t += sum(2 * pair(a, cells[j]) for j in range(i))
+        return t
+
+    inter = sum(pair(a, b) for a in fc if np.linalg.det(full(a["cov"])) >= 1e-5 for b in mc)
+    ref_terms = np.array([inter, own(fc), own(mc)])
+    ref = -np.log(inter) + 0.5 * np.log(ref_terms[1]) + 0.5 * np.log(ref_terms[2])
+    mapp = R.indoor_map_params()
+    fm = R.Maps(ctx, 1, mapp, 64, with_grid=True)
+    fm.upload(0, fc)
+    fm.reindex()
+    mm = R.Maps(ctx, 1, mapp, 64, with_grid=False)
+    mm.upload(0, mc)
+    out = torch.zeros(1, dtype=torch.float64, device=dev)
+    terms = torch.zeros((1, 3), dtype=torch.float64, device=dev)
+    ident = torch.tensor([[1.0, 0.0, 0.0, 0.0]], dtype=torch.float64, device=dev)
+    host.cs_divergence_batch(ctx, fm, 0, 1, torch.zeros(1, dtype=torch.int32, device=dev), mm, 0, 1, ident, out, terms)
+    ctx.synchronize()
+    assert sum(np.linalg.det(full(a["cov"])) < 1e-5 for a in fc) >= 3
+    got = terms.cpu().numpy()[0]
+    assert np.isclose(got[0], ref_terms[0], rtol=3e-5), (got, ref_terms)                # fp32 pair terms (Sf + Sq is well conditioned)
+    # the maps' own terms hold sqrt(det(S^-1)) of single cells: the reference's float cofactor determinant of a covariance
+    # with condition number ~1e3 carries ~1e-3 relative error against float64
+    assert np.allclose(got[1:], ref_terms[1:], rtol=3e-3), (got, ref_terms)
+    assert np.isclose(out.cpu().numpy()[0], ref, rtol=0, atol=3e-3)
