@@ -473,12 +473,18 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   RANDT_TICK(7);
 
   const int g = tid & 7, gbase = lane & ~7, group = tid >> 3;
-  // pass-1 chain of lane g: sum x, sum y, sum i, max i;  pass-2 chain: c00 c11 c22 c01 c02 c12
+  // Eight lanes per cluster.  The sums are SEQUENTIAL fp32 chains in the reference's point order (one addition per point
+  // and chain, nothing to parallelise), so what counts is how few instructions a point costs the wavefront:
+  //   pass 1: lanes 0..2 carry sum x / y / i -- one v_add per point.  The maximum is order-free and exact: all eight lanes
+  //           take every eighth point and combine afterwards (it used to ride in the serial loop, doubling its length);
+  //   pass 2: every lane forms ONE deviation d = p[j] - mean per point and takes the second factor from a neighbour with a
+  //           quad permutation (chains sit so that ONE pattern serves both quads): sub, mul, add instead of two subs, mul, add.
+  //   lane : 0     1     2     3    4    5     6     7
+  //   d of : x     y     x     y    i    i     x     y          second factor = d of quad lanes [0, 1, 1, 1]
+  //   chain: c00   c11   c01   -    -    c22   c02   c12
   const float* p1 = g == 0 ? sx : (g == 1 ? sy : si);
-  const float* pa = (g == 0 || g == 3 || g == 4) ? sx : ((g == 1 || g == 5) ? sy : si);
-  const float* pb = (g == 0) ? sx : ((g == 1 || g == 3) ? sy : si);
-  const int ia = (g == 0 || g == 3 || g == 4) ? 0 : ((g == 1 || g == 5) ? 1 : 2);
-  const int ib = (g == 0) ? 0 : ((g == 1 || g == 3) ? 1 : 2);
+  const float* pd = (g == 0 || g == 2 || g == 6) ? sx : ((g == 1 || g == 3 || g == 7) ? sy : si);
+  const int id = (g == 0 || g == 2 || g == 6) ? 0 : ((g == 1 || g == 3 || g == 7) ? 1 : 2);
   for (int r0 = 0; r0 < nc; r0 += BUILD_BLOCK / 8) {
     const int oc = r0 + group;
     const int c = oc < nc ? (int)order[oc] : -1;
@@ -491,31 +497,114 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       }
     }
     const int k = e - s;
-    // per-lane trip counts: the hardware masks the lanes of finished clusters (cheaper than selecting per point)
-    float acc = 0.f, accm = 0.f;  // two independent one-op chains per point: sum (lanes 0..2) and max (lane 3)
-#pragma unroll 8
-    for (int j = s; j < e; ++j) {
-      const float v = p1[j];
-      acc += v;
-      accm = fmaxf(accm, v);  // std::max(max_intensity_, intensity): one v_max_f32 (NaN-free data; +0 start)
+    // The serial loops take EIGHT points per trip, software-pipelined: the reads of the next eight are in flight while
+    // the dependent chain consumes the current eight, and the per-lane bounds (exec masking) are paid once per eight points;
+    // at most seven points are left for the plain loop behind.
+    float acc = 0.f;
+    {
+      const float* q = p1 + s;
+      int j = 0;
+      if (k >= 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = q[u];
+        for (; j + 24 <= k; j += 16) {  // two blocks per trip: the buffers swap roles, no register copies
+          float w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w[u] = q[j + 8 + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += v[u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = q[j + 16 + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += w[u];
+        }
+        if (j + 16 <= k) {
+          float w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w[u] = q[j + 8 + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += v[u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = w[u];
+          j += 8;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+        j += 8;
+      }
+      for (; j < k; ++j) acc += q[j];
+    }
+    float accm = 0.f;  // std::max(max_intensity_, intensity) from +0 (NaN-free data): exact in any order
+    {
+      int j = s + g;
+      for (; j + 24 < e; j += 32) {
+        const float v0 = si[j], v1 = si[j + 8], v2 = si[j + 16], v3 = si[j + 24];
+        const float a = v0 > v1 ? v0 : v1, b = v2 > v3 ? v2 : v3;
+        const float c = a > b ? a : b;
+        accm = c > accm ? c : accm;
+      }
+      for (; j < e; j += 8) {
+        const float v = si[j];
+        accm = v > accm ? v : accm;
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      const float o = __shfl_xor(accm, off, 64);
+      accm = o > accm ? o : accm;
     }
     if (r0 == 0) RANDT_TICK(10);
     const float nf = (float)(uint32_t)k;
     const float mean = acc / nf;
     const float m0 = __shfl(mean, gbase + 0, 64), m1 = __shfl(mean, gbase + 1, 64), m2 = __shfl(mean, gbase + 2, 64);
-    const float maxi = __shfl(accm, gbase + 3, 64);
-    const float ma = ia == 0 ? m0 : (ia == 1 ? m1 : m2);
-    const float mb = ib == 0 ? m0 : (ib == 1 ? m1 : m2);
+    const float maxi = accm;
+    const float md = id == 0 ? m0 : (id == 1 ? m1 : m2);
     float cacc = 0.f;
-#pragma unroll 8
-    for (int j = s; j < e; ++j) {
-      const float da = pa[j] - ma, db = pb[j] - mb;
-      cacc += (da * db);
+    {
+      const float* q = pd + s;
+      // second factor: the deviation a quad neighbour formed (a quad belongs to one cluster: its lanes run the same trips)
+      auto term = [&](float v) {
+        const float da = v - md;
+        const float db = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(da), 0x54 /* quad_perm [0,1,1,1] */, 0xf, 0xf, true));
+        cacc += (da * db);
+      };
+      int j = 0;
+      if (k >= 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = q[u];
+        for (; j + 24 <= k; j += 16) {
+          float w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w[u] = q[j + 8 + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) term(v[u]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = q[j + 16 + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) term(w[u]);
+        }
+        if (j + 16 <= k) {
+          float w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w[u] = q[j + 8 + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) term(v[u]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = w[u];
+          j += 8;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) term(v[u]);
+        j += 8;
+      }
+      for (; j < k; ++j) term(q[j]);
     }
     if (r0 == 0) RANDT_TICK(11);
     const float cv = cacc / nf;
-    const float c00 = __shfl(cv, gbase + 0, 64), c11 = __shfl(cv, gbase + 1, 64), c22 = __shfl(cv, gbase + 2, 64);
-    const float c01 = __shfl(cv, gbase + 3, 64), c02 = __shfl(cv, gbase + 4, 64), c12 = __shfl(cv, gbase + 5, 64);
+    const float c00 = __shfl(cv, gbase + 0, 64), c11 = __shfl(cv, gbase + 1, 64), c22 = __shfl(cv, gbase + 5, 64);
+    const float c01 = __shfl(cv, gbase + 2, 64), c02 = __shfl(cv, gbase + 6, 64), c12 = __shfl(cv, gbase + 7, 64);
     if (g == 0 && k > 0) {
       randt_cell cell;
       cell.mean[0] = m0;
