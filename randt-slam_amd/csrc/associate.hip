@@ -35,9 +35,8 @@ using namespace randt_dev;
 #define ASSOC_MAX_R 7    // window <= 15x15 = 225 slots = 4 lane passes
 #define ASSOC_PASSES 4
 #ifndef ASSOC_CH
-#define ASSOC_CH 64      // moving cells per chunk (64 or 128)
-#endif
-#define ASSOC_CH_LOG2 (ASSOC_CH == 128 ? 7 : 6)
+#define ASSOC_CH 64      // moving cells per chunk of the widest instantiation; the kernel is a template on the chunk size CH (16 / 32 / 64):
+#endif                   // the LDS of a workgroup is proportional to it (36 KB at 64, 18 KB at 32), and what a co-running batch pays for is LDS x time
 #define ASSOC_CAND 64    // candidates per cell: <= (k-1) + 8R = 63 for k <= 8, R <= 7
 #define ASSOC_CS 65      // LDS stride of a cell's candidate / slot row (odd: thread-per-cell accesses are conflict-free)
 #define ASSOC_QS 11      // LDS stride of a query record (odd => conflict-free)
@@ -98,13 +97,26 @@ __device__ __forceinline__ unsigned long long prefix_mask(int n) {
   return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
 }
 
-template <bool STAGE_GRID>
-__global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const int32_t* __restrict__ fixed_idx,
+#ifdef RANDT_ASSOC_VGPR  // experiment knob (tools/ab_build.sh)
+#define RANDT_ASSOC_ATTR __attribute__((amdgpu_num_vgpr(RANDT_ASSOC_VGPR)))
+#else
+#define RANDT_ASSOC_ATTR
+#endif
+template <bool STAGE_GRID, int CH>
+__global__ __launch_bounds__(ASSOC_BLOCK) RANDT_ASSOC_ATTR void k_associate(MapView fixed, const int32_t* __restrict__ fixed_idx,
                                                            MapView moving, int moving_first,
                                                            const int32_t* __restrict__ moving_idx,
                                                            const double* __restrict__ guess4, int k, int metric_mahal,
-                                                           int transform_full, int32_t* __restrict__ corr, int ch /* cells per chunk <= ASSOC_CH */) {
+                                                           int transform_full, int32_t* __restrict__ corr, int ch /* cells per chunk <= CH */) {
+  constexpr int CH_LOG2 = CH > 64 ? 7 : (CH > 32 ? 6 : (CH > 16 ? 5 : 4));
+  static_assert(CH % ASSOC_WAVES == 0 && CH >= 16 && CH <= 64, "chunk size (P2a runs one thread per cell on ONE wavefront)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // This kernel is a chain of L2 round trips with a few instructions between them.  Sharing a SIMD with solve wavefronts
+  // (16 batches in flight: three fp64-bound wavefronts per SIMD that are older, and the issue arbiter prefers older ones) it
+  // used to wait for the issue port at every step of that chain while holding 36 KB of LDS.  Raised issue priority lets it
+  // through -- it needs few slots, the solves hardly notice: 9.67 -> 10.54 M registrations/s together with the same line in
+  // k_ndt_build (profiles/experiments/r03_issue_priority.md).
+  __builtin_amdgcn_s_setprio(RANDT_LATENCY_KERNEL_PRIO);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pair = blockIdx.x;
   const int fmap = fixed_idx ? fixed_idx[pair] : 0;
@@ -122,15 +134,15 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
   const int grid_words = STAGE_GRID ? ((n_slots + 3) & ~3) : 0;
   int32_t* wtab = lgrid + grid_words;                       // [256] packed (i+128) << 8 | (j+128)
   float* qrec = reinterpret_cast<float*>(wtab + 256);       // [CH][QS]: mean3, cov6, centre(bits), pad
-  int32_t* clen = reinterpret_cast<int32_t*>(qrec + ASSOC_CH * ASSOC_QS + 1);  // [CH]
-  int32_t* cpref = clen + ASSOC_CH;                         // [CH + 1]
-  int32_t* cand = cpref + ASSOC_CH + 4;                     // [CH][CS]
-  float* cdist = reinterpret_cast<float*>(cand + ASSOC_CH * ASSOC_CS);  // [CH][CS]
+  int32_t* clen = reinterpret_cast<int32_t*>(qrec + CH * ASSOC_QS + 1);  // [CH]
+  int32_t* cpref = clen + CH;                         // [CH + 1]
+  int32_t* cand = cpref + CH + 4;                     // [CH][CS]
+  float* cdist = reinterpret_cast<float*>(cand + CH * ASSOC_CS);  // [CH][CS]
   int32_t* p0tab = reinterpret_cast<int32_t*>(cdist);       // [CH][CS] window slots 0..63 of every cell (dead before P3 writes cdist)
   // [CH][2] occupied / in-range bits; CH * CS is odd, so the word offset is rounded up to an even one (8-byte aligned ds_read_b64)
   unsigned long long* pmask = reinterpret_cast<unsigned long long*>(
-      smem + ((static_cast<size_t>(reinterpret_cast<char*>(cdist + ASSOC_CH * ASSOC_CS) - smem) + 7) & ~static_cast<size_t>(7)));
-  int32_t* ulist = reinterpret_cast<int32_t*>(pmask + 2 * ASSOC_CH);                                // [CH + 1] cells left to P2b, count last
+      smem + ((static_cast<size_t>(reinterpret_cast<char*>(cdist + CH * ASSOC_CS) - smem) + 7) & ~static_cast<size_t>(7)));
+  int32_t* ulist = reinterpret_cast<int32_t*>(pmask + 2 * CH);                                // [CH + 1] cells left to P2b, count last
 
   const int R = fixed.rmax - 1 > 0 ? fixed.rmax - 1 : 0;  // last radius the reference evaluates
   const int side = 2 * R + 1, nwin = side * side;
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     // ---- P1b: slots 0..63 of every cell's window (one wavefront per cell; all gathers of the chunk in flight together)
     {
       const int lane_i = (wtab[lane] >> 8) - 128, lane_j = (wtab[lane] & 255) - 128;
-      constexpr int PER_WAVE = ASSOC_CH / ASSOC_WAVES;
+      constexpr int PER_WAVE = CH / ASSOC_WAVES;
       int32_t civ[PER_WAVE];
 #pragma unroll
       for (int t = 0; t < PER_WAVE; ++t) {  // every request of this wavefront's cells first ...
@@ -255,11 +267,11 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
       const bool open = c < nch && len < 0;
       const unsigned long long om = __ballot(open);
       if (open) ulist[__popcll(om & prefix_mask(lane))] = c;
-      if (lane == 0) ulist[ASSOC_CH] = __popcll(om);
+      if (lane == 0) ulist[CH] = __popcll(om);
     }
     __syncthreads();
     // ---- P2b: the cells P2a left open, one wavefront per cell (outer rings / wrapping windows)
-    const int n_open = ulist[ASSOC_CH];
+    const int n_open = ulist[CH];
     for (int u = wave; u < n_open; u += ASSOC_WAVES) {
       const int c = ulist[u];
       const uint32_t center = __float_as_uint(qrec[c * ASSOC_QS + 9]);
@@ -399,24 +411,24 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
     if (wave == 0) {
       int carry = 0;
 #pragma unroll
-      for (int h = 0; h < ASSOC_CH / 64; ++h) {
+      for (int h = 0; h < (CH + 63) / 64; ++h) {
         const int e = h * 64 + lane;
         const int v = e < nch ? clen[e] : 0;
         const int incl = wave_inclusive_scan(v);
-        cpref[e] = carry + incl - v;
+        if (e < CH) cpref[e] = carry + incl - v;
         carry += __builtin_amdgcn_readlane(incl, 63);
       }
-      if (lane == 0) cpref[ASSOC_CH] = carry;
+      if (lane == 0) cpref[CH] = carry;
     }
     __syncthreads();
-    const int total = cpref[ASSOC_CH];
+    const int total = cpref[CH];
 
     ASSOC_TICK(3);
     // ---- P3: one thread per (cell, candidate): gather + fp32 distance
     for (int p = tid; p < total; p += ASSOC_BLOCK) {
       int lo = 0, hi = nch;  // largest c with cpref[c] <= p
 #pragma unroll
-      for (int s = 0; s < ASSOC_CH_LOG2 + 1; ++s) {
+      for (int s = 0; s < CH_LOG2 + 1; ++s) {
         const int mid = (lo + hi) >> 1;
         if (hi - lo > 1) {
           if (cpref[mid] <= p) lo = mid; else hi = mid;
@@ -475,13 +487,34 @@ __global__ __launch_bounds__(ASSOC_BLOCK) void k_associate(MapView fixed, const 
   }
 }
 
-size_t assoc_lds_bytes(int n_slots, bool stage) {
-  size_t words = (stage ? ((n_slots + 3) & ~3) : 0) + 256 + (ASSOC_CH * ASSOC_QS + 1) + ASSOC_CH + (ASSOC_CH + 4) +
-                 2 * ASSOC_CH * ASSOC_CS + 2 /* pmask alignment */ + 4 * ASSOC_CH + ASSOC_CH + 4;
+size_t assoc_lds_bytes(int n_slots, bool stage, int CH = ASSOC_CH) {
+  size_t words = (stage ? ((n_slots + 3) & ~3) : 0) + 256 + (CH * ASSOC_QS + 1) + CH + (CH + 4) +
+                 2 * CH * ASSOC_CS + 2 /* pmask alignment */ + 4 * CH + CH + 4;
   return words * 4 + 64;
 }
 
+template <bool STAGE, int CH>
+int launch_associate_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
+                         int n_pairs, const double* d_guess4, int k, int full, int32_t* d_corr, const int32_t* d_moving_idx, bool spread) {
+  const size_t lds = assoc_lds_bytes(fixed.n_slots, STAGE, CH);
+  int split = 1;
+  if (spread) {
+    split = (moving.cap + CH - 1) / CH;
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+  }
+  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<STAGE, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_associate<STAGE, CH>), dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
+                     moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, CH);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
+
 }  // namespace
+
+#ifndef RANDT_ASSOC_SMALL_CH
+#define RANDT_ASSOC_SMALL_CH 16
+#endif
 
 int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
                      int moving_first, int n_pairs, const double* d_guess4, int k, int lookup_mahalanobis,
@@ -495,34 +528,24 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "maps with <= 225 slots not supported by the association kernel", hipSuccess);
   const int full = (use_intensity && lookup_mahalanobis) ? 1 : 0;
   const bool stage = ctx->assoc_stage_grid && assoc_lds_bytes(fixed.n_slots, true) <= (size_t)ctx->lds_limit / 2;
-  const size_t lds = assoc_lds_bytes(fixed.n_slots, stage);
-  // small batches: one workgroup per (pair, chunk); large ones fill the chip by pairs alone
-  // (a handful of pairs -- the terms of a fixed-lag window -- in chunks of 16 cells: the wavefront-per-cell phases of a
-  // chunk are serial rounds, and the launch is all latency)
-  int split = 1, ch = ASSOC_CH;
-  // (a lone batch of up to two pairs per CU -- the size at which the solve takes its split geometry -- is latency too, unless
-  // the caller keeps several batches in flight: RANDT_SOLVE_THROUGHPUT)
+  // Chunk size and placement.  A handful of pairs (the terms of a fixed-lag window, one loop-closure candidate) and a lone
+  // batch of up to two pairs per CU (the size at which the solve takes its split geometry) are all latency: one workgroup per
+  // (pair, chunk), 16-cell chunks for the handful (the wavefront-per-cell phases of a chunk are serial rounds).  Batches
+  // that share the chip with other batches (RANDT_SOLVE_THROUGHPUT, or more than two pairs per CU) are charged for LDS x
+  // time: one workgroup per pair walking RANDT_ASSOC_TP_CH-cell chunks.
   const bool lone = ctx->solve_mode != RANDT_SOLVE_THROUGHPUT && n_pairs <= 2 * ctx->n_cus;
-  if (n_pairs <= 64 || lone) {
-#ifndef RANDT_ASSOC_SMALL_CH
-#define RANDT_ASSOC_SMALL_CH 16
-#endif
-    ch = n_pairs <= 8 ? RANDT_ASSOC_SMALL_CH : ASSOC_CH;
-    split = (moving.cap + ch - 1) / ch;
-    if (split > 64) split = 64;
-    if (split < 1) split = 1;
-  }
+  const bool spread = n_pairs <= 64 || lone;
+  const int chunk = spread ? (n_pairs <= 8 ? RANDT_ASSOC_SMALL_CH : ASSOC_CH) : ctx->assoc_tp_ch;
+#define RANDT_ASSOC_GO(ST, CC) \
+  return launch_associate_cfg<ST, CC>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_guess4, k, full, d_corr, d_moving_idx, spread)
   if (stage) {
-    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_associate<true>, dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
-                       moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, ch);
-  } else {
-    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_associate<false>, dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx,
-                       moving, moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, ch);
+    if (chunk <= 16) RANDT_ASSOC_GO(true, 16);
+    if (chunk <= 32) RANDT_ASSOC_GO(true, 32);
+    RANDT_ASSOC_GO(true, 64);
   }
-  RANDT_HIP_CHECK(ctx, hipGetLastError());
-  return RANDT_OK;
+  if (chunk <= 16) RANDT_ASSOC_GO(false, 16);
+  if (chunk <= 32) RANDT_ASSOC_GO(false, 32);
+  if (chunk <= 48) RANDT_ASSOC_GO(false, 48);
+  RANDT_ASSOC_GO(false, 64);
+#undef RANDT_ASSOC_GO
 }

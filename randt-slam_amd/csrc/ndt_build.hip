@@ -133,12 +133,15 @@ template <bool REG>
 __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restrict__ pts, int pitch,
                                                            const int32_t* __restrict__ n_pts_arr, int stride,
                                                            int ioff, int row_size, float resolution, MapView out,
-                                                           int first_map, int npad, int nb_cap, int aux_bytes,
+                                                           int first_map, int npad, int nb_cap, int aux_bytes, int bigcap,
                                                            int32_t* __restrict__ fallback_ws, int lane_ordered_atomics,
                                                            int32_t* misrank_word) {
   constexpr int PPT = 8;
   constexpr bool KEEP = REG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // latency-bound chains (LDS atomics, the serial fp32 sums) that hold 30 KB of LDS: raised issue priority, so that solve
+  // wavefronts sharing the SIMD do not stretch them (see k_associate)
+  __builtin_amdgcn_s_setprio(RANDT_LATENCY_KERNEL_PRIO);
   // points in labelClouds order; the three arrays are shifted by 16 banks against each other because the
   // lanes of a cluster group read x[j], y[j] and i[j] in the same instruction.
   // REG  : [ sx | sy | si  ==  bins ] | cstart u16 | order u16 | pre u16 | scratch        (37 KB at N = 2048: 4 per CU)
@@ -154,21 +157,24 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   unsigned long long* bins;
   int* scratch;
   int32_t* plab = nullptr;
-  uint16_t *order, *pre;
+  // blist[i]: the cluster that becomes compact cell i (clusters above min_points, in label order; bit 15: its mean fell outside
+  // the map); order[j]: those i in hand-out order.  At most n / (min_points + 1) clusters qualify (bigcap), so these lists take
+  // 1.4 KB at N = 2000 instead of two per-cluster arrays of 8 KB: 30.5 KB per workgroup, FIVE workgroups per CU instead of four.
+  uint16_t *order, *blist;
   if (REG) {
     bins = reinterpret_cast<unsigned long long*>(smem);
     char* p = smem + aux_bytes;  // aux_bytes = max(points, bins)
     cstart = reinterpret_cast<uint16_t*>(p);
     order = reinterpret_cast<uint16_t*>(p + cstart_bytes);
-    pre = order + npad;
-    scratch = reinterpret_cast<int*>(pre + npad);
+    blist = order + bigcap;
+    scratch = reinterpret_cast<int*>(blist + bigcap);  // bigcap is a multiple of 8: 16-byte aligned
   } else {
     cstart = reinterpret_cast<uint16_t*>(after_pts);
     bins = reinterpret_cast<unsigned long long*>(after_pts + cstart_bytes);
     scratch = reinterpret_cast<int*>(reinterpret_cast<char*>(bins) + aux_bytes);  // [64]
     plab = scratch + 64;  // per-point word [npad] (label, later bin | rank)
     order = reinterpret_cast<uint16_t*>(plab);
-    pre = order + npad;
+    blist = order + bigcap;
   }
   // fallback only: unsorted / sorted labels in global memory (rare path, 2 x npad words per scan)
   int32_t* lab = fallback_ws + (size_t)blockIdx.x * 2 * npad;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     const int big = (c < nc && (long long)(cstart[c + 1] - cstart[c]) > (long long)out.min_points) ? 1 : 0;
     int tot;
     const int idx = n_cells + block_exclusive_scan_256(big, scratch, &tot);
-    if (c < nc) pre[c] = (uint16_t)(big ? (idx < 0xffff ? idx : 0xfffe) : 0xffff);
+    if (big && idx < bigcap) blist[idx] = (uint16_t)c;  // (idx < bigcap always: at most n / (min_points + 1) clusters are this large)
     n_cells += tot;
   }
   RANDT_TICK(6);
@@ -454,7 +460,9 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   if (tid < 32) bcount[tid] = 0;
   if (tid == 0) scratch[4] = 0;  // "a cluster mean fell outside the map"
   __syncthreads();
-  for (int c = tid; c < nc; c += BUILD_BLOCK) {
+  const int n_big = n_cells < bigcap ? n_cells : bigcap;
+  for (int i = tid; i < n_big; i += BUILD_BLOCK) {
+    const int c = blist[i];
     const int kc = (cstart[c + 1] - cstart[c]) >> 3;
     atomicAdd(&bcount[31 - (kc < 31 ? kc : 31)], 1);
   }
@@ -465,9 +473,10 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     if (tid < 32) bcount[tid] = incl - v;
   }
   __syncthreads();
-  for (int c = tid; c < nc; c += BUILD_BLOCK) {
+  for (int i = tid; i < n_big; i += BUILD_BLOCK) {
+    const int c = blist[i];
     const int kc = (cstart[c + 1] - cstart[c]) >> 3;
-    order[atomicAdd(&bcount[31 - (kc < 31 ? kc : 31)], 1)] = (uint16_t)c;
+    order[atomicAdd(&bcount[31 - (kc < 31 ? kc : 31)], 1)] = (uint16_t)i;
   }
   __syncthreads();
   RANDT_TICK(7);
@@ -485,16 +494,14 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
   const float* p1 = g == 0 ? sx : (g == 1 ? sy : si);
   const float* pd = (g == 0 || g == 2 || g == 6) ? sx : ((g == 1 || g == 3 || g == 7) ? sy : si);
   const int id = (g == 0 || g == 2 || g == 6) ? 0 : ((g == 1 || g == 3 || g == 7) ? 1 : 2);
-  for (int r0 = 0; r0 < nc; r0 += BUILD_BLOCK / 8) {
+  for (int r0 = 0; r0 < n_big; r0 += BUILD_BLOCK / 8) {  // only clusters that become cells are handed out
     const int oc = r0 + group;
-    const int c = oc < nc ? (int)order[oc] : -1;
-    int s = 0, e = 0, target = 0xffff;
-    if (c >= 0) {
-      target = pre[c];
-      if (target != 0xffff) {
-        s = cstart[c];
-        e = cstart[c + 1];
-      }
+    int s = 0, e = 0, target = 0xffff, c = -1;
+    if (oc < n_big) {
+      target = order[oc];
+      c = blist[target];
+      s = cstart[c];
+      e = cstart[c + 1];
     }
     const int k = e - s;
     // The serial loops take EIGHT points per trip, software-pipelined: the reads of the next eight are in flight while
@@ -621,16 +628,16 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
       cell.reserved = 0;
       cell_regularize(cell);
       const uint32_t slot = coord_to_index(out, cell.mean[0], cell.mean[1]);
-      if (slot < (uint32_t)out.n_slots && target != 0xfffe) {  // reference: vector::at throws otherwise
+      if (slot < (uint32_t)out.n_slots) {  // reference: vector::at throws otherwise
         if (target < out.cap) {
           store_cell(cells + target, cell);
           // later cluster overwrites the slot, both cells stay in grid_ (quirk A.7-5)
           if (grid) atomicMax(&grid[slot], target);
         }
       } else {
-        // dropped: later cells move down.  2 = cannot be repaired by moving cells (index marker overflow)
-        atomicMax(&scratch[4], target == 0xfffe ? 2 : 1);
-        if (target != 0xfffe) pre[c] = 0xfffd;
+        // dropped: later cells move down
+        atomicMax(&scratch[4], 1);
+        blist[target] = (uint16_t)(c | 0x8000);
       }
     }
     if (r0 == 0) RANDT_TICK(12);
@@ -649,10 +656,9 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restri
     }
     __syncthreads();
     int n_final = 0;
-    for (int c0 = 0; c0 < nc; c0 += BUILD_BLOCK) {
-      const int c = c0 + tid;
-      const int prov = c < nc ? (int)pre[c] : 0xffff;
-      const bool keep = prov < 0xfffd;
+    for (int c0 = 0; c0 < n_big; c0 += BUILD_BLOCK) {
+      const int prov = c0 + tid;
+      const bool keep = prov < n_big && (blist[prov] & 0x8000) == 0;
       randt_cell cell;
       if (keep) cell = load_cell(cells + prov);
       int tot;
@@ -816,10 +822,16 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   const size_t cstart_bytes = (((size_t)npad + 2) * 2 + 15) & ~(size_t)15;
   size_t lds, aux;
   int nb_cap;
+  // clusters that can become cells: more than min_points points each (lists of two u16 per such cluster, see the kernel)
+  const int mp_eff = out.min_points > 0 ? out.min_points : 0;
+  int bigcap = npad / (mp_eff + 1) + 1;
+  bigcap = (bigcap + 7) & ~7;
+  if (bigcap > npad) bigcap = npad;
   if (reg) {
-    // [points == bins] | cstart | order + pre | scratch
-    const size_t tail = cstart_bytes + (size_t)npad * 4 + 256;
-    size_t budget = (size_t)ctx->lds_limit / 4;
+    // [points == bins] | cstart | order + blist | scratch
+    const size_t tail = cstart_bytes + (size_t)bigcap * 4 + 256;
+    size_t budget = (size_t)ctx->lds_limit / 5;
+    if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit / 4;
     if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit / 3;
     if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit / 2;
     if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit;
@@ -869,7 +881,7 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<REG>),                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
     hipLaunchKernelGGL((k_ndt_build<REG>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,            \
-                       d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux, d_fallback,            \
+                       d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux, bigcap, d_fallback,    \
                        rank_mode, ctx->misrank_word);                                                                       \
   } while (0)
   if (reg) RANDT_BUILD_LAUNCH(true);

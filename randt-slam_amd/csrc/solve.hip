@@ -35,6 +35,19 @@
 
 using namespace randt_solve;
 
+// Issue priority inside the solve (s_setprio): the residual trips are throughput work, the reduction and the solver algebra
+// behind them one dependent fp64 chain per wavefront.  RANDT_SOLVE_PRIO_ALG > 0 raises the chain's priority over the trips of
+// the wavefronts it shares the SIMD with; RANDT_SOLVE_PRIO_PRO is the priority of the prologue (correspondence count and
+// compaction: global round trips).
+#ifndef RANDT_SOLVE_PRIO_ALG
+#define RANDT_SOLVE_PRIO_ALG 0
+#endif
+#ifndef RANDT_SOLVE_PRIO_PRO
+#define RANDT_SOLVE_PRIO_PRO 3
+#endif
+#define RANDT_PRIO_TRIPS() do { if (RANDT_SOLVE_PRIO_ALG > 0) __builtin_amdgcn_s_setprio(0); } while (0)
+#define RANDT_PRIO_CHAIN() do { if (RANDT_SOLVE_PRIO_ALG > 0) __builtin_amdgcn_s_setprio(RANDT_SOLVE_PRIO_ALG); } while (0)
+
 namespace {
 
 // base sums of one pass: cost, g_b (tx, ty, theta), G upper (tt: 00 01 02 11 12 22)
@@ -142,6 +155,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   double c, s, tx, ty;
   pass_pose<D, PARAM>(x, c, s, tx, ty);
   const Rot rot = make_rot(c, s);
+  RANDT_PRIO_TRIPS();
   double acc[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) acc[i] = 0.0;
@@ -182,6 +196,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  RANDT_PRIO_CHAIN();
   double badf = wave_any(bad != 0);
   if (MODE == 0) {
     mx = wave_max(mx);
@@ -562,6 +577,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
   // J^T J.  That takes ~70 registers out of the pass and lets a third wavefront share the SIMD.
   __shared__ double cold_all[RPB * WAVES][56];  // one copy per WAVEFRONT: the two wavefronts of BLOCK = 128 run the solver redundantly and are only synchronised inside a pass
 
+  if (RANDT_SOLVE_PRIO_PRO > 0) __builtin_amdgcn_s_setprio(RANDT_SOLVE_PRIO_PRO);
   const int sub = RPB > 1 ? (int)(threadIdx.x >> 6) : 0;
   const int tid = (RPB > 1 || SPLIT) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   const int split_wave = SPLIT ? (int)(threadIdx.x >> 6) : 0;   // split mode: every wavefront runs the prologue below for itself
@@ -708,6 +724,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
   (SPLIT ? eval_pass_split<D, PARAM, MODE, AM2>(S, XP, L, OUT, &s_req, s_part, s_badflag, split_W, tid) \
          : eval_pass<D, PARAM, MODE, BLOCK, AM2>(S, XP, L, OUT, red, parity, tid))
 
+  if (RANDT_SOLVE_PRIO_PRO > 0 && RANDT_SOLVE_PRIO_ALG != RANDT_SOLVE_PRIO_PRO) __builtin_amdgcn_s_setprio(RANDT_SOLVE_PRIO_ALG);
   // ---- raw residuals at the initial point -> gnc_mu (ndt_matcher.cpp:466-476)
   Loss L = AM2 ? make_loss_am2(P.loss_a, 1.0, P.weight) : make_loss(P.loss_a, P.alpha, 1.0, P.weight);
   Base cur, cnd;
