@@ -97,13 +97,16 @@ __device__ __forceinline__ unsigned long long prefix_mask(int n) {
   return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
 }
 
-#ifdef RANDT_ASSOC_VGPR  // experiment knob (tools/ab_build.sh)
-#define RANDT_ASSOC_ATTR __attribute__((amdgpu_num_vgpr(RANDT_ASSOC_VGPR)))
-#else
-#define RANDT_ASSOC_ATTR
+// TP ("throughput placement"): the batch shares the chip with other batches' solves, whose three wavefronts per SIMD leave
+// 104 of the 512 registers -- this kernel takes 131 when left alone (three wavefronts per SIMD of its own) and then has to wait
+// for a SIMD with only two solve wavefronts.  Held to five per SIMD (96 registers, 22 dwords spilled) it fits beside three:
+// +1.7 % in the pipelined region together with k_ndt_build at 64; a lone batch is latency and keeps the registers
+// (24.5 against 27.2 us per 512 pairs).
+#ifndef RANDT_ASSOC_TP_WPE
+#define RANDT_ASSOC_TP_WPE 5
 #endif
-template <bool STAGE_GRID, int CH>
-__global__ __launch_bounds__(ASSOC_BLOCK) RANDT_ASSOC_ATTR void k_associate(MapView fixed, const int32_t* __restrict__ fixed_idx,
+template <bool STAGE_GRID, int CH, bool TP>
+__global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP ? RANDT_ASSOC_TP_WPE : 1, TP ? RANDT_ASSOC_TP_WPE : 8))) void k_associate(MapView fixed, const int32_t* __restrict__ fixed_idx,
                                                            MapView moving, int moving_first,
                                                            const int32_t* __restrict__ moving_idx,
                                                            const double* __restrict__ guess4, int k, int metric_mahal,
@@ -493,7 +496,7 @@ size_t assoc_lds_bytes(int n_slots, bool stage, int CH = ASSOC_CH) {
   return words * 4 + 64;
 }
 
-template <bool STAGE, int CH>
+template <bool STAGE, int CH, bool TP = false>
 int launch_associate_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
                          int n_pairs, const double* d_guess4, int k, int full, int32_t* d_corr, const int32_t* d_moving_idx, bool spread) {
   const size_t lds = assoc_lds_bytes(fixed.n_slots, STAGE, CH);
@@ -503,8 +506,8 @@ int launch_associate_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_
     if (split > 64) split = 64;
     if (split < 1) split = 1;
   }
-  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<STAGE, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_associate<STAGE, CH>), dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
+  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<STAGE, CH, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_associate<STAGE, CH, TP>), dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
                      moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, CH);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
@@ -546,6 +549,8 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   if (chunk <= 16) RANDT_ASSOC_GO(false, 16);
   if (chunk <= 32) RANDT_ASSOC_GO(false, 32);
   if (chunk <= 48) RANDT_ASSOC_GO(false, 48);
+  if (!spread)
+    return launch_associate_cfg<false, 64, true>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_guess4, k, full, d_corr, d_moving_idx, spread);
   RANDT_ASSOC_GO(false, 64);
 #undef RANDT_ASSOC_GO
 }

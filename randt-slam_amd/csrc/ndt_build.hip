@@ -129,8 +129,14 @@ __device__ void cluster_stats_sequential(const float* sx, const float* sy, const
 // Dynamic LDS: sx | sy | si [npad] | cstart[npad+2] | aux (bins u64[nb_cap] / labels / order+prefix) | scratch
 // REG: scans of <= 2048 points keep their points and labels in registers (8 per lane, loops fully unrolled);
 // larger scans keep the per-point word in LDS and re-read the points (L2-hot) with rolled loops.
-template <bool REG>
-__global__ __launch_bounds__(BUILD_BLOCK) void k_ndt_build(const float* __restrict__ pts, int pitch,
+// TP: see k_associate -- sharing the chip with other batches' solves, the kernel is held to 64 registers (eight wavefronts per
+// SIMD; no spills, but the chain loops lose their second buffer of loads in flight: 30 -> 36 us for a lone batch, which
+// therefore keeps its 88).
+#ifndef RANDT_BUILD_TP_WPE
+#define RANDT_BUILD_TP_WPE 8
+#endif
+template <bool REG, bool TP>
+__global__ __launch_bounds__(BUILD_BLOCK) __attribute__((amdgpu_waves_per_eu(TP ? RANDT_BUILD_TP_WPE : 1, TP ? RANDT_BUILD_TP_WPE : 8))) void k_ndt_build(const float* __restrict__ pts, int pitch,
                                                            const int32_t* __restrict__ n_pts_arr, int stride,
                                                            int ioff, int row_size, float resolution, MapView out,
                                                            int first_map, int npad, int nb_cap, int aux_bytes, int bigcap,
@@ -876,16 +882,19 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
     ctx->last_error = "NDT build: the LDS atomic ranking failed its lane-order check on this device; ballot ranking from now on (results unaffected)";
   }
   const int rank_mode = ctx->lds_atomics_lane_ordered ? (ctx->debug_force_misrank ? 2 : 1) : 0;
-#define RANDT_BUILD_LAUNCH(REG)                                                                                            \
+#define RANDT_BUILD_LAUNCH(REG, TP)                                                                                        \
   do {                                                                                                                     \
-    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<REG>),                              \
+    RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ndt_build<REG, TP>),                          \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
-    hipLaunchKernelGGL((k_ndt_build<REG>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,            \
+    hipLaunchKernelGGL((k_ndt_build<REG, TP>), dim3(n_scans), dim3(BUILD_BLOCK), lds, ctx->stream, d_points, pitch,            \
                        d_n_points, stride, ioff, row_size, resolution, out, first_map, npad, nb_cap, (int)aux, bigcap, d_fallback,    \
                        rank_mode, ctx->misrank_word);                                                                       \
   } while (0)
-  if (reg) RANDT_BUILD_LAUNCH(true);
-  else RANDT_BUILD_LAUNCH(false);
+  // placement (see the kernel): batches that share the chip with other batches' solves
+  const bool tp = ctx->solve_mode == RANDT_SOLVE_THROUGHPUT || n_scans > 2 * ctx->n_cus;
+  if (reg && tp) RANDT_BUILD_LAUNCH(true, true);
+  else if (reg) RANDT_BUILD_LAUNCH(true, false);
+  else RANDT_BUILD_LAUNCH(false, false);
 #undef RANDT_BUILD_LAUNCH
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
