@@ -23,6 +23,9 @@
 using namespace randt_dev;
 
 #define BUILD_BLOCK 256
+#ifndef RANDT_CHAIN_FENCE
+#define RANDT_CHAIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 #ifdef RANDT_TIMING
 __device__ long long g_randt_timing[32];
@@ -525,10 +528,12 @@ __global__ __launch_bounds__(BUILD_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
           float w[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) w[u] = q[j + 8 + u];
+        if (TP) RANDT_CHAIN_FENCE();  // (64-register instantiation) the reads above are issued before the additions below start
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc += v[u];
 #pragma unroll
           for (int u = 0; u < 8; ++u) v[u] = q[j + 16 + u];
+        if (TP) RANDT_CHAIN_FENCE();  // (64-register instantiation) the reads above are issued before the additions below start
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc += w[u];
         }
@@ -536,6 +541,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
           float w[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) w[u] = q[j + 8 + u];
+        if (TP) RANDT_CHAIN_FENCE();  // (64-register instantiation) the reads above are issued before the additions below start
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc += v[u];
 #pragma unroll
@@ -591,10 +597,12 @@ __global__ __launch_bounds__(BUILD_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
           float w[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) w[u] = q[j + 8 + u];
+        if (TP) RANDT_CHAIN_FENCE();  // (64-register instantiation) the reads above are issued before the additions below start
 #pragma unroll
           for (int u = 0; u < 8; ++u) term(v[u]);
 #pragma unroll
           for (int u = 0; u < 8; ++u) v[u] = q[j + 16 + u];
+        if (TP) RANDT_CHAIN_FENCE();  // (64-register instantiation) the reads above are issued before the additions below start
 #pragma unroll
           for (int u = 0; u < 8; ++u) term(w[u]);
         }
@@ -602,6 +610,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
           float w[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) w[u] = q[j + 8 + u];
+        if (TP) RANDT_CHAIN_FENCE();  // (64-register instantiation) the reads above are issued before the additions below start
 #pragma unroll
           for (int u = 0; u < 8; ++u) term(v[u]);
 #pragma unroll
