@@ -46,7 +46,7 @@ N_SIMDS, CLOCK_GHZ = 1024, 2.4          # 256 CUs x 4 SIMDs, max clock (MI355X_M
 VALU_PEAK = N_SIMDS * CLOCK_GHZ         # G SIMD-cycles/s of VALU issue
 SAT_COPIES = 12                         # chip-filling launch of the roofline section: 12 copies of the batch = 6144 registrations =
                                         # exactly two rounds of the 3072 resident wavefronts (3 per SIMD) of the one-wavefront solve kernel
-HOT_KERNELS = ("k_ndt_build<true>", "k_associate<false>", "k_solve<3,1,64,true,4,false>")
+HOT_KERNELS = ("k_ndt_build<true,true>", "k_associate<false,64,true>", "k_solve<3,1,64,true,4,false>")
 
 
 def effective_cpus():
@@ -87,7 +87,7 @@ def load_counters():
     if not files:
         return {}, None, "no committed counter summary"
     rows = {}
-    want_wgs = {"k_ndt_build<true>": 512, "k_associate<false>": 512, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch
+    want_wgs = {"k_ndt_build<true,true>": 512, "k_associate<false,64,true>": 512, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch
     stamp = None
     for r in csv.DictReader(open(files[-1])):
         stamp = r.get("csrc_hash", stamp)

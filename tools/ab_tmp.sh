@@ -1,11 +1,8 @@
-H="--odometry-scans 0 --polar-scans 0 --slam-scans 0 --polar-odometry-scans 0 --no-cpu-baseline --no-roofline-sections"
-P='import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], round(d["value"]/1e6,3),"M/s", round(d["ms_per_step"]*1e3/d["config"]["batch_per_gpu"]*512,1),"us/512", d.get("pose_err_vs_oracle",{}).get("max_abs_translation_m"))'
-python -c "import torch; print(torch.cuda.get_device_properties(0).name)"; python - <<'PY'
-import ctypes
-h=ctypes.CDLL('/opt/rocm/lib/libamdhip64.so'); lo=ctypes.c_int(); hi=ctypes.c_int(); print('prio range', h.hipDeviceGetStreamPriorityRange(ctypes.byref(lo),ctypes.byref(hi)), lo.value, hi.value)
+mkdir -p gpurun_out/r03_g5
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r03_g5/pytest.log 2>&1; tail -2 gpurun_out/r03_g5/pytest.log
+timeout 300 python bench.py > gpurun_out/r03_g5/bench.json 2> gpurun_out/r03_g5/bench.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r03_g5/bench.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['path']['frac'], d['single_batch']['batch_latency_us'], d['single_batch']['kernel_us'])
 PY
-for rep in 1 2; do
-python bench.py $H --steps 3000 2>/dev/null | python -c "$P" "base"
-for pr in -1 0 1; do RANDT_SOLVE_STREAM_PRIO=$pr python bench.py $H --steps 3000 2>/dev/null | python -c "$P" "solve_stream_prio=$pr"; done
-for pr in -1 0; do GPU_MAX_HW_QUEUES=32 RANDT_SOLVE_STREAM_PRIO=$pr python bench.py $H --steps 3000 2>/dev/null | python -c "$P" "q32 solve_stream_prio=$pr"; done
-done
