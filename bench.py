@@ -607,6 +607,24 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
     big.scan_maps[0].close()
     if throughput_mode:
         ctxs[0].set_solve_mode(R._capi.SOLVE_THROUGHPUT)
+    # ---- the dominant kernel SUSTAINED: the 512-registration solve launches of all streams back to back (what the kernel does
+    # when the tail of one launch is covered by the next ones; the single chip-filling launch above pays its own tail)
+    if ks is not None and throughput_mode and len(streams) > 1 and len(full.ctxs) >= len(streams):
+        n_s, per = len(streams), 96
+        sp = [[full.guess4.clone() for _ in range(per)] for _ in range(n_s)]
+        for j in range(n_s):                                   # (the streams' correspondence tables are those of the headline region)
+            full.step(j, streams[j], full.poses[j], None, "solve")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(per):
+            for j in range(n_s):
+                full.step(j, streams[j], sp[j][i], None, "solve")
+        torch.cuda.synchronize()
+        us_512 = (time.perf_counter() - t0) / (per * n_s) * 1e6
+        roof["sustained"] = {"us_per_512_launch": us_512, "achieved": ks["valu_issue_cycles"] / us_512 * 1e-3,
+                             "frac": ks["valu_issue_cycles"] / us_512 * 1e-3 / VALU_PEAK,
+                             "note": "%d x %d launches of the 512-registration solve on %d streams, wall clock between synchronisations "
+                                     "(nothing else running): the same kernel with its launch tails covered" % (per, n_s, n_s)}
     return out
 
 

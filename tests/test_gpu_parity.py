@@ -65,6 +65,48 @@ def test_association_identical(rig, osub, mahal, intensity):
         assert np.array_equal(corr[i, : om.n_cells], oc), f"pair {i}"
 
 
+def test_throughput_placement_instantiations_bit_exact(rig, osub):
+    """RANDT_SOLVE_THROUGHPUT (the caller keeps several batches in flight) selects the register-capped instantiations of the build
+    (64 registers, fenced chain reads) and of the association (96 registers, spills): same cells, index grids and
+    correspondence tables, bit for bit, as the oracle -- and the same poses as the lone-batch geometry."""
+    torch = rig.torch
+    ctx = rig.ctx
+    ctx.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
+    maps = R.Maps(ctx, rig.B, rig.mapp, rig.scan_cap, with_grid=True)
+    R.ndt_build_batch(ctx, rig.points, rig.clu, maps)
+    ctx.synchronize()
+    counts = maps.counts()
+    oms = [oracle_scan_map(rig.prob["scans"][i]) for i in range(rig.B)]
+    for i in range(rig.B):
+        cells, grid = maps.download(i)
+        assert counts[i] == oms[i].n_cells
+        assert cells_equal(cells, oms[i].cells()), f"scan {i}: cell statistics differ"
+        assert np.array_equal(grid, oms[i].grid())
+    mp = R.default_matcher_params()
+    k = mp.n_neighbours
+    g4 = synth.pose3_to_pose4(rig.prob["guess"])
+    guess = torch.from_numpy(g4).to(rig.dev)
+    corr = torch.full((rig.B, rig.scan_cap, k), -7, dtype=torch.int32, device=rig.dev)
+    R.associate_batch(ctx, rig.submaps, rig.fixed_idx, maps, 0, rig.B, guess, mp, corr)
+    ctx.synchronize()
+    c = corr.cpu().numpy()
+    for i in range(rig.B):
+        oc, _ = po.associate(osub[rig.prob["submap_of"][i]], oms[i], g4[i], k, 1, 1)
+        assert np.array_equal(c[i, : oms[i].n_cells], oc), f"pair {i}"
+    # whole path in both placements: identical poses and result records
+    out = []
+    for mode in (R._capi.SOLVE_THROUGHPUT, R._capi.SOLVE_AUTO):  # (ends in SOLVE_AUTO, the module's default)
+        ctx.set_solve_mode(mode)
+        pose = torch.from_numpy(g4.copy()).to(rig.dev)
+        res = torch.zeros((rig.B, 64), dtype=torch.uint8, device=rig.dev)
+        R.scan_register_batch(ctx, rig.points, rig.clu, rig.submaps, rig.fixed_idx, maps, mp, pose, res)
+        ctx.synchronize()
+        out.append((pose.cpu().numpy(), res.cpu().numpy()))
+    assert ctx._lib is not None
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    maps.close()
+
+
 def _solve_both(rig, osub, mp, trace_len=3 * 512 + 1):
     torch = rig.torch
     k = mp.n_neighbours
