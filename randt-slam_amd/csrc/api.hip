@@ -203,6 +203,7 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
   }
   if (const char* e = getenv("RANDT_ASSOC_STAGE_GRID")) ctx->assoc_stage_grid = atoi(e) ? 1 : 0;
   if (const char* e = getenv("RANDT_ASSOC_TP_CH")) ctx->assoc_tp_ch = atoi(e) > 0 ? atoi(e) : ctx->assoc_tp_ch;
+  if (const char* e = getenv("RANDT_ASSOC_TP_PPW")) ctx->assoc_tp_ppw = atoi(e) > 0 ? atoi(e) : ctx->assoc_tp_ppw;
   if (const char* e = getenv("RANDT_BUILD_TILED")) ctx->build_tiled = atoi(e) ? 1 : 0;
   {
     // does this device serve colliding LDS atomics in lane order?  (one 64-thread launch; if the probe cannot run or says

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
                                                            MapView moving, int moving_first,
                                                            const int32_t* __restrict__ moving_idx,
                                                            const double* __restrict__ guess4, int k, int metric_mahal,
-                                                           int transform_full, int32_t* __restrict__ corr, int ch /* cells per chunk <= CH */) {
+                                                           int transform_full, int32_t* __restrict__ corr, int ch /* cells per chunk <= CH */, int n_pairs_total, int ppw) {
   constexpr int CH_LOG2 = CH > 64 ? 7 : (CH > 32 ? 6 : (CH > 16 ? 5 : 4));
   static_assert(CH % ASSOC_WAVES == 0 && CH >= 16 && CH <= 64, "chunk size (P2a runs one thread per cell on ONE wavefront)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,7 +121,14 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
   // k_ndt_build (profiles/experiments/r03_issue_priority.md).
   __builtin_amdgcn_s_setprio(RANDT_LATENCY_KERNEL_PRIO);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pair = blockIdx.x;
+  // TP: a workgroup walks `ppw` pairs one after the other -- in the pipelined region fewer, longer-lived workgroups are cheaper than
+  // many short ones (4 per workgroup: +2 %; spreading a pair's chunks over workgroups, the lone-batch placement: -3 .. -7 %).  A
+  // compile-time single trip otherwise, so the lone-batch instantiations keep their code.
+  const int n_walk = TP ? ppw : 1;
+  for (int pp = 0; pp < n_walk; ++pp) {
+  const int pair = TP ? (int)blockIdx.x * ppw + pp : (int)blockIdx.x;
+  if (TP && pair >= n_pairs_total) break;
+  if (TP) __syncthreads();  // the previous pair's LDS is free
   const int fmap = fixed_idx ? fixed_idx[pair] : 0;
   const int mmap = moving_idx ? moving_idx[pair] : moving_first + pair;
   const int n_slots = fixed.n_slots;
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
     }
     ASSOC_TICK(5);
   }
+  }
 }
 
 size_t assoc_lds_bytes(int n_slots, bool stage, int CH = ASSOC_CH) {
@@ -507,8 +515,9 @@ int launch_associate_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_
     if (split < 1) split = 1;
   }
   RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<STAGE, CH, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_associate<STAGE, CH, TP>), dim3(n_pairs, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
-                     moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, CH);
+  const int ppw = TP ? (ctx->assoc_tp_ppw > 0 ? ctx->assoc_tp_ppw : 1) : 1;  // pairs per workgroup
+  hipLaunchKernelGGL((k_associate<STAGE, CH, TP>), dim3((n_pairs + ppw - 1) / ppw, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
+                     moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, CH, n_pairs, ppw);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }

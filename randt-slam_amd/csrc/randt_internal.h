@@ -56,6 +56,7 @@ struct randt_ctx {
   int window_general = 0;            // RANDT_WINDOW_GENERAL=1: every window takes window_gen.hip (tests: the two kernels agree)
   int debug_force_misrank = 0;       // RANDT_DEBUG_FORCE_MISRANK=1: test hook, makes the in-kernel order check fail
   int build_tiled = 0;       // RANDT_BUILD_TILED=1: every scan through the multi-workgroup build (normally only > 7168 points)
+  int assoc_tp_ppw = 4;      // pairs per association workgroup when batches share the chip (RANDT_ASSOC_TP_PPW)
   int assoc_tp_ch = 64;      // cells per chunk of the association when batches share the chip (16 / 32 / 48 / 64; RANDT_ASSOC_TP_CH)
   int assoc_stage_grid = 0;  // 1: stage the fixed map's index grid in LDS; 0: gather it from L2 (same speed alone, but 36 KB instead of 76 KB of LDS leaves room for co-running build workgroups: +2 % end to end)
 };
