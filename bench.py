@@ -87,7 +87,7 @@ def load_counters():
     if not files:
         return {}, None, "no committed counter summary"
     rows = {}
-    want_wgs = {"k_ndt_build<true,true>": 512, "k_associate<false,64,true>": 512, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch
+    want_wgs = {"k_ndt_build<true,true>": 512, "k_associate<false,64,true>": 128, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch (the association walks four pairs per workgroup)
     stamp = None
     for r in csv.DictReader(open(files[-1])):
         stamp = r.get("csrc_hash", stamp)

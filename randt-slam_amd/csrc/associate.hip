@@ -515,7 +515,10 @@ int launch_associate_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_
     if (split < 1) split = 1;
   }
   RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<STAGE, CH, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int ppw = TP ? (ctx->assoc_tp_ppw > 0 ? ctx->assoc_tp_ppw : 1) : 1;  // pairs per workgroup
+  // pairs per workgroup: the walk is for callers that keep several batches in flight (or a batch that fills the chip several
+  // times over); a lone batch of a few hundred pairs more than the split geometry takes stays one pair per workgroup
+  const bool walk = TP && (ctx->solve_mode == RANDT_SOLVE_THROUGHPUT || n_pairs >= 8 * ctx->n_cus);
+  const int ppw = walk ? (ctx->assoc_tp_ppw > 0 ? ctx->assoc_tp_ppw : 1) : 1;
   hipLaunchKernelGGL((k_associate<STAGE, CH, TP>), dim3((n_pairs + ppw - 1) / ppw, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
                      moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, CH, n_pairs, ppw);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
