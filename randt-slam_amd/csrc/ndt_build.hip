@@ -845,12 +845,19 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   if (reg) {
     // [points == bins] | cstart | order + blist | scratch
     const size_t tail = cstart_bytes + (size_t)bigcap * 4 + 256;
-    size_t budget = (size_t)ctx->lds_limit / 5;
-    if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit / 4;
-    if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit / 3;
-    if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit / 2;
-    if (tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes) > budget) budget = (size_t)ctx->lds_limit;
-    if (tail + pts_bytes + 1024 > budget) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel", hipSuccess);
+    // the smallest share of the CU's LDS (a fifth = five workgroups per CU, a quarter, ...) that holds every label bin the
+    // cluster grid can produce AND the points with their 1 KB margin; the whole LDS (bins capped by the room left) otherwise
+    const size_t want = tail + ((size_t)nb_want * 8 > pts_bytes ? (size_t)nb_want * 8 : pts_bytes);
+    const size_t least = tail + pts_bytes + 1024;
+    size_t budget = (size_t)ctx->lds_limit;
+    for (int share = 5; share >= 2; --share) {
+      const size_t b = (size_t)ctx->lds_limit / share;
+      if (want <= b && least <= b) {
+        budget = b;
+        break;
+      }
+    }
+    if (least > budget) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the LDS build kernel", hipSuccess);
     const size_t room = (budget - tail) / 8;
     nb_cap = (int)((size_t)nb_want < room ? (size_t)nb_want : room);
     aux = (size_t)nb_cap * 8 > pts_bytes ? (size_t)nb_cap * 8 : pts_bytes;

@@ -171,6 +171,21 @@ def _build_both(env, pts, mapp_args, clu_args, cap, ioff=3):
     return cells, grid, om, maps
 
 
+@pytest.mark.parametrize("n_points", [1984, 2000, 2048])
+@pytest.mark.parametrize("min_points", [0, 1, 2, 3])
+def test_build_lds_budget_for_every_min_points(env, n_points, min_points):
+    """The build kernel's LDS holds one list entry per cluster that can become a cell (n / (min_points + 1) of them): small
+    `min_points_per_cell` values at the largest register-resident scan sizes sit right at the five-workgroups-per-CU budget (a
+    randomised soak found the launcher refusing 2048 points at min_points = 2).  Same cells as the oracle for all of them."""
+    rng = np.random.default_rng(100 * n_points + min_points)
+    pts = np.zeros((n_points, 4), dtype=F)
+    pts[:, :2] = (rng.integers(-20, 20, (n_points, 2)) * 0.5 + 0.25 + rng.normal(0, 0.05, (n_points, 2))).astype(F)
+    pts[:, 3] = rng.uniform(10, 90, n_points)
+    cells, grid, om, _ = _build_both(env, pts, (100, 100, 0.5, 0.0, 0.0, 4.0, min_points, 0), (2304, 24.0), 2048)
+    assert om.n_cells > 50
+    assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+
+
 def test_cluster_means_outside_the_map_shift_the_cell_indices(env):
     """clusters whose mean leaves a SMALL map are dropped (vector::at in the reference): every later cell's
     compact index shifts, which the build kernel handles by redoing the statistics in strict cluster order."""

@@ -1,5 +1,5 @@
 """Randomised parity soak (not part of the test suite): many random scenes / parameter sets through the HIP
-build + association + solve and through the CPU oracle; reports any mismatch.  Usage: parity_soak.py [n_cases] [seed]"""
+build + association + solve and through the CPU oracle; reports any mismatch.  Usage: parity_soak.py [n_cases] [seed]   (SOAK_THROUGHPUT=1: the throughput-placement kernels)"""
 import os
 import sys
 
@@ -18,6 +18,8 @@ VERBOSE = os.environ.get("SOAK_VERBOSE") == "1"
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
 ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+if os.environ.get("SOAK_THROUGHPUT") == "1":   # the register-capped build / association instantiations and the one-wavefront solve
+    ctx.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
 bad = {"build": 0, "assoc": 0, "pose": 0, "iters": 0}
 worst = 0.0
 n_solved = n_well = bad_well = 0
