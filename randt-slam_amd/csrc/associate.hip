@@ -5,7 +5,8 @@
 // (src/ndt_representation/ndt_map.cpp:101-175) and Cell::mahalanobisSquaredIntensity
 // (src/ndt_representation/ndt_cell.cpp:172-176).
 //
-// One workgroup (256 threads) per (scan, submap) pair, phases per chunk of 64 moving cells so that every
+// One workgroup (256 threads) per (scan, submap) pair -- per FOUR pairs, one after the other, when batches share the chip; per
+// (pair, chunk) for a lone batch (launch_associate below) --, phases per chunk of 64 moving cells so that every
 // global-memory round trip is taken once by all lanes together instead of once per cell, and so that the per-cell
 // logic runs one THREAD per cell (64 cells per wave-instruction) instead of one wavefront per cell:
 //   P0  a ring-major table of the (2R+1)^2 window offsets is built; optionally (RANDT_ASSOC_STAGE_GRID=1) the

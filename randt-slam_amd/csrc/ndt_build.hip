@@ -129,7 +129,7 @@ __device__ void cluster_stats_sequential(const float* sx, const float* sy, const
 // (3 sums + max, then 6 covariance sums) are independent: a group of 8 lanes owns a cluster and
 // each lane walks ONE chain.  Clusters are handed to the 32 groups in descending size so that a
 // round's wavefronts finish together.
-// Dynamic LDS: sx | sy | si [npad] | cstart[npad+2] | aux (bins u64[nb_cap] / labels / order+prefix) | scratch
+// Dynamic LDS: sx | sy | si [npad] | cstart[npad+2] | aux (bins u64[nb_cap] / labels / order + blist of the clusters that become cells) | scratch
 // REG: scans of <= 2048 points keep their points and labels in registers (8 per lane, loops fully unrolled);
 // larger scans keep the per-point word in LDS and re-read the points (L2-hot) with rolled loops.
 // TP: see k_associate -- sharing the chip with other batches' solves, the kernel is held to 64 registers (eight wavefronts per
@@ -153,10 +153,10 @@ __global__ __launch_bounds__(BUILD_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
   __builtin_amdgcn_s_setprio(RANDT_LATENCY_KERNEL_PRIO);
   // points in labelClouds order; the three arrays are shifted by 16 banks against each other because the
   // lanes of a cluster group read x[j], y[j] and i[j] in the same instruction.
-  // REG  : [ sx | sy | si  ==  bins ] | cstart u16 | order u16 | pre u16 | scratch        (37 KB at N = 2048: 4 per CU)
+  // REG  : [ sx | sy | si  ==  bins ] | cstart u16 | order u16 | blist u16 | scratch      (30.5 KB at N = 2000: 5 per CU)
   //        the label bins are dead once every point knows its final position (kept in registers), so the sorted
   //        points are scattered over them;
-  // !REG : sx | sy | si | cstart u16 | bins | scratch | per-point words (order / pre alias them after the placement).
+  // !REG : sx | sy | si | cstart u16 | bins | scratch | per-point words (order / blist alias them after the placement).
   float* sx = reinterpret_cast<float*>(smem);
   float* sy = sx + npad + 16;
   float* si = sy + npad + 16;
