@@ -218,10 +218,14 @@ def _brute_closest(cells, grid, size, res, offset, max_dist, q_mean, q_cov, k, m
     return targets[:k]
 
 
+@pytest.mark.parametrize("placement", ["lone", "throughput"])
 @pytest.mark.parametrize("metric", [1, 0])
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_k5_association_vs_numpy_brute_force(env, metric, seed):
+def test_k5_association_vs_numpy_brute_force(env, metric, seed, placement):
+    """placement "throughput": RANDT_SOLVE_THROUGHPUT and six copies of the pair -- the register-capped instantiation whose
+    workgroups walk four pairs (one full walk + a ragged one); every copy must give the same table."""
     torch, dev, ctx, _ = env
+    n_copies = 6 if placement == "throughput" else 1
     F = np.float32
     rng = np.random.default_rng(500 + seed)
     size, res, max_dist, n_cells, k = 40, 0.5, 4.0, 300, 4
@@ -248,15 +252,24 @@ def test_k5_association_vs_numpy_brute_force(env, metric, seed):
     mapp = R.MapParams(size, size, res, 0.0, 0.0, max_dist, 5, 0)
     fm = R.Maps(ctx, 1, mapp, n_cells, with_grid=True)
     fm.upload(0, cells, grid)
-    mm = R.Maps(ctx, 1, mapp, 128, with_grid=False)
-    mm.upload(0, mc)
+    mm = R.Maps(ctx, n_copies, mapp, 128, with_grid=False)
+    for j in range(n_copies):
+        mm.upload(j, mc)
     th = 0.1
-    pose4 = np.array([[np.cos(th), np.sin(th), 0.3, -0.2]])
+    pose4 = np.tile(np.array([[np.cos(th), np.sin(th), 0.3, -0.2]]), (n_copies, 1))
     mp = R.default_matcher_params(n_neighbours=k, lookup_mahalanobis=metric, use_intensity=1)
-    corr = torch.full((1, 128, k), -7, dtype=torch.int32, device=dev)
-    R.associate_batch(ctx, fm, torch.zeros(1, dtype=torch.int32, device=dev), mm, 0, 1, torch.from_numpy(pose4).to(dev), mp, corr)
-    ctx.synchronize()
-    got_all = corr.cpu().numpy()[0]
+    corr = torch.full((n_copies, 128, k), -7, dtype=torch.int32, device=dev)
+    if placement == "throughput":
+        ctx.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
+    try:
+        R.associate_batch(ctx, fm, torch.zeros(n_copies, dtype=torch.int32, device=dev), mm, 0, n_copies, torch.from_numpy(pose4).to(dev), mp, corr)
+        ctx.synchronize()
+    finally:
+        ctx.set_solve_mode(R._capi.SOLVE_AUTO)
+    got_copies = corr.cpu().numpy()
+    for j in range(1, n_copies):
+        assert np.array_equal(got_copies[j, :n_q], got_copies[0, :n_q]), j
+    got_all = got_copies[0]
     # the query as the reference forms it: float affine of the guess (transformMap / transformCell, ndt_matcher.cpp:203-209)
     c, s, tx, ty = F(np.cos(th)), F(np.sin(th)), F(0.3), F(-0.2)
     Rm = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
