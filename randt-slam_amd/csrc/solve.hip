@@ -717,6 +717,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
   }
 #endif
   if (SPLIT && split_wave != 0) {
+    // the helpers serve one residual trip per pass and sleep; wavefront 0 is the registration's critical path -- and shares its
+    // SIMD with helpers of the CU's other registration: it keeps the raised priority for the whole solve, the helpers give it up
+    // (one 512-registration batch alone: 112.0 -> 104.4 us)
+    __builtin_amdgcn_s_setprio(0);
     split_helper<D, PARAM, AM2>(S, &s_req, s_part + (size_t)(split_wave - 1) * 64 * 6, &s_badflag[split_wave], split_wave, tid);
     return;
   }
@@ -724,7 +728,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
   (SPLIT ? eval_pass_split<D, PARAM, MODE, AM2>(S, XP, L, OUT, &s_req, s_part, s_badflag, split_W, tid) \
          : eval_pass<D, PARAM, MODE, BLOCK, AM2>(S, XP, L, OUT, red, parity, tid))
 
-  if (RANDT_SOLVE_PRIO_PRO > 0 && RANDT_SOLVE_PRIO_ALG != RANDT_SOLVE_PRIO_PRO) __builtin_amdgcn_s_setprio(RANDT_SOLVE_PRIO_ALG);
+  if (SPLIT) __builtin_amdgcn_s_setprio(3);  // wavefront 0 of a split-mode registration (see the helpers' branch above)
+  else if (RANDT_SOLVE_PRIO_PRO > 0 && RANDT_SOLVE_PRIO_ALG != RANDT_SOLVE_PRIO_PRO) __builtin_amdgcn_s_setprio(RANDT_SOLVE_PRIO_ALG);
   // ---- raw residuals at the initial point -> gnc_mu (ndt_matcher.cpp:466-476)
   Loss L = AM2 ? make_loss_am2(P.loss_a, 1.0, P.weight) : make_loss(P.loss_a, P.alpha, 1.0, P.weight);
   Base cur, cnd;
