@@ -551,7 +551,9 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   // time: one workgroup per pair walking RANDT_ASSOC_TP_CH-cell chunks.
   const bool lone = ctx->solve_mode != RANDT_SOLVE_THROUGHPUT && n_pairs <= 2 * ctx->n_cus;
   const bool spread = n_pairs <= 64 || lone;
-  const int chunk = spread ? (n_pairs <= 8 ? RANDT_ASSOC_SMALL_CH : ASSOC_CH) : ctx->assoc_tp_ch;
+  // lone batches: as many (pair, chunk) workgroups as stay resident in one round -- 16-cell chunks up to 128 pairs (64 pairs:
+  // 17.9 -> 15.0 us), 32-cell ones above (512 pairs: 24.8 -> 23.5 us; 16-cell chunks would need a second round there: 36.5)
+  const int chunk = spread ? (n_pairs <= 128 ? RANDT_ASSOC_SMALL_CH : 32) : ctx->assoc_tp_ch;
 #define RANDT_ASSOC_GO(ST, CC) \
   return launch_associate_cfg<ST, CC>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_guess4, k, full, d_corr, d_moving_idx, spread)
   if (stage) {
