@@ -22,6 +22,7 @@
 #define SC_MAX_SECTOR 128
 #define SC_MAX_RING 64
 #define SC_MAX_CAND 32
+#define SC_TERM_CAP 4096  // (shift, column) cosine terms of one candidate kept in LDS (32 KB): (2 radius + 1) x num_sector <= this
 
 namespace {
 
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
                                                         int32_t* __restrict__ loop_id, float* __restrict__ yaw,
                                                         double* __restrict__ min_dist_out) {
   __shared__ double k1[SC_MAX_SECTOR], k2[SC_MAX_SECTOR];
+  __shared__ double n1[SC_MAX_SECTOR], n2[SC_MAX_SECTOR];  // column norms of the query / the candidate (shift-independent)
+  __shared__ double term[SC_TERM_CAP];
   __shared__ double sv[4];
   __shared__ int si[4];
   __shared__ int cand[SC_MAX_CAND];
@@ -184,10 +187,20 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
   }
   // ---- pairwise distances (distanceBtnScanContext) in candidate order
   const double* sc1 = desc + (size_t)node * R * S;
+  // The column-shift search evaluates, per shift, sum over the columns of dot / (|a| |b|): the norms do not depend on the shift
+  // and the (shift, column) dot products not on each other, so they are formed once / by all 256 threads; only each shift's sum
+  // over the columns stays one thread's left-to-right loop (the reference's order) -- same numbers, ~30x less serial work.
+  const int n_shift = 2 * P.radius + 1;
+  const bool spread_shifts = n_shift <= S && n_shift * S <= SC_TERM_CAP;
   if (tid < S) {
-    double a = 0;
-    for (int r = 0; r < R; ++r) a += sc1[(size_t)tid * R + r];
+    double a = 0, na = 0;
+    for (int r = 0; r < R; ++r) {
+      const double v = sc1[(size_t)tid * R + r];
+      a += v;
+      na += v * v;
+    }
     k1[tid] = a / R;
+    n1[tid] = sqrt(na);
   }
   double min_d = 10000000;
   int nn_align = 0, nn_idx = 0;
@@ -196,9 +209,14 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
     const double* sc2 = desc + (size_t)ci * R * S;
     __syncthreads();
     if (tid < S) {
-      double b = 0;
-      for (int r = 0; r < R; ++r) b += sc2[(size_t)tid * R + r];
+      double b = 0, nb = 0;
+      for (int r = 0; r < R; ++r) {
+        const double v = sc2[(size_t)tid * R + r];
+        b += v;
+        nb += v * v;
+      }
       k2[tid] = b / R;
+      n2[tid] = sqrt(nb);
     }
     __syncthreads();
     // fastAlignUsingVkey: thread = shift, first minimal shift wins
@@ -224,7 +242,44 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
     // column-shift search: the 2 radius + 1 shifts around it, ascending shift value = thread order
     double dv = 1e300;
     int ds = 0x7fffffff;
-    if (tid < S) {
+    if (spread_shifts) {
+      // every (shift slot, column) term by all threads; slot i holds shift argmin - radius + i (mod S)
+      for (int p = tid; p < n_shift * S; p += SC_BLOCK) {
+        const int slot = p / S, col = p - slot * S;
+        int sh = argmin_vkey - P.radius + slot;
+        sh = sh < 0 ? sh + S : (sh >= S ? sh - S : sh);
+        int j = col - sh;
+        j = j < 0 ? j + S : j;
+        const double* a = sc1 + (size_t)col * R;
+        const double* b = sc2 + (size_t)j * R;
+        double dot = 0;
+        for (int r = 0; r < R; ++r) dot += a[r] * b[r];
+        const double na = n1[col], nb2 = n2[j];
+        term[p] = (na == 0 || nb2 == 0) ? 1e300 : dot / (na * nb2);  // 1e300: the column is skipped
+      }
+      __syncthreads();
+      if (tid < S) {
+        int delta = tid - argmin_vkey;
+        delta = delta < 0 ? delta + S : delta;
+        const bool in = delta <= P.radius || S - delta <= P.radius;
+        if (in) {
+          const int slot = delta <= P.radius ? P.radius + delta : P.radius - (S - delta);
+          int n_eff = 0;
+          double sum = 0;
+          for (int col = 0; col < S; ++col) {
+            const double t = term[slot * S + col];
+            if (t == 1e300) continue;
+            sum = sum + t;
+            n_eff = n_eff + 1;
+          }
+          const double d = 1.0 - sum / n_eff;
+          if (d < 10000000) {  // NaN (no effective column) never wins, like "cur < min"
+            dv = d;
+            ds = tid;
+          }
+        }
+      }
+    } else if (tid < S) {
       // is shift `tid` in the search space {argmin + ii mod S, |ii| <= radius}?
       int delta = tid - argmin_vkey;
       delta = delta < 0 ? delta + S : delta;
