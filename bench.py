@@ -592,6 +592,10 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
                 "note": "all three launches of a step / ms_per_step of the 16-stream headline region (throughput, no residency involved)",
                 "chip_filling_launch_us": {"k_ndt_build": sat_build_us, "k_associate": sat_assoc_us, "k_solve": sat_us,
                                            "registrations": big.B},
+                # each kernel by itself: issue cycles of its chip-filling launch / that launch's duration (the two short kernels are
+                # chains of LDS atomics / L2 round trips: their chip time, not their issue slots, is what the pipelined region overlaps)
+                "frac_by_kernel": {n: cyc[n] * SAT_COPIES / us * 1e-3 / VALU_PEAK
+                                   for n, us in zip(HOT_KERNELS, (sat_build_us, sat_assoc_us, sat_us))},
             }
         flops = ks["fp64_flops"]
         out["roofline_fp64"] = {"bound": "fp64_valu", "kernel": "k_solve", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
