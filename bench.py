@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # vector fp64 (half the 157.3 TF fp32 vector rate)
 N_SIMDS, CLOCK_GHZ = 1024, 2.4          # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip table)
 VALU_PEAK = N_SIMDS * CLOCK_GHZ         # G SIMD-cycles/s of VALU issue
-SAT_COPIES = 12                         # chip-filling launch of the roofline section: 12 copies of the batch = 6144 registrations =
-                                        # exactly two rounds of the 3072 resident wavefronts (3 per SIMD) of the one-wavefront solve kernel
+SAT_COPIES = 16                         # chip-filling launch of the roofline section: 16 copies of the batch = 8192 registrations =
+                                        # exactly two rounds of the 4096 resident wavefronts (4 per SIMD) of the one-wavefront solve kernel
 HOT_KERNELS = ("k_ndt_build<true,true>", "k_associate<false,64,true>", "k_solve<3,1,64,true,4,false>")
 
 
@@ -493,7 +493,7 @@ def main():
 def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file, b_alg, value, s_per_step, counters_stale=None, throughput_mode=True):
     """Clean (non-overlapped) measurements behind the `roofline` object, all with HIP events on the launch stream:
       single_batch      ONE 512-registration batch at a time on one stream: latency, rate, per-kernel durations;
-      chip-filling      the dominant kernel (k_solve) with SAT_COPIES copies of the batch = 4096 registrations in ONE
+      chip-filling      the dominant kernel (k_solve) with SAT_COPIES copies of the batch = 8192 registrations in ONE
                         launch, one stream: the launch fills the chip by itself, so its duration is a per-launch cost and
                         the rocprofv3 kernel trace of the same command shows the same number."""
     st, B = streams[0], full.B

@@ -544,16 +544,20 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, int tid, dou
 // Wavefronts per SIMD.  The closed-form-loss kernels (AM2) are pinned to THREE (<= 168 registers): with the cold solver
 // state in LDS they need ~190, and squeezed to 168 the compiler parks ~20 dwords in scratch, one access of which sits in
 // the residual loop -- measured -12 % per chip-filling solve launch against two wavefronts per SIMD (a lone wavefront is
-// VALU-active about half the time; the third fills the gaps).  Four per SIMD (128 registers) spill 70 dwords and lose.
-// The general-alpha kernels carry pow() and stay at two.  RANDT_SOLVE_WPE: experiment knob (tools/ab_build.sh).
+// VALU-active about half the time; the third fills the gaps).  Four per SIMD (128 registers) spilled 70 dwords and lost then; since
+// the solver state moves in bulk (136 registers at three) it is 9 dwords, and since the short kernels run at raised priority in
+// register-capped instantiations the one-wavefront kernels are pinned to FOUR: the 512-registration launches of
+// 16 streams 27.8 -> 25.9 us each, the pipelined region 11.05 -> 11.43 M registrations/s (it was +-0 before those changes).
+// The general-alpha kernels carry pow() and stay at two, BLOCK = 128 at three.  RANDT_SOLVE_WPE: experiment knob (tools/ab_build.sh).
 #ifdef RANDT_SOLVE_WPE
 #define RANDT_SOLVE_OCC(AM2, SPLIT) __attribute__((amdgpu_waves_per_eu(RANDT_SOLVE_WPE, RANDT_SOLVE_WPE)))
 #else
 #ifndef RANDT_SPLIT_WPE
 #define RANDT_SPLIT_WPE 4  // split mode: wavefront 0's pass holds ONE residual trip -> 127 registers (five spilled dwords), four per SIMD
 #endif
+#define RANDT_SOLVE_WPE_OF(AM2, SPLIT, BLOCK) ((SPLIT) ? RANDT_SPLIT_WPE : ((AM2) ? ((BLOCK) == 64 ? 4 : 3) : 2))
 #define RANDT_SOLVE_OCC(AM2, SPLIT) \
-  __attribute__((amdgpu_waves_per_eu((SPLIT) ? RANDT_SPLIT_WPE : ((AM2) ? 3 : 2), (SPLIT) ? RANDT_SPLIT_WPE : ((AM2) ? 3 : 2))))
+  __attribute__((amdgpu_waves_per_eu(RANDT_SOLVE_WPE_OF(AM2, SPLIT, BLOCK), RANDT_SOLVE_WPE_OF(AM2, SPLIT, BLOCK))))
 #endif
 template <int D, int PARAM, int BLOCK, bool AM2, int RPB, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_OCC(AM2, SPLIT) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
