@@ -98,13 +98,12 @@ __device__ __forceinline__ unsigned long long prefix_mask(int n) {
   return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
 }
 
-// TP ("throughput placement"): the batch shares the chip with other batches' solves, whose three wavefronts per SIMD leave
-// 104 of the 512 registers -- this kernel takes 131 when left alone (three wavefronts per SIMD of its own) and then has to wait
-// for a SIMD with only two solve wavefronts.  Held to five per SIMD (96 registers, 22 dwords spilled) it fits beside three:
-// +1.7 % in the pipelined region together with k_ndt_build at 64; a lone batch is latency and keeps the registers
-// (24.5 against 27.2 us per 512 pairs).
+// TP ("throughput placement"): the batch shares the chip with other batches' solves.  Left alone the kernel takes 131 registers
+// (three wavefronts per SIMD of its own).  While the solve held 136 x 3 per SIMD it was capped at 96 (22 spilled dwords) to fit
+// beside three solves (+1.7 %); since the solve runs at 128 x 4 everything on the chip is placed in 128-register slots and this
+// kernel is held to exactly that (no spills): 11.38 -> 11.76 M registrations/s.  A lone batch keeps the registers it likes.
 #ifndef RANDT_ASSOC_TP_WPE
-#define RANDT_ASSOC_TP_WPE 5
+#define RANDT_ASSOC_TP_WPE 4
 #endif
 template <bool STAGE_GRID, int CH, bool TP>
 __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP ? RANDT_ASSOC_TP_WPE : 1, TP ? RANDT_ASSOC_TP_WPE : 8))) void k_associate(MapView fixed, const int32_t* __restrict__ fixed_idx,
