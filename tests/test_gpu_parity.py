@@ -67,7 +67,7 @@ def test_association_identical(rig, osub, mahal, intensity):
 
 def test_throughput_placement_instantiations_bit_exact(rig, osub):
     """RANDT_SOLVE_THROUGHPUT (the caller keeps several batches in flight) selects the register-capped instantiations of the build
-    (64 registers, fenced chain reads) and of the association (96 registers, spills): same cells, index grids and
+    (64 registers, fenced chain reads) and of the association (128 registers, four-pair walk): same cells, index grids and
     correspondence tables, bit for bit, as the oracle -- and the same poses as the lone-batch geometry."""
     torch = rig.torch
     ctx = rig.ctx
