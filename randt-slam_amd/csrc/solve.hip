@@ -28,218 +28,13 @@
 // candidate is evaluated WITH its Jacobian so an accepted step needs no second pass.  The template
 // parameter AM2 selects the closed-form loss of the shipped Barron shape (-2), which keeps pow() out of
 // the kernel.
-#include "randt_internal.h"
-#include "solve_math.h"
-
-#include <float.h>
+#include "solve_pass.h"
 
 using namespace randt_solve;
-
-// Issue priority inside the solve (s_setprio): the residual trips are throughput work, the reduction and the solver algebra
-// behind them one dependent fp64 chain per wavefront.  RANDT_SOLVE_PRIO_ALG > 0 raises the chain's priority over the trips of
-// the wavefronts it shares the SIMD with; RANDT_SOLVE_PRIO_PRO is the priority of the prologue (correspondence count and
-// compaction: global round trips).
-#ifndef RANDT_SOLVE_PRIO_ALG
-#define RANDT_SOLVE_PRIO_ALG 0
-#endif
-#ifndef RANDT_SOLVE_PRIO_PRO
-#define RANDT_SOLVE_PRIO_PRO 3
-#endif
-#define RANDT_PRIO_TRIPS() do { if (RANDT_SOLVE_PRIO_ALG > 0) __builtin_amdgcn_s_setprio(0); } while (0)
-#define RANDT_PRIO_CHAIN() do { if (RANDT_SOLVE_PRIO_ALG > 0) __builtin_amdgcn_s_setprio(RANDT_SOLVE_PRIO_ALG); } while (0)
+using namespace randt_pass;
+using namespace randt_lm;
 
 namespace {
-
-// base sums of one pass: cost, g_b (tx, ty, theta), G upper (tt: 00 01 02 11 12 22)
-struct Base {
-  double v[10];
-};
-
-// ---------------------------------------------------------------- Sophus SE(2) pieces ----------
-__device__ __forceinline__ void so2_normalize(double& c, double& s) {
-  const double len = sqrt(c * c + s * s);
-  c = c / len;
-  s = s / len;
-}
-
-// Sophus::Manifold<SE2>::Plus(T, delta) = T * exp(delta) (ceres_manifold.hpp, se2.hpp, so2.hpp)
-__device__ __forceinline__ void se2_plus(const double* x, const double* d, double* xp) {
-  const double theta = d[2];
-  double c = cos(theta), s = sin(theta);
-  so2_normalize(c, s);
-  double sbt, omcbt;
-  if (uni(fabs(theta) < 1e-10)) {
-    const double tsq = theta * theta;
-    sbt = 1.0 - (1.0 / 6.0) * tsq;
-    omcbt = 0.5 * theta - (1.0 / 24.0) * theta * tsq;
-  } else {
-    sbt = s / theta;
-    omcbt = (1.0 - c) / theta;
-  }
-  const double ex = sbt * d[0] - omcbt * d[1];
-  const double ey = omcbt * d[0] + sbt * d[1];
-  double re = x[0] * c - x[1] * s;
-  double im = x[0] * s + x[1] * c;
-  const double sq = re * re + im * im;
-  if (uni(sq != 1.0)) {
-    const double scale = 2.0 / (1.0 + sq);
-    re *= scale;
-    im *= scale;
-  }
-  so2_normalize(re, im);
-  xp[0] = re;
-  xp[1] = im;
-  xp[2] = x[2] + (x[0] * ex - x[1] * ey);
-  xp[3] = x[3] + (x[1] * ex + x[0] * ey);
-}
-
-template <int PARAM>
-__device__ __forceinline__ void plus(const double* x, const double* d, double* xp) {
-  if (PARAM == RANDT_PARAM_MANIFOLD) {
-    se2_plus(x, d, xp);
-  } else if (PARAM == RANDT_PARAM_AMBIENT4) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xp[i] = x[i] + d[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xp[i] = x[i] + d[i];
-    xp[3] = 0.0;
-  }
-}
-
-// RANDT_PARAM_VECTOR and RANDT_PARAM_ANALYTIC optimise the same (pos[2], rot) blocks; ANALYTIC only swaps the NDT functor's
-// rotation Jacobian for the reference's hand-written one (solve_math.h, residual_sq_v)
-__device__ __forceinline__ constexpr bool vec_like(int param) { return param == RANDT_PARAM_VECTOR || param == RANDT_PARAM_ANALYTIC; }
-
-// valid correspondences of one registration, compacted once into LDS: (moving index << 21) | fixed index
-constexpr int PAIR_CAP = 1024;
-constexpr int PAIR_SHIFT = 21;
-constexpr unsigned PAIR_MASK = (1u << PAIR_SHIFT) - 1u;
-
-struct Stage {
-  const float4* mov;      // moving cell records (3 x float4 each)
-  const float4* fix;      // fixed cell records
-  const int* corr;        // [M*k] compact fixed index or -1
-  const unsigned* pairs;  // LDS: compacted valid correspondences, or nullptr (then the raw slots are walked)
-  int n_pairs;
-  int pack16;             // pairs hold (3 * moving index) << 16 | 3 * fixed index (both record offsets in float4 units < 2^16)
-  int n_slots, k, fixed_cap;
-  unsigned kmagic;        // ceil(2^32 / k): slot / k == umulhi(slot, kmagic) for slot < 2^32 / k (k >= 2)
-};
-
-// cos / sin of the rotation and the translation of ambient point x (what a pass evaluates the residuals at)
-template <int D, int PARAM>
-__device__ __forceinline__ void pass_pose(const double* x, double& c, double& s, double& tx, double& ty) {
-#pragma clang fp contract(off)
-  if (vec_like(PARAM)) {
-    c = cos(x[2]);
-    s = sin(x[2]);
-    tx = x[0];
-    ty = x[1];
-  } else {
-    // R = AngleAxis(atan2(sp, cp)): cos/sin of the angle == normalised stored complex
-    const double inv = fast_rsqrt(fma(x[0], x[0], x[1] * x[1]));
-    c = x[0] * inv;
-    s = x[1] * inv;
-    tx = x[2];
-    ty = x[3];
-  }
-}
-
-// Pass over all correspondence slots at ambient point x.  MODE 0: max raw residual (out.v[0]);
-// MODE 1: the ten base sums with loss + corrector (Ceres residual_block.cc / corrector.cc).
-// Returns false if any residual was non-finite.  red: [2][BLOCK/64][12] LDS, parity alternates per call.
-template <int D, int PARAM, int MODE, int BLOCK, bool AM2>
-__device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const Loss& L, Base& out, double* red, int& parity, int tid) {
-  constexpr int WAVES = BLOCK / 64;
-  double c, s, tx, ty;
-  pass_pose<D, PARAM>(x, c, s, tx, ty);
-  const Rot rot = make_rot(c, s);
-  RANDT_PRIO_TRIPS();
-  double acc[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) acc[i] = 0.0;
-  double mx = -DBL_MAX;
-  int bad = 0;
-  // one residual; mv / fv = moving / fixed cell record
-  auto one_rec = [&](const float4* mv, const float4* fv) {
-    double jb[3];
-    const double sq = residual_sq<D, MODE == 1, PARAM == RANDT_PARAM_ANALYTIC>(mv, fv, rot, tx, ty, jb);
-    // closed-form loss: a non-finite residual makes the cost sum non-finite (u or 1 / (u^2 s) is NaN / 0 x inf), which the
-    // caller tests after the reduction -- no per-residual class test in the hot loop
-    if (!(MODE == 1 && AM2) && !isfinite(sq)) bad = 1;
-    if (MODE == 0) {
-      mx = sq > mx ? sq : mx;
-    } else {
-      accumulate_residual<AM2>(L, sq, jb, acc);
-    }
-  };
-  auto one = [&](unsigned mi, unsigned ci) { one_rec(S.mov + (size_t)mi * 3, S.fix + (size_t)ci * 3); };
-  if (S.n_pairs > 0 && S.pack16) {  // scalar: the dense list in LDS, record BYTE offsets two shifts / masks away
-    // (32-bit offsets against the uniform table bases: the loads take the scalar-base addressing form, no 64-bit adds)
-    const char* mb = reinterpret_cast<const char*>(S.mov);
-    const char* fb = reinterpret_cast<const char*>(S.fix);
-    for (int e = tid; e < S.n_pairs; e += BLOCK) {
-      const unsigned u = S.pairs[e];
-      one_rec(reinterpret_cast<const float4*>(mb + ((u >> 12) & 0xffff0u)), reinterpret_cast<const float4*>(fb + ((u << 4) & 0xffff0u)));
-    }
-  } else if (S.n_pairs > 0) {
-    for (int e = tid; e < S.n_pairs; e += BLOCK) {
-      const unsigned u = S.pairs[e];
-      one(u >> PAIR_SHIFT, u & PAIR_MASK);
-    }
-  } else {
-    for (int slot = tid; slot < S.n_slots; slot += BLOCK) {
-      const int cr = S.corr[slot];
-      if (cr < 0 || cr >= S.fixed_cap) continue;
-      one(S.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, S.kmagic) /* slot / k */, (unsigned)cr);
-    }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  RANDT_PRIO_CHAIN();
-  double badf = wave_any(bad != 0);
-  if (MODE == 0) {
-    mx = wave_max(mx);
-    if (WAVES > 1) {
-      double* r = red + parity * (WAVES * 12);
-      parity ^= 1;
-      if (lane == 0) {
-        r[wave * 12 + 0] = mx;
-        r[wave * 12 + 1] = badf;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) {
-        mx = r[w * 12] > mx ? r[w * 12] : mx;
-        badf = r[w * 12 + 1] > badf ? r[w * 12 + 1] : badf;
-      }
-    }
-    out.v[0] = mx > 0.0 ? sqrt(mx) : 0.0;  // max raw residual
-    return uni(badf == 0.0);
-  }
-  wave_sum10(acc);
-  if (WAVES > 1) {
-    double* r = red + parity * (WAVES * 12);
-    parity ^= 1;
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < 10; ++i) r[wave * 12 + i] = acc[i];
-      r[wave * 12 + 10] = badf;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = 0.0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-#pragma unroll
-      for (int i = 0; i < 10; ++i) acc[i] += r[w * 12 + i];
-      badf = r[w * 12 + 10] > badf ? r[w * 12 + 10] : badf;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 10; ++i) out.v[i] = acc[i];
-  return uni(badf == 0.0 && isfinite(acc[0]));
-}
 
 // ---------------------------------------------------------------- split mode (small batches) ---
 // A batch that cannot fill the chip with one wavefront per registration (one 512-registration loop-closure burst is 512
@@ -404,124 +199,6 @@ __device__ __forceinline__ bool eval_pass_split(const Stage& S, const double* x,
   for (int i = 0; i < 10; ++i) out.v[i] = acc[i];
   ST(3);
   return uni(badf == 0.0 && isfinite(acc[0]));
-}
-
-// packed lower triangle: (i, j), i >= j  ->  i (i + 1) / 2 + j
-__device__ __forceinline__ constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
-
-// g = T g_b, H = T G T^T (packed lower, NT (NT + 1) / 2 entries) for the parameterisation at ambient point x.
-// T is NT x 3 (see header); its zero / one entries are spelled out so that no multiplications by zero are left
-// (the compiler may not fold 0 * x under IEEE rules).
-template <int PARAM, int NT>
-__device__ __forceinline__ void to_param(const Base& B, const double* x, double* g, double* H) {
-  const double gb0 = B.v[1], gb1 = B.v[2], gb2 = B.v[3];
-  const double G00 = B.v[4], G01 = B.v[5], G02 = B.v[6], G11 = B.v[7], G12 = B.v[8], G22 = B.v[9];
-  if (vec_like(PARAM)) {
-    g[0] = gb0; g[1] = gb1; g[2] = gb2;
-    H[sym(0, 0)] = G00; H[sym(1, 0)] = G01; H[sym(1, 1)] = G11;
-    H[sym(2, 0)] = G02; H[sym(2, 1)] = G12; H[sym(2, 2)] = G22;
-    return;
-  }
-  const double cp = x[0], sp = x[1];
-  const double in2 = fast_rcp(cp * cp + sp * sp);
-  const double a = -sp * in2, b = cp * in2;  // d theta / d c, d theta / d s  (theta = atan2(s, c))
-  if (PARAM == RANDT_PARAM_AMBIENT4) {
-    // rows of T: c -> (0, 0, a); s -> (0, 0, b); tx -> (1, 0, 0); ty -> (0, 1, 0)
-    const double aG = a * G22, bG = b * G22;
-    g[0] = a * gb2; g[1] = b * gb2; g[2] = gb0; g[NT - 1] = gb1;
-    H[sym(0, 0)] = aG * a;
-    H[sym(1, 0)] = bG * a; H[sym(1, 1)] = bG * b;
-    H[sym(2, 0)] = a * G02; H[sym(2, 1)] = b * G02; H[sym(2, 2)] = G00;
-    H[sym(NT - 1, 0)] = a * G12; H[sym(NT - 1, 1)] = b * G12; H[sym(NT - 1, 2)] = G01; H[sym(NT - 1, NT - 1)] = G11;
-  } else {
-    // ambient row times Sophus PlusJacobian [[0,0,-s],[0,0,c],[c,-s,0],[s,c,0]] (stored complex):
-    // T = [[cp, sp, 0], [-sp, cp, 0], [0, 0, w]], w = a (-sp) + b cp
-    const double w = a * (-sp) + b * cp;
-    g[0] = cp * gb0 + sp * gb1;
-    g[1] = cp * gb1 - sp * gb0;
-    g[2] = w * gb2;
-    const double r00 = cp * G00 + sp * G01, r01 = cp * G01 + sp * G11;   // (R G2) rows
-    const double r10 = cp * G01 - sp * G00, r11 = cp * G11 - sp * G01;
-    H[sym(0, 0)] = r00 * cp + r01 * sp;
-    H[sym(1, 0)] = r10 * cp + r11 * sp;
-    H[sym(1, 1)] = r11 * cp - r10 * sp;
-    H[sym(2, 0)] = w * (cp * G02 + sp * G12);
-    H[sym(2, 1)] = w * (cp * G12 - sp * G02);
-    H[sym(2, 2)] = (w * G22) * w;
-  }
-}
-
-// Solve of the NT x NT SPD system A y = g by LDL^T (A packed lower, destroyed): NT reciprocals,
-// no square roots.  Returns false if a pivot is not positive.
-template <int NT>
-__device__ __forceinline__ bool ldlt_solve(double* A, const double* g, double* y) {
-  bool ok = true;
-  double inv_d[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    double d = A[sym(j, j)];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= A[sym(j, k)] * A[sym(j, k)] * A[sym(k, k)];
-    if (!(d > 0.0)) ok = false;
-    A[sym(j, j)] = d;
-    inv_d[j] = fast_rcp(d);
-#pragma unroll
-    for (int i = j + 1; i < NT; ++i) {
-      double a = A[sym(i, j)];
-#pragma unroll
-      for (int k = 0; k < j; ++k) a -= A[sym(i, k)] * A[sym(j, k)] * A[sym(k, k)];
-      A[sym(i, j)] = a * inv_d[j];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    double a = g[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) a -= A[sym(i, k)] * y[k];
-    y[i] = a;
-  }
-#pragma unroll
-  for (int i = 0; i < NT; ++i) y[i] *= inv_d[i];
-#pragma unroll
-  for (int i = NT - 1; i >= 0; --i) {
-    double a = y[i];
-#pragma unroll
-    for (int k = i + 1; k < NT; ++k) a -= A[sym(k, i)] * y[k];
-    y[i] = a;
-  }
-  return ok;
-}
-
-template <int PARAM>
-__device__ __forceinline__ double ambient_norm(const double* x) {
-  double n = 0.0;
-  constexpr int NA = vec_like(PARAM) ? 3 : 4;
-#pragma unroll
-  for (int i = 0; i < NA; ++i) n += x[i] * x[i];
-  return n > 0.0 ? n * fast_rsqrt(n) : 0.0;  // sqrt to ~1 ulp without the IEEE sequence (only feeds the parameter-tolerance test)
-}
-
-// Is ||x - Plus(x, -g)||_inf <= gtol (TrustRegionMinimizer::GradientToleranceReached)?  For the
-// manifold the displacement is >= 0.4 max|g_i| (|omega| <= pi), so the exact Plus is only
-// evaluated for tiny gradients.
-template <int PARAM, int NT>
-__device__ __forceinline__ bool gradient_converged(const double* x, const double* g, double gtol) {
-  double gm = 0.0;
-#pragma unroll
-  for (int i = 0; i < NT; ++i) gm = fabs(g[i]) > gm ? fabs(g[i]) : gm;
-  if (PARAM != RANDT_PARAM_MANIFOLD) return uni(gm <= gtol);
-  if (uni(0.4 * gm > gtol && gm < 3.0)) return false;
-  double neg[NT], xp[4];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) neg[i] = -g[i];
-  plus<PARAM>(x, neg, xp);
-  double m = 0.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const double a = fabs(x[i] - xp[i]);
-    m = a > m ? a : m;
-  }
-  return uni(m <= gtol);
 }
 
 __device__ __forceinline__ void trace_push(double* tr, int max_len, int tid, double cost, double radius, int flag) {
@@ -740,8 +417,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
   bool ok = RANDT_EVAL(0, x, cur);
   const double raw_max = cur.v[0];
   res.n_evals++;
-  double gnc_mu = 2.0 * (raw_max * raw_max) / (P.mu_scale * P.mu_scale);
-  gnc_mu = fmin(gnc_mu, P.mu_cap);
+  double gnc_mu = gnc_mu_start(raw_max, P.mu_scale, P.mu_cap);
   res.mu0 = gnc_mu;
   int term = RANDT_TERM_FAILURE;
   if (!ok) res.status = 2;
@@ -756,7 +432,6 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
       // statement group.  The arithmetic is statement for statement the reference's.
       double step[NT], delta[NT];
       constexpr int NS = NT * (NT + 1) / 2;
-      constexpr int NAmb = vec_like(PARAM) ? 3 : 4;
       double* const sigma = cold + 4;  // [NT]
       double* const diag = cold + 8;   // [NT]  LM diagonal of the current point (kept across rejected steps: reuse_diagonal)
       double* const gs = cold + 12;    // [NT]  Jacobi-scaled gradient / J^T J (packed lower) at the current point
@@ -794,7 +469,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
 #pragma unroll
         for (int i = 0; i < NT; ++i) {  // jacobi scaling 1 / (1 + sqrt(H_ii)), fixed per solve; Newton-refined rsqrt / rcp (~1 ulp:
           const double hii = H[sym(i, i)];  // the scaling is a change of variables, exact arithmetic does not see it)
-          sg[i] = fast_rcp(1.0 + (hii > 0.0 ? hii * fast_rsqrt(hii) : 0.0));
+          sg[i] = jacobi_scale(hii);
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -809,7 +484,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
             if (i == j) RANDT_COLD_SET(diag[i], fmin(fmax(hs, P.dmin), P.dmax));  // LevenbergMarquardtStrategy: clamp of the scaled J^T J diagonal
           }
         }
-        gconv = gradient_converged<PARAM, NT>(xr, g, P.gtol);
+        gconv = gradient_converged<PARAM, NT, true>(xr, g, P.gtol);
         // FinalizeIterationAndCheckIfMinimizerCanContinue of iteration zero: the starting point is the best one so far
         RANDT_COLD_SET(minimum_cost, cost);
 #pragma unroll
@@ -829,7 +504,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
         res.iterations++;
 
         // ---- LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled normal equations
-        double A[NS], Hr[NS], gr[NT], dg[NT], sg[NT], xr[4];
+        double Hr[NS], gr[NT], dg[NT], sg[NT], xr[4];
 #pragma unroll
         for (int i = 0; i < NS; ++i) Hr[i] = Hs[i];
 #pragma unroll
@@ -840,27 +515,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) xr[i] = x[i];
-        const double inv_radius = fast_rcp(radius);
-#pragma unroll
-        for (int i = 0; i < NS; ++i) A[i] = Hr[i];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) A[sym(i, i)] += dg[i] * inv_radius;  // (sqrt(D^2 / radius))^2
-        bool solved = ldlt_solve<NT>(A, gr, step);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          if (!isfinite(step[i])) solved = false;
-          step[i] = -step[i];
-        }
-        // model_cost_change = -(J step)^T (r + J step / 2) = -(step.g + step^T H step / 2)
-        double mcc = 0.0;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-          double hs = 0.0;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) hs += Hr[sym(i, j)] * step[j];
-          mcc += step[i] * (gr[i] + 0.5 * hs);
-        }
-        mcc = -mcc;
+        double mcc;
+        const bool solved = compute_step<NT>(Hr, gr, dg, radius, step, mcc);  // + model_cost_change = -(step.g + step^T H step / 2)
         const bool valid = uni(solved && mcc > 0.0);
         if (!valid) {
           // ---- HandleInvalidStep
@@ -877,7 +533,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
 #pragma unroll
         for (int i = 0; i < NT; ++i) delta[i] = step[i] * sg[i];
         double cnew[4];
-        plus<PARAM>(xr, delta, cnew);
+        plus<PARAM, true>(xr, delta, cnew);
 #pragma unroll
         for (int i = 0; i < 4; ++i) RANDT_COLD_SET(cand[i], cnew[i]);
         RANDT_COLD_SYNC();
@@ -903,9 +559,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
         for (int i = 0; i < NS; ++i) ssn[i] = ss[i];
 
         // ---- ParameterToleranceReached / FunctionToleranceReached (before accept/reject)
-        double sn2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NAmb; ++i) sn2 += (xc[i] - cc[i]) * (xc[i] - cc[i]);
+        const double sn2 = step_norm_sq<PARAM>(xc, cc);
         const double ptol_abs = P.ptol * (xn_cur + P.ptol);
         if (uni(sn2 <= ptol_abs * ptol_abs)) { term = RANDT_TERM_CONVERGENCE_PARAMETER; break; }
         const double cost_change = cost - cand_cost;
@@ -929,11 +583,9 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
               RANDT_COLD_SET(Hs[sym(i, j)], hs);
               if (i == j) RANDT_COLD_SET(diag[i], fmin(fmax(hs, P.dmin), P.dmax));  // the LM diagonal of the new point
             }
-          gconv = gradient_converged<PARAM, NT>(cc, g, P.gtol);
+          gconv = gradient_converged<PARAM, NT, true>(cc, g, P.gtol);
           step_ok = true;
-          const double t = 2.0 * rel - 1.0;
-          radius = radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - t * t * t));
-          radius = fmin(P.rmax, radius);
+          radius = radius_after_success(radius, rel, P.rmax);
           decrease = 2.0;
           // FinalizeIteration...: x is copied to the user parameters when the accepted point lowers the minimum cost
           if (uni(cost < mincost)) {

@@ -9,7 +9,7 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (randt_internal.h is left out on purpose: it also carries the launcher declarations of every other translation unit, which
 # change without touching a hot kernel; MapView / SolveParams / randt_ctx live there and change rarely -- re-collect when they do)
-HOT_SOURCES = ("solve.hip", "solve_math.h", "associate.hip", "ndt_build.hip", "cell_math.h")
+HOT_SOURCES = ("solve.hip", "solve_pass.h", "solve_algebra.h", "solve_math.h", "associate.hip", "ndt_build.hip", "cell_math.h")
 
 
 def _strip(text):
