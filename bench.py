@@ -6,8 +6,11 @@ registrations (8 submaps x 64 scans; 2000-point radar scans vs 100x100-slot 0.5 
 registration = NDT build from the raw points + association against its submap + the full GNC / Levenberg-Marquardt
 solve, all on the GPU through the C ABI of librandt_hip.so.  Inputs are resident in HBM before the timed region starts.
 
-Timed region: at least --steps steps AND at least --min-seconds of wall time (a 20-step region is 1.7 ms: clocks have
-not settled); the JSON reports the number of steps actually timed ("steps") next to the requested minimum.
+Timed region: an UNTIMED settle region of at least --min-seconds first (clocks, caches, allocator; it is clocked on the
+side and reported as `sustained` = the rate the path holds when steps keep coming), then EXACTLY --steps steps between
+barrier + synchronize on both sides -- the headline `value`.  The exact-K region is run --repeats times, each fully
+bracketed; the median region is reported, all are listed.  A K-step region pays the pipeline's fill and drain (a step's
+three launches last ~0.3 ms under load): with the driver's K = 20 the headline is a BURST figure, `sustained` the steady one.
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU; "nccl" = RCCL over xGMI).  Independent registrations
 shard with no data-path collective; the only collectives are the set-up broadcast of the submap tables and the result
@@ -209,9 +212,10 @@ _HUNG_THREADS = []   # watchdog victims (a collective that never returned): the 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000, help="minimum number of timed steps")
+    ap.add_argument("--steps", type=int, default=1000, help="steps of the timed region (exactly this many)")
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--min-seconds", type=float, default=0.3, help="the timed region also lasts at least this long")
+    ap.add_argument("--min-seconds", type=float, default=0.3, help="length of the untimed settle region in front of the timed one (clocked on the side: `sustained`)")
+    ap.add_argument("--repeats", type=int, default=9, help="the exact --steps region is run this many times (median reported, all listed)")
     ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
                     help="multi-GPU regions to time (the headline value is the weak one unless only strong is asked for)")
     ap.add_argument("--batch-scale", type=int, default=1,
@@ -231,6 +235,7 @@ def main():
                     help="BASELINE config 5 side measurement: full local-fuser loop on raw polar scans (0 = skip)")
     ap.add_argument("--event-every", type=int, default=EVENT_EVERY, help="bracket the launches of every N-th timed step with HIP events (stage residency)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config2", action="store_true", help="skip the single-pair latency section (BASELINE config 2)")
     ap.add_argument("--no-roofline-sections", action="store_true", help="skip the single-stream / chip-filling-launch sections")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock budget of each CPU baseline leg")
     args = ap.parse_args()
@@ -375,20 +380,37 @@ def main():
     warm_up(torch, full, streams, args.warmup * n_streams)
 
     # ---------------- timed region (weak = the headline) --------------------------------------------
-    # the region is re-run with more steps until it lasts --min-seconds (the LAST region is the reported one; `elapsed` is
-    # already the maximum over ranks, so every rank takes the same decision)
-    def region(batch, use_streams=None):
-        n = args.steps
+    # settle (untimed for the headline, clocked on the side), then EXACTLY args.steps steps, args.repeats times; `elapsed` is
+    # already the maximum over ranks, so every rank takes the same decisions
+    def settle(batch, use_streams=None):
+        n, best = max(args.steps, 16 * n_streams), None
+        if args.min_seconds <= 0:
+            return None
         for _ in range(6):
             r = timed_region(torch, dist, world, dev, batch, use_streams or streams, n, args.only)
+            best = (n,) + r
             if r[0] >= args.min_seconds:
                 break
             n = int(math.ceil(n * max(1.5, 1.25 * args.min_seconds / max(r[0], 1e-9))))
-        return (n,) + r
+        return best
+
+    def region(batch, use_streams=None):
+        sus = settle(batch, use_streams)
+        runs = [timed_region(torch, dist, world, dev, batch, use_streams or streams, args.steps, args.only) for _ in range(max(1, args.repeats))]
+        order = sorted(range(len(runs)), key=lambda i: runs[i][0])
+        r = runs[order[len(order) // 2]]
+        info = {"repeats": len(runs), "region_ms": [x[0] * 1e3 for x in runs]}
+        if sus is not None:
+            info["sustained"] = {"steps": sus[0], "timed_region_s": sus[1], "ms_per_step": sus[1] / sus[0] * 1e3,
+                                 "value": batch.B * sus[0] * (world if batch is full else 1) / sus[1], "unit": "registrations/s",
+                                 "stage_ms": [float(v) for v in sus[3]],
+                                 "note": "the settle region in front of the timed one: %d steps back to back on %d streams, same bracketing; "
+                                         "the steady rate (what rounds 1-3 reported as the headline)" % (sus[0], len(use_streams or streams))}
+        return (args.steps,) + r + (info,)
 
     out = {}
     if args.scaling != "strong" or world == 1:
-        n_steps, elapsed, t_enqueued, stage_ms, pose0 = region(full)
+        n_steps, elapsed, t_enqueued, stage_ms, pose0, rinfo = region(full)
         value = B * n_steps * world / elapsed
         scaling = "weak"
     strong = None
@@ -398,13 +420,13 @@ def main():
             # through the C ABI: shard + kernels + RCCL gather of poses / records inside every step
             part = GroupBatch(R, torch, grp, submaps_g, mapp, clu, mp, *to_dev(base))
             warm_up(torch, part, streams[:1], 4)
-            s_steps, s_elapsed, s_enq, s_stage, s_pose0 = region(part, streams[:1])
+            s_steps, s_elapsed, s_enq, s_stage, s_pose0, s_info = region(part, streams[:1])
             all_pose, all_res, t_gather = s_pose0, part.results[0], None
             how = "randt_group_scan_register_batch_dev (C ABI, RCCL gather inside every step, one stream)"
         else:
             part = Batch(R, torch, ctxs, submaps_v, mapp, clu, mp, *to_dev(base, lo, hi))
             warm_up(torch, part, streams, 2 * n_streams)
-            s_steps, s_elapsed, s_enq, s_stage, s_pose0 = region(part)
+            s_steps, s_elapsed, s_enq, s_stage, s_pose0, s_info = region(part)
             # result gather (all-gather of 32-B poses + 64-B records) and the bit-identity check against the unsharded batch
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -420,7 +442,8 @@ def main():
                   "entry": how,
                   "stage_ms": {"ndt_build": float(s_stage[0]), "associate": float(s_stage[1]), "solve": float(s_stage[2])},
                   "result_gather_ms": None if t_gather is None else t_gather * 1e3, "submap_broadcast_ms": t_bcast * 1e3,
-                  "submap_broadcast_bytes": int(cb + nb + gb)}
+                  "submap_broadcast_bytes": int(cb + nb + gb), "repeats": s_info["repeats"], "region_ms": s_info["region_ms"],
+                  "sustained": s_info.get("sustained")}
         if rank == 0:
             ref = Batch(R, torch, ctxs[:1], submaps_v[:1], mapp, clu, mp, *to_dev(base))
             rp = ref.guess4.clone()
@@ -429,7 +452,7 @@ def main():
             strong["poses_bit_identical_to_unsharded"] = bool(torch.equal(all_pose.cpu(), rp.cpu()) and
                                                               torch.equal(all_res.cpu(), ref.results[0].cpu()))
         if args.scaling == "strong":
-            n_steps, elapsed, t_enqueued, stage_ms, pose0, value, scaling = s_steps, s_elapsed, s_enq, s_stage, s_pose0, strong["value"], "strong"
+            n_steps, elapsed, t_enqueued, stage_ms, pose0, value, scaling, rinfo = s_steps, s_elapsed, s_enq, s_stage, s_pose0, strong["value"], "strong", s_info
 
     if rank == 0:
         res = full.results[0].cpu().numpy().view(R.RESULT_DTYPE).reshape(-1)
@@ -453,10 +476,15 @@ def main():
                 "mean_scan_cells": m_mean, "mean_residuals": n_res_mean, "mean_lm_iterations": float(res["iterations"].mean()),
                 "mean_passes": float(res["n_evals"].mean()),
             },
+            "repeats": rinfo["repeats"], "region_ms": rinfo["region_ms"],
+            "region_note": "value = batch x steps / the MEDIAN of `repeats` regions of exactly `steps` steps, each between barrier + synchronize "
+                           "(fill and drain of the 16-stream pipeline included: a burst figure at small --steps); `sustained` = the settle region",
             "host_enqueue_ms_per_step": t_enqueued / n_steps * 1e3,
             "stage_ms": {"ndt_build": float(stage_ms[0]), "associate": float(stage_ms[1]), "solve": float(stage_ms[2]),
                          "note": "HIP-event residency of each launch while %d batches share the chip (not a per-step cost)" % n_streams},
         }
+        if "sustained" in rinfo:
+            out["sustained"] = rinfo["sustained"]
         if strong is not None:
             out["strong_scaling"] = strong
         # Everything below is a side measurement on rank 0: a failure there must never cost the headline line.
@@ -473,9 +501,15 @@ def main():
         if not args.no_roofline_sections and args.only is None and args.batch_scale == 1:
             # (at N > 1 too: rank 0 alone, the other ranks wait at the closing barrier; per-GPU figures)
             side(None, roofline_sections, R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file,
-                 b_alg, value / world, elapsed / n_steps, counters_stale, throughput_mode)
+                 b_alg, (rinfo["sustained"]["value"] if "sustained" in rinfo else value) / world,
+                 (rinfo["sustained"]["ms_per_step"] * 1e-3 if "sustained" in rinfo else elapsed / n_steps), counters_stale, throughput_mode)
         if not args.no_cpu_baseline and world == 1:
             side(None, cpu_baseline, weak_prob, mp, pose0.cpu().numpy(), args.cpu_seconds)
+        if world == 1 and args.only is None and not args.no_config2:
+            side("config2_single_pair", config2_single_pair, R, torch, ctx, submaps, full, mapp, clu, mp, weak_prob, not args.no_cpu_baseline,
+                 min(3.0, args.cpu_seconds))
+            if throughput_mode:
+                ctx.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
         if args.odometry_scans > 0 and world == 1:
             side("config3_streaming_odometry", streaming_odometry, ctx, args.odometry_scans, not args.no_cpu_baseline)
         if args.polar_scans > 0 and world == 1:
@@ -589,7 +623,7 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
             roof["path"] = {
                 "valu_issue_cycles_per_step": tot, "by_kernel": {n: cyc[n] for n in HOT_KERNELS},
                 "achieved": tot / (s_per_step * 1e6) * 1e-3, "frac": tot / (s_per_step * 1e6) * 1e-3 / VALU_PEAK,
-                "note": "all three launches of a step / ms_per_step of the 16-stream headline region (throughput, no residency involved)",
+                "note": "all three launches of a step / ms_per_step of the 16-stream SUSTAINED region (throughput, no residency involved)",
                 "chip_filling_launch_us": {"k_ndt_build": sat_build_us, "k_associate": sat_assoc_us, "k_solve": sat_us,
                                            "registrations": big.B},
                 # each kernel by itself: issue cycles of its chip-filling launch / that launch's duration (the two short kernels are
@@ -629,6 +663,104 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
                              "frac": ks["valu_issue_cycles"] / us_512 * 1e-3 / VALU_PEAK,
                              "note": "%d x %d launches of the 512-registration solve on %d streams, wall clock between synchronisations "
                                      "(nothing else running): the same kernel with its launch tails covered" % (per, n_s, n_s)}
+    return out
+
+
+def config2_single_pair(R, torch, ctx, submaps, full, mapp, clu, mp, prob, with_cpu, budget_s):
+    """BASELINE config 2 as a caller feels it (LocalFuser calls estimateLoopConstraint one candidate at a time,
+    local_fuser.cpp:335,387,395): host call -> result latency of ONE registration on an otherwise idle GPU, through
+    (a) randt_register_pair (maps resident, host pose in / out, synchronous) and (b) randt_scan_register_batch_dev with B = 1
+    (raw scan resident, NDT build + association + solve, then a stream synchronisation), with the HIP-event kernel share of (b);
+    beside them the CPU oracle on the same pair at one thread and with its residual blocks over all granted cores (what
+    Ceres' num_threads = hardware_concurrency() does, ndt_matcher.cpp:376,461)."""
+    from randt_slam_amd import host
+
+    dev = full.points.device
+    st = torch.cuda.current_stream()
+    ctx.set_solve_mode(R._capi.SOLVE_AUTO)
+    pts = full.points[:1].contiguous()
+    fidx = full.fixed_idx[:1].contiguous()
+    g4 = full.guess4[:1].contiguous()
+    sub_i = int(fidx[0].item())
+    ws = R.Maps(ctx, 1, mapp, 512, with_grid=False)
+    res = torch.zeros((1, 64), dtype=torch.uint8, device=dev)
+    reps = 300
+    lat_b, ker_b = [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i in range(reps + 20):
+        pose = g4.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record(st)
+        R.scan_register_batch(ctx, pts, clu, submaps, fidx, ws, mp, pose, res)
+        e1.record(st)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        if i >= 20:
+            lat_b.append((t1 - t0) * 1e6)
+            ker_b.append(e0.elapsed_time(e1) * 1e3)
+    g_host = g4.cpu().numpy()[0]
+    lat_a = []
+    for i in range(reps + 20):
+        t0 = time.perf_counter()
+        p_a, r_a = host.register_pair(ctx, submaps, sub_i, ws, 0, mp, g_host)
+        t1 = time.perf_counter()
+        if i >= 20:
+            lat_a.append((t1 - t0) * 1e6)
+    q = lambda v: {"median_us": float(np.median(v)), "p10_us": float(np.percentile(v, 10)), "p90_us": float(np.percentile(v, 90)), "calls": len(v)}
+    out = {"workload": "ONE 2000-point scan against ONE 100x100-slot submap (registration 0 of the config-4 batch), GPU otherwise idle",
+           "randt_register_pair": dict(q(lat_a), note="scan cells already built and resident; host pose in, pose + record out, synchronous"),
+           "randt_scan_register_batch_dev_B1": dict(q(lat_b), kernel_us_hip_events=float(np.median(ker_b)),
+                                                    note="raw scan resident; NDT build + association + solve (split geometry, eight wavefronts) "
+                                                         "+ one stream synchronisation; kernel_us = first launch to last launch end on the stream"),
+           "iterations": int(r_a["iterations"]), "n_residuals": int(r_a["n_residuals"])}
+    ws.close()
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        from randt_slam_amd import synth
+
+        ip = synth.indoor_params()
+        mk = lambda cap=None: po.Map(ip["size_x"], ip["size_y"], ip["resolution"], (0, 0), ip["max_neighbour_dist"], ip["min_points_per_cell"], cap)
+        sm = prob["submaps"][sub_i]
+        osub = mk()
+        for t in range(len(sm["kf_scans"])):
+            m = mk(512)
+            m.build(sm["kf_scans"][t], ip["n_clusters"], ip["max_range"])
+            m.transform(synth.pose3_to_pose4(sm["kf_rel"][t]))
+            osub.merge(m)
+        op = po.default_params()
+        for name, _ in mp._fields_:
+            if name != "reserved":
+                setattr(op, name, getattr(mp, name))
+        eff, logical, quota = effective_cpus()
+        cores = max(1, min(po.num_threads(), eff))
+        g0 = synth.pose3_to_pose4(prob["guess"])[0]
+
+        def leg(threads):
+            po.set_eval_threads(threads)
+            v, t_total, p4 = [], 0.0, None
+            try:
+                while t_total < budget_s or len(v) < 5:
+                    t0 = time.perf_counter()
+                    om = mk(512)
+                    om.build(prob["scans"][0], ip["n_clusters"], ip["max_range"])
+                    rc, p4, cost, stt = po.register_pair(osub, om, op, g0)
+                    dt = time.perf_counter() - t0
+                    v.append(dt * 1e6)
+                    t_total += dt
+            finally:
+                po.set_eval_threads(1)
+            return v, p4
+
+        v1, p1 = leg(1)
+        vn, pn = leg(cores)
+        out["cpu_oracle"] = {"kind": "port", "one_thread": dict(q(v1), cores=1),
+                             "residual_parallel": dict(q(vn), cores=cores,
+                                                       note="OpenMP over the residual blocks of the ONE problem (timing only: the cost is then "
+                                                            "a reduction in another order than the oracle proper)"),
+                             "sample": "NDT build + association + GNC/LM solve of the same pair, repeated for %.0f s per leg" % budget_s,
+                             "pose_vs_gpu_max_abs": float(np.abs(np.asarray(p1) - np.asarray(p_a)).max())}
     return out
 
 
@@ -816,6 +948,21 @@ def streaming_odometry(ctx, n_scans, with_cpu):
             pc = cpu.process_scan(scans[i], i * dt)
         out["cpu_oracle_scans_per_sec"] = n_cpu / (time.perf_counter() - t0)
         out["cpu_oracle_sample"] = "first %d scans, 1 thread (sequential path)" % n_cpu
+        # the same drive with the residual blocks of every window problem over all granted cores: what the reference's
+        # num_threads = hardware_concurrency() (ndt_matcher.cpp:376) buys on the sequential path (timing only, other summation order)
+        import pyoracle as po
+        eff, _, _ = effective_cpus()
+        cores = max(1, min(po.num_threads(), eff))
+        po.set_eval_threads(cores)
+        try:
+            cpu = odometry.Odometry(OracleBackend(), mp, wp)
+            t0 = time.perf_counter()
+            for i in range(n_cpu):
+                cpu.process_scan(scans[i], i * dt)
+            out["cpu_oracle_residual_parallel"] = {"scans_per_sec": n_cpu / (time.perf_counter() - t0), "cores": cores,
+                                                   "sample": "the same %d scans, residual blocks over %d OpenMP threads" % (n_cpu, cores)}
+        finally:
+            po.set_eval_threads(1)
     return out
 
 

@@ -436,6 +436,11 @@ def se2_inv(a):
     return out
 
 
+def set_eval_threads(n):
+    """TIMING ONLY: residual blocks of one problem over n OpenMP threads (changes the summation order); 1 restores the oracle proper."""
+    lib().orc_set_eval_threads(int(n))
+
+
 def num_threads():
     return lib().orc_num_threads()
 

@@ -35,6 +35,12 @@ static int32_t trunc_to_i32(float v) {
   return (int32_t)v;
 }
 
+/* TIMING ONLY (bench.py's cpu_baseline legs): residual blocks of ONE problem evaluated by several OpenMP threads, what
+ * Ceres does with options.num_threads = hardware_concurrency() (ndt_matcher.cpp:376,461).  The cost is then a reduction
+ * over threads, i.e. summed in another order than the sequential evaluation every parity test uses (default 1). */
+static int g_eval_threads = 1;
+void orc_set_eval_threads(int n) { g_eval_threads = n > 1 ? n : 1; }
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -1103,51 +1109,68 @@ static void x_to_pose4(const pair_user* u, const double* x, double p4[4]) {
 }
 
 /* ResidualBlock::Evaluate + Corrector (Ceres 2.1.0 residual_block.cc, corrector.cc). */
+/* one residual block of the pair problem; returns 0 on a non-finite residual */
+static int pair_eval_block(const pair_user* u, const double* p4, int i, int nj, double* total, double* residuals, double* jac) {
+  double j[4];
+  int d = u->d;
+  double r = orc_ndt_residual(d, u->parameterization, p4, u->mm + (size_t)i * d, u->mc + (size_t)i * d * d,
+                              u->fm + (size_t)i * d, u->fc + (size_t)i * d * d, jac ? j : NULL);
+  if (!isfinite(r)) return 0;
+  double sq = r * r;
+  if (!u->apply_loss) {
+    *total += 0.5 * sq;
+    if (residuals) residuals[i] = r;
+    if (jac) for (int a = 0; a < nj; ++a) jac[(size_t)i * nj + a] = j[a];
+    return 1;
+  }
+  double rho[3];
+  orc_barron_scaled(sq, u->loss_a, u->loss_alpha, u->loss_mu, u->loss_w, rho);
+  *total += 0.5 * rho[0];
+  if (residuals || jac) {
+    double sqrt_rho1 = sqrt(rho[1]);
+    double residual_scaling, alpha_sq_norm;
+    if (sq == 0.0 || rho[2] <= 0.0) {
+      residual_scaling = sqrt_rho1;
+      alpha_sq_norm = 0.0;
+    } else {
+      const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+      const double alpha = 1.0 - sqrt(D);
+      residual_scaling = sqrt_rho1 / (1 - alpha);
+      alpha_sq_norm = alpha / sq;
+    }
+    if (jac) {
+      /* CorrectJacobian: J = sqrt_rho1 * (J - alpha_sq_norm * r r^T J); one residual row */
+      for (int a = 0; a < nj; ++a) {
+        double ja = j[a];
+        if (alpha_sq_norm != 0.0) ja = ja - alpha_sq_norm * r * (r * ja);
+        jac[(size_t)i * nj + a] = sqrt_rho1 * ja;
+      }
+    }
+    if (residuals) residuals[i] = residual_scaling * r;
+  }
+  return 1;
+}
+
+/* ResidualBlock::Evaluate + Corrector (Ceres 2.1.0 residual_block.cc, corrector.cc). */
 static int pair_eval(void* user, const double* x, double* cost, double* residuals, double* jac) {
   const pair_user* u = (const pair_user*)user;
   const int nj = u->parameterization == ORC_PARAM_AMBIENT4 ? 4 : 3;
   double p4[4];
   x_to_pose4(u, x, p4);
   double total = 0;
-  for (int i = 0; i < u->n; ++i) {
-    double j[4];
-    int d = u->d;
-    double r = orc_ndt_residual(d, u->parameterization, p4, u->mm + (size_t)i * d, u->mc + (size_t)i * d * d,
-                                u->fm + (size_t)i * d, u->fc + (size_t)i * d * d, jac ? j : NULL);
-    if (!isfinite(r)) return 0;
-    double sq = r * r;
-    if (!u->apply_loss) {
-      total += 0.5 * sq;
-      if (residuals) residuals[i] = r;
-      if (jac) for (int a = 0; a < nj; ++a) jac[(size_t)i * nj + a] = j[a];
-      continue;
-    }
-    double rho[3];
-    orc_barron_scaled(sq, u->loss_a, u->loss_alpha, u->loss_mu, u->loss_w, rho);
-    total += 0.5 * rho[0];
-    if (residuals || jac) {
-      double sqrt_rho1 = sqrt(rho[1]);
-      double residual_scaling, alpha_sq_norm;
-      if (sq == 0.0 || rho[2] <= 0.0) {
-        residual_scaling = sqrt_rho1;
-        alpha_sq_norm = 0.0;
-      } else {
-        const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
-        const double alpha = 1.0 - sqrt(D);
-        residual_scaling = sqrt_rho1 / (1 - alpha);
-        alpha_sq_norm = alpha / sq;
-      }
-      if (jac) {
-        /* CorrectJacobian: J = sqrt_rho1 * (J - alpha_sq_norm * r r^T J); one residual row */
-        for (int a = 0; a < nj; ++a) {
-          double ja = j[a];
-          if (alpha_sq_norm != 0.0) ja = ja - alpha_sq_norm * r * (r * ja);
-          jac[(size_t)i * nj + a] = sqrt_rho1 * ja;
-        }
-      }
-      if (residuals) residuals[i] = residual_scaling * r;
-    }
+#ifdef _OPENMP
+  if (g_eval_threads > 1) { /* timing only: see orc_set_eval_threads */
+    int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(g_eval_threads) reduction(+ : total) reduction(| : bad)
+    for (int i = 0; i < u->n; ++i)
+      if (!pair_eval_block(u, p4, i, nj, &total, residuals, jac)) bad |= 1;
+    if (bad) return 0;
+    *cost = total;
+    return 1;
   }
+#endif
+  for (int i = 0; i < u->n; ++i)
+    if (!pair_eval_block(u, p4, i, nj, &total, residuals, jac)) return 0;
   *cost = total;
   return 1;
 }
@@ -1781,14 +1804,24 @@ static int win_eval(void* user, const double* x, double* cost, double* residuals
       }
       row += 2;
     }
-    while (ndt_at < u->n_ndt && u->ndt_state[ndt_at] == j) {
+    int ndt_end = ndt_at;
+    while (ndt_end < u->n_ndt && u->ndt_state[ndt_end] == j) ++ndt_end;
+    /* vector form: NDTFrameToMap{,Intensity}FactorResidual on (pos, rot) (ceres_residuals.h:421-451, 486-518) */
+    const double pv[4] = {cos(st[j].rot), sin(st[j].rot), st[j].pos[0], st[j].pos[1]};
+    int bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_eval_threads) reduction(+ : total) reduction(| : bad) if (g_eval_threads > 1)
+#endif
+    for (int at = ndt_at; at < ndt_end; ++at) {
       const int d = u->d;
+      const int rw_i = row + (at - ndt_at);
       double jl[4];
-      /* vector form: NDTFrameToMap{,Intensity}FactorResidual on (pos, rot) (ceres_residuals.h:421-451, 486-518) */
-      const double pv[4] = {cos(st[j].rot), sin(st[j].rot), st[j].pos[0], st[j].pos[1]};
-      double r = orc_ndt_residual(d, u->vec ? (u->analytic ? ORC_PARAM_ANALYTIC : ORC_PARAM_VECTOR) : ORC_PARAM_MANIFOLD, u->vec ? pv : st[j].pose, u->mm + (size_t)ndt_at * d,
-                                  u->mc + (size_t)ndt_at * d * d, u->fm + (size_t)ndt_at * d, u->fc + (size_t)ndt_at * d * d, jac ? jl : NULL);
-      if (!isfinite(r)) return 0;
+      double r = orc_ndt_residual(d, u->vec ? (u->analytic ? ORC_PARAM_ANALYTIC : ORC_PARAM_VECTOR) : ORC_PARAM_MANIFOLD, u->vec ? pv : st[j].pose, u->mm + (size_t)at * d,
+                                  u->mc + (size_t)at * d * d, u->fm + (size_t)at * d, u->fc + (size_t)at * d * d, jac ? jl : NULL);
+      if (!isfinite(r)) {
+        bad |= 1;
+        continue;
+      }
       const double sq = r * r;
       double rs = 1.0, js = 1.0;
       if (u->apply_loss) {
@@ -1807,14 +1840,15 @@ static int win_eval(void* user, const double* x, double* cost, double* residuals
       } else {
         total += 0.5 * sq;
       }
-      if (residuals) residuals[row] = rs * r;
+      if (residuals) residuals[rw_i] = rs * r;
       if (jac) {
-        double* rw = jac + (size_t)row * nt;
+        double* rw = jac + (size_t)rw_i * nt;
         for (int e = 0; e < 3; ++e) rw[u->off_tan[j][0] + e] = js * jl[e];
       }
-      ++row;
-      ++ndt_at;
     }
+    if (bad) return 0;
+    row += ndt_end - ndt_at;
+    ndt_at = ndt_end;
   }
   *cost = total;
   return 1;

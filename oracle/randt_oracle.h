@@ -324,6 +324,8 @@ void orc_se2_mul(const double a4[4], const double b4[4], double out4[4]);
 void orc_se2_inv(const double a4[4], double out4[4]);
 
 int orc_num_threads(void);
+/* timing only: OpenMP threads over the residual blocks of ONE problem (Ceres' options.num_threads); default 1 = sequential sums */
+void orc_set_eval_threads(int n);
 
 #ifdef __cplusplus
 }

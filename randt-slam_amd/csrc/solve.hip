@@ -236,8 +236,15 @@ __device__ __forceinline__ void trace_push(double* tr, int max_len, int tid, dou
 #define RANDT_SOLVE_OCC(AM2, SPLIT) \
   __attribute__((amdgpu_waves_per_eu(RANDT_SOLVE_WPE_OF(AM2, SPLIT, BLOCK), RANDT_SOLVE_WPE_OF(AM2, SPLIT, BLOCK))))
 #endif
+#ifdef RANDT_SOLVE_NUM_VGPR  // experiment knob: cap the one-wavefront closed-form kernels below their 128-register slot
+#define RANDT_SOLVE_VGPR_CAP __attribute__((amdgpu_num_vgpr(RANDT_SOLVE_NUM_VGPR)))
+#undef RANDT_SOLVE_OCC
+#define RANDT_SOLVE_OCC(AM2, SPLIT)
+#else
+#define RANDT_SOLVE_VGPR_CAP
+#endif
 template <int D, int PARAM, int BLOCK, bool AM2, int RPB, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_OCC(AM2, SPLIT) void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
+__global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_OCC(AM2, SPLIT) RANDT_SOLVE_VGPR_CAP void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
                                                       int moving_first, const int32_t* __restrict__ corr, SolveParams P,
                                                       double* __restrict__ pose4, randt_result* __restrict__ results,
                                                       double* trace, int trace_len, int n_total) {

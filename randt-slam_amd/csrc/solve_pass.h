@@ -23,6 +23,10 @@
 
 namespace randt_pass {
 using namespace randt_solve;
+
+__device__ __forceinline__ double sgpr_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 using randt_lm::Base;
 using randt_lm::vec_like;
 
@@ -69,7 +73,14 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
   constexpr int WAVES = BLOCK / 64;
   double c, s, tx, ty;
   pass_pose<D, PARAM>(x, c, s, tx, ty);
-  const Rot rot = make_rot(c, s);
+  // the evaluation point is the same in every lane: its rotation products, the translation and the loss constants live in
+  // SGPRs (a VALU instruction takes one scalar operand) instead of 2 x 12 vector registers per lane -- the four-per-SIMD
+  // kernels then need 122 registers and no scratch (128 with seven spilled dwords before; same speed, round 4)
+  c = sgpr_f64(c); s = sgpr_f64(s); tx = sgpr_f64(tx); ty = sgpr_f64(ty);
+  Rot rot = make_rot(c, s);
+  rot.c2 = sgpr_f64(rot.c2); rot.s2 = sgpr_f64(rot.s2); rot.cs = sgpr_f64(rot.cs); rot.cs2 = sgpr_f64(rot.cs2); rot.c2ms2 = sgpr_f64(rot.c2ms2);
+  Loss Lu = L;
+  Lu.ts = sgpr_f64(L.ts); Lu.weight = sgpr_f64(L.weight); Lu.half_w_pre = sgpr_f64(L.half_w_pre);
   RANDT_PRIO_TRIPS();
   double acc[10];
 #pragma unroll
@@ -86,7 +97,7 @@ __device__ __forceinline__ bool eval_pass(const Stage& S, const double* x, const
     if (MODE == 0) {
       mx = sq > mx ? sq : mx;
     } else {
-      accumulate_residual<AM2>(L, sq, jb, acc);
+      accumulate_residual<AM2>(Lu, sq, jb, acc);
     }
   };
   auto one = [&](unsigned mi, unsigned ci) { one_rec(S.mov + (size_t)mi * 3, S.fix + (size_t)ci * 3); };

@@ -27,7 +27,13 @@ def test_bench_single_gpu_contract():
     for k in REQUIRED + ["cpu_baseline"]:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps_requested"] == 4 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64"
-    assert d["steps"] >= 4 and d["timed_region_s"] >= 0.1                            # --min-seconds 0.1 below
+    assert d["steps"] == 4 and d["repeats"] == len(d["region_ms"]) >= 1             # EXACTLY what was asked for
+    assert d["sustained"]["timed_region_s"] >= 0.1 and d["sustained"]["value"] > 1e5  # --min-seconds 0.1 below: the settle region
+    c2 = d["config2_single_pair"]
+    assert c2["randt_register_pair"]["median_us"] > 10 and c2["randt_scan_register_batch_dev_B1"]["kernel_us_hip_events"] > 10
+    assert c2["cpu_oracle"]["one_thread"]["cores"] == 1 and c2["cpu_oracle"]["residual_parallel"]["cores"] >= 1
+    assert c2["cpu_oracle"]["pose_vs_gpu_max_abs"] <= 1e-6
+    assert d["config3_streaming_odometry"]["cpu_oracle_residual_parallel"]["scans_per_sec"] > 0
     assert abs(d["ms_per_step"] * d["steps"] * 1e-3 - d["timed_region_s"]) < 1e-9
     assert d["value"] > 1e5 and "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
