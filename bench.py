@@ -147,15 +147,15 @@ class Batch:
         R, cx = self.R, self.ctxs[j]
         if events is not None:
             events[0].record(stream)
-        if only in (None, "build"):
+        if only in (None, "build", "no-associate"):
             R.ndt_build_batch(cx, self.points, self.clu, self.scan_maps[j])
         if events is not None:
             events[1].record(stream)
-        if only in (None, "associate"):
+        if only in (None, "associate", "no-build"):
             R.associate_batch(cx, self.submaps_v[j], self.fixed_idx, self.scan_maps[j], 0, self.B, pose, self.mp, self.corrs[j])
         if events is not None:
             events[2].record(stream)
-        if only in (None, "solve"):
+        if only in (None, "solve", "no-build", "no-associate"):
             R.solve_batch(cx, self.submaps_v[j], self.fixed_idx, self.scan_maps[j], 0, self.B, self.corrs[j], self.mp, pose, self.results[j])
         if events is not None:
             events[3].record(stream)
@@ -220,7 +220,7 @@ def main():
                     help="multi-GPU regions to time (the headline value is the weak one unless only strong is asked for)")
     ap.add_argument("--batch-scale", type=int, default=1,
                     help="diagnostic: registrations per step = 512 x this (the headline workload is 1)")
-    ap.add_argument("--only", choices=["build", "associate", "solve"], default=None,
+    ap.add_argument("--only", choices=["build", "associate", "solve", "no-build", "no-associate"], default=None,
                     help="diagnostic: time ONE stage alone at saturation (the printed value is then not the headline metric)")
     ap.add_argument("--streams", type=int, default=16, help="in-flight batches: step i runs on HIP stream i %% streams "
                     "(GPU_MAX_HW_QUEUES is raised to match unless already set: HIP maps streams onto 4 hardware queues by default)")
