@@ -513,6 +513,8 @@ int randt_group_create_rank(int device, void* stream, int rank, int world, const
 int randt_group_destroy(randt_group* g);
 int randt_group_info(const randt_group* g, int* world, int* n_local, int* first_rank, int* transport);
 randt_ctx* randt_group_ctx(randt_group* g, int local_member);
+/* Text of the group's last failure.  g == NULL: why THIS THREAD's last randt_group_create / randt_group_create_rank failed
+ * (the RCCL / HIP error text -- the group object no longer exists then); "" if it succeeded. */
 const char* randt_group_last_error(const randt_group* g);
 int randt_group_synchronize(randt_group* g);
 /* Cells, counts and index grids of maps [first, first + count) of every member's batch := those of rank `root`'s batch

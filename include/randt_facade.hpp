@@ -527,7 +527,8 @@ class HierarchicalMap {
 class DeviceGroup {
  public:
   explicit DeviceGroup(const std::vector<int>& devices, int transport = RANDT_TRANSPORT_AUTO) {
-    facade_check(randt_group_create(devices.data(), static_cast<int>(devices.size()), nullptr, transport, &g_), "randt_group_create", nullptr);
+    if (!facade_check(randt_group_create(devices.data(), static_cast<int>(devices.size()), nullptr, transport, &g_), "randt_group_create", nullptr))
+      std::cout << "WARNING: randt_group_create: " << randt_group_last_error(nullptr) << std::endl;  // the RCCL / HIP text survives the object
     if (g_) randt_group_info(g_, &world_, &n_local_, nullptr, &transport_);
   }
   ~DeviceGroup() { randt_group_destroy(g_); }

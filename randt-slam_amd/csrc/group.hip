@@ -16,9 +16,16 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>
-
 #include "randt_internal.h"
+
+// The handful of RCCL (= NCCL API) declarations this file needs, spelled out locally: the library is opened with dlopen and must
+// also BUILD on a ROCm installation without the RCCL development headers (single-GPU users).  Values as in nccl.h / rccl.h.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;           // every other value is an error (text from ncclGetErrorString)
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+}
 
 namespace {
 
@@ -29,6 +36,7 @@ struct Rccl {
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -64,6 +72,7 @@ const Rccl& rccl() {
     x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
     x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
     x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
+    x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
     x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
     x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
     x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
@@ -85,14 +94,23 @@ struct randt_group {
   std::vector<hipEvent_t> ev_done;       // PEER transport: "member i's copies of this exchange are enqueued behind this"
   std::vector<void*> stage;              // randt_group_register_pairs: per-member device staging block
   std::vector<size_t> stage_bytes;
+  std::vector<void*> gbuf;               // result gather: world x pad rows of 96 bytes (pose + record), one exchange per step
+  std::vector<size_t> gbuf_bytes;
   std::string last_error;
 };
 
 namespace {
 
+// why the last randt_group_create* of this thread failed: the group object is gone by then (randt_group_last_error(NULL))
+thread_local std::string t_create_error;
+
 int gerr(randt_group* g, int status, const std::string& what) {
   if (g) g->last_error = what;
   return status;
+}
+int create_failed(randt_group* g, int rc) {
+  t_create_error = (g && !g->last_error.empty()) ? g->last_error : std::string("randt_group_create: status ") + std::to_string(rc);
+  return rc;
 }
 int gerr_hip(randt_group* g, const char* what, hipError_t e) {
   return gerr(g, RANDT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -150,6 +168,8 @@ int make_members(randt_group* g, const int* devices, int n, void* const* streams
     g->ev_done.push_back(ev2);
     g->stage.push_back(nullptr);
     g->stage_bytes.push_back(0);
+    g->gbuf.push_back(nullptr);
+    g->gbuf_bytes.push_back(0);
     if (e != hipSuccess) return gerr_hip(g, "hipEventCreateWithFlags", e);
   }
   return RANDT_OK;
@@ -216,6 +236,109 @@ int bcast_table(randt_group* g, void* const* ptr, size_t bytes, int root) {
   return RANDT_OK;
 }
 
+// ---- result gather of a sharded batch: ONE exchange per step (round-3 verdict, item 3a).  Every member packs its shard's
+// (pose, record) pairs into 96-byte rows at its rank's slot of a group-owned buffer (equal padded shards, so that RCCL's
+// all-gather contract holds although shards may differ by a row), ONE ncclAllGather (or one peer copy per member pair)
+// moves the rows, and an unpack kernel scatters the other ranks' rows into the caller's pose / record arrays.  Before:
+// two allgather_rows calls = one ncclBroadcast per owner rank and array (16 collectives per step at eight GPUs).
+struct GatherRow {
+  double pose[4];
+  randt_result res;
+};
+static_assert(sizeof(GatherRow) == 96, "gather row: 32-byte pose + 64-byte record");
+
+__device__ __forceinline__ void shard_of_row(int n, int world, int j, int& r, int& lo) {  // randt_shard_range, inverted
+  const int base = n / world, rem = n % world, big = rem * (base + 1);
+  r = j < big ? j / (base + 1) : rem + (base > 0 ? (j - big) / base : 0);
+  lo = r * base + (r < rem ? r : rem);
+}
+
+// 16-byte pieces: six per row (two of the pose, four of the record)
+__global__ __launch_bounds__(256) void k_gather_pack(const double* __restrict__ pose4, const randt_result* __restrict__ res, int lo, int hi,
+                                                     GatherRow* __restrict__ slot) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, row = t / 6, piece = t % 6;
+  if (row >= hi - lo) return;
+  const uint4 v = piece < 2 ? reinterpret_cast<const uint4*>(pose4 + 4 * (size_t)(lo + row))[piece]
+                            : reinterpret_cast<const uint4*>(res + lo + row)[piece - 2];
+  reinterpret_cast<uint4*>(slot + row)[piece] = v;
+}
+__global__ __launch_bounds__(256) void k_gather_unpack(const GatherRow* __restrict__ buf, int world, int pad, int n, int own_lo, int own_hi,
+                                                       double* __restrict__ pose4, randt_result* __restrict__ res) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, j = t / 6, piece = t % 6;
+  if (j >= n || (j >= own_lo && j < own_hi)) return;  // own rows are in place already
+  int r, lo;
+  shard_of_row(n, world, j, r, lo);
+  const uint4 v = reinterpret_cast<const uint4*>(buf + (size_t)r * pad + (j - lo))[piece];
+  if (piece < 2) reinterpret_cast<uint4*>(pose4 + 4 * (size_t)j)[piece] = v;
+  else reinterpret_cast<uint4*>(res + j)[piece - 2] = v;
+}
+
+int gather_results(randt_group* g, double* const* d_pose4, randt_result* const* d_results, int n) {
+  if (n == 0 || (g->world == 1 && g->transport != RANDT_TRANSPORT_RCCL)) return RANDT_OK;  // (a one-rank RCCL group still makes the call)
+  const int pad = (n + g->world - 1) / g->world;
+  const size_t need = sizeof(GatherRow) * (size_t)pad * g->world;
+  for (int i = 0; i < g->n_local; ++i) {
+    randt_ctx* c = g->ctx[i];
+    DevSwitch sw(c->device);
+    if (g->gbuf_bytes[i] < need) {  // grown outside the steady state (first step of a batch size)
+      if (g->transport != RANDT_TRANSPORT_RCCL) {
+        const int rc = randt_group_synchronize(g);  // PEER: another member may still read this member's old buffer
+        if (rc) return rc;
+      } else {
+        G_HIP(g, hipStreamSynchronize(c->stream));
+      }
+      if (g->gbuf[i]) (void)hipFree(g->gbuf[i]);
+      g->gbuf[i] = nullptr;
+      g->gbuf_bytes[i] = 0;
+      G_HIP(g, hipMalloc(&g->gbuf[i], need));
+      g->gbuf_bytes[i] = need;
+    }
+    int lo, hi;
+    randt_shard_range(n, g->world, g->first_rank + i, &lo, &hi);
+    if (hi > lo) {
+      GatherRow* slot = static_cast<GatherRow*>(g->gbuf[i]) + (size_t)(g->first_rank + i) * pad;
+      hipLaunchKernelGGL(k_gather_pack, dim3(((hi - lo) * 6 + 255) / 256), dim3(256), 0, c->stream, d_pose4[i], d_results[i], lo, hi, slot);
+      G_HIP(g, hipGetLastError());
+    }
+  }
+  if (g->transport == RANDT_TRANSPORT_RCCL) {
+    const Rccl& R = rccl();
+    G_NCCL(g, R.GroupStart());
+    int rc = RANDT_OK;
+    for (int i = 0; i < g->n_local && !rc; ++i) {
+      DevSwitch sw(g->ctx[i]->device);
+      char* base = static_cast<char*>(g->gbuf[i]);
+      const size_t slot_b = sizeof(GatherRow) * (size_t)pad;
+      const ncclResult_t q = R.AllGather(base + (size_t)(g->first_rank + i) * slot_b, base, slot_b, ncclChar, g->comm[i], g->ctx[i]->stream);  // in place
+      if (q != ncclSuccess) rc = gerr_nccl(g, "ncclAllGather", q);
+    }
+    const ncclResult_t e = R.GroupEnd();
+    if (!rc && e != ncclSuccess) rc = gerr_nccl(g, "ncclGroupEnd", e);
+    if (rc) return rc;
+  } else {
+    int rc = record_all(g);
+    for (int src = 0; src < g->n_local && !rc; ++src) {
+      int lo, hi;
+      randt_shard_range(n, g->world, src, &lo, &hi);
+      const size_t off = sizeof(GatherRow) * (size_t)src * pad, bytes = sizeof(GatherRow) * (size_t)(hi - lo);
+      for (int dst = 0; dst < g->n_local && !rc; ++dst)
+        if (dst != src) rc = peer_copy(g, dst, static_cast<char*>(g->gbuf[dst]) + off, src, static_cast<const char*>(g->gbuf[src]) + off, bytes);
+    }
+    if (rc) return rc;
+  }
+  for (int i = 0; i < g->n_local; ++i) {
+    randt_ctx* c = g->ctx[i];
+    DevSwitch sw(c->device);
+    int lo, hi;
+    randt_shard_range(n, g->world, g->first_rank + i, &lo, &hi);
+    hipLaunchKernelGGL(k_gather_unpack, dim3((n * 6 + 255) / 256), dim3(256), 0, c->stream, static_cast<const GatherRow*>(g->gbuf[i]), g->world, pad, n,
+                       lo, hi, d_pose4[i], d_results[i]);
+    G_HIP(g, hipGetLastError());
+  }
+  // PEER: no member may pack its next step's rows over a slot another member is still copying from
+  return g->transport == RANDT_TRANSPORT_RCCL ? RANDT_OK : peer_fence(g);
+}
+
 }  // namespace
 
 extern "C" {
@@ -229,7 +352,8 @@ void randt_shard_range(int n_items, int world, int rank, int* lo, int* hi) {
   if (hi) *hi = l + base + (rank < rem ? 1 : 0);
 }
 
-const char* randt_group_last_error(const randt_group* g) { return g ? g->last_error.c_str() : ""; }
+// g == NULL: why this thread's last randt_group_create / randt_group_create_rank failed (the text of the RCCL / HIP error)
+const char* randt_group_last_error(const randt_group* g) { return g ? g->last_error.c_str() : t_create_error.c_str(); }
 
 int randt_group_destroy(randt_group* g) {
   if (!g) return RANDT_OK;
@@ -238,6 +362,7 @@ int randt_group_destroy(randt_group* g) {
     (void)hipStreamSynchronize(g->ctx[i]->stream);
     if (i < g->comm.size() && g->comm[i] && rccl().CommDestroy) (void)rccl().CommDestroy(g->comm[i]);
     if (g->stage[i]) (void)hipFree(g->stage[i]);
+    if (g->gbuf[i]) (void)hipFree(g->gbuf[i]);
     if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
     if (g->ev_done[i]) (void)hipEventDestroy(g->ev_done[i]);
     (void)randt_ctx_destroy(g->ctx[i]);
@@ -250,17 +375,25 @@ int randt_group_destroy(randt_group* g) {
 int randt_group_create(const int* devices, int n, void* const* streams, int transport, randt_group** out) {
   if (!out) return RANDT_ERR_INVALID;
   *out = nullptr;
-  if (!devices || n < 1 || n > 64 || transport < RANDT_TRANSPORT_AUTO || transport > RANDT_TRANSPORT_RCCL) return RANDT_ERR_INVALID;
+  t_create_error.clear();
+  if (!devices || n < 1 || n > 64 || transport < RANDT_TRANSPORT_AUTO || transport > RANDT_TRANSPORT_RCCL)
+    return create_failed(nullptr, RANDT_ERR_INVALID);
   int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RANDT_ERR_NODEVICE;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return create_failed(nullptr, RANDT_ERR_NODEVICE);
   std::set<int> distinct;
   for (int i = 0; i < n; ++i) {
-    if (devices[i] < 0 || devices[i] >= n_dev) return RANDT_ERR_INVALID;
+    if (devices[i] < 0 || devices[i] >= n_dev) {
+      t_create_error = "device index " + std::to_string(devices[i]) + " out of range (" + std::to_string(n_dev) + " visible)";
+      return RANDT_ERR_INVALID;
+    }
     distinct.insert(devices[i]);
   }
   const bool all_distinct = (int)distinct.size() == n;
   if (transport == RANDT_TRANSPORT_AUTO) transport = (n > 1 && all_distinct && rccl().handle) ? RANDT_TRANSPORT_RCCL : RANDT_TRANSPORT_PEER;
-  if (transport == RANDT_TRANSPORT_RCCL && !all_distinct) return RANDT_ERR_INVALID;  // RCCL refuses two ranks on one device
+  if (transport == RANDT_TRANSPORT_RCCL && !all_distinct) {
+    t_create_error = "RANDT_TRANSPORT_RCCL needs distinct devices (RCCL refuses two ranks on one device); use RANDT_TRANSPORT_PEER for virtual ranks";
+    return RANDT_ERR_INVALID;
+  }
   randt_group* g = new (std::nothrow) randt_group();
   if (!g) return RANDT_ERR_NOMEM;
   g->world = g->n_local = n;
@@ -292,7 +425,7 @@ int randt_group_create(const int* devices, int n, void* const* streams, int tran
       }
   }
   if (rc) {
-    // keep the message for the caller? there is no object to ask once destroyed: statuses are all the caller gets here
+    create_failed(g, rc);  // the text survives the object: randt_group_last_error(NULL)
     randt_group_destroy(g);
     return rc;
   }
@@ -314,10 +447,11 @@ int randt_group_unique_id(void* out128) {
 int randt_group_create_rank(int device, void* stream, int rank, int world, const void* unique_id128, randt_group** out) {
   if (!out) return RANDT_ERR_INVALID;
   *out = nullptr;
-  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !unique_id128)) return RANDT_ERR_INVALID;
+  t_create_error.clear();
+  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !unique_id128)) return create_failed(nullptr, RANDT_ERR_INVALID);
   int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RANDT_ERR_NODEVICE;
-  if (device < 0 || device >= n_dev) return RANDT_ERR_INVALID;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return create_failed(nullptr, RANDT_ERR_NODEVICE);
+  if (device < 0 || device >= n_dev) return create_failed(nullptr, RANDT_ERR_INVALID);
   randt_group* g = new (std::nothrow) randt_group();
   if (!g) return RANDT_ERR_NOMEM;
   g->world = world;
@@ -340,6 +474,7 @@ int randt_group_create_rank(int device, void* stream, int rank, int world, const
     }
   }
   if (rc) {
+    create_failed(g, rc);
     randt_group_destroy(g);
     return rc;
   }
@@ -456,10 +591,7 @@ int randt_group_register_batch_dev(randt_group* g, randt_maps* const* fixed, con
                                             hi - lo, mp, d_pose4[i] + 4 * (size_t)lo, d_results[i] + lo);
     if (rc) return gerr_member(g, i, rc, "randt_register_batch_dev");
   }
-  if (!gather) return RANDT_OK;
-  int rc = randt_group_allgather_rows(g, reinterpret_cast<void* const*>(d_pose4), n_pairs, sizeof(double) * 4);
-  if (!rc) rc = randt_group_allgather_rows(g, reinterpret_cast<void* const*>(d_results), n_pairs, sizeof(randt_result));
-  return rc;
+  return gather ? gather_results(g, d_pose4, d_results, n_pairs) : RANDT_OK;
 }
 
 int randt_group_scan_register_batch_dev(randt_group* g, const float* const* d_points, int n_scans, int pitch_points,
@@ -481,10 +613,7 @@ int randt_group_scan_register_batch_dev(randt_group* g, const float* const* d_po
         (d_fixed_idx && d_fixed_idx[i]) ? d_fixed_idx[i] + lo : nullptr, scan_maps[i], mp, d_pose4[i] + 4 * (size_t)lo, d_results[i] + lo);
     if (rc) return gerr_member(g, i, rc, "randt_scan_register_batch_dev");
   }
-  if (!gather) return RANDT_OK;
-  int rc = randt_group_allgather_rows(g, reinterpret_cast<void* const*>(d_pose4), n_scans, sizeof(double) * 4);
-  if (!rc) rc = randt_group_allgather_rows(g, reinterpret_cast<void* const*>(d_results), n_scans, sizeof(randt_result));
-  return rc;
+  return gather ? gather_results(g, d_pose4, d_results, n_scans) : RANDT_OK;
 }
 
 int randt_group_register_pairs(randt_group* g, randt_maps* const* fixed, const int32_t* h_fixed_idx, randt_maps* const* moving,

@@ -611,8 +611,8 @@ class Group:
             rc = self._lib.randt_group_create_rank(int(device), C.c_void_p(stream) if stream else None, int(rank), int(world), _dptr(uid),
                                                    C.byref(h))
             where = "randt_group_create_rank"
-        if rc:
-            raise RandtError(rc, where)
+        if rc:  # the group object is gone; the library keeps the text of this thread's last failed creation
+            raise RandtError(rc, where, (self._lib.randt_group_last_error(None) or b"").decode())
         self._h = h
         w, nl, fr, tr = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         self._lib.randt_group_info(self._h, C.byref(w), C.byref(nl), C.byref(fr), C.byref(tr))

@@ -58,6 +58,25 @@ def test_bench_two_ranks_control_flow():
     # config 4 as BASELINE states it: ONE 512 batch split over the ranks, results gathered, identical to the unsharded run
     ss = d["strong_scaling"]
     assert ss["registrations_per_gpu_per_step"] == 256 and ss["value"] > 1e5 and ss["poses_bit_identical_to_unsharded"] is True
+    assert d["group_fallback"] is False and "gloo" in d["group_transport"]      # (a control-flow test, not a fallback)
+
+
+def test_bench_group_path_on_one_rank():
+    """The multi-GPU code of bench.py -- randt_group over RCCL created per stream (unique id, ncclCommInitRank, agreement),
+    the strong region through randt_group_scan_register_batch_dev with the ONE-exchange gather (ncclAllGather of packed rows),
+    the same region without the exchange, several groups in flight, and the loud fallback keys -- with a single rank on this
+    box's one GPU (--force-group-path): everything except more than one peer."""
+    r = subprocess.run([sys.executable, "bench.py", "--force-group-path", "--steps", "6", "--warmup", "1", "--repeats", "3", "--min-seconds", "0.05",
+                        "--no-cpu-baseline", "--no-config2", "--no-roofline-sections", "--odometry-scans", "0", "--polar-scans", "0",
+                        "--slam-scans", "0", "--polar-odometry-scans", "0", "--streams", "4"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_PORT="29535"))
+    d = _last_json(r.stdout)
+    assert d["group_fallback"] is False and "RCCL" in d["group_transport"] and "group_error" not in d
+    ss = d["strong_scaling"]
+    assert ss["poses_bit_identical_to_unsharded"] is True and ss["steps"] == 6 and "ncclAllGather" in ss["entry"]
+    assert ss["kernel_us_per_step"] > 10 and abs(ss["gather_us_per_step"]) < ss["kernel_us_per_step"]
+    assert ss["pipelined"]["groups_in_flight"] == 4 and ss["pipelined"]["value"] > 1e5
+    assert "expected_ceiling" in ss
 
 
 def test_bench_two_ranks_rccl():
@@ -71,3 +90,4 @@ def test_bench_two_ranks_rccl():
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["strong_scaling"]["poses_bit_identical_to_unsharded"] is True
+    assert d["group_fallback"] is False and d["strong_scaling"]["pipelined"]["value"] > 1e5

@@ -143,10 +143,12 @@ def test_rccl_two_devices_one_process(base):
 
 def test_group_argument_checks(base):
     prob, rig, mp, g4, _, _ = base
-    with pytest.raises(R.RandtError):
+    with pytest.raises(R.RandtError) as e1:
         R.Group(devices=[0, 0], transport=_capi.TRANSPORT_RCCL)      # RCCL refuses two ranks on one device
-    with pytest.raises(R.RandtError):
+    assert "distinct devices" in str(e1.value)                           # the text survives the (never created) group object
+    with pytest.raises(R.RandtError) as e2:
         R.Group(devices=[99])
+    assert "out of range" in str(e2.value)
     grp = R.Group(devices=[0, 0])
     foreign = R.Maps(rig.ctx, 1, rig.mapp, 16, with_grid=True)           # not created on the members' contexts
     with pytest.raises(R.RandtError):
