@@ -52,6 +52,9 @@ SAT_COPIES = 16                         # chip-filling launch of the roofline se
 HOT_KERNELS = ("k_ndt_build<true,true>", "k_associate<false,64,true>", "k_solve<3,1,64,true,4,false>")
 
 
+FILTER_ROWS = {}   # counter rows of k_filter_rows / k_filter_emit from the committed summary (load_counters)
+
+
 def effective_cpus():
     """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes of this pool show
     256 logical CPUs behind a 16-CPU quota: 128 OpenMP threads there are 16 cores' worth of time slices)."""
@@ -90,10 +93,13 @@ def load_counters():
     if not files:
         return {}, None, "no committed counter summary"
     rows = {}
+    FILTER_ROWS.clear()
     want_wgs = {"k_ndt_build<true,true>": 512, "k_associate<false,64,true>": 128, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch (the association walks four pairs per workgroup)
     stamp = None
     for r in csv.DictReader(open(files[-1])):
         stamp = r.get("csrc_hash", stamp)
+        if r["kernel"].startswith("k_filter_") and r["kernel"] not in FILTER_ROWS:     # the config-5 polar filter (16 scans per launch)
+            FILTER_ROWS[r["kernel"]] = {k: (float(v) if v not in ("", None) and k not in ("kernel", "csrc_hash") else v) for k, v in r.items()}
         if r["kernel"] in HOT_KERNELS and r["kernel"] not in rows and int(r["grid_size"]) == want_wgs[r["kernel"]] * int(r["workgroup_size"]):
             rows[r["kernel"]] = {k: (float(v) if v not in ("", None) and k not in ("kernel", "csrc_hash") else v) for k, v in r.items()}
     rel = os.path.relpath(files[-1], ROOT)
@@ -861,7 +867,17 @@ def polar_filter(ctx, n_scans):
         t_b += e[1].elapsed_time(e[2])
     t_f, t_b = t_f / reps * 1e-3, t_b / reps * 1e-3
     nbytes = raw.numel() * 4
-    return {"scans_per_launch": n_scans, "raw_bytes_per_scan": nbytes // n_scans, "filter_ms": t_f * 1e3, "ndt_build_ms": t_b * 1e3,
+    roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": nbytes / t_f / 1e9, "frac": nbytes / t_f / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes": nbytes, "traffic": None,
+            "note": "f-1 stage end to end (k_filter_rows + k_filter_emit, HIP events on the launch stream): raw polar bytes read once / duration"}
+    fr, fe = FILTER_ROWS.get("k_filter_rows<true>"), FILTER_ROWS.get("k_filter_emit<true>")
+    if fr and fe and n_scans == 16:
+        # HBM bytes from the TCC counters of the committed summary (FETCH_SIZE KB x2 per the gfx950 note + WRITE_SIZE KB), both kernels
+        roof["traffic"] = int((2.0 * (fr.get("FETCH_SIZE", 0.0) + fe.get("FETCH_SIZE", 0.0)) + fr.get("WRITE_SIZE", 0.0) + fe.get("WRITE_SIZE", 0.0)) * 1024)
+        if fr.get("single_stream_avg_us"):
+            roof["rocprof_avg_us"] = {"k_filter_rows": fr.get("single_stream_avg_us"), "k_filter_emit": fe.get("single_stream_avg_us")}
+            roof["k_filter_rows_frac"] = nbytes / (float(fr["single_stream_avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS
+    return {"roofline": roof, "scans_per_launch": n_scans, "raw_bytes_per_scan": nbytes // n_scans, "filter_ms": t_f * 1e3, "ndt_build_ms": t_b * 1e3,
             "filter_GBps": nbytes / t_f / 1e9, "filter_hbm_frac": nbytes / t_f / 1e9 / HBM_PEAK_GBS,
             "scans_per_sec_filter_plus_build": n_scans / (t_f + t_b), "mean_filtered_points": float(counts.float().mean().item()),
             "status_ok": bool((status == 0).all().item())}

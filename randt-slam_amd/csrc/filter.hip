@@ -54,7 +54,8 @@ struct RowRec {
   int32_t kept;     // points of the run that pass the range / intensity thresholds
   float angle;      // atan2 of the row's first point (the reference's current_angle)
   float maxi;       // peak intensity
-  int32_t pad[2];
+  float peak_range; // hypot of the detection (the emission's per-azimuth peak record)
+  int32_t bad;      // 1: an azimuth change inside the row (the scan is not organised azimuth after azimuth)
 };
 
 struct FilterArgs {
@@ -103,19 +104,21 @@ __device__ __forceinline__ bool keep_point(const FilterArgs& A, float x, float y
 // kept: how many bins of the walked part of the run (d = 0 .. stop for DIR = -1, d = 1 .. stop for DIR = +1, so that the
 // detection itself is counted once) pass the output thresholds (:110-118) -- the same loads serve both questions.
 template <int DIR, bool PACKED>
-__device__ __forceinline__ long long expand_run(const FilterArgs& A, const float* base, long long n, long long m, int lane, int& kept) {
+__device__ __forceinline__ long long expand_run(const FilterArgs& A, const float* base, long long n, long long m, int lane, int& kept, float* range_m = nullptr) {
   kept = 0;
   for (long long d0 = 0;; d0 += 64) {
     const long long a = m + DIR * (d0 + lane), b = a + DIR;
     const bool a_in = a >= 0 && a <= n - 1, b_in = b >= 0 && b <= n - 1;
     bool stop = true, keep = false;
+    float ha = 0.f;
     if (a_in) {
-      float ax, ay, ai, bx = 0.f, by = 0.f, bi = 0.f, ha;
+      float ax, ay, ai, bx = 0.f, by = 0.f, bi = 0.f;
       fetch<PACKED>(A, base, a, ax, ay, ai);
       if (b_in) fetch<PACKED>(A, base, b, bx, by, bi);
       keep = keep_point(A, ax, ay, ai, ha) && (DIR < 0 || d0 + lane > 0);
       if (b_in) stop = ((double)(ha - hypot_f(bx, by)) > (double)A.thr) || (ai <= bi) || ((double)ha < (double)A.min_d);
     }
+    if (range_m && d0 == 0) *range_m = __shfl(ha, 0, 64);
     const unsigned long long mask = __ballot(stop), kmask = __ballot(keep);
     if (mask) {
       const int first = __ffsll((long long)mask) - 1;
@@ -157,9 +160,12 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
   const RowRec* rows = A.rows + (size_t)scan * A.n_az;
   // consecutive azimuths must differ by more than the reference's 1e-4 rad threshold
   int bad = 0;
-  for (int r = 1 + tid; r < A.n_az; r += FILT_EBLOCK)
-    if (!(fabsf(rows[r].angle - rows[r - 1].angle) > 0.0001)) bad = 1;
-  if (bad) atomicMax(&A.status[scan], 1);
+  for (int r = tid; r < A.n_az; r += FILT_EBLOCK) {
+    const RowRec cur = rows[r];
+    if (cur.bad) bad = 1;  // an azimuth change inside a row (k_filter_rows)
+    if (r > 0 && !(fabsf(cur.angle - rows[r - 1].angle) > 0.0001)) bad = 1;
+  }
+  bad = __syncthreads_or(bad);
 
   int n_det = 0, n_out = 0;
   float* out = A.out_pts + (size_t)scan * A.pitch_out * 4;
@@ -174,7 +180,8 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
     rec.closer = 0;
     rec.further = -1;
     rec.kept = 0;
-    rec.angle = rec.maxi = 0.f;
+    rec.angle = rec.maxi = rec.peak_range = 0.f;
+    rec.bad = 0;
     if (r < n_rows) rec = rows[r];
     const bool det = rec.m >= 0;
     int tot_det, tot_kept;
@@ -182,10 +189,8 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
     int out_at = n_out + block_excl_scan<FILT_EBLOCK / 64>(det ? rec.kept : 0, scratch, &tot_kept);
     if (det) {
       if (pk) {
-        float mx, my, mi;
-        fetch<PACKED>(A, base, rec.m, mx, my, mi);
         pk[3 * det_at + 0] = rec.angle;
-        pk[3 * det_at + 1] = hypot_f(mx, my);
+        pk[3 * det_at + 1] = rec.peak_range;
         pk[3 * det_at + 2] = rec.maxi;
       }
       // the run, eight bins per round trip (the loads of a round are independent; the stores are not)
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
   if (tid == 0) {
     A.out_counts[scan] = n_out <= A.pitch_out ? n_out : A.pitch_out;
     if (A.peak_counts) A.peak_counts[scan] = n_det;
-    if (n_out > A.pitch_out) atomicMax(&A.status[scan], 2);
+    A.status[scan] = n_out > A.pitch_out ? 2 : (bad ? 1 : 0);  // written, not max-ed: no clearing launch in front of the two kernels
   }
 }
 
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs 
   __shared__ int s_bad[2][FILT_WAVES];
   __shared__ long long s_run[2][2];  // closer, further (double-buffered: one barrier per use)
   __shared__ int s_kept[2][2];
+  __shared__ float s_range[2];
   const int scan = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = A.raw + (size_t)scan * A.n_az * A.n_bins * A.stride;
   const long long n = (long long)A.n_az * A.n_bins;
@@ -340,7 +346,6 @@ __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs 
       }
       bad |= s_bad[par][w];
     }
-    if (bad && tid == 0) atomicMax(&A.status[scan], 1);
     // the row's detection; quirk: the first boundary pushes current_max_idx = 0 even if azimuth 0 had no valid return;
     // the last azimuth is never flushed
     long long m = (best_i > 0.f && best_idx != 0x7fffffff) ? r0 + best_idx : -1;
@@ -352,17 +357,22 @@ __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs 
     if (row == A.n_az - 1) m = -1;
     long long closer = 0, further = -1;
     int kept = 0;
+    float range_m = 0.f;
     if (m >= 0) {  // uniform over the workgroup
       if (wave == 0) {
-        int kc;
-        const long long c = expand_run<-1, PACKED>(A, base, n, m, lane, kc);
+        int kc = 0;
+        long long c = 0;
+        float rm = 0.f;
+        c = expand_run<-1, PACKED>(A, base, n, m, lane, kc, &rm);  // (+ the detection's range for the peak record: lane 0's hypot)
         if (lane == 0) {
           s_run[par][0] = c;
           s_kept[par][0] = kc;
+          s_range[par] = rm;
         }
       } else if (wave == 1) {
-        int kf;
-        const long long f = expand_run<+1, PACKED>(A, base, n, m, lane, kf);
+        int kf = 0;
+        long long f = 0;
+        f = expand_run<+1, PACKED>(A, base, n, m, lane, kf);
         if (lane == 0) {
           s_run[par][1] = f;
           s_kept[par][1] = kf;
@@ -372,6 +382,7 @@ __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs 
       closer = s_run[par][0];
       further = s_run[par][1];
       kept = s_kept[par][0] + s_kept[par][1];
+      range_m = s_range[par];
     }
     if (tid == 0) {
       RowRec rec;
@@ -381,7 +392,8 @@ __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs 
       rec.kept = kept;
       rec.angle = a0;
       rec.maxi = pk_i;
-      rec.pad[0] = rec.pad[1] = 0;
+      rec.peak_range = range_m;
+      rec.bad = bad;
       A.rows[(size_t)scan * A.n_az + row] = rec;
     }
     par ^= 1;  // the next row's exchange goes through the other half of the LDS buffers
@@ -447,7 +459,6 @@ int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az
   A.status = d_status;
   A.pitch_out = pitch_out;
   A.rows = (RowRec*)d_scratch;
-  RANDT_HIP_CHECK(ctx, hipMemsetAsync(d_status, 0, sizeof(int32_t) * n_scans, ctx->stream));
   // Row workgroups per scan: one per row as long as all of them are resident at once; beyond that as many as the chip
   // holds (occupancy x CUs), each walking several rows with its next row's loads already in flight.
   int per_scan = n_az;
