@@ -741,7 +741,7 @@ int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving,
 static int check_matcher_params(randt_ctx* ctx, const randt_matcher_params* mp) {
   const char* bad = nullptr;
   auto pos = [](double v) { return isfinite(v) && v > 0.0; };
-  if (mp->n_neighbours <= 0 || mp->n_neighbours > 64) bad = "n_neighbours must be in 1..64 (1..8 where the library associates itself)";
+  if (mp->n_neighbours <= 0 || mp->n_neighbours > 64) bad = "n_neighbours must be in 1..64 (1..16 where the library associates itself)";
   else if (!(isfinite(mp->gnc_divisor) && mp->gnc_divisor > 1.0)) bad = "gnc_divisor must be finite and > 1 (the GNC loop divides mu by it until mu <= 1/sqrt(divisor))";
   else if (mp->gnc_steps < 1 || mp->gnc_steps > 64) bad = "gnc_steps must be in 1..64";
   else if (mp->max_iterations < 0) bad = "max_iterations must be >= 0";
@@ -779,8 +779,8 @@ int randt_associate_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int
   // nothing else must not be refused for solver parameters this entry never reads
   if (!ctx || !fixed || !mp || n_pairs < 0 || !range_ok(moving, moving_first, n_pairs)) return RANDT_ERR_INVALID;
   if (mp->n_neighbours < 1) return randt_set_error(ctx, RANDT_ERR_INVALID, "n_neighbours must be >= 1", hipSuccess);
-  if (mp->n_neighbours > 8)
-    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "n_neighbours > 8 not supported by the association kernel (it keeps eight candidates per cell)", hipSuccess);
+  if (mp->n_neighbours > 16)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "n_neighbours > 16 not supported by the association kernel (it keeps at most sixteen candidates per cell)", hipSuccess);
   if (n_pairs == 0) return RANDT_OK;
   if (!d_guess4 || !d_corr) return RANDT_ERR_INVALID;
   return launch_associate(ctx, fixed->v, d_fixed_idx, moving->v, moving_first, n_pairs, d_guess4, mp->n_neighbours,

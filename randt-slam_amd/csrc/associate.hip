@@ -41,6 +41,10 @@ using namespace randt_dev;
 #define ASSOC_CAND 64    // candidates per cell: <= (k-1) + 8R = 63 for k <= 8, R <= 7
 #define ASSOC_CS 65      // LDS stride of a cell's candidate / slot row (odd: thread-per-cell accesses are conflict-free)
 #define ASSOC_QS 11      // LDS stride of a query record (odd => conflict-free)
+#define ASSOC_WIDE_MAX_R 15   // the WIDE instantiation: window <= 31 x 31 (max_neighbour_dist / resolution <= 16), k <= 16
+#define ASSOC_WIDE_CAND 144   // (k - 1) + 8 R <= 15 + 120
+#define ASSOC_WIDE_CS 145
+#define ASSOC_WIDE_WT 1024    // window table entries (>= 31^2 = 961)
 
 #ifdef RANDT_TIMING
 __device__ long long g_randt_assoc_timing[16];
@@ -105,7 +109,7 @@ __device__ __forceinline__ unsigned long long prefix_mask(int n) {
 #ifndef RANDT_ASSOC_TP_WPE
 #define RANDT_ASSOC_TP_WPE 4
 #endif
-template <bool STAGE_GRID, int CH, bool TP>
+template <bool STAGE_GRID, int CH, bool TP, bool WIDE = false>
 __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP ? RANDT_ASSOC_TP_WPE : 1, TP ? RANDT_ASSOC_TP_WPE : 8))) void k_associate(MapView fixed, const int32_t* __restrict__ fixed_idx,
                                                            MapView moving, int moving_first,
                                                            const int32_t* __restrict__ moving_idx,
@@ -113,6 +117,11 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
                                                            int transform_full, int32_t* __restrict__ corr, int ch /* cells per chunk <= CH */, int n_pairs_total, int ppw) {
   constexpr int CH_LOG2 = CH > 64 ? 7 : (CH > 32 ? 6 : (CH > 16 ? 5 : 4));
   static_assert(CH % ASSOC_WAVES == 0 && CH >= 16 && CH <= 64, "chunk size (P2a runs one thread per cell on ONE wavefront)");
+  // WIDE: configurations beyond every shipped one -- window radius up to ASSOC_WIDE_MAX_R (a 0.25 m map with the same 4 m window:
+  // radius 15, 31 x 31 slots) and up to 16 neighbours: longer candidate rows ((k - 1) + 8 R <= 143), a window table of 33^2
+  // entries, a 16-entry top-k list, and a ring-by-ring walk of the outer window (P2b).  A correctness path, not a tuned one.
+  constexpr int CS = WIDE ? ASSOC_WIDE_CS : ASSOC_CS, CAND = WIDE ? ASSOC_WIDE_CAND : ASSOC_CAND, KMAX = WIDE ? 16 : 8;
+  constexpr int WT = WIDE ? ASSOC_WIDE_WT : 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // This kernel is a chain of L2 round trips with a few instructions between them.  Sharing a SIMD with solve wavefronts
   // (16 batches in flight: three fp64-bound wavefronts per SIMD that are older, and the issue arbiter prefers older ones) it
@@ -143,15 +152,15 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
   int32_t* lgrid = reinterpret_cast<int32_t*>(smem);
   const int grid_words = STAGE_GRID ? ((n_slots + 3) & ~3) : 0;
   int32_t* wtab = lgrid + grid_words;                       // [256] packed (i+128) << 8 | (j+128)
-  float* qrec = reinterpret_cast<float*>(wtab + 256);       // [CH][QS]: mean3, cov6, centre(bits), pad
+  float* qrec = reinterpret_cast<float*>(wtab + WT);       // [CH][QS]: mean3, cov6, centre(bits), pad
   int32_t* clen = reinterpret_cast<int32_t*>(qrec + CH * ASSOC_QS + 1);  // [CH]
   int32_t* cpref = clen + CH;                         // [CH + 1]
   int32_t* cand = cpref + CH + 4;                     // [CH][CS]
-  float* cdist = reinterpret_cast<float*>(cand + CH * ASSOC_CS);  // [CH][CS]
+  float* cdist = reinterpret_cast<float*>(cand + CH * CS);  // [CH][CS]
   int32_t* p0tab = reinterpret_cast<int32_t*>(cdist);       // [CH][CS] window slots 0..63 of every cell (dead before P3 writes cdist)
   // [CH][2] occupied / in-range bits; CH * CS is odd, so the word offset is rounded up to an even one (8-byte aligned ds_read_b64)
   unsigned long long* pmask = reinterpret_cast<unsigned long long*>(
-      smem + ((static_cast<size_t>(reinterpret_cast<char*>(cdist + CH * ASSOC_CS) - smem) + 7) & ~static_cast<size_t>(7)));
+      smem + ((static_cast<size_t>(reinterpret_cast<char*>(cdist + CH * CS) - smem) + 7) & ~static_cast<size_t>(7)));
   int32_t* ulist = reinterpret_cast<int32_t*>(pmask + 2 * CH);                                // [CH + 1] cells left to P2b, count last
 
   const int R = fixed.rmax - 1 > 0 ? fixed.rmax - 1 : 0;  // last radius the reference evaluates
@@ -170,10 +179,10 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
       for (int i = tid; i < n_slots; i += ASSOC_BLOCK) lgrid[i] = ggrid[i];
     }
   }
-  if (tid < 256) {
+  for (int w = tid; w < WT; w += ASSOC_BLOCK) {
     int i = 0, j = 0;
-    if (tid < nwin) ring_offset(tid, i, j);
-    wtab[tid] = ((i + 128) << 8) | (j + 128);
+    if (w < nwin) ring_offset(w, i, j);
+    wtab[w] = ((i + 128) << 8) | (j + 128);
   }
   const int32_t* grid = STAGE_GRID ? lgrid : ggrid;
 
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
             const uint32_t ni = ctr + (uint32_t)lane_i + (uint32_t)lane_j * (uint32_t)fixed.size_x;
             ci = ni < (uint32_t)n_slots ? -1 : -2;  // a stored index below -1 counts as an empty slot
           }
-          p0tab[cc * ASSOC_CS + lane] = ci;
+          p0tab[cc * CS + lane] = ci;
           const unsigned long long o = __ballot(ci >= 0), v = __ballot(ci >= -1);
           if (lane == 0) {
             pmask[2 * cc] = o;
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
       const int c = lane;
       int len = -1;  // -1: not settled here (P2b)
       if (c < nch && !need_dup) {
-        const int32_t* row = p0tab + c * ASSOC_CS;
+        const int32_t* row = p0tab + c * CS;
         const unsigned long long occ = pmask[2 * c], val = pmask[2 * c + 1];
         const int r_hi = R < 3 ? R : 3;  // radii completely inside the 64 slots
         int rstar = -1;
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
           while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1ull;
-            cand[c * ASSOC_CS + len] = row[b];
+            cand[c * CS + len] = row[b];
             ++len;
           }
         }
@@ -285,7 +294,40 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
     for (int u = wave; u < n_open; u += ASSOC_WAVES) {
       const int c = ulist[u];
       const uint32_t center = __float_as_uint(qrec[c * ASSOC_QS + 9]);
-      const int32_t ci_pass0 = p0tab[c * ASSOC_CS + lane];
+      const int32_t ci_pass0 = p0tab[c * CS + lane];
+      if (WIDE && !need_dup) {
+        // radii 0 .. 3 (the first 49 slots) are known not to end the search (P2a); from radius 4 on ring by ring, as the
+        // reference's loop does: collect the ring, then test "enough targets or every slot seen", then "r >= rmax"
+        const unsigned long long pm49 = prefix_mask(49);
+        const unsigned long long o0 = __ballot(ci_pass0 >= 0) & pm49, v0 = __ballot(ci_pass0 >= -1) & pm49;
+        int base = 0, nt = __popcll(o0), nadj = __popcll(v0);
+        if ((o0 >> lane) & 1ull) cand[c * CS + __popcll(o0 & prefix_mask(lane))] = ci_pass0;
+        base = nt;
+        for (int r = 4; r <= R; ++r) {
+          const int w_end = (2 * r + 1) * (2 * r + 1);
+          for (int w0 = (2 * r - 1) * (2 * r - 1); w0 < w_end; w0 += 64) {
+            const int w = w0 + lane;
+            int32_t ci = -2;
+            if (w < w_end) {
+              const int packed = wtab[w];
+              const uint32_t ni = center + (uint32_t)((packed >> 8) - 128) + (uint32_t)((packed & 255) - 128) * (uint32_t)fixed.size_x;
+              if (ni < (uint32_t)n_slots) {
+                ci = grid[ni];
+                if (ci < -1) ci = -1;
+              }
+            }
+            const unsigned long long o = __ballot(ci >= 0), v = __ballot(ci >= -1);
+            const int pos = base + __popcll(o & prefix_mask(lane));
+            if (ci >= 0 && pos < CAND) cand[c * CS + pos] = ci;
+            base += __popcll(o);
+            nt += __popcll(o);
+            nadj += __popcll(v);
+          }
+          if (!(nt < k && nadj < n_slots)) break;
+        }
+        if (lane == 0) clen[c] = base < CAND ? base : CAND;
+        continue;
+      }
       // the outer rings' slots, all requested before the first one is looked at (one L2 round trip per cell, not per pass)
       int32_t ci_outer[ASSOC_PASSES];
 #pragma unroll
@@ -344,11 +386,11 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
             const bool in = cidx[p] >= 0 && (p * 64 + lane) < need;
             const unsigned long long m = __ballot(in);
             const int pos = base + __popcll(m & prefix_mask(lane));
-            if (in && pos < ASSOC_CAND) cand[c * ASSOC_CS + pos] = cidx[p];
+            if (in && pos < CAND) cand[c * CS + pos] = cidx[p];
             base += __popcll(m);
           }
         }
-        if (lane == 0) clen[c] = base < ASSOC_CAND ? base : ASSOC_CAND;
+        if (lane == 0) clen[c] = base < CAND ? base : CAND;
         continue;
       }
       // tiny maps (size_x <= 2R): the window wraps onto itself and the reference drops repeated entries
@@ -407,12 +449,12 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
             const bool in = cidx[p] >= 0 && (p * 64 + lane) < need && !window_dup(wi[p], wj[p], rstar, fixed.size_x);
             const unsigned long long m = __ballot(in);
             const int pos = base + __popcll(m & prefix_mask(lane));
-            if (in && pos < ASSOC_CAND) cand[c * ASSOC_CS + pos] = cidx[p];
+            if (in && pos < CAND) cand[c * CS + pos] = cidx[p];
             base += __popcll(m);
           }
         }
       }
-      if (lane == 0) clen[c] = base < ASSOC_CAND ? base : ASSOC_CAND;
+      if (lane == 0) clen[c] = base < CAND ? base : CAND;
     }
     __syncthreads();
 
@@ -445,7 +487,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
         }
       }
       const int c = lo, jj = p - cpref[lo];
-      const int32_t fi_raw = cand[c * ASSOC_CS + jj];
+      const int32_t fi_raw = cand[c * CS + jj];
       const int32_t fi = fi_raw < fixed.cap ? fi_raw : fixed.cap - 1;
       const randt_cell f = load_cell(fcells + fi);
       const float* o = qrec + c * ASSOC_QS;
@@ -460,7 +502,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
         const float dx = o[0] - f.mean[0], dy = o[1] - f.mean[1];
         d = sqrtf(dx * dx + dy * dy);
       }
-      cdist[c * ASSOC_CS + jj] = d;
+      cdist[c * CS + jj] = d;
     }
     __syncthreads();
 
@@ -472,15 +514,15 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
       const int c = tid;
       constexpr unsigned long long EMPTY = ~0ull;
       const int n = clen[c];
-      unsigned long long best[8];
+      unsigned long long best[KMAX];
 #pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) best[s2] = EMPTY;
+      for (int s2 = 0; s2 < KMAX; ++s2) best[s2] = EMPTY;
       for (int jj = 0; jj < n; ++jj) {
-        const uint32_t u = __float_as_uint(cdist[c * ASSOC_CS + jj] + 0.0f);  // -0 -> +0
+        const uint32_t u = __float_as_uint(cdist[c * CS + jj] + 0.0f);  // -0 -> +0
         const uint32_t ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // numeric order as unsigned order
-        unsigned long long key = ((unsigned long long)ord << 32) | (uint32_t)cand[c * ASSOC_CS + jj];
+        unsigned long long key = ((unsigned long long)ord << 32) | (uint32_t)cand[c * CS + jj];
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
+        for (int s2 = 0; s2 < KMAX; ++s2) {
           if (s2 < k) {  // uniform
             if (key == best[s2]) key = EMPTY;  // a repeated (distance, index) pair counts once
             const unsigned long long lo = key < best[s2] ? key : best[s2];
@@ -490,7 +532,7 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
         }
       }
 #pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2)
+      for (int s2 = 0; s2 < KMAX; ++s2)
         if (s2 < k) out[(size_t)(c0 + c) * k + s2] = best[s2] == EMPTY ? -1 : (int32_t)(uint32_t)best[s2];
     }
     ASSOC_TICK(5);
@@ -498,28 +540,29 @@ __global__ __launch_bounds__(ASSOC_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
   }
 }
 
-size_t assoc_lds_bytes(int n_slots, bool stage, int CH = ASSOC_CH) {
-  size_t words = (stage ? ((n_slots + 3) & ~3) : 0) + 256 + (CH * ASSOC_QS + 1) + CH + (CH + 4) +
-                 2 * CH * ASSOC_CS + 2 /* pmask alignment */ + 4 * CH + CH + 4;
+size_t assoc_lds_bytes(int n_slots, bool stage, int CH = ASSOC_CH, bool wide = false) {
+  const int cs = wide ? ASSOC_WIDE_CS : ASSOC_CS, wt = wide ? ASSOC_WIDE_WT : 256;
+  size_t words = (stage ? ((n_slots + 3) & ~3) : 0) + wt + (CH * ASSOC_QS + 1) + CH + (CH + 4) +
+                 2 * CH * cs + 2 /* pmask alignment */ + 4 * CH + CH + 4;
   return words * 4 + 64;
 }
 
-template <bool STAGE, int CH, bool TP = false>
+template <bool STAGE, int CH, bool TP = false, bool WIDE = false>
 int launch_associate_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
                          int n_pairs, const double* d_guess4, int k, int full, int32_t* d_corr, const int32_t* d_moving_idx, bool spread) {
-  const size_t lds = assoc_lds_bytes(fixed.n_slots, STAGE, CH);
+  const size_t lds = assoc_lds_bytes(fixed.n_slots, STAGE, CH, WIDE);
   int split = 1;
   if (spread) {
     split = (moving.cap + CH - 1) / CH;
     if (split > 64) split = 64;
     if (split < 1) split = 1;
   }
-  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<STAGE, CH, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<STAGE, CH, TP, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // pairs per workgroup: the walk is for callers that keep several batches in flight (or a batch that fills the chip several
   // times over); a lone batch of a few hundred pairs more than the split geometry takes stays one pair per workgroup
   const bool walk = TP && (ctx->solve_mode == RANDT_SOLVE_THROUGHPUT || n_pairs >= 8 * ctx->n_cus);
   const int ppw = walk ? (ctx->assoc_tp_ppw > 0 ? ctx->assoc_tp_ppw : 1) : 1;
-  hipLaunchKernelGGL((k_associate<STAGE, CH, TP>), dim3((n_pairs + ppw - 1) / ppw, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
+  hipLaunchKernelGGL((k_associate<STAGE, CH, TP, WIDE>), dim3((n_pairs + ppw - 1) / ppw, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
                      moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, CH, n_pairs, ppw);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
@@ -536,12 +579,19 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
                      int use_intensity, int32_t* d_corr, const int32_t* d_moving_idx) {
   if (n_pairs <= 0) return RANDT_OK;
   if (!fixed.grid) return randt_set_error(ctx, RANDT_ERR_INVALID, "fixed maps need an index grid", hipSuccess);
-  if (fixed.rmax - 1 > ASSOC_MAX_R)
-    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "max_neighbour_dist/resolution > 8 not supported by the association kernel", hipSuccess);
-  if (k > 8) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "n_neighbours > 8 not supported by the association kernel", hipSuccess);
+  if (fixed.rmax - 1 > ASSOC_WIDE_MAX_R)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "max_neighbour_dist/resolution > 16 not supported by the association kernel", hipSuccess);
+  if (k > 16) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "n_neighbours > 16 not supported by the association kernel", hipSuccess);
   if (fixed.n_slots <= 225)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "maps with <= 225 slots not supported by the association kernel", hipSuccess);
   const int full = (use_intensity && lookup_mahalanobis) ? 1 : 0;
+  if (fixed.rmax - 1 > ASSOC_MAX_R || k > 8) {
+    // beyond every shipped configuration (ndt_map.cpp:117 and ndt_matcher.cpp:210 take any value): the WIDE instantiation,
+    // one workgroup per (pair, 32-cell chunk); maps narrower than such a window (the reference's std::find de-duplication) stay refused
+    if (fixed.size_x <= 2 * (fixed.rmax - 1) && fixed.rmax - 1 > ASSOC_MAX_R)
+      return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "maps narrower than a window of radius > 7 are not supported by the association kernel", hipSuccess);
+    return launch_associate_cfg<false, 32, false, true>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_guess4, k, full, d_corr, d_moving_idx, true);
+  }
   const bool stage = ctx->assoc_stage_grid && assoc_lds_bytes(fixed.n_slots, true) <= (size_t)ctx->lds_limit / 2;
   // Chunk size and placement.  A handful of pairs (the terms of a fixed-lag window, one loop-closure candidate) and a lone
   // batch of up to two pairs per CU (the size at which the solve takes its split geometry) are all latency: one workgroup per
