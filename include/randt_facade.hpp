@@ -19,6 +19,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <iostream>
 #include <limits>
@@ -145,10 +146,15 @@ inline bool facade_check(int rc, const char* what, randt_ctx* ctx) {
 
 class Context {
  public:
-  explicit Context(int device = 0, void* stream = nullptr) {
+  // solve_mode: RANDT_SOLVE_AUTO (default) lets the library give a lone batch of up to two registrations per CU several
+  // wavefronts per registration, which assumes the device is otherwise idle; a caller that keeps several batches in flight
+  // (several contexts / streams on one GPU) says RANDT_SOLVE_THROUGHPUT here, or loses ~2x throughput
+  explicit Context(int device = 0, void* stream = nullptr, int solve_mode = RANDT_SOLVE_AUTO) {
     // without a device every later call on this context fails with a status (there is no CPU fallback)
-    facade_check(randt_ctx_create(device, stream, &ctx_), "randt_ctx_create", nullptr);
+    if (facade_check(randt_ctx_create(device, stream, &ctx_), "randt_ctx_create", nullptr) && solve_mode != RANDT_SOLVE_AUTO)
+      facade_check(randt_ctx_set_solve_mode(ctx_, solve_mode), "randt_ctx_set_solve_mode", ctx_);
   }
+  void setSolveMode(int solve_mode) { facade_check(randt_ctx_set_solve_mode(ctx_, solve_mode), "randt_ctx_set_solve_mode", ctx_); }
   ~Context() { randt_ctx_destroy(ctx_); }
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
@@ -594,6 +600,18 @@ class Matcher {
     int fcap = 1, mcap = 1;
     for (const Map* m : fixed_ndts) fcap = std::max(fcap, m->capacity());
     for (const Map* m : moving_ndts) mcap = std::max(mcap, m->capacity());
+    // one parameter set per batch (the reference has one, with a zero centre): differently centred or scaled maps would be
+    // associated in the wrong geometry without an error
+    for (const Map* m : fixed_ndts)
+      if (std::memcmp(&m->params(), &fixed_ndts[0]->params(), sizeof(randt_map_params)) != 0) {
+        facade_check(RANDT_ERR_INVALID, "estimateLoopConstraintBatch: the fixed maps must share one geometry (centre, resolution, window)", nullptr);
+        return cost;
+      }
+    for (const Map* m : moving_ndts)
+      if (std::memcmp(&m->params(), &moving_ndts[0]->params(), sizeof(randt_map_params)) != 0) {
+        facade_check(RANDT_ERR_INVALID, "estimateLoopConstraintBatch: the moving maps must share one geometry", nullptr);
+        return cost;
+      }
     std::vector<randt_maps*> fb(static_cast<size_t>(n_local), nullptr), mb(static_cast<size_t>(n_local), nullptr);
     auto cleanup = [&] {
       randt_group_synchronize(g);
@@ -705,6 +723,16 @@ class Matcher {
     int fcap = 1, mcap = 1;
     for (const Map& m : fixed_ndts) fcap = std::max(fcap, m.capacity());
     for (size_t i = 1; i <= S; ++i) mcap = std::max(mcap, moving_ndts.end()[-static_cast<long>(i)].capacity());
+    for (const Map& m : fixed_ndts)
+      if (std::memcmp(&m.params(), &fixed_ndts.front().params(), sizeof(randt_map_params)) != 0) {
+        facade_check(RANDT_ERR_INVALID, "estimateTransformCeres: the fixed maps of a window must share one geometry (centre, resolution, window)", nullptr);
+        return;
+      }
+    for (size_t i = 1; i <= S; ++i)
+      if (std::memcmp(&moving_ndts.end()[-static_cast<long>(i)].params(), &moving_ndts.back().params(), sizeof(randt_map_params)) != 0) {
+        facade_check(RANDT_ERR_INVALID, "estimateTransformCeres: the moving maps of a window must share one geometry", nullptr);
+        return;
+      }
     if (!ensure_stage(ctx, fixed_ndts.front().params(), fcap, nf, moving_ndts.back().params(), mcap, static_cast<int>(S))) return;
     std::vector<int32_t> fslots, mslots;
     int rc = RANDT_OK;
@@ -823,23 +851,27 @@ class Matcher {
   // internal batches the deque overload of estimateTransformCeres copies the window's maps into
   bool ensure_stage(const std::shared_ptr<Context>& ctx, const randt_map_params& fp, int fcap, int n_fixed, const randt_map_params& mpar,
                     int mcap, int n_moving) {
-    auto fits = [](randt_maps* b, const randt_map_params& p, int cap_needed, int n) {
+    // a staging batch is reused only for maps of the SAME geometry (centre, resolution, window, min points: the association
+    // and the index arithmetic read them from the batch) -- not merely the same slot count
+    auto fits = [](randt_maps* b, const randt_map_params& have, const randt_map_params& p, int cap_needed, int n) {
       if (!b) return false;
       int nm = 0, cap = 0, slots = 0;
       randt_maps_info(b, &nm, &cap, &slots, nullptr);
-      return nm >= n && cap >= cap_needed && slots == p.size_x * p.size_y;
+      return nm >= n && cap >= cap_needed && std::memcmp(&have, &p, sizeof(randt_map_params)) == 0;
     };
     if (stage_ctx_ != ctx) release_stage();
     int rc = RANDT_OK;
-    if (!fits(stage_fixed_, fp, fcap, n_fixed)) {
+    if (!fits(stage_fixed_, stage_fixed_params_, fp, fcap, n_fixed)) {
       randt_maps_destroy(stage_fixed_);
       stage_fixed_ = nullptr;
       rc = randt_maps_create(ctx->get(), std::max(2, n_fixed), &fp, fcap, 1, &stage_fixed_);
+      stage_fixed_params_ = fp;
     }
-    if (!rc && !fits(stage_moving_, mpar, mcap, n_moving)) {
+    if (!rc && !fits(stage_moving_, stage_moving_params_, mpar, mcap, n_moving)) {
       randt_maps_destroy(stage_moving_);
       stage_moving_ = nullptr;
       rc = randt_maps_create(ctx->get(), std::max(4, n_moving), &mpar, mcap, 0, &stage_moving_);
+      stage_moving_params_ = mpar;
     }
     stage_ctx_ = ctx;
     return facade_check(rc, "randt_maps_create (window staging)", ctx->get());
@@ -856,6 +888,7 @@ class Matcher {
   std::vector<double> imu_constraints_;
   std::shared_ptr<Context> stage_ctx_;
   randt_maps *stage_fixed_ = nullptr, *stage_moving_ = nullptr;
+  randt_map_params stage_fixed_params_{}, stage_moving_params_{};  // what the staging batches were created with
 };
 
 // rc::navigation::ndt::ScanContextParameters (include/ndt_slam/ndt_slam_parameters.h; ndt_slam.cpp:515-552)

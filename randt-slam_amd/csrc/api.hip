@@ -230,6 +230,11 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
     if (hipHostMalloc(&pin, 64, hipHostMallocDefault) == hipSuccess && pin) {
       memset(pin, 0, 64);
       ctx->misrank_word = static_cast<int32_t*>(pin);
+      if (hipMalloc(reinterpret_cast<void**>(&ctx->d_misrank_count), 64) == hipSuccess) (void)hipMemset(ctx->d_misrank_count, 0, 64);
+      else {
+        ctx->d_misrank_count = nullptr;
+        (void)hipGetLastError();
+      }
     } else {
       (void)hipGetLastError();
       ctx->lds_atomics_lane_ordered = 0;
@@ -247,7 +252,9 @@ int randt_debug_build_rank_fallbacks(randt_ctx* ctx) {
   if (!ctx) return 0;
   DeviceGuard dev_guard__(ctx);
   (void)hipStreamSynchronize(ctx->stream);
-  return ctx->build_rank_fallbacks + (ctx->misrank_word ? *reinterpret_cast<volatile int32_t*>(ctx->misrank_word) * (ctx->lds_atomics_lane_ordered ? 1 : 0) : 0);
+  int32_t n = 0;
+  if (ctx->d_misrank_count && hipMemcpy(&n, ctx->d_misrank_count, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) n = 0;
+  return n;
 }
 
 int randt_ctx_destroy(randt_ctx* ctx) {
@@ -257,6 +264,7 @@ int randt_ctx_destroy(randt_ctx* ctx) {
   if (ctx->small) (void)hipFree(ctx->small);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->misrank_word) (void)hipHostFree(ctx->misrank_word);
+  if (ctx->d_misrank_count) (void)hipFree(ctx->d_misrank_count);
   delete ctx;
   return RANDT_OK;
 }
@@ -446,6 +454,10 @@ int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int s
   if (!range_ok(dst, dst_first, count) || !range_ok(src, src_first, count)) return RANDT_ERR_INVALID;
   if (dst->v.n_slots != src->v.n_slots || dst->v.cap < src->v.cap) return RANDT_ERR_INVALID;
   randt_ctx* ctx = dst->ctx;
+  // the copied index grids and cell means only mean the same thing in a batch of the same geometry
+  if (dst->p.size_x != src->p.size_x || dst->p.size_y != src->p.size_y || dst->p.resolution != src->p.resolution ||
+      dst->p.center_x != src->p.center_x || dst->p.center_y != src->p.center_y)
+    return randt_set_error(ctx, RANDT_ERR_INVALID, "randt_maps_copy: the two batches differ in map geometry (size, resolution or centre)", hipSuccess);
   for (int i = 0; i < count; ++i) {
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(dst->v.cells + (size_t)(dst_first + i) * dst->v.cap,
                                         src->v.cells + (size_t)(src_first + i) * src->v.cap,

@@ -51,8 +51,8 @@ struct randt_ctx {
   int n_cus = 256;           // compute units of the context's device
   int lds_atomics_lane_ordered = 0;  // device self-test at context creation (api.hip): same-address LDS atomics of one instruction
                                      // are served in ascending lane order -> the build kernels rank points with one atomic each
-  int32_t* misrank_word = nullptr;   // pinned host word the build kernel counts its ranking fallbacks in (device-visible)
-  int build_rank_fallbacks = 0;      // workgroups that re-ranked with ballots so far (randt_debug_build_rank_fallbacks)
+  int32_t* misrank_word = nullptr;   // pinned host word a build workgroup that had to re-rank sets to 1 (plain store, device-visible)
+  int32_t* d_misrank_count = nullptr;  // device word: how many workgroups re-ranked with ballots so far (randt_debug_build_rank_fallbacks)
   int window_general = 0;            // RANDT_WINDOW_GENERAL=1: every window takes window_gen.hip (tests: the two kernels agree)
   int debug_force_misrank = 0;       // RANDT_DEBUG_FORCE_MISRANK=1: test hook, makes the in-kernel order check fail
   int build_tiled = 0;       // RANDT_BUILD_TILED=1: every scan through the multi-workgroup build (normally only > 7168 points)

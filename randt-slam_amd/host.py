@@ -64,9 +64,12 @@ def indoor_cluster_params():
 
 class Context:
     """randt_ctx: one per device / caller thread.  ``stream``: a hipStream_t handle (int), e.g.
-    ``torch.cuda.current_stream().cuda_stream``; None = the null stream."""
+    ``torch.cuda.current_stream().cuda_stream``; None = the null stream.  ``solve_mode``: _capi.SOLVE_THROUGHPUT for a
+    caller that keeps several batches in flight on several contexts / streams of one GPU -- the default (SOLVE_AUTO) gives a
+    lone small batch several wavefronts per registration, which assumes an otherwise idle device and costs ~2x throughput
+    when it is not (set_solve_mode changes it later)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, solve_mode=None):
         self._lib = _capi.load()
         h = C.c_void_p()
         rc = self._lib.randt_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
@@ -74,6 +77,8 @@ class Context:
             raise RandtError(rc, "randt_ctx_create")
         self._h = h
         self.device = device
+        if solve_mode is not None:
+            self.set_solve_mode(solve_mode)
 
     def _check(self, rc, where):
         if rc:

@@ -272,4 +272,4 @@ def test_atomic_ranking_is_checked_in_every_launch_and_falls_back(built, monkeyp
     build_and_check(sick)                                                      # the launcher has seen the report ...
     assert lib.randt_debug_lds_atomics_lane_ordered(sick._h) == 0              # ... and switched the context to ballots
     assert lib.randt_debug_build_rank_fallbacks(sick._h) == n                  # no further fallbacks: ballots from the start
-    assert "lane-order check" in lib.randt_last_error(sick._h).decode()
+    assert lib.randt_last_error(sick._h).decode() == ""                       # a downgrade is not an error: no stale text for a later failure to show
