@@ -49,7 +49,7 @@ N_SIMDS, CLOCK_GHZ = 1024, 2.4          # 256 CUs x 4 SIMDs, max clock (MI355X_M
 VALU_PEAK = N_SIMDS * CLOCK_GHZ         # G SIMD-cycles/s of VALU issue
 SAT_COPIES = 16                         # chip-filling launch of the roofline section: 16 copies of the batch = 8192 registrations =
                                         # exactly two rounds of the 4096 resident wavefronts (4 per SIMD) of the one-wavefront solve kernel
-HOT_KERNELS = ("k_ndt_build<true,true>", "k_associate<false,64,true>", "k_solve<3,1,64,true,4,false>")
+HOT_KERNELS = ("k_ndt_build<true,true>", "k_associate<false,64,true,false>", "k_solve<3,1,64,true,4,false>")
 
 
 FILTER_ROWS = {}   # counter rows of k_filter_rows / k_filter_emit from the committed summary (load_counters)
@@ -94,7 +94,7 @@ def load_counters():
         return {}, None, "no committed counter summary"
     rows = {}
     FILTER_ROWS.clear()
-    want_wgs = {"k_ndt_build<true,true>": 512, "k_associate<false,64,true>": 128, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch (the association walks four pairs per workgroup)
+    want_wgs = {"k_ndt_build<true,true>": 512, "k_associate<false,64,true,false>": 128, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch (the association walks four pairs per workgroup)
     stamp = None
     for r in csv.DictReader(open(files[-1])):
         stamp = r.get("csrc_hash", stamp)

@@ -64,7 +64,8 @@ def trace_durations(path):
     for r in csv.DictReader(open(path)):
         n = kname(r["Kernel_Name"])
         if n:
-            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
+            # (the counter CSV's Grid_Size is the whole grid: multiply the trace's three dimensions out for 2-D launches)
+            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0)) * max(1, int(r.get("Grid_Size_Y", 1))) * max(1, int(r.get("Grid_Size_Z", 1)))
             agg[(n, grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return agg
 
