@@ -1,0 +1,61 @@
+"""-m gpu: a C++ caller drives the facade through LocalFuser::processScan's call pattern (tests/cpp/local_fuser_drive.cpp:
+Maps by value in deques, the reference-signature Matcher::estimateTransformCeres, transformMap + mergeMapCell,
+predictTransform, a submap roll-over with overlap) on the committed 40-scan drive -- and lands on the poses of the Python
+harness (randt-slam_amd/odometry.py, the same C ABI underneath) and on the golden fixture the CPU oracle generated
+(tests/golden/odometry_drive.npz).  north_star's "host C++ calls the kernels", as a drive and not only as a smoke test."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import randt_slam_amd as R
+from randt_slam_amd import odometry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "randt-slam_amd")
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "local_fuser_drive")
+    subprocess.check_call([
+        "g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "local_fuser_drive.cpp"),
+        "-L", LIBDIR, "-lrandt_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe,
+    ])
+    return exe
+
+
+def test_cpp_local_fuser_drive_matches_the_python_harness_and_the_golden_fixture(built, tmp_path):
+    import torch
+    from make_golden_odometry import DT, N_SCANS, SMALL, drive_inputs
+
+    traj, scans = drive_inputs()
+    arr = np.ascontiguousarray(np.stack(scans), dtype=np.float32)
+    assert arr.shape[0] == N_SCANS and arr.shape[2] == 4 and DT == 0.25
+    path = tmp_path / "scans.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([arr.shape[0], arr.shape[1]], dtype=np.int32).tobytes())
+        f.write(arr.tobytes())
+    exe = _build(tmp_path)
+    out = tmp_path / "poses.txt"
+    r = subprocess.run([exe, str(path), str(out), str(SMALL["submap_size_poses"]), str(SMALL["submap_overlap"])], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "1 submaps finished" in r.stdout
+    cpp = np.loadtxt(out)
+    assert cpp.shape == (N_SCANS, 4)
+
+    # the Python harness on the same drive (same kernels through the same ABI; the C++ caller copies Maps by value and merges a
+    # transformed copy where the harness merges in place with a pose)
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    odo = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, R.window_params(), SMALL)
+    py = np.array([odo.process_scan(scans[i], i * DT).copy() for i in range(N_SCANS)])
+    assert odo.n_finished_submaps == 1
+    assert np.abs(cpp - py).max() <= 1e-9, np.abs(cpp - py).max()
+
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "odometry_drive.npz"))
+    assert np.abs(cpp - gold["poses4"]).max() <= 1e-6, np.abs(cpp - gold["poses4"]).max()

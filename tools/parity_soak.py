@@ -26,13 +26,13 @@ n_solved = n_well = bad_well = 0
 worst_well = 0.0
 for case in range(n_cases):
     # random map / clustering geometry around the shipped presets
-    res = float(rng.choice([0.4, 0.5, 0.75, 1.2]))
-    size = int(rng.choice([60, 100, 140]))
+    res = float(rng.choice([0.4, 0.5, 0.75, 1.2] if os.environ.get("SOAK_OLD_DRAW") == "1" else [0.25, 0.4, 0.5, 0.75, 1.2]))                 # (0.25 m: window radii beyond 7, the association's WIDE instantiation, round 4)
+    size = int(rng.choice([60, 100, 140])) if res > 0.3 else int(rng.choice([120, 200]))
     max_range = float(rng.choice([10.0, 12.0, 20.0]))
     mapp_args = (size, size, res, float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.choice([2.0, 4.0])) * res / 0.5 if rng.random() < 0.5 else 4.0,
                  int(rng.integers(2, 7)), 0)
-    if int(mapp_args[5] / res) - 1 > 7:
-        mapp_args = mapp_args[:5] + (7.9 * res,) + mapp_args[6:]
+    if int(mapp_args[5] / res) - 1 > 15:
+        mapp_args = mapp_args[:5] + (15.9 * res,) + mapp_args[6:]
     n_clusters = int((2 * max_range / res) ** 2)
     mapp, clu = R.MapParams(*mapp_args), R.ClusterParams(n_clusters, max_range)
     world = synth.make_world(seed=int(rng.integers(0, 10000)))
@@ -66,7 +66,7 @@ for case in range(n_cases):
         continue
     if om.n_cells == 0 or of.n_cells == 0:
         continue
-    k = int(rng.choice([1, 3, 4, 6]))
+    k = int(rng.choice([1, 3, 4, 6] if os.environ.get("SOAK_OLD_DRAW") == "1" else [1, 3, 4, 6, 4, 4, 9, 12, 16]))
     mp = R.default_matcher_params(n_neighbours=k, lookup_mahalanobis=int(rng.random() < 0.7), use_intensity=int(rng.random() < 0.7),
                                   parameterization=int(rng.choice([R.PARAM_AMBIENT4, R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC])),
                                   gnc_steps=int(rng.choice([1, 2, 3])))
@@ -96,6 +96,8 @@ for case in range(n_cases):
         worst_well = max(worst_well, err)
         bad_well += err > 1e-4
     it_g, it_o = int(r["iterations"].item() if hasattr(r["iterations"], "item") else r["iterations"]), int(st["n_iterations"])
+    if VERBOSE and well and err > 1e-6:
+        print("well-posed case %d err %.3e k %d res %.2f param %d gnc %d n_res %d iters gpu %d oracle %d" % (case, err, k, res, mp.parameterization, mp.gnc_steps, int(st["n_residuals"]), int(r["iterations"]), int(st["n_iterations"])))
     if err > 1e-4 or it_g != it_o:
         bad["pose" if err > 1e-4 else "iters"] += 1
         if VERBOSE:
