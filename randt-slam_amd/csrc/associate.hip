@@ -582,8 +582,6 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   if (fixed.rmax - 1 > ASSOC_WIDE_MAX_R)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "max_neighbour_dist/resolution > 16 not supported by the association kernel", hipSuccess);
   if (k > 16) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "n_neighbours > 16 not supported by the association kernel", hipSuccess);
-  if (fixed.n_slots <= 225)
-    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "maps with <= 225 slots not supported by the association kernel", hipSuccess);
   const int full = (use_intensity && lookup_mahalanobis) ? 1 : 0;
   if (fixed.rmax - 1 > ASSOC_MAX_R || k > 8) {
     // beyond every shipped configuration (ndt_map.cpp:117 and ndt_matcher.cpp:210 take any value): the WIDE instantiation,

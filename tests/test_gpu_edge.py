@@ -327,6 +327,20 @@ def test_association_on_a_map_narrower_than_the_window(env):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("sx,sy,res,max_dist,k", [(15, 15, 0.5, 4.0, 4), (16, 14, 0.5, 4.0, 3), (10, 20, 0.5, 4.0, 5), (12, 12, 0.5, 2.0, 2),
+                                                  (8, 8, 1.0, 4.0, 4), (6, 30, 0.5, 1.5, 3), (20, 11, 0.4, 1.0, 8)])
+def test_association_on_maps_smaller_than_one_window(env, sx, sy, res, max_dist, k):
+    """Maps with no more slots than one search window (<= 225): the reference's loop then also ends on `adjacent.size() <
+    n_cells_` (every slot seen, ndt_map.cpp:119), and windows wrap in both directions.  Refused until round 4 -- untested, not
+    unsupported: the popcount / de-duplication paths give the oracle's tables."""
+    ext = 0.45 * min(sx, sy) * res
+    mapp = (sx, sy, res, 0.0, 0.0, max_dist, 3, 0)
+    got, want, nm, nf = _assoc_both(env, _blobs(51, 14, ext, n=800), _blobs(52, 10, ext, n=600), mapp, (2304, 24.0), k,
+                                    guess=(np.cos(0.1), np.sin(0.1), 0.1, -0.05))
+    assert nm > 2 and nf > 2 and sx * sy <= 225
+    assert np.array_equal(got, want)
+
+
 def test_error_convention_status_codes_not_exceptions(env):
     """the ABI never throws and never falls back: bad arguments -> RANDT_ERR_INVALID, sizes beyond the kernels ->
     RANDT_ERR_UNSUPPORTED with a message, outputs untouched (SURVEY 8(b) error convention)."""
