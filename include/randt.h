@@ -286,7 +286,10 @@ int randt_points_transform(randt_ctx* ctx, float* h_points, int n_points, int st
  * Map::getClosestCells / getAdjacentIndizes (ndt_map.cpp:101-175) and
  * Cell::mahalanobisSquaredIntensity (ndt_cell.cpp:172-176).
  * Pair p registers moving map (moving_first + p) against fixed map d_fixed_idx[p] from guess
- * d_guess4[p].  d_corr: n_pairs x cell_capacity(moving) x k int32, -1 padded. */
+ * d_guess4[p].  d_corr: n_pairs x cell_capacity(moving) x k int32, -1 padded.
+ * Limits (RANDT_ERR_UNSUPPORTED beyond; the reference has none): window
+ * int(max_neighbour_dist / resolution) <= 16, k = mp->n_neighbours <= 16; maps narrower than the window only up to a
+ * window of 8. */
 int randt_associate_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t* d_fixed_idx,
                               const randt_maps* moving, int moving_first, int n_pairs,
                               const double* d_guess4, const randt_matcher_params* mp, int32_t* d_corr);
