@@ -96,6 +96,13 @@ for case in range(n_cases):
         worst_well = max(worst_well, err)
         bad_well += err > 1e-4
     it_g, it_o = int(r["iterations"].item() if hasattr(r["iterations"], "item") else r["iterations"]), int(st["n_iterations"])
+    if VERBOSE and well and err > 1e-5:
+        # yardstick: the oracle against ITSELF with the initial translation moved by one ulp -- is this registration a flat valley?
+        g_ulp = g4.copy()
+        g_ulp[2] = np.nextafter(g_ulp[2], np.inf)
+        _, p_u, cost_u, st_u = po.register_pair(of, om, to_oracle_params(mp), g_ulp)
+        err_u = max(abs(p_u[2] - p4[2]), abs(p_u[3] - p4[3]), abs(synth.wrap_angle(np.arctan2(p_u[1], p_u[0]) - np.arctan2(p4[1], p4[0]))))
+        print("  oracle vs one-ulp-perturbed oracle: %.3e (iterations %d vs %d); costs gpu %.12g oracle %.12g perturbed %.12g" % (err_u, int(st_u["n_iterations"]), it_o if False else int(st["n_iterations"]), float(r["cost"]), cost, cost_u))
     if VERBOSE and well and err > 1e-6:
         print("well-posed case %d err %.3e k %d res %.2f param %d gnc %d n_res %d iters gpu %d oracle %d" % (case, err, k, res, mp.parameterization, mp.gnc_steps, int(st["n_residuals"]), int(r["iterations"]), int(st["n_iterations"])))
     if err > 1e-4 or it_g != it_o:
