@@ -261,6 +261,7 @@ int randt_ctx_destroy(randt_ctx* ctx) {
   if (!ctx) return RANDT_OK;
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->build_ws) (void)hipFree(ctx->build_ws);
+  if (ctx->build_wide_ws) (void)hipFree(ctx->build_wide_ws);
   if (ctx->small) (void)hipFree(ctx->small);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->misrank_word) (void)hipHostFree(ctx->misrank_word);

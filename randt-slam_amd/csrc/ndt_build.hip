@@ -824,15 +824,25 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
     }
     int rc = launch_ndt_build_big(ctx, d_points, n_scans, pitch, d_n_points, stride, ioff, cp, out, first_map, ctx->build_ws, d_polar, beam_cov9);
     if (rc) return rc;
-    // The tiled path keeps <= 8192 label bins per tile.  A scan whose labels span more (points many times max_range away
-    // from the sensor) cannot be sorted by it: that is reported here, which costs this path one synchronisation.
+    // The tiled path keeps <= 8192 label bins per tile.  A scan whose labels span more (points many times max_range away from
+    // the sensor, a cluster grid of more than ~7900 clusters) is refused by it on the device; that is learnt here -- one
+    // synchronisation on this cold path -- and such scans are built again through the sorting path (ndt_build_big.hip).
     std::vector<int32_t> st((size_t)4 * n_scans);
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(st.data(), ctx->build_ws, sizeof(int32_t) * 4 * n_scans, hipMemcpyDeviceToHost, ctx->stream));
     RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int s = 0; s < n_scans; ++s)
-      if (st[4 * (size_t)s + 2] != 0)
-        return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan above 7168 points whose cluster labels span more than 8192 values "
-                               "(points far outside max_range): not supported by the tiled build", hipSuccess);
+    std::vector<int32_t> npts;
+    for (int s = 0; s < n_scans; ++s) {
+      if (st[4 * (size_t)s + 2] == 0) continue;
+      if (d_n_points && npts.empty()) {
+        npts.resize(n_scans);
+        RANDT_HIP_CHECK(ctx, hipMemcpy(npts.data(), d_n_points, sizeof(int32_t) * n_scans, hipMemcpyDeviceToHost));
+      }
+      int n = d_n_points ? npts[s] : pitch;
+      n = n < 0 ? 0 : (n > pitch ? pitch : n);
+      rc = launch_ndt_build_big_wide(ctx, d_points + (size_t)s * pitch * stride, n, stride, ioff, cp, out, first_map + s,
+                                     d_polar ? d_polar + (size_t)s * pitch * 2 : nullptr, beam_cov9);
+      if (rc) return rc;
+    }
     return RANDT_OK;
   }
   // Grid::cluster (grid.cpp:8-9)

@@ -18,6 +18,15 @@
 //   k_big_stats    eight lanes per cluster, one accumulator chain per lane, walking the sorted arrays sequentially
 //   k_big_finish   per scan: cell count; moves cells down if a cluster mean fell outside the map (like the
 //                  one-workgroup kernel's repair path)
+// A scan whose labels span more than a tile's 8192 bins (points many times max_range away from the sensor, or a cluster grid of
+// more than ~7900 clusters: grid.cpp:8-11 takes any n_clusters) takes launch_ndt_build_big_wide below instead of the counting sort: a
+// stable device radix sort of (label, point index) -- rocPRIM, a plain library sort on a cold path -- IS labelClouds' order; cluster
+// bounds are the label changes, and the statistics / finish kernels run unchanged on them.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
 #include "cell_math.h"
 
 using namespace randt_dev;
@@ -403,7 +412,145 @@ __global__ void k_big_init(int32_t* range, int n_scans) {
   }
 }
 
+// ---- wide label spans: sort instead of count (one scan at a time; see the header)
+__global__ void k_wide_keys(BigArgs A, int n, uint32_t* keys, uint32_t* vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x, y, in;
+  fetch_point(A, A.pts, i, x, y, in);
+  keys[i] = (uint32_t)big_label(x, y, A.row_size, A.resolution) ^ 0x80000000u;  // signed order as unsigned order
+  vals[i] = (uint32_t)i;
+}
+__global__ void k_wide_heads(const uint32_t* keys, int n, uint32_t* head) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// cid: inclusive scan of head (cluster number + 1 of every sorted point)
+__global__ void k_wide_starts(const uint32_t* head, const uint32_t* cid, int n, uint32_t* cstart, int32_t* range) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (head[i]) cstart[cid[i] - 1u] = (uint32_t)i;
+  if (i == n - 1) {
+    const uint32_t nc = cid[i];
+    cstart[nc] = (uint32_t)n;
+    range[0] = 0;                // the statistics / finish kernels see clusters 0 .. nc - 1 as their "bins"
+    range[1] = (int32_t)nc - 1;
+    range[2] = 0;
+    range[3] = 0;
+  }
+}
+__global__ void k_wide_accept(const uint32_t* cstart, const int32_t* range, int n, int min_points, uint32_t* accept) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int nc = range[1] + 1;
+  // Cell::addPointCloud: n_points_(0) + size > min_points_per_cell_ (ndt_cell.cpp:26)
+  accept[c] = (c < nc && (long long)(cstart[c + 1] - cstart[c]) > (long long)min_points) ? 1u : 0u;
+}
+__global__ void k_wide_pre(const uint32_t* accept, const uint32_t* excl, int n, uint32_t* pre) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) pre[c] = accept[c] ? excl[c] : 0xffffffffu;
+}
+__global__ void k_wide_scatter(BigArgs A, int n, const uint32_t* vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int src = (int)vals[i];
+  float x, y, in;
+  fetch_point(A, A.pts, src, x, y, in);
+  A.sx[i] = x;
+  A.sy[i] = y;
+  A.si[i] = in;
+  if (A.polar) {
+    A.sa[i] = A.polar[2 * (size_t)src];
+    A.sr[i] = A.polar[2 * (size_t)src + 1];
+  }
+}
+
 }  // namespace
+
+// One scan whose labels span more than BIG_NB_MAX values (host-side n: the caller has synchronised to learn that the tiled path
+// refused it).  d_points / d_polar: THIS scan's points; map: its index in `out`.  Uses ctx->build_wide_ws (grown on demand).
+int launch_ndt_build_big_wide(randt_ctx* ctx, const float* d_points, int n, int stride, int ioff, const randt_cluster_params* cp,
+                              const MapView& out, int map, const float* d_polar, const float* beam_cov9) {
+  if (n <= 0) return RANDT_OK;
+  const size_t npad = ((size_t)n + 63) & ~(size_t)63;
+  size_t t_sort = 0, t_scan = 0;
+  {
+    uint32_t* nul = nullptr;
+    RANDT_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, t_sort, nul, nul, nul, nul, (size_t)n, 0, 32, ctx->stream));
+    RANDT_HIP_CHECK(ctx, rocprim::inclusive_scan(nullptr, t_scan, nul, nul, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+    size_t t_ex = 0;
+    RANDT_HIP_CHECK(ctx, rocprim::exclusive_scan(nullptr, t_ex, nul, nul, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+    t_scan = t_scan > t_ex ? t_scan : t_ex;
+  }
+  const size_t t_tmp = ((t_sort > t_scan ? t_sort : t_scan) + 255) & ~(size_t)255;
+  const size_t need = 256 + 9 * (npad + 64) * 4 + (d_polar ? 2 * npad * 4 : 0) + t_tmp + 4096;
+  if (need > ctx->build_wide_ws_bytes) {
+    if (ctx->build_wide_ws) {
+      RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->build_wide_ws);
+      ctx->build_wide_ws = nullptr;
+      ctx->build_wide_ws_bytes = 0;
+    }
+    RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->build_wide_ws, need));
+    ctx->build_wide_ws_bytes = need;
+  }
+  char* w = static_cast<char*>(ctx->build_wide_ws);
+  auto take = [&](size_t bytes) {
+    char* p = w;
+    w += (bytes + 255) & ~(size_t)255;
+    return p;
+  };
+  int32_t* range = (int32_t*)take(16);
+  uint32_t* k_in = (uint32_t*)take((npad + 64) * 4);
+  uint32_t* k_out = (uint32_t*)take((npad + 64) * 4);
+  uint32_t* v_in = (uint32_t*)take((npad + 64) * 4);
+  uint32_t* v_out = (uint32_t*)take((npad + 64) * 4);
+  uint32_t* cstart = (uint32_t*)take((npad + 64) * 4);
+  uint32_t* pre = (uint32_t*)take((npad + 64) * 4);
+  BigArgs A;
+  memset(&A, 0, sizeof(A));
+  A.polar = d_polar;
+  for (int i = 0; i < 9; ++i) A.beam[i] = (d_polar && beam_cov9) ? beam_cov9[i] : 0.f;
+  A.pts = d_points;
+  A.n_pts_arr = nullptr;
+  A.pitch = n;
+  A.stride = stride;
+  A.ioff = ioff;
+  A.row_size = (int)sqrt((double)cp->n_clusters);           // Grid::cluster (grid.cpp:8-9)
+  A.resolution = cp->max_range * 2 / (float)A.row_size;
+  A.n_tiles = 1;
+  A.first_map = map;
+  A.npad = (int)npad;
+  A.range = range;
+  A.bin_start = cstart;
+  A.pre = pre;
+  A.sx = (float*)take(npad * 4);
+  A.sy = (float*)take(npad * 4);
+  A.si = (float*)take(npad * 4);
+  if (d_polar) {
+    A.sa = (float*)take(npad * 4);
+    A.sr = (float*)take(npad * 4);
+  }
+  void* tmp = take(t_tmp);
+  hipStream_t st = ctx->stream;
+  const dim3 blk(256), grd((n + 255) / 256);
+  hipLaunchKernelGGL(k_wide_keys, grd, blk, 0, st, A, n, k_in, v_in);
+  size_t tb = t_tmp;
+  RANDT_HIP_CHECK(ctx, rocprim::radix_sort_pairs(tmp, tb, k_in, k_out, v_in, v_out, (size_t)n, 0, 32, st));  // stable: labelClouds' order
+  hipLaunchKernelGGL(k_wide_heads, grd, blk, 0, st, k_out, n, k_in /* head */);
+  tb = t_tmp;
+  RANDT_HIP_CHECK(ctx, rocprim::inclusive_scan(tmp, tb, k_in, v_in /* cluster number + 1 */, (size_t)n, rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_wide_starts, grd, blk, 0, st, k_in, v_in, n, cstart, range);
+  hipLaunchKernelGGL(k_wide_accept, grd, blk, 0, st, cstart, range, n, out.min_points, k_in /* accept */);
+  tb = t_tmp;
+  RANDT_HIP_CHECK(ctx, rocprim::exclusive_scan(tmp, tb, k_in, v_in /* provisional compact index */, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(k_wide_pre, grd, blk, 0, st, k_in, v_in, n, pre);
+  hipLaunchKernelGGL(k_wide_scatter, grd, blk, 0, st, A, n, v_out);
+  hipLaunchKernelGGL(k_big_stats, dim3(64, 1), dim3(BIG_BLOCK), 0, st, A, out);
+  hipLaunchKernelGGL(k_big_finish, dim3(1), dim3(BIG_BLOCK), 0, st, A, out);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
 
 // Workspace bytes of the tiled path for a batch.
 size_t ndt_build_big_ws_bytes(int n_scans, int pitch, int with_polar) {

@@ -37,6 +37,8 @@ struct randt_ctx {
   void* small = nullptr;     // 4 KB of device scratch for the synchronous host-level conveniences (lazily allocated)
   void* build_ws = nullptr;  // label scratch of k_ndt_build's fallback sort (its own buffer: callers stage points in ws)
   size_t build_ws_bytes = 0;
+  void* build_wide_ws = nullptr;  // tiled build, scans whose labels span more than a tile's bins: sort workspace (ndt_build_big.hip)
+  size_t build_wide_ws_bytes = 0;
   double* d_trace = nullptr;
   int trace_len = 0;
   int lds_limit = 160 * 1024;
@@ -108,6 +110,8 @@ size_t ndt_build_big_ws_bytes(int n_scans, int pitch, int with_polar = 0);
 int launch_ndt_build_big(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride,
                          int ioff, const randt_cluster_params* cp, const MapView& out, int first_map, void* d_ws, const float* d_polar = nullptr,
                          const float* beam_cov9 = nullptr);
+int launch_ndt_build_big_wide(randt_ctx* ctx, const float* d_points, int n, int stride, int ioff, const randt_cluster_params* cp,
+                              const MapView& out, int map, const float* d_polar, const float* beam_cov9);
 int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count, const double* d_pose4);
 int launch_maps_reindex(randt_ctx* ctx, const MapView& m, int first, int count);
 int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,

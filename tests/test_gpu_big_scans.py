@@ -117,14 +117,42 @@ def test_cluster_means_outside_the_map_are_dropped_in_order(env):
     assert len(cells) == om.n_cells and cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
 
 
-def test_label_range_beyond_the_tiled_path_is_reported(env):
+@pytest.mark.parametrize("case", ["far_outliers", "fine_cluster_grid", "batch_of_mixed_scans", "ragged_counts"])
+def test_label_ranges_beyond_a_tile_take_the_sorting_path(env, case):
+    """Scans above 7168 points whose cluster labels span more than the 8192 bins a tile of the counting sort holds -- garbage
+    returns thousands of max_range away, or a cluster grid of more than ~7900 clusters (grid.cpp:8-11 takes any n_clusters) --
+    were refused until round 4; they now go through a stable device radix sort of (label, point index), which IS labelClouds'
+    order: same cells, same compact order, same index grid as the oracle."""
     torch, dev, ctx = env
-    pts = _dense_scan(8000, 9900).copy()
-    pts[::97, 0] += 30000.0                                       # garbage returns 2500 x max_range away
-    maps = R.Maps(ctx, 1, R.indoor_map_params(), 2048, with_grid=True)
-    with pytest.raises(R.RandtError) as e:
-        R.ndt_build_batch(ctx, torch.from_numpy(pts[None]).to(dev), R.indoor_cluster_params(), maps)
-    assert e.value.status == R._capi.ERR_UNSUPPORTED and "8192" in str(e.value)
-    R.ndt_build_batch(ctx, torch.from_numpy(_dense_scan(8000, 9901)[None]).to(dev), R.indoor_cluster_params(), maps)   # context stays usable
+    clu = R.indoor_cluster_params()
+    if case == "far_outliers":
+        scans = [_dense_scan(8000, 9900).copy()]
+        scans[0][::97, 0] += 30000.0                              # garbage returns 2500 x max_range away
+        scans[0][5::131, 1] -= 17000.0
+    elif case == "fine_cluster_grid":
+        clu = R.ClusterParams(16384, 24.0)                        # 128 x 128 clusters
+        scans = [_dense_scan(12000, 9910)]
+    elif case == "batch_of_mixed_scans":                          # one ordinary scan between two wide ones: only those take the sort
+        a, b, c = _dense_scan(9000, 9920).copy(), _dense_scan(9000, 9921), _dense_scan(9000, 9922).copy()
+        a[::61, 1] += 9000.0
+        c[3::73, 0] -= 12345.0
+        scans = [a, b, c]
+    else:
+        a, b = _dense_scan(9000, 9930).copy(), _dense_scan(9000, 9931).copy()
+        a[::89, 0] += 20000.0
+        b[::89, 0] += 20000.0
+        scans = [a, b]
+    pts = np.stack(scans)
+    n_pts = None
+    if case == "ragged_counts":
+        n_pts = np.array([8123, 7400], dtype=np.int32)
+    maps = R.Maps(ctx, len(scans), R.indoor_map_params(), 4096, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(pts).to(dev), clu, maps, n_points=None if n_pts is None else torch.from_numpy(n_pts).to(dev))
     ctx.synchronize()
-    assert maps.counts()[0] > 50
+    for i, sc in enumerate(scans):
+        n = len(sc) if n_pts is None else int(n_pts[i])
+        om = po.Map(IP["size_x"], IP["size_y"], IP["resolution"], (0.0, 0.0), IP["max_neighbour_dist"], IP["min_points_per_cell"], 4096)
+        om.build(sc[:n], clu.n_clusters, clu.max_range)
+        cells, grid = maps.download(i)
+        assert om.n_cells > 50 and len(cells) == om.n_cells, (case, i, len(cells), om.n_cells)
+        assert cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid()), (case, i)
