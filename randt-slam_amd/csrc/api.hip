@@ -1100,7 +1100,7 @@ int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans,
   if (!d_raw || !d_out_points || !d_out_counts || !d_status) return RANDT_ERR_INVALID;
   if (stride_floats == 4 && ((size_t)d_raw & 15) != 0) return randt_set_error(ctx, RANDT_ERR_INVALID, "packed xyzI input must be 16-byte aligned", hipSuccess);
   if ((long long)n_azimuths * n_bins > (1ll << 30)) return RANDT_ERR_UNSUPPORTED;
-  int rc = ensure_ws(ctx, (size_t)n_scans * n_azimuths * 32 + 256);
+  int rc = ensure_ws(ctx, (size_t)n_scans * n_azimuths * (32 + 4 * 2 * 16) + 512);  // row records + FILT_STAGE staged points per row (filter.hip)
   if (rc) return rc;
   return launch_filter_scan(ctx, d_raw, n_scans, n_azimuths, n_bins, stride_floats, intensity_index, fp, d_out_points, pitch_out,
                             d_out_counts, d_out_polar, d_peaks, d_peak_counts, d_status, ctx->ws);

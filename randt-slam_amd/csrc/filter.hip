@@ -5,27 +5,32 @@
 // per azimuth the strongest return inside (min_range, max_range), then the run of monotonically
 // decreasing intensity around it, thresholded by min_intensity, transformed sensor -> base.
 //
-//   k_filter_rows   256-thread workgroups that each walk a strided set of azimuth rows of one scan (one row each when a
-//                   launch has few scans, several when it has many).  Per row:
+//   k_filter_rows   one WAVEFRONT per azimuth row (four rows per 256-thread workgroup, no barrier, no LDS).  Per row:
 //                   1. the row of the raw polar scan (16 B / point, 19.2 MB for 400 x 3000) is read exactly once with
-//                      coalesced float4 loads, ALL of a lane's loads in flight at once (12 for 3000 bins); per-row
-//                      arg-max (strict '>', first index wins) by shuffles + a 4-way LDS combine; the same pass verifies
-//                      that the cloud really
-//                      is organised azimuth after azimuth (the reference detects azimuth changes with
-//                      |atan2 - current| > 1e-4 while walking the cloud sequentially);
-//                   2. the row's detection is expanded towards / away from the sensor right there, while the row is
-//                      cache-hot: wavefront 0 walks inwards and wavefront 1 outwards, 64 bins per step (one lane per
-//                      bin evaluates the reference's stopping rule, the first lane that stops ends the walk) instead
-//                      of one dependent load pair per bin; the same loads count the run's points that pass the output
-//                      thresholds; a 32-byte row record goes to scratch.
+//                      coalesced dwordx4 loads, twelve of them in flight per lane as a ring that never drains before
+//                      the row ends; the arg-max (strict '>', first index wins) stays in registers and is combined by
+//                      shuffles; the same pass checks that the cloud really is organised azimuth after azimuth (the
+//                      reference detects azimuth changes with |atan2 - current| > 1e-4 while walking the cloud
+//                      sequentially): a cross / dot test flags, a flagged row is walked again with the exact atan2f;
+//                   2. the row's detection is expanded towards / away from the sensor by the same wavefront while the
+//                      row is cache-hot (expand_both below); the same loads count the run's points that pass the output
+//                      thresholds and -- for runs of <= FILT_STAGE kept points that end within 32 bins on both sides:
+//                      nearly all -- produce the output points themselves (the "stage"); a 32-byte row record.
 //   k_filter_emit   one workgroup per scan: replays the reference's detection-list semantics (last azimuth never
 //                   flushed, the very first boundary pushes index 0), block-scans the kept counts over the rows and
-//                   emits the points and the per-azimuth peaks in the reference's order (run bins re-read from L2,
-//                   eight independent loads at a time).
-// Measured alternatives (16 scans per launch, 307 MB): emission fused into the row kernel behind a device-scope ticket
-// 130 us (every row workgroup then ends with a store acknowledgement and a returning atomic under full read load);
-// a second register set holding the workgroup's next row (191 registers, two workgroups per CU) 93 us; this version
-// (128 registers, four per CU) 72 us; the same with non-temporal row loads (the run expansion then misses L2) 100 us; squeezed to 96 / 80 registers by the compiler (spills) 84 / 104 us.
+//                   emits the points and the per-azimuth peaks in the reference's order: staged rows are copied (record
+//                   and stage arrive in one round trip), the others re-read their run, eight independent loads at a time.
+// Measured (16 scans per launch, 307 MB, rocprofv3 averages; a bare read of the same bytes takes 44 .. 45 us when consecutive
+// launches meet their lines in the 256 MB Infinity Cache and 48.4 .. 49.5 us per 307 MB of a 1.2 GB buffer, i.e. from HBM:
+// tools/hbm_stream_probe.hip):
+//   rounds 3 / early 4  a WORKGROUP per row, barrier between arg-max and expansion: 58.2 + 7.6 (emission) us; with expansion
+//                       and per-point tests compiled out still 53.6: it paid for the barrier, behind which four wavefronts
+//                       have nothing in flight; next row in a second register set (191 registers, two per CU) 93;
+//                       non-temporal row loads 100; 96 / 80 registers (spills) 84 / 104; emission behind a ticket per row 130;
+//                       next row's loads issued before the barrier (+ a fifth wavefront for the expansion) 54 .. 69
+//   this file           wavefront per row 54.8 -> ring of loads 53.2 -> exact test out of the loop, scalar row base, one
+//                       dwordx4 per point 51.4; 4 .. 16 loads per lane x 3 .. 6 wavefronts per SIMD: all within 1 us (the
+//                       kernel sits on what HBM gives a read-only stream); emission 7.6 -> 5.6 us with the stage
 #include "randt_internal.h"
 
 #include <math.h>
@@ -35,6 +40,7 @@
 
 #define FILT_BLOCK 256
 #define FILT_WAVES (FILT_BLOCK / 64)
+#define FILT_STAGE 4     // kept points per row that the row kernel hands to the emission ready-made (2 float4 each)
 #define FILT_EBLOCK 512  // emission kernel: all azimuth rows of a 400-row scan in one round
 #ifndef FILT_UNROLL
 #define FILT_UNROLL 12
@@ -55,12 +61,13 @@ struct RowRec {
   float angle;      // atan2 of the row's first point (the reference's current_angle)
   float maxi;       // peak intensity
   float peak_range; // hypot of the detection (the emission's per-azimuth peak record)
-  int32_t bad;      // 1: an azimuth change inside the row (the scan is not organised azimuth after azimuth)
+  int32_t bad;      // bit 0: an azimuth change inside the row (the scan is not organised azimuth after azimuth);
+                    // bit 1: all of the row's kept points are in the stage
 };
 
 struct FilterArgs {
   const float* raw;   // [n_scans][n_az][n_bins][stride]
-  int n_az, n_bins, stride, ioff;
+  int n_scans, n_az, n_bins, stride, ioff;
   float min_d, max_d, min_i, thr;
   double lo2, hi2;    // range test on the squared distance: min_d < hypot(x, y) < max_d  <=>  lo2 <= x^2 + y^2 <= hi2
   float T[12];
@@ -71,8 +78,10 @@ struct FilterArgs {
   int32_t* peak_counts;  // nullable
   int32_t* status;       // [n_scans] 0 ok, 1 not azimuth-organised, 2 output overflow
   int pitch_out;
+  int out_vec;        // out_pts is 16-byte aligned
   // scratch
   RowRec* rows;       // [n_scans][n_az]
+  float4* stage;      // [n_scans][n_az][FILT_STAGE][2]: {x' y' z' I}, {atan2 range - -} of a row's first kept points
 };
 
 // PACKED: 16-byte x y z I records (one dwordx4 load per point), known at compile time so that a row's loads are
@@ -95,38 +104,6 @@ __device__ __forceinline__ void fetch(const FilterArgs& A, const float* base, lo
 __device__ __forceinline__ bool keep_point(const FilterArgs& A, float x, float y, float in, float& dist) {
   dist = hypot_f(x, y);
   return (double)dist > (double)A.min_d && (double)dist < (double)A.max_d && (double)in > (double)A.min_i;
-}
-
-// One direction of the run expansion (:80-108), DIR = -1 towards the sensor, +1 away from it: the first d >= 0 at which
-//   (m + DIR (d + 1) leaves the cloud)  or  hypot(a) - hypot(b) > thr  or  I(a) <= I(b)  or  hypot(a) < min_range
-// with a = m + DIR d, b = a + DIR; returns that a.  Sequential in the reference; here 64 values of d per step, one per
-// lane, the lowest stopping lane wins (lanes beyond it evaluate bins the reference never touches: discarded).
-// kept: how many bins of the walked part of the run (d = 0 .. stop for DIR = -1, d = 1 .. stop for DIR = +1, so that the
-// detection itself is counted once) pass the output thresholds (:110-118) -- the same loads serve both questions.
-template <int DIR, bool PACKED>
-__device__ __forceinline__ long long expand_run(const FilterArgs& A, const float* base, long long n, long long m, int lane, int& kept, float* range_m = nullptr) {
-  kept = 0;
-  for (long long d0 = 0;; d0 += 64) {
-    const long long a = m + DIR * (d0 + lane), b = a + DIR;
-    const bool a_in = a >= 0 && a <= n - 1, b_in = b >= 0 && b <= n - 1;
-    bool stop = true, keep = false;
-    float ha = 0.f;
-    if (a_in) {
-      float ax, ay, ai, bx = 0.f, by = 0.f, bi = 0.f;
-      fetch<PACKED>(A, base, a, ax, ay, ai);
-      if (b_in) fetch<PACKED>(A, base, b, bx, by, bi);
-      keep = keep_point(A, ax, ay, ai, ha) && (DIR < 0 || d0 + lane > 0);
-      if (b_in) stop = ((double)(ha - hypot_f(bx, by)) > (double)A.thr) || (ai <= bi) || ((double)ha < (double)A.min_d);
-    }
-    if (range_m && d0 == 0) *range_m = __shfl(ha, 0, 64);
-    const unsigned long long mask = __ballot(stop), kmask = __ballot(keep);
-    if (mask) {
-      const int first = __ffsll((long long)mask) - 1;
-      kept += __popcll(kmask & (first == 63 ? ~0ull : ((1ull << (first + 1)) - 1ull)));
-      return m + DIR * (d0 + (long long)first);
-    }
-    kept += __popcll(kmask);
-  }
 }
 
 template <int NW>
@@ -152,28 +129,33 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total) 
   return base + incl - v;
 }
 
+// the output point of a kept return: pcl::transformPointCloud with initial_transform_radar_baselink_ (:124)
+__device__ __forceinline__ float4 to_base(const FilterArgs& A, float x, float y, float z, float in) {
+  float4 o;
+  o.x = ((A.T[0] * x + A.T[1] * y) + A.T[2] * z) + A.T[3];
+  o.y = ((A.T[4] * x + A.T[5] * y) + A.T[6] * z) + A.T[7];
+  o.z = ((A.T[8] * x + A.T[9] * y) + A.T[10] * z) + A.T[11];
+  o.w = in;
+  return o;
+}
+template <bool PACKED>
+__device__ __forceinline__ float fetch_z(const FilterArgs& A, const float* base, long long i) {
+  return PACKED ? reinterpret_cast<const float4*>(base)[i].z : (A.stride > 2 ? base[(size_t)i * A.stride + 2] : 0.f);
+}
 template <bool PACKED>
 __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
   __shared__ int scratch[FILT_EBLOCK / 64];
   const int scan = blockIdx.x, tid = threadIdx.x;
   const float* base = A.raw + (size_t)scan * A.n_az * A.n_bins * A.stride;
   const RowRec* rows = A.rows + (size_t)scan * A.n_az;
-  // consecutive azimuths must differ by more than the reference's 1e-4 rad threshold
   int bad = 0;
-  for (int r = tid; r < A.n_az; r += FILT_EBLOCK) {
-    const RowRec cur = rows[r];
-    if (cur.bad) bad = 1;  // an azimuth change inside a row (k_filter_rows)
-    if (r > 0 && !(fabsf(cur.angle - rows[r - 1].angle) > 0.0001)) bad = 1;
-  }
-  bad = __syncthreads_or(bad);
-
   int n_det = 0, n_out = 0;
   float* out = A.out_pts + (size_t)scan * A.pitch_out * 4;
   float* pol = A.out_polar ? A.out_polar + (size_t)scan * A.pitch_out * 2 : nullptr;
   float* pk = A.peaks ? A.peaks + (size_t)scan * A.n_az * 3 : nullptr;
   // the last azimuth is never flushed (the push happens when the NEXT azimuth starts): its record says "none"
   const int n_rows = A.n_az - 1;
-  for (int r0 = 0; r0 < n_rows; r0 += FILT_EBLOCK) {
+  for (int r0 = 0; r0 < A.n_az; r0 += FILT_EBLOCK) {
     const int r = r0 + tid;
     RowRec rec;
     rec.m = -1;
@@ -182,7 +164,23 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
     rec.kept = 0;
     rec.angle = rec.maxi = rec.peak_range = 0.f;
     rec.bad = 0;
-    if (r < n_rows) rec = rows[r];
+    float4 st[2 * FILT_STAGE];  // the row's staged points, fetched in the same round trip as its record
+#pragma unroll
+    for (int k = 0; k < 2 * FILT_STAGE; ++k) st[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n_rows) {
+      rec = rows[r];
+      const float4* sp = A.stage + ((size_t)scan * A.n_az + r) * (2 * FILT_STAGE);
+#pragma unroll
+      for (int k = 0; k < 2 * FILT_STAGE; ++k)
+        if (pol || !(k & 1)) st[k] = sp[k];
+    }
+    // (the same round trip serves the organisation check: an azimuth change inside a row -- k_filter_rows --, and consecutive
+    // azimuths must differ by more than the reference's 1e-4 rad threshold; the last row's record only takes part here)
+    if (r < A.n_az) {
+      const RowRec cur = r < n_rows ? rec : rows[r];
+      if (cur.bad & 1) bad = 1;
+      if (r > 0 && !(fabsf(cur.angle - rows[r - 1].angle) > 0.0001)) bad = 1;
+    }
     const bool det = rec.m >= 0;
     int tot_det, tot_kept;
     const int det_at = n_det + block_excl_scan<FILT_EBLOCK / 64>(det ? 1 : 0, scratch, &tot_det);
@@ -193,35 +191,43 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
         pk[3 * det_at + 1] = rec.peak_range;
         pk[3 * det_at + 2] = rec.maxi;
       }
-      // the run, eight bins per round trip (the loads of a round are independent; the stores are not)
-      for (long long j0 = rec.closer; j0 <= rec.further; j0 += 8) {
-        float x[8], y[8], in[8], z[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const long long j = j0 + u;
-          x[u] = y[u] = in[u] = z[u] = 0.f;
-          if (j <= rec.further) {
-            fetch<PACKED>(A, base, j, x[u], y[u], in[u]);
-            z[u] = PACKED ? reinterpret_cast<const float4*>(base)[j].z : (A.stride > 2 ? base[(size_t)j * A.stride + 2] : 0.f);
+      auto put = [&](const float4& o, float ang, float dist) {
+        if (out_at < A.pitch_out) {
+          if (A.out_vec) {  // 16-byte aligned output: one store per point
+            reinterpret_cast<float4*>(out)[out_at] = o;
+          } else {
+            float* op = out + (size_t)out_at * 4;
+            op[0] = o.x, op[1] = o.y, op[2] = o.z, op[3] = o.w;
+          }
+          if (pol) {
+            pol[2 * (size_t)out_at + 0] = ang;
+            pol[2 * (size_t)out_at + 1] = dist;
           }
         }
+        ++out_at;
+      };
+      if (rec.bad & 2) {
+        // the row kernel left the run's kept points ready-made
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          float dist;
-          if (j0 + u <= rec.further && keep_point(A, x[u], y[u], in[u], dist)) {
-            if (out_at < A.pitch_out) {
-              float* o = out + (size_t)out_at * 4;
-              // pcl::transformPointCloud with initial_transform_radar_baselink_ (:124)
-              o[0] = ((A.T[0] * x[u] + A.T[1] * y[u]) + A.T[2] * z[u]) + A.T[3];
-              o[1] = ((A.T[4] * x[u] + A.T[5] * y[u]) + A.T[6] * z[u]) + A.T[7];
-              o[2] = ((A.T[8] * x[u] + A.T[9] * y[u]) + A.T[10] * z[u]) + A.T[11];
-              o[3] = in[u];
-              if (pol) {
-                pol[2 * (size_t)out_at + 0] = atan2f(y[u], x[u]);
-                pol[2 * (size_t)out_at + 1] = dist;
-              }
+        for (int k = 0; k < FILT_STAGE; ++k)
+          if (k < rec.kept) put(st[2 * k], st[2 * k + 1].x, st[2 * k + 1].y);
+      } else {
+        // the run, eight bins per round trip (the loads of a round are independent; the stores are not)
+        for (long long j0 = rec.closer; j0 <= rec.further; j0 += 8) {
+          float x[8], y[8], in[8], z[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const long long j = j0 + u;
+            x[u] = y[u] = in[u] = z[u] = 0.f;
+            if (j <= rec.further) {
+              fetch<PACKED>(A, base, j, x[u], y[u], in[u]);
+              z[u] = fetch_z<PACKED>(A, base, j);
             }
-            ++out_at;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            float dist;
+            if (j0 + u <= rec.further && keep_point(A, x[u], y[u], in[u], dist)) put(to_base(A, x[u], y[u], z[u], in[u]), pol ? atan2f(y[u], x[u]) : 0.f, dist);
           }
         }
       }
@@ -229,6 +235,7 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
     n_det += tot_det;
     n_out += tot_kept;
   }
+  bad = __syncthreads_or(bad);
   if (tid == 0) {
     A.out_counts[scan] = n_out <= A.pitch_out ? n_out : A.pitch_out;
     if (A.peak_counts) A.peak_counts[scan] = n_det;
@@ -236,174 +243,221 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
   }
 }
 
-// Four wavefronts per SIMD (<= 128 registers; the compiler would take 145 and drop to three): 79 -> 72 us per 16 scans.
+// The run expansion (:80-108) in direction DIR = -1 (towards the sensor) / +1 (away from it): the first d >= 0 at which
+//   (m + DIR (d + 1) leaves the cloud)  or  hypot(a) - hypot(b) > thr  or  I(a) <= I(b)  or  hypot(a) < min_range
+// with a = m + DIR d, b = a + DIR; the run ends at that a.  Sequential in the reference; here both directions in ONE
+// wavefront: lanes 0..31 walk inwards, lanes 32..63 outwards, 32 values of d per step and direction, one lane per bin
+// evaluates the stopping rule and the lowest stopping lane of a half ends its walk (lanes beyond it evaluate bins the
+// reference never touches: discarded); the loads of both directions share a round trip (runs are a handful of bins: 2
+// kept points per azimuth in the Oxford-shaped scans).
+// kept: how many bins of the walked parts (d = 0 .. stop inwards, d = 1 .. stop outwards, so that the detection itself
+// is counted once) pass the output thresholds (:110-118) -- the same loads serve both questions.
+template <bool PACKED>
+__device__ __forceinline__ bool expand_both(const FilterArgs& A, const float* base, long long n, long long m, int lane, long long& closer, long long& further,
+                                            int& kept, float& range_m, float4* stage) {
+  const int half = lane >> 5, l = lane & 31;
+  const long long dir = half ? 1 : -1;
+  bool done_c = false, done_f = false, staged = false;
+  closer = further = m;
+  kept = 0;
+  range_m = 0.f;
+  for (long long d0 = 0; !(done_c && done_f); d0 += 32) {
+    const long long a = m + dir * (d0 + l), b = a + dir;
+    const bool live = half ? !done_f : !done_c;
+    const bool a_in = live && a >= 0 && a <= n - 1, b_in = b >= 0 && b <= n - 1;
+    bool stop = true, keep = false;
+    float ha = 0.f, ax = 0.f, ay = 0.f, ai = 0.f;
+    if (a_in) {
+      float bx = 0.f, by = 0.f, bi = 0.f;
+      fetch<PACKED>(A, base, a, ax, ay, ai);
+      if (b_in) fetch<PACKED>(A, base, b, bx, by, bi);
+      keep = keep_point(A, ax, ay, ai, ha) && (half == 0 || d0 + l > 0);  // the detection itself is counted once (inward half)
+      if (b_in) stop = ((double)(ha - hypot_f(bx, by)) > (double)A.thr) || (ai <= bi) || ((double)ha < (double)A.min_d);
+    }
+    if (d0 == 0) range_m = __shfl(ha, 0, 64);  // hypot of the detection: the per-azimuth peak record
+    const unsigned long long mask = __ballot(stop), kmask = __ballot(keep);
+    const unsigned int mc = (unsigned int)mask, mf = (unsigned int)(mask >> 32), kc = (unsigned int)kmask, kf = (unsigned int)(kmask >> 32);
+    unsigned int vc = 0, vf = 0;  // the kept bins of this step that belong to the run
+    if (!done_c) {
+      if (mc) {
+        const int first = __ffs((int)mc) - 1;
+        vc = kc & (first == 31 ? ~0u : ((1u << (first + 1)) - 1u));
+        closer = m - (d0 + first);
+        done_c = true;
+      } else {
+        vc = kc;
+      }
+    }
+    if (!done_f) {
+      if (mf) {
+        const int first = __ffs((int)mf) - 1;
+        vf = kf & (first == 31 ? ~0u : ((1u << (first + 1)) - 1u));
+        further = m + (d0 + first);
+        done_f = true;
+      } else {
+        vf = kf;
+      }
+    }
+    kept += __popc(vc) + __popc(vf);
+    // A run that ends within the first step on both sides (nearly all do) and keeps <= FILT_STAGE points hands them to the
+    // emission ready-made, in cloud order (inward lanes: higher lane = lower index): the emission then has no second,
+    // dependent look at the raw scan.  Same expressions as the emission's own path (to_base, atan2f, keep_point's range).
+    if (d0 == 0 && done_c && done_f && stage && kept <= FILT_STAGE) {
+      staged = true;
+      const bool mine = half ? ((vf >> l) & 1u) : ((vc >> l) & 1u);
+      if (mine) {
+        const int rank = half ? __popc(vc) + __popc(vf & ((1u << l) - 1u)) : __popc(l == 31 ? 0u : (vc >> (l + 1)));
+        stage[2 * rank] = to_base(A, ax, ay, fetch_z<PACKED>(A, base, a), ai);
+        if (A.out_polar) stage[2 * rank + 1] = make_float4(atan2f(ay, ax), ha, 0.f, 0.f);
+      }
+    }
+  }
+  return staged;
+}
+
+// One WAVEFRONT per azimuth row, no barrier and no LDS: the 16 wavefronts of a CU run free of each other, each streams its
+// row through a ring of FILT_UNROLL loads (12 KB in flight per wavefront, 192 KB per CU), keeps the arg-max in registers
+// and expands the run itself (history and measurements: top of the file).
 #ifndef FILT_WPE
 #define FILT_WPE 4
 #endif
 #define FILT_OCC __attribute__((amdgpu_waves_per_eu(FILT_WPE, FILT_WPE)))
-template <bool PACKED>
+// I3: the intensity is the fourth float of a packed record (x y z I, the reference's PointXYZI) -- known at compile time so
+// that the streaming loop has no branch on ioff
+template <bool PACKED, bool I3>
 __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs A) {
-  __shared__ float s_i[2][FILT_WAVES];
-  __shared__ int s_idx[2][FILT_WAVES];
-  __shared__ int s_bad[2][FILT_WAVES];
-  __shared__ long long s_run[2][2];  // closer, further (double-buffered: one barrier per use)
-  __shared__ int s_kept[2][2];
-  __shared__ float s_range[2];
-  const int scan = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63;
+  // scan * n_az + row, in a scalar register (everything derived from it -- row base, trip counts -- stays scalar)
+  const long long g = (long long)blockIdx.x * FILT_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (g >= (long long)A.n_scans * A.n_az) return;
+  const int scan = (int)(g / A.n_az), row = (int)(g - (long long)scan * A.n_az);
   const float* base = A.raw + (size_t)scan * A.n_az * A.n_bins * A.stride;
-  const long long n = (long long)A.n_az * A.n_bins;
-  // packed rows of up to FILT_UNROLL * 256 bins: the whole row in flight at once, the next row behind it
-  const bool one_shot = PACKED && A.n_bins <= FILT_UNROLL * FILT_BLOCK;
-  int par = 0;
+  const long long n = (long long)A.n_az * A.n_bins, r0 = (long long)row * A.n_bins;
 
-  // all loads of a row (one_shot): FILT_UNROLL per lane, no control flow between them (bins past the end of the row
-  // re-read its last bin and are skipped when the row is visited)
-  auto issue = [&](int row, float4* pt) {
-    const float4* rp = reinterpret_cast<const float4*>(base) + (long long)row * A.n_bins;
+  float best_i = 0.f;  // max_intensity starts at 0: only intensity > 0 can win
+  int best_idx = 0x7fffffff;
+  int bad = 0;
+  // the row's first point (lane 0 of the first chunk): its angle is the reference's current_angle for this azimuth
+  float x0 = 0.f, y0 = 0.f, a0 = 0.f;
+  bool near_cut = false;
+  // The kernel must stay on the HBM roofline, so the two per-point tests are restated without transcendental
+  // work: (a) range: hypot() in float after a double sqrt is monotone in d2 = x^2 + y^2, so the launcher
+  // bisects the two double thresholds once; (b) organisation: a point whose direction is within 4e-5 rad of
+  // the row's first point (|cross| <= 4e-5 dot) cannot differ from it by 1e-4 in atan2f; only other points
+  // (none in an organised scan) and rows next to the +-pi cut take the exact atan2f comparison.
+  // The streaming loop only FLAGS such points; a flagged row is walked a second time with the exact test (below).
+  bool suspect = false;
+  auto visit = [&](int b, float px, float py, float pin) {
+    const float cross = x0 * py - y0 * px, dot = x0 * px + y0 * py;
+    suspect |= !(fabsf(cross) <= 4e-5f * dot);
+    const double d2 = (double)px * (double)px + (double)py * (double)py;
+    if (d2 >= A.lo2 && d2 <= A.hi2) {
+      if (pin > best_i) {  // a lane meets its bins in increasing order: strict '>' keeps the first
+        best_i = pin;
+        best_idx = b;
+      }
+    }
+  };
+  // The row as a sequence of 64-bin loads (one record per lane), FILT_UNROLL of them in flight as a ring: a slot is
+  // re-issued for the load FILT_UNROLL further on as soon as its point has been visited, so the wavefront never drains
+  // between the start and the end of its row (loads return in order: the wait for slot u is vmcnt(FILT_UNROLL - 1)).
+  const int n_loads = (A.n_bins + 63) >> 6;
+  const unsigned rec = PACKED ? 16u : 4u * (unsigned)A.stride;          // bytes per point
+  const char* rb = reinterpret_cast<const char*>(base + r0 * A.stride);  // uniform; lane offsets within a row fit 32 bits
+  float4 pt[FILT_UNROLL];
+  auto issue = [&](int u, int l) {  // bins past the end of the row re-read its last bin and are skipped when visited
+    const int b0 = l * 64 + lane;
+    const unsigned off = (unsigned)(b0 < A.n_bins ? b0 : A.n_bins - 1) * rec;
+    if (PACKED) {
+      pt[u] = *reinterpret_cast<const float4*>(rb + off);
+    } else {
+      const float* p = reinterpret_cast<const float*>(rb + off);
+      pt[u].x = p[0];
+      pt[u].y = p[1];
+      pt[u].w = p[A.ioff];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < FILT_UNROLL; ++u) issue(u, u);
+  x0 = __shfl(pt[0].x, 0, 64);  // the row's first point
+  y0 = __shfl(pt[0].y, 0, 64);
+  a0 = atan2f(y0, x0);
+  near_cut = !(fabsf(a0) < 3.14f);
+  auto visit_slot = [&](int u, int l, bool whole) {  // whole: all 64 bins of the load are inside the row
+    const int b = l * 64 + lane;
+    if (PACKED) asm volatile("" ::"v"(pt[u].z));  // keeps the record ONE dwordx4 load (z is not needed here: the compiler would split it in two)
+    if (whole || b < A.n_bins) visit(b, pt[u].x, pt[u].y, (!PACKED || I3) ? pt[u].w : (A.ioff == 2 ? pt[u].z : pt[u].x));
+  };
+  // steady state: no branch around a load (the compiler's wait counts stay exact: vmcnt(FILT_UNROLL - 1) per slot); the
+  // re-issues of the last of these rounds may run past the row (clamped, <= FILT_UNROLL - 1 loads of one cached record)
+  int l0 = 0;
+  for (; l0 + FILT_UNROLL < n_loads; l0 += FILT_UNROLL) {
 #pragma unroll
     for (int u = 0; u < FILT_UNROLL; ++u) {
-      const int b = tid + u * FILT_BLOCK;
-      pt[u] = rp[b < A.n_bins ? b : A.n_bins - 1];
+      visit_slot(u, l0 + u, true);  // l0 + u < n_loads - FILT_UNROLL: not the row's last load
+      issue(u, l0 + u + FILT_UNROLL);
     }
-  };
-  // everything else of a row; pt: the row's points if one_shot (else the row is streamed here)
-  auto finish = [&](int row, const float4* pt) {
-    const long long r0 = (long long)row * A.n_bins;
-    float best_i = 0.f;  // max_intensity starts at 0: only intensity > 0 can win
-    int best_idx = 0x7fffffff;
-    int bad = 0;
-    // angle of the row's first point = the reference's current_angle for this azimuth
-    float x0, y0, i0;
-    fetch<PACKED>(A, base, r0, x0, y0, i0);
-    const float a0 = atan2f(y0, x0);
-    // The kernel must stay on the HBM roofline, so the two per-point tests are restated without transcendental
-    // work: (a) range: hypot() in float after a double sqrt is monotone in d2 = x^2 + y^2, so the launcher
-    // bisects the two double thresholds once; (b) organisation: a point whose direction is within 4e-5 rad of
-    // the row's first point (|cross| <= 4e-5 dot) cannot differ from it by 1e-4 in atan2f; only other points
-    // (none in an organised scan) and rows next to the +-pi cut take the exact atan2f comparison.
-    const bool near_cut = !(fabsf(a0) < 3.14f);
-    auto visit = [&](int b, float px, float py, float pin) {
-      const float cross = x0 * py - y0 * px, dot = x0 * px + y0 * py;
-      if (near_cut || !(fabsf(cross) <= 4e-5f * dot)) {
-        const float ang = atan2f(py, px);
-        if (fabsf(ang - a0) > 0.0001) bad = 1;  // an azimuth change inside the row
-      }
-      const double d2 = (double)px * (double)px + (double)py * (double)py;
-      if (d2 >= A.lo2 && d2 <= A.hi2) {
-        if (pin > best_i || (pin == best_i && pin > 0.f && b < best_idx)) {
-          best_i = pin;
-          best_idx = b;
-        }
-      }
-    };
-    if (one_shot) {
+  }
 #pragma unroll
-      for (int u = 0; u < FILT_UNROLL; ++u) {
-        const int b = tid + u * FILT_BLOCK;
-        if (b < A.n_bins) visit(b, pt[u].x, pt[u].y, A.ioff == 3 ? pt[u].w : (A.ioff == 2 ? pt[u].z : pt[u].x));
+  for (int u = 0; u < FILT_UNROLL; ++u) visit_slot(u, l0 + u, false);  // the last round: nothing left to issue
+  if (__ballot(suspect || near_cut)) {
+    // the exact organisation test (rare: the row at the +-pi cut, and clouds that are not organised azimuth after azimuth):
+    // the row once more, eight loads in flight
+    for (int l0 = 0; l0 < n_loads; l0 += 8) {
+      float qx[8], qy[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b0 = (l0 + u) * 64 + lane;
+        const float* q = reinterpret_cast<const float*>(rb + (unsigned)(b0 < A.n_bins ? b0 : A.n_bins - 1) * rec);
+        qx[u] = q[0];
+        qy[u] = q[1];
       }
-    } else {
-      for (int b0 = tid; b0 < A.n_bins; b0 += 4 * FILT_BLOCK) {
-        float lx[4], ly[4], li[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int b = b0 + u * FILT_BLOCK;
-          lx[u] = ly[u] = li[u] = 0.f;
-          if (b < A.n_bins) fetch<PACKED>(A, base, r0 + b, lx[u], ly[u], li[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int b = b0 + u * FILT_BLOCK;
-          if (b < A.n_bins) visit(b, lx[u], ly[u], li[u]);
+      for (int u = 0; u < 8; ++u) {
+        const float cross = x0 * qy[u] - y0 * qx[u], dot = x0 * qx[u] + y0 * qy[u];
+        if ((l0 + u) * 64 + lane < A.n_bins && (near_cut || !(fabsf(cross) <= 4e-5f * dot))) {
+          const float ang = atan2f(qy[u], qx[u]);
+          if (fabsf(ang - a0) > 0.0001) bad = 1;  // an azimuth change inside the row
         }
       }
     }
-    // wave arg-max: larger intensity wins, ties -> smaller index
+  }
+  // arg-max over the wavefront: larger intensity wins, ties -> smaller index (strict '>', first index wins)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float oi = __shfl_xor(best_i, off, 64);
-      const int ox = __shfl_xor(best_idx, off, 64);
-      if (oi > best_i || (oi == best_i && ox < best_idx)) {
-        best_i = oi;
-        best_idx = ox;
-      }
-      bad |= __shfl_xor(bad, off, 64);
+  for (int off = 32; off > 0; off >>= 1) {
+    const float oi = __shfl_xor(best_i, off, 64);
+    const int ox = __shfl_xor(best_idx, off, 64);
+    if (oi > best_i || (oi == best_i && ox < best_idx)) {
+      best_i = oi;
+      best_idx = ox;
     }
-    if (lane == 0) {
-      s_i[par][wave] = best_i;
-      s_idx[par][wave] = best_idx;
-      s_bad[par][wave] = bad;
-    }
-    __syncthreads();
-    best_i = s_i[par][0];  // every thread: the same combine in the same order
-    best_idx = s_idx[par][0];
-    bad = s_bad[par][0];
-#pragma unroll
-    for (int w = 1; w < FILT_WAVES; ++w) {
-      if (s_i[par][w] > best_i || (s_i[par][w] == best_i && s_idx[par][w] < best_idx)) {
-        best_i = s_i[par][w];
-        best_idx = s_idx[par][w];
-      }
-      bad |= s_bad[par][w];
-    }
-    // the row's detection; quirk: the first boundary pushes current_max_idx = 0 even if azimuth 0 had no valid return;
-    // the last azimuth is never flushed
-    long long m = (best_i > 0.f && best_idx != 0x7fffffff) ? r0 + best_idx : -1;
-    float pk_i = best_i;
-    if (row == 0 && m < 0) {
-      m = 0;
-      pk_i = 0.f;
-    }
-    if (row == A.n_az - 1) m = -1;
-    long long closer = 0, further = -1;
-    int kept = 0;
-    float range_m = 0.f;
-    if (m >= 0) {  // uniform over the workgroup
-      if (wave == 0) {
-        int kc = 0;
-        long long c = 0;
-        float rm = 0.f;
-        c = expand_run<-1, PACKED>(A, base, n, m, lane, kc, &rm);  // (+ the detection's range for the peak record: lane 0's hypot)
-        if (lane == 0) {
-          s_run[par][0] = c;
-          s_kept[par][0] = kc;
-          s_range[par] = rm;
-        }
-      } else if (wave == 1) {
-        int kf = 0;
-        long long f = 0;
-        f = expand_run<+1, PACKED>(A, base, n, m, lane, kf);
-        if (lane == 0) {
-          s_run[par][1] = f;
-          s_kept[par][1] = kf;
-        }
-      }
-      __syncthreads();
-      closer = s_run[par][0];
-      further = s_run[par][1];
-      kept = s_kept[par][0] + s_kept[par][1];
-      range_m = s_range[par];
-    }
-    if (tid == 0) {
-      RowRec rec;
-      rec.m = (int32_t)m;
-      rec.closer = (int32_t)closer;
-      rec.further = (int32_t)further;
-      rec.kept = kept;
-      rec.angle = a0;
-      rec.maxi = pk_i;
-      rec.peak_range = range_m;
-      rec.bad = bad;
-      A.rows[(size_t)scan * A.n_az + row] = rec;
-    }
-    par ^= 1;  // the next row's exchange goes through the other half of the LDS buffers
-  };
-
-  float4 pa[FILT_UNROLL];
-  const int G = gridDim.x;
-  for (int row = blockIdx.x; row < A.n_az; row += G) {
-    if (one_shot) issue(row, pa);
-    finish(row, pa);
+    bad |= __shfl_xor(bad, off, 64);
+  }
+  // the row's detection; quirk: the first boundary pushes current_max_idx = 0 even if azimuth 0 had no valid return;
+  // the last azimuth is never flushed
+  long long m = (best_i > 0.f && best_idx != 0x7fffffff) ? r0 + best_idx : -1;
+  float pk_i = best_i;
+  if (row == 0 && m < 0) {
+    m = 0;
+    pk_i = 0.f;
+  }
+  if (row == A.n_az - 1) m = -1;
+  long long closer = 0, further = -1;
+  int kept = 0;
+  float range_m = 0.f;
+  bool staged = false;
+  if (m >= 0) staged = expand_both<PACKED>(A, base, n, m, lane, closer, further, kept, range_m, A.stage + (size_t)g * (2 * FILT_STAGE));  // uniform over the wavefront
+  if (lane == 0) {
+    RowRec rec;
+    rec.m = (int32_t)m;
+    rec.closer = (int32_t)closer;
+    rec.further = (int32_t)further;
+    rec.kept = kept;
+    rec.angle = a0;
+    rec.maxi = pk_i;
+    rec.peak_range = range_m;
+    rec.bad = (bad ? 1 : 0) | (staged ? 2 : 0);
+    A.rows[g] = rec;
   }
 }
 
@@ -435,6 +489,7 @@ int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az
                        float* d_peaks, int32_t* d_peak_counts, int32_t* d_status, void* d_scratch) {
   FilterArgs A;
   A.raw = d_raw;
+  A.n_scans = n_scans;
   A.n_az = n_az;
   A.n_bins = n_bins;
   A.stride = stride;
@@ -458,33 +513,19 @@ int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az
   A.peak_counts = d_peak_counts;
   A.status = d_status;
   A.pitch_out = pitch_out;
-  A.rows = (RowRec*)d_scratch;
-  // Row workgroups per scan: one per row as long as all of them are resident at once; beyond that as many as the chip
-  // holds (occupancy x CUs), each walking several rows with its next row's loads already in flight.
-  int per_scan = n_az;
-  {
-    static int resident_of[64] = {0};  // resident workgroups per device (a process may hold contexts on several GPUs)
-    int& resident = resident_of[ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0];
-    if (resident == 0) {
-      int per_cu = 0, cus = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_filter_rows<true>, FILT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
-      resident = per_cu * cus;
-    }
-    const long long total = (long long)n_scans * n_az;
-    if (total > resident) {
-      const int rows_per_wg = (int)((total + resident - 1) / resident);
-      per_scan = (n_az + rows_per_wg - 1) / rows_per_wg;
-    }
-#ifdef FILT_ROWS_PER_WG
-    per_scan = (n_az + FILT_ROWS_PER_WG - 1) / FILT_ROWS_PER_WG;
-#endif
-  }
-  if (stride == 4) {
-    hipLaunchKernelGGL(k_filter_rows<true>, dim3(per_scan, n_scans), dim3(FILT_BLOCK), 0, ctx->stream, A);
+  A.out_vec = ((uintptr_t)d_out_pts & 15) == 0;
+  A.rows = (RowRec*)d_scratch;  // [n_scans * n_az] records, then the stage (api.hip sizes the workspace: FILT_WS_PER_ROW)
+  A.stage = (float4*)((char*)d_scratch + (((size_t)n_scans * n_az * sizeof(RowRec) + 255) & ~(size_t)255));
+  // one wavefront per azimuth row, four rows per workgroup; the dispatcher back-fills the chip as workgroups retire
+  const int row_wgs = (int)(((long long)n_scans * n_az + FILT_WAVES - 1) / FILT_WAVES);
+  if (stride == 4 && ioff == 3) {
+    hipLaunchKernelGGL((k_filter_rows<true, true>), dim3(row_wgs), dim3(FILT_BLOCK), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_filter_emit<true>, dim3(n_scans), dim3(FILT_EBLOCK), 0, ctx->stream, A);
+  } else if (stride == 4) {
+    hipLaunchKernelGGL((k_filter_rows<true, false>), dim3(row_wgs), dim3(FILT_BLOCK), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_filter_emit<true>, dim3(n_scans), dim3(FILT_EBLOCK), 0, ctx->stream, A);
   } else {
-    hipLaunchKernelGGL(k_filter_rows<false>, dim3(per_scan, n_scans), dim3(FILT_BLOCK), 0, ctx->stream, A);
+    hipLaunchKernelGGL((k_filter_rows<false, false>), dim3(row_wgs), dim3(FILT_BLOCK), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_filter_emit<false>, dim3(n_scans), dim3(FILT_EBLOCK), 0, ctx->stream, A);
   }
   RANDT_HIP_CHECK(ctx, hipGetLastError());

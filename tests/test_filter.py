@@ -180,3 +180,90 @@ def test_hip_filter_pcl_stride_and_long_rows(built):
     long_rows = np.stack([small_polar(400 + s, n_az=6, n_bins=3500)[0] for s in range(2)])
     res = _run_hip_filter(ctx, dev, long_rows, host.filter_params(), pitch=8192)
     _check_against_oracle(res, long_rows, po.filter_params())
+
+
+def crafted_runs(seed, n_az=16, n_bins=200):
+    """Rows whose runs take every road through the row kernel's expansion and the emission: a run of ~90 bins (several
+    32-bin steps on both sides), one of 7 kept points (one step, more than the stage holds), short ones (handed over
+    ready-made), one that walks out of its row into the next, a row next to the +-pi cut, z != 0."""
+    rng = np.random.default_rng(seed)
+    az = -np.pi + (np.arange(n_az) + 0.5) * (2 * np.pi / n_az)
+    az[9] = np.pi - 0.0005                                   # exact atan2f test for this row (|angle| >= 3.14)
+    az[10] = -np.pi + 0.02
+    r = (np.arange(n_bins) + 0.5) * 0.16
+    I = rng.uniform(0, 5, (n_az, n_bins))
+
+    def ramp(a, c, half, top):
+        for d in range(-half, half + 1):
+            if 0 <= c + d < n_bins:
+                I[a, c + d] = top - 0.37 * abs(d) + (0.01 if d > 0 else 0.0)   # strictly decreasing away from c, no ties
+    ramp(1, 60, 45, 90.0)
+    ramp(2, 50, 3, 60.0)
+    ramp(3, 40, 1, 50.0)
+    ramp(4, 30, 2, 70.0)
+    for d in range(0, 8):                                    # peak near the end of row 5, still falling over row 6's first bins
+        a, b = divmod(5 * n_bins + 196 + d, n_bins)
+        I[a, b] = 80.0 - 2.0 * d
+    I[5, 190:196] = 80.0 - 2.0 * np.arange(6, 0, -1)
+    ramp(9, 45, 2, 40.0)
+    ramp(10, 45, 1, 40.0)
+    raw = np.zeros((n_az, n_bins, 4), np.float32)
+    raw[..., 0] = r[None] * np.cos(az)[:, None]
+    raw[..., 1] = r[None] * np.sin(az)[:, None]
+    raw[..., 2] = rng.uniform(-0.5, 0.5, (n_az, n_bins))
+    raw[..., 3] = I
+    return raw
+
+
+@pytest.mark.gpu
+def test_hip_filter_run_shapes_stage_and_fallback(built):
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    scans = np.stack([crafted_runs(s) for s in range(3)])
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    T = np.array([[c, -s_, 0.1, 0.3], [s_, c, -0.2, -0.7], [0.05, 0.0, 1.0, 1.5]], dtype=np.float32)
+    kw = dict(min_range=0.6, max_range=40.0, min_intensity=6.0, beam_thr=100.0, sensor_to_base=T)
+    fp, ofp = host.filter_params(**kw), po.filter_params(**kw)
+    res = _run_hip_filter(ctx, dev, scans, fp)
+    _check_against_oracle(res, scans, ofp)
+    cnt0 = int(res[3][0])
+    runs = [po.filter_scan(scans[0].reshape(-1, 4), ofp)[0]]
+    assert cnt0 == runs[0] and cnt0 > 100                     # the long run is in there
+    # polar angles too (atan2f: libm vs ocml)
+    for s in range(len(scans)):
+        cnt, _, pol, _ = po.filter_scan(scans[s].reshape(-1, 4), ofp)
+        assert np.allclose(res[1][s, :cnt, 0], pol[:, 0], atol=1e-6)
+    # default thresholds on the same clouds (runs end at once towards the sensor: 0.16 m per bin > 0.04)
+    res = _run_hip_filter(ctx, dev, scans, host.filter_params(sensor_to_base=T))
+    _check_against_oracle(res, scans, po.filter_params(sensor_to_base=T))
+    # intensity in the third float of the packed record (the other packed instantiation of the row kernel)
+    swapped = scans.copy()
+    swapped[..., 2], swapped[..., 3] = scans[..., 3], scans[..., 2]
+    out, polar, peaks, counts, pcounts, status = _run_hip_filter(ctx, dev, swapped, fp, intensity_index=2)
+    assert status.tolist() == [0] * len(scans)
+    for s in range(len(scans)):
+        cnt, pts, pol, pk = po.filter_scan(swapped[s].reshape(-1, 4), ofp, ioff=2)
+        assert counts[s] == cnt and pcounts[s] == len(pk)
+        assert np.array_equal(out[s, :cnt].view(np.uint32), pts.view(np.uint32)) and np.array_equal(polar[s, :cnt, 1], pol[:, 1])
+    # an output buffer that is not 16-byte aligned, no polar / peak outputs, and one that is too small (status 2, clipped)
+    n_scans, pitch = len(scans), 4096
+    flat = torch.zeros(n_scans * pitch * 4 + 1, dtype=torch.float32, device=dev)
+    out_t = flat[1:].view(n_scans, pitch, 4)
+    counts_t = torch.zeros(n_scans, dtype=torch.int32, device=dev)
+    status_t = torch.zeros(n_scans, dtype=torch.int32, device=dev)
+    d_scans = torch.from_numpy(scans).to(dev)
+    host.filter_scan_batch(ctx, d_scans, fp, out_t, counts_t, status_t)
+    ctx.synchronize()
+    assert status_t.cpu().tolist() == [0] * n_scans
+    for s in range(n_scans):
+        cnt, pts, _, _ = po.filter_scan(scans[s].reshape(-1, 4), ofp)
+        assert counts_t[s].item() == cnt and np.array_equal(out_t[s, :cnt].cpu().numpy().view(np.uint32), pts.view(np.uint32))
+    small = torch.zeros((n_scans, 8, 4), dtype=torch.float32, device=dev)
+    host.filter_scan_batch(ctx, d_scans, fp, small, counts_t, status_t)
+    ctx.synchronize()
+    assert status_t.cpu().tolist() == [2] * n_scans and counts_t.cpu().tolist() == [8] * n_scans
+    for s in range(n_scans):
+        _, pts, _, _ = po.filter_scan(scans[s].reshape(-1, 4), ofp)
+        assert np.array_equal(small[s].cpu().numpy().view(np.uint32), pts[:8].view(np.uint32))
