@@ -455,7 +455,7 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
  * Cholesky along the odometry chain, one lane per right-hand side, dense Schur complement on the poses that
  * loop closures touch (see csrc/posegraph.hip).  The defaults are Ceres' Solver::Options defaults plus
  * max_num_iterations = 200000 (:52). */
-#define RANDT_PG_MAX_SEPARATORS 2048
+#define RANDT_PG_MAX_SEPARATORS 16384  /* the dense Schur complement takes 2 x (3 n)^2 x 8 B of device memory: 39 GB at the limit */
 typedef struct randt_pg_params {
   int32_t use_robust_loss;  /* GlobalFuserParameters::use_robust_loss */
   int32_t max_iterations;
@@ -480,7 +480,8 @@ void randt_pg_params_default(randt_pg_params* p);
  * edge e: h_id_begin/h_id_end, h_meas [E][3] = (trans.translation(), trans.log()(2)), h_sqrt_info [E][9]
  * row-major.  An edge is used iff id_begin + 1 == id_end || id_end <= max_update_index.  Host buffers: the graph
  * lives on the host in the reference and is a few hundred KB.  RANDT_ERR_UNSUPPORTED if more than
- * RANDT_PG_MAX_SEPARATORS poses carry loop closures. */
+ * RANDT_PG_MAX_SEPARATORS poses carry loop closures (2048 until round 4); a device allocation that fails is reported
+ * as the HIP error it is. */
 int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int n_edges, const int32_t* h_id_begin,
                               const int32_t* h_id_end, const double* h_meas, const double* h_sqrt_info,
                               int max_update_index, const randt_pg_params* p, randt_pg_result* out);

@@ -280,3 +280,25 @@ def test_hip_reaches_the_independently_computed_optimum(built):
     # poses are within a millimetre
     xd, rd = host.pose_graph_optimize(ctx, g["x0"], g["id_begin"], g["id_end"], g["meas"], g["sqrt_info"], len(g["x0"]))
     assert rd["termination"] == 1 and np.abs(xd - g["x_opt"]).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_hip_pose_graph_beyond_2048_loop_closure_poses(built):
+    """2600 poses carry loop closures (the separator limit was 2048 until round 4; the dense oracle would need hours): noise-free
+    measurements make the truth a known answer, the first pose stays fixed, and the Schur complement is 7800 x 7800."""
+    import torch
+
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    n = 5200
+    loops = [(2 * i, 2 * i + 2600) for i in range(1300)]                       # 2600 distinct poses
+    truth, _, ia, ib, meas, sq = make_graph(n, loops, seed=31, noise=(0, 0, 0), laps=2.0, radius=80.0)
+    rng = np.random.default_rng(32)
+    x0 = [truth[0].copy()]
+    for i in range(n - 1):
+        x0.append(compose(x0[-1], meas[i] + rng.normal(size=3) * [0.004, 0.004, 0.0004]))   # drifting dead reckoning
+    x0 = np.array(x0)
+    kw = dict(function_tolerance=1e-16, parameter_tolerance=1e-13, gradient_tolerance=1e-13, max_iterations=60)
+    xg, rg = host.pose_graph_optimize(ctx, x0, ia, ib, meas, sq, n, host.pg_params(**kw))
+    assert rg["n_separator_poses"] > 2500 and rg["n_residual_blocks"] == n - 1 + 1300        # (pose 0 is constant, not a separator)
+    assert np.array_equal(xg[0], x0[0])
+    assert np.abs(xg - truth).max() < 1e-6 and rg["final_cost"] < 1e-12 * rg["initial_cost"]
