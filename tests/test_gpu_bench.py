@@ -42,6 +42,8 @@ def test_bench_single_gpu_contract():
     # the line's frac follows from the committed counter summary: cycles per launch / measured launch duration / peak
     assert abs(rf["valu_issue_cycles_per_launch"] / rf["avg_launch_us"] * 1e-3 / rf["peak"] - rf["frac"]) < 1e-12
     assert d["single_batch"]["value"] > 1e5 and d["single_batch"]["batch_latency_us"] > 10
+    pf = d["config5_polar_filter"]                                              # f-1: the one HBM-streaming stage has its own roofline object
+    assert pf["status_ok"] and pf["roofline"]["bound"] == "hbm" and 0.0 < pf["roofline"]["frac"] < 1.0 and pf["roofline"]["algorithmic_bytes"] == 2 * 19200000
     assert d["cpu_baseline"]["single_thread"]["cores"] == 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["pose_err_vs_oracle"]["max_abs_translation_m"] <= 1e-4 and d["pose_err_vs_oracle"]["max_abs_rotation_rad"] <= 1e-4
