@@ -428,9 +428,9 @@ int randt_predict_state(const randt_state* last, double stamp, randt_state* next
  * pose = Sophus::SE2d(rot, pos). */
 int randt_predict_state_param(const randt_state* last, double stamp, int parameterization, randt_state* next);
 /* Matcher::estimateTransformCeres (ndt_matcher.cpp:322-424): fixed-lag smoother over n_states = S+1
- * states (oldest first; its pose is held constant), S <= 7, n_fixed <= 2 (the shipped lag smoothing_steps: 3 runs the kernel
- * tuned for it, window.hip; lags 4..7 -- ndt_matcher.cpp:343 takes any -- the general kernel, window_gen.hip; beyond:
- * RANDT_ERR_UNSUPPORTED).  Per state j = 1..S: MotionModelFactorSE2 to
+ * states (oldest first; its pose is held constant), S <= 12, n_fixed <= 2 (the shipped lag smoothing_steps: 3 runs the kernel
+ * tuned for it, window.hip; lags 4..7 -- ndt_matcher.cpp:343 takes any -- the general kernel, window_gen.hip; 8..12 the same
+ * source compiled for the longer band, window_gen_big.hip; beyond: RANDT_ERR_UNSUPPORTED).  Per state j = 1..S: MotionModelFactorSE2 to
  * its predecessor (ceres_residuals.h:621-679), optional RotationalResidualSE2 (:338-370, h_imu[j-1]),
  * and NDT factors of moving map moving_idx[j-1] against every fixed map (association at the state's
  * own pose), robustified by Scaled(Barron) with weight ndt_weight / (n_cells * k); GNC loop as in the

@@ -802,7 +802,7 @@ double orc_ndt_residual(int d, int parameterization, const double* pose4, const 
 
 /* ============================================================ generic LM (Ceres 2.1.0) ==== */
 
-#define ORC_MAX_TANGENT 72
+#define ORC_MAX_TANGENT 160 /* windows of up to 15 optimised states: 9 S + 5 tangent dimensions */
 
 typedef struct orc_problem {
   int n_ambient, n_tangent, n_res;
@@ -1667,7 +1667,7 @@ typedef struct win_user {
   int analytic;                 /* ... with the reference's hand-written NDT Jacobian (use_analytic_expressions_for_optimization) */
   int S, F, d, k;               /* states 0..S (0 = oldest, pose constant), fixed maps */
   int const_vel, use_imu;
-  orc_state base[8];            /* constant parts (stamps, oldest pose, constant blocks) */
+  orc_state base[16];           /* constant parts (stamps, oldest pose, constant blocks) */
   const double* imu;
   const double* sqrtI;
   double weight_imu, weight_imu_bias;
@@ -1678,7 +1678,7 @@ typedef struct win_user {
   int apply_loss;
   double loss_a, loss_alpha, loss_mu, loss_w;
   /* layout */
-  int off_amb[8][5], off_tan[8][5]; /* block offsets per state: pose, v, w, a, b ; -1 = constant */
+  int off_amb[16][5], off_tan[16][5]; /* block offsets per state: pose, v, w, a, b ; -1 = constant */
   int n_amb, n_tan, n_res;
 } win_user;
 
@@ -1761,7 +1761,7 @@ static void win_scatter(const win_user* u, double* row, int j, int blk, const do
  * i.e. oldest pair first: motion(j-1,j), [imu(j-1,j)], NDT(j, f = 0..F-1). */
 static int win_eval(void* user, const double* x, double* cost, double* residuals, double* jac) {
   win_user* u = (win_user*)user;
-  orc_state st[8];
+  orc_state st[16];
   win_unpack(u, x, st);
   const int nt = u->n_tan;
   double total = 0;
@@ -1858,7 +1858,7 @@ int orc_register_window(orc_map* const* fixed, int n_fixed, orc_map* const* movi
                         const double* imu, const orc_matcher_params* p, const orc_window_params* wp, double trans4[4],
                         orc_solve_stats* st) {
   const int S = n_states - 1;
-  if (S < 1 || S > 7 || n_fixed < 1) return -1;
+  if (S < 1 || S > 15 || n_fixed < 1) return -1; /* (the arrays above; the reference takes any lag, ndt_matcher.cpp:343) */
   orc_solve_stats local;
   if (!st) st = &local;
   memset(st, 0, sizeof(*st));

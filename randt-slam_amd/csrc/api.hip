@@ -1359,7 +1359,7 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   if (!ctx || !fixed || !moving || !h_fixed_idx || !h_moving_idx || !h_states || !mp || !wp || !h_trans4) return RANDT_ERR_INVALID;
   const int S = n_states - 1;
   if (S < 1 || S > RANDT_WIN_MAX_STATES - 1 || n_fixed < 1 || n_fixed > 2)
-    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..7 optimised states, 1..2 fixed maps", hipSuccess);
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..12 optimised states, 1..2 fixed maps", hipSuccess);
   if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_VECTOR && mp->parameterization != RANDT_PARAM_ANALYTIC)
     return randt_set_error(ctx, RANDT_ERR_INVALID, "window solve: parameterization must be RANDT_PARAM_MANIFOLD, _VECTOR or _ANALYTIC", hipSuccess);
   const bool vec = mp->parameterization != RANDT_PARAM_MANIFOLD;
@@ -1430,10 +1430,10 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   const size_t span = off_desc + sizeof(WinDesc) - off_states;
   int rc = ensure_ws(ctx, off_desc + sizeof(WinDesc) + 64);
   if (rc) return rc;
-  if (!ctx->h_pin) RANDT_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pin, 8192, hipHostMallocDefault));
-  if (span > 4096) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window staging image too large", hipSuccess);
+  if (!ctx->h_pin) RANDT_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pin, 16384, hipHostMallocDefault));
+  if (span > 8192) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window staging image too large", hipSuccess);
   char* ws = (char*)ctx->ws;
-  char* img = (char*)ctx->h_pin;           // upload image; the download lands at img + 4096
+  char* img = (char*)ctx->h_pin;           // upload image; the download lands at img + 8192
   memset(img, 0, span);
   double* h_packed = reinterpret_cast<double*>(img);
   for (int j = 0; j <= S; ++j) {  // 12 doubles per state (window.hip, ST_STRIDE)
@@ -1460,7 +1460,7 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   rc = launch_solve_window(ctx, fixed->v, moving->v, W, (const WinDesc*)(ws + off_desc), (const int32_t*)ws, mp, (double*)(ws + off_states), (randt_result*)(ws + off_res));
   if (rc) return rc;
   randt_result r;
-  char* back = img + 4096;
+  char* back = img + 8192;
   const size_t back_span = off_res + sizeof(randt_result) - off_states;
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(back, ws + off_states, back_span, hipMemcpyDeviceToHost, ctx->stream));
   RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -33,7 +33,7 @@ struct randt_ctx {
   // scratch (grown on demand, never inside a timed region after warm-up)
   void* ws = nullptr;
   size_t ws_bytes = 0;
-  void* h_pin = nullptr;     // 8 KB of pinned host memory: staging image of the synchronous host-level entries (one copy per direction)
+  void* h_pin = nullptr;     // 16 KB of pinned host memory: staging image of the synchronous host-level entries (one copy per direction)
   void* small = nullptr;     // 4 KB of device scratch for the synchronous host-level conveniences (lazily allocated)
   void* build_ws = nullptr;  // label scratch of k_ndt_build's fallback sort (its own buffer: callers stage points in ws)
   size_t build_ws_bytes = 0;
@@ -123,8 +123,8 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
                      int use_intensity, int32_t* d_corr, const int32_t* d_moving_idx = nullptr);
 
 // fixed-lag window problem description (kernel argument, by value)
-#define RANDT_WIN_MAX_STATES 8   // window_gen.hip: <= 7 optimised states + the constant one (window.hip takes <= 3 + 1)
-#define RANDT_WIN_MAX_TERMS 14   // (state, fixed map) NDT terms: 7 states x 2 fixed maps
+#define RANDT_WIN_MAX_STATES 13  // <= 12 optimised states + the constant one (window.hip takes <= 3 + 1, window_gen.hip 4..7, window_gen_big.hip 8..12)
+#define RANDT_WIN_MAX_TERMS 24   // (state, fixed map) NDT terms: 12 states x 2 fixed maps
 struct WinDesc {
   int S, n_terms, n_tan, n_amb, use_imu, const_vel, k, d3;
   int vec, pad_;  // vec: (pos[2], rot) parameter blocks instead of the SE(2) manifold (optimize_on_manifold: false); pad_: 1 = RANDT_PARAM_ANALYTIC
@@ -138,9 +138,12 @@ struct WinDesc {
 int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
                         const int32_t* d_corr, const randt_matcher_params* mp, double* d_states /* (S+1) x 10 */,
                         randt_result* d_result);
-// window_gen.hip: the general kernel (4..7 optimised states); launch_solve_window routes to it
+// window_gen.hip: the general kernel (4..7 optimised states); launch_solve_window routes to it, and it routes 8..12 states to
+// the second compilation of the same source (window_gen_big.hip)
 int launch_solve_window_gen(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
                             const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result);
+int launch_solve_window_gen_big(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
+                                const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result);
 int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
                  int moving_first, int n_pairs, const int32_t* d_corr, const randt_matcher_params* mp,
                  double* d_pose4, randt_result* d_results);

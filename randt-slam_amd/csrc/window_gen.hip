@@ -31,12 +31,21 @@
 #define GEN_WAVES 8
 #define GEN_NDT_WAVES 7
 #define GEN_FACTOR_WAVE 7
+// The sizes below are this translation unit's; window_gen_big.hip compiles the same source a second time for 8..12
+// optimised states (GEN_LEVELS 1: the rejection chain's radii are then solved one after the other -- the LDS that the
+// six workspaces of the 4..7 instantiation take goes into the longer band).
+#ifndef GEN_SMAX
 #define GEN_SMAX 7
 #define GEN_NMAX 72
 #define GEN_TMAX 14
+#define GEN_LEVELS 6
+#define GEN_LAUNCHER launch_solve_window_gen
+#define GEN_LIMIT_TEXT "window too large for the device solver (<= 7 optimised states, <= 2 fixed maps)"
+#endif
 #define GEN_HB 17                 // half bandwidth: columns of two adjacent 9-dimensional state blocks are at most 17 apart
 #define GEN_BW (2 * GEN_HB + 1)   // stored band: column b of row a at [a][b - a + GEN_HB]
-#define GEN_LEVELS 6
+static_assert(GEN_SMAX * 16 + GEN_SMAX * 8 <= GEN_BLOCK && GEN_NMAX <= 128 && GEN_SMAX + 1 <= RANDT_WIN_MAX_STATES && GEN_TMAX <= RANDT_WIN_MAX_TERMS,
+              "thread partitions of gen_weight / gen_assemble and the descriptor's arrays");
 
 namespace {
 using namespace randt_solve;
@@ -203,8 +212,8 @@ __device__ double gen_weight(const WinDesc& W, GShared& sh, int buf) {
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) sh.Ju[buf][f][i * 16 + c] = out[i];
-  } else if (tid >= 128 && tid < 128 + W.S * 8) {
-    const int f = (tid - 128) >> 3, i = (tid - 128) & 7;
+  } else if (tid >= GEN_SMAX * 16 && tid < GEN_SMAX * 16 + W.S * 8) {
+    const int f = (tid - GEN_SMAX * 16) >> 3, i = (tid - GEN_SMAX * 16) & 7;
     double a = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) a += W.sqrtI[i * 8 + k] * sh.ru[buf][f][k];
@@ -680,11 +689,12 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_solve_window_gen(MapView fixed, M
 
 }  // namespace
 
-int launch_solve_window_gen(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
-                            const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result) {
-  if (desc.n_tan > GEN_NMAX || desc.S > GEN_SMAX || desc.n_terms > GEN_TMAX)
-    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window too large for the device solver (<= 7 optimised states, <= 2 fixed maps)",
-                           hipSuccess);
+int GEN_LAUNCHER(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
+                 const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result) {
+#if GEN_SMAX == 7
+  if (desc.S > GEN_SMAX) return launch_solve_window_gen_big(ctx, fixed, moving, desc, d_desc, d_corr, P, d_states, d_result);
+#endif
+  if (desc.n_tan > GEN_NMAX || desc.S > GEN_SMAX || desc.n_terms > GEN_TMAX) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, GEN_LIMIT_TEXT, hipSuccess);
 #define RANDT_GEN_LAUNCH(DD, AA, NN)                                                                                             \
   hipLaunchKernelGGL((k_solve_window_gen<DD, AA, NN>), dim3(1), dim3(GEN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
                      d_states, d_result, ctx->d_trace, ctx->trace_len)

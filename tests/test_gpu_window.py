@@ -24,7 +24,7 @@ def to_oracle_wp(wp):
     return o
 
 
-def _make_drive(env=None):
+def _make_drive(env=None, n_scans=8):
     import os
 
     import torch
@@ -41,7 +41,7 @@ def _make_drive(env=None):
                 os.environ[k] = v
 
     world = synth.make_world()
-    n_scans, dt = 8, 0.25
+    dt = 0.25
     traj = synth.make_trajectory(3100, n_scans + 34, step=0.25)
     origin_inv = synth.se2_inv3(traj[0])
     rel = np.array([synth.se2_mul3(origin_inv, p) for p in traj])
@@ -81,6 +81,12 @@ def _make_drive(env=None):
 @pytest.fixture(scope="module")
 def drive(built):
     return _make_drive()
+
+
+@pytest.fixture(scope="module")
+def drive_long(built):
+    """Fourteen scans: windows of up to twelve optimised states (window_gen_big.hip)."""
+    return _make_drive(n_scans=14)
 
 
 @pytest.fixture(scope="module")
@@ -190,6 +196,16 @@ def test_window_longer_lags_match_oracle(drive, lag, kw):
     _run_drive(drive, lag=lag, **kw)
 
 
+# ---- smoothing_steps 8..12: the same kernel source compiled for the longer band (window_gen_big.hip; one Cholesky workspace)
+@pytest.mark.parametrize("lag,kw", [
+    (8, dict()),
+    (10, dict(param=R.PARAM_VECTOR, use_imu=1)),
+    (12, dict(n_fixed=2, use_imu=1, const_vel=0)),              # the largest problem: 113 tangent dimensions, 24 NDT terms
+])
+def test_window_lags_of_eight_to_twelve_match_oracle(drive_long, lag, kw):
+    _run_drive(drive_long, lag=lag, **kw)
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(n_fixed=2, use_imu=1, const_vel=0), dict(param=R.PARAM_VECTOR, n_fixed=2)])
 def test_general_window_kernel_on_three_state_windows(drive_general, kw):
     """The general kernel on the windows the tuned kernel normally takes: same oracle, same assertions (decision trace included)."""
@@ -200,10 +216,10 @@ def test_window_lag_beyond_the_device_solver_is_refused(drive):
     ctx = drive["ctx"]
     mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
     st = R.make_state(synth.pose3_to_pose4(drive["truth"][0]), stamp=0.0)
-    states = np.array([st] * 9, dtype=R.STATE_DTYPE)            # 8 optimised states
+    states = np.array([st] * 14, dtype=R.STATE_DTYPE)           # 13 optimised states
     with pytest.raises(R.RandtError) as e:
-        R.register_window(ctx, drive["sub"], [0], drive["smaps"], list(range(8)), states, mp, R.window_params(), st["pose"])
-    assert e.value.status == 3 and "1..7 optimised states" in str(e.value)                 # RANDT_ERR_UNSUPPORTED
+        R.register_window(ctx, drive["sub"], [0], drive["smaps"], [i % 8 for i in range(13)], states, mp, R.window_params(), st["pose"])
+    assert e.value.status == 3 and "1..12 optimised states" in str(e.value)                # RANDT_ERR_UNSUPPORTED
 
 
 def test_window_rejection_gate(drive):

@@ -9,7 +9,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/randt-slam_amd/csrc
 OUT=$ROOT/build/ab/$NAME
 mkdir -p "$OUT"
-ALL="api ndt_build associate solve window window_gen filter csdiv scancontext posegraph cellops ndt_build_big group"
+ALL="api ndt_build associate solve window window_gen window_gen_big filter csdiv scancontext posegraph cellops ndt_build_big group"
 UNITS=${*:-$ALL}
 COMMON="$EXTRA -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$SRC -Wall -Wno-unused-function -Wno-pass-failed"
 pids=()
