@@ -11,7 +11,7 @@ import randt_slam_amd as R  # noqa: E402
 from randt_slam_amd import synth  # noqa: E402
 
 
-def make_drive(env=None):
+def make_drive(env=None, n_scans=8):
     """Device side of the drive fixture in tests/test_gpu_window.py: a submap of 8 keyframes, a sparser second one, 8 scans."""
     import torch
 
@@ -26,7 +26,7 @@ def make_drive(env=None):
             else:
                 os.environ[k] = v
     world = synth.make_world()
-    n_scans, dt = 8, 0.25
+    dt = 0.25
     traj = synth.make_trajectory(3100, n_scans + 34, step=0.25)
     origin_inv = synth.se2_inv3(traj[0])
     rel = np.array([synth.se2_mul3(origin_inv, p) for p in traj])
@@ -76,14 +76,17 @@ def run(drive, lag, n_fixed, use_imu, const_vel, reps=5):
 
 
 if __name__ == "__main__":
-    tuned, general = make_drive(), make_drive({"RANDT_WINDOW_GENERAL": "1"})
+    tuned, general, long_drive = make_drive(), make_drive({"RANDT_WINDOW_GENERAL": "1"}), make_drive(n_scans=14)
     for name, d, lag, kw in [("tuned   lag 3", tuned, 3, dict(n_fixed=1, use_imu=0, const_vel=1)),
                              ("general lag 3", general, 3, dict(n_fixed=1, use_imu=0, const_vel=1)),
                              ("tuned   lag 3 2 fixed imu acc", tuned, 3, dict(n_fixed=2, use_imu=1, const_vel=0)),
                              ("general lag 3 2 fixed imu acc", general, 3, dict(n_fixed=2, use_imu=1, const_vel=0)),
                              ("general lag 5", tuned, 5, dict(n_fixed=1, use_imu=0, const_vel=1)),
                              ("general lag 7", tuned, 7, dict(n_fixed=1, use_imu=0, const_vel=1)),
-                             ("general lag 7 2 fixed imu acc", tuned, 7, dict(n_fixed=2, use_imu=1, const_vel=0))]:
+                             ("general lag 7 2 fixed imu acc", tuned, 7, dict(n_fixed=2, use_imu=1, const_vel=0)),
+                             ("big     lag 8", long_drive, 8, dict(n_fixed=1, use_imu=0, const_vel=1)),      # window_gen_big.hip
+                             ("big     lag 12", long_drive, 12, dict(n_fixed=1, use_imu=0, const_vel=1)),
+                             ("big     lag 12 2 fixed imu acc", long_drive, 12, dict(n_fixed=2, use_imu=1, const_vel=0))]:
         rows = run(d, lag, **kw)
         S, us, it, ev, nr = rows[-1]
         print(f"{name:32s} S={S} {us:8.1f} us/window  iterations={it} passes={ev} residuals={nr}  us/iteration={us / max(it, 1):.2f}")
