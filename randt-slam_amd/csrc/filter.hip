@@ -38,7 +38,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef FILT_BLOCK
 #define FILT_BLOCK 256
+#endif
 #define FILT_WAVES (FILT_BLOCK / 64)
 #define FILT_STAGE 4     // kept points per row that the row kernel hands to the emission ready-made (2 float4 each)
 #define FILT_EBLOCK 512  // emission kernel: all azimuth rows of a 400-row scan in one round
