@@ -157,6 +157,19 @@ int main() {
     report("wave_rows_64scans_per16", 12, 4, g, time_us([&] { hipLaunchKernelGGL((k_wave_rows<12, 4, 0>), dim3(g), dim3(256), 0, 0, d_big, d_out, (int)rows4, 1.0, 1e9); }, reps) / 4);
     report("wave_rows_visit_64scans_per16", 12, 4, g, time_us([&] { hipLaunchKernelGGL((k_wave_rows<12, 4, 1>), dim3(g), dim3(256), 0, 0, d_big, d_out, (int)rows4, 1.0, 1e9); }, reps) / 4);
     report("rows_64scans_per16", 12, 4, 2048, time_us([&] { hipLaunchKernelGGL((k_rows<12, 4>), dim3(2048), dim3(256), 0, 0, d_big, d_out, (int)rows4); }, reps) / 4);
+    // ... and as FOUR launches of 16 scans each over the four quarters of that buffer (what a stream of filter launches over
+    // distinct inputs does): every launch pays its own fill and drain
+    {
+      const int gq = (int)((n_rows + 3) / 4);
+      int turn = 0;
+      report("wave_rows_16scans_rotating_quarters", 12, 4, gq, time_us([&] {
+        hipLaunchKernelGGL((k_wave_rows<12, 4, 0>), dim3(gq), dim3(256), 0, 0, d_big + (size_t)(turn++ & 3) * n, d_out, (int)n_rows, 1.0, 1e9);
+      }, reps));
+      turn = 0;
+      report("wave_rows_visit_16scans_rotating_quarters", 12, 4, gq, time_us([&] {
+        hipLaunchKernelGGL((k_wave_rows<12, 4, 1>), dim3(gq), dim3(256), 0, 0, d_big + (size_t)(turn++ & 3) * n, d_out, (int)n_rows, 1.0, 1e9);
+      }, reps));
+    }
     CHECK(hipFree(d_big));
   }
   {

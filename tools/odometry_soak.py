@@ -22,7 +22,7 @@ for d in (range(n_drives) if os.environ.get('SOAK_DRIVE') is None else [int(os.e
     scans = [synth.make_scan(world, traj[i], 40000 + 1000 * d + i) for i in range(n_scans)]
     small = dict(submap_size_poses=int(rng.choice([24, 40])), submap_overlap=8)
     if os.environ.get("SOAK_LAGS") == "1":   # lags beyond the shipped 3: the general window kernel (window_gen.hip)
-        small["smoothing_steps"] = int(rng.choice([3, 4, 5, 6, 7]))
+        small["smoothing_steps"] = int(rng.choice([3, 4, 5, 6, 7] if os.environ.get("SOAK_LONG_LAGS") != "1" else [8, 9, 10, 11, 12]))   # (8..12: window_gen_big.hip, round 4)
     param = R.PARAM_MANIFOLD if os.environ.get("SOAK_PARAMS") != "1" else int(rng.choice([R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC]))
     # (the harness feeds no gyro increments, so the IMU factor stays off: with use_imu = 1 and all-zero measurements the
     #  problem contradicts itself, costs are ~1e5 and last-bit differences amplify by 1e4 per scan -- chaos, not parity)
