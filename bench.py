@@ -574,6 +574,8 @@ def main():
                  min(3.0, args.cpu_seconds))
             if throughput_mode:
                 ctx.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
+        if world == 1 and args.only is None and not args.no_config2:
+            side("loop_gate_and_search", loop_gate_and_search, R, torch, ctx, submaps, full, mp, weak_prob, not args.no_cpu_baseline, min(2.0, args.cpu_seconds))
         if args.odometry_scans > 0 and world == 1:
             side("config3_streaming_odometry", streaming_odometry, ctx, args.odometry_scans, not args.no_cpu_baseline)
         if args.polar_scans > 0 and world == 1:
@@ -826,6 +828,122 @@ def config2_single_pair(R, torch, ctx, submaps, full, mapp, clu, mp, prob, with_
                              "sample": "NDT build + association + GNC/LM solve of the same pair, repeated for %.0f s per leg" % budget_s,
                              "pose_vs_gpu_max_abs": float(np.abs(np.asarray(p1) - np.asarray(p_a)).max())}
     return out
+
+
+def loop_gate_and_search(R, torch, ctx, submaps, full, mp, prob, with_cpu, budget_s):
+    """SURVEY rows f-2 and f-3 as measurements (the two steps around a loop registration, local_fuser.cpp:329-340, 387-402):
+    (f-2) Map::calculateCSDivergence for the whole config-4 batch -- 512 scans, each against its own submap at its registered
+    pose: one launch, HIP events; beside it the CPU oracle on a bounded sample;
+    (f-3) Matcher::estimateTransformGlobalBNB: the batched cost kernel on 4096 candidate poses of one pair, and one whole
+    search from a pose 1.1 m / 0.1 rad off (host call -> result); the CPU oracle's search beside it."""
+    from randt_slam_amd import host, synth
+
+    dev = full.points.device
+    st = torch.cuda.current_stream()
+    B, n_sub = full.B, submaps.n_maps if hasattr(submaps, "n_maps") else int(prob["submap_of"].max()) + 1
+    scan_maps = full.scan_maps[0]
+    R.ndt_build_batch(ctx, full.points, full.clu, scan_maps)
+    pose = torch.from_numpy(synth.pose3_to_pose4(prob["truth"])).to(dev)
+    out_v = torch.zeros(B, dtype=torch.float64, device=dev)
+    terms = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_cs = []
+    for i in range(25):
+        e0.record(st)
+        host.cs_divergence_batch(ctx, submaps, 0, n_sub, full.fixed_idx, scan_maps, 0, B, pose, out_v, terms)
+        e1.record(st)
+        torch.cuda.synchronize()
+        if i >= 5:
+            t_cs.append(e0.elapsed_time(e1) * 1e-3)
+    t_cs = float(np.median(t_cs))
+    n_moving = scan_maps.counts().astype(np.int64)
+    n_fixed_sub = submaps.counts().astype(np.int64)
+    n_fixed = n_fixed_sub[prob["submap_of"]]
+    # interaction per pair + the self terms (ndt_map.cpp:42-99; symmetric halves): the moving one per scan, the fixed one ONCE per
+    # submap (it does not depend on the pair: k_cs_self) -- the reference, called pair by pair, evaluates it for every pair
+    overlaps = int((n_fixed * n_moving).sum() + (n_fixed_sub * n_fixed_sub).sum() // 2 + (n_moving * n_moving).sum() // 2)
+    overlaps_ref = int((n_fixed * n_moving).sum() + (n_fixed * n_fixed).sum() + (n_moving * n_moving).sum())
+    r = {"f2_cs_divergence": {"pairs_per_launch": B, "us_per_launch": t_cs * 1e6, "pairs_per_sec": B / t_cs, "gaussian_overlaps_evaluated": overlaps,
+                              "overlaps_per_sec": overlaps / t_cs, "gaussian_overlaps_in_the_reference_loops": overlaps_ref, "mean_value": float(out_v.mean().item()),
+                              "below_loop_closure_gate_3.6": int((out_v < 3.6).sum().item())}}
+    # f-3: cost batch + one search
+    mpb = mp
+    g1 = full.guess4[:1].contiguous()
+    corr = torch.full((1, 512, mp.n_neighbours), -1, dtype=torch.int32, device=dev)
+    R.associate_batch(ctx, submaps, full.fixed_idx[:1].contiguous(), scan_maps, 0, 1, g1, mp, corr)
+    sub0 = int(full.fixed_idx[0].item())
+    rng = np.random.default_rng(5)
+    n_poses = 4096
+    poses = torch.from_numpy(synth.pose3_to_pose4(prob["truth"][0] + rng.normal(0, [0.5, 0.5, 0.1], (n_poses, 3)))).to(dev)
+    cost = torch.zeros(n_poses, dtype=torch.float64, device=dev)
+    nres = torch.zeros(1, dtype=torch.int32, device=dev)
+    t_ev = []
+    for i in range(25):
+        e0.record(st)
+        host.eval_cost_batch(ctx, submaps, sub0, scan_maps, 0, corr, mp, 1.5, poses, cost, nres)
+        e1.record(st)
+        torch.cuda.synchronize()
+        if i >= 5:
+            t_ev.append(e0.elapsed_time(e1) * 1e-3)
+    t_ev = float(np.median(t_ev))
+    bad = synth.pose3_to_pose4(prob["truth"][0] + np.array([0.9, -0.7, 0.1]))
+    bp = host.bnb_params(cost_threshold=2.0)
+    lat = []
+    for i in range(12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mc, t4, ne = host.search_global(ctx, submaps, sub0, scan_maps, 0, mp, bp, bad)
+        lat.append(time.perf_counter() - t0)
+    t_search = float(np.median(lat[2:]))
+    est = synth.pose4_to_pose3(t4)
+    r["f3_global_search"] = {"cost_batch": {"poses": n_poses, "residuals_per_pose": int(nres.item()), "us_per_launch": t_ev * 1e6,
+                                            "pose_evaluations_per_sec": n_poses / t_ev, "residual_evaluations_per_sec": n_poses * int(nres.item()) / t_ev},
+                             "search": {"ms_per_search": t_search * 1e3, "cost_evaluations": int(ne), "min_cost": float(mc),
+                                        "error_vs_truth_m": float(np.hypot(*(est[:2] - prob["truth"][0][:2])))}}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+
+        ip = synth.indoor_params()
+
+        def omap(cap=None):
+            return po.Map(ip["size_x"], ip["size_y"], ip["resolution"], (0, 0), ip["max_neighbour_dist"], ip["min_points_per_cell"], cap)
+        sm = prob["submaps"][int(prob["submap_of"][0])]
+        osub = omap()
+        for t in range(len(sm["kf_scans"])):
+            m = omap(512)
+            m.build(sm["kf_scans"][t], ip["n_clusters"], ip["max_range"])
+            m.transform(synth.pose3_to_pose4(sm["kf_rel"][t]))
+            osub.merge(m)
+        idx = [i for i in range(B) if prob["submap_of"][i] == prob["submap_of"][0]][:16]
+        oscans = []
+        for i in idx:
+            m = omap(512)
+            m.build(prob["scans"][i], ip["n_clusters"], ip["max_range"])
+            m.transform(synth.pose3_to_pose4(prob["truth"][i]))
+            oscans.append(m)
+        done, t_tot, worst = 0, 0.0, 0.0
+        gv = out_v.cpu().numpy()
+        while t_tot < budget_s:
+            t0 = time.perf_counter()
+            vals = [po.cs_divergence(osub, m)[0] for m in oscans]
+            t_tot += time.perf_counter() - t0
+            done += len(oscans)
+        worst = float(np.abs(np.array(vals) - gv[idx]).max())
+        r["f2_cs_divergence"]["cpu_oracle"] = {"pairs_per_sec": done / t_tot, "cores": 1, "sample": "%d pairs of submap %d, repeated for %.1f s" % (len(idx), int(prob["submap_of"][0]), t_tot),
+                                              "max_abs_difference_vs_gpu": worst}
+        oscan0 = omap(512)
+        oscan0.build(prob["scans"][0], ip["n_clusters"], ip["max_range"])
+        op = po.default_params()
+        for name, _ in mp._fields_:
+            if name != "reserved":
+                setattr(op, name, getattr(mp, name))
+        t0 = time.perf_counter()
+        omc, ot4, one = po.search_global_bnb(osub, oscan0, op, po.bnb_params(cost_threshold=2.0), bad)
+        t_o = time.perf_counter() - t0
+        r["f3_global_search"]["cpu_oracle"] = {"ms_per_search": t_o * 1e3, "cores": 1, "cost_evaluations": int(one),
+                                               "same_result": bool(one == ne and np.array_equal(ot4, t4))}
+    return r
 
 
 def polar_filter(ctx, n_scans):

@@ -894,7 +894,7 @@ int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int f
     return RANDT_ERR_INVALID;
   if (n_pairs == 0) return RANDT_OK;
   if (!d_out) return RANDT_ERR_INVALID;
-  const int max_tiles = (fixed->v.cap + 255) / 256;
+  const int max_tiles = (fixed->v.cap + RANDT_CS_SELF_OUTER - 1) / RANDT_CS_SELF_OUTER;  // partial sums of the fixed maps' self terms (csdiv.hip)
   int rc = ensure_ws(ctx, sizeof(double) * (size_t)fixed_count * max_tiles + 256);
   if (rc) return rc;
   return launch_cs_divergence(ctx, fixed->v, fixed_first, fixed_count, d_fixed_idx, moving->v, moving_first, n_pairs, d_pose4,

@@ -122,6 +122,7 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
                      int moving_first, int n_pairs, const double* d_guess4, int k, int lookup_mahalanobis,
                      int use_intensity, int32_t* d_corr, const int32_t* d_moving_idx = nullptr);
 
+#define RANDT_CS_SELF_OUTER 16  // csdiv.hip: outer cells per workgroup of the self-term kernel (= one partial sum; api.hip sizes the workspace)
 // fixed-lag window problem description (kernel argument, by value)
 #define RANDT_WIN_MAX_STATES 13  // <= 12 optimised states + the constant one (window.hip takes <= 3 + 1, window_gen.hip 4..7, window_gen_big.hip 8..12)
 #define RANDT_WIN_MAX_TERMS 24   // (state, fixed map) NDT terms: 12 states x 2 fixed maps

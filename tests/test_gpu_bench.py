@@ -42,6 +42,9 @@ def test_bench_single_gpu_contract():
     # the line's frac follows from the committed counter summary: cycles per launch / measured launch duration / peak
     assert abs(rf["valu_issue_cycles_per_launch"] / rf["avg_launch_us"] * 1e-3 / rf["peak"] - rf["frac"]) < 1e-12
     assert d["single_batch"]["value"] > 1e5 and d["single_batch"]["batch_latency_us"] > 10
+    lg = d["loop_gate_and_search"]                                              # f-2 / f-3 have measurements of their own
+    assert lg["f2_cs_divergence"]["pairs_per_sec"] > 1e4 and lg["f2_cs_divergence"]["cpu_oracle"]["max_abs_difference_vs_gpu"] < 1e-9
+    assert lg["f3_global_search"]["cost_batch"]["pose_evaluations_per_sec"] > 1e5 and lg["f3_global_search"]["cpu_oracle"]["same_result"] is True
     pf = d["config5_polar_filter"]                                              # f-1: the one HBM-streaming stage has its own roofline object
     assert pf["status_ok"] and pf["roofline"]["bound"] == "hbm" and 0.0 < pf["roofline"]["frac"] < 1.0 and pf["roofline"]["algorithmic_bytes"] == 2 * 19200000
     assert d["cpu_baseline"]["single_thread"]["cores"] == 1
