@@ -4,9 +4,9 @@
 // src/ndt_slam/ndt_slam.cpp:515-552), the stage that hands loop-closure candidates to
 // Matcher::estimateLoopConstraint (local_fuser.cpp:323-335):
 //   k_sc_make     makeScancontext + makeRingkey / makeSectorkey (:156-237), one workgroup per keyframe scan:
-//                 bin index and value of every point into LDS, then ONE THREAD PER BIN walks the points in input
-//                 order, so every bin sum runs in the reference's sequential order (no atomics, bit-reproducible,
-//                 including the quirk that a touched bin starts at NO_POINT = -1000);
+//                 bin index and value of every point into LDS, a stable counting sort of the points by bin, then ONE
+//                 THREAD PER BIN folds its points in input order, so every bin sum runs in the reference's sequential
+//                 order (bit-reproducible, including the quirk that a touched bin starts at NO_POINT = -1000);
 //   k_sc_detect   detectLoopClosureID (:261-341), one workgroup per query node: float ring-key distances to the
 //                 searchable part of the database, k rounds of (distance, index) arg-min = the k nearest keys,
 //                 then per candidate the sector-key alignment, the column-shift search of the cosine distance and
@@ -71,34 +71,95 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_make(const float* __restrict__ 
     pz[i] = z;
     pbin[i] = (uint16_t)bin;
   }
+  // Every bin sum must run in the points' input order (the reference's loop, bit for bit).  Round 3 gave a thread four bins and
+  // let it walk all n points (a 2000-step chain: 100 us for one scan); adding in input order 64 points at a time through LDS is
+  // no better, because consecutive points of a radar sweep share a bin (91 us).  So the points are SORTED by bin first -- a
+  // stable counting sort on integers -- and a thread then folds only its own bins' points, in order:
+  //   ranks   a wavefront walks the points 64 at a time; the lanes of a step that share a bin find each other with one ballot
+  //           per distinct bin, the group's first lane takes (and advances) the bin's counter in LDS, every lane's rank is that
+  //           base + its position in the group.  Steps run in program order, so ranks follow the input order; the four
+  //           wavefronts take the bins with (bin mod 4) == their number: disjoint counters, four independent chains;
+  //   scan    exclusive prefix of the counters -> first[bin];
+  //   place   zs[first[bin] + rank] = the point's value;
+  //   fold    one thread per bin: NO_POINT + z + z + ... over its slice of `zs`.
+  uint16_t* prank = pbin + pitch;                      // [pitch]
+  float* zs = reinterpret_cast<float*>(smem + (((size_t)pitch * 8 + 15) & ~(size_t)15));  // [pitch] the values in bin order
+  int* cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(zs) + (((size_t)pitch * 4 + 15) & ~(size_t)15));  // [nb]
+  int* first = cnt + nb;                               // [nb]
+  double* dl = reinterpret_cast<double*>(first + nb);  // [nb] the finished descriptor
+  __shared__ int wsum[SC_BLOCK / 64];
+  for (int b = tid; b < nb; b += SC_BLOCK) cnt[b] = 0;
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const int b = i < n ? pbin[i] : 0xffff;
+      const bool mine = b != 0xffff && (b & 3) == wave;
+      // the groups of this step, one ballot per DISTINCT bin (consecutive points of a sweep share bins: a handful per step)
+      unsigned long long todo = __ballot(mine), grp = 0ull;
+      while (todo) {  // wave-uniform
+        const int head = __ffsll((long long)todo) - 1;
+        const int hb = __shfl(b, head, 64);
+        const unsigned long long g = __ballot(mine && b == hb);
+        if (mine && b == hb) grp = g;
+        todo &= ~g;
+      }
+      const int leader = mine ? __ffsll((long long)grp) - 1 : lane;
+      int base = 0;
+      if (mine && lane == leader) base = atomicAdd(&cnt[b], __popcll(grp));  // all groups' counters in one LDS instruction
+      base = __shfl(base, leader, 64);
+      if (mine) prank[i] = (uint16_t)(base + __popcll(grp & lt));
+    }
+  }
+  __syncthreads();
+  {  // exclusive prefix over the bins: a contiguous chunk per thread, wave scan of the chunk sums, four wave totals
+    const int chunk = (nb + SC_BLOCK - 1) / SC_BLOCK;
+    const int b0 = tid * chunk, b1 = (b0 + chunk) < nb ? (b0 + chunk) : nb;
+    int local = 0;
+    for (int b = b0; b < b1; ++b) local += cnt[b];
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
+    for (int b = b0; b < b1; ++b) {
+      first[b] = run;
+      run += cnt[b];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += SC_BLOCK) {
+    const int b = pbin[i];
+    if (b != 0xffff) zs[first[b] + prank[i]] = pz[i];
+  }
   __syncthreads();
   double* d = desc + (size_t)scan * nb;
-  // thread t owns bins t, t + 256, ...: one pass over the points per group of four bins
-  for (int b0 = tid; b0 < nb; b0 += 4 * SC_BLOCK) {
-    double acc[4] = {-1000, -1000, -1000, -1000};  // NO_POINT; values are ADDED to it (:187)
-    for (int i = 0; i < n; ++i) {
-      const int b = pbin[i];
-      const double z = (double)pz[i];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (b == b0 + u * SC_BLOCK) acc[u] += z;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int b = b0 + u * SC_BLOCK;
-      if (b < nb) d[b] = acc[u] == -1000 ? 0.0 : acc[u];
-    }
+  for (int b = tid; b < nb; b += SC_BLOCK) {
+    double a = -1000;  // NO_POINT; values are ADDED to it (:187)
+    const int k0 = first[b], k1 = k0 + cnt[b];
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) a += (double)zs[k];  // (the reads do not depend on the sum: only the additions are a chain)
+    a = a == -1000 ? 0.0 : a;
+    d[b] = a;
+    dl[b] = a;  // the keys below read the descriptor from LDS (from global memory each of their 20 .. 45 steps was an L2 round trip)
   }
   __syncthreads();
   if (tid < R) {  // rowwise mean
     double a = 0;
-    for (int s = 0; s < S; ++s) a += d[(size_t)s * R + tid];
+    for (int s = 0; s < S; ++s) a += dl[(size_t)s * R + tid];
     ring_key[(size_t)scan * R + tid] = a / S;
   }
   if (tid >= 64 && tid - 64 < S) {  // columnwise mean (second wavefront onwards)
     const int s = tid - 64;
     double a = 0;
-    for (int r = 0; r < R; ++r) a += d[(size_t)s * R + r];
+    for (int r = 0; r < R; ++r) a += dl[(size_t)s * R + r];
     sector_key[(size_t)scan * S + s] = a / R;
   }
 }
@@ -355,7 +416,7 @@ int launch_sc_make(randt_ctx* ctx, const float* d_points, int n_scans, int pitch
   if (n_scans <= 0) return RANDT_OK;
   if (p->num_ring < 1 || p->num_ring > SC_MAX_RING || p->num_sector < 1 || p->num_sector > SC_MAX_SECTOR)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan context: num_ring <= 64 and num_sector <= 128", hipSuccess);
-  const size_t lds = (size_t)pitch * 6 + 16;
+  const size_t lds = (((size_t)pitch * 8 + 15) & ~(size_t)15) + (((size_t)pitch * 4 + 15) & ~(size_t)15) + (size_t)p->num_ring * p->num_sector * 16 + 16;  // per point: value, bin, rank, sorted value; per bin: count, first, sum
   if (lds > (size_t)ctx->lds_limit) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan too large for the scan-context kernel", hipSuccess);
   RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_make), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_sc_make, dim3(n_scans), dim3(SC_BLOCK), lds, ctx->stream, d_points, pitch, d_n_points, stride, ioff, to_dev(p),
