@@ -196,7 +196,11 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
                                                         const double* __restrict__ pos, const double* __restrict__ dist, int n_db,
                                                         const int32_t* __restrict__ query_ids, float* __restrict__ d2ws, int d2pitch,
                                                         int32_t* __restrict__ loop_id, float* __restrict__ yaw,
-                                                        double* __restrict__ min_dist_out) {
+                                                        double* __restrict__ min_dist_out, int staged) {
+  // staged: the query's and the current candidate's descriptor (S x R doubles each) are copied into LDS with coalesced loads;
+  // every dot product below then reads LDS instead of walking two global columns element by element (a candidate cost 12 us of
+  // L2 round trips that way).  Descriptors too large for it stay in global memory.
+  extern __shared__ __attribute__((aligned(16))) char sc_dyn[];
   __shared__ double k1[SC_MAX_SECTOR], k2[SC_MAX_SECTOR];
   __shared__ double n1[SC_MAX_SECTOR], n2[SC_MAX_SECTOR];  // column norms of the query / the candidate (shift-independent)
   __shared__ double term[SC_TERM_CAP];
@@ -248,6 +252,13 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
   }
   // ---- pairwise distances (distanceBtnScanContext) in candidate order
   const double* sc1 = desc + (size_t)node * R * S;
+  double* s1 = reinterpret_cast<double*>(sc_dyn);
+  double* s2 = s1 + (size_t)R * S;
+  if (staged) {
+    for (int i = tid; i < R * S; i += SC_BLOCK) s1[i] = sc1[i];
+    __syncthreads();
+    sc1 = s1;
+  }
   // The column-shift search evaluates, per shift, sum over the columns of dot / (|a| |b|): the norms do not depend on the shift
   // and the (shift, column) dot products not on each other, so they are formed once / by all 256 threads; only each shift's sum
   // over the columns stays one thread's left-to-right loop (the reference's order) -- same numbers, ~30x less serial work.
@@ -255,6 +266,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
   const bool spread_shifts = n_shift <= S && n_shift * S <= SC_TERM_CAP;
   if (tid < S) {
     double a = 0, na = 0;
+#pragma unroll 4
     for (int r = 0; r < R; ++r) {
       const double v = sc1[(size_t)tid * R + r];
       a += v;
@@ -269,8 +281,14 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
     const int ci = cand[c];
     const double* sc2 = desc + (size_t)ci * R * S;
     __syncthreads();
+    if (staged) {
+      for (int i = tid; i < R * S; i += SC_BLOCK) s2[i] = sc2[i];
+      __syncthreads();
+      sc2 = s2;
+    }
     if (tid < S) {
       double b = 0, nb = 0;
+#pragma unroll 4
       for (int r = 0; r < R; ++r) {
         const double v = sc2[(size_t)tid * R + r];
         b += v;
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
     int ns = 0x7fffffff;
     if (tid < S) {
       double nn = 0;
+#pragma unroll 4
       for (int s = 0; s < S; ++s) {
         int j = s - tid;
         j = j < 0 ? j + S : j;
@@ -314,6 +333,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
         const double* a = sc1 + (size_t)col * R;
         const double* b = sc2 + (size_t)j * R;
         double dot = 0;
+#pragma unroll 4
         for (int r = 0; r < R; ++r) dot += a[r] * b[r];
         const double na = n1[col], nb2 = n2[j];
         term[p] = (na == 0 || nb2 == 0) ? 1e300 : dot / (na * nb2);  // 1e300: the column is skipped
@@ -327,6 +347,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
           const int slot = delta <= P.radius ? P.radius + delta : P.radius - (S - delta);
           int n_eff = 0;
           double sum = 0;
+#pragma unroll 4
           for (int col = 0; col < S; ++col) {
             const double t = term[slot * S + col];
             if (t == 1e300) continue;
@@ -432,8 +453,12 @@ int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_d
   if (p->num_ring < 1 || p->num_ring > SC_MAX_RING || p->num_sector < 1 || p->num_sector > SC_MAX_SECTOR || p->num_candidates < 1 ||
       p->num_candidates > SC_MAX_CAND)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "scan context: num_ring <= 64, num_sector <= 128, num_candidates <= 32", hipSuccess);
-  hipLaunchKernelGGL(k_sc_detect, dim3(n_queries), dim3(SC_BLOCK), 0, ctx->stream, to_dev(p), d_desc, d_ring_keys, d_pos, d_dist, n_db,
-                     d_query_ids, d_ws, n_db, d_loop_id, d_yaw, d_min_dist);
+  size_t lds = 2 * sizeof(double) * (size_t)p->num_ring * p->num_sector;
+  const int staged = lds + 40 * 1024 <= (size_t)ctx->lds_limit ? 1 : 0;  // (the kernel's static arrays take 37 KB)
+  if (!staged) lds = 0;
+  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_detect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sc_detect, dim3(n_queries), dim3(SC_BLOCK), lds, ctx->stream, to_dev(p), d_desc, d_ring_keys, d_pos, d_dist, n_db,
+                     d_query_ids, d_ws, n_db, d_loop_id, d_yaw, d_min_dist, staged);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
