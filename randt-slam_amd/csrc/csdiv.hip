@@ -227,7 +227,8 @@ int launch_cs_divergence(randt_ctx* ctx, const MapView& fixed, int fixed_first, 
   const int max_tiles = (fixed.cap + CS_SELF_OUTER - 1) / CS_SELF_OUTER;
   hipLaunchKernelGGL(k_cs_self, dim3(max_tiles, fixed_count), dim3(CS_BLOCK), 0, ctx->stream, fixed, fixed_first, max_tiles, d_partial);
   const size_t lds = (size_t)moving.cap * (9 * 4 + 4);  // transformed moving cells + their validity flags
-  if (lds + 1024 > (size_t)ctx->lds_limit) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "moving-map capacity too large for the CS-divergence kernel", hipSuccess);
+  if (lds + 12 * 1024 > (size_t)ctx->lds_limit)  // (+ the kernel's static tile of fixed cells: 10.3 KB)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "moving-map capacity too large for the CS-divergence kernel", hipSuccess);
   RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_cs_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_cs_pair, dim3(n_pairs), dim3(CS_PBLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving, moving_first, d_pose4,
                      d_partial, fixed_first, max_tiles, d_out, d_terms);
