@@ -347,7 +347,8 @@ int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
  * (moving_first + p), the moving map first transformed by d_pose4[p] like local_fuser.cpp:338
  * (d_pose4 may be NULL = already transformed).  The fixed maps' self terms are computed once per map.
  * d_out[p] = -log(interaction) + 0.5 log(fixed term) + 0.5 log(moving term); d_terms (nullable):
- * the three sums per pair. */
+ * the three sums per pair.  The moving maps' CAPACITY is bounded by the LDS that holds a transformed moving map
+ * (40 B per cell: <= ~3700 cells; scan maps have a few hundred): beyond it RANDT_ERR_UNSUPPORTED. */
 int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed_first, int fixed_count,
                                   const int32_t* d_fixed_idx, const randt_maps* moving, int moving_first, int n_pairs,
                                   const double* d_pose4, double* d_out, double* d_terms);
