@@ -948,7 +948,7 @@ int randt_sc_detect_batch_dev(randt_ctx* ctx, const randt_sc_params* p, const do
   if (!ctx || !p || n_db < 0 || n_queries < 0) return RANDT_ERR_INVALID;
   if (n_queries == 0) return RANDT_OK;
   if (!d_desc || !d_ring_keys || !d_pos || !d_dist || !d_loop_id || !d_yaw) return RANDT_ERR_INVALID;
-  int rc = ensure_ws(ctx, sizeof(float) * (size_t)n_queries * (size_t)(n_db > 0 ? n_db : 1) + 256);
+  int rc = ensure_ws(ctx, sc_detect_ws_bytes(n_queries, n_db, p->num_candidates));
   if (rc) return rc;
   return launch_sc_detect(ctx, p, d_desc, d_ring_keys, d_pos, d_dist, n_db, d_query_ids, n_queries, (float*)ctx->ws, d_loop_id, d_yaw,
                           d_min_dist);
@@ -1054,7 +1054,7 @@ int randt_sc_db_detect(randt_sc_db* db, int node_id, int* loop_id, float* yaw_di
   DeviceGuard dev_guard__(db ? db->ctx : nullptr);
   if (!db || !loop_id || !yaw_diff_rad || node_id < 0 || node_id >= db->n) return RANDT_ERR_INVALID;
   randt_ctx* ctx = db->ctx;
-  int rc = ensure_ws(ctx, sizeof(float) * (size_t)db->n + 256);
+  int rc = ensure_ws(ctx, sc_detect_ws_bytes(1, db->n, db->p.num_candidates));
   if (rc) return rc;
   int32_t* d_q = db->out_id + 1;
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(d_q, &node_id, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));

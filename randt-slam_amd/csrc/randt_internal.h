@@ -159,6 +159,7 @@ int launch_cs_divergence(randt_ctx* ctx, const MapView& fixed, int fixed_first, 
 
 int launch_sc_make(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride, int ioff,
                    const randt_sc_params* p, double* d_desc, double* d_ring_keys, double* d_sector_keys);
+size_t sc_detect_ws_bytes(int n_queries, int n_db, int n_cand);  // workspace launch_sc_detect needs behind d_ws
 int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_desc, const double* d_ring_keys, const double* d_pos,
                      const double* d_dist, int n_db, const int32_t* d_query_ids, int n_queries, float* d_ws, int32_t* d_loop_id,
                      float* d_yaw, double* d_min_dist);

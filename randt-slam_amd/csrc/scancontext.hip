@@ -192,11 +192,19 @@ __device__ __forceinline__ void block_argmin(double& v, int& idx, double* sv, in
     }
 }
 
+// what a (query, candidate) workgroup leaves for k_sc_pick
+struct ScCandidate {
+  double cd;           // distanceBtnScanContext + the odometry term
+  int32_t shift, idx;  // argmin shift, database index (-1: this query has fewer candidates)
+};
+
+// One workgroup per (query, candidate rank): the candidates of a query are independent of each other until the final
+// "smallest distance, first one wins" (k_sc_pick), and each is a chain of short phases (~8 us) -- ten of them in a row were
+// most of a query's 106 us.  Every workgroup forms the ring-key distances itself and runs the arg-min rounds up to its own rank.
 __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double* __restrict__ desc, const double* __restrict__ ring_keys,
                                                         const double* __restrict__ pos, const double* __restrict__ dist, int n_db,
                                                         const int32_t* __restrict__ query_ids, float* __restrict__ d2ws, int d2pitch,
-                                                        int32_t* __restrict__ loop_id, float* __restrict__ yaw,
-                                                        double* __restrict__ min_dist_out, int staged) {
+                                                        ScCandidate* __restrict__ records, int staged) {
   // staged: the query's and the current candidate's descriptor (S x R doubles each) are copied into LDS with coalesced loads;
   // every dot product below then reads LDS instead of walking two global columns element by element (a candidate cost 12 us of
   // L2 round trips that way).  Descriptors too large for it stay in global memory.
@@ -207,16 +215,13 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
   __shared__ double sv[4];
   __shared__ int si[4];
   __shared__ int cand[SC_MAX_CAND];
-  const int q = blockIdx.x, tid = threadIdx.x;
+  const int q = blockIdx.x, c_only = blockIdx.y, tid = threadIdx.x;
   const int node = query_ids ? query_ids[q] : q;
   const int R = P.R, S = P.S;
-  float* d2 = d2ws + (size_t)q * d2pitch;
-  if (node < P.exclude_recent + 1 || node >= n_db) {  // early return (:274-278)
-    if (tid == 0) {
-      loop_id[q] = -1;
-      yaw[q] = 0.0f;
-      if (min_dist_out) min_dist_out[q] = 10000000;
-    }
+  float* d2 = d2ws + ((size_t)q * gridDim.y + c_only) * d2pitch;
+  ScCandidate* rec = records + (size_t)q * gridDim.y + c_only;
+  if (node < P.exclude_recent + 1 || node >= n_db) {  // early return (:274-278): k_sc_pick says so
+    if (tid == 0) rec->idx = -1;
     return;
   }
   const int n_search = node + 1 - P.exclude_recent;
@@ -233,7 +238,11 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
   __syncthreads();
   // ---- the k nearest keys in ascending (distance, index) order
   const int kk = P.n_cand < n_search ? P.n_cand : n_search;
-  for (int c = 0; c < kk; ++c) {
+  if (c_only >= kk) {  // uniform
+    if (tid == 0) rec->idx = -1;
+    return;
+  }
+  for (int c = 0; c <= c_only; ++c) {
     double bv = 1e300;
     int bi = 0x7fffffff;
     for (int i = tid; i < n_search; i += SC_BLOCK) {
@@ -275,10 +284,8 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
     k1[tid] = a / R;
     n1[tid] = sqrt(na);
   }
-  double min_d = 10000000;
-  int nn_align = 0, nn_idx = 0;
-  for (int c = 0; c < kk; ++c) {
-    const int ci = cand[c];
+  {
+    const int ci = cand[c_only];
     const double* sc2 = desc + (size_t)ci * R * S;
     __syncthreads();
     if (staged) {
@@ -401,17 +408,33 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
     t_err = (t_err > 0.0 ? t_err : 0.0) / (dist[ci] - dist[node]);
     const double odom_dist = 1 - exp(-(t_err * t_err) / (2 * P.assumed_drift * P.assumed_drift));
     const double cd = min_sc + odom_dist * R * P.odom_weight;
-    if (cd < min_d) {
-      min_d = cd;
-      nn_align = argmin_shift;
-      nn_idx = ci;
+    if (tid == 0) {
+      rec->cd = cd;
+      rec->shift = argmin_shift;
+      rec->idx = ci;
     }
   }
-  if (tid == 0) {
-    loop_id[q] = min_d < P.dist_thresh ? nn_idx : -1;
-    yaw[q] = (float)((float)(nn_align * (360.0 / (double)S)) * M_PI / 180.0);
-    if (min_dist_out) min_dist_out[q] = min_d;
+}
+
+// the candidates of a query in rank order: the smallest distance wins, the first one on ties (:318-327)
+__global__ __launch_bounds__(64) void k_sc_pick(ScParams P, int n_queries, int n_cand, const ScCandidate* __restrict__ records,
+                                                int32_t* __restrict__ loop_id, float* __restrict__ yaw, double* __restrict__ min_dist_out) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= n_queries) return;
+  double min_d = 10000000;
+  int nn_align = 0, nn_idx = 0;
+  for (int c = 0; c < n_cand; ++c) {
+    const ScCandidate r = records[(size_t)q * n_cand + c];
+    if (r.idx < 0) break;  // (ranks beyond the query's candidates, or the early return)
+    if (r.cd < min_d) {
+      min_d = r.cd;
+      nn_align = r.shift;
+      nn_idx = r.idx;
+    }
   }
+  loop_id[q] = min_d < P.dist_thresh ? nn_idx : -1;
+  yaw[q] = (float)((float)(nn_align * (360.0 / (double)P.S)) * M_PI / 180.0);
+  if (min_dist_out) min_dist_out[q] = min_d;
 }
 
 ScParams to_dev(const randt_sc_params* p) {
@@ -431,6 +454,11 @@ ScParams to_dev(const randt_sc_params* p) {
 }
 
 }  // namespace
+
+size_t sc_detect_ws_bytes(int n_queries, int n_db, int n_cand) {
+  const size_t q = n_queries > 0 ? n_queries : 1, c = n_cand > 0 ? n_cand : 1, n = n_db > 0 ? n_db : 1;
+  return ((q * c * sizeof(ScCandidate) + 255) & ~(size_t)255) + sizeof(float) * q * c * n + 256;
+}
 
 int launch_sc_make(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride, int ioff,
                    const randt_sc_params* p, double* d_desc, double* d_ring_keys, double* d_sector_keys) {
@@ -457,8 +485,13 @@ int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_d
   const int staged = lds + 40 * 1024 <= (size_t)ctx->lds_limit ? 1 : 0;  // (the kernel's static arrays take 37 KB)
   if (!staged) lds = 0;
   RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_detect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_sc_detect, dim3(n_queries), dim3(SC_BLOCK), lds, ctx->stream, to_dev(p), d_desc, d_ring_keys, d_pos, d_dist, n_db,
-                     d_query_ids, d_ws, n_db, d_loop_id, d_yaw, d_min_dist, staged);
+  // workspace (sc_detect_ws_bytes): the records, then one copy of the ring-key distances per (query, candidate rank)
+  ScCandidate* records = reinterpret_cast<ScCandidate*>(d_ws);
+  float* d2ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d_ws) + (((size_t)n_queries * p->num_candidates * sizeof(ScCandidate) + 255) & ~(size_t)255));
+  hipLaunchKernelGGL(k_sc_detect, dim3(n_queries, p->num_candidates), dim3(SC_BLOCK), lds, ctx->stream, to_dev(p), d_desc, d_ring_keys, d_pos, d_dist,
+                     n_db, d_query_ids, d2ws, n_db, records, staged);
+  hipLaunchKernelGGL(k_sc_pick, dim3((n_queries + 63) / 64), dim3(64), 0, ctx->stream, to_dev(p), n_queries, p->num_candidates, records, d_loop_id,
+                     d_yaw, d_min_dist);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
