@@ -237,6 +237,8 @@ def main():
                     help="pair-solve geometry of the timed region's contexts: throughput = one wavefront per registration, auto = the "
                          "library's choice per launch (splits a lone small batch); default = throughput when several streams keep batches in flight")
     ap.add_argument("--odometry-scans", type=int, default=1000, help="BASELINE config 3 side measurement (0 = skip)")
+    ap.add_argument("--cpp-drive-scans", type=int, default=300,
+                    help="side measurement: the drop-in path driven from C++ with host buffers and Maps by value (tests/cpp/local_fuser_drive.cpp; 0 = skip)")
     ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
     ap.add_argument("--slam-scans", type=int, default=300,
                     help="side measurement: whole SLAM call pattern (odometry + loop closure + pose graph) on a two-lap drive (0 = skip)")
@@ -578,6 +580,9 @@ def main():
             side("loop_gate_and_search", loop_gate_and_search, R, torch, ctx, submaps, full, mp, weak_prob, not args.no_cpu_baseline, min(2.0, args.cpu_seconds))
         if args.odometry_scans > 0 and world == 1:
             side("config3_streaming_odometry", streaming_odometry, ctx, args.odometry_scans, not args.no_cpu_baseline)
+        if args.cpp_drive_scans > 0 and world == 1:
+            py = out.get("config3_streaming_odometry", {})
+            side("cpp_local_fuser_drive", cpp_local_fuser_drive, ctx, args.cpp_drive_scans, py.get("ms_per_scan") if isinstance(py, dict) else None)
         if args.polar_scans > 0 and world == 1:
             side("config5_polar_filter", polar_filter, ctx, args.polar_scans)
         if args.slam_scans > 0 and world == 1:
@@ -1200,6 +1205,68 @@ def streaming_odometry(ctx, n_scans, with_cpu):
                                                    "sample": "the same %d scans, residual blocks over %d OpenMP threads" % (n_cpu, cores)}
         finally:
             po.set_eval_threads(1)
+    return out
+
+
+def cpp_local_fuser_drive(ctx, n_scans, python_ms_per_scan=None):
+    """The drop-in path as the reference's node would run it (round-4 verdict, item 1): a C++ caller of include/randt_facade.hpp
+    with LocalFuser::processScan's call pattern (tests/cpp/local_fuser_drive.cpp: Maps BY VALUE -- every copy the reference makes,
+    local_fuser.cpp:128-136,173-178 --, the reference-signature Matcher::estimateTransformCeres, transformMap + mergeMapCell), fed
+    HOST buffers scan by scan.  Same synthetic drive as config 3.  Reported: wall time per scan after a warm-up, and what the
+    context's storage pool / pinned ring leave of the allocator: hipMalloc / hipFree / stream synchronisations per steady-state
+    scan (randt_ctx_pool_stats).  Three legs: packed x y z I points through Map::addScan, pcl::PointXYZI records (32 B, the
+    reference's own host layout) through Map::addScan, and the reference's own insertion -- host clustering + one
+    Map::insertCluster per cluster (HierarchicalMap::addClusters, ndt_hierarchical_map.cpp:28-33)."""
+    import subprocess
+    import tempfile
+
+    from randt_slam_amd import synth
+
+    world = synth.make_world()
+    traj = synth.make_trajectory(3300, n_scans, step=0.25)
+    scans = np.ascontiguousarray(np.stack([synth.make_scan(world, traj[i], 20000 + i) for i in range(n_scans)]), dtype=np.float32)
+    libdir = os.path.join(ROOT, "randt-slam_amd")
+    out = {"workload": "config 3's drive (%d sequential 2000-point scans, indoor parameters, 135-state submaps with 20-state overlap) from HOST "
+                       "buffers through the C++ facade, Maps by value" % n_scans}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "local_fuser_drive")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "local_fuser_drive.cpp"),
+                               "-L", libdir, "-lrandt_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
+        path = os.path.join(tmp, "scans.bin")
+        with open(path, "wb") as f:
+            f.write(np.array([scans.shape[0], scans.shape[1]], dtype=np.int32).tobytes())
+            f.write(scans.tobytes())
+        # steady state = behind the first submap roll-over (scan 135) and its 20-scan overlap: by then the pool has seen every
+        # size the drive asks for and the workspaces have their final size
+        warm = 160 if n_scans >= 300 else n_scans // 4
+        poses = {}
+        for key, flags, n in (("add_scan_packed", [], n_scans), ("add_scan_pointxyzi", ["--xyzi8"], n_scans),
+                              ("add_clusters_pointxyzi", ["--xyzi8", "--clusters"], min(n_scans, 120))):
+            if n < n_scans:   # a shorter drive: the same file header with fewer scans
+                sub = os.path.join(tmp, "scans_%d.bin" % n)
+                with open(sub, "wb") as f:
+                    f.write(np.array([n, scans.shape[1]], dtype=np.int32).tobytes())
+                    f.write(scans[:n].tobytes())
+            else:
+                sub = path
+            pf = os.path.join(tmp, key + ".txt")
+            best = None
+            for rep in range(2):   # the first pass after an idle period runs slower (clock ramp): the better of two
+                r = subprocess.run([exe, sub, pf, "135", "20", "--timing", str(warm if n == n_scans else n // 4)] + flags, capture_output=True, text=True, timeout=600)
+                if r.returncode != 0:
+                    raise RuntimeError("local_fuser_drive %s: rc %d: %s" % (key, r.returncode, (r.stdout + r.stderr)[-400:]))
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                j = json.loads(line)
+                if best is None or j["ms_per_scan"] < best["ms_per_scan"]:
+                    best = j
+            out[key] = best
+            poses[key] = np.loadtxt(pf)
+        out["poses_equal_across_legs"] = {
+            "packed_vs_pointxyzi_max_abs": float(np.abs(poses["add_scan_packed"] - poses["add_scan_pointxyzi"]).max()),
+            "add_scan_vs_add_clusters_max_abs": float(np.abs(poses["add_scan_pointxyzi"][:len(poses["add_clusters_pointxyzi"])] - poses["add_clusters_pointxyzi"]).max())}
+    if python_ms_per_scan:
+        out["python_resident_loop_ms_per_scan"] = python_ms_per_scan
+        out["cpp_over_python_resident"] = out["add_scan_pointxyzi"]["ms_per_scan"] / python_ms_per_scan
     return out
 
 

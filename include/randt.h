@@ -177,6 +177,26 @@ int randt_ctx_set_trace(randt_ctx* ctx, double* d_trace, int max_len);
 enum { RANDT_SOLVE_AUTO = 0, RANDT_SOLVE_THROUGHPUT = 1 };
 int randt_ctx_set_solve_mode(randt_ctx* ctx, int mode);
 void randt_matcher_params_default(randt_matcher_params* p);
+/* Device storage pool of a context.  The reference copies Maps by value several times per scan
+ * (local_fuser.cpp:128-130,135,173-178; ndt_map.h:129-131) and inserts clusters one by one
+ * (ndt_hierarchical_map.cpp:28-33); behind this ABI every such copy is a randt_maps_create / randt_maps_clone +
+ * randt_maps_destroy.  Their storage therefore comes from a per-context pool: a destroyed batch parks its block (no
+ * hipFree, no synchronisation -- the next owner's work is enqueued on the same stream behind the previous owner's), a
+ * created batch takes a parked block of a fitting size (no hipMalloc).  In steady state a scan of the drop-in drive makes
+ * no allocator call at all; the counters below are how tests / bench.py check that.
+ *   device_allocs / device_frees  hipMalloc / hipFree calls this context has made (pool misses, workspace growth)
+ *   stream_syncs                  host waits on the context's stream (hipStreamSynchronize / a pinned segment's event)
+ *   pool_hits                     allocations served from parked blocks
+ *   pool_bytes / pool_blocks      what is parked right now
+ * randt_ctx_pool_trim really frees everything parked (synchronises); the pool never parks more than 1 GiB
+ * (RANDT_POOL_MAX_BYTES). */
+typedef struct randt_pool_stats {
+  int64_t device_allocs, device_frees, stream_syncs, pool_hits;
+  int64_t pool_bytes, pool_blocks;
+  int64_t reserved[2];
+} randt_pool_stats;
+int randt_ctx_pool_stats(const randt_ctx* ctx, randt_pool_stats* out);
+int randt_ctx_pool_trim(randt_ctx* ctx);
 
 /* ------------------------------------------------------------------ maps -------------------- */
 /* Replaces Map::initialize (ndt_map.cpp:7-21) for n_maps maps at once.  Storage per map:
@@ -199,8 +219,12 @@ int randt_maps_clear(randt_maps* m, int first, int count);
 int randt_maps_upload(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, const int32_t* h_grid);
 int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cells, int* n_cells, int32_t* h_grid);
 int randt_maps_counts(randt_maps* m, int first, int count, int32_t* h_counts);
-/* Device copy of whole maps (Map copy-construction, local_fuser.cpp:43-44,128-129). */
+/* Device copy of whole maps (Map copy-construction, local_fuser.cpp:43-44,128-129): one launch for cells, counts and
+ * index grids of all `count` maps, async on dst's stream. */
 int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int src_first, int count);
+/* Map's copy constructor in one call: a new batch with the geometry, capacity and (if src has one) index grid of src,
+ * holding a copy of maps [first, first + count) -- pooled storage, ONE launch, no clearing pass, async. */
+int randt_maps_clone(const randt_maps* src, int first, int count, randt_maps** out);
 
 /* ------------------------------------------------------------------ NDT build (a1-a4) ------- */
 /* Replaces RadarPreprocessor::processScan's clustering + HierarchicalMap::addClusters:
@@ -213,7 +237,9 @@ int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int s
 int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
                               const int32_t* d_n_points, int stride_floats, int intensity_index,
                               const randt_cluster_params* cp, randt_maps* out, int first_map);
-/* Host convenience for one scan (copies the points, synchronises). */
+/* Host convenience for one scan: the points are staged through the context's pinned ring (the host buffer is free when the
+ * call returns) and the build is enqueued -- no synchronisation (scans too large for a ring segment, > 512 KB, take a pageable
+ * copy and wait for it). */
 int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int stride_floats,
                     int intensity_index, const randt_cluster_params* cp, randt_maps* out, int map_idx);
 /* The same with pNDT cells: Cell::updateCell's `params_.use_pndt` branch (ndt_cell.cpp:67-82, 102; NDTCellParameters
@@ -230,12 +256,12 @@ int randt_ndt_build_pndt_batch_dev(randt_ctx* ctx, const float* d_points, int n_
 
 /* ------------------------------------------------------------------ transform / merge (a9,a18) */
 /* Map::transformMap (ndt_map.cpp:177-182, Cell::transformCell ndt_cell.cpp:117-123); like the
- * reference it leaves the index grid stale.  h_pose4: one pose per map. */
+ * reference it leaves the index grid stale.  h_pose4: one pose per map (copied before the call returns; asynchronous). */
 int randt_maps_transform(randt_maps* m, int first, int count, const double* h_pose4);
 /* Rolling-submap update: for t = 0..n_moving-1, transform moving map (moving_first + t) by
  * h_pose4[t] (Map::transformMapWithPointCloud, local_fuser.cpp:175-177) and merge it into
  * fixed map fixed_idx with Map::mergeMapCell (ndt_map.cpp:191-207, Cell::operator+= ndt_cell.h:133-142),
- * strictly in order.  The moving maps themselves are not modified. */
+ * strictly in order.  The moving maps themselves are not modified.  Asynchronous (the poses are copied before the call returns). */
 int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_first,
                      int n_moving, const double* h_pose4);
 /* NOT in the reference: rebuild the index grid of maps [first, first+count) from the cells' current means (async).
@@ -249,7 +275,11 @@ int randt_maps_reindex(randt_maps* m, int first, int count);
  *  - randt_maps_insert_cluster: Map::insertCluster (ndt_map.cpp:238-245) -- ONE cell from all the points
  *    (Cell::addPointCloud / updateCell), appended if accepted (n > min_points), its mean's slot pointed at it.
  *    *accepted (nullable) = 1 if a cell was added; a cluster whose mean lies outside the index grid is dropped like
- *    the batched build drops it (the reference's std::vector::at throws there).
+ *    the batched build drops it (the reference's std::vector::at throws there).  With accepted = NULL on a library-owned
+ *    batch the call is ASYNCHRONOUS (HierarchicalMap::addClusters inserts hundreds of clusters per scan,
+ *    ndt_hierarchical_map.cpp:28-33): nothing is read back, and a cluster that could not be placed (outside the grid ->
+ *    RANDT_ERR_INVALID, capacity exhausted -> RANDT_ERR_UNSUPPORTED) is reported ONCE by the next synchronising read of the
+ *    batch -- randt_maps_counts / randt_maps_download return that status with their outputs valid.
  *  - randt_maps_insert_cells: Map::insertCell (ndt_map.h:137-140) for set_grid = 0 (cells appended, index grid
  *    untouched); set_grid = 1 also points each cell's slot at it (the tail of insertCluster).
  *  - randt_closest_cells: Map::getClosestCells (ndt_map.cpp:101-151) for n_queries query cells: h_out[q][k] compact

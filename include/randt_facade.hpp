@@ -329,9 +329,22 @@ class Map {
       ctx_ = o.ctx_;
       params_ = o.params_;
       cap_ = o.cap_;
-      create();
-      check(randt_maps_copy(m_, 0, o.m_, 0, 1), "randt_maps_copy");
+      known_nonempty_ = o.known_nonempty_;
+      // pooled storage + one launch, asynchronous: the reference copies Maps ~7 times per scan (local_fuser.cpp:128-130,135,173-178)
+      check(randt_maps_clone(o.m_, 0, 1, &m_), "randt_maps_clone");
     }
+    return *this;
+  }
+  Map(Map&& o) noexcept { *this = std::move(o); }
+  Map& operator=(Map&& o) noexcept {
+    if (this == &o) return *this;
+    release();
+    ctx_ = std::move(o.ctx_);
+    params_ = o.params_;
+    cap_ = o.cap_;
+    known_nonempty_ = o.known_nonempty_;
+    m_ = o.m_;
+    o.m_ = nullptr;
     return *this;
   }
   ~Map() { release(); }
@@ -358,6 +371,7 @@ class Map {
   // points: n x stride floats (pcl::PointXYZI: stride 8, intensity at 4).
   void addScan(const float* points, int n, int stride, int intensity_index, const RadarPreprocessorParameters& rp) {
     randt_cluster_params cp{rp.n_clusters, static_cast<float>(rp.max_range)};
+    known_nonempty_ = false;  // the build replaces the map's content
     check(randt_ndt_build(ctx_->get(), points, n, stride, intensity_index, &cp, m_, 0), "randt_ndt_build");
   }
 
@@ -404,7 +418,13 @@ class Map {
     check(randt_maps_counts(m_, 0, 1, &n), "randt_maps_counts");
     return static_cast<unsigned int>(n);
   }
-  bool isEmpty() const { return get_n_cells() == 0; }
+  // A map only ever gains cells until it is cleared or rebuilt, so once a non-zero count has been read it is remembered:
+  // LocalFuser::processScan's per-scan "_current_submap.isEmpty()" (local_fuser.cpp:123) then costs no device round trip.
+  bool isEmpty() const {
+    if (known_nonempty_) return false;
+    known_nonempty_ = get_n_cells() != 0;
+    return !known_nonempty_;
+  }
 
   std::vector<Cell> getCells() const {
     std::vector<randt_cell> raw(cap_);
@@ -464,7 +484,10 @@ class Map {
     check(randt_maps_merge(m_, 0, moving_map.m_, 0, 1, pose.data()), "randt_maps_merge");
   }
 
-  void clear() { check(randt_maps_clear(m_, 0, 1), "randt_maps_clear"); }
+  void clear() {
+    known_nonempty_ = false;
+    check(randt_maps_clear(m_, 0, 1), "randt_maps_clear");
+  }
 
   // double Map::calculateCSDivergence(const Map& m_map)                       (ndt_map.cpp:42-99)
   // (the moving map already transformed by the caller, like local_fuser.cpp:338-339)
@@ -481,9 +504,12 @@ class Map {
   int capacity() const { return cap_; }
 
  private:
-  void create() { check(randt_maps_create(ctx_->get(), 1, &params_, cap_, 1, &m_), "randt_maps_create"); }
+  void create() {
+    known_nonempty_ = false;
+    check(randt_maps_create(ctx_->get(), 1, &params_, cap_, 1, &m_), "randt_maps_create");
+  }
   void release() {
-    if (m_) randt_maps_destroy(m_);
+    if (m_) randt_maps_destroy(m_);  // the storage goes back to the context's pool: no hipFree, no synchronisation
     m_ = nullptr;
   }
   bool check(int rc, const char* what) const { return facade_check(rc, what, ctx_ ? ctx_->get() : nullptr); }
@@ -498,6 +524,7 @@ class Map {
   randt_map_params params_{};
   int cap_ = 0;
   randt_maps* m_ = nullptr;
+  mutable bool known_nonempty_ = false;
 };
 
 // rc::navigation::ndt::HierarchicalMap, the NDT side only (include/ndt_representation/ndt_hierarchical_map.h): the OGM

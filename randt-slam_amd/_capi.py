@@ -34,6 +34,11 @@ class MapParams(C.Structure):
     ]
 
 
+class PoolStats(C.Structure):
+    _fields_ = [("device_allocs", C.c_int64), ("device_frees", C.c_int64), ("stream_syncs", C.c_int64), ("pool_hits", C.c_int64),
+                ("pool_bytes", C.c_int64), ("pool_blocks", C.c_int64), ("reserved", C.c_int64 * 2)]
+
+
 class ClusterParams(C.Structure):
     _fields_ = [("n_clusters", C.c_int32), ("max_range", C.c_float)]
 
@@ -107,6 +112,8 @@ SYMBOLS = {
     "randt_ctx_set_trace": (_I, [_V, _V, _I]),
     "randt_ctx_set_solve_mode": (_I, [_V, _I]),
     "randt_matcher_params_default": (None, [_P(MatcherParams)]),
+    "randt_ctx_pool_stats": (_I, [_V, _P(PoolStats)]),
+    "randt_ctx_pool_trim": (_I, [_V]),
     "randt_maps_create": (_I, [_V, _I, _P(MapParams), _I, _I, _P(_V)]),
     "randt_maps_create_external": (_I, [_V, _I, _P(MapParams), _I, _V, _V, _V, _P(_V)]),
     "randt_maps_destroy": (_I, [_V]),
@@ -119,6 +126,7 @@ SYMBOLS = {
     "randt_maps_download": (_I, [_V, _I, _V, _I, _P(_I), _V]),
     "randt_maps_counts": (_I, [_V, _I, _I, _V]),
     "randt_maps_copy": (_I, [_V, _I, _V, _I, _I]),
+    "randt_maps_clone": (_I, [_V, _I, _I, _P(_V)]),
     "randt_ndt_build_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ClusterParams), _V, _I]),
     "randt_ndt_build": (_I, [_V, _V, _I, _I, _I, _P(ClusterParams), _V, _I]),
     "randt_ndt_build_pndt_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _V, _V, _P(ClusterParams), _V, _I]),

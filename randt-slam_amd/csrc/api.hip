@@ -23,18 +23,103 @@ int randt_set_error(randt_ctx* ctx, int status, const char* what, hipError_t e) 
   return status;
 }
 
+// ---------------------------------------------------------------- storage pool, counters, pinned ring ----------
+hipError_t randt_hip_malloc(randt_ctx* ctx, void** p, size_t bytes) {
+  if (ctx) ++ctx->stats.device_allocs;
+  return hipMalloc(p, bytes);
+}
+hipError_t randt_hip_free(randt_ctx* ctx, void* p) {
+  if (ctx) ++ctx->stats.device_frees;
+  return hipFree(p);
+}
+hipError_t randt_sync(randt_ctx* ctx) {
+  ++ctx->stats.stream_syncs;
+  return hipStreamSynchronize(ctx->stream);
+}
+
+// A parked block serves a request if it is large enough and at most twice as large (+ 4 KB): a 64 KB scan map does not
+// take a 520 KB submap block.  Sizes are rounded to 256 bytes so that equal requests meet equal blocks.
+hipError_t randt_dev_alloc(randt_ctx* ctx, void** p, size_t bytes, size_t* granted) {
+  const size_t want = (bytes + 255) & ~(size_t)255;
+  auto it = ctx->pool_free.lower_bound(want);
+  if (it != ctx->pool_free.end() && it->first <= 2 * want + 4096) {
+    *p = it->second;
+    if (granted) *granted = it->first;
+    ctx->pool_bytes -= it->first;
+    ctx->pool_free.erase(it);
+    ++ctx->stats.pool_hits;
+    return hipSuccess;
+  }
+  const hipError_t e = randt_hip_malloc(ctx, p, want);
+  if (granted) *granted = want;
+  return e;
+}
+
+void randt_dev_release(randt_ctx* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  if (bytes > ctx->pool_cap || ctx->pool_bytes + bytes > ctx->pool_cap) {
+    // really freed: the stream may still use the block
+    (void)randt_sync(ctx);
+    (void)randt_hip_free(ctx, p);
+    return;
+  }
+  ctx->pool_free.emplace(bytes, p);
+  ctx->pool_bytes += bytes;
+}
+
+void* randt_pin_take(randt_ctx* ctx, size_t bytes) {
+  bytes = (bytes + 63) & ~(size_t)63;
+  if (bytes > randt_ctx::kPinSegBytes) return nullptr;
+  if (!ctx->pin_ring) {
+    void* r = nullptr;
+    if (hipHostMalloc(&r, randt_ctx::kPinSegs * randt_ctx::kPinSegBytes, hipHostMallocDefault) != hipSuccess || !r) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    for (int i = 0; i < randt_ctx::kPinSegs; ++i)
+      if (hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(r);
+        for (int j = 0; j < i; ++j) (void)hipEventDestroy(ctx->pin_ev[j]);
+        return nullptr;
+      }
+    ctx->pin_ring = static_cast<char*>(r);
+    ctx->pin_cur = 0;
+    ctx->pin_off = 0;
+  }
+  if (ctx->pin_off + bytes > randt_ctx::kPinSegBytes) {
+    // this segment is full: everything enqueued so far may still read it -> an event behind it; the next segment is
+    // reusable once ITS event (recorded a whole ring revolution ago) has passed -- normally long ago
+    (void)hipEventRecord(ctx->pin_ev[ctx->pin_cur], ctx->stream);
+    ctx->pin_pending[ctx->pin_cur] = true;
+    ctx->pin_cur = (ctx->pin_cur + 1) % randt_ctx::kPinSegs;
+    ctx->pin_off = 0;
+    if (ctx->pin_pending[ctx->pin_cur]) {
+      if (hipEventQuery(ctx->pin_ev[ctx->pin_cur]) != hipSuccess) {
+        (void)hipGetLastError();
+        ++ctx->stats.stream_syncs;
+        (void)hipEventSynchronize(ctx->pin_ev[ctx->pin_cur]);
+      }
+      ctx->pin_pending[ctx->pin_cur] = false;
+    }
+  }
+  char* out = ctx->pin_ring + (size_t)ctx->pin_cur * randt_ctx::kPinSegBytes + ctx->pin_off;
+  ctx->pin_off += bytes;
+  return out;
+}
+
 namespace {
 
 int ensure_ws(randt_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return RANDT_OK;
   if (ctx->ws) {
-    RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    RANDT_HIP_CHECK(ctx, hipFree(ctx->ws));
+    RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+    RANDT_HIP_CHECK(ctx, randt_hip_free(ctx, ctx->ws));
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
   }
   size_t want = bytes + bytes / 4 + 4096;
-  RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->ws, want));
+  RANDT_HIP_CHECK(ctx, randt_hip_malloc(ctx, &ctx->ws, want));
   ctx->ws_bytes = want;
   return RANDT_OK;
 }
@@ -205,6 +290,10 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
   if (const char* e = getenv("RANDT_ASSOC_TP_CH")) ctx->assoc_tp_ch = atoi(e) > 0 ? atoi(e) : ctx->assoc_tp_ch;
   if (const char* e = getenv("RANDT_ASSOC_TP_PPW")) ctx->assoc_tp_ppw = atoi(e) > 0 ? atoi(e) : ctx->assoc_tp_ppw;
   if (const char* e = getenv("RANDT_BUILD_TILED")) ctx->build_tiled = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("RANDT_POOL_MAX_BYTES")) {
+    const long long v = atoll(e);
+    if (v >= 0) ctx->pool_cap = (size_t)v;  // 0: nothing is parked (every destroy synchronises and frees, like before the pool)
+  }
   {
     // does this device serve colliding LDS atomics in lane order?  (one 64-thread launch; if the probe cannot run or says
     // no, the build kernels keep the ballot ranking, which assumes nothing)
@@ -251,14 +340,43 @@ int randt_debug_lds_atomics_lane_ordered(const randt_ctx* ctx) { return ctx ? ct
 int randt_debug_build_rank_fallbacks(randt_ctx* ctx) {
   if (!ctx) return 0;
   DeviceGuard dev_guard__(ctx);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)randt_sync(ctx);
   int32_t n = 0;
   if (ctx->d_misrank_count && hipMemcpy(&n, ctx->d_misrank_count, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) n = 0;
   return n;
 }
 
+int randt_ctx_pool_stats(const randt_ctx* ctx, randt_pool_stats* out) {
+  if (!ctx || !out) return RANDT_ERR_INVALID;
+  *out = ctx->stats;
+  out->pool_bytes = (int64_t)ctx->pool_bytes;
+  out->pool_blocks = (int64_t)ctx->pool_free.size();
+  return RANDT_OK;
+}
+
+int randt_ctx_pool_trim(randt_ctx* ctx) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx) return RANDT_ERR_INVALID;
+  if (ctx->pool_free.empty()) return RANDT_OK;
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+  for (auto& kv : ctx->pool_free) (void)randt_hip_free(ctx, kv.second);
+  ctx->pool_free.clear();
+  ctx->pool_bytes = 0;
+  return RANDT_OK;
+}
+
 int randt_ctx_destroy(randt_ctx* ctx) {
   if (!ctx) return RANDT_OK;
+  DeviceGuard dev_guard__(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->tmp_cluster) (void)randt_maps_destroy(ctx->tmp_cluster);
+  for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+  ctx->pool_free.clear();
+  if (ctx->pin_ring) {
+    (void)hipHostFree(ctx->pin_ring);
+    for (int i = 0; i < randt_ctx::kPinSegs; ++i)
+      if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+  }
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->build_ws) (void)hipFree(ctx->build_ws);
   if (ctx->build_wide_ws) (void)hipFree(ctx->build_wide_ws);
@@ -273,13 +391,19 @@ int randt_ctx_destroy(randt_ctx* ctx) {
 // 4 KB that the synchronous host-level entries carve their pose / index / result words from (they synchronise before
 // returning, so one block per context is enough and nothing is allocated per call).
 static int small_block(randt_ctx* ctx, char** out) {
-  if (!ctx->small) RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->small, 4096));
+  if (!ctx->small) RANDT_HIP_CHECK(ctx, randt_hip_malloc(ctx, &ctx->small, 4096));
   *out = static_cast<char*>(ctx->small);
   return RANDT_OK;
 }
 
 int randt_ctx_set_stream(randt_ctx* ctx, void* stream) {
   if (!ctx) return RANDT_ERR_INVALID;
+  if ((hipStream_t)stream != ctx->stream) {
+    // parked blocks, the workspace and the pinned ring are ordered by the OLD stream: let it drain before another one reuses them
+    DeviceGuard dev_guard__(ctx);
+    RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+    for (int i = 0; i < randt_ctx::kPinSegs; ++i) ctx->pin_pending[i] = false;
+  }
   ctx->stream = (hipStream_t)stream;
   return RANDT_OK;
 }
@@ -287,7 +411,7 @@ int randt_ctx_set_stream(randt_ctx* ctx, void* stream) {
 int randt_ctx_synchronize(randt_ctx* ctx) {
   DeviceGuard dev_guard__(ctx);
   if (!ctx) return RANDT_ERR_INVALID;
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   return RANDT_OK;
 }
 
@@ -327,47 +451,76 @@ int randt_maps_create_external(randt_ctx* ctx, int n_maps, const randt_map_param
   return RANDT_OK;
 }
 
+// Layout of a library-owned batch inside its ONE pooled block: [cells | counts | deferred status (2 words) | grid].
+static void block_layout(int n_maps, const randt_map_params* p, int cell_capacity, int with_grid, size_t* off_counts, size_t* off_grid,
+                         size_t* total) {
+  const size_t cb = (randt_maps_cells_bytes(n_maps, cell_capacity) + 255) & ~(size_t)255;
+  const size_t nb = (sizeof(int32_t) * ((size_t)n_maps + 2) + 255) & ~(size_t)255;
+  *off_counts = cb;
+  *off_grid = cb + nb;
+  *total = cb + nb + (with_grid ? ((randt_maps_grid_bytes(n_maps, p) + 255) & ~(size_t)255) : 0);
+}
+
+// a batch on pooled storage, contents undefined (create clears it, clone copies into it)
+static int maps_alloc(randt_ctx* ctx, int n_maps, const randt_map_params* p, int cell_capacity, int with_grid, randt_maps** out) {
+  size_t off_counts, off_grid, total, granted = 0;
+  block_layout(n_maps, p, cell_capacity, with_grid, &off_counts, &off_grid, &total);
+  void* blk = nullptr;
+  const hipError_t e = randt_dev_alloc(ctx, &blk, total, &granted);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // a failed hipMalloc leaves a sticky last-error; nothing else was allocated
+    return randt_set_error(ctx, e == hipErrorOutOfMemory ? RANDT_ERR_NOMEM : RANDT_ERR_HIP, "hipMalloc (map storage)", e);
+  }
+  char* b = static_cast<char*>(blk);
+  const int rc = randt_maps_create_external(ctx, n_maps, p, cell_capacity, b, b + off_counts, with_grid ? b + off_grid : nullptr, out);
+  if (rc) {
+    randt_dev_release(ctx, blk, granted);
+    return rc;
+  }
+  (*out)->owns = true;  // from here on randt_maps_destroy returns the block
+  (*out)->block = blk;
+  (*out)->block_bytes = granted;
+  return RANDT_OK;
+}
+
+// zeroes the cell records, the counts and the deferred-status words and sets the index grids to -1: one launch
+__global__ __launch_bounds__(256) void k_maps_init(MapView v, size_t cell_words /* 16-byte words */) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4* c = reinterpret_cast<uint4*>(v.cells);
+  for (size_t i = t0; i < cell_words; i += stride) c[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = t0; i < (size_t)v.n_maps + 2; i += stride) v.counts[i] = 0;
+  if (v.grid) {
+    const size_t n = (size_t)v.n_maps * v.n_slots;
+    for (size_t i = t0; i < n; i += stride) v.grid[i] = -1;
+  }
+}
+
 int randt_maps_create(randt_ctx* ctx, int n_maps, const randt_map_params* p, int cell_capacity, int with_grid,
                       randt_maps** out) {
   DeviceGuard dev_guard__(ctx);
   if (!ctx || !out || bad_params(p, n_maps, cell_capacity)) return RANDT_ERR_INVALID;
-  void *cells = nullptr, *counts = nullptr, *grid = nullptr;
   *out = nullptr;
-  // every failure path below releases what was allocated before it (a long-running node retrying after an
-  // out-of-memory must not lose HBM on every attempt)
-  hipError_t e = hipMalloc(&cells, randt_maps_cells_bytes(n_maps, cell_capacity));
-  if (e == hipSuccess) e = hipMalloc(&counts, sizeof(int32_t) * n_maps);
-  if (e == hipSuccess && with_grid) e = hipMalloc(&grid, randt_maps_grid_bytes(n_maps, p));
-  int rc = RANDT_OK;
-  if (e != hipSuccess) rc = randt_set_error(ctx, e == hipErrorOutOfMemory ? RANDT_ERR_NOMEM : RANDT_ERR_HIP, "hipMalloc (map storage)", e);
-  if (!rc) rc = randt_maps_create_external(ctx, n_maps, p, cell_capacity, cells, counts, grid, out);
-  if (!rc) {
-    (*out)->owns = true;  // from here on randt_maps_destroy releases the buffers
-    e = hipMemsetAsync(cells, 0, randt_maps_cells_bytes(n_maps, cell_capacity), ctx->stream);
-    if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "hipMemsetAsync (map storage)", e);
-    if (!rc) rc = randt_maps_clear(*out, 0, n_maps);
-    if (rc) {
-      (void)randt_maps_destroy(*out);
-      *out = nullptr;
-    }
-    return rc;
+  int rc = maps_alloc(ctx, n_maps, p, cell_capacity, with_grid, out);
+  if (rc) return rc;
+  const size_t words = randt_maps_cells_bytes(n_maps, cell_capacity) / 16;
+  size_t work = words > (size_t)n_maps * (*out)->v.n_slots ? words : (size_t)n_maps * (*out)->v.n_slots;
+  int bx = (int)((work + 255) / 256);
+  bx = bx > 1024 ? 1024 : (bx < 1 ? 1 : bx);
+  hipLaunchKernelGGL(k_maps_init, dim3(bx), dim3(256), 0, ctx->stream, (*out)->v, words);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    rc = randt_set_error(ctx, RANDT_ERR_HIP, "k_maps_init", e);
+    (void)randt_maps_destroy(*out);
+    *out = nullptr;
   }
-  (void)hipGetLastError();  // a failed hipMalloc leaves a sticky last-error
-  if (cells) (void)hipFree(cells);
-  if (counts) (void)hipFree(counts);
-  if (grid) (void)hipFree(grid);
   return rc;
 }
 
 int randt_maps_destroy(randt_maps* m) {
   DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!m) return RANDT_OK;
-  if (m->owns) {
-    (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipFree(m->v.cells);
-    (void)hipFree(m->v.counts);
-    if (m->v.grid) (void)hipFree(m->v.grid);
-  }
+  // no synchronisation: the block's next owner is served by the same stream (randt_internal.h, storage pool)
+  if (m->owns) randt_dev_release(m->ctx, m->block, m->block_bytes);
   delete m;
   return RANDT_OK;
 }
@@ -389,6 +542,7 @@ int randt_maps_device_ptrs(const randt_maps* m, void** d_cells, void** d_counts,
   return RANDT_OK;
 }
 
+static int deferred_status(randt_maps* m, const int32_t d[2]);
 static bool range_ok(const randt_maps* m, int first, int count) {
   return m && first >= 0 && count >= 0 && first + count <= m->v.n_maps;
 }
@@ -417,7 +571,7 @@ int randt_maps_upload(randt_maps* m, int idx, const randt_cell* h_cells, int n_c
   if (h_grid && m->v.grid)
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(m->v.grid + (size_t)idx * m->v.n_slots, h_grid, sizeof(int32_t) * m->v.n_slots,
                                         hipMemcpyHostToDevice, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   return RANDT_OK;
 }
 
@@ -426,8 +580,16 @@ int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cel
   if (!range_ok(m, idx, 1)) return RANDT_ERR_INVALID;
   randt_ctx* ctx = m->ctx;
   int32_t n = 0;
+  int32_t deferred[2] = {0, 0};
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&n, m->v.counts + idx, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (m->deferred_pending)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(deferred, m->v.counts + m->v.n_maps, sizeof(deferred), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+  if (m->deferred_pending) {
+    m->deferred_pending = false;
+    const int drc = deferred_status(m, deferred);
+    if (drc) return drc;
+  }
   if (n_cells) *n_cells = n;
   int c = n < max_cells ? n : max_cells;
   if (h_cells && c > 0)
@@ -436,7 +598,7 @@ int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cel
   if (h_grid && m->v.grid)
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_grid, m->v.grid + (size_t)idx * m->v.n_slots, sizeof(int32_t) * m->v.n_slots,
                                         hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   return RANDT_OK;
 }
 
@@ -446,7 +608,43 @@ int randt_maps_counts(randt_maps* m, int first, int count, int32_t* h_counts) {
   randt_ctx* ctx = m->ctx;
   if (count)
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, m->v.counts + first, sizeof(int32_t) * count, hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t deferred[2] = {0, 0};
+  if (m->deferred_pending)
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(deferred, m->v.counts + m->v.n_maps, sizeof(deferred), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+  if (m->deferred_pending) {
+    m->deferred_pending = false;
+    return deferred_status(m, deferred);
+  }
+  return RANDT_OK;
+}
+
+// cells (whole capacity: the tail behind `count` stays whatever the source holds -- zero for library-owned batches), counts
+// and index grids of `count` maps: blockIdx.y = map
+__global__ __launch_bounds__(256) void k_maps_copy(MapView dst, int dst_first, MapView src, int src_first, int zero_deferred) {
+  const int i = blockIdx.y;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint4* sc = reinterpret_cast<const uint4*>(src.cells + (size_t)(src_first + i) * src.cap);
+  uint4* dc = reinterpret_cast<uint4*>(dst.cells + (size_t)(dst_first + i) * dst.cap);
+  const size_t words = (size_t)src.cap * (sizeof(randt_cell) / 16);
+  for (size_t w = t0; w < words; w += stride) dc[w] = sc[w];
+  if (dst.grid && src.grid) {
+    const int32_t* sg = src.grid + (size_t)(src_first + i) * src.n_slots;
+    int32_t* dg = dst.grid + (size_t)(dst_first + i) * dst.n_slots;
+    for (size_t w = t0; w < (size_t)src.n_slots; w += stride) dg[w] = sg[w];
+  }
+  if (t0 == 0) dst.counts[dst_first + i] = src.counts[src_first + i];
+  if (zero_deferred && t0 == 0 && i == 0) dst.counts[dst.n_maps] = dst.counts[dst.n_maps + 1] = 0;  // a fresh library-owned batch
+}
+
+static int launch_maps_copy(randt_ctx* ctx, const MapView& dst, int dst_first, const MapView& src, int src_first, int count,
+                            int zero_deferred = 0) {
+  const size_t words = (size_t)src.cap * (sizeof(randt_cell) / 16);
+  const size_t work = words > (size_t)src.n_slots ? words : (size_t)src.n_slots;
+  int bx = (int)((work + 255) / 256);
+  bx = bx > 128 ? 128 : (bx < 1 ? 1 : bx);
+  hipLaunchKernelGGL(k_maps_copy, dim3(bx, count), dim3(256), 0, ctx->stream, dst, dst_first, src, src_first, zero_deferred);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
 
@@ -459,19 +657,23 @@ int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int s
   if (dst->p.size_x != src->p.size_x || dst->p.size_y != src->p.size_y || dst->p.resolution != src->p.resolution ||
       dst->p.center_x != src->p.center_x || dst->p.center_y != src->p.center_y)
     return randt_set_error(ctx, RANDT_ERR_INVALID, "randt_maps_copy: the two batches differ in map geometry (size, resolution or centre)", hipSuccess);
-  for (int i = 0; i < count; ++i) {
-    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(dst->v.cells + (size_t)(dst_first + i) * dst->v.cap,
-                                        src->v.cells + (size_t)(src_first + i) * src->v.cap,
-                                        sizeof(randt_cell) * src->v.cap, hipMemcpyDeviceToDevice, ctx->stream));
-    if (dst->v.grid && src->v.grid)
-      RANDT_HIP_CHECK(ctx, hipMemcpyAsync(dst->v.grid + (size_t)(dst_first + i) * dst->v.n_slots,
-                                          src->v.grid + (size_t)(src_first + i) * src->v.n_slots,
-                                          sizeof(int32_t) * src->v.n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+  if (count == 0) return RANDT_OK;
+  return launch_maps_copy(ctx, dst->v, dst_first, src->v, src_first, count);
+}
+
+int randt_maps_clone(const randt_maps* src, int first, int count, randt_maps** out) {
+  DeviceGuard dev_guard__(src ? src->ctx : nullptr);
+  if (!out || !range_ok(src, first, count) || count < 1) return RANDT_ERR_INVALID;
+  *out = nullptr;
+  randt_ctx* ctx = src->ctx;
+  int rc = maps_alloc(ctx, count, &src->p, src->v.cap, src->v.grid ? 1 : 0, out);
+  if (rc) return rc;
+  rc = launch_maps_copy(ctx, (*out)->v, 0, src->v, first, count, 1);  // + the two deferred-status words behind the counts start at zero
+  if (rc) {
+    (void)randt_maps_destroy(*out);
+    *out = nullptr;
   }
-  if (count)
-    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(dst->v.counts + dst_first, src->v.counts + src_first, sizeof(int32_t) * count,
-                                        hipMemcpyDeviceToDevice, ctx->stream));
-  return RANDT_OK;
+  return rc;
 }
 
 int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans, int pitch_points,
@@ -505,22 +707,31 @@ int randt_ndt_build_pndt_batch_dev(randt_ctx* ctx, const float* d_points, int n_
                           d_polar, beam_cov9);
 }
 
+// host points -> the context's workspace without a synchronisation: through the pinned ring when they fit a segment (one
+// memcpy + one async DMA; the host buffer is free on return), a pageable copy + wait otherwise
+static int stage_points(randt_ctx* ctx, const float* h_points, size_t bytes, size_t ws_extra, const float** d_points) {
+  int rc = ensure_ws(ctx, bytes + ws_extra);
+  if (rc) return rc;
+  if (void* pin = randt_pin_take(ctx, bytes)) {
+    memcpy(pin, h_points, bytes);
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_points, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RANDT_HIP_CHECK(ctx, randt_sync(ctx));  // a pageable source of this size may still be read after the call returns
+  }
+  *d_points = static_cast<const float*>(ctx->ws);
+  return RANDT_OK;
+}
+
 int randt_ndt_build(randt_ctx* ctx, const float* h_points, int n_points, int stride_floats, int intensity_index,
                     const randt_cluster_params* cp, randt_maps* out, int map_idx) {
   DeviceGuard dev_guard__(ctx);
-  if (!ctx || n_points < 0 || (n_points > 0 && !h_points)) return RANDT_ERR_INVALID;
-  if (n_points == 0) {
-    int rc = randt_maps_clear(out, map_idx, 1);
-    if (rc) return rc;
-    return randt_ctx_synchronize(ctx);
-  }
-  size_t bytes = sizeof(float) * (size_t)n_points * stride_floats;
-  int rc = ensure_ws(ctx, bytes);
+  if (!ctx || n_points < 0 || (n_points > 0 && !h_points) || stride_floats < 3) return RANDT_ERR_INVALID;
+  if (n_points == 0) return randt_maps_clear(out, map_idx, 1);
+  const float* d_points = nullptr;
+  int rc = stage_points(ctx, h_points, sizeof(float) * (size_t)n_points * stride_floats, 0, &d_points);
   if (rc) return rc;
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_points, bytes, hipMemcpyHostToDevice, ctx->stream));
-  rc = randt_ndt_build_batch_dev(ctx, (const float*)ctx->ws, 1, n_points, nullptr, stride_floats, intensity_index, cp, out, map_idx);
-  if (rc) return rc;
-  return randt_ctx_synchronize(ctx);
+  return randt_ndt_build_batch_dev(ctx, d_points, 1, n_points, nullptr, stride_floats, intensity_index, cp, out, map_idx);
 }
 
 // ---------------------------------------------------------------- single-cell / single-cluster map edits --------
@@ -533,18 +744,28 @@ static int append_from(randt_maps* m, int idx, const randt_maps* src, int set_gr
   int rc = small_block(ctx, &d_blk);
   if (rc) return rc;
   int32_t* d_status = reinterpret_cast<int32_t*>(d_blk + 512);
-  rc = launch_maps_append(ctx, m->v, idx, src->v, 0, set_grid, d_status);
+  rc = launch_maps_append(ctx, m->v, idx, src->v, 0, set_grid, d_status, 0);
   int32_t h_status[2] = {0, 0};
   if (!rc) {
     hipError_t e = hipMemcpyAsync(h_status, d_status, sizeof(h_status), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = randt_sync(ctx);
     if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "append status read-back", e);
   } else {
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)randt_sync(ctx);
   }
   if (n_dropped) *n_dropped = h_status[0];
   if (n_outside) *n_outside = h_status[1];
   return rc;
+}
+
+// What asynchronous inserts (randt_maps_insert_cluster with accepted = NULL) could not report when they ran: the append
+// kernel ADDS its dropped / outside counts to two words behind the batch's counts; the next synchronising read of the batch
+// (randt_maps_counts / randt_maps_download) fetches them in the same round trip, reports once and clears them.
+static int deferred_status(randt_maps* m, const int32_t d[2]) {
+  if (!d[0] && !d[1]) return RANDT_OK;
+  (void)hipMemsetAsync(m->v.counts + m->v.n_maps, 0, 2 * sizeof(int32_t), m->ctx->stream);
+  if (d[1]) return randt_set_error(m->ctx, RANDT_ERR_INVALID, "an earlier asynchronous insert: cluster mean outside the map's index grid", hipSuccess);
+  return randt_set_error(m->ctx, RANDT_ERR_UNSUPPORTED, "an earlier asynchronous insert: map cell capacity exhausted", hipSuccess);
 }
 
 int randt_maps_insert_cells(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, int set_grid) {
@@ -553,7 +774,7 @@ int randt_maps_insert_cells(randt_maps* m, int idx, const randt_cell* h_cells, i
   if (n_cells == 0) return RANDT_OK;
   randt_ctx* ctx = m->ctx;
   randt_maps* tmp = nullptr;
-  int rc = randt_maps_create(ctx, 1, &m->p, n_cells, 0, &tmp);
+  int rc = maps_alloc(ctx, 1, &m->p, n_cells, 0, &tmp);  // pooled, fully overwritten by the upload
   if (rc) return rc;
   rc = randt_maps_upload(tmp, 0, h_cells, n_cells, nullptr);
   int dropped = 0, outside = 0;
@@ -572,19 +793,34 @@ int randt_maps_insert_cluster(randt_maps* m, int idx, const float* h_points, int
   if (accepted) *accepted = 0;
   if (n_points == 0) return RANDT_OK;
   randt_ctx* ctx = m->ctx;
-  randt_maps* tmp = nullptr;
-  int rc = randt_maps_create(ctx, 1, &m->p, 4, 0, &tmp);
-  if (rc) return rc;
+  // the one-cell scratch map lives as long as the context; only its geometry follows the target's
+  if (!ctx->tmp_cluster) {
+    int rc = randt_maps_create(ctx, 1, &m->p, 4, 0, &ctx->tmp_cluster);
+    if (rc) return rc;
+  }
+  randt_maps* tmp = ctx->tmp_cluster;
+  {
+    void *c = tmp->v.cells, *n = tmp->v.counts;
+    fill_view(tmp, 1, &m->p, 4);
+    tmp->v.cells = static_cast<randt_cell*>(c);
+    tmp->v.counts = static_cast<int32_t*>(n);
+    tmp->v.grid = nullptr;
+  }
   // one voxel that swallows every point: row = 1, res = 2 * max_range (grid.cpp:8-13) -> label 0 for |x|, |y| < res
   randt_cluster_params one;
   one.n_clusters = 1;
   one.max_range = 1.0e9f;
-  rc = randt_ndt_build(ctx, h_points, n_points, stride_floats, intensity_index, &one, tmp, 0);
+  int rc = randt_ndt_build(ctx, h_points, n_points, stride_floats, intensity_index, &one, tmp, 0);
+  if (rc) return rc;
+  if (!accepted && m->owns) {
+    // asynchronous: nothing comes back to the host; an unplaceable cell is reported by the next synchronising read
+    m->deferred_pending = true;
+    return launch_maps_append(ctx, m->v, idx, tmp->v, 0, 1, m->v.counts + m->v.n_maps, 1);
+  }
   int32_t cnt = 0;
-  if (!rc) rc = randt_maps_counts(tmp, 0, 1, &cnt);
+  rc = randt_maps_counts(tmp, 0, 1, &cnt);
   int dropped = 0, outside = 0;
   if (!rc && cnt > 0) rc = append_from(m, idx, tmp, 1, &dropped, &outside);
-  (void)randt_maps_destroy(tmp);
   if (rc) return rc;
   if (outside) return randt_set_error(ctx, RANDT_ERR_INVALID, "cluster mean outside the map's index grid", hipSuccess);
   if (dropped) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "map cell capacity exhausted", hipSuccess);
@@ -599,12 +835,17 @@ int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   if (n_queries == 0) return RANDT_OK;
   if (!h_queries || !h_out) return RANDT_ERR_INVALID;
   randt_maps* tmp = nullptr;
-  int rc = randt_maps_create(ctx, 1, &fixed->p, n_queries, 0, &tmp);
+  int rc = maps_alloc(ctx, 1, &fixed->p, n_queries, 0, &tmp);  // pooled, fully overwritten by the upload
   if (rc) return rc;
   rc = randt_maps_upload(tmp, 0, h_queries, n_queries, nullptr);
   char* d_blk = nullptr;
+  size_t blk_bytes = 0;
   const size_t corr_bytes = sizeof(int32_t) * (size_t)n_queries * k;
-  if (!rc && hipMalloc(&d_blk, 256 + corr_bytes) != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_NOMEM, "hipMalloc", hipErrorOutOfMemory);
+  if (!rc && randt_dev_alloc(ctx, reinterpret_cast<void**>(&d_blk), 256 + corr_bytes, &blk_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    d_blk = nullptr;
+    rc = randt_set_error(ctx, RANDT_ERR_NOMEM, "hipMalloc", hipErrorOutOfMemory);
+  }
   if (!rc) {
     const double ident[4] = {1.0, 0.0, 0.0, 0.0};
     double* d_pose = reinterpret_cast<double*>(d_blk);
@@ -616,13 +857,13 @@ int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
     if (!rc) rc = launch_associate(ctx, fixed->v, d_fi, tmp->v, 0, 1, d_pose, k, lookup_mahalanobis, use_intensity, d_corr);
     if (!rc) {
       e = hipMemcpyAsync(h_out, d_corr, corr_bytes, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) e = randt_sync(ctx);
       if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "closest cells read-back", e);
     } else {
-      (void)hipStreamSynchronize(ctx->stream);
+      (void)randt_sync(ctx);
     }
   }
-  if (d_blk) (void)hipFree(d_blk);
+  if (d_blk) randt_dev_release(ctx, d_blk, blk_bytes);
   (void)randt_maps_destroy(tmp);
   return rc;
 }
@@ -643,7 +884,7 @@ int cells_roundtrip(randt_ctx* ctx, int op, randt_cell* h_a, const randt_cell* h
   if (rc) return rc;
   if (h_out) RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_out, ws + off_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   else RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_a, ws, cb, hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   return RANDT_OK;
 }
 }  // namespace
@@ -675,7 +916,7 @@ int randt_points_transform(randt_ctx* ctx, float* h_points, int n_points, int st
   rc = launch_points_transform(ctx, (float*)ws, n_points, stride_floats, (const double*)(ws + off_pose));
   if (rc) return rc;
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_points, ws, pb, hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   return RANDT_OK;
 }
 
@@ -708,7 +949,7 @@ int randt_cell_add_points(randt_ctx* ctx, randt_cell* h_cell, const float* h_poi
   int32_t acc = 0;
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_cell, ws + off_cell, sizeof(randt_cell), hipMemcpyDeviceToHost, ctx->stream));
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&acc, ws + off_acc, sizeof(acc), hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   if (accepted) *accepted = acc;
   return RANDT_OK;
 }
@@ -720,17 +961,36 @@ int randt_maps_reindex(randt_maps* m, int first, int count) {
   return launch_maps_reindex(m->ctx, m->v, first, count);
 }
 
+// host poses for a kernel of this stream: the pinned ring (read by the device in place, nothing to wait for), else the
+// workspace + a synchronisation
+static int stage_poses(randt_ctx* ctx, const double* h_pose4, int count, const double** d_pose4, bool* must_sync) {
+  const size_t bytes = sizeof(double) * 4 * (size_t)count;
+  *must_sync = false;
+  if (void* pin = randt_pin_take(ctx, bytes)) {
+    memcpy(pin, h_pose4, bytes);
+    *d_pose4 = static_cast<const double*>(pin);
+    return RANDT_OK;
+  }
+  int rc = ensure_ws(ctx, bytes);
+  if (rc) return rc;
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_pose4, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *d_pose4 = static_cast<const double*>(ctx->ws);
+  *must_sync = true;  // ws is reused by the next call
+  return RANDT_OK;
+}
+
 int randt_maps_transform(randt_maps* m, int first, int count, const double* h_pose4) {
   DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!range_ok(m, first, count) || (count > 0 && !h_pose4)) return RANDT_ERR_INVALID;
   if (count == 0) return RANDT_OK;
   randt_ctx* ctx = m->ctx;
-  int rc = ensure_ws(ctx, sizeof(double) * 4 * count);
+  const double* d_pose4 = nullptr;
+  bool must_sync = false;
+  int rc = stage_poses(ctx, h_pose4, count, &d_pose4, &must_sync);
   if (rc) return rc;
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_pose4, sizeof(double) * 4 * count, hipMemcpyHostToDevice, ctx->stream));
-  rc = launch_maps_transform(ctx, m->v, first, count, (const double*)ctx->ws);
+  rc = launch_maps_transform(ctx, m->v, first, count, d_pose4);
   if (rc) return rc;
-  return randt_ctx_synchronize(ctx);  // ws is reused by the next call
+  return must_sync ? randt_ctx_synchronize(ctx) : RANDT_OK;
 }
 
 int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_first, int n_moving,
@@ -740,12 +1000,13 @@ int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving,
     return RANDT_ERR_INVALID;
   if (n_moving == 0) return RANDT_OK;
   randt_ctx* ctx = fixed->ctx;
-  int rc = ensure_ws(ctx, sizeof(double) * 4 * n_moving);
+  const double* d_pose4 = nullptr;
+  bool must_sync = false;
+  int rc = stage_poses(ctx, h_pose4, n_moving, &d_pose4, &must_sync);
   if (rc) return rc;
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ws, h_pose4, sizeof(double) * 4 * n_moving, hipMemcpyHostToDevice, ctx->stream));
-  rc = launch_maps_merge(ctx, fixed->v, fixed_idx, moving->v, moving_first, n_moving, (const double*)ctx->ws);
+  rc = launch_maps_merge(ctx, fixed->v, fixed_idx, moving->v, moving_first, n_moving, d_pose4);
   if (rc) return rc;
-  return randt_ctx_synchronize(ctx);
+  return must_sync ? randt_ctx_synchronize(ctx) : RANDT_OK;
 }
 
 // The solve kernels run the reference's GNC / trust-region loops ON THE DEVICE (`do { ... mu /= divisor } while (mu > 1 /
@@ -863,11 +1124,11 @@ int randt_register_pair(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   if (!rc) {
     hipError_t e3 = hipMemcpyAsync(h_pose4, d_pose, sizeof(double) * 4, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e4 = hipMemcpyAsync(&r, d_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream);
-    hipError_t e5 = hipStreamSynchronize(ctx->stream);
+    hipError_t e5 = randt_sync(ctx);
     if (e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
       rc = randt_set_error(ctx, RANDT_ERR_HIP, "download", e5 != hipSuccess ? e5 : (e3 != hipSuccess ? e3 : e4));
   } else {
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)randt_sync(ctx);
   }
   if (h_result) *h_result = r;
   return rc;
@@ -921,10 +1182,10 @@ int randt_cs_divergence(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   if (!rc) {
     e = hipMemcpyAsync(out, d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && h_terms) e = hipMemcpyAsync(h_terms, d_terms, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = randt_sync(ctx);
     if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "cs divergence read-back", e);
   } else {
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)randt_sync(ctx);
   }
   return rc;
 }
@@ -979,7 +1240,7 @@ int sc_db_reserve(randt_sc_db* db, int want) {
     RANDT_HIP_CHECK(ctx, hipMalloc(&fresh, sizeof(double) * a.per * cap));
     if (db->n > 0)
       RANDT_HIP_CHECK(ctx, hipMemcpyAsync(fresh, *a.p, sizeof(double) * a.per * db->n, hipMemcpyDeviceToDevice, ctx->stream));
-    RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RANDT_HIP_CHECK(ctx, randt_sync(ctx));
     if (*a.p) (void)hipFree(*a.p);
     *a.p = fresh;
   }
@@ -1044,7 +1305,7 @@ int randt_sc_db_append(randt_sc_db* db, const float* h_points, int n_points, int
   const double pd[3] = {odom_position[0], odom_position[1], traversed_distance};
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(db->pos + 2 * (size_t)db->n, pd, sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(db->dist + db->n, pd + 2, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the host buffers may go away
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));  // the host buffers may go away
   if (node_id) *node_id = db->n;
   db->n += 1;
   return RANDT_OK;
@@ -1066,7 +1327,7 @@ int randt_sc_db_detect(randt_sc_db* db, int node_id, int* loop_id, float* yaw_di
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&id, db->out_id, sizeof(id), hipMemcpyDeviceToHost, ctx->stream));
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(yaw_diff_rad, db->out_yaw, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(&md, db->out_md, sizeof(md), hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   *loop_id = id;
   if (min_dist) *min_dist = md;
   return RANDT_OK;
@@ -1084,7 +1345,7 @@ int randt_sc_db_download(const randt_sc_db* db, int node_id, double* h_desc, dou
   if (h_sector_key)
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_sector_key, db->sector + (size_t)db->p.num_sector * node_id, sizeof(double) * db->p.num_sector,
                                         hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   return RANDT_OK;
 }
 
@@ -1162,8 +1423,9 @@ int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   double min_cost = 100000.0;
   double best[4] = {1.0, 0.0, 0.0, 0.0};
   int evals = 0;
-  void* d_blk = nullptr;  // [guess4 | idx | n_res] + corr live in a private allocation (ws is used for poses / costs)
-  RANDT_HIP_CHECK(ctx, hipMalloc(&d_blk, 256 + corr_bytes));
+  void* d_blk = nullptr;  // [guess4 | idx | n_res] + corr live in a pooled block of their own (ws is used for poses / costs)
+  size_t blk_bytes = 0;
+  RANDT_HIP_CHECK(ctx, randt_dev_alloc(ctx, &d_blk, 256 + corr_bytes, &blk_bytes));
   double* d_guess = (double*)d_blk;
   int32_t* d_idx = (int32_t*)((char*)d_blk + 64);
   int32_t* d_nres = d_idx + 4;
@@ -1189,7 +1451,7 @@ int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
     if (rc) break;
     e = hipMemcpyAsync(h_cost.data(), d_cost, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&n_res, d_nres, sizeof(n_res), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = randt_sync(ctx);
     if (e != hipSuccess) { rc = randt_set_error(ctx, RANDT_ERR_HIP, "cost read-back", e); break; }
     evals += P;
     next_nodes.clear();
@@ -1229,8 +1491,7 @@ int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
     }
     level_nodes.swap(next_nodes);
   }
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_blk);
+  randt_dev_release(ctx, d_blk, blk_bytes);  // every level ended with a synchronisation: nothing reads it any more
   if (rc) return rc;
   memcpy(h_trans4, best, sizeof(best));  // trans = best_trans (identity if nothing qualified), :606
   if (min_cost_out) *min_cost_out = min_cost;
@@ -1463,7 +1724,7 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   char* back = img + 8192;
   const size_t back_span = off_res + sizeof(randt_result) - off_states;
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(back, ws + off_states, back_span, hipMemcpyDeviceToHost, ctx->stream));
-  RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
   memcpy(&r, back + (off_res - off_states), sizeof(r));
   h_packed = reinterpret_cast<double*>(back);
   for (int j = 0; j <= S; ++j) {

@@ -1,15 +1,13 @@
 // NDT construction kernels for gfx950 (compiled with -ffp-contract=off, see cell_math.h):
 //   k_ndt_build     one workgroup per radar scan: voxel key -> stable LDS counting sort -> per-cluster
 //                   fp32 mean / covariance / regularisation -> compact cell table + index grid
-//   k_maps_transform  Map::transformMap
-//   k_maps_merge      rolling-submap update (transform + Map::mergeMapCell), ordered
+// (Map::transformMap / mergeMapCell / insertCell live in mapops.hip.)
 //
 // Replaces (paths relative to /root/reference/ros/ndt_radar_slam/):
 //   src/radar_preprocessing/grid.cpp:7-14                      Grid::cluster
 //   src/radar_preprocessing/radar_preprocessor.cpp:151-169     ClusterGenerator::labelClouds
 //   src/ndt_representation/ndt_map.cpp:238-245                 Map::insertCluster
 //   src/ndt_representation/ndt_cell.cpp:25-114                 Cell::addPointCloud / updateCell
-//   src/ndt_representation/ndt_map.cpp:177-207, ndt_cell.h:133-142   transformMap / mergeMapCell / operator+=
 //
 // Data layout: points are read once from HBM as 16-byte (stride 4) or strided records, kept in registers while
 // they are sorted (scans <= 2048 points) and scattered as label-sorted SoA x/y/intensity into LDS; per-label
@@ -708,99 +706,6 @@ __global__ __launch_bounds__(BUILD_BLOCK) __attribute__((amdgpu_waves_per_eu(TP 
   if (tid == 0) out.counts[map] = n_cells < out.cap ? n_cells : out.cap;
 }
 
-__global__ __launch_bounds__(256) void k_maps_transform(MapView m, int first, int count, const double* __restrict__ pose4) {
-  const int map = first + blockIdx.y;
-  float aff[4];
-  pose_to_affine_f(pose4 + 4 * blockIdx.y, aff);
-  const int n = m.counts[map];
-  randt_cell* cells = m.cells + (size_t)map * m.cap;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    randt_cell c = load_cell(cells + i);
-    cell_transform(c, aff);
-    store_cell(cells + i, c);
-  }
-}
-
-// Single workgroup; moving maps applied strictly in order.  Within one moving map, cells that fall
-// into the same fixed slot are applied in cell order by the thread owning the first of them; new
-// cells receive compact indices in cell order (Map::insertCell).  LDS: slot[cap] u32 | scratch.
-__global__ __launch_bounds__(256) void k_maps_merge(MapView fixed, int fixed_idx, MapView moving, int moving_first,
-                                                    int n_moving, const double* __restrict__ pose4) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* slots = reinterpret_cast<uint32_t*>(smem);
-  int* scratch = reinterpret_cast<int*>(slots + moving.cap);
-  const int tid = threadIdx.x;
-  randt_cell* fcells = fixed.cells + (size_t)fixed_idx * fixed.cap;
-  int32_t* fgrid = fixed.grid + (size_t)fixed_idx * fixed.n_slots;
-  int n_cells = fixed.counts[fixed_idx];
-  for (int t = 0; t < n_moving; ++t) {
-    const int mmap = moving_first + t;
-    const randt_cell* mcells = moving.cells + (size_t)mmap * moving.cap;
-    const int M = moving.counts[mmap];
-    float aff[4];
-    pose_to_affine_f(pose4 + 4 * t, aff);
-    for (int i = tid; i < M; i += 256) {
-      randt_cell c = load_cell(mcells + i);
-      cell_transform(c, aff);
-      slots[i] = coord_to_index(fixed, c.mean[0], c.mean[1]);
-    }
-    __syncthreads();
-    for (int i0 = 0; i0 < M; i0 += 256) {
-      const int i = i0 + tid;
-      bool leader = false, insert = false;
-      uint32_t s = 0;
-      int32_t existing = -1;
-      if (i < M) {
-        s = slots[i];
-        if (s < (uint32_t)fixed.n_slots) {  // ndt_map.cpp:196
-          leader = true;
-          for (int j = 0; j < i; ++j)
-            if (slots[j] == s) { leader = false; break; }
-          if (leader) {
-            existing = fgrid[s];
-            insert = existing < 0;
-          }
-        }
-      }
-      int tot;
-      int newidx = n_cells + block_exclusive_scan_256(insert ? 1 : 0, scratch, &tot);
-      if (leader) {
-        int target = insert ? newidx : existing;
-        bool have = true;
-        randt_cell acc;
-        if (insert) {
-          if (newidx < fixed.cap) {
-            acc = load_cell(mcells + i);
-            cell_transform(acc, aff);
-            fgrid[s] = newidx;
-          } else {
-            have = false;  // capacity exhausted: drop (oracle does the same)
-          }
-        } else {
-          acc = load_cell(fcells + target);
-          randt_cell c = load_cell(mcells + i);
-          cell_transform(c, aff);
-          cell_merge(acc, c);
-        }
-        if (have) {
-          for (int j = i + 1; j < M; ++j) {
-            if (slots[j] == s) {
-              randt_cell c = load_cell(mcells + j);
-              cell_transform(c, aff);
-              cell_merge(acc, c);
-            }
-          }
-          store_cell(fcells + target, acc);
-        }
-      }
-      n_cells += tot;
-      if (n_cells > fixed.cap) n_cells = fixed.cap;
-    }
-    __syncthreads();  // workgroup-scope fence + barrier: next moving map sees this one's cells/grid
-  }
-  if (tid == 0) fixed.counts[fixed_idx] = n_cells;
-}
-
 }  // namespace
 
 int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points,
@@ -814,12 +719,12 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
     const size_t want = ndt_build_big_ws_bytes(n_scans, pitch, d_polar ? 1 : 0);
     if (want > ctx->build_ws_bytes) {
       if (ctx->build_ws) {
-        RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        RANDT_HIP_CHECK(ctx, hipFree(ctx->build_ws));
+        RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+        RANDT_HIP_CHECK(ctx, randt_hip_free(ctx, ctx->build_ws));
         ctx->build_ws = nullptr;
         ctx->build_ws_bytes = 0;
       }
-      RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->build_ws, want));
+      RANDT_HIP_CHECK(ctx, randt_hip_malloc(ctx, &ctx->build_ws, want));
       ctx->build_ws_bytes = want;
     }
     int rc = launch_ndt_build_big(ctx, d_points, n_scans, pitch, d_n_points, stride, ioff, cp, out, first_map, ctx->build_ws, d_polar, beam_cov9);
@@ -829,7 +734,7 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
     // synchronisation on this cold path -- and such scans are built again through the sorting path (ndt_build_big.hip).
     std::vector<int32_t> st((size_t)4 * n_scans);
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(st.data(), ctx->build_ws, sizeof(int32_t) * 4 * n_scans, hipMemcpyDeviceToHost, ctx->stream));
-    RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RANDT_HIP_CHECK(ctx, randt_sync(ctx));
     std::vector<int32_t> npts;
     for (int s = 0; s < n_scans; ++s) {
       if (st[4 * (size_t)s + 2] == 0) continue;
@@ -899,12 +804,12 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
     const size_t want = sizeof(int32_t) * 2 * (size_t)npad * n_scans + 256;
     if (want > ctx->build_ws_bytes) {
       if (ctx->build_ws) {
-        RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        RANDT_HIP_CHECK(ctx, hipFree(ctx->build_ws));
+        RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+        RANDT_HIP_CHECK(ctx, randt_hip_free(ctx, ctx->build_ws));
         ctx->build_ws = nullptr;
         ctx->build_ws_bytes = 0;
       }
-      RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->build_ws, want + want / 4));
+      RANDT_HIP_CHECK(ctx, randt_hip_malloc(ctx, &ctx->build_ws, want + want / 4));
       ctx->build_ws_bytes = want + want / 4;
     }
   }
@@ -931,99 +836,6 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
   else if (reg) RANDT_BUILD_LAUNCH(true, false);
   else RANDT_BUILD_LAUNCH(false, false);
 #undef RANDT_BUILD_LAUNCH
-  RANDT_HIP_CHECK(ctx, hipGetLastError());
-  return RANDT_OK;
-}
-
-// Map::insertCell / the tail of Map::insertCluster (ndt_map.h:137-140, ndt_map.cpp:242-243): append the cells of one
-// map to another in order; with set_grid the slot of each cell's mean points at its new compact index.  Sequential
-// by construction (a later cell overwrites the slot of an earlier one), so one lane does it.  status[0] counts cells
-// dropped for capacity, status[1] cells whose mean lies outside the index grid (std::vector::at throws there).
-__global__ __launch_bounds__(64) void k_maps_append(MapView dst, int dst_idx, MapView src, int src_idx, int set_grid,
-                                                    int32_t* __restrict__ status) {
-  if (threadIdx.x != 0) return;
-  const int n_src = min(src.counts[src_idx], src.cap);
-  int n = dst.counts[dst_idx];
-  randt_cell* dcells = dst.cells + (size_t)dst_idx * dst.cap;
-  const randt_cell* scells = src.cells + (size_t)src_idx * src.cap;
-  int32_t* grid = dst.grid ? dst.grid + (size_t)dst_idx * dst.n_slots : nullptr;
-  int dropped = 0, outside = 0;
-  for (int i = 0; i < n_src; ++i) {
-    const randt_cell c = load_cell(scells + i);
-    if (set_grid && grid) {
-      const uint32_t slot = coord_to_index(dst, c.mean[0], c.mean[1]);
-      if (slot >= (uint32_t)dst.n_slots) {
-        ++outside;
-        continue;
-      }
-      if (n >= dst.cap) {
-        ++dropped;
-        continue;
-      }
-      grid[slot] = n;
-    } else if (n >= dst.cap) {
-      ++dropped;
-      continue;
-    }
-    store_cell(dcells + n, c);
-    ++n;
-  }
-  dst.counts[dst_idx] = n;
-  if (status) {
-    status[0] = dropped;
-    status[1] = outside;
-  }
-}
-
-// Rebuild the index grid of a map from its cells' current means (later cells win a shared slot, as insertion order
-// would have it).  The reference never does this after Map::transformMap (ndt_map.cpp:177-182 leaves grid_indizes_
-// stale); this is the opt-in repair.  One workgroup per map.
-__global__ __launch_bounds__(256) void k_maps_reindex(MapView m, int first) {
-  const int map = first + blockIdx.x;
-  if (!m.grid) return;
-  int32_t* grid = m.grid + (size_t)map * m.n_slots;
-  const randt_cell* cells = m.cells + (size_t)map * m.cap;
-  const int n = min(m.counts[map], m.cap);
-  for (int s = threadIdx.x; s < m.n_slots; s += 256) grid[s] = -1;
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const uint32_t slot = coord_to_index(m, cells[i].mean[0], cells[i].mean[1]);
-    if (slot < (uint32_t)m.n_slots) atomicMax(&grid[slot], i);
-  }
-}
-
-int launch_maps_reindex(randt_ctx* ctx, const MapView& m, int first, int count) {
-  if (count <= 0) return RANDT_OK;
-  hipLaunchKernelGGL(k_maps_reindex, dim3(count), dim3(256), 0, ctx->stream, m, first);
-  RANDT_HIP_CHECK(ctx, hipGetLastError());
-  return RANDT_OK;
-}
-
-int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,
-                       int32_t* d_status) {
-  hipLaunchKernelGGL(k_maps_append, dim3(1), dim3(64), 0, ctx->stream, dst, dst_idx, src, src_idx, set_grid, d_status);
-  RANDT_HIP_CHECK(ctx, hipGetLastError());
-  return RANDT_OK;
-}
-
-int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count, const double* d_pose4) {
-  if (count <= 0) return RANDT_OK;
-  int bx = (m.cap + 255) / 256;
-  if (bx > 64) bx = 64;
-  hipLaunchKernelGGL(k_maps_transform, dim3(bx, count), dim3(256), 0, ctx->stream, m, first, count, d_pose4);
-  RANDT_HIP_CHECK(ctx, hipGetLastError());
-  return RANDT_OK;
-}
-
-int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const MapView& moving, int moving_first,
-                      int n_moving, const double* d_pose4) {
-  if (n_moving <= 0) return RANDT_OK;
-  size_t lds = (size_t)moving.cap * 4 + 64;
-  if (lds > (size_t)ctx->lds_limit) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "moving map capacity too large for merge kernel", hipSuccess);
-  RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_maps_merge),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_maps_merge, dim3(1), dim3(256), lds, ctx->stream, fixed, fixed_idx, moving, moving_first,
-                     n_moving, d_pose4);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }

@@ -486,12 +486,12 @@ int launch_ndt_build_big_wide(randt_ctx* ctx, const float* d_points, int n, int 
   const size_t need = 256 + 9 * (npad + 64) * 4 + (d_polar ? 2 * npad * 4 : 0) + t_tmp + 4096;
   if (need > ctx->build_wide_ws_bytes) {
     if (ctx->build_wide_ws) {
-      RANDT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-      (void)hipFree(ctx->build_wide_ws);
+      RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+      (void)randt_hip_free(ctx, ctx->build_wide_ws);
       ctx->build_wide_ws = nullptr;
       ctx->build_wide_ws_bytes = 0;
     }
-    RANDT_HIP_CHECK(ctx, hipMalloc(&ctx->build_wide_ws, need));
+    RANDT_HIP_CHECK(ctx, randt_hip_malloc(ctx, &ctx->build_wide_ws, need));
     ctx->build_wide_ws_bytes = need;
   }
   char* w = static_cast<char*>(ctx->build_wide_ws);

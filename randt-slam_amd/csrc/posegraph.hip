@@ -825,7 +825,8 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
   carve();  // sizing pass
   const size_t bytes = cv.off + 256;
   char* blk = nullptr;
-  RANDT_HIP_CHECK(ctx, hipMalloc(&blk, bytes));
+  size_t blk_bytes = 0;
+  RANDT_HIP_CHECK(ctx, randt_dev_alloc(ctx, reinterpret_cast<void**>(&blk), bytes, &blk_bytes));  // the context's storage pool (api.hip)
   cv = Carver{blk, 0};
   carve();
   d.ia = d_ia; d.ib = d_ib; d.meas = d_meas; d.sqi = d_sqi; d.inc_off = d_inc_off; d.inc_ent = d_inc_ent;
@@ -984,8 +985,8 @@ int randt_pose_graph_optimize(randt_ctx* ctx, int n_poses, double* h_poses, int 
     }
   }
 #undef PG_TRY
-  (void)hipStreamSynchronize(st);
-  (void)hipFree(blk);
+  (void)randt_sync(ctx);
+  randt_dev_release(ctx, blk, blk_bytes);
   if (rc != RANDT_OK) return rc;
   memcpy(h_poses, best.data(), sizeof(double) * 3 * (size_t)n_poses);
   if (out) {

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 
 #include "randt.h"
@@ -61,13 +62,46 @@ struct randt_ctx {
   int assoc_tp_ppw = 4;      // pairs per association workgroup when batches share the chip (RANDT_ASSOC_TP_PPW)
   int assoc_tp_ch = 64;      // cells per chunk of the association when batches share the chip (16 / 32 / 48 / 64; RANDT_ASSOC_TP_CH)
   int assoc_stage_grid = 0;  // 1: stage the fixed map's index grid in LDS; 0: gather it from L2 (same speed alone, but 36 KB instead of 76 KB of LDS leaves room for co-running build workgroups: +2 % end to end)
+  // ---- device storage pool (api.hip, randt_dev_alloc / randt_dev_release): the blocks of destroyed map batches and of the
+  // host-level entries' temporaries are kept and handed out again.  A block goes back the moment its owner is destroyed,
+  // WITHOUT a synchronisation: everything a context does is enqueued on its one stream, so whatever is enqueued on the
+  // block's next owner runs after the previous owner's last kernel.  (A map batch that another context's stream still reads
+  // must not be destroyed -- which was already the rule when destroy only synchronised its own stream.)
+  std::multimap<size_t, void*> pool_free;  // block size -> block
+  size_t pool_bytes = 0;                   // bytes parked in pool_free
+  size_t pool_cap = (size_t)1 << 30;       // park at most this much (RANDT_POOL_MAX_BYTES); beyond it blocks are really freed
+  randt_pool_stats stats{};                // allocator / synchronisation counters (randt_ctx_pool_stats)
+  // ---- pinned, device-visible argument ring (randt_pin_take): poses, indices and scan points of the host-level entries are
+  // written here by the host and read by the device (kernels directly, or an async copy) -- no pageable staging copy, no
+  // synchronisation "because the buffer is reused": a segment is only reused after the event recorded behind its last user
+  char* pin_ring = nullptr;
+  static constexpr int kPinSegs = 4;
+  static constexpr size_t kPinSegBytes = 512 * 1024;
+  int pin_cur = 0;
+  size_t pin_off = 0;
+  hipEvent_t pin_ev[kPinSegs] = {nullptr, nullptr, nullptr, nullptr};
+  bool pin_pending[kPinSegs] = {false, false, false, false};
+  randt_maps* tmp_cluster = nullptr;  // one-cell scratch map of randt_maps_insert_cluster (created once per context)
 };
+
+// counted wrappers (randt_ctx_pool_stats reports them; tests assert a steady-state scan of the drop-in drive makes none)
+hipError_t randt_dev_alloc(randt_ctx* ctx, void** p, size_t bytes, size_t* granted = nullptr);  // pool first, hipMalloc otherwise
+void randt_dev_release(randt_ctx* ctx, void* p, size_t bytes);                                   // back to the pool (bytes = what was granted)
+hipError_t randt_hip_malloc(randt_ctx* ctx, void** p, size_t bytes);  // plain hipMalloc, counted (grow-only workspaces)
+hipError_t randt_hip_free(randt_ctx* ctx, void* p);
+hipError_t randt_sync(randt_ctx* ctx);                                // hipStreamSynchronize(ctx->stream), counted
+// bytes of pinned host memory the device can read under the same address, valid until the stream has passed the work
+// enqueued next; nullptr if the request is larger than a segment (callers fall back to a pageable copy + synchronisation)
+void* randt_pin_take(randt_ctx* ctx, size_t bytes);
 
 struct randt_maps {
   randt_ctx* ctx = nullptr;
   randt_map_params p{};
   MapView v{};
   bool owns = false;
+  void* block = nullptr;    // owns: ONE pooled block [cells | counts | 2 deferred-status words | grid]
+  size_t block_bytes = 0;
+  bool deferred_pending = false;  // an asynchronous insert has run since the last synchronising read (api.hip, deferred_status)
 };
 
 // Parameters of the solve kernel (POD copy of randt_matcher_params + derived values).
@@ -115,7 +149,7 @@ int launch_ndt_build_big_wide(randt_ctx* ctx, const float* d_points, int n, int 
 int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count, const double* d_pose4);
 int launch_maps_reindex(randt_ctx* ctx, const MapView& m, int first, int count);
 int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,
-                       int32_t* d_status);
+                       int32_t* d_status, int accumulate /* status[] += instead of = */);
 int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const MapView& moving, int moving_first,
                       int n_moving, const double* d_pose4);
 int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,

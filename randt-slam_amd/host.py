@@ -95,6 +95,15 @@ class Context:
         _capi.SOLVE_THROUGHPUT (always one wavefront each: several batches in flight on several contexts)."""
         self._check(self._lib.randt_ctx_set_solve_mode(self._h, int(mode)), "randt_ctx_set_solve_mode")
 
+    def pool_stats(self):
+        """randt_ctx_pool_stats: allocator / synchronisation counters of the context and what its storage pool holds."""
+        st = _capi.PoolStats()
+        self._check(self._lib.randt_ctx_pool_stats(self._h, C.byref(st)), "randt_ctx_pool_stats")
+        return {k: int(getattr(st, k)) for k, _ in _capi.PoolStats._fields_ if k != "reserved"}
+
+    def pool_trim(self):
+        self._check(self._lib.randt_ctx_pool_trim(self._h), "randt_ctx_pool_trim")
+
     def set_trace(self, d_trace, max_len):
         self._check(self._lib.randt_ctx_set_trace(self._h, _dptr(d_trace), int(max_len)), "randt_ctx_set_trace")
 
@@ -191,6 +200,17 @@ class Maps:
         count = self.n_maps - first if count is None else count
         out = np.zeros(count, dtype=np.int32)
         self.ctx._check(self._lib.randt_maps_counts(self._h, first, count, _dptr(out)), "randt_maps_counts")
+        return out
+
+    def clone(self, first=0, count=None):
+        """randt_maps_clone: a new library-owned batch holding a copy of maps [first, first + count) (Map's copy constructor)."""
+        count = self.n_maps - first if count is None else count
+        h = C.c_void_p()
+        self.ctx._check(self._lib.randt_maps_clone(self._h, first, count, C.byref(h)), "randt_maps_clone")
+        out = Maps.__new__(Maps)
+        out.ctx, out._lib = self.ctx, self._lib
+        out.n_maps, out.capacity, out.params, out.n_slots = int(count), self.capacity, self.params, self.n_slots
+        out.with_grid, out._storage, out._h = self.with_grid, None, h
         return out
 
     def copy_from(self, src, dst_first=0, src_first=0, count=None):

@@ -59,3 +59,27 @@ def test_cpp_local_fuser_drive_matches_the_python_harness_and_the_golden_fixture
 
     gold = np.load(os.path.join(ROOT, "tests", "golden", "odometry_drive.npz"))
     assert np.abs(cpp - gold["poses4"]).max() <= 1e-6, np.abs(cpp - gold["poses4"]).max()
+
+
+def test_cpp_drive_from_host_buffers_makes_no_allocator_call_in_steady_state(built):
+    """Round-4 verdict, item 1: the reference-shaped drive (Maps by value, every copy local_fuser.cpp:128-136,173-178 makes; host
+    pcl::PointXYZI buffers) behind the context's storage pool and pinned ring: per steady-state scan NO hipMalloc / hipFree and at
+    most two host waits on the stream (one is inherent: the window solve's result), the same poses whatever the point layout or the
+    insertion call, and a rate within 1.15 x of the Python harness that keeps everything resident (bench.py's two sections)."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    py = bench.streaming_odometry(ctx, 300, False)
+    out = bench.cpp_local_fuser_drive(ctx, 300, py["ms_per_scan"])
+    for leg in ("add_scan_packed", "add_scan_pointxyzi", "add_clusters_pointxyzi"):
+        j = out[leg]
+        assert j["device_allocs_per_scan"] == 0 and j["device_frees_per_scan"] == 0, (leg, j)
+        assert j["stream_syncs_per_scan"] <= 2.0, (leg, j)
+        assert j["pool_hits_per_scan"] >= 5, (leg, j)        # the Map copies are there, and they are served from parked blocks
+    assert out["add_scan_pointxyzi"]["submaps_finished"] == 2
+    assert out["poses_equal_across_legs"]["packed_vs_pointxyzi_max_abs"] == 0.0
+    assert out["poses_equal_across_legs"]["add_scan_vs_add_clusters_max_abs"] == 0.0   # cluster by cluster = the one-launch build, bit for bit
+    assert out["cpp_over_python_resident"] <= 1.15, out

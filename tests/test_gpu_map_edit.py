@@ -97,3 +97,66 @@ def test_closest_cells_match_the_oracle_search(env):
     got7 = fixed.closest_cells(0, q[:8], k=7)
     want7, _ = po.associate(sub, scan, ident, k=7, lookup_mahalanobis=True, use_intensity=True)
     assert np.array_equal(got7, want7[:8])
+
+
+def test_storage_pool_reuses_blocks_and_clones_are_exact(built):
+    """Round-4 verdict, item 1(a): destroyed batches park their storage in the context's pool (no hipFree, no synchronisation),
+    created / cloned batches take it from there (no hipMalloc); a recycled block starts as clean as a fresh one; randt_maps_clone
+    = create + copy in one launch; the pool can be trimmed and switched off (RANDT_POOL_MAX_BYTES=0 is exercised by the bench)."""
+    import ctypes as C
+
+    import torch
+
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    mapp, clu = R.indoor_map_params(), R.indoor_cluster_params()
+    d_pts = torch.from_numpy(_scan(1200)[None]).cuda()
+
+    a = R.Maps(ctx, 1, mapp, 600, with_grid=True)
+    R.ndt_build_batch(ctx, d_pts, clu, a)
+    cells_a, grid_a = a.download(0)
+    assert len(cells_a) > 20
+    s0 = ctx.pool_stats()
+    b = a.clone()                      # a pool miss: nothing is parked yet
+    s1 = ctx.pool_stats()
+    assert s1["device_allocs"] == s0["device_allocs"] + 1 and s1["pool_hits"] == s0["pool_hits"] and s1["stream_syncs"] == s0["stream_syncs"]
+    cells_b, grid_b = b.download(0)
+    assert cells_b.tobytes() == cells_a.tobytes() and np.array_equal(grid_a, grid_b)
+    s1 = ctx.pool_stats()
+    b.close()                          # parks the block: no free, no synchronisation
+    s2 = ctx.pool_stats()
+    assert s2["device_frees"] == s1["device_frees"] and s2["stream_syncs"] == s1["stream_syncs"]
+    assert s2["pool_blocks"] == 1 and s2["pool_bytes"] >= 600 * 48 + 4 * 10000
+    c = R.Maps(ctx, 1, mapp, 600, with_grid=True)       # same size: served from the pool, and CLEAN although the block held a map
+    s3 = ctx.pool_stats()
+    assert s3["device_allocs"] == s2["device_allocs"] and s3["pool_hits"] == s2["pool_hits"] + 1 and s3["pool_blocks"] == 0
+    cells_c, grid_c = c.download(0)
+    assert len(cells_c) == 0 and (grid_c == -1).all()
+    # ... over its whole capacity, like a fresh one (the cells behind `count` are what randt_maps_copy / RCCL broadcasts move)
+    d_cells = C.c_void_p()
+    ctx._check(ctx._lib.randt_maps_device_ptrs(c._h, C.byref(d_cells), None, None), "randt_maps_device_ptrs")
+    whole = torch.ones(600 * 48, dtype=torch.uint8, device="cuda")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(C.c_void_p(whole.data_ptr()), d_cells, 600 * 48, 3) == 0
+    assert int(whole.cpu().numpy().astype(np.int64).sum()) == 0
+    # a much smaller request does not take a big block (<= 2x rule): the 70 KB class is not handed to a 3 KB scan map
+    c.close()
+    small = R.Maps(ctx, 1, mapp, 64, with_grid=False)
+    s4 = ctx.pool_stats()
+    assert s4["pool_blocks"] == 1 and s4["device_allocs"] == s3["device_allocs"] + 1
+    small.close()
+    ctx.pool_trim()
+    s5 = ctx.pool_stats()
+    assert s5["pool_blocks"] == 0 and s5["pool_bytes"] == 0 and s5["device_frees"] == s4["device_frees"] + 2
+    # merges / transforms take their poses through the pinned ring: no synchronisation, same result as the oracle-checked paths
+    m = a.clone()
+    sub = R.Maps(ctx, 1, mapp, mapp.size_x * mapp.size_y, with_grid=True)
+    before = ctx.pool_stats()["stream_syncs"]
+    m.transform(0, np.array([[np.cos(0.3), np.sin(0.3), 1.0, -2.0]]))
+    sub.merge(0, a, 0, np.array([[1.0, 0.0, 0.0, 0.0]]))
+    assert ctx.pool_stats()["stream_syncs"] == before
+    got, _ = sub.download(0)
+    assert 20 < len(got) <= len(cells_a)      # (cells that share a slot are merged, all others inserted)
+    moved, _ = m.download(0)
+    c3, s3_ = np.cos(0.3), np.sin(0.3)
+    assert np.allclose(moved["mean"][:, 0], c3 * cells_a["mean"][:, 0] - s3_ * cells_a["mean"][:, 1] + 1.0, atol=1e-5)
