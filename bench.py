@@ -1027,11 +1027,43 @@ def polar_filter(ctx, n_scans):
         long_launch = {"scans_per_launch": 64, "ms": t64 * 1e3, "achieved": 4 * nbytes / t64 / 1e9, "frac": 4 * nbytes / t64 / 1e9 / HBM_PEAK_GBS,
                        "status_ok": bool((status64 == 0).all().item()), "same_counts": bool((counts64.view(4, 16) == counts.view(1, 16)).all().item())}
         del raw64, out64
+    # ONE scan per launch -- what the online node runs (a 4 Hz sensor hands over one scan at a time): (a) a lone launch between
+    # two host synchronisations, median of 30, each over another of the 16 distinct scans; (b) the same launches as a chain of 64
+    single_scan = None
+    if n_scans >= 2:
+        o1 = torch.zeros((1, pitch, 4), dtype=torch.float32, device=dev)
+        c1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        s1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        for i in range(n_scans):
+            host.filter_scan_batch(ctx, raw[i:i + 1], fp, o1, c1, s1)
+        torch.cuda.synchronize()
+        lone = []
+        for i in range(30):
+            e[0].record(st)
+            host.filter_scan_batch(ctx, raw[i % n_scans:i % n_scans + 1], fp, o1, c1, s1)
+            e[1].record(st)
+            torch.cuda.synchronize()
+            lone.append(e[0].elapsed_time(e[1]) * 1e-3)
+        t1 = float(np.median(lone))
+        e[0].record(st)
+        for i in range(64):
+            host.filter_scan_batch(ctx, raw[i % n_scans:i % n_scans + 1], fp, o1, c1, s1)
+        e[1].record(st)
+        torch.cuda.synchronize()
+        tc = e[0].elapsed_time(e[1]) / 64 * 1e-3
+        b1 = nbytes // n_scans
+        single_scan = {"us": t1 * 1e6, "achieved": b1 / t1 / 1e9, "frac": b1 / t1 / 1e9 / HBM_PEAK_GBS,
+                       "chain_us_per_launch": tc * 1e6, "chain_frac": b1 / tc / 1e9 / HBM_PEAK_GBS, "bytes": b1,
+                       "same_count_as_batched": bool(int(c1.item()) == int(counts[63 % n_scans].item())), "status_ok": bool(int(s1.item()) == 0),
+                       "note": "k_filter_rows + k_filter_emit of ONE 400 x 3000 scan (19.2 MB), HIP events; a kernel of this shape that only loads "
+                               "takes 5.6 us launched alone (tools/filter_ticket_probe.hip: 0.43 of 8 TB/s is what one scan per launch can reach)"}
     roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": nbytes / t_f / 1e9, "frac": nbytes / t_f / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes": nbytes, "traffic": None,
             "note": "f-1 stage end to end (k_filter_rows + k_filter_emit, HIP events on the launch stream): raw polar bytes read once / duration "
                     "of ONE launch between two host synchronisations; back_to_back: the same launch as a stream of 20 over four distinct inputs; "
                     "long_launch: 64 scans (1.23 GB) in one launch"}
+    if single_scan:
+        roof["single_scan"] = single_scan
     if long_launch:
         roof["long_launch"] = long_launch
     if t_bb:

@@ -1809,43 +1809,54 @@ static int win_eval(void* user, const double* x, double* cost, double* residuals
     /* vector form: NDTFrameToMap{,Intensity}FactorResidual on (pos, rot) (ceres_residuals.h:421-451, 486-518) */
     const double pv[4] = {cos(st[j].rot), sin(st[j].rot), st[j].pos[0], st[j].pos[1]};
     int bad = 0;
+    /* one NDT residual block of state j: the statement of the sequential loop and of the timing-only OpenMP loop below */
+#define WIN_NDT_BLOCK(TOTAL, BAD)                                                                                          \
+  do {                                                                                                                     \
+        const int d = u->d;                                                                                                \
+        const int rw_i = row + (at - ndt_at);                                                                              \
+        double jl[4];                                                                                                      \
+        double r = orc_ndt_residual(d, u->vec ? (u->analytic ? ORC_PARAM_ANALYTIC : ORC_PARAM_VECTOR) : ORC_PARAM_MANIFOLD, u->vec ? pv : st[j].pose, u->mm + (size_t)at * d,\
+                                    u->mc + (size_t)at * d * d, u->fm + (size_t)at * d, u->fc + (size_t)at * d * d, jac ? jl : NULL);\
+        if (!isfinite(r)) {                                                                                                \
+          (BAD) |= 1;                                                                                                      \
+          break;                                                                                                           \
+        }                                                                                                                  \
+        const double sq = r * r;                                                                                           \
+        double rs = 1.0, js = 1.0;                                                                                         \
+        if (u->apply_loss) {                                                                                               \
+          double rho[3];                                                                                                   \
+          orc_barron_scaled(sq, u->loss_a, u->loss_alpha, u->loss_mu, u->loss_w, rho);                                     \
+          (TOTAL) += 0.5 * rho[0];                                                                                         \
+          const double sqrt_rho1 = sqrt(rho[1]);                                                                           \
+          if (sq == 0.0 || rho[2] <= 0.0) {                                                                                \
+            rs = js = sqrt_rho1;                                                                                           \
+          } else {                                                                                                         \
+            const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];                                                             \
+            const double alpha = 1.0 - sqrt(D);                                                                            \
+            rs = sqrt_rho1 / (1 - alpha);                                                                                  \
+            js = sqrt_rho1 * (1.0 - alpha);                                                                                \
+          }                                                                                                                \
+        } else {                                                                                                           \
+          (TOTAL) += 0.5 * sq;                                                                                             \
+        }                                                                                                                  \
+        if (residuals) residuals[rw_i] = rs * r;                                                                           \
+        if (jac) {                                                                                                         \
+          double* rw = jac + (size_t)rw_i * nt;                                                                            \
+          for (int e = 0; e < 3; ++e) rw[u->off_tan[j][0] + e] = js * jl[e];                                               \
+        }                                                                                                                  \
+  } while (0)
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(g_eval_threads) reduction(+ : total) reduction(| : bad) if (g_eval_threads > 1)
+    if (g_eval_threads > 1) { /* timing only (orc_set_eval_threads): another summation order */
+#pragma omp parallel for schedule(static) num_threads(g_eval_threads) reduction(+ : total) reduction(| : bad)
+      for (int at = ndt_at; at < ndt_end; ++at) WIN_NDT_BLOCK(total, bad);
+    } else
 #endif
-    for (int at = ndt_at; at < ndt_end; ++at) {
-      const int d = u->d;
-      const int rw_i = row + (at - ndt_at);
-      double jl[4];
-      double r = orc_ndt_residual(d, u->vec ? (u->analytic ? ORC_PARAM_ANALYTIC : ORC_PARAM_VECTOR) : ORC_PARAM_MANIFOLD, u->vec ? pv : st[j].pose, u->mm + (size_t)at * d,
-                                  u->mc + (size_t)at * d * d, u->fm + (size_t)at * d, u->fc + (size_t)at * d * d, jac ? jl : NULL);
-      if (!isfinite(r)) {
-        bad |= 1;
-        continue;
-      }
-      const double sq = r * r;
-      double rs = 1.0, js = 1.0;
-      if (u->apply_loss) {
-        double rho[3];
-        orc_barron_scaled(sq, u->loss_a, u->loss_alpha, u->loss_mu, u->loss_w, rho);
-        total += 0.5 * rho[0];
-        const double sqrt_rho1 = sqrt(rho[1]);
-        if (sq == 0.0 || rho[2] <= 0.0) {
-          rs = js = sqrt_rho1;
-        } else {
-          const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
-          const double alpha = 1.0 - sqrt(D);
-          rs = sqrt_rho1 / (1 - alpha);
-          js = sqrt_rho1 * (1.0 - alpha);
-        }
-      } else {
-        total += 0.5 * sq;
-      }
-      if (residuals) residuals[rw_i] = rs * r;
-      if (jac) {
-        double* rw = jac + (size_t)rw_i * nt;
-        for (int e = 0; e < 3; ++e) rw[u->off_tan[j][0] + e] = js * jl[e];
-      }
+    {
+      /* default: strictly sequential sums, ((total + t1) + t2) + ... -- an `if (0)` OpenMP reduction would still add a private
+         partial sum to total at the end, i.e. total + (t1 + t2 + ...) */
+      for (int at = ndt_at; at < ndt_end; ++at) WIN_NDT_BLOCK(total, bad);
     }
+#undef WIN_NDT_BLOCK
     if (bad) return 0;
     row += ndt_end - ndt_at;
     ndt_at = ndt_end;

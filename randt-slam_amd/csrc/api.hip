@@ -1624,7 +1624,9 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   if (mp->parameterization != RANDT_PARAM_MANIFOLD && mp->parameterization != RANDT_PARAM_VECTOR && mp->parameterization != RANDT_PARAM_ANALYTIC)
     return randt_set_error(ctx, RANDT_ERR_INVALID, "window solve: parameterization must be RANDT_PARAM_MANIFOLD, _VECTOR or _ANALYTIC", hipSuccess);
   const bool vec = mp->parameterization != RANDT_PARAM_MANIFOLD;
-  if (mp->n_neighbours <= 0 || mp->n_neighbours > 8) return RANDT_ERR_INVALID;
+  if (mp->n_neighbours <= 0) return randt_set_error(ctx, RANDT_ERR_INVALID, "n_neighbours must be >= 1", hipSuccess);
+  if (mp->n_neighbours > 8)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window solve: n_neighbours <= 8 (the pair registration takes up to 16; every shipped configuration uses 4)", hipSuccess);
   {
     const int prc = check_matcher_params(ctx, mp);
     if (prc) return prc;

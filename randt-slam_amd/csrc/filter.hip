@@ -5,14 +5,14 @@
 // per azimuth the strongest return inside (min_range, max_range), then the run of monotonically
 // decreasing intensity around it, thresholded by min_intensity, transformed sensor -> base.
 //
-//   k_filter_rows   one WAVEFRONT per azimuth row (four rows per 256-thread workgroup, no barrier, no LDS).  Per row:
+//   k_filter_rows   one 256-thread WORKGROUP per azimuth row (round 5; rounds 3 / 4: history below).  Per row:
 //                   1. the row of the raw polar scan (16 B / point, 19.2 MB for 400 x 3000) is read exactly once with
-//                      coalesced dwordx4 loads, twelve of them in flight per lane as a ring that never drains before
-//                      the row ends; the arg-max (strict '>', first index wins) stays in registers and is combined by
-//                      shuffles; the same pass checks that the cloud really is organised azimuth after azimuth (the
-//                      reference detects azimuth changes with |atan2 - current| > 1e-4 while walking the cloud
+//                      coalesced dwordx4 loads, twelve per lane = the whole row in flight at once; the arg-max (strict '>',
+//                      first index wins) stays in registers, is combined by shuffles and, over the four wavefronts, through
+//                      LDS behind ONE barrier; the same pass checks that the cloud really is organised azimuth after azimuth
+//                      (the reference detects azimuth changes with |atan2 - current| > 1e-4 while walking the cloud
 //                      sequentially): a cross / dot test flags, a flagged row is walked again with the exact atan2f;
-//                   2. the row's detection is expanded towards / away from the sensor by the same wavefront while the
+//                   2. the row's detection is expanded towards / away from the sensor by wavefront 0 while the
 //                      row is cache-hot (expand_both below); the same loads count the run's points that pass the output
 //                      thresholds and -- for runs of <= FILT_STAGE kept points that end within 32 bins on both sides:
 //                      nearly all -- produce the output points themselves (the "stage"); a 32-byte row record.
@@ -22,15 +22,18 @@
 //                   and stage arrive in one round trip), the others re-read their run, eight independent loads at a time.
 // Measured (16 scans per launch, 307 MB, rocprofv3 averages; a bare read of the same bytes takes 44 .. 45 us when consecutive
 // launches meet their lines in the 256 MB Infinity Cache and 48.4 .. 49.5 us per 307 MB of a 1.2 GB buffer, i.e. from HBM:
-// tools/hbm_stream_probe.hip):
-//   rounds 3 / early 4  a WORKGROUP per row, barrier between arg-max and expansion: 58.2 + 7.6 (emission) us; with expansion
-//                       and per-point tests compiled out still 53.6: it paid for the barrier, behind which four wavefronts
+// tools/hbm_stream_probe.hip; 51.5 us as launches of 16 scans over distinct inputs):
+//   rounds 3 / early 4  a PERSISTENT workgroup walking rows, barrier between arg-max and expansion: 58.2 + 7.6 (emission) us; with
+//                       expansion and per-point tests compiled out still 53.6: it paid for the barrier, behind which four wavefronts
 //                       have nothing in flight; next row in a second register set (191 registers, two per CU) 93;
 //                       non-temporal row loads 100; 96 / 80 registers (spills) 84 / 104; emission behind a ticket per row 130;
 //                       next row's loads issued before the barrier (+ a fifth wavefront for the expansion) 54 .. 69
-//   this file           wavefront per row 54.8 -> ring of loads 53.2 -> exact test out of the loop, scalar row base, one
-//                       dwordx4 per point 51.4; 4 .. 16 loads per lane x 3 .. 6 wavefronts per SIMD: all within 1 us (the
-//                       kernel sits on what HBM gives a read-only stream); emission 7.6 -> 5.6 us with the stage
+//   round 4             wavefront per row 54.8 -> ring of loads 53.2 -> exact test out of the loop, scalar row base, one
+//                       dwordx4 per point 51.4 over one input, 56.3 .. 56.6 over distinct inputs; emission 7.6 -> 5.6 us with the
+//                       stage.  ONE scan per launch: 11.97 + 5.22 us = 0.14 of 8 TB/s (400 wavefronts, 47 dependent rounds each)
+//   round 5 (this file) a workgroup per ROW (not persistent: three wavefronts retire at the barrier, the dispatcher refills):
+//                       52.6 + 5.6 us over distinct inputs, ONE scan 7.9 + 4.4 us (profiles/experiments/r05_filter_workgroup_per_row.md;
+//                       the emission folded into the row kernel behind a per-scan ticket: +12 .. +290 us, priced there)
 #include "randt_internal.h"
 
 #include <math.h>
@@ -94,7 +97,7 @@ __device__ __forceinline__ void fetch(const FilterArgs& A, const float* base, lo
     const float4 p = reinterpret_cast<const float4*>(base)[i];
     x = p.x;
     y = p.y;
-    in = A.ioff == 3 ? p.w : (A.ioff == 2 ? p.z : p.x);
+    in = A.ioff == 3 ? p.w : (A.ioff == 2 ? p.z : (A.ioff == 1 ? p.y : p.x));
   } else {
     const float* p = base + (size_t)i * A.stride;
     x = p[0];
@@ -109,21 +112,21 @@ __device__ __forceinline__ bool keep_point(const FilterArgs& A, float x, float y
 }
 
 template <int NW>
-__device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total) {
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long* scratch, unsigned long long* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = v;
+  unsigned long long incl = v;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(incl, off, 64);
+    const unsigned long long t = __shfl_up(incl, off, 64);
     if (lane >= off) incl += t;
   }
   __syncthreads();
   if (lane == 63) scratch[wave] = incl;
   __syncthreads();
-  int base = 0, tot = 0;
+  unsigned long long base = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
-    const int s = scratch[w];
+    const unsigned long long s = scratch[w];
     if (w < wave) base += s;
     tot += s;
   }
@@ -146,7 +149,7 @@ __device__ __forceinline__ float fetch_z(const FilterArgs& A, const float* base,
 }
 template <bool PACKED>
 __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
-  __shared__ int scratch[FILT_EBLOCK / 64];
+  __shared__ unsigned long long scratch[FILT_EBLOCK / 64];
   const int scan = blockIdx.x, tid = threadIdx.x;
   const float* base = A.raw + (size_t)scan * A.n_az * A.n_bins * A.stride;
   const RowRec* rows = A.rows + (size_t)scan * A.n_az;
@@ -184,9 +187,13 @@ __global__ __launch_bounds__(FILT_EBLOCK) void k_filter_emit(FilterArgs A) {
       if (r > 0 && !(fabsf(cur.angle - rows[r - 1].angle) > 0.0001)) bad = 1;
     }
     const bool det = rec.m >= 0;
-    int tot_det, tot_kept;
-    const int det_at = n_det + block_excl_scan<FILT_EBLOCK / 64>(det ? 1 : 0, scratch, &tot_det);
-    int out_at = n_out + block_excl_scan<FILT_EBLOCK / 64>(det ? rec.kept : 0, scratch, &tot_kept);
+    // ONE block scan for both running counts: detections in the upper, kept points in the lower 32 bits (neither can carry:
+    // a scan holds < 2^30 points)
+    unsigned long long tot;
+    const unsigned long long at = block_excl_scan<FILT_EBLOCK / 64>(det ? ((1ull << 32) | (unsigned long long)(unsigned)rec.kept) : 0ull, scratch, &tot);
+    const int tot_det = (int)(tot >> 32), tot_kept = (int)(unsigned)tot;
+    const int det_at = n_det + (int)(at >> 32);
+    int out_at = n_out + (int)(unsigned)at;
     if (det) {
       if (pk) {
         pk[3 * det_at + 0] = rec.angle;
@@ -317,41 +324,52 @@ __device__ __forceinline__ bool expand_both(const FilterArgs& A, const float* ba
   return staged;
 }
 
-// One WAVEFRONT per azimuth row, no barrier and no LDS: the 16 wavefronts of a CU run free of each other, each streams its
-// row through a ring of FILT_UNROLL loads (12 KB in flight per wavefront, 192 KB per CU), keeps the arg-max in registers
-// and expands the run itself (history and measurements: top of the file).
+// One 256-thread WORKGROUP per azimuth row (round 5).  The whole row -- up to FILT_UNROLL x 256 = 3072 bins, 48 KB -- is in
+// flight at once, twelve dwordx4 loads per lane issued back to back; every lane keeps the arg-max of its own bins, a wavefront
+// reduces with shuffles, the four partial results meet in LDS behind ONE barrier, and wavefront 0 alone expands the run while
+// the row is cache-hot (expand_both) and writes the row record; the other three retire at the barrier.
+// Why not the wavefront-per-row kernel of round 4 any more (history at the top of the file): a launch of ONE scan has 400 rows
+// = 400 wavefronts for 1024 SIMDs, each walking its row through a ring of twelve loads -- 47 dependent rounds, 12 us, 0.14 of
+// the HBM rate (round-4 verdict).  Split four ways the row needs ONE round trip, and tools/filter_ticket_probe.hip measured the
+// organisation ahead at every launch size: 6.8 against 9.7 us per scan launched alone, 50.5 against 60.8 us per 16 scans over
+// distinct inputs (a bare 16-scan read: 51.5).  The same probe priced the remaining idea -- folding the emission into the scan's
+// last-arriving workgroup behind a device-scope ticket -- at +70 .. +290 us per 16 scans (one __threadfence per workgroup walks
+// the L2): the emission stays a launch of its own.
 #ifndef FILT_WPE
 #define FILT_WPE 4
 #endif
 #define FILT_OCC __attribute__((amdgpu_waves_per_eu(FILT_WPE, FILT_WPE)))
 // I3: the intensity is the fourth float of a packed record (x y z I, the reference's PointXYZI) -- known at compile time so
-// that the streaming loop has no branch on ioff
+// that the visiting code has no branch on ioff
 template <bool PACKED, bool I3>
 __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs A) {
-  const int lane = threadIdx.x & 63;
-  // scan * n_az + row, in a scalar register (everything derived from it -- row base, trip counts -- stays scalar)
-  const long long g = (long long)blockIdx.x * FILT_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (g >= (long long)A.n_scans * A.n_az) return;
+  __shared__ float s_best[FILT_WAVES];
+  __shared__ int s_idx[FILT_WAVES], s_flag[FILT_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long g = blockIdx.x;  // scan * n_az + row
   const int scan = (int)(g / A.n_az), row = (int)(g - (long long)scan * A.n_az);
   const float* base = A.raw + (size_t)scan * A.n_az * A.n_bins * A.stride;
   const long long n = (long long)A.n_az * A.n_bins, r0 = (long long)row * A.n_bins;
+  const unsigned rec = PACKED ? 16u : 4u * (unsigned)A.stride;          // bytes per point
+  const char* rb = reinterpret_cast<const char*>(base + r0 * A.stride);  // uniform; lane offsets within a row fit 32 bits
 
   float best_i = 0.f;  // max_intensity starts at 0: only intensity > 0 can win
   int best_idx = 0x7fffffff;
-  int bad = 0;
-  // the row's first point (lane 0 of the first chunk): its angle is the reference's current_angle for this azimuth
-  float x0 = 0.f, y0 = 0.f, a0 = 0.f;
-  bool near_cut = false;
+  // the row's first point: its angle is the reference's current_angle for this azimuth (a uniform address: one scalar load)
+  const float x0 = reinterpret_cast<const float*>(rb)[0], y0 = reinterpret_cast<const float*>(rb)[1];
   // The kernel must stay on the HBM roofline, so the two per-point tests are restated without transcendental
   // work: (a) range: hypot() in float after a double sqrt is monotone in d2 = x^2 + y^2, so the launcher
   // bisects the two double thresholds once; (b) organisation: a point whose direction is within 4e-5 rad of
-  // the row's first point (|cross| <= 4e-5 dot) cannot differ from it by 1e-4 in atan2f; only other points
-  // (none in an organised scan) and rows next to the +-pi cut take the exact atan2f comparison.
-  // The streaming loop only FLAGS such points; a flagged row is walked a second time with the exact test (below).
+  // the row's first point (|cross| <= 4e-5 dot, dot > 0) cannot differ from it by 1e-4 in atan2f; only other points
+  // (none in an organised scan) and rows next to the +-pi cut take the exact atan2f comparison (below).
+  // near_cut: |atan2f(y0, x0)| >= 3.14, decided without the atan2f (a superset: tan(pi - 3.14) = 0.00159)
+  const bool near_cut = x0 < 0.f && fabsf(y0) <= 0.002f * fabsf(x0);
   bool suspect = false;
   auto visit = [&](int b, float px, float py, float pin) {
     const float cross = x0 * py - y0 * px, dot = x0 * px + y0 * py;
-    suspect |= !(fabsf(cross) <= 4e-5f * dot);
+    // (dot > 0: a zero-filled return passes 0 <= 0, but the reference's atan2(0, 0) = 0 starts a new azimuth there)
+    suspect |= !(fabsf(cross) <= 4e-5f * dot) || !(dot > 0.f);
     const double d2 = (double)px * (double)px + (double)py * (double)py;
     if (d2 >= A.lo2 && d2 <= A.hi2) {
       if (pin > best_i) {  // a lane meets its bins in increasing order: strict '>' keeps the first
@@ -360,68 +378,28 @@ __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs 
       }
     }
   };
-  // The row as a sequence of 64-bin loads (one record per lane), FILT_UNROLL of them in flight as a ring: a slot is
-  // re-issued for the load FILT_UNROLL further on as soon as its point has been visited, so the wavefront never drains
-  // between the start and the end of its row (loads return in order: the wait for slot u is vmcnt(FILT_UNROLL - 1)).
-  const int n_loads = (A.n_bins + 63) >> 6;
-  const unsigned rec = PACKED ? 16u : 4u * (unsigned)A.stride;          // bytes per point
-  const char* rb = reinterpret_cast<const char*>(base + r0 * A.stride);  // uniform; lane offsets within a row fit 32 bits
-  float4 pt[FILT_UNROLL];
-  auto issue = [&](int u, int l) {  // bins past the end of the row re-read its last bin and are skipped when visited
-    const int b0 = l * 64 + lane;
-    const unsigned off = (unsigned)(b0 < A.n_bins ? b0 : A.n_bins - 1) * rec;
-    if (PACKED) {
-      pt[u] = *reinterpret_cast<const float4*>(rb + off);
-    } else {
-      const float* p = reinterpret_cast<const float*>(rb + off);
-      pt[u].x = p[0];
-      pt[u].y = p[1];
-      pt[u].w = p[A.ioff];
-    }
-  };
+  // lane t holds bins t, t + 256, ...: FILT_UNROLL loads per lane and round, all issued before the first is looked at (rows
+  // beyond 3072 bins take further rounds)
+  for (int c0 = 0; c0 < A.n_bins; c0 += FILT_UNROLL * FILT_BLOCK) {
+    float4 pt[FILT_UNROLL];
 #pragma unroll
-  for (int u = 0; u < FILT_UNROLL; ++u) issue(u, u);
-  x0 = __shfl(pt[0].x, 0, 64);  // the row's first point
-  y0 = __shfl(pt[0].y, 0, 64);
-  a0 = atan2f(y0, x0);
-  near_cut = !(fabsf(a0) < 3.14f);
-  auto visit_slot = [&](int u, int l, bool whole) {  // whole: all 64 bins of the load are inside the row
-    const int b = l * 64 + lane;
-    if (PACKED) asm volatile("" ::"v"(pt[u].z));  // keeps the record ONE dwordx4 load (z is not needed here: the compiler would split it in two)
-    if (whole || b < A.n_bins) visit(b, pt[u].x, pt[u].y, (!PACKED || I3) ? pt[u].w : (A.ioff == 2 ? pt[u].z : pt[u].x));
-  };
-  // steady state: no branch around a load (the compiler's wait counts stay exact: vmcnt(FILT_UNROLL - 1) per slot); the
-  // re-issues of the last of these rounds may run past the row (clamped, <= FILT_UNROLL - 1 loads of one cached record)
-  int l0 = 0;
-  for (; l0 + FILT_UNROLL < n_loads; l0 += FILT_UNROLL) {
+    for (int u = 0; u < FILT_UNROLL; ++u) {  // bins past the end of the row re-read its last bin and are skipped when visited
+      const int b0 = c0 + u * FILT_BLOCK + tid;
+      const unsigned off = (unsigned)(b0 < A.n_bins ? b0 : A.n_bins - 1) * rec;
+      if (PACKED) {
+        pt[u] = *reinterpret_cast<const float4*>(rb + off);
+      } else {
+        const float* p = reinterpret_cast<const float*>(rb + off);
+        pt[u].x = p[0];
+        pt[u].y = p[1];
+        pt[u].w = p[A.ioff];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < FILT_UNROLL; ++u) {
-      visit_slot(u, l0 + u, true);  // l0 + u < n_loads - FILT_UNROLL: not the row's last load
-      issue(u, l0 + u + FILT_UNROLL);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < FILT_UNROLL; ++u) visit_slot(u, l0 + u, false);  // the last round: nothing left to issue
-  if (__ballot(suspect || near_cut)) {
-    // the exact organisation test (rare: the row at the +-pi cut, and clouds that are not organised azimuth after azimuth):
-    // the row once more, eight loads in flight
-    for (int l0 = 0; l0 < n_loads; l0 += 8) {
-      float qx[8], qy[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b0 = (l0 + u) * 64 + lane;
-        const float* q = reinterpret_cast<const float*>(rb + (unsigned)(b0 < A.n_bins ? b0 : A.n_bins - 1) * rec);
-        qx[u] = q[0];
-        qy[u] = q[1];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float cross = x0 * qy[u] - y0 * qx[u], dot = x0 * qx[u] + y0 * qy[u];
-        if ((l0 + u) * 64 + lane < A.n_bins && (near_cut || !(fabsf(cross) <= 4e-5f * dot))) {
-          const float ang = atan2f(qy[u], qx[u]);
-          if (fabsf(ang - a0) > 0.0001) bad = 1;  // an azimuth change inside the row
-        }
-      }
+      const int b = c0 + u * FILT_BLOCK + tid;
+      if (PACKED) asm volatile("" ::"v"(pt[u].z));  // keeps the record ONE dwordx4 load (z is not needed here: the compiler would split it in two)
+      if (b < A.n_bins) visit(b, pt[u].x, pt[u].y, (!PACKED || I3) ? pt[u].w : (A.ioff == 2 ? pt[u].z : (A.ioff == 1 ? pt[u].y : pt[u].x)));
     }
   }
   // arg-max over the wavefront: larger intensity wins, ties -> smaller index (strict '>', first index wins)
@@ -433,8 +411,54 @@ __global__ __launch_bounds__(FILT_BLOCK) FILT_OCC void k_filter_rows(FilterArgs 
       best_i = oi;
       best_idx = ox;
     }
-    bad |= __shfl_xor(bad, off, 64);
   }
+  const int flagged = __ballot(suspect) != 0ull ? 1 : 0;
+  if (lane == 0) {
+    s_best[wave] = best_i;
+    s_idx[wave] = best_idx;
+    s_flag[wave] = flagged;
+  }
+  __syncthreads();
+  int any_flag = 0;
+  best_i = s_best[0];
+  best_idx = s_idx[0];
+#pragma unroll
+  for (int w = 0; w < FILT_WAVES; ++w) {
+    any_flag |= s_flag[w];
+    if (w > 0 && (s_best[w] > best_i || (s_best[w] == best_i && s_idx[w] < best_idx))) {
+      best_i = s_best[w];
+      best_idx = s_idx[w];
+    }
+  }
+  int bad = 0;
+  float a0 = 0.f;
+  if (any_flag || near_cut) {  // uniform over the workgroup
+    // the exact organisation test (rare: the row at the +-pi cut, and clouds that are not organised azimuth after azimuth):
+    // the row once more, eight loads in flight per lane
+    a0 = atan2f(y0, x0);
+    const bool cut = !(fabsf(a0) < 3.14f);
+    for (int c0 = 0; c0 < A.n_bins; c0 += 8 * FILT_BLOCK) {
+      float qx[8], qy[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b0 = c0 + u * FILT_BLOCK + tid;
+        const float* q = reinterpret_cast<const float*>(rb + (unsigned)(b0 < A.n_bins ? b0 : A.n_bins - 1) * rec);
+        qx[u] = q[0];
+        qy[u] = q[1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float cross = x0 * qy[u] - y0 * qx[u], dot = x0 * qx[u] + y0 * qy[u];
+        if (c0 + u * FILT_BLOCK + tid < A.n_bins && (cut || !(fabsf(cross) <= 4e-5f * dot) || !(dot > 0.f))) {
+          const float ang = atan2f(qy[u], qx[u]);
+          if (fabsf(ang - a0) > 0.0001) bad = 1;  // an azimuth change inside the row
+        }
+      }
+    }
+    bad = __syncthreads_or(bad);
+  }
+  if (wave != 0) return;
+  if (!(any_flag || near_cut)) a0 = atan2f(y0, x0);
   // the row's detection; quirk: the first boundary pushes current_max_idx = 0 even if azimuth 0 had no valid return;
   // the last azimuth is never flushed
   long long m = (best_i > 0.f && best_idx != 0x7fffffff) ? r0 + best_idx : -1;
@@ -518,8 +542,9 @@ int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az
   A.out_vec = ((uintptr_t)d_out_pts & 15) == 0;
   A.rows = (RowRec*)d_scratch;  // [n_scans * n_az] records, then the stage (api.hip sizes the workspace: FILT_WS_PER_ROW)
   A.stage = (float4*)((char*)d_scratch + (((size_t)n_scans * n_az * sizeof(RowRec) + 255) & ~(size_t)255));
-  // one wavefront per azimuth row, four rows per workgroup; the dispatcher back-fills the chip as workgroups retire
-  const int row_wgs = (int)(((long long)n_scans * n_az + FILT_WAVES - 1) / FILT_WAVES);
+  // one workgroup per azimuth row; the dispatcher back-fills the chip as workgroups retire
+  if ((long long)n_scans * n_az > 0x7fffffffll) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "filter: more than 2^31 azimuth rows in one launch", hipSuccess);
+  const int row_wgs = n_scans * n_az;
   if (stride == 4 && ioff == 3) {
     hipLaunchKernelGGL((k_filter_rows<true, true>), dim3(row_wgs), dim3(FILT_BLOCK), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_filter_emit<true>, dim3(n_scans), dim3(FILT_EBLOCK), 0, ctx->stream, A);

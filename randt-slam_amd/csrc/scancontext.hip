@@ -7,10 +7,11 @@
 //                 bin index and value of every point into LDS, a stable counting sort of the points by bin, then ONE
 //                 THREAD PER BIN folds its points in input order, so every bin sum runs in the reference's sequential
 //                 order (bit-reproducible, including the quirk that a touched bin starts at NO_POINT = -1000);
-//   k_sc_detect   detectLoopClosureID (:261-341), one workgroup per query node: float ring-key distances to the
-//                 searchable part of the database, k rounds of (distance, index) arg-min = the k nearest keys,
-//                 then per candidate the sector-key alignment, the column-shift search of the cosine distance and
-//                 the odometry term (distanceBtnScanContext, :115-152).
+//   k_sc_knn      detectLoopClosureID's candidate search (:261-300), one workgroup per query node: float ring-key
+//                 distances to the searchable part of the database, k rounds of (distance, index) arg-min = the k nearest keys;
+//   k_sc_detect   the rest of detectLoopClosureID (:300-341), one workgroup per (query, candidate rank): sector-key
+//                 alignment, the column-shift search of the cosine distance and the odometry term
+//                 (distanceBtnScanContext, :115-152); k_sc_pick takes the first smallest distance.
 // Every reduction is a per-thread left-to-right loop in the oracle's order.
 #include "randt_internal.h"
 
@@ -198,34 +199,24 @@ struct ScCandidate {
   int32_t shift, idx;  // argmin shift, database index (-1: this query has fewer candidates)
 };
 
-// One workgroup per (query, candidate rank): the candidates of a query are independent of each other until the final
-// "smallest distance, first one wins" (k_sc_pick), and each is a chain of short phases (~8 us) -- ten of them in a row were
-// most of a query's 106 us.  Every workgroup forms the ring-key distances itself and runs the arg-min rounds up to its own rank.
-__global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double* __restrict__ desc, const double* __restrict__ ring_keys,
-                                                        const double* __restrict__ pos, const double* __restrict__ dist, int n_db,
-                                                        const int32_t* __restrict__ query_ids, float* __restrict__ d2ws, int d2pitch,
-                                                        ScCandidate* __restrict__ records, int staged) {
-  // staged: the query's and the current candidate's descriptor (S x R doubles each) are copied into LDS with coalesced loads;
-  // every dot product below then reads LDS instead of walking two global columns element by element (a candidate cost 12 us of
-  // L2 round trips that way).  Descriptors too large for it stay in global memory.
-  extern __shared__ __attribute__((aligned(16))) char sc_dyn[];
-  __shared__ double k1[SC_MAX_SECTOR], k2[SC_MAX_SECTOR];
-  __shared__ double n1[SC_MAX_SECTOR], n2[SC_MAX_SECTOR];  // column norms of the query / the candidate (shift-independent)
-  __shared__ double term[SC_TERM_CAP];
+// The candidate search of a query, once (every (query, rank) workgroup used to repeat it on a distance row of its
+// own -- n_queries x n_candidates x n_db floats of workspace): the squared float distances of the ring keys (nanoflann L2,
+// accumulated in float) and the k nearest keys in ascending (distance, index) order.  One workgroup per query; cand_out
+// [q][c] = database index of rank c, -1 beyond the query's candidates (or for the early return, :274-278).
+__global__ __launch_bounds__(SC_BLOCK) void k_sc_knn(ScParams P, const double* __restrict__ ring_keys, int n_db, const int32_t* __restrict__ query_ids,
+                                                     float* __restrict__ d2ws, int d2pitch, int32_t* __restrict__ cand_out) {
   __shared__ double sv[4];
   __shared__ int si[4];
-  __shared__ int cand[SC_MAX_CAND];
-  const int q = blockIdx.x, c_only = blockIdx.y, tid = threadIdx.x;
+  const int q = blockIdx.x, tid = threadIdx.x;
   const int node = query_ids ? query_ids[q] : q;
-  const int R = P.R, S = P.S;
-  float* d2 = d2ws + ((size_t)q * gridDim.y + c_only) * d2pitch;
-  ScCandidate* rec = records + (size_t)q * gridDim.y + c_only;
-  if (node < P.exclude_recent + 1 || node >= n_db) {  // early return (:274-278): k_sc_pick says so
-    if (tid == 0) rec->idx = -1;
+  const int R = P.R;
+  float* d2 = d2ws + (size_t)q * d2pitch;
+  int32_t* cand = cand_out + (size_t)q * P.n_cand;
+  if (node < P.exclude_recent + 1 || node >= n_db) {
+    for (int c = tid; c < P.n_cand; c += SC_BLOCK) cand[c] = -1;
     return;
   }
   const int n_search = node + 1 - P.exclude_recent;
-  // ---- squared float distances of the ring keys (nanoflann L2, accumulated in float)
   for (int i = tid; i < n_search; i += SC_BLOCK) {
     float acc = 0.0f;
     for (int r = 0; r < R; ++r) {
@@ -236,13 +227,12 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
     d2[i] = acc;
   }
   __syncthreads();
-  // ---- the k nearest keys in ascending (distance, index) order
   const int kk = P.n_cand < n_search ? P.n_cand : n_search;
-  if (c_only >= kk) {  // uniform
-    if (tid == 0) rec->idx = -1;
-    return;
-  }
-  for (int c = 0; c <= c_only; ++c) {
+  for (int c = 0; c < P.n_cand; ++c) {
+    if (c >= kk) {  // uniform
+      if (tid == 0) cand[c] = -1;
+      continue;
+    }
     double bv = 1e300;
     int bi = 0x7fffffff;
     for (int i = tid; i < n_search; i += SC_BLOCK) {
@@ -258,6 +248,33 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
       d2[bi] = -1.0f;
     }
     __syncthreads();
+  }
+}
+
+// One workgroup per (query, candidate rank): the candidates of a query are independent of each other until the final
+// "smallest distance, first one wins" (k_sc_pick), and each is a chain of short phases (~8 us) -- ten of them in a row were
+// most of a query's 106 us.  The candidates themselves come from k_sc_knn.
+__global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double* __restrict__ desc, const double* __restrict__ ring_keys,
+                                                        const double* __restrict__ pos, const double* __restrict__ dist, int n_db,
+                                                        const int32_t* __restrict__ query_ids, const int32_t* __restrict__ cand_in,
+                                                        ScCandidate* __restrict__ records, int staged) {
+  // staged: the query's and the current candidate's descriptor (S x R doubles each) are copied into LDS with coalesced loads;
+  // every dot product below then reads LDS instead of walking two global columns element by element (a candidate cost 12 us of
+  // L2 round trips that way).  Descriptors too large for it stay in global memory.
+  extern __shared__ __attribute__((aligned(16))) char sc_dyn[];
+  __shared__ double k1[SC_MAX_SECTOR], k2[SC_MAX_SECTOR];
+  __shared__ double n1[SC_MAX_SECTOR], n2[SC_MAX_SECTOR];  // column norms of the query / the candidate (shift-independent)
+  __shared__ double term[SC_TERM_CAP];
+  __shared__ double sv[4];
+  __shared__ int si[4];
+  const int q = blockIdx.x, c_only = blockIdx.y, tid = threadIdx.x;
+  const int node = query_ids ? query_ids[q] : q;
+  const int R = P.R, S = P.S;
+  ScCandidate* rec = records + (size_t)q * gridDim.y + c_only;
+  const int ci = cand_in[(size_t)q * gridDim.y + c_only];  // uniform
+  if (ci < 0) {  // the early return (:274-278) or a rank beyond the query's candidates: k_sc_pick says so
+    if (tid == 0) rec->idx = -1;
+    return;
   }
   // ---- pairwise distances (distanceBtnScanContext) in candidate order
   const double* sc1 = desc + (size_t)node * R * S;
@@ -285,7 +302,6 @@ __global__ __launch_bounds__(SC_BLOCK) void k_sc_detect(ScParams P, const double
     n1[tid] = sqrt(na);
   }
   {
-    const int ci = cand[c_only];
     const double* sc2 = desc + (size_t)ci * R * S;
     __syncthreads();
     if (staged) {
@@ -455,9 +471,11 @@ ScParams to_dev(const randt_sc_params* p) {
 
 }  // namespace
 
+// records | candidate indices | one row of ring-key distances per query
 size_t sc_detect_ws_bytes(int n_queries, int n_db, int n_cand) {
-  const size_t q = n_queries > 0 ? n_queries : 1, c = n_cand > 0 ? n_cand : 1, n = n_db > 0 ? n_db : 1;
-  return ((q * c * sizeof(ScCandidate) + 255) & ~(size_t)255) + sizeof(float) * q * c * n + 256;
+  const size_t q = n_queries > 0 ? n_queries : 1, n = n_db > 0 ? n_db : 1;
+  const size_t c = n_cand < 1 ? 1 : (n_cand > SC_MAX_CAND ? SC_MAX_CAND : n_cand);  // (launch_sc_detect refuses counts outside 1 .. SC_MAX_CAND)
+  return ((q * c * sizeof(ScCandidate) + 255) & ~(size_t)255) + ((q * c * sizeof(int32_t) + 255) & ~(size_t)255) + sizeof(float) * q * n + 256;
 }
 
 int launch_sc_make(randt_ctx* ctx, const float* d_points, int n_scans, int pitch, const int32_t* d_n_points, int stride, int ioff,
@@ -485,11 +503,14 @@ int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_d
   const int staged = lds + 40 * 1024 <= (size_t)ctx->lds_limit ? 1 : 0;  // (the kernel's static arrays take 37 KB)
   if (!staged) lds = 0;
   RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_detect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // workspace (sc_detect_ws_bytes): the records, then one copy of the ring-key distances per (query, candidate rank)
+  // workspace (sc_detect_ws_bytes): the records, the candidate indices, one row of ring-key distances per query
   ScCandidate* records = reinterpret_cast<ScCandidate*>(d_ws);
-  float* d2ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d_ws) + (((size_t)n_queries * p->num_candidates * sizeof(ScCandidate) + 255) & ~(size_t)255));
+  char* after = reinterpret_cast<char*>(d_ws) + (((size_t)n_queries * p->num_candidates * sizeof(ScCandidate) + 255) & ~(size_t)255);
+  int32_t* cand = reinterpret_cast<int32_t*>(after);
+  float* d2ws = reinterpret_cast<float*>(after + (((size_t)n_queries * p->num_candidates * sizeof(int32_t) + 255) & ~(size_t)255));
+  hipLaunchKernelGGL(k_sc_knn, dim3(n_queries), dim3(SC_BLOCK), 0, ctx->stream, to_dev(p), d_ring_keys, n_db, d_query_ids, d2ws, n_db, cand);
   hipLaunchKernelGGL(k_sc_detect, dim3(n_queries, p->num_candidates), dim3(SC_BLOCK), lds, ctx->stream, to_dev(p), d_desc, d_ring_keys, d_pos, d_dist,
-                     n_db, d_query_ids, d2ws, n_db, records, staged);
+                     n_db, d_query_ids, cand, records, staged);
   hipLaunchKernelGGL(k_sc_pick, dim3((n_queries + 63) / 64), dim3(64), 0, ctx->stream, to_dev(p), n_queries, p->num_candidates, records, d_loop_id,
                      d_yaw, d_min_dist);
   RANDT_HIP_CHECK(ctx, hipGetLastError());

@@ -116,6 +116,61 @@ def test_hip_filter_flags_unorganised_input(built):
     assert status.item() == 1                              # loud, never a silently different result
 
 
+@pytest.mark.gpu
+def test_hip_filter_flags_a_zero_filled_return_inside_a_row(built):
+    """a point with x = y = 0 inside a row passes a bare |cross| <= eps * dot test (0 <= 0), but the
+    reference's atan2(0, 0) = 0 differs from the row's angle by more than 1e-4 and starts a new azimuth there
+    (radar_preprocessor.cpp:56-75): such a cloud must be flagged (status 1), never filtered as if the row were whole.
+    A row that really lies on the +x axis (angle 0) is not split by the reference either, and stays unflagged."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    raw, _ = small_polar(5)
+    assert abs(np.arctan2(raw[4, 0, 1], raw[4, 0, 0])) > 0.01
+    hit = raw.copy()
+    hit[4, 33, :2] = 0.0                                  # a zero-filled return in the middle of row 4, intensity kept
+    res = _run_hip_filter(ctx, dev, hit[None], host.filter_params())
+    assert res[5].tolist() == [1]
+    # the same defect in the PCL layout (the strided instantiation of the row kernel)
+    pcl = np.zeros(hit.shape[:2] + (8,), dtype=np.float32)
+    pcl[..., :3], pcl[..., 3], pcl[..., 4] = hit[..., :3], 1.0, hit[..., 3]
+    assert _run_hip_filter(ctx, dev, pcl[None], host.filter_params(), intensity_index=4)[5].tolist() == [1]
+    # a row along +x: atan2(0, 0) = 0 = the row's own angle -> the reference sees no azimuth change, and neither do we
+    n_az, n_bins = raw.shape[:2]
+    flat = raw.copy()
+    r = np.hypot(raw[0, :, 0], raw[0, :, 1])
+    others = np.arctan2(raw[1:, 0, 1], raw[1:, 0, 0])
+    assert np.abs(others).min() > 1e-3                    # row 0 can take angle 0 without colliding with a neighbour
+    flat[0, :, 0], flat[0, :, 1] = r, 0.0
+    flat[0, 20, :2] = 0.0
+    res = _run_hip_filter(ctx, dev, flat[None], host.filter_params())
+    assert res[5].tolist() == [0]
+    _check_against_oracle(res, flat[None], po.filter_params())
+
+
+@pytest.mark.gpu
+def test_hip_filter_packed_records_with_the_intensity_in_any_slot(built):
+    """ADVICE r4 (low): packed 16-byte records accept intensity_index 1 .. 3 (the API allows any slot below the stride);
+    index 1 used to read x.  Index 1 means "the intensity is y": odd, but it must be what the oracle computes for it."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    scans = np.stack([small_polar(700 + s)[0] for s in range(2)])
+    for ioff in (1, 2, 3):
+        raw = scans.copy()
+        if ioff == 2:
+            raw = raw[..., [0, 1, 3, 2]].copy()
+        out, polar, peaks, counts, pcounts, status = _run_hip_filter(ctx, dev, raw, host.filter_params(min_intensity=0.5), intensity_index=ioff)
+        assert status.tolist() == [0, 0]
+        for s in range(2):
+            cnt, pts, pol, pk = po.filter_scan(raw[s].reshape(-1, 4), po.filter_params(min_intensity=0.5), ioff=ioff)
+            assert counts[s] == cnt and pcounts[s] == len(pk), (ioff, s)
+            assert np.array_equal(out[s, :cnt].view(np.uint32), pts.view(np.uint32)), (ioff, s)
+        assert counts.sum() > 0
+
+
 def _run_hip_filter(ctx, dev, scans, fp, intensity_index=None, pitch=4096):
     import torch
 

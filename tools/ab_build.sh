@@ -9,14 +9,14 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/randt-slam_amd/csrc
 OUT=$ROOT/build/ab/$NAME
 mkdir -p "$OUT"
-ALL="api ndt_build associate solve window window_gen window_gen_big filter csdiv scancontext posegraph cellops ndt_build_big group"
+ALL="api ndt_build associate solve window window_gen window_gen_big filter csdiv scancontext posegraph cellops ndt_build_big group mapops"
 UNITS=${*:-$ALL}
 COMMON="$EXTRA -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$SRC -Wall -Wno-unused-function -Wno-pass-failed"
 pids=()
 for f in $ALL; do
   if [[ " $UNITS " == *" $f "* ]]; then
     exact=""
-    case $f in ndt_build|associate|filter|csdiv|scancontext|cellops|ndt_build_big) exact="-ffp-contract=off";; esac
+    case $f in ndt_build|associate|filter|csdiv|scancontext|cellops|ndt_build_big|mapops) exact="-ffp-contract=off";; esac
     /opt/rocm/bin/hipcc $COMMON $exact -c "$SRC/$f.hip" -o "$OUT/$f.o" &
     pids+=($!)
   else

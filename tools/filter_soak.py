@@ -63,6 +63,11 @@ for case in range(n_cases):
         s, a, b = int(rng.integers(0, n_scans)), int(rng.integers(0, n_az - 1)), int(rng.integers(1, n_bins))
         scans[s, a, b, :2] = scans[s, (a + n_az // 2) % n_az, b, :2]
         unorganised = s
+    elif rng.random() < 0.08 and n_az > 3 and n_bins > 2:                        # a zero-filled return inside a row: the reference's atan2(0, 0) = 0
+        s, a, b = int(rng.integers(0, n_scans)), int(rng.integers(0, n_az - 1)), int(rng.integers(1, n_bins))   # starts a new azimuth there -> status 1
+        if abs(float(np.arctan2(scans[s, a, 0, 1], scans[s, a, 0, 0]))) > 2e-4:   # (unless the row lies on the +x axis: angle 0 either way)
+            scans[s, a, b, :2] = 0.0
+            unorganised = s
     # record layouts: packed x y z I; packed x y I z (intensity in the third float); PCL's 8-float PointXYZI; 5 floats
     if layout == "xyzi":
         raw, ioff, oracle_in = scans, 3, scans

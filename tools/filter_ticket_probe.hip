@@ -1,0 +1,323 @@
+// Round 5, verdict item 2 (f-1 at ONE scan per launch and the fill / drain of the 16-scan launch): what do the building blocks
+// of a fused polar filter cost on this part, before anything is rebuilt?
+//   wave_rows      k_filter_rows' loads + per-point arithmetic, one wavefront per row (the shipped organisation)
+//   wg_rows        one 256-thread WORKGROUP per row: the whole 3000-bin row in flight at once (12 dwordx4 per lane), the four
+//                  partial arg-maxes combined through LDS behind one barrier (the "segment-parallel" organisation for launches
+//                  that cannot fill the chip with one wavefront per row: 400 rows = 400 wavefronts on 1024 SIMDs)
+//   + ticket       every workgroup ends with __threadfence() + one atomicAdd on its scan's counter (device scope)
+//   + tail         the workgroup that takes a scan's last ticket reads the scan's 400 row records (32 B each) + 64 B of staged
+//                  points per row and writes ~800 output points: the emission folded into the last-arriving workgroup
+// over n_scans = 1 (rotating over 48 distinct scans: 0.9 GB, nothing is met again in the 256 MB Infinity Cache) and 16 (rotating
+// over 4 distinct 16-scan inputs).  Times: HIP events over a chain of launches; run under `rocprofv3 --kernel-trace --stats`
+// for the per-kernel durations.
+//   hipcc --offload-arch=gfx950 -O2 tools/filter_ticket_probe.hip -o /tmp/ftp && /tmp/ftp
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHECK(x)                                                                   \
+  do {                                                                             \
+    hipError_t e = (x);                                                            \
+    if (e != hipSuccess) {                                                         \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+constexpr int N_AZ = 400, N_BINS = 3000;
+
+struct Rec {
+  int m, closer, further, kept;
+  float angle, maxi, range;
+  int bad;
+};
+
+__device__ __forceinline__ void visit(float px, float py, float pin, int b, float x0, float y0, double lo2, double hi2, float& best, int& best_idx, int& bad) {
+  const float cross = x0 * py - y0 * px, dot = x0 * px + y0 * py;
+  if (!(fabsf(cross) <= 4e-5f * dot) || !(dot > 0.f)) bad = 1;
+  const double d2 = (double)px * (double)px + (double)py * (double)py;
+  if (b < N_BINS && d2 >= lo2 && d2 <= hi2 && pin > best) {
+    best = pin;
+    best_idx = b;
+  }
+}
+
+// agent-scope relaxed atomic accesses: "sc1" stores write through the XCD's L2, "sc1" loads do not hit its stale lines
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int MODE>
+__device__ __forceinline__ void put_row(Rec* recs, float4* stage, size_t g, int lane, const Rec& rc, const float4& q) {
+  if (MODE >= 4) {  // every word the tail reads goes out as an agent-scope store
+    if (lane < 4) {
+      float* sp = reinterpret_cast<float*>(stage + g * 4 + lane);
+      st_agent(sp + 0, q.x), st_agent(sp + 1, q.y), st_agent(sp + 2, q.z), st_agent(sp + 3, q.w);
+    }
+    if (lane == 0) {
+      int* rp = reinterpret_cast<int*>(recs + g);
+      st_agent(rp + 0, rc.m), st_agent(rp + 1, rc.closer), st_agent(rp + 2, rc.further), st_agent(rp + 3, rc.kept);
+      st_agent(reinterpret_cast<float*>(rp) + 4, rc.angle), st_agent(reinterpret_cast<float*>(rp) + 5, rc.maxi), st_agent(reinterpret_cast<float*>(rp) + 6, rc.range);
+      st_agent(rp + 7, rc.bad);
+    }
+  } else {
+    if (lane < 4) stage[g * 4 + lane] = q;
+    if (lane == 0) recs[g] = rc;
+  }
+}
+// MODE 0: rows only; 1: + ticket behind __threadfence; 2: + tail by the last workgroup of a scan; 3: the ticket as ONE release
+// atomic (no full fence), the tail behind one acquire fence; 4: no fence at all: the records leave as agent-scope stores, the
+// ticket is a relaxed atomic behind s_waitcnt vmcnt(0), the tail reads with agent-scope loads
+template <int MODE>
+__device__ __forceinline__ void finish(int scan, int n_wg_per_scan, Rec* recs, float4* stage, int* ticket, float4* out) {
+  if (MODE == 0) return;
+  if (MODE >= 3) {
+    __shared__ int last3;
+    if (MODE == 4) __builtin_amdgcn_s_waitcnt(0);  // every wavefront: its own stores acknowledged (a barrier orders execution, not memory)
+    __syncthreads();  // (the row's writers have issued their stores)
+    if (threadIdx.x == 0) {
+      int old;
+      if (MODE == 3) {
+        old = __hip_atomic_fetch_add(&ticket[scan], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        __builtin_amdgcn_s_waitcnt(0);  // every store of this wavefront acknowledged
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        old = __hip_atomic_fetch_add(&ticket[scan], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      last3 = old == n_wg_per_scan - 1;
+    }
+    __syncthreads();
+    if (!last3) return;
+    if (MODE == 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0) __hip_atomic_store(&ticket[scan], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int at = 0;
+    for (int r0 = 0; r0 < N_AZ; r0 += 256) {
+      const int r = r0 + threadIdx.x;
+      if (r < N_AZ) {
+        const size_t g = (size_t)scan * N_AZ + r;
+        Rec rc;
+        float4 a, b;
+        if (MODE == 3) {
+          rc = recs[g];
+          a = stage[g * 4], b = stage[g * 4 + 2];
+        } else {
+          const int* rp = reinterpret_cast<const int*>(recs + g);
+          rc.kept = ld_agent(rp + 3);
+          rc.angle = ld_agent(reinterpret_cast<const float*>(rp) + 4);
+          rc.maxi = ld_agent(reinterpret_cast<const float*>(rp) + 5);
+          const float* sa = reinterpret_cast<const float*>(stage + g * 4);
+          a = make_float4(ld_agent(sa), ld_agent(sa + 1), ld_agent(sa + 2), ld_agent(sa + 3));
+          b = make_float4(ld_agent(sa + 8), ld_agent(sa + 9), ld_agent(sa + 10), ld_agent(sa + 11));
+        }
+        out[(size_t)scan * 4096 + 2 * r] = make_float4(a.x + rc.angle, a.y, a.z, a.w);
+        out[(size_t)scan * 4096 + 2 * r + 1] = make_float4(b.x + rc.maxi, b.y, b.z, b.w);
+        at += rc.kept;
+      }
+    }
+    if (at == 123456) out[0].x = 1.f;
+    return;
+  }
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(&ticket[scan], 1) == n_wg_per_scan - 1;
+  }
+  __syncthreads();
+  if (MODE < 2 || !last) return;
+  __threadfence();
+  if (threadIdx.x == 0) ticket[scan] = 0;  // ready for the next launch
+  int at = 0;
+  for (int r0 = 0; r0 < N_AZ; r0 += 256) {
+    const int r = r0 + threadIdx.x;
+    if (r < N_AZ) {
+      const Rec rc = recs[(size_t)scan * N_AZ + r];
+      const float4* sp = stage + ((size_t)scan * N_AZ + r) * 4;
+      const float4 a = sp[0], b = sp[2];
+      // (the real emission block-scans the kept counts; a fixed two points per row stand in for it here)
+      out[(size_t)scan * 4096 + 2 * r] = make_float4(a.x + rc.angle, a.y, a.z, a.w);
+      out[(size_t)scan * 4096 + 2 * r + 1] = make_float4(b.x + rc.maxi, b.y, b.z, b.w);
+      at += rc.kept;
+    }
+  }
+  if (at == 123456) out[0].x = 1.f;
+}
+
+// one wavefront per row, four rows of ONE scan per workgroup
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wave_rows(const float4* __restrict__ raw, Rec* recs, float4* stage, int* ticket, float4* out,
+                                                                                            double lo2, double hi2) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wg_per_scan = (N_AZ + 3) / 4;
+  const int scan = blockIdx.x / wg_per_scan, row = (blockIdx.x - scan * wg_per_scan) * 4 + wave;
+  if (row < N_AZ) {
+    const float4* rp = raw + ((size_t)scan * N_AZ + row) * N_BINS;
+    float best = 0.f, x0 = 0.f, y0 = 0.f;
+    int best_idx = 0x7fffffff, bad = 0;
+    for (int c0 = 0; c0 < N_BINS; c0 += 12 * 64) {
+      float4 pt[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        const int b = c0 + u * 64 + lane;
+        pt[u] = rp[b < N_BINS ? b : N_BINS - 1];
+      }
+      if (c0 == 0) {
+        x0 = __shfl(pt[0].x, 0, 64);
+        y0 = __shfl(pt[0].y, 0, 64);
+      }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) visit(pt[u].x, pt[u].y, pt[u].w, c0 + u * 64 + lane, x0, y0, lo2, hi2, best, best_idx, bad);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float oi = __shfl_xor(best, off, 64);
+      const int ox = __shfl_xor(best_idx, off, 64);
+      if (oi > best || (oi == best && ox < best_idx)) best = oi, best_idx = ox;
+      bad |= __shfl_xor(bad, off, 64);
+    }
+    // the expansion's dependent look at the peak's neighbourhood (one round trip, cache-hot)
+    const int nb = best_idx == 0x7fffffff ? 0 : best_idx;
+    const float4 q = rp[min(max(nb - 32 + lane, 0), N_BINS - 1)];
+    const unsigned long long keep = __ballot(q.w > 0.5f * best);
+    Rec rc;
+    rc.m = nb, rc.closer = nb - 1, rc.further = nb + 1, rc.kept = __popcll(keep) & 3;
+    rc.angle = x0, rc.maxi = best, rc.range = y0, rc.bad = bad;
+    put_row<MODE>(recs, stage, (size_t)scan * N_AZ + row, lane, rc, q);
+  }
+  finish<MODE>(scan, wg_per_scan, recs, stage, ticket, out);
+}
+
+// one 256-thread workgroup per row: the whole row in flight, partial arg-maxes combined through LDS
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wg_rows(const float4* __restrict__ raw, Rec* recs, float4* stage, int* ticket, float4* out,
+                                                                                          double lo2, double hi2) {
+  __shared__ float s_best[4];
+  __shared__ int s_idx[4], s_bad[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int scan = blockIdx.x / N_AZ, row = blockIdx.x - scan * N_AZ;
+  const float4* rp = raw + ((size_t)scan * N_AZ + row) * N_BINS;
+  float4 pt[12];
+#pragma unroll
+  for (int u = 0; u < 12; ++u) {
+    const int b = u * 256 + threadIdx.x;
+    pt[u] = rp[b < N_BINS ? b : N_BINS - 1];
+  }
+  const float4 first = rp[0];  // (every wavefront needs the row's first point; a cached line after the first toucher)
+  const float x0 = first.x, y0 = first.y;
+  float best = 0.f;
+  int best_idx = 0x7fffffff, bad = 0;
+#pragma unroll
+  for (int u = 0; u < 12; ++u) visit(pt[u].x, pt[u].y, pt[u].w, u * 256 + threadIdx.x, x0, y0, lo2, hi2, best, best_idx, bad);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float oi = __shfl_xor(best, off, 64);
+    const int ox = __shfl_xor(best_idx, off, 64);
+    if (oi > best || (oi == best && ox < best_idx)) best = oi, best_idx = ox;
+    bad |= __shfl_xor(bad, off, 64);
+  }
+  if (lane == 0) s_best[wave] = best, s_idx[wave] = best_idx, s_bad[wave] = bad;
+  __syncthreads();
+  if (wave == 0) {
+    best = s_best[0], best_idx = s_idx[0], bad = s_bad[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      if (s_best[w] > best || (s_best[w] == best && s_idx[w] < best_idx)) best = s_best[w], best_idx = s_idx[w];
+      bad |= s_bad[w];
+    }
+    const int nb = best_idx == 0x7fffffff ? 0 : best_idx;
+    const float4 q = rp[min(max(nb - 32 + lane, 0), N_BINS - 1)];
+    const unsigned long long keep = __ballot(q.w > 0.5f * best);
+    Rec rc;
+    rc.m = nb, rc.closer = nb - 1, rc.further = nb + 1, rc.kept = __popcll(keep) & 3;
+    rc.angle = x0, rc.maxi = best, rc.range = y0, rc.bad = bad;
+    put_row<MODE>(recs, stage, (size_t)scan * N_AZ + row, lane, rc, q);
+  }
+  finish<MODE>(scan, N_AZ, recs, stage, ticket, out);
+}
+
+// the shipped emission's shape: one 512-thread workgroup per scan over the row records
+__global__ __launch_bounds__(512) void k_emit(const Rec* recs, const float4* stage, float4* out) {
+  const int scan = blockIdx.x, r = threadIdx.x;
+  if (r < N_AZ) {
+    const Rec rc = recs[(size_t)scan * N_AZ + r];
+    const float4* sp = stage + ((size_t)scan * N_AZ + r) * 4;
+    const float4 a = sp[0], b = sp[2];
+    out[(size_t)scan * 4096 + 2 * r] = make_float4(a.x + rc.angle, a.y, a.z, a.w);
+    out[(size_t)scan * 4096 + 2 * r + 1] = make_float4(b.x + rc.maxi, b.y, b.z, b.w);
+  }
+}
+
+template <typename F>
+double time_us(F launch, int reps) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int r = 0; r < 4; ++r) launch(r);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) launch(r);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  return 1e3 * ms / reps;
+}
+
+int main() {
+  const size_t scan_pts = (size_t)N_AZ * N_BINS;
+  const int n_distinct = 64;  // 64 x 19.2 MB = 1.23 GB
+  float4* d_raw;
+  CHECK(hipMalloc(&d_raw, n_distinct * scan_pts * 16));
+  {
+    const size_t n = n_distinct * scan_pts * 4;
+    unsigned int* h = (unsigned int*)malloc(n * 4);
+    unsigned int x = 12345u;
+    for (size_t i = 0; i < n; ++i) {
+      x = x * 1664525u + 1013904223u;
+      h[i] = 0x3f000000u | (x >> 9);
+    }
+    CHECK(hipMemcpy(d_raw, h, n * 4, hipMemcpyHostToDevice));
+    free(h);
+  }
+  Rec* d_recs;
+  float4 *d_stage, *d_out;
+  int* d_ticket;
+  CHECK(hipMalloc(&d_recs, 16 * N_AZ * sizeof(Rec)));
+  CHECK(hipMalloc(&d_stage, 16 * N_AZ * 4 * sizeof(float4)));
+  CHECK(hipMalloc(&d_out, 16 * 4096 * sizeof(float4)));
+  CHECK(hipMalloc(&d_ticket, 64 * sizeof(int)));
+  CHECK(hipMemset(d_ticket, 0, 64 * sizeof(int)));
+  printf("kernel,scans_per_launch,us_per_launch,TB_per_s,frac_of_8\n");
+  for (int ns : {1, 16}) {
+    const double bytes = (double)ns * scan_pts * 16.0;
+    const int n_in = n_distinct / ns;  // distinct inputs to rotate over
+    const int reps = ns == 1 ? 192 : 24;
+    auto in = [&](int r) { return d_raw + (size_t)(r % n_in) * ns * scan_pts; };
+    auto rep = [&](const char* name, double us) { printf("%s,%d,%.2f,%.3f,%.3f\n", name, ns, us, bytes / us * 1e-6, bytes / us * 1e-6 / 8.0); };
+    const int g_wave = ns * ((N_AZ + 3) / 4), g_wg = ns * N_AZ;
+#define RUN(name, K, G)                                                                                                            \
+  CHECK(hipMemset(d_ticket, 0, 64 * sizeof(int)));                                                                                  \
+  rep(name, time_us([&](int r) { hipLaunchKernelGGL(K, dim3(G), dim3(256), 0, 0, in(r), d_recs, d_stage, d_ticket, d_out, 1.0, 1e9); }, reps));
+    RUN("wave_rows", (k_wave_rows<0>), g_wave);
+    RUN("wave_rows+ticket", (k_wave_rows<1>), g_wave);
+    CHECK(hipMemset(d_ticket, 0, 64 * sizeof(int)));
+    RUN("wave_rows+ticket+tail", (k_wave_rows<2>), g_wave);
+    RUN("wg_rows", (k_wg_rows<0>), g_wg);
+    RUN("wg_rows+ticket", (k_wg_rows<1>), g_wg);
+    CHECK(hipMemset(d_ticket, 0, 64 * sizeof(int)));
+    RUN("wg_rows+ticket+tail", (k_wg_rows<2>), g_wg);
+    RUN("wg_rows+release ticket+acquire tail", (k_wg_rows<3>), g_wg);
+    RUN("wg_rows+agent stores+relaxed ticket+agent-load tail", (k_wg_rows<4>), g_wg);
+    RUN("wave_rows+release ticket+acquire tail", (k_wave_rows<3>), g_wave);
+    RUN("wave_rows+agent stores+relaxed ticket+agent-load tail", (k_wave_rows<4>), g_wave);
+    rep("wave_rows then emit kernel", time_us([&](int r) {
+          hipLaunchKernelGGL((k_wave_rows<0>), dim3(g_wave), dim3(256), 0, 0, in(r), d_recs, d_stage, d_ticket, d_out, 1.0, 1e9);
+          hipLaunchKernelGGL(k_emit, dim3(ns), dim3(512), 0, 0, d_recs, d_stage, d_out);
+        }, reps));
+    rep("wg_rows then emit kernel", time_us([&](int r) {
+          hipLaunchKernelGGL((k_wg_rows<0>), dim3(g_wg), dim3(256), 0, 0, in(r), d_recs, d_stage, d_ticket, d_out, 1.0, 1e9);
+          hipLaunchKernelGGL(k_emit, dim3(ns), dim3(512), 0, 0, d_recs, d_stage, d_out);
+        }, reps));
+  }
+  return 0;
+}
