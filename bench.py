@@ -52,6 +52,7 @@ SAT_COPIES = 16                         # chip-filling launch of the roofline se
 HOT_KERNELS = ("k_ndt_build<true,true>", "k_associate<false,64,true,false>", "k_solve<3,1,64,true,4,false>")
 
 
+WINDOW_ROW = {}    # counter row of k_solve_window (the fixed-lag solve of config 3) from the committed summary
 FILTER_ROWS = {}   # counter rows of k_filter_rows / k_filter_emit from the committed summary (load_counters)
 
 
@@ -94,12 +95,15 @@ def load_counters():
         return {}, None, "no committed counter summary"
     rows = {}
     FILTER_ROWS.clear()
+    WINDOW_ROW.clear()
     want_wgs = {"k_ndt_build<true,true>": 512, "k_associate<false,64,true,false>": 128, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch (the association walks four pairs per workgroup)
     stamp = None
     for r in csv.DictReader(open(files[-1])):
         stamp = r.get("csrc_hash", stamp)
         if r["kernel"].startswith("k_filter_") and r["kernel"] not in FILTER_ROWS:     # the config-5 polar filter (16 scans per launch)
             FILTER_ROWS[r["kernel"]] = {k: (float(v) if v not in ("", None) and k not in ("kernel", "csrc_hash") else v) for k, v in r.items()}
+        if r["kernel"].startswith("k_solve_window<") and not WINDOW_ROW:
+            WINDOW_ROW.update({k: (float(v) if v not in ("", None) and k not in ("kernel", "csrc_hash") else v) for k, v in r.items()})
         if r["kernel"] in HOT_KERNELS and r["kernel"] not in rows and int(r["grid_size"]) == want_wgs[r["kernel"]] * int(r["workgroup_size"]):
             rows[r["kernel"]] = {k: (float(v) if v not in ("", None) and k not in ("kernel", "csrc_hash") else v) for k, v in r.items()}
     rel = os.path.relpath(files[-1], ROOT)
@@ -237,6 +241,8 @@ def main():
                     help="pair-solve geometry of the timed region's contexts: throughput = one wavefront per registration, auto = the "
                          "library's choice per launch (splits a lone small batch); default = throughput when several streams keep batches in flight")
     ap.add_argument("--odometry-scans", type=int, default=1000, help="BASELINE config 3 side measurement (0 = skip)")
+    ap.add_argument("--replica-steps", type=int, default=150,
+                    help="side measurement: R = 64 / 256 replicas of config 3's loop in lock-step, this many steps each (0 = skip)")
     ap.add_argument("--cpp-drive-scans", type=int, default=300,
                     help="side measurement: the drop-in path driven from C++ with host buffers and Maps by value (tests/cpp/local_fuser_drive.cpp; 0 = skip)")
     ap.add_argument("--polar-scans", type=int, default=16, help="BASELINE config 5 side measurement: polar filter (0 = skip)")
@@ -580,6 +586,8 @@ def main():
             side("loop_gate_and_search", loop_gate_and_search, R, torch, ctx, submaps, full, mp, weak_prob, not args.no_cpu_baseline, min(2.0, args.cpu_seconds))
         if args.odometry_scans > 0 and world == 1:
             side("config3_streaming_odometry", streaming_odometry, ctx, args.odometry_scans, not args.no_cpu_baseline)
+        if args.replica_steps > 0 and world == 1:
+            side("config3_replicas", config3_replicas, ctx, args.replica_steps)
         if args.cpp_drive_scans > 0 and world == 1:
             py = out.get("config3_streaming_odometry", {})
             side("cpp_local_fuser_drive", cpp_local_fuser_drive, ctx, args.cpp_drive_scans, py.get("ms_per_scan") if isinstance(py, dict) else None)
@@ -1237,6 +1245,75 @@ def streaming_odometry(ctx, n_scans, with_cpu):
                                                    "sample": "the same %d scans, residual blocks over %d OpenMP threads" % (n_cpu, cores)}
         finally:
             po.set_eval_threads(1)
+    return out
+
+
+def config3_replicas(ctx, n_steps, replica_counts=(64, 256)):
+    """BASELINE config 3 does not shard (scan t needs pose t-1: SURVEY 8(e) "replicas only"); its scaling axis is R independent
+    odometry loops on one GPU.  randt-slam_amd/odometry.py::ReplicaOdometry advances R of them in lock-step -- per step ONE NDT
+    build launch (R scans), ONE randt_register_window_batch (R windows, a workgroup each) and, on keyframe steps, ONE
+    randt_maps_merge_batch -- where R Odometry objects need R contexts / streams and a host round trip each.  Replica r
+    replays config 3's drive from scan r on (every replica sees other scans at every step).  Reported per R: scans/s of the
+    whole loop (Python harness: the per-replica host work -- constant-velocity prediction, state packing -- is in it), the
+    window call's share, and the window kernel's issue-slot fraction of the CHIP from the committed counter row of
+    k_solve_window (one window alone: 0.26 of ONE compute unit's issue rate = 0.001 of the chip)."""
+    import torch
+
+    import randt_slam_amd as R
+    from randt_slam_amd import host, odometry, synth
+
+    rmax = max(replica_counts)
+    world = synth.make_world()
+    dt = 0.25
+    traj = synth.make_trajectory(3300, n_steps + rmax, step=0.25)
+    scans = np.stack([synth.make_scan(world, traj[i], 20000 + i) for i in range(n_steps + rmax)])
+    d_all = torch.from_numpy(scans).to(torch.device("cuda", ctx.device))
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    wp = R.window_params()
+    st = torch.cuda.current_stream()
+    out = {"workload": "R replicas of config 3's loop in lock-step, replica r = the drive from scan r on; %d steps per replica, one submap roll-over" % n_steps,
+           "single_loop_reference": "config3_streaming_odometry (one Odometry object, one window per launch)"}
+    cyc = WINDOW_ROW.get("valu_issue_cycles")
+    real_call = host.register_window_batch
+    for n_rep in replica_counts:
+        acc = {"host_s": 0.0, "ev": []}
+
+        def timed_call(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            t0 = time.perf_counter()
+            r = real_call(*a, **k)
+            acc["host_s"] += time.perf_counter() - t0
+            e1.record(st)
+            acc["ev"].append((e0, e1))
+            return r
+
+        for timed in (False, True):
+            rep = odometry.ReplicaOdometry(ctx, n_rep, R.indoor_map_params(), R.indoor_cluster_params(), mp, wp)
+            host.register_window_batch = timed_call if timed else real_call
+            try:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n_steps if timed else min(12, n_steps)):
+                    poses = rep.process_scans(d_all[i:i + n_rep], i * dt)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            finally:
+                host.register_window_batch = real_call
+        dev_ms = float(np.mean([a.elapsed_time(b) for a, b in acc["ev"]]))
+        origin_inv = synth.se2_inv3(traj[0])
+        est = synth.pose4_to_pose3(poses[0])
+        rel = synth.se2_mul3(origin_inv, traj[n_steps - 1])
+        sect = {"replicas": n_rep, "steps": n_steps, "scans_per_sec": n_rep * n_steps / el, "ms_per_step": el / n_steps * 1e3,
+                "window_batch_call_ms_per_step": acc["host_s"] / max(1, len(acc["ev"])) * 1e3, "window_batch_device_ms": dev_ms,
+                "windows_per_sec_in_the_window_call": n_rep / (acc["host_s"] / max(1, len(acc["ev"]))),
+                "registrations": rep.n_registrations, "rejected": rep.n_rejected, "submaps_finished": rep.n_finished_submaps,
+                "replica0_end_pose_error_vs_truth_m": float(np.hypot(est[0] - rel[0], est[1] - rel[1]))}
+        if cyc:
+            sect["window_kernel_issue_frac_of_chip"] = n_rep * float(cyc) / (dev_ms * 1e-3) / (VALU_PEAK * 1e9)
+            sect["window_kernel_issue_cycles_per_window"] = float(cyc)
+        out["R%d" % n_rep] = sect
+        del rep
     return out
 
 

@@ -264,6 +264,11 @@ int randt_maps_transform(randt_maps* m, int first, int count, const double* h_po
  * strictly in order.  The moving maps themselves are not modified.  Asynchronous (the poses are copied before the call returns). */
 int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving, int moving_first,
                      int n_moving, const double* h_pose4);
+/* The same for n_fixed independent submaps in ONE launch (replicas of the odometry advancing in lock-step): fixed map
+ * (fixed_first + p) receives moving maps [moving_first + p * n_moving_each, + n_moving_each) at h_pose4[p * n_moving_each + t],
+ * each merge exactly randt_maps_merge's. */
+int randt_maps_merge_batch(randt_maps* fixed, int fixed_first, int n_fixed, const randt_maps* moving, int moving_first,
+                           int n_moving_each, const double* h_pose4);
 /* NOT in the reference: rebuild the index grid of maps [first, first+count) from the cells' current means (async).
  * Map::transformMap leaves grid_indizes_ stale (ndt_map.cpp:177-182), so a transformed map answers getClosestCells
  * through the slots its cells USED to occupy -- which is what randt_maps_transform reproduces.  Callers that want a
@@ -458,6 +463,8 @@ int randt_predict_state(const randt_state* last, double stamp, randt_state* next
  * takes when optimize_on_manifold is false (ndt_matcher.cpp:27-41): mid-point heading, NormalizeAngle'd rotation,
  * pose = Sophus::SE2d(rot, pos). */
 int randt_predict_state_param(const randt_state* last, double stamp, int parameterization, randt_state* next);
+/* The same for n independent states (the replicas of randt_register_window_batch): next[i] = prediction of last[i] to `stamp`. */
+int randt_predict_state_batch(const randt_state* last, int n, double stamp, int parameterization, randt_state* next);
 /* Matcher::estimateTransformCeres (ndt_matcher.cpp:322-424): fixed-lag smoother over n_states = S+1
  * states (oldest first; its pose is held constant), S <= 12, n_fixed <= 2 (the shipped lag smoothing_steps: 3 runs the kernel
  * tuned for it, window.hip; lags 4..7 -- ndt_matcher.cpp:343 takes any -- the general kernel, window_gen.hip; 8..12 the same
@@ -478,6 +485,17 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
                           const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
                           const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
                           double h_trans4[4], int* rejected, randt_result* h_result);
+/* NOT in the reference (its node runs one odometry): n_windows INDEPENDENT fixed-lag windows of one shape -- the same number of
+ * states and of fixed maps, e.g. R replicas of the sequential path ("replicas only") advancing in lock-step, or one
+ * window re-solved from n_windows priors -- in ONE association launch and ONE solve launch (a workgroup per window: the single
+ * entry uses 1 of the chip's 256 compute units), one pinned image per direction, one synchronisation.  Window w is exactly what
+ * randt_register_window computes for its slice of the window-major arrays (bit-identical): h_fixed_idx[w][n_fixed],
+ * h_moving_idx[w][n_states - 1], h_states[w][n_states] (in / out), h_imu[w][n_states - 1] (nullable), h_trans4[w][4] (in: prior,
+ * out: newest pose), rejected[w], h_results[w] (both nullable).  All windows read their maps from the two batches `fixed` / `moving`. */
+int randt_register_window_batch(randt_ctx* ctx, int n_windows, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
+                                const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
+                                const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
+                                double* h_trans4, int* rejected, randt_result* h_results);
 
 /* ------------------------------------------------------------------ pose graph (f-4) */
 /* GlobalFuser::optimizePoseGraph (src/global_fuser/global_fuser.cpp:13-105): 2-D pose graph with

@@ -132,6 +132,7 @@ SYMBOLS = {
     "randt_ndt_build_pndt_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _V, _V, _P(ClusterParams), _V, _I]),
     "randt_maps_transform": (_I, [_V, _I, _I, _V]),
     "randt_maps_merge": (_I, [_V, _I, _V, _I, _I, _V]),
+    "randt_maps_merge_batch": (_I, [_V, _I, _I, _V, _I, _I, _V]),
     "randt_maps_reindex": (_I, [_V, _I, _I]),
     "randt_maps_insert_cluster": (_I, [_V, _I, _V, _I, _I, _I, _P(_I)]),
     "randt_maps_insert_cells": (_I, [_V, _I, _V, _I, _I]),
@@ -164,7 +165,9 @@ SYMBOLS = {
     "randt_pose_graph_optimize": (_I, [_V, _I, _V, _I, _V, _V, _V, _V, _I, _P(PgParams), _P(PgResult)]),
     "randt_predict_state": (_I, [_V, C.c_double, _V]),
     "randt_predict_state_param": (_I, [_V, C.c_double, _I, _V]),
+    "randt_predict_state_batch": (_I, [_V, _I, C.c_double, _I, _V]),
     "randt_register_window": (_I, [_V, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _P(_I), _V]),
+    "randt_register_window_batch": (_I, [_V, _I, _V, _V, _I, _V, _V, _V, _I, _V, _P(MatcherParams), _P(WindowParams), _V, _V, _V]),
     # multi-GPU group
     "randt_shard_range": (None, [_I, _I, _I, _P(_I), _P(_I)]),
     "randt_group_create": (_I, [_P(_I), _I, _P(_V), _I, _P(_V)]),

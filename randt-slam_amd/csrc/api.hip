@@ -1009,6 +1009,23 @@ int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving,
   return must_sync ? randt_ctx_synchronize(ctx) : RANDT_OK;
 }
 
+int randt_maps_merge_batch(randt_maps* fixed, int fixed_first, int n_fixed, const randt_maps* moving, int moving_first, int n_moving_each,
+                           const double* h_pose4) {
+  DeviceGuard dev_guard__(fixed ? fixed->ctx : nullptr);
+  if (!range_ok(fixed, fixed_first, n_fixed) || n_moving_each < 0 || !range_ok(moving, moving_first, n_fixed * (n_moving_each > 0 ? n_moving_each : 0)) ||
+      (n_fixed > 0 && n_moving_each > 0 && !h_pose4) || !fixed->v.grid)
+    return RANDT_ERR_INVALID;
+  if (n_fixed == 0 || n_moving_each == 0) return RANDT_OK;
+  randt_ctx* ctx = fixed->ctx;
+  const double* d_pose4 = nullptr;
+  bool must_sync = false;
+  int rc = stage_poses(ctx, h_pose4, n_fixed * n_moving_each, &d_pose4, &must_sync);
+  if (rc) return rc;
+  rc = launch_maps_merge(ctx, fixed->v, fixed_first, moving->v, moving_first, n_moving_each, d_pose4, n_fixed);
+  if (rc) return rc;
+  return must_sync ? randt_ctx_synchronize(ctx) : RANDT_OK;
+}
+
 // The solve kernels run the reference's GNC / trust-region loops ON THE DEVICE (`do { ... mu /= divisor } while (mu > 1 /
 // sqrt(divisor))`, ndt_matcher.cpp:382-397,466-483): a divisor <= 1 or a non-finite scale that merely hangs a CPU thread
 // in the reference would hang a GPU queue here, so the ABI rejects such parameter sets before anything is enqueued.
@@ -1612,12 +1629,25 @@ int randt_predict_state_param(const randt_state* last, double stamp, int paramet
   return RANDT_OK;
 }
 
-int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
-                          const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
-                          const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
-                          double h_trans4[4], int* rejected, randt_result* h_result) {
+int randt_predict_state_batch(const randt_state* last, int n, double stamp, int parameterization, randt_state* next) {
+  if (n < 0 || (n > 0 && (!last || !next))) return RANDT_ERR_INVALID;
+  for (int i = 0; i < n; ++i) {
+    const int rc = randt_predict_state_param(&last[i], stamp, parameterization, &next[i]);
+    if (rc) return rc;
+  }
+  return RANDT_OK;
+}
+
+// n_windows fixed-lag windows of ONE shape (the same number of states and of fixed maps: replicas in lock-step) in one
+// association launch + one solve launch (a workgroup per window), one pinned image up and one back, one synchronisation.
+// Arrays are window-major: h_fixed_idx[w][n_fixed], h_moving_idx[w][S], h_states[w][n_states], h_imu[w][S], h_trans4[w][4].
+static int register_windows(randt_ctx* ctx, int n_windows, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
+                            const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
+                            const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp, double* h_trans4,
+                            int* rejected, randt_result* h_results) {
   DeviceGuard dev_guard__(ctx);
-  if (!ctx || !fixed || !moving || !h_fixed_idx || !h_moving_idx || !h_states || !mp || !wp || !h_trans4) return RANDT_ERR_INVALID;
+  if (!ctx || !fixed || !moving || !h_fixed_idx || !h_moving_idx || !h_states || !mp || !wp || !h_trans4 || n_windows < 0) return RANDT_ERR_INVALID;
+  if (n_windows == 0) return RANDT_OK;
   const int S = n_states - 1;
   if (S < 1 || S > RANDT_WIN_MAX_STATES - 1 || n_fixed < 1 || n_fixed > 2)
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window: 1..12 optimised states, 1..2 fixed maps", hipSuccess);
@@ -1633,141 +1663,180 @@ int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t
     if (!(isfinite(wp->ndt_weight) && wp->ndt_weight > 0.0) || !isfinite(wp->weight_imu) || !isfinite(wp->weight_imu_bias))
       return randt_set_error(ctx, RANDT_ERR_INVALID, "window weights must be finite (ndt_weight > 0)", hipSuccess);
   }
-  for (int f = 0; f < n_fixed; ++f)
-    if (!range_ok(fixed, h_fixed_idx[f], 1)) return RANDT_ERR_INVALID;
-  for (int j = 0; j < S; ++j)
-    if (!range_ok(moving, h_moving_idx[j], 1)) return RANDT_ERR_INVALID;
+  for (int w = 0; w < n_windows; ++w) {
+    for (int f = 0; f < n_fixed; ++f)
+      if (!range_ok(fixed, h_fixed_idx[(size_t)w * n_fixed + f], 1)) return RANDT_ERR_INVALID;
+    for (int j = 0; j < S; ++j)
+      if (!range_ok(moving, h_moving_idx[(size_t)w * S + j], 1)) return RANDT_ERR_INVALID;
+  }
   const int k = mp->n_neighbours;
-  const double prior_t[2] = {h_trans4[2], h_trans4[3]};
-  const double prior_rot = atan2(h_trans4[1], h_trans4[0]);
+  const int T = S * n_fixed;  // NDT terms per window
+  const size_t NT = (size_t)n_windows * T;
+  if (NT * moving->v.cap * k > 0x7fffffffull) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window batch: correspondence tables beyond 2^31 entries", hipSuccess);
 
-  WinDesc W;
-  memset(&W, 0, sizeof(W));
-  W.S = S;
-  W.vec = vec ? 1 : 0;
-  W.pad_ = mp->parameterization == RANDT_PARAM_ANALYTIC ? 1 : 0;  // the NDT functor's analytic rotation Jacobian (launch_solve_window picks the instantiation)
-  W.k = k;
-  W.d3 = mp->use_intensity ? 1 : 0;
-  W.const_vel = wp->use_constant_velocity_model ? 1 : 0;
-  W.use_imu = (wp->use_imu && h_imu) ? 1 : 0;
-  W.w_imu = wp->weight_imu;
-  W.w_bias = wp->weight_imu_bias;
-  W.ndt_weight = wp->ndt_weight;
-  memcpy(W.sqrtI, wp->motion_sqrtI, sizeof(W.sqrtI));
-  // tangent / ambient layout in Ceres' parameter-block order (ndt_matcher.cpp:290-320)
-  int a = 0, t = 0;
-  for (int j = 0; j <= S; ++j) {
-    if (j == 0) { W.off_amb[j][0] = W.off_tan[j][0] = -1; } else { W.off_amb[j][0] = a; W.off_tan[j][0] = t; a += vec ? 3 : 4; t += 3; }
-    W.off_amb[j][1] = a; W.off_tan[j][1] = t; a += 2; t += 2;
-    W.off_amb[j][2] = a; W.off_tan[j][2] = t; a += 1; t += 1;
-    if (W.const_vel) { W.off_amb[j][3] = W.off_tan[j][3] = -1; } else { W.off_amb[j][3] = a; W.off_tan[j][3] = t; a += 2; t += 2; }
-    if (W.use_imu && j > 0) { W.off_amb[j][4] = a; W.off_tan[j][4] = t; a += 1; t += 1; } else { W.off_amb[j][4] = W.off_tan[j][4] = -1; }
-    if (j > 0) {
-      W.raw_dt[j] = h_states[j].stamp - h_states[j - 1].stamp;
-      W.imu[j - 1] = W.use_imu ? h_imu[j - 1] : 0.0;
-    }
-  }
-  W.n_amb = a;
-  W.n_tan = t;
-  W.n_terms = 0;
-  int32_t h_idx[2 * RANDT_WIN_MAX_TERMS];
-  double h_guess[4 * RANDT_WIN_MAX_TERMS];
-  for (int j = 1; j <= S; ++j)
-    for (int f = 0; f < n_fixed; ++f) {
-      const int q = W.n_terms++;
-      W.term_state[q] = j;
-      W.term_moving[q] = h_moving_idx[j - 1];
-      W.term_fixed[q] = h_fixed_idx[f];
-      h_idx[q] = h_fixed_idx[f];
-      h_idx[RANDT_WIN_MAX_TERMS + q] = h_moving_idx[j - 1];
-      memcpy(h_guess + 4 * q, h_states[j].pose, sizeof(double) * 4);  // association at the state's own pose (:364)
-    }
-  // workspace: corr | [ states | guess | idx | result | descriptor ]  -- the bracketed span is ONE host image, staged in
-  // pinned memory and moved with one copy per direction (five small pageable copies cost ~40 us per scan)
-  const size_t corr_bytes = sizeof(int32_t) * (size_t)W.n_terms * moving->v.cap * k;
+  // device workspace: corr | [ states | results | guess | fixed idx | moving idx | descriptors ] -- the bracketed span is ONE
+  // host image, staged in pinned memory and moved with one copy per direction: all of it up, [ states | results ] back
+  // (five small pageable copies cost ~40 us per scan)
+  const size_t st_stride = 12 * RANDT_WIN_MAX_STATES;  // doubles per window (window.hip, ST_STRIDE x states)
+  const size_t corr_stride = (size_t)T * moving->v.cap * k;
+  const size_t corr_bytes = sizeof(int32_t) * corr_stride * n_windows;
   const size_t off_states = (corr_bytes + 255) & ~(size_t)255;
-  const size_t off_guess = off_states + sizeof(double) * 12 * RANDT_WIN_MAX_STATES;
-  const size_t off_idx = off_guess + sizeof(h_guess);
-  const size_t off_res = off_idx + sizeof(h_idx) + 64;
-  const size_t off_desc = (off_res + sizeof(randt_result) + 64 + 255) & ~(size_t)255;
-  const size_t span = off_desc + sizeof(WinDesc) - off_states;
-  int rc = ensure_ws(ctx, off_desc + sizeof(WinDesc) + 64);
+  const size_t res_bytes = sizeof(randt_result) * n_windows;
+  const size_t off_res = off_states + sizeof(double) * st_stride * n_windows;
+  const size_t off_guess = off_res + res_bytes;
+  const size_t off_fidx = off_guess + sizeof(double) * 4 * NT;
+  const size_t off_midx = off_fidx + ((sizeof(int32_t) * NT + 63) & ~(size_t)63);
+  const size_t off_desc = (off_midx + sizeof(int32_t) * NT + 255) & ~(size_t)255;
+  const size_t up_span = off_desc + sizeof(WinDesc) * n_windows - off_states;
+  const size_t back_span = off_guess - off_states;  // states | results
+  int rc = ensure_ws(ctx, off_states + up_span + 64);
   if (rc) return rc;
-  if (!ctx->h_pin) RANDT_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pin, 16384, hipHostMallocDefault));
-  if (span > 8192) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window staging image too large", hipSuccess);
-  char* ws = (char*)ctx->ws;
-  char* img = (char*)ctx->h_pin;           // upload image; the download lands at img + 8192
-  memset(img, 0, span);
-  double* h_packed = reinterpret_cast<double*>(img);
-  for (int j = 0; j <= S; ++j) {  // 12 doubles per state (window.hip, ST_STRIDE)
-    double* o = h_packed + 12 * j;
-    if (vec) {  // the parameters are pos and rot; the pose slots carry cos / sin of rot for the NDT pass
-      o[0] = cos(h_states[j].rot); o[1] = sin(h_states[j].rot); o[2] = h_states[j].pos[0]; o[3] = h_states[j].pos[1];
-    } else {
-      memcpy(o, h_states[j].pose, sizeof(double) * 4);
+  const size_t pin_need = up_span + back_span + 512;
+  if (pin_need > ctx->h_pin_bytes) {
+    if (ctx->h_pin) {
+      RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+      (void)hipHostFree(ctx->h_pin);
+      ctx->h_pin = nullptr;
+      ctx->h_pin_bytes = 0;
     }
-    o[4] = h_states[j].lin_vel[0]; o[5] = h_states[j].lin_vel[1]; o[6] = h_states[j].rot_vel;
-    o[7] = h_states[j].lin_acc[0]; o[8] = h_states[j].lin_acc[1]; o[9] = h_states[j].imu_bias;
-    o[10] = h_states[j].rot; o[11] = 0.0;
+    const size_t want = pin_need < 16384 ? 16384 : pin_need + pin_need / 2;
+    RANDT_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault));
+    ctx->h_pin_bytes = want;
   }
-  memcpy(img + (off_guess - off_states), h_guess, sizeof(h_guess));
-  memcpy(img + (off_idx - off_states), h_idx, sizeof(h_idx));
-  // the window descriptor is indexed dynamically by the kernel: it lives in device memory, not in kernel arguments
-  memcpy(img + (off_desc - off_states), &W, sizeof(W));
-  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_states, img, span, hipMemcpyHostToDevice, ctx->stream));
-  const int32_t* d_fidx = (const int32_t*)(ws + off_idx);
-  const int32_t* d_midx = d_fidx + RANDT_WIN_MAX_TERMS;
-  rc = launch_associate(ctx, fixed->v, d_fidx, moving->v, 0, W.n_terms, (const double*)(ws + off_guess), k, mp->lookup_mahalanobis,
-                        mp->use_intensity, (int32_t*)ws, d_midx);
+  char* ws = (char*)ctx->ws;
+  char* img = (char*)ctx->h_pin;  // upload image; the download lands behind it
+  char* back = img + ((up_span + 255) & ~(size_t)255);
+  memset(img, 0, up_span);
+  double* h_guess = reinterpret_cast<double*>(img + (off_guess - off_states));
+  int32_t* h_fi = reinterpret_cast<int32_t*>(img + (off_fidx - off_states));
+  int32_t* h_mi = reinterpret_cast<int32_t*>(img + (off_midx - off_states));
+  WinDesc* h_desc = reinterpret_cast<WinDesc*>(img + (off_desc - off_states));
+  for (int w = 0; w < n_windows; ++w) {
+    const randt_state* st = h_states + (size_t)w * n_states;
+    const int32_t* fidx = h_fixed_idx + (size_t)w * n_fixed;
+    const int32_t* midx = h_moving_idx + (size_t)w * S;
+    const double* imu = h_imu ? h_imu + (size_t)w * S : nullptr;
+    WinDesc& W = h_desc[w];
+    W.S = S;
+    W.vec = vec ? 1 : 0;
+    W.pad_ = mp->parameterization == RANDT_PARAM_ANALYTIC ? 1 : 0;  // the NDT functor's analytic rotation Jacobian (launch_solve_window picks the instantiation)
+    W.k = k;
+    W.d3 = mp->use_intensity ? 1 : 0;
+    W.const_vel = wp->use_constant_velocity_model ? 1 : 0;
+    W.use_imu = (wp->use_imu && imu) ? 1 : 0;
+    W.w_imu = wp->weight_imu;
+    W.w_bias = wp->weight_imu_bias;
+    W.ndt_weight = wp->ndt_weight;
+    memcpy(W.sqrtI, wp->motion_sqrtI, sizeof(W.sqrtI));
+    // tangent / ambient layout in Ceres' parameter-block order (ndt_matcher.cpp:290-320)
+    int a = 0, t = 0;
+    for (int j = 0; j <= S; ++j) {
+      if (j == 0) { W.off_amb[j][0] = W.off_tan[j][0] = -1; } else { W.off_amb[j][0] = a; W.off_tan[j][0] = t; a += vec ? 3 : 4; t += 3; }
+      W.off_amb[j][1] = a; W.off_tan[j][1] = t; a += 2; t += 2;
+      W.off_amb[j][2] = a; W.off_tan[j][2] = t; a += 1; t += 1;
+      if (W.const_vel) { W.off_amb[j][3] = W.off_tan[j][3] = -1; } else { W.off_amb[j][3] = a; W.off_tan[j][3] = t; a += 2; t += 2; }
+      if (W.use_imu && j > 0) { W.off_amb[j][4] = a; W.off_tan[j][4] = t; a += 1; t += 1; } else { W.off_amb[j][4] = W.off_tan[j][4] = -1; }
+      if (j > 0) {
+        W.raw_dt[j] = st[j].stamp - st[j - 1].stamp;
+        W.imu[j - 1] = W.use_imu ? imu[j - 1] : 0.0;
+      }
+    }
+    W.n_amb = a;
+    W.n_tan = t;
+    W.n_terms = 0;
+    for (int j = 1; j <= S; ++j)
+      for (int f = 0; f < n_fixed; ++f) {
+        const int q = W.n_terms++;
+        W.term_state[q] = j;
+        W.term_moving[q] = midx[j - 1];
+        W.term_fixed[q] = fidx[f];
+        h_fi[(size_t)w * T + q] = fidx[f];
+        h_mi[(size_t)w * T + q] = midx[j - 1];
+        memcpy(h_guess + 4 * ((size_t)w * T + q), st[j].pose, sizeof(double) * 4);  // association at the state's own pose (:364)
+      }
+    double* h_packed = reinterpret_cast<double*>(img) + st_stride * w;
+    for (int j = 0; j <= S; ++j) {  // 12 doubles per state (window.hip, ST_STRIDE)
+      double* o = h_packed + 12 * j;
+      if (vec) {  // the parameters are pos and rot; the pose slots carry cos / sin of rot for the NDT pass
+        o[0] = cos(st[j].rot); o[1] = sin(st[j].rot); o[2] = st[j].pos[0]; o[3] = st[j].pos[1];
+      } else {
+        memcpy(o, st[j].pose, sizeof(double) * 4);
+      }
+      o[4] = st[j].lin_vel[0]; o[5] = st[j].lin_vel[1]; o[6] = st[j].rot_vel;
+      o[7] = st[j].lin_acc[0]; o[8] = st[j].lin_acc[1]; o[9] = st[j].imu_bias;
+      o[10] = st[j].rot; o[11] = 0.0;
+    }
+  }
+  // (the window descriptors are indexed dynamically by the kernel: they live in device memory, not in kernel arguments)
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + off_states, img, up_span, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_associate(ctx, fixed->v, (const int32_t*)(ws + off_fidx), moving->v, 0, (int)NT, (const double*)(ws + off_guess), k, mp->lookup_mahalanobis,
+                        mp->use_intensity, (int32_t*)ws, (const int32_t*)(ws + off_midx));
   if (rc) return rc;
-  rc = launch_solve_window(ctx, fixed->v, moving->v, W, (const WinDesc*)(ws + off_desc), (const int32_t*)ws, mp, (double*)(ws + off_states), (randt_result*)(ws + off_res));
+  rc = launch_solve_window(ctx, fixed->v, moving->v, h_desc[0], (const WinDesc*)(ws + off_desc), (const int32_t*)ws, mp, (double*)(ws + off_states),
+                           (randt_result*)(ws + off_res), n_windows, (int)corr_stride, (int)st_stride);
   if (rc) return rc;
-  randt_result r;
-  char* back = img + 8192;
-  const size_t back_span = off_res + sizeof(randt_result) - off_states;
   RANDT_HIP_CHECK(ctx, hipMemcpyAsync(back, ws + off_states, back_span, hipMemcpyDeviceToHost, ctx->stream));
   RANDT_HIP_CHECK(ctx, randt_sync(ctx));
-  memcpy(&r, back + (off_res - off_states), sizeof(r));
-  h_packed = reinterpret_cast<double*>(back);
-  for (int j = 0; j <= S; ++j) {
-    const double* o = h_packed + 12 * j;
-    h_states[j].lin_vel[0] = o[4]; h_states[j].lin_vel[1] = o[5]; h_states[j].rot_vel = o[6];
-    h_states[j].lin_acc[0] = o[7]; h_states[j].lin_acc[1] = o[8]; h_states[j].imu_bias = o[9];
-    // both pose representations (ndt_matcher.cpp:399-406, local_fuser.cpp:141-150)
-    h_states[j].pos[0] = o[2];
-    h_states[j].pos[1] = o[3];
-    if (vec) {  // Sophus::SE2d(rot, pos)
-      h_states[j].rot = o[10];
-      h_states[j].pose[0] = cos(o[10]); h_states[j].pose[1] = sin(o[10]); h_states[j].pose[2] = o[2]; h_states[j].pose[3] = o[3];
-    } else {
-      memcpy(h_states[j].pose, o, sizeof(double) * 4);
-      h_states[j].rot = atan2(o[1], o[0]);
+  for (int w = 0; w < n_windows; ++w) {
+    randt_state* st = h_states + (size_t)w * n_states;
+    double* trans4 = h_trans4 + 4 * (size_t)w;
+    const double prior_t[2] = {trans4[2], trans4[3]};
+    const double prior_rot = atan2(trans4[1], trans4[0]);
+    const double* h_packed = reinterpret_cast<const double*>(back) + st_stride * w;
+    for (int j = 0; j <= S; ++j) {
+      const double* o = h_packed + 12 * j;
+      st[j].lin_vel[0] = o[4]; st[j].lin_vel[1] = o[5]; st[j].rot_vel = o[6];
+      st[j].lin_acc[0] = o[7]; st[j].lin_acc[1] = o[8]; st[j].imu_bias = o[9];
+      // both pose representations (ndt_matcher.cpp:399-406, local_fuser.cpp:141-150)
+      st[j].pos[0] = o[2];
+      st[j].pos[1] = o[3];
+      if (vec) {  // Sophus::SE2d(rot, pos)
+        st[j].rot = o[10];
+        st[j].pose[0] = cos(o[10]); st[j].pose[1] = sin(o[10]); st[j].pose[2] = o[2]; st[j].pose[3] = o[3];
+      } else {
+        memcpy(st[j].pose, o, sizeof(double) * 4);
+        st[j].rot = atan2(o[1], o[0]);
+      }
     }
-  }
-  // rejection gate (ndt_matcher.cpp:411-422)
-  int rej = 0;
-  {
-    randt_state* X = &h_states[S];
-    const double pc = cos(prior_rot), ps = sin(prior_rot);
-    const double re = X->pose[0] * pc + X->pose[1] * ps, im = X->pose[0] * ps - X->pose[1] * pc;
-    const double dth = atan2(im, re);
-    if (fabs(X->pose[2] - prior_t[0]) > wp->pose_reject_translation || fabs(X->pose[3] - prior_t[1]) > wp->pose_reject_translation ||
-        fabs(dth) > wp->pose_reject_rotation) {
-      printf("Rejected new estimated transform!\n");
-      rej = 1;
-      memcpy(X->pos, h_states[S - 1].pos, sizeof(X->pos));
-      memcpy(X->pose, h_states[S - 1].pose, sizeof(X->pose));
-      X->rot = h_states[S - 1].rot;
-      X->lin_vel[0] = X->lin_vel[1] = 0.0;
-      X->rot_vel = 0.0;
-      X->lin_acc[0] = X->lin_acc[1] = 0.0;
-      X->imu_bias = h_states[S - 1].imu_bias;
+    // rejection gate (ndt_matcher.cpp:411-422)
+    int rej = 0;
+    {
+      randt_state* X = &st[S];
+      const double pc = cos(prior_rot), ps = sin(prior_rot);
+      const double re = X->pose[0] * pc + X->pose[1] * ps, im = X->pose[0] * ps - X->pose[1] * pc;
+      const double dth = atan2(im, re);
+      if (fabs(X->pose[2] - prior_t[0]) > wp->pose_reject_translation || fabs(X->pose[3] - prior_t[1]) > wp->pose_reject_translation ||
+          fabs(dth) > wp->pose_reject_rotation) {
+        printf("Rejected new estimated transform!\n");
+        rej = 1;
+        memcpy(X->pos, st[S - 1].pos, sizeof(X->pos));
+        memcpy(X->pose, st[S - 1].pose, sizeof(X->pose));
+        X->rot = st[S - 1].rot;
+        X->lin_vel[0] = X->lin_vel[1] = 0.0;
+        X->rot_vel = 0.0;
+        X->lin_acc[0] = X->lin_acc[1] = 0.0;
+        X->imu_bias = st[S - 1].imu_bias;
+      }
     }
+    memcpy(trans4, st[S].pose, sizeof(double) * 4);
+    if (rejected) rejected[w] = rej;
+    if (h_results) memcpy(&h_results[w], back + (off_res - off_states) + sizeof(randt_result) * w, sizeof(randt_result));
   }
-  memcpy(h_trans4, h_states[S].pose, sizeof(double) * 4);
-  if (rejected) *rejected = rej;
-  if (h_result) *h_result = r;
   return RANDT_OK;
+}
+
+int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
+                          const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
+                          const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
+                          double h_trans4[4], int* rejected, randt_result* h_result) {
+  return register_windows(ctx, 1, fixed, h_fixed_idx, n_fixed, moving, h_moving_idx, h_states, n_states, h_imu, mp, wp, h_trans4, rejected, h_result);
+}
+
+int randt_register_window_batch(randt_ctx* ctx, int n_windows, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
+                                const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
+                                const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,
+                                double* h_trans4, int* rejected, randt_result* h_results) {
+  return register_windows(ctx, n_windows, fixed, h_fixed_idx, n_fixed, moving, h_moving_idx, h_states, n_states, h_imu, mp, wp, h_trans4, rejected, h_results);
 }
 
 }  // extern "C"

@@ -33,6 +33,11 @@ __global__ __launch_bounds__(256) void k_maps_merge(MapView fixed, int fixed_idx
   uint32_t* slots = reinterpret_cast<uint32_t*>(smem);
   int* scratch = reinterpret_cast<int*>(slots + moving.cap);
   const int tid = threadIdx.x;
+  // a batch of independent merges (randt_maps_merge_batch): workgroup p merges moving maps [moving_first + p n_moving, + n_moving)
+  // into fixed map fixed_idx + p (one pair: blockIdx.x = 0)
+  fixed_idx += blockIdx.x;
+  moving_first += blockIdx.x * n_moving;
+  pose4 += 4 * (size_t)blockIdx.x * n_moving;
   randt_cell* fcells = fixed.cells + (size_t)fixed_idx * fixed.cap;
   int32_t* fgrid = fixed.grid + (size_t)fixed_idx * fixed.n_slots;
   int n_cells = fixed.counts[fixed_idx];
@@ -192,8 +197,8 @@ int launch_maps_transform(randt_ctx* ctx, const MapView& m, int first, int count
 }
 
 int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const MapView& moving, int moving_first,
-                      int n_moving, const double* d_pose4) {
-  if (n_moving <= 0) return RANDT_OK;
+                      int n_moving, const double* d_pose4, int n_pairs) {
+  if (n_moving <= 0 || n_pairs <= 0) return RANDT_OK;
   size_t lds = (size_t)moving.cap * 4 + 64;
   if (lds > (size_t)ctx->lds_limit) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "moving map capacity too large for merge kernel", hipSuccess);
   static size_t lds_granted = 0;  // the attribute is per process and device code object; raised, never lowered
@@ -202,7 +207,7 @@ int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_granted = lds;
   }
-  hipLaunchKernelGGL(k_maps_merge, dim3(1), dim3(256), lds, ctx->stream, fixed, fixed_idx, moving, moving_first,
+  hipLaunchKernelGGL(k_maps_merge, dim3(n_pairs), dim3(256), lds, ctx->stream, fixed, fixed_idx, moving, moving_first,
                      n_moving, d_pose4);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;

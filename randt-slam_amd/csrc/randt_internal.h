@@ -34,7 +34,8 @@ struct randt_ctx {
   // scratch (grown on demand, never inside a timed region after warm-up)
   void* ws = nullptr;
   size_t ws_bytes = 0;
-  void* h_pin = nullptr;     // 16 KB of pinned host memory: staging image of the synchronous host-level entries (one copy per direction)
+  void* h_pin = nullptr;     // pinned host memory: staging image of the window entries (one copy per direction), grown on demand
+  size_t h_pin_bytes = 0;
   void* small = nullptr;     // 4 KB of device scratch for the synchronous host-level conveniences (lazily allocated)
   void* build_ws = nullptr;  // label scratch of k_ndt_build's fallback sort (its own buffer: callers stage points in ws)
   size_t build_ws_bytes = 0;
@@ -151,7 +152,7 @@ int launch_maps_reindex(randt_ctx* ctx, const MapView& m, int first, int count);
 int launch_maps_append(randt_ctx* ctx, const MapView& dst, int dst_idx, const MapView& src, int src_idx, int set_grid,
                        int32_t* d_status, int accumulate /* status[] += instead of = */);
 int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const MapView& moving, int moving_first,
-                      int n_moving, const double* d_pose4);
+                      int n_moving, const double* d_pose4, int n_pairs = 1);
 int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
                      int moving_first, int n_pairs, const double* d_guess4, int k, int lookup_mahalanobis,
                      int use_intensity, int32_t* d_corr, const int32_t* d_moving_idx = nullptr);
@@ -170,15 +171,20 @@ struct WinDesc {
   double raw_dt[RANDT_WIN_MAX_STATES];  // stamp[j] - stamp[j-1], index j
   double w_imu, w_bias, ndt_weight;
 };
+// n_windows windows of ONE shape (desc = the first one's: S, n_terms, layout) in one launch, one workgroup each; window w's
+// descriptor is d_desc[w], its correspondence tables / states / result lie w * corr_stride ints / w * state_stride doubles / w
+// records behind the first window's
 int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
-                        const int32_t* d_corr, const randt_matcher_params* mp, double* d_states /* (S+1) x 10 */,
-                        randt_result* d_result);
+                        const int32_t* d_corr, const randt_matcher_params* mp, double* d_states /* (S+1) x 12 */,
+                        randt_result* d_result, int n_windows = 1, int corr_stride = 0, int state_stride = 0);
 // window_gen.hip: the general kernel (4..7 optimised states); launch_solve_window routes to it, and it routes 8..12 states to
 // the second compilation of the same source (window_gen_big.hip)
 int launch_solve_window_gen(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
-                            const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result);
+                            const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result, int n_windows,
+                            int corr_stride, int state_stride);
 int launch_solve_window_gen_big(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
-                                const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result);
+                                const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result, int n_windows,
+                                int corr_stride, int state_stride);
 int launch_solve(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving,
                  int moving_first, int n_pairs, const int32_t* d_corr, const randt_matcher_params* mp,
                  double* d_pose4, randt_result* d_results);

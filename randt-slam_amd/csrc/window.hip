@@ -672,8 +672,15 @@ template <int D, bool AM2, bool ANALYTIC>
 __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapView moving, const WinDesc* __restrict__ Wp,
                                                             const int32_t* __restrict__ corr, SolveParams P,
                                                             double* __restrict__ states, randt_result* __restrict__ result,
-                                                            double* trace, int trace_len) {
+                                                            double* trace, int trace_len, int corr_stride, int state_stride) {
   __shared__ Shared sh;
+  // one workgroup per window of a batch (randt_register_window_batch): descriptors, correspondence tables, states, results and
+  // traces of window w lie w strides behind the first window's (a single window: blockIdx.x = 0)
+  Wp += blockIdx.x;
+  corr += (size_t)blockIdx.x * corr_stride;
+  states += (size_t)blockIdx.x * state_stride;
+  result += blockIdx.x;
+  if (trace) trace += (size_t)blockIdx.x * trace_len;
   // dynamically indexed (state j, term t): read from device memory on demand instead of pinning ~200 SGPRs
   const WinDesc& W = *Wp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1124,7 +1131,9 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
 }  // namespace
 
 int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
-                        const int32_t* d_corr, const randt_matcher_params* mp, double* d_states, randt_result* d_result) {
+                        const int32_t* d_corr, const randt_matcher_params* mp, double* d_states, randt_result* d_result, int n_windows,
+                        int corr_stride, int state_stride) {
+  if (n_windows <= 0) return RANDT_OK;
   SolveParams P;
   P.loss_a = mp->loss_scale;
   P.mu_scale = mp->mu_scale;
@@ -1148,10 +1157,10 @@ int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& mov
   P.max_invalid = mp->max_consecutive_invalid_steps;
   // more than three optimised states (no shipped configuration): the general kernel
   if (desc.n_tan > WIN_NMAX || desc.S > WIN_SMAX || desc.n_terms > 6 || ctx->window_general)
-    return launch_solve_window_gen(ctx, fixed, moving, desc, d_desc, d_corr, P, d_states, d_result);
+    return launch_solve_window_gen(ctx, fixed, moving, desc, d_desc, d_corr, P, d_states, d_result, n_windows, corr_stride, state_stride);
 #define RANDT_WIN_LAUNCH(DD, AA, NN)                                                                                       \
-  hipLaunchKernelGGL((k_solve_window<DD, AA, NN>), dim3(1), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
-                     d_states, d_result, ctx->d_trace, ctx->trace_len)
+  hipLaunchKernelGGL((k_solve_window<DD, AA, NN>), dim3(n_windows), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
+                     d_states, d_result, ctx->d_trace, ctx->trace_len, corr_stride, state_stride)
   const bool am2 = P.alpha == -2.0;
   if (desc.pad_) {  // RANDT_PARAM_ANALYTIC: the reference's hand-written NDT functor (never set by a shipped configuration)
     if (desc.d3) {

@@ -400,8 +400,14 @@ template <int D, bool AM2, bool ANALYTIC>
 __global__ __launch_bounds__(GEN_BLOCK) void k_solve_window_gen(MapView fixed, MapView moving, const WinDesc* __restrict__ Wp,
                                                                 const int32_t* __restrict__ corr, SolveParams P,
                                                                 double* __restrict__ states, randt_result* __restrict__ result,
-                                                                double* trace, int trace_len) {
+                                                                double* trace, int trace_len, int corr_stride, int state_stride) {
   __shared__ GShared sh;
+  // one workgroup per window of a batch (window.hip, k_solve_window)
+  Wp += blockIdx.x;
+  corr += (size_t)blockIdx.x * corr_stride;
+  states += (size_t)blockIdx.x * state_stride;
+  result += blockIdx.x;
+  if (trace) trace += (size_t)blockIdx.x * trace_len;
   const WinDesc& W = *Wp;  // indexed dynamically (state j, term q): read from device memory on demand
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = W.n_tan, S = W.S;
@@ -690,14 +696,15 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_solve_window_gen(MapView fixed, M
 }  // namespace
 
 int GEN_LAUNCHER(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
-                 const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result) {
+                 const int32_t* d_corr, const SolveParams& P, double* d_states, randt_result* d_result, int n_windows, int corr_stride,
+                 int state_stride) {
 #if GEN_SMAX == 7
-  if (desc.S > GEN_SMAX) return launch_solve_window_gen_big(ctx, fixed, moving, desc, d_desc, d_corr, P, d_states, d_result);
+  if (desc.S > GEN_SMAX) return launch_solve_window_gen_big(ctx, fixed, moving, desc, d_desc, d_corr, P, d_states, d_result, n_windows, corr_stride, state_stride);
 #endif
   if (desc.n_tan > GEN_NMAX || desc.S > GEN_SMAX || desc.n_terms > GEN_TMAX) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, GEN_LIMIT_TEXT, hipSuccess);
 #define RANDT_GEN_LAUNCH(DD, AA, NN)                                                                                             \
-  hipLaunchKernelGGL((k_solve_window_gen<DD, AA, NN>), dim3(1), dim3(GEN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
-                     d_states, d_result, ctx->d_trace, ctx->trace_len)
+  hipLaunchKernelGGL((k_solve_window_gen<DD, AA, NN>), dim3(n_windows), dim3(GEN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
+                     d_states, d_result, ctx->d_trace, ctx->trace_len, corr_stride, state_stride)
   const bool am2 = P.alpha == -2.0;
   if (desc.pad_) {  // RANDT_PARAM_ANALYTIC
     if (desc.d3) {

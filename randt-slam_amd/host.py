@@ -232,6 +232,12 @@ class Maps:
         self.ctx._check(self._lib.randt_maps_merge(self._h, fixed_idx, moving._h, moving_first, len(p), _dptr(p)),
                         "randt_maps_merge")
 
+    def merge_batch(self, fixed_first, n_fixed, moving, moving_first, poses4):
+        """randt_maps_merge_batch: self[fixed_first + p] receives moving[moving_first + p * m + t] at poses4[p * m + t], one launch."""
+        p = np.ascontiguousarray(poses4, dtype=np.float64).reshape(-1, 4)
+        self.ctx._check(self._lib.randt_maps_merge_batch(self._h, fixed_first, n_fixed, moving._h, moving_first, len(p) // max(1, n_fixed), _dptr(p)),
+                        "randt_maps_merge_batch")
+
     def insert_cluster(self, idx, points, intensity_index=None):
         """Map::insertCluster: one cell from all `points` (n, stride) float32; returns True if the cell was accepted."""
         pts = np.ascontiguousarray(points, dtype=np.float32)
@@ -419,6 +425,16 @@ def predict_state(last, stamp, parameterization=_capi.PARAM_MANIFOLD):
     return out[0]
 
 
+def predict_states(last, stamp, parameterization=_capi.PARAM_MANIFOLD):
+    """randt_predict_state_batch: predict_state for an array of independent states (one call)."""
+    a = np.ascontiguousarray(last, dtype=STATE_DTYPE)
+    out = np.zeros(len(a), dtype=STATE_DTYPE)
+    rc = _capi.load().randt_predict_state_batch(_dptr(a), len(a), float(stamp), int(parameterization), _dptr(out))
+    if rc:
+        raise RandtError(rc, "randt_predict_state_batch")
+    return out
+
+
 def register_window(ctx, fixed, fixed_idx, moving, moving_idx, states, mp, wp, trans4, imu=None):
     """Matcher::estimateTransformCeres.  states: STATE_DTYPE array (S+1, oldest first).
     Returns (states_out, trans_out, rejected, result)."""
@@ -433,6 +449,23 @@ def register_window(ctx, fixed, fixed_idx, moving, moving_idx, states, mp, wp, t
                                               _dptr(im), C.byref(mp), C.byref(wp), _dptr(t), C.byref(rej), _dptr(res)),
                "randt_register_window")
     return st, t, bool(rej.value), res[0]
+
+
+def register_window_batch(ctx, fixed, fixed_idx, moving, moving_idx, states, mp, wp, trans4, imu=None):
+    """randt_register_window_batch: W independent windows of one shape in one launch.  fixed_idx (W, n_fixed), moving_idx (W, S),
+    states STATE_DTYPE (W, S + 1), trans4 (W, 4), imu None or (W, S).  Returns (states_out, trans_out, rejected (W,), results (W,))."""
+    st = np.array(states, dtype=STATE_DTYPE).copy()
+    W, n_states = st.shape
+    fi = np.ascontiguousarray(fixed_idx, dtype=np.int32).reshape(W, -1)
+    mi = np.ascontiguousarray(moving_idx, dtype=np.int32).reshape(W, n_states - 1)
+    t = np.array(trans4, dtype=np.float64).reshape(W, 4).copy()
+    im = None if imu is None else np.ascontiguousarray(imu, dtype=np.float64).reshape(W, n_states - 1)
+    rej = np.zeros(W, dtype=np.int32)
+    res = np.zeros(W, dtype=RESULT_DTYPE)
+    ctx._check(ctx._lib.randt_register_window_batch(ctx._h, W, fixed._h, _dptr(fi), fi.shape[1], moving._h, _dptr(mi), _dptr(st), n_states,
+                                                    _dptr(im), C.byref(mp), C.byref(wp), _dptr(t), _dptr(rej), _dptr(res)),
+               "randt_register_window_batch")
+    return st, t, rej.astype(bool), res
 
 
 # ------------------------------------------------------------------ scan filter (f-1) ---------------

@@ -302,3 +302,171 @@ class Odometry:
         self._unref(scan)
         self.n_scans += 1
         return self.get_transform()
+
+
+class ReplicaOdometry:
+    """R independent copies of the front-end loop above advancing in LOCK-STEP on one GPU -- the sequential path's only scaling
+    axis (scan t needs pose t-1, "replicas only"): R vehicles / R replays, each with its own scans, submaps and
+    trajectory, sharing nothing.  All replicas follow the same schedule (keyframes, insertion delay and submap roll-over depend
+    on scan counts only: local_fuser.cpp:152-164, ndt_slam.cpp:219-223), so one step is ONE launch per stage for all of them:
+    randt_ndt_build_batch_dev (R scans), randt_register_window_batch (R windows, a workgroup each), randt_maps_merge_batch (R
+    keyframe merges) -- where R Odometry objects need R contexts / streams and a host round trip each.
+    Every replica computes exactly what an Odometry object computes on its scans (bit-identical: tests/test_gpu_window.py).
+
+    Map layout: logical slot j of replica r is map j * R + r of the two shared batches, so that the maps one stage touches
+    are contiguous over the replicas."""
+
+    def __init__(self, ctx, n_replicas, map_params, cluster_params, matcher_params, window_params, params=None, scan_capacity=512,
+                 scan_slots=24, submap_slots=4):
+        import torch
+
+        p = dict(indoor_params())
+        if params:
+            p.update(params)
+        self.torch, self.ctx, self.R = torch, ctx, int(n_replicas)
+        self.clu, self.mp, self.wp = cluster_params, matcher_params, window_params
+        R = self.R
+        self.scans = host.Maps(ctx, scan_slots * R, map_params, scan_capacity, with_grid=False)
+        self.subs = host.Maps(ctx, submap_slots * R, map_params, map_params.size_x * map_params.size_y, with_grid=True)
+        self.free_scans, self.free_subs = list(range(scan_slots)), list(range(submap_slots))
+        self.insertion_step = p["insertion_step"]
+        self.insertion_delay = p["smoothing_steps"] + 1
+        self.smoothing_steps = p["smoothing_steps"]
+        self.submap_size_poses, self.submap_overlap = p["submap_size_poses"], p["submap_overlap"]
+        self.vector = int(getattr(matcher_params, "parameterization", 0)) in (2, 3)
+        self.current_submap = self._new_submap()
+        self.last_submap_transformed = None
+        self.submap_known_nonempty = False
+        self.trajectory = []                                   # list over time of (R,) STATE_DTYPE arrays
+        self.map_window, self.next_maps_to_insert = [], []     # logical scan slots
+        self.refs = {}
+        ident = np.tile(np.array([1.0, 0.0, 0.0, 0.0]), (R, 1))
+        self.current_transform, self.current_global_transform = ident.copy(), ident.copy()
+        self.n_finished_submaps = 0
+        self.last_state = None
+        self.n_scans = self.n_registrations = self.n_rejected = 0
+        self.last_results = None
+        self._ar = np.arange(R, dtype=np.int32)
+
+    # ---- slot bookkeeping (logical slots, shared by all replicas)
+    def _new_submap(self):
+        if not self.free_subs:
+            raise host.RandtError(3, "ReplicaOdometry", "submap slot pool exhausted")
+        j = self.free_subs.pop(0)
+        self.subs.clear(j * self.R, self.R)
+        return j
+
+    def _ref(self, h):
+        self.refs[h] = self.refs.get(h, 0) + 1
+
+    def _unref(self, h):
+        self.refs[h] -= 1
+        if self.refs[h] == 0:
+            del self.refs[h]
+            self.free_scans.append(h)
+
+    @staticmethod
+    def _mul(a, b):       # Sophus SE2 product on (R, 4) arrays, complex re-normalised (the arithmetic of _se2_mul4, row by row)
+        re, im = a[:, 0] * b[:, 0] - a[:, 1] * b[:, 1], a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0]
+        n = np.hypot(re, im)
+        return np.stack([re / n, im / n, a[:, 2] + a[:, 0] * b[:, 2] - a[:, 1] * b[:, 3], a[:, 3] + a[:, 1] * b[:, 2] + a[:, 0] * b[:, 3]], 1)
+
+    @staticmethod
+    def _inv(a):
+        c, s = a[:, 0], -a[:, 1]
+        return np.stack([c, s, -(c * a[:, 2] - s * a[:, 3]), -(s * a[:, 2] + c * a[:, 3])], 1)
+
+    def get_transform(self):
+        return self._mul(self.current_global_transform, self.current_transform)
+
+    def submap_complete(self):
+        return len(self.trajectory) >= self.submap_size_poses
+
+    def _submap_nonempty(self):
+        if not self.submap_known_nonempty:
+            n = self.subs.counts(self.current_submap * self.R, self.R)
+            if (n > 0).any() and not (n > 0).all():
+                raise host.RandtError(3, "ReplicaOdometry", "replicas left lock-step: some submaps are empty, some are not")
+            self.submap_known_nonempty = bool((n > 0).all())
+        return self.submap_known_nonempty
+
+    def initialize_new_submap(self, initial_transform):
+        R = self.R
+        self.last_state = self.trajectory[-1].copy()
+        if self.last_submap_transformed is not None:
+            self.free_subs.append(self.last_submap_transformed)
+        old_to_new = self._mul(self._inv(self.current_global_transform), initial_transform)        # local_fuser.cpp:45
+        dst = self.free_subs.pop(0)
+        self.subs.copy_from(self.subs, dst_first=dst * R, src_first=self.current_submap * R, count=R)   # :44
+        self.subs.transform(dst * R, old_to_new)                                                      # :46 (index grid left stale)
+        self.last_submap_transformed = dst
+        for h in self.next_maps_to_insert + self.map_window:
+            self._unref(h)
+        self.next_maps_to_insert, self.map_window = [], []
+        self.current_transform = np.tile(np.array([1.0, 0.0, 0.0, 0.0]), (R, 1))
+        self.current_global_transform = np.array(initial_transform, dtype=np.float64)
+        self.free_subs.append(self.current_submap)
+        self.current_submap = self._new_submap()
+        self.submap_known_nonempty = False
+        self.trajectory = []
+        self.n_finished_submaps += 1
+
+    def _process(self, scan, stamp):
+        R, ar = self.R, self._ar
+        if self._submap_nonempty():
+            last = self.trajectory[-1]
+            par = host._capi.PARAM_VECTOR if self.vector else host._capi.PARAM_MANIFOLD
+            self.trajectory.append(host.predict_states(last, stamp, par))      # Matcher::predictTransform, O(1) host math per replica
+            self.map_window.append(scan)
+            self._ref(scan)
+            fixed = [self.current_submap]
+            if len(self.trajectory) < self.submap_overlap and self.n_finished_submaps > 0:
+                fixed.append(self.last_submap_transformed)
+            S = min(len(self.trajectory) - 1, self.smoothing_steps)
+            states = np.stack(self.trajectory[-S - 1:], axis=1)                 # (R, S + 1)
+            fidx = np.stack([np.int32(j) * R + ar for j in fixed], 1)
+            midx = np.stack([np.int32(j) * R + ar for j in self.map_window[-S:]], 1)
+            states, trans, rej, res = host.register_window_batch(self.ctx, self.subs, fidx, self.scans, midx, states, self.mp, self.wp, self.current_transform)
+            for j in range(S + 1):
+                self.trajectory[len(self.trajectory) - S - 1 + j] = states[:, j].copy()
+            self.current_transform = trans
+            self.n_registrations += R
+            self.n_rejected += int(rej.sum())
+            self.last_results = res
+            n = len(self.trajectory)
+            if len(self.map_window) >= self.smoothing_steps:
+                self._unref(self.map_window.pop(0))
+            if n % self.insertion_step == 0:
+                self.next_maps_to_insert.append(scan)
+                self._ref(scan)
+            if n >= self.insertion_delay + self.insertion_step and (n - self.insertion_delay) % self.insertion_step == 0:
+                smoothed = self.trajectory[-self.insertion_delay - 1]["pose"]
+                kf = self.next_maps_to_insert.pop(0)
+                self.subs.merge_batch(self.current_submap * R, R, self.scans, kf * R, smoothed)
+                self._unref(kf)
+        else:
+            st = np.zeros(R, dtype=STATE_DTYPE)
+            st["pose"] = self.current_transform
+            st["pos"] = self.current_transform[:, 2:]
+            st["rot"] = np.arctan2(self.current_transform[:, 1], self.current_transform[:, 0])
+            if self.n_finished_submaps > 0:
+                for f in ("lin_vel", "rot_vel", "lin_acc", "imu_bias"):
+                    st[f] = self.last_state[f]
+            st["stamp"] = stamp
+            self.trajectory.append(st)
+            self.subs.merge_batch(self.current_submap * R, R, self.scans, scan * R, self.current_transform)
+
+    def process_scans(self, points, stamp):
+        """points: (R, n_points, stride) float32 device tensor, scan r for replica r.  Returns the (R, 4) global poses."""
+        if not self.free_scans:
+            raise host.RandtError(3, "ReplicaOdometry", "scan slot pool exhausted")
+        scan = self.free_scans.pop(0)
+        host.ndt_build_batch(self.ctx, points, self.clu, self.scans, first_map=scan * self.R)
+        self._ref(scan)
+        self._process(scan, stamp)
+        if self.submap_complete():
+            self.initialize_new_submap(self.get_transform())
+            self._process(scan, stamp)
+        self._unref(scan)
+        self.n_scans += 1
+        return self.get_transform()
