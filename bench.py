@@ -52,6 +52,7 @@ SAT_COPIES = 16                         # chip-filling launch of the roofline se
 HOT_KERNELS = ("k_ndt_build<true,true>", "k_associate<false,64,true,false>", "k_solve<3,1,64,true,4,false>")
 
 
+ALL_ROWS = []      # every row of the committed counter summary (empty when the counters are refused as stale)
 WINDOW_ROW = {}    # counter row of k_solve_window (the fixed-lag solve of config 3) from the committed summary
 FILTER_ROWS = {}   # counter rows of k_filter_rows / k_filter_emit from the committed summary (load_counters)
 
@@ -96,10 +97,12 @@ def load_counters():
     rows = {}
     FILTER_ROWS.clear()
     WINDOW_ROW.clear()
+    del ALL_ROWS[:]
     want_wgs = {"k_ndt_build<true,true>": 512, "k_associate<false,64,true,false>": 128, "k_solve<3,1,64,true,4,false>": 128}   # workgroups of a 512-registration launch (the association walks four pairs per workgroup)
     stamp = None
     for r in csv.DictReader(open(files[-1])):
         stamp = r.get("csrc_hash", stamp)
+        ALL_ROWS.append({k: (float(v) if v not in ("", None) and k not in ("kernel", "csrc_hash") else v) for k, v in r.items()})
         if r["kernel"].startswith("k_filter_") and r["kernel"] not in FILTER_ROWS:     # the config-5 polar filter (16 scans per launch)
             FILTER_ROWS[r["kernel"]] = {k: (float(v) if v not in ("", None) and k not in ("kernel", "csrc_hash") else v) for k, v in r.items()}
         if r["kernel"].startswith("k_solve_window<") and not WINDOW_ROW:
@@ -109,8 +112,47 @@ def load_counters():
     rel = os.path.relpath(files[-1], ROOT)
     now = csrc_hash()
     if stamp != now:
+        del ALL_ROWS[:]
         return {}, rel, "counters in %s were taken from other kernel code (stamp %s, current sources %s): re-run tools/collect_profiles.sh" % (rel, stamp, now)
     return rows, rel, None
+
+
+def row_bytes(r):
+    """HBM bytes of one dispatch from its TCC counters: FETCH_SIZE KB x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE KB."""
+    return (2.0 * r.get("FETCH_SIZE", 0.0) + r.get("WRITE_SIZE", 0.0)) * 1024.0
+
+
+def find_row(prefix, grid=None, most_dispatched_below=None):
+    """A row of the committed counter summary: kernel name starting with `prefix`, at `grid` threads, or -- among launches of at
+    most `most_dispatched_below` threads -- the one the collection run dispatched most often (the per-scan launches of the
+    odometry drive that is part of every collection run)."""
+    best = None
+    for r in ALL_ROWS:
+        if not r["kernel"].startswith(prefix):
+            continue
+        if grid is not None and int(r["grid_size"]) == grid:
+            return r
+        if most_dispatched_below is not None and int(r["grid_size"]) <= most_dispatched_below and (best is None or r["dispatches"] > best["dispatches"]):
+            best = r
+    return best
+
+
+def hbm_achieved(counters, ms_per_step, sustained_ms_per_step, counters_file, counters_stale):
+    """north_star's "achieved HBM-bandwidth fraction" of the headline path, from counters: FETCH_SIZE x 2 + WRITE_SIZE of the three
+    launches of a 512-registration step / the step time / 8 TB/s.  SURVEY 8(d) expected 1 .. 10 %: the path is bound by vector-ALU
+    issue slots and the latency of its dependent chains (roofline), not by bytes."""
+    if counters_stale or not all(n in counters for n in HOT_KERNELS):
+        return {"frac": None, "counters_refused": counters_stale or "no counter rows for the three kernels"}
+    by = {n: row_bytes(counters[n]) for n in HOT_KERNELS}
+    tot = sum(by.values())
+    out = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "bytes_per_step": int(tot), "bytes_by_kernel": {n: int(v) for n, v in by.items()},
+           "bytes_per_registration": tot / 512.0, "achieved": tot / (ms_per_step * 1e-3) / 1e9, "frac": tot / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "counters": counters_file,
+           "note": "PMC bytes of the three launches of one 512-registration step (FETCH_SIZE x 2 + WRITE_SIZE, %s) / ms_per_step of "
+                   "the headline region; `sustained`: the same over the settle region's step" % counters_file}
+    if sustained_ms_per_step:
+        out["sustained"] = {"achieved": tot / (sustained_ms_per_step * 1e-3) / 1e9, "frac": tot / (sustained_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return out
 
 
 class GroupBatch:
@@ -154,10 +196,14 @@ class Batch:
         self.results = [torch.zeros((self.B, 64), dtype=torch.uint8, device=dev) for _ in range(n)]
         self.corrs = [torch.full((self.B, scan_cap, k), -1, dtype=torch.int32, device=dev) for _ in range(n)]
         self.scan_maps = [R.Maps(ctxs[i], self.B, mapp, scan_cap, with_grid=False) for i in range(n)]
+        self.points_rotation, self._turn = None, 0   # distinct_inputs: a list of point batches at different addresses, one per step in turn
 
     def step(self, j, stream, pose, events=None, only=None):
         """Enqueue build -> associate -> solve of the whole batch on stream slot j (asynchronous)."""
         R, cx = self.R, self.ctxs[j]
+        if self.points_rotation is not None:
+            self.points = self.points_rotation[self._turn % len(self.points_rotation)]
+            self._turn += 1
         if events is not None:
             events[0].record(stream)
         if only in (None, "build", "no-associate"):
@@ -241,6 +287,8 @@ def main():
                     help="pair-solve geometry of the timed region's contexts: throughput = one wavefront per registration, auto = the "
                          "library's choice per launch (splits a lone small batch); default = throughput when several streams keep batches in flight")
     ap.add_argument("--odometry-scans", type=int, default=1000, help="BASELINE config 3 side measurement (0 = skip)")
+    ap.add_argument("--distinct-inputs", type=int, default=20,
+                    help="side measurement: the headline region again over this many copies of the point batch at distinct addresses (> 256 MB; 0 / 1 = skip)")
     ap.add_argument("--replica-steps", type=int, default=150,
                     help="side measurement: R = 64 / 256 replicas of config 3's loop in lock-step, this many steps each (0 = skip)")
     ap.add_argument("--cpp-drive-scans", type=int, default=300,
@@ -551,6 +599,8 @@ def main():
         }
         if "sustained" in rinfo:
             out["sustained"] = rinfo["sustained"]
+        out["hbm_achieved"] = hbm_achieved(counters, elapsed / n_steps * 1e3, rinfo["sustained"]["ms_per_step"] if "sustained" in rinfo else None,
+                                           counters_file, counters_stale)
         if multi:
             # LOUD: a first-ever RCCL failure on a multi-GPU node must not look like a pass
             out["group_fallback"] = bool(grp is None and not via_cpu)
@@ -574,7 +624,28 @@ def main():
             # (at N > 1 too: rank 0 alone, the other ranks wait at the closing barrier; per-GPU figures)
             side(None, roofline_sections, R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file,
                  b_alg, (rinfo["sustained"]["value"] if "sustained" in rinfo else value) / world,
-                 (rinfo["sustained"]["ms_per_step"] * 1e-3 if "sustained" in rinfo else elapsed / n_steps), counters_stale, throughput_mode)
+                 (rinfo["sustained"]["ms_per_step"] * 1e-3 if "sustained" in rinfo else elapsed / n_steps), counters_stale, throughput_mode,
+                 elapsed / n_steps)
+        if world == 1 and args.only is None and args.batch_scale == 1 and args.distinct_inputs > 1:
+            def distinct_region():
+                # the headline once more with the point batches at DISTINCT addresses: step s reads copy s % n of the 512 scans
+                # (n x 16.4 MB > the 256 MB Infinity Cache: no step meets its input again in a cache); the working sets of the 16
+                # streams (scan cell tables, correspondences: 265 MB) were distinct all along
+                n = args.distinct_inputs
+                full.points_rotation = [full.points] + [full.points.clone() for _ in range(n - 1)]
+                try:
+                    warm_up(torch, full, streams, 2 * n_streams)
+                    d_steps, d_elapsed, _, _, d_pose0, d_info = region(full)
+                finally:
+                    full.points_rotation = None
+                r = {"copies": n, "input_bytes": int(n * full.points.numel() * 4), "steps": d_steps, "ms_per_step": d_elapsed / d_steps * 1e3,
+                     "value": B * d_steps / d_elapsed, "unit": "registrations/s", "region_ms": d_info["region_ms"],
+                     "poses_equal_headline": bool(torch.equal(d_pose0, pose0)),
+                     "note": "same values at other addresses: identical results, nothing re-read from the Infinity Cache"}
+                if "sustained" in d_info:
+                    r["sustained"] = {k: d_info["sustained"][k] for k in ("steps", "ms_per_step", "value")}
+                return r
+            side("distinct_inputs", distinct_region)
         if not args.no_cpu_baseline and world == 1:
             side(None, cpu_baseline, weak_prob, mp, pose0.cpu().numpy(), args.cpu_seconds)
         if world == 1 and args.only is None and not args.no_config2:
@@ -603,7 +674,8 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file, b_alg, value, s_per_step, counters_stale=None, throughput_mode=True):
+def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, counters, counters_file, b_alg, value, s_per_step, counters_stale=None, throughput_mode=True,
+                      headline_s_per_step=None):
     """Clean (non-overlapped) measurements behind the `roofline` object, all with HIP events on the launch stream:
       single_batch      ONE 512-registration batch at a time on one stream: latency, rate, per-kernel durations;
       chip-filling      the dominant kernel (k_solve) with SAT_COPIES copies of the batch = 8192 registrations in ONE
@@ -701,8 +773,14 @@ def roofline_sections(R, torch, full, streams, ctxs, submaps_v, mapp, clu, mp, c
             tot = sum(cyc[n] for n in HOT_KERNELS)
             roof["path"] = {
                 "valu_issue_cycles_per_step": tot, "by_kernel": {n: cyc[n] for n in HOT_KERNELS},
-                "achieved": tot / (s_per_step * 1e6) * 1e-3, "frac": tot / (s_per_step * 1e6) * 1e-3 / VALU_PEAK,
-                "note": "all three launches of a step / ms_per_step of the 16-stream SUSTAINED region (throughput, no residency involved)",
+                # the headline's OWN step time (exactly --steps steps between synchronisations: fill and drain of the pipeline are in
+                # it), and the sustained step beside it
+                "achieved": tot / ((headline_s_per_step or s_per_step) * 1e6) * 1e-3,
+                "frac": tot / ((headline_s_per_step or s_per_step) * 1e6) * 1e-3 / VALU_PEAK,
+                "ms_per_step": (headline_s_per_step or s_per_step) * 1e3,
+                "sustained": {"ms_per_step": s_per_step * 1e3, "achieved": tot / (s_per_step * 1e6) * 1e-3, "frac": tot / (s_per_step * 1e6) * 1e-3 / VALU_PEAK},
+                "note": "all three launches of a step / ms_per_step of the headline region (`sustained`: of the settle region: the steady "
+                        "rate of the 16-stream pipeline; throughput, no residency involved)",
                 "chip_filling_launch_us": {"k_ndt_build": sat_build_us, "k_associate": sat_assoc_us, "k_solve": sat_us,
                                            "registrations": big.B},
                 # each kernel by itself: issue cycles of its chip-filling launch / that launch's duration (the two short kernels are
@@ -1076,10 +1154,18 @@ def polar_filter(ctx, n_scans):
         roof["long_launch"] = long_launch
     if t_bb:
         roof["back_to_back"] = {"ms": t_bb * 1e3, "achieved": nbytes / t_bb / 1e9, "frac": nbytes / t_bb / 1e9 / HBM_PEAK_GBS, "launches": 20, "distinct_inputs": 4}
-    fr, fe = FILTER_ROWS.get("k_filter_rows<true,true>"), FILTER_ROWS.get("k_filter_emit<true>")
+    # counter rows of the two kernels at THIS launch size (a workgroup of 256 threads per row; 512 threads per scan)
+    fr, fe = find_row("k_filter_rows<true,true>", n_scans * 400 * 256), find_row("k_filter_emit<true>", n_scans * 512)
+    fr1, fe1 = find_row("k_filter_rows<true,true>", 400 * 256), find_row("k_filter_emit<true>", 512)
+    if single_scan and fr1 and fe1 and fr1.get("single_stream_avg_us") and fe1.get("single_stream_avg_us"):
+        us = float(fr1["single_stream_avg_us"]) + float(fe1["single_stream_avg_us"])
+        single_scan["rocprof_avg_us"] = {"k_filter_rows": float(fr1["single_stream_avg_us"]), "k_filter_emit": float(fe1["single_stream_avg_us"])}
+        single_scan["rocprof_frac"] = single_scan["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS   # bytes / (rocprofv3 durations of the two kernels) / 8 TB/s
     if fr and fe and n_scans == 16:
         # HBM bytes from the TCC counters of the committed summary (FETCH_SIZE KB x2 per the gfx950 note + WRITE_SIZE KB), both kernels
         roof["traffic"] = int((2.0 * (fr.get("FETCH_SIZE", 0.0) + fe.get("FETCH_SIZE", 0.0)) + fr.get("WRITE_SIZE", 0.0) + fe.get("WRITE_SIZE", 0.0)) * 1024)
+        # the counted bytes (not the algorithmic ones) over the same launch duration
+        roof["hbm_achieved"] = {"bytes_per_launch": roof["traffic"], "achieved": roof["traffic"] / t_f / 1e9, "frac": roof["traffic"] / t_f / 1e9 / HBM_PEAK_GBS}
         if fr.get("single_stream_avg_us"):
             roof["rocprof_avg_us"] = {"k_filter_rows": fr.get("single_stream_avg_us"), "k_filter_emit": fe.get("single_stream_avg_us")}
             roof["k_filter_rows_frac"] = nbytes / (float(fr["single_stream_avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS
@@ -1218,6 +1304,21 @@ def streaming_odometry(ctx, n_scans, with_cpu):
     out = {"scans": n_scans, "scans_per_sec": n_scans / el, "ms_per_scan": el / n_scans * 1e3,
            "mean_lm_iterations_per_scan": iters / max(1, odo.n_registrations), "submaps_finished": odo.n_finished_submaps,
            "end_pose_error_vs_truth_m": float(np.hypot(est[0] - rel[0], est[1] - rel[1]))}
+    # BASELINE config 3 asks for "registrations/sec + HBM GB/s": the PMC bytes of the launches one scan costs (committed counter
+    # summary; its collection run contains this very loop) x scans/s.  One window is one workgroup on one of 256 compute units
+    # walking a dependent chain: the loop moves ~0.6 MB per scan and uses a few GB/s of the 8 TB/s -- latency-bound by construction.
+    rows = {"k_ndt_build (one 2000-point scan)": (find_row("k_ndt_build<", 256), 1.0),
+            "k_associate (the window's NDT terms)": (find_row("k_associate<false,16", most_dispatched_below=65536), 1.0),
+            "k_solve_window": (find_row("k_solve_window<"), 1.0),
+            "k_maps_merge (every insertion_step-th scan)": (find_row("k_maps_merge"), 0.25)}
+    if all(r is not None for r, _ in rows.values()):
+        per_scan = sum(row_bytes(r) * w for r, w in rows.values())
+        out["hbm_achieved"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "bytes_per_scan": int(per_scan),
+                               "bytes_by_launch": {k: int(row_bytes(r) * w) for k, (r, w) in rows.items()},
+                               "achieved": per_scan * n_scans / el / 1e9, "frac": per_scan * n_scans / el / 1e9 / HBM_PEAK_GBS,
+                               "note": "FETCH_SIZE x 2 + WRITE_SIZE of the per-scan launches (committed counter summary) x scans/s"}
+    else:
+        out["hbm_achieved"] = {"frac": None, "counters_refused": "no (current) counter rows for the per-scan launches"}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         sys.path.insert(0, os.path.join(ROOT, "tests"))
