@@ -289,6 +289,7 @@ def main():
     ap.add_argument("--odometry-scans", type=int, default=1000, help="BASELINE config 3 side measurement (0 = skip)")
     ap.add_argument("--distinct-inputs", type=int, default=20,
                     help="side measurement: the headline region again over this many copies of the point batch at distinct addresses (> 256 MB; 0 / 1 = skip)")
+    ap.add_argument("--no-auto-region", action="store_true", help="skip the headline region with the contexts in RANDT_SOLVE_AUTO")
     ap.add_argument("--replica-steps", type=int, default=150,
                     help="side measurement: R = 64 / 256 replicas of config 3's loop in lock-step, this many steps each (0 = skip)")
     ap.add_argument("--cpp-drive-scans", type=int, default=300,
@@ -646,6 +647,26 @@ def main():
                     r["sustained"] = {k: d_info["sustained"][k] for k in ("steps", "ms_per_step", "value")}
                 return r
             side("distinct_inputs", distinct_region)
+        if world == 1 and args.only is None and args.batch_scale == 1 and throughput_mode and n_streams > 1 and not args.no_auto_region:
+            def auto_region():
+                # the headline region with every context left in RANDT_SOLVE_AUTO: the library itself has to notice that 16 contexts
+                # keep batches in flight (enqueue stamps / hipStreamQuery) and take the throughput placement -- same rate, same poses
+                for c in ctxs:
+                    c.set_solve_mode(R._capi.SOLVE_AUTO)
+                try:
+                    warm_up(torch, full, streams, 2 * n_streams)
+                    a_steps, a_elapsed, _, _, a_pose0, a_info = region(full)
+                finally:
+                    for c in ctxs:
+                        c.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
+                r = {"value": B * a_steps / a_elapsed, "unit": "registrations/s", "ms_per_step": a_elapsed / a_steps * 1e3,
+                     "vs_explicit_throughput_mode": (B * a_steps / a_elapsed) / value, "poses_equal_headline": bool(torch.equal(a_pose0, pose0))}
+                if "sustained" in a_info:
+                    r["sustained"] = {k: a_info["sustained"][k] for k in ("steps", "ms_per_step", "value")}
+                    if "sustained" in rinfo:
+                        r["sustained"]["vs_explicit_throughput_mode"] = a_info["sustained"]["value"] / rinfo["sustained"]["value"]
+                return r
+            side("solve_auto_detection", auto_region)
         if not args.no_cpu_baseline and world == 1:
             side(None, cpu_baseline, weak_prob, mp, pose0.cpu().numpy(), args.cpu_seconds)
         if world == 1 and args.only is None and not args.no_config2:

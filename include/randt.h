@@ -167,14 +167,19 @@ int randt_ctx_synchronize(randt_ctx* ctx);
  * (max_len per registration; first double of each block = number written).  NULL disables. */
 int randt_ctx_set_trace(randt_ctx* ctx, double* d_trace, int max_len);
 /* How the pair solve lays a batch out on the device (results are bit-identical either way):
- *   RANDT_SOLVE_AUTO (default)  chosen per launch from the batch size, assuming the device has nothing else to do: a batch
- *                               too small to give every SIMD a registration of its own (<= 3 per compute unit: one
- *                               loop-closure burst, the per-GPU share of a multi-GPU split) gets several wavefronts per
- *                               registration, which shortens the batch's latency (512 registrations: 148 -> 117 us);
+ *   RANDT_SOLVE_AUTO (default)  chosen per launch from the batch size AND from what else the process has in flight on the
+ *                               device: a batch too small to give every SIMD a registration of its own (<= 3 per compute
+ *                               unit: one loop-closure burst, the per-GPU share of a multi-GPU split) gets several
+ *                               wavefronts per registration, which shortens the batch's latency (512 registrations: 148 ->
+ *                               117 us) -- unless another context of this process has work in flight on the same device
+ *                               (it enqueued within the last 100 us, or its stream reports busy): then the batch takes the
+ *                               throughput placement below, as if the caller had asked for it.  Work of OTHER processes or of
+ *                               the caller's own kernels is not seen;
  *   RANDT_SOLVE_THROUGHPUT      always one wavefront per registration: for callers that keep several batches in flight on
  *                               several contexts / streams (bench.py's 16-stream region), where the chip is full anyway and
- *                               helper wavefronts only take slots away from other batches. */
-enum { RANDT_SOLVE_AUTO = 0, RANDT_SOLVE_THROUGHPUT = 1 };
+ *                               helper wavefronts only take slots away from other batches;
+ *   RANDT_SOLVE_LATENCY         never look at other contexts: the latency placement whenever the batch size allows it. */
+enum { RANDT_SOLVE_AUTO = 0, RANDT_SOLVE_THROUGHPUT = 1, RANDT_SOLVE_LATENCY = 2 };
 int randt_ctx_set_solve_mode(randt_ctx* ctx, int mode);
 void randt_matcher_params_default(randt_matcher_params* p);
 /* Device storage pool of a context.  The reference copies Maps by value several times per scan

@@ -186,7 +186,7 @@ SYMBOLS = {
     "randt_group_register_pairs": (_I, [_V, _P(_V), _V, _P(_V), _I, _P(MatcherParams), _V, _V]),
 }
 TRANSPORT_AUTO, TRANSPORT_PEER, TRANSPORT_RCCL = 0, 1, 2
-SOLVE_AUTO, SOLVE_THROUGHPUT = 0, 1
+SOLVE_AUTO, SOLVE_THROUGHPUT, SOLVE_LATENCY = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
 _lib = None

@@ -6,6 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
+#include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -23,6 +27,42 @@ int randt_set_error(randt_ctx* ctx, int status, const char* what, hipError_t e) 
   return status;
 }
 
+// ---------------------------------------------------------------- who else is using the device (RANDT_SOLVE_AUTO) ----------
+namespace {
+std::mutex g_ctx_mu;
+std::vector<randt_ctx*> g_ctxs;  // every live context of this process
+inline long long now_ns() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+}  // namespace
+
+void randt_note_enqueue(randt_ctx* ctx) { ctx->last_enqueue_ns.store(now_ns(), std::memory_order_relaxed); }
+
+bool randt_device_shared(randt_ctx* ctx) {
+  const long long now = now_ns();
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  if (g_ctxs.size() < 2) return false;
+  // pass 1: somebody enqueued a moment ago (the pipelined caller: every decision ends here, a few loads)
+  for (randt_ctx* o : g_ctxs) {
+    if (o == ctx || o->device != ctx->device) continue;
+    const long long t = o->last_enqueue_ns.load(std::memory_order_relaxed);
+    if (t != 0 && now - t < 100000ll) return true;
+  }
+  // pass 2: older stamps -- ask the stream, once per stamp
+  for (randt_ctx* o : g_ctxs) {
+    if (o == ctx || o->device != ctx->device) continue;
+    long long t = o->last_enqueue_ns.load(std::memory_order_relaxed);
+    if (t == 0) continue;
+    const hipError_t e = hipStreamQuery(o->stream);
+    if (e == hipErrorNotReady) return true;
+    (void)hipGetLastError();
+    o->last_enqueue_ns.compare_exchange_strong(t, 0ll, std::memory_order_relaxed);  // drained (unless it has enqueued again meanwhile)
+  }
+  return false;
+}
+
 // ---------------------------------------------------------------- storage pool, counters, pinned ring ----------
 hipError_t randt_hip_malloc(randt_ctx* ctx, void** p, size_t bytes) {
   if (ctx) ++ctx->stats.device_allocs;
@@ -34,7 +74,9 @@ hipError_t randt_hip_free(randt_ctx* ctx, void* p) {
 }
 hipError_t randt_sync(randt_ctx* ctx) {
   ++ctx->stats.stream_syncs;
-  return hipStreamSynchronize(ctx->stream);
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  ctx->last_enqueue_ns.store(0, std::memory_order_relaxed);  // drained: other contexts need not count this one as busy
+  return e;
 }
 
 // A parked block serves a request if it is large enough and at most twice as large (+ 4 KB): a 64 KB scan map does not
@@ -329,9 +371,17 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
       ctx->lds_atomics_lane_ordered = 0;
     }
   }
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    g_ctxs.push_back(ctx);
+  }
   *out = ctx;
   return RANDT_OK;
 }
+
+// debug / test hook (not part of the ABI): the geometry the context's last pair-solve launch took: split width W >= 2
+// (several wavefronts per registration: the latency placement) or 0 (one wavefront per registration)
+int randt_debug_last_solve_placement(const randt_ctx* ctx) { return ctx ? ctx->last_placement : -1; }
 
 // debug / test hook (not part of the ABI): did the LDS atomic ordering self-test pass on this context's device?
 int randt_debug_lds_atomics_lane_ordered(const randt_ctx* ctx) { return ctx ? ctx->lds_atomics_lane_ordered : 0; }
@@ -367,6 +417,10 @@ int randt_ctx_pool_trim(randt_ctx* ctx) {
 
 int randt_ctx_destroy(randt_ctx* ctx) {
   if (!ctx) return RANDT_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), ctx), g_ctxs.end());
+  }
   DeviceGuard dev_guard__(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->tmp_cluster) (void)randt_maps_destroy(ctx->tmp_cluster);
@@ -423,7 +477,7 @@ int randt_ctx_set_trace(randt_ctx* ctx, double* d_trace, int max_len) {
 }
 
 int randt_ctx_set_solve_mode(randt_ctx* ctx, int mode) {
-  if (!ctx || (mode != RANDT_SOLVE_AUTO && mode != RANDT_SOLVE_THROUGHPUT)) return RANDT_ERR_INVALID;
+  if (!ctx || (mode != RANDT_SOLVE_AUTO && mode != RANDT_SOLVE_THROUGHPUT && mode != RANDT_SOLVE_LATENCY)) return RANDT_ERR_INVALID;
   ctx->solve_mode = mode;
   return RANDT_OK;
 }

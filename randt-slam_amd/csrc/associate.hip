@@ -549,7 +549,8 @@ size_t assoc_lds_bytes(int n_slots, bool stage, int CH = ASSOC_CH, bool wide = f
 
 template <bool STAGE, int CH, bool TP = false, bool WIDE = false>
 int launch_associate_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
-                         int n_pairs, const double* d_guess4, int k, int full, int32_t* d_corr, const int32_t* d_moving_idx, bool spread) {
+                         int n_pairs, const double* d_guess4, int k, int full, int32_t* d_corr, const int32_t* d_moving_idx, bool spread,
+                         bool shared = false) {
   const size_t lds = assoc_lds_bytes(fixed.n_slots, STAGE, CH, WIDE);
   int split = 1;
   if (spread) {
@@ -560,7 +561,7 @@ int launch_associate_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_
   RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_associate<STAGE, CH, TP, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // pairs per workgroup: the walk is for callers that keep several batches in flight (or a batch that fills the chip several
   // times over); a lone batch of a few hundred pairs more than the split geometry takes stays one pair per workgroup
-  const bool walk = TP && (ctx->solve_mode == RANDT_SOLVE_THROUGHPUT || n_pairs >= 8 * ctx->n_cus);
+  const bool walk = TP && (n_pairs >= 8 * ctx->n_cus || shared);
   const int ppw = walk ? (ctx->assoc_tp_ppw > 0 ? ctx->assoc_tp_ppw : 1) : 1;
   hipLaunchKernelGGL((k_associate<STAGE, CH, TP, WIDE>), dim3((n_pairs + ppw - 1) / ppw, split), dim3(ASSOC_BLOCK), lds, ctx->stream, fixed, d_fixed_idx, moving,
                      moving_first, d_moving_idx, d_guess4, k, full, full, d_corr, CH, n_pairs, ppw);
@@ -596,7 +597,10 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   // (pair, chunk), 16-cell chunks for the handful (the wavefront-per-cell phases of a chunk are serial rounds).  Batches
   // that share the chip with other batches (RANDT_SOLVE_THROUGHPUT, or more than two pairs per CU) are charged for LDS x
   // time: one workgroup per pair walking RANDT_ASSOC_TP_CH-cell chunks.
-  const bool lone = ctx->solve_mode != RANDT_SOLVE_THROUGHPUT && n_pairs <= 2 * ctx->n_cus;
+  // (does this batch have the device to itself?  RANDT_SOLVE_AUTO looks at the process's other contexts: randt_internal.h)
+  const bool shared = n_pairs > 64 && randt_throughput_placement(ctx);
+  randt_note_enqueue(ctx);
+  const bool lone = !shared && n_pairs <= 2 * ctx->n_cus;
   const bool spread = n_pairs <= 64 || lone;
   // lone batches: as many (pair, chunk) workgroups as stay resident in one round -- 16-cell chunks up to 128 pairs (64 pairs:
   // 17.9 -> 15.0 us), 32-cell ones above (512 pairs: 24.8 -> 23.5 us; 16-cell chunks would need a second round there: 36.5)
@@ -612,7 +616,7 @@ int launch_associate(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixe
   if (chunk <= 32) RANDT_ASSOC_GO(false, 32);
   if (chunk <= 48) RANDT_ASSOC_GO(false, 48);
   if (!spread)
-    return launch_associate_cfg<false, 64, true>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_guess4, k, full, d_corr, d_moving_idx, spread);
+    return launch_associate_cfg<false, 64, true>(ctx, fixed, d_fixed_idx, moving, moving_first, n_pairs, d_guess4, k, full, d_corr, d_moving_idx, spread, shared);
   RANDT_ASSOC_GO(false, 64);
 #undef RANDT_ASSOC_GO
 }

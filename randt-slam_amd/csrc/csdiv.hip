@@ -224,6 +224,7 @@ __global__ __launch_bounds__(CS_PBLOCK) void k_cs_pair(MapView fixed, const int3
 int launch_cs_divergence(randt_ctx* ctx, const MapView& fixed, int fixed_first, int fixed_count, const int32_t* d_fixed_idx,
                          const MapView& moving, int moving_first, int n_pairs, const double* d_pose4, double* d_partial,
                          double* d_out, double* d_terms) {
+  randt_note_enqueue(ctx);  // (RANDT_SOLVE_AUTO of the process's other contexts: this one has work in flight)
   const int max_tiles = (fixed.cap + CS_SELF_OUTER - 1) / CS_SELF_OUTER;
   hipLaunchKernelGGL(k_cs_self, dim3(max_tiles, fixed_count), dim3(CS_BLOCK), 0, ctx->stream, fixed, fixed_first, max_tiles, d_partial);
   const size_t lds = (size_t)moving.cap * (9 * 4 + 4);  // transformed moving cells + their validity flags

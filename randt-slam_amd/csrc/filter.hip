@@ -513,6 +513,7 @@ double first_true(Pred pred) {
 int launch_filter_scan(randt_ctx* ctx, const float* d_raw, int n_scans, int n_az, int n_bins, int stride, int ioff,
                        const randt_filter_params* fp, float* d_out_pts, int pitch_out, int32_t* d_out_counts, float* d_polar,
                        float* d_peaks, int32_t* d_peak_counts, int32_t* d_status, void* d_scratch) {
+  randt_note_enqueue(ctx);  // (RANDT_SOLVE_AUTO of the process's other contexts: this one has work in flight)
   FilterArgs A;
   A.raw = d_raw;
   A.n_scans = n_scans;

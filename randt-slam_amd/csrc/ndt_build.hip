@@ -831,7 +831,8 @@ int launch_ndt_build(randt_ctx* ctx, const float* d_points, int n_scans, int pit
                        rank_mode, ctx->misrank_word, ctx->d_misrank_count);                                                                       \
   } while (0)
   // placement (see the kernel): batches that share the chip with other batches' solves
-  const bool tp = ctx->solve_mode == RANDT_SOLVE_THROUGHPUT || n_scans > 2 * ctx->n_cus;
+  const bool tp = n_scans > 2 * ctx->n_cus || randt_throughput_placement(ctx);
+  randt_note_enqueue(ctx);
   if (reg && tp) RANDT_BUILD_LAUNCH(true, true);
   else if (reg) RANDT_BUILD_LAUNCH(true, false);
   else RANDT_BUILD_LAUNCH(false, false);

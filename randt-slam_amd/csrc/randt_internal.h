@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <string>
 
@@ -51,7 +52,10 @@ struct randt_ctx {
                              // which the dispatcher places unevenly when they arrive from 16 queues
   int solve_split = -1;      // wavefronts per registration in the pair solve: -1 = chosen from the batch size (solve.hip, split_width),
                              // 0 = never split, 2..8 = forced (RANDT_SOLVE_SPLIT; experiments)
-  int solve_mode = 0;        // RANDT_SOLVE_AUTO / RANDT_SOLVE_THROUGHPUT (randt_ctx_set_solve_mode)
+  int solve_mode = 0;        // RANDT_SOLVE_AUTO / RANDT_SOLVE_THROUGHPUT / RANDT_SOLVE_LATENCY (randt_ctx_set_solve_mode)
+  std::atomic<long long> last_enqueue_ns{0};  // CLOCK_MONOTONIC of this context's last kernel enqueue, 0 = known to have drained
+                                              // (randt_note_enqueue / randt_device_shared: the placement decision of RANDT_SOLVE_AUTO)
+  int last_placement = 0;    // debug: what the last pair-solve launch chose: split width W (>= 2), 0 = one wavefront per registration
   int n_cus = 256;           // compute units of the context's device
   int lds_atomics_lane_ordered = 0;  // device self-test at context creation (api.hip): same-address LDS atomics of one instruction
                                      // are served in ascending lane order -> the build kernels rank points with one atomic each
@@ -84,6 +88,19 @@ struct randt_ctx {
   bool pin_pending[kPinSegs] = {false, false, false, false};
   randt_maps* tmp_cluster = nullptr;  // one-cell scratch map of randt_maps_insert_cluster (created once per context)
 };
+
+// RANDT_SOLVE_AUTO's question "does this batch have the device to itself?" (api.hip).  Every launcher of the hot path notes its
+// enqueue; a context that is about to choose a placement asks whether ANOTHER context of this process has work in flight on the
+// same device: one that enqueued within the last 100 us (cannot have drained unless the library itself synchronised it, which
+// resets its stamp), or -- for older stamps -- one whose stream hipStreamQuery reports busy (asked once per stamp).
+void randt_note_enqueue(randt_ctx* ctx);
+bool randt_device_shared(randt_ctx* ctx);
+// the placement of a batch that shares the chip: the caller said so, or the library sees it
+inline bool randt_throughput_placement(randt_ctx* ctx) {
+  if (ctx->solve_mode == RANDT_SOLVE_THROUGHPUT) return true;
+  if (ctx->solve_mode == RANDT_SOLVE_LATENCY) return false;
+  return randt_device_shared(ctx);
+}
 
 // counted wrappers (randt_ctx_pool_stats reports them; tests assert a steady-state scan of the drop-in drive makes none)
 hipError_t randt_dev_alloc(randt_ctx* ctx, void** p, size_t bytes, size_t* granted = nullptr);  // pool first, hipMalloc otherwise

@@ -703,13 +703,12 @@ int launch_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx,
 // 117 us against 148 us for one wavefront each; 64 registrations: 97 against 128), W = 4 up to three per CU; beyond that
 // every SIMD has a registration of its own and splitting only adds barriers.  RANDT_SOLVE_SPLIT = 0 / 2..8 overrides
 // (experiments: tools/split_probe.py).
-int split_width(const randt_ctx* ctx, const MapView& fixed, const MapView& moving, int n_pairs, int k) {
+int split_width(randt_ctx* ctx, const MapView& fixed, const MapView& moving, int n_pairs, int k) {
   if ((long long)moving.cap * k > SPLIT_PAIR_CAP || fixed.cap > (int)PAIR_MASK + 1 || moving.cap > (1 << (32 - PAIR_SHIFT))) return 0;
   if (ctx->solve_split >= 0) return ctx->solve_split < 2 ? 0 : (ctx->solve_split > SPLIT_MAXW ? SPLIT_MAXW : ctx->solve_split);
-  if (ctx->solve_mode == RANDT_SOLVE_THROUGHPUT) return 0;
-  if (n_pairs <= 2 * ctx->n_cus) return 8;
-  if (n_pairs <= 3 * ctx->n_cus) return 4;
-  return 0;
+  if (n_pairs > 3 * ctx->n_cus) return 0;
+  if (randt_throughput_placement(ctx)) return 0;  // the caller says, or the library sees, that other batches share the chip
+  return n_pairs <= 2 * ctx->n_cus ? 8 : 4;
 }
 
 template <int D, int PARAM>
@@ -720,6 +719,8 @@ int launch_one(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx,
   const bool am2 = P.alpha == -2.0;
   if (block == 64 && am2) {
     const int W = split_width(ctx, fixed, moving, n_pairs, P.k);
+    ctx->last_placement = W >= 2 ? W : 0;
+    randt_note_enqueue(ctx);
     if (W >= 2) {
       hipLaunchKernelGGL((k_solve<D, PARAM, 64, true, 1, true>), dim3(n_pairs), dim3(64 * W), 0, ctx->stream, fixed, d_fixed_idx, moving,
                          moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len, n_pairs);

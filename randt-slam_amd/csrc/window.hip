@@ -1133,6 +1133,7 @@ __global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapVi
 int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& moving, const WinDesc& desc, const WinDesc* d_desc,
                         const int32_t* d_corr, const randt_matcher_params* mp, double* d_states, randt_result* d_result, int n_windows,
                         int corr_stride, int state_stride) {
+  randt_note_enqueue(ctx);  // (RANDT_SOLVE_AUTO of the process's other contexts: this one has work in flight)
   if (n_windows <= 0) return RANDT_OK;
   SolveParams P;
   P.loss_a = mp->loss_scale;

@@ -61,6 +61,8 @@ def test_bench_single_gpu_contract():
     assert 0.0 < c3["frac"] < 0.01 and c3["bytes_per_scan"] > 1e5
     rp = d["config3_replicas"]
     assert rp["R64"]["scans_per_sec"] > 2e4 and rp["R256"]["scans_per_sec"] > rp["R64"]["scans_per_sec"] and 0.0 < rp["R256"]["window_kernel_issue_frac_of_chip"] < 1.0
+    sa = d["solve_auto_detection"]                                               # verdict item 6: AUTO = the explicit mode's rate (4-step bursts are noisy: a wide band)
+    assert sa["poses_equal_headline"] is True and 0.6 < sa["sustained"]["vs_explicit_throughput_mode"] < 1.6
     cd = d["cpp_local_fuser_drive"]
     assert cd["add_scan_pointxyzi"]["ms_per_scan"] > 0.05 and cd["add_clusters_pointxyzi"]["ms_per_scan"] > cd["add_scan_pointxyzi"]["ms_per_scan"]
     assert cd["poses_equal_across_legs"]["packed_vs_pointxyzi_max_abs"] == 0.0 and cd["poses_equal_across_legs"]["add_scan_vs_add_clusters_max_abs"] == 0.0

@@ -14,7 +14,7 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # (40 scans of the fixed-lag odometry stay in: k_solve_window gets counter rows; the polar filter of config 5 stays in: its two kernels are the one HBM-streaming stage and get their FETCH_SIZE / WRITE_SIZE rows too)
-HEAD_ONLY="--odometry-scans 40 --polar-scans 16 --slam-scans 0 --polar-odometry-scans 0 --no-cpu-baseline --no-config2 --cpp-drive-scans 0 --replica-steps 0 --distinct-inputs 0"
+HEAD_ONLY="--odometry-scans 40 --polar-scans 16 --slam-scans 0 --polar-odometry-scans 0 --no-cpu-baseline --no-config2 --cpp-drive-scans 0 --replica-steps 0 --distinct-inputs 0 --no-auto-region"
 
 python tools/csrc_hash.py > "$OUT/csrc_hash.txt"   # fingerprint of the kernels these counters belong to
 # the cost table's evidence: issue rates and the shader clock, three time bases (tools/clock_probe.hip)
