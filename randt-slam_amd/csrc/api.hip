@@ -316,6 +316,7 @@ int randt_ctx_create(int device, void* stream, randt_ctx** out) {
     const int r = atoi(e);
     if (r == 1 || r == 2 || r == 4 || r == 8) ctx->solve_rpb = r;
   }
+  if (const char* e = getenv("RANDT_SOLVE_GROUP")) ctx->solve_group = atoi(e) ? 1 : 0;  // (unset: chosen from the launch size)
   if (const char* e = getenv("RANDT_SOLVE_SPLIT")) {
     const int w = atoi(e);
     if (w >= 0 && w <= 8) ctx->solve_split = w;
@@ -432,6 +433,7 @@ int randt_ctx_destroy(randt_ctx* ctx) {
       if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
   }
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->order_ws) (void)hipFree(ctx->order_ws);
   if (ctx->build_ws) (void)hipFree(ctx->build_ws);
   if (ctx->build_wide_ws) (void)hipFree(ctx->build_wide_ws);
   if (ctx->small) (void)hipFree(ctx->small);

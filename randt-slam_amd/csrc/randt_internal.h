@@ -50,6 +50,11 @@ struct randt_ctx {
   int solve_rpb = 4;         // independent registrations (one wavefront each) per workgroup in the pair solve: 1, 2, 4, 8
                              // (RANDT_SOLVE_RPB).  4 = one per SIMD of a CU: +9 % end to end over single-wavefront workgroups,
                              // which the dispatcher places unevenly when they arrive from 16 queues
+  int solve_group = -1;      // the one-wavefront solve's workgroups take their registrations through k_solve_order's size-sorted order:
+                             // -1 = for launches of >= 8 registrations per compute unit, 0 / 1 = never / always (RANDT_SOLVE_GROUP;
+                             // round-5 experiment, profiles/experiments/r05_solve_length_grouping.md)
+  void* order_ws = nullptr;  // the order itself (int32 per registration, grown on demand)
+  size_t order_ws_bytes = 0;
   int solve_split = -1;      // wavefronts per registration in the pair solve: -1 = chosen from the batch size (solve.hip, split_width),
                              // 0 = never split, 2..8 = forced (RANDT_SOLVE_SPLIT; experiments)
   int solve_mode = 0;        // RANDT_SOLVE_AUTO / RANDT_SOLVE_THROUGHPUT / RANDT_SOLVE_LATENCY (randt_ctx_set_solve_mode)

@@ -247,7 +247,7 @@ template <int D, int PARAM, int BLOCK, bool AM2, int RPB, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_OCC(AM2, SPLIT) RANDT_SOLVE_VGPR_CAP void k_solve(MapView fixed, const int32_t* __restrict__ fixed_idx, MapView moving,
                                                       int moving_first, const int32_t* __restrict__ corr, SolveParams P,
                                                       double* __restrict__ pose4, randt_result* __restrict__ results,
-                                                      double* trace, int trace_len, int n_total) {
+                                                      double* trace, int trace_len, int n_total, const int32_t* __restrict__ order) {
   static_assert(RPB == 1 || BLOCK == 64, "several registrations per workgroup: one wavefront each");
   static_assert(!SPLIT || (BLOCK == 64 && RPB == 1), "split mode: wavefront 0 is the one-wavefront solver, the others serve residual trips");
   constexpr int NT = PARAM == RANDT_PARAM_AMBIENT4 ? 4 : 3;
@@ -270,8 +270,11 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAXW : BLOCK* RPB) RANDT_SOLVE_O
   const int tid = (RPB > 1 || SPLIT) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   const int split_wave = SPLIT ? (int)(threadIdx.x >> 6) : 0;   // split mode: every wavefront runs the prologue below for itself
   const int split_W = SPLIT ? (int)(blockDim.x >> 6) : 1;
-  const int pair = blockIdx.x * RPB + sub;
-  if (pair >= n_total) return;  // RPB > 1: a whole wavefront leaves; there is no workgroup barrier below in that mode
+  const int slot = blockIdx.x * RPB + sub;
+  if (slot >= n_total) return;  // RPB > 1: a whole wavefront leaves; there is no workgroup barrier below in that mode
+  // order (nullable, RPB > 1): the registrations of the batch sorted by descending size (k_solve_order), so that the four that
+  // share a workgroup -- its LDS and its place in the dispatcher's queue are held until the slowest ends -- are of one length class
+  const int pair = (RPB > 1 && order) ? order[slot] : slot;
   double* red = red_all[sub];
   int* s_count = s_count_all[sub];
   unsigned* s_pairs = s_pairs_all[sub];
@@ -686,11 +689,60 @@ __global__ __launch_bounds__(64) void k_eval_cost(MapView fixed, int fmap, MapVi
   }
 }
 
+// Registrations of a batch in descending order of their residual trips, ceil(cells x k / 64) -- what a one-wavefront solve's
+// duration is made of besides its (unpredictable) number of passes: round 5, tools/solve_length_probe.py: the trips explain
+// 78 % of the variance of passes x trips over the config-4 batch, the passes themselves cannot be predicted (R^2 <= 0.06).
+// A counting sort over 64 keys by ONE workgroup; the order inside a key is whatever the atomics give (a placement, not a result).
+__global__ __launch_bounds__(1024) void k_solve_order(MapView moving, int moving_first, int n, int k, int32_t* __restrict__ order) {
+  __shared__ int hist[64], base[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  auto key_of = [&](int i) {
+    int M = moving.counts[moving_first + i];
+    M = M > moving.cap ? moving.cap : M;
+    const int trips = (M * k + 63) >> 6;
+    return 63 - (trips > 63 ? 63 : trips);  // ascending key = descending size
+  };
+  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[key_of(i)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 0; b < 64; ++b) {
+      base[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[key_of(i)], 1)] = i;
+}
+
 template <int D, int PARAM, int BLOCK, bool AM2, int RPB = 1>
 int launch_cfg(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx, const MapView& moving, int moving_first,
                int n_pairs, const int32_t* d_corr, const SolveParams& P, double* d_pose4, randt_result* d_results) {
+  const int32_t* d_order = nullptr;
+  // measured (round 5, profiles/experiments/r05_solve_length_grouping.md): a launch that fills the chip several times over gains
+  // 3.8 % (8192 registrations: 595 -> 572 us); the 512-registration launches of the 16-stream pipeline gain nothing -- wavefronts
+  // that end early give their ISSUE slots to their SIMD neighbours anyway, only LDS and wave slots wait for the slowest -- so the
+  // sort is taken from eight registrations per compute unit upwards (RANDT_SOLVE_GROUP = 0 / 1: never / always)
+  const bool grouped = ctx->solve_group < 0 ? n_pairs >= 8 * ctx->n_cus : ctx->solve_group > 0;
+  if (RPB > 1 && grouped && n_pairs >= 2 * RPB) {
+    const size_t need = sizeof(int32_t) * (size_t)n_pairs;
+    if (need > ctx->order_ws_bytes) {
+      if (ctx->order_ws) {
+        RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+        RANDT_HIP_CHECK(ctx, randt_hip_free(ctx, ctx->order_ws));
+        ctx->order_ws = nullptr;
+        ctx->order_ws_bytes = 0;
+      }
+      RANDT_HIP_CHECK(ctx, randt_hip_malloc(ctx, &ctx->order_ws, need + need / 2 + 256));
+      ctx->order_ws_bytes = need + need / 2 + 256;
+    }
+    hipLaunchKernelGGL(k_solve_order, dim3(1), dim3(1024), 0, ctx->stream, moving, moving_first, n_pairs, P.k, static_cast<int32_t*>(ctx->order_ws));
+    d_order = static_cast<const int32_t*>(ctx->order_ws);
+  }
   hipLaunchKernelGGL((k_solve<D, PARAM, BLOCK, AM2, RPB>), dim3((n_pairs + RPB - 1) / RPB), dim3(BLOCK * RPB), 0, ctx->stream, fixed,
-                     d_fixed_idx, moving, moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len, n_pairs);
+                     d_fixed_idx, moving, moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len, n_pairs, d_order);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }
@@ -723,7 +775,7 @@ int launch_one(randt_ctx* ctx, const MapView& fixed, const int32_t* d_fixed_idx,
     randt_note_enqueue(ctx);
     if (W >= 2) {
       hipLaunchKernelGGL((k_solve<D, PARAM, 64, true, 1, true>), dim3(n_pairs), dim3(64 * W), 0, ctx->stream, fixed, d_fixed_idx, moving,
-                         moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len, n_pairs);
+                         moving_first, d_corr, P, d_pose4, d_results, ctx->d_trace, ctx->trace_len, n_pairs, nullptr);
       RANDT_HIP_CHECK(ctx, hipGetLastError());
       return RANDT_OK;
     }
