@@ -436,6 +436,14 @@ def se2_inv(a):
     return out
 
 
+def sqrt_zero_count(reset=False):
+    """Evaluations at which orc_ndt_residual's sqrt(0) guard (zero Jacobian row where the reference's autodiff gives NaN) fired."""
+    f = lib().orc_sqrt_zero_count
+    f.restype = C.c_longlong
+    f.argtypes = [C.c_int]
+    return int(f(1 if reset else 0))
+
+
 def set_eval_threads(n):
     """TIMING ONLY: residual blocks of one problem over n OpenMP threads (changes the summation order); 1 restores the oracle proper."""
     lib().orc_set_eval_threads(int(n))

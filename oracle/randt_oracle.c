@@ -38,6 +38,14 @@ static int32_t trunc_to_i32(float v) {
 /* TIMING ONLY (bench.py's cpu_baseline legs): residual blocks of ONE problem evaluated by several OpenMP threads, what
  * Ceres does with options.num_threads = hardware_concurrency() (ndt_matcher.cpp:376,461).  The cost is then a reduction
  * over threads, i.e. summed in another order than the sequential evaluation every parity test uses (default 1). */
+/* how often the sqrt(0) guard of orc_ndt_residual (SPEC DECISION 4) has fired since the last reset: the reference has no such
+   guard (autodiff of sqrt(0) is NaN there), so every count is an evaluation where the two would part (tests/test_oracle_eigen_bound.py) */
+static long long g_sqrt_zero_count = 0;
+long long orc_sqrt_zero_count(int reset) {
+  const long long n = g_sqrt_zero_count;
+  if (reset) g_sqrt_zero_count = 0;
+  return n;
+}
 static int g_eval_threads = 1;
 void orc_set_eval_threads(int n) { g_eval_threads = n > 1 ? n : 1; }
 
@@ -756,6 +764,10 @@ double orc_ndt_residual(int d, int parameterization, const double* pose4, const 
     if (!(r > 0.0)) {
       /* SPEC DECISION: autodiff of sqrt(0) is inf/NaN in the reference (ceres_residuals.h:545);
        * guard with a zero Jacobian row. */
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+      g_sqrt_zero_count += 1;
       for (int i = 0; i < nj; ++i) jac[i] = 0.0;
       return r;
     }

@@ -160,6 +160,8 @@ typedef struct orc_solve_stats {
 /* One residual + Jacobian (ceres_residuals.h:454-552 through Ceres autodiff x Sophus manifold).
  * d = 2 or 3.  mm/fm: means (d), mc/fc: full dxd row-major covariances.  pose4 = [c,s,tx,ty].
  * jac (may be NULL): 3 entries for MANIFOLD / VECTOR, 4 for AMBIENT4.  Returns raw residual r. */
+/* evaluations (with Jacobian) at which the sqrt(0) guard fired since the last reset (reset != 0 clears the count) */
+long long orc_sqrt_zero_count(int reset);
 double orc_ndt_residual(int d, int parameterization, const double* pose4, const double* mm,
                         const double* mc, const double* fm, const double* fc, double* jac);
 

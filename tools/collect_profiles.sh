@@ -40,3 +40,9 @@ for s in sq_a sq_b sq_c fetch write; do
 done
 find "$OUT" -name '*agent_info.csv' -delete
 du -sh "$OUT"
+# summarise ON THE BOX (the raw traces of the default command exceed what gpurun copies back) and keep only the summaries,
+# the bench lines and the error logs
+mkdir -p "$OUT/summary"
+python tools/pmc_summary.py "$OUT" "$OUT/summary/$TAG" > "$OUT/summary/pmc_summary.log" 2>&1
+rm -rf "$OUT"/pmc_*/ "$OUT/stats" "$OUT/single"
+du -sh "$OUT"
