@@ -130,6 +130,8 @@ def find_row(prefix, grid=None, most_dispatched_below=None):
     for r in ALL_ROWS:
         if not r["kernel"].startswith(prefix):
             continue
+        if grid is None and most_dispatched_below is None:
+            return r                       # any launch size: the first (heaviest) row of that kernel
         if grid is not None and int(r["grid_size"]) == grid:
             return r
         if most_dispatched_below is not None and int(r["grid_size"]) <= most_dispatched_below and (best is None or r["dispatches"] > best["dispatches"]):
