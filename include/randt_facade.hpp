@@ -318,41 +318,38 @@ struct State {
 };
 
 // rc::navigation::ndt::Map: one device-resident NDT map.
+// COPIES SHARE THEIR STORAGE UNTIL ONE OF THEM IS WRITTEN (round 5).  The reference copies Maps by value ~7 times per scan
+// (local_fuser.cpp:128-136,173-178) and writes to almost none of the copies: fmap / mmap / the deques' elements are only read,
+// smoothed_map / global_map are never used.  A copy here is a shared_ptr copy; the first mutator called on a Map whose storage
+// is shared clones it first (randt_maps_clone: pooled block, one launch) -- value semantics as far as any caller of this class
+// can tell, no device work for copies that are only read.  (Writes THROUGH THE C ABI on handle() bypass this: use
+// mutable_handle().)
 class Map {
+  struct Storage {
+    randt_maps* m = nullptr;
+    std::uint64_t id = 0, version = 0;   // identity of the storage object and a counter of writes to it (Matcher's staging cache)
+    bool known_nonempty = false;
+    ~Storage() {
+      if (m) randt_maps_destroy(m);  // the block goes back to the context's pool: no hipFree, no synchronisation
+    }
+  };
+  static std::uint64_t next_id() {
+    static std::uint64_t n = 0;
+    return ++n;
+  }
+
  public:
   Map() = default;
-  Map(const Map& o) { *this = o; }  // the reference copies Maps by value all over (local_fuser.cpp:128-129)
-  Map& operator=(const Map& o) {
-    if (this == &o) return *this;
-    release();
-    if (o.m_) {
-      ctx_ = o.ctx_;
-      params_ = o.params_;
-      cap_ = o.cap_;
-      known_nonempty_ = o.known_nonempty_;
-      // pooled storage + one launch, asynchronous: the reference copies Maps ~7 times per scan (local_fuser.cpp:128-130,135,173-178)
-      check(randt_maps_clone(o.m_, 0, 1, &m_), "randt_maps_clone");
-    }
-    return *this;
-  }
-  Map(Map&& o) noexcept { *this = std::move(o); }
-  Map& operator=(Map&& o) noexcept {
-    if (this == &o) return *this;
-    release();
-    ctx_ = std::move(o.ctx_);
-    params_ = o.params_;
-    cap_ = o.cap_;
-    known_nonempty_ = o.known_nonempty_;
-    m_ = o.m_;
-    o.m_ = nullptr;
-    return *this;
-  }
-  ~Map() { release(); }
+  Map(const Map&) = default;             // shares the storage (copy-on-write)
+  Map& operator=(const Map&) = default;
+  Map(Map&&) noexcept = default;
+  Map& operator=(Map&&) noexcept = default;
+  ~Map() = default;
 
   // Map::initialize (ndt_map.cpp:7-21)
   void initialize(std::shared_ptr<Context> ctx, const NDTMapParameters& p, double center_x, double center_y,
                   int cell_capacity = 0) {
-    release();
+    s_.reset();
     ctx_ = std::move(ctx);
     params_.size_x = p.size_x;
     params_.size_y = p.size_y;
@@ -371,19 +368,22 @@ class Map {
   // points: n x stride floats (pcl::PointXYZI: stride 8, intensity at 4).
   void addScan(const float* points, int n, int stride, int intensity_index, const RadarPreprocessorParameters& rp) {
     randt_cluster_params cp{rp.n_clusters, static_cast<float>(rp.max_range)};
-    known_nonempty_ = false;  // the build replaces the map's content
-    check(randt_ndt_build(ctx_->get(), points, n, stride, intensity_index, &cp, m_, 0), "randt_ndt_build");
+    if (!writable()) return;
+    s_->known_nonempty = false;  // the build replaces the map's content
+    check(randt_ndt_build(ctx_->get(), points, n, stride, intensity_index, &cp, s_->m, 0), "randt_ndt_build");
   }
 
   // void insertCluster(const pcl::PointCloud<pcl::PointXYZI>& cluster, const std::vector<...>& angle_dists)
   //                                                                                    (ndt_map.cpp:238-245)
   // One cell from all the points of an already separated cluster; appended and indexed if it is accepted.
   void insertCluster(const float* points, int n, int stride, int intensity_index) {
-    check(randt_maps_insert_cluster(m_, 0, points, n, stride, intensity_index, nullptr), "randt_maps_insert_cluster");
+    if (!writable()) return;
+    check(randt_maps_insert_cluster(s_->m, 0, points, n, stride, intensity_index, nullptr), "randt_maps_insert_cluster");
   }
   // int insertCell(const Cell& cell): grid_.push_back(cell), index grid untouched (ndt_map.h:137-140)
   int insertCell(const Cell& cell) {
-    check(randt_maps_insert_cells(m_, 0, &cell.raw(), 1, 0), "randt_maps_insert_cells");
+    if (!writable()) return -1;
+    check(randt_maps_insert_cells(s_->m, 0, &cell.raw(), 1, 0), "randt_maps_insert_cells");
     return static_cast<int>(get_n_cells()) - 1;
   }
   // void update(): Cell::updateCell on every cell (ndt_map.cpp:247-251).  Cells are always held in their updated
@@ -415,21 +415,22 @@ class Map {
 
   unsigned int get_n_cells() const {
     int32_t n = 0;
-    check(randt_maps_counts(m_, 0, 1, &n), "randt_maps_counts");
+    check(randt_maps_counts(handle(), 0, 1, &n), "randt_maps_counts");
     return static_cast<unsigned int>(n);
   }
   // A map only ever gains cells until it is cleared or rebuilt, so once a non-zero count has been read it is remembered:
   // LocalFuser::processScan's per-scan "_current_submap.isEmpty()" (local_fuser.cpp:123) then costs no device round trip.
   bool isEmpty() const {
-    if (known_nonempty_) return false;
-    known_nonempty_ = get_n_cells() != 0;
-    return !known_nonempty_;
+    if (!s_) return true;
+    if (s_->known_nonempty) return false;
+    s_->known_nonempty = get_n_cells() != 0;
+    return !s_->known_nonempty;
   }
 
   std::vector<Cell> getCells() const {
     std::vector<randt_cell> raw(cap_);
     int n = 0;
-    check(randt_maps_download(m_, 0, raw.data(), cap_, &n, nullptr), "randt_maps_download");
+    check(randt_maps_download(handle(), 0, raw.data(), cap_, &n, nullptr), "randt_maps_download");
     std::vector<Cell> out;
     out.reserve(n);
     for (int i = 0; i < n && i < cap_; ++i) out.emplace_back(raw[i], ctx_, params_.min_points_per_cell);
@@ -439,7 +440,7 @@ class Map {
   std::vector<int> getGridIndizes() const {
     std::vector<int32_t> g(static_cast<size_t>(params_.size_x) * params_.size_y);
     int n = 0;
-    check(randt_maps_download(m_, 0, nullptr, 0, &n, g.data()), "randt_maps_download");
+    check(randt_maps_download(handle(), 0, nullptr, 0, &n, g.data()), "randt_maps_download");
     return std::vector<int>(g.begin(), g.end());
   }
 
@@ -470,61 +471,89 @@ class Map {
   size_t getPointsInCell(size_t i) const { return getCells().at(i).getNumCells(); }
 
   // Map::transformMap (ndt_map.cpp:177-182); index grid stays stale like in the reference
-  void transformMap(const SE2d& trans) { check(randt_maps_transform(m_, 0, 1, trans.data()), "randt_maps_transform"); }
+  void transformMap(const SE2d& trans) {
+    if (writable()) check(randt_maps_transform(s_->m, 0, 1, trans.data()), "randt_maps_transform");
+  }
   // Map::transformMapWithPointCloud (ndt_map.cpp:184-189): the per-cell point clouds only feed the OGM, which is not
   // part of this path -- the cell statistics move exactly as in transformMap
   void transformMapWithPointCloud(const SE2d& trans) { transformMap(trans); }
   // NOT in the reference: make a transformed map searchable again (DESIGN "reference quirks")
-  void reindex() { check(randt_maps_reindex(m_, 0, 1), "randt_maps_reindex"); }
+  void reindex() {
+    if (writable()) check(randt_maps_reindex(s_->m, 0, 1), "randt_maps_reindex");
+  }
 
   // Map::mergeMapCell (ndt_map.cpp:191-207): moving_map is expected already transformed, as in
   // local_fuser.cpp:177,190; mergeMapCellAt fuses the transform.
   void mergeMapCell(const Map& moving_map) { mergeMapCellAt(moving_map, SE2d()); }
   void mergeMapCellAt(const Map& moving_map, const SE2d& pose) {
-    check(randt_maps_merge(m_, 0, moving_map.m_, 0, 1, pose.data()), "randt_maps_merge");
+    if (!writable()) return;
+    s_->known_nonempty = s_->known_nonempty || (moving_map.s_ && moving_map.s_->known_nonempty);
+    check(randt_maps_merge(s_->m, 0, moving_map.handle(), 0, 1, pose.data()), "randt_maps_merge");
   }
 
   void clear() {
-    known_nonempty_ = false;
-    check(randt_maps_clear(m_, 0, 1), "randt_maps_clear");
+    if (!s_) return;
+    if (s_.use_count() > 1) {  // the copies keep the content; this map gets a fresh (cleared) batch instead of a clone to clear
+      s_.reset();
+      create();
+      return;
+    }
+    ++s_->version;
+    s_->known_nonempty = false;
+    check(randt_maps_clear(s_->m, 0, 1), "randt_maps_clear");
   }
 
   // double Map::calculateCSDivergence(const Map& m_map)                       (ndt_map.cpp:42-99)
   // (the moving map already transformed by the caller, like local_fuser.cpp:338-339)
   double calculateCSDivergence(const Map& m_map) const {
     double v = 0.0;
-    if (!check(randt_cs_divergence(ctx_->get(), m_, 0, m_map.m_, 0, nullptr, &v, nullptr), "randt_cs_divergence"))
+    if (!check(randt_cs_divergence(ctx_->get(), handle(), 0, m_map.handle(), 0, nullptr, &v, nullptr), "randt_cs_divergence"))
       return failed_value();  // NaN: "identical maps" (0) would pass a loop-closure gate
     return v;
   }
 
-  randt_maps* handle() const { return m_; }
+  // read access for the C ABI (registration, copies); writes through it are invisible to the maps that share the storage
+  randt_maps* handle() const { return s_ ? s_->m : nullptr; }
+  // write access: detaches from the copies first
+  randt_maps* mutable_handle() { return writable() ? s_->m : nullptr; }
+  // identity and write counter of the storage behind this map: equal pairs = equal device content (Matcher's staging cache)
+  std::uint64_t storage_id() const { return s_ ? s_->id : 0; }
+  std::uint64_t storage_version() const { return s_ ? s_->version : 0; }
   const std::shared_ptr<Context>& context() const { return ctx_; }
   const randt_map_params& params() const { return params_; }
   int capacity() const { return cap_; }
 
  private:
   void create() {
-    known_nonempty_ = false;
-    check(randt_maps_create(ctx_->get(), 1, &params_, cap_, 1, &m_), "randt_maps_create");
+    s_ = std::make_shared<Storage>();
+    s_->id = next_id();
+    check(randt_maps_create(ctx_->get(), 1, &params_, cap_, 1, &s_->m), "randt_maps_create");
   }
-  void release() {
-    if (m_) randt_maps_destroy(m_);  // the storage goes back to the context's pool: no hipFree, no synchronisation
-    m_ = nullptr;
+  // before a write: a storage of its own (clone if copies share it), write counter bumped
+  bool writable() {
+    if (!s_ || !s_->m) return false;
+    if (s_.use_count() > 1) {
+      auto fresh = std::make_shared<Storage>();
+      fresh->id = next_id();
+      fresh->known_nonempty = s_->known_nonempty;
+      if (!check(randt_maps_clone(s_->m, 0, 1, &fresh->m), "randt_maps_clone")) return false;
+      s_ = std::move(fresh);
+    }
+    ++s_->version;
+    return true;
   }
   bool check(int rc, const char* what) const { return facade_check(rc, what, ctx_ ? ctx_->get() : nullptr); }
   void closest(const randt_cell& q, int n_neighbours, int mahalanobis, std::vector<size_t>& indizes) const {
     if (n_neighbours <= 0) return;
     std::vector<int32_t> out(static_cast<size_t>(n_neighbours), -1);
-    check(randt_closest_cells(ctx_->get(), m_, 0, &q, 1, n_neighbours, mahalanobis, 1, out.data()), "randt_closest_cells");
+    check(randt_closest_cells(ctx_->get(), handle(), 0, &q, 1, n_neighbours, mahalanobis, 1, out.data()), "randt_closest_cells");
     for (int32_t v : out)
       if (v >= 0) indizes.push_back(static_cast<size_t>(v));  // appended, like the reference's push_back
   }
   std::shared_ptr<Context> ctx_;
   randt_map_params params_{};
   int cap_ = 0;
-  randt_maps* m_ = nullptr;
-  mutable bool known_nonempty_ = false;
+  std::shared_ptr<Storage> s_;
 };
 
 // rc::navigation::ndt::HierarchicalMap, the NDT side only (include/ndt_representation/ndt_hierarchical_map.h): the OGM
@@ -761,16 +790,14 @@ class Matcher {
         return;
       }
     if (!ensure_stage(ctx, fixed_ndts.front().params(), fcap, nf, moving_ndts.back().params(), mcap, static_cast<int>(S))) return;
+    // A staging slot that already holds a map's current content (same storage, same write counter) is not copied again: from
+    // one scan to the next the window keeps S - 1 of its S scan maps, and the submap only changes on keyframe scans.
     std::vector<int32_t> fslots, mslots;
-    int rc = RANDT_OK;
-    for (int f = 0; f < nf && !rc; ++f) {
-      rc = randt_maps_copy(stage_fixed_, f, fixed_ndts[f].handle(), 0, 1);
-      fslots.push_back(f);
-    }
-    for (size_t i = S; i >= 1 && !rc; --i) {  // moving_ndts.end()[-i], i = S..1 -> slots 0..S-1 (oldest first)
-      rc = randt_maps_copy(stage_moving_, static_cast<int>(S - i), moving_ndts.end()[-static_cast<long>(i)].handle(), 0, 1);
-      mslots.push_back(static_cast<int32_t>(S - i));
-    }
+    std::vector<const Map*> fneed, mneed;
+    for (const Map& m : fixed_ndts) fneed.push_back(&m);
+    for (size_t i = S; i >= 1; --i) mneed.push_back(&moving_ndts.end()[-static_cast<long>(i)]);  // oldest first
+    int rc = place_in_stage(stage_fixed_, stage_fixed_keys_, fneed, fslots);
+    if (!rc) rc = place_in_stage(stage_moving_, stage_moving_keys_, mneed, mslots);
     if (!facade_check(rc, "randt_maps_copy (window staging)", ctx->get())) return;
     estimateTransformCeres(trans, trajectory, initial_angle_guess, stamp, stage_fixed_, fslots, stage_moving_, mslots, ctx->get(), window_params(),
                            stats);
@@ -875,6 +902,33 @@ class Matcher {
     mp->parameterization = analytic() ? RANDT_PARAM_ANALYTIC : (parameters_.optimize_on_manifold ? RANDT_PARAM_AMBIENT4 : RANDT_PARAM_VECTOR);
     return true;
   }
+  using StageKey = std::pair<std::uint64_t, std::uint64_t>;  // (Map::storage_id, Map::storage_version) of what a staging slot holds
+  static int place_in_stage(randt_maps* batch, std::vector<StageKey>& keys, const std::vector<const Map*>& need, std::vector<int32_t>& slots) {
+    slots.assign(need.size(), -1);
+    std::vector<char> used(keys.size(), 0);
+    for (size_t i = 0; i < need.size(); ++i) {  // what is already there
+      const StageKey k{need[i]->storage_id(), need[i]->storage_version()};
+      if (k.first == 0) continue;
+      for (size_t sl = 0; sl < keys.size(); ++sl)
+        if (!used[sl] && keys[sl] == k) {
+          slots[i] = static_cast<int32_t>(sl);
+          used[sl] = 1;
+          break;
+        }
+    }
+    for (size_t i = 0; i < need.size(); ++i) {  // the rest: one device copy each into a slot nobody needs
+      if (slots[i] >= 0) continue;
+      size_t sl = 0;
+      while (sl < keys.size() && used[sl]) ++sl;
+      if (sl == keys.size()) return RANDT_ERR_INVALID;
+      const int rc = randt_maps_copy(batch, static_cast<int>(sl), need[i]->handle(), 0, 1);
+      if (rc) return rc;
+      keys[sl] = StageKey{need[i]->storage_id(), need[i]->storage_version()};
+      used[sl] = 1;
+      slots[i] = static_cast<int32_t>(sl);
+    }
+    return RANDT_OK;
+  }
   // internal batches the deque overload of estimateTransformCeres copies the window's maps into
   bool ensure_stage(const std::shared_ptr<Context>& ctx, const randt_map_params& fp, int fcap, int n_fixed, const randt_map_params& mpar,
                     int mcap, int n_moving) {
@@ -893,12 +947,14 @@ class Matcher {
       stage_fixed_ = nullptr;
       rc = randt_maps_create(ctx->get(), std::max(2, n_fixed), &fp, fcap, 1, &stage_fixed_);
       stage_fixed_params_ = fp;
+      stage_fixed_keys_.assign(static_cast<size_t>(std::max(2, n_fixed)), StageKey{0, 0});
     }
     if (!rc && !fits(stage_moving_, stage_moving_params_, mpar, mcap, n_moving)) {
       randt_maps_destroy(stage_moving_);
       stage_moving_ = nullptr;
       rc = randt_maps_create(ctx->get(), std::max(4, n_moving), &mpar, mcap, 0, &stage_moving_);
       stage_moving_params_ = mpar;
+      stage_moving_keys_.assign(static_cast<size_t>(std::max(4, n_moving)), StageKey{0, 0});
     }
     stage_ctx_ = ctx;
     return facade_check(rc, "randt_maps_create (window staging)", ctx->get());
@@ -907,6 +963,8 @@ class Matcher {
     randt_maps_destroy(stage_fixed_);
     randt_maps_destroy(stage_moving_);
     stage_fixed_ = stage_moving_ = nullptr;
+    stage_fixed_keys_.clear();
+    stage_moving_keys_.clear();
     stage_ctx_.reset();
   }
 
@@ -916,6 +974,7 @@ class Matcher {
   std::shared_ptr<Context> stage_ctx_;
   randt_maps *stage_fixed_ = nullptr, *stage_moving_ = nullptr;
   randt_map_params stage_fixed_params_{}, stage_moving_params_{};  // what the staging batches were created with
+  std::vector<StageKey> stage_fixed_keys_, stage_moving_keys_;     // what each staging slot holds
 };
 
 // rc::navigation::ndt::ScanContextParameters (include/ndt_slam/ndt_slam_parameters.h; ndt_slam.cpp:515-552)

@@ -78,7 +78,7 @@ def test_cpp_drive_from_host_buffers_makes_no_allocator_call_in_steady_state(bui
         j = out[leg]
         assert j["device_allocs_per_scan"] == 0 and j["device_frees_per_scan"] == 0, (leg, j)
         assert j["stream_syncs_per_scan"] <= 2.0, (leg, j)
-        assert j["pool_hits_per_scan"] >= 5, (leg, j)        # the Map copies are there, and they are served from parked blocks
+        assert j["pool_hits_per_scan"] >= 1, (leg, j)        # every scan creates maps (and clones the ones it writes to): all from parked blocks
     assert out["add_scan_pointxyzi"]["submaps_finished"] == 2
     assert out["poses_equal_across_legs"]["packed_vs_pointxyzi_max_abs"] == 0.0
     assert out["poses_equal_across_legs"]["add_scan_vs_add_clusters_max_abs"] == 0.0   # cluster by cluster = the one-launch build, bit for bit
