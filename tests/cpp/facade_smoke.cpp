@@ -200,6 +200,21 @@ int main() {
                 near_pt.empty() ? (size_t)99 : near_pt[0], pos);
     edit_ok = cells.size() == 2 && grid.at(idx0) == 0 && near_pt.size() == 2 && near_pt[0] == 1 && near_cell.size() == 1 &&
               near_cell[0] == 0 && pos == 2 && m.get_n_cells() == 3;
+    // Maps are VALUES (the reference copies them all over, local_fuser.cpp:128-136,173-178): copies share their storage until one
+    // is written, and no write to one is ever seen through another
+    Map copy = m, third = m;
+    const bool shared = copy.handle() == m.handle() && third.handle() == m.handle();          // three values, one device batch
+    copy.transformMap(SE2d(0.4, 2.0, -1.0));                                                    // the copy detaches and moves ...
+    const auto moved = copy.getCells(), still = m.getCells();
+    const bool detached = copy.handle() != m.handle() && third.handle() == m.handle() && moved.size() == 3 && still.size() == 3 &&
+                          still[0].getMean() == cells[0].getMean() && moved[0].getMean() != cells[0].getMean();  // ... the original does not
+    m.clear();                                                                                  // the original is written: `third` keeps the content
+    const bool kept = m.get_n_cells() == 0 && m.isEmpty() && third.get_n_cells() == 3 && !third.isEmpty() && third.getCells()[1].getMean() == cells[1].getMean();
+    Map fourth = third;
+    fourth.insertCluster(blob2.data(), 30, 4, 3);                                               // a write to the newest copy
+    const bool grew = fourth.get_n_cells() == 4 && third.get_n_cells() == 3 && copy.get_n_cells() == 3;
+    std::printf("map values: shared %d detached %d kept %d grew %d\n", shared, detached, kept, grew);
+    edit_ok = edit_ok && shared && detached && kept && grew;
   }
   // Cell mutators through the facade (ndt_cell.h:24-154) and the never-throw behaviour
   bool cell_ok = true;

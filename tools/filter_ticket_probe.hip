@@ -5,6 +5,7 @@
 //                  partial arg-maxes combined through LDS behind one barrier (the "segment-parallel" organisation for launches
 //                  that cannot fill the chip with one wavefront per row: 400 rows = 400 wavefronts on 1024 SIMDs)
 //   + ticket       every workgroup ends with __threadfence() + one atomicAdd on its scan's counter (device scope)
+//   look-back      no emission pass: a decoupled look-back scan over the rows of a scan (k_wg_rows_lookback)
 //   + tail         the workgroup that takes a scan's last ticket reads the scan's 400 row records (32 B each) + 64 B of staged
 //                  points per row and writes ~800 output points: the emission folded into the last-arriving workgroup
 // over n_scans = 1 (rotating over 48 distinct scans: 0.9 GB, nothing is met again in the 256 MB Infinity Cache) and 16 (rotating
@@ -235,6 +236,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   finish<MODE>(scan, N_AZ, recs, stage, ticket, out);
 }
 
+// MODE 5 -- no emission pass at all: a DECOUPLED LOOK-BACK over the rows of a scan (the single-pass prefix scan of rocPRIM / CUB).
+// Every row publishes ONE self-contained 64-bit word (flag | launch epoch | detections | kept points) with a relaxed agent-scope
+// atomic store -- no fence: the word IS the data --, reads its predecessors' words (a wavefront looks 64 rows back at once) until it
+// meets an inclusive prefix, publishes its own inclusive prefix and writes its output points where they belong.  Relies on
+// workgroups being dispatched in block order (a predecessor is running or done), like every look-back scan.
+__device__ __forceinline__ unsigned long long ld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wg_rows_lookback(const float4* __restrict__ raw, unsigned long long* flags, float4* out, int* counts,
+                                                                                                   unsigned epoch, double lo2, double hi2) {
+  __shared__ float s_best[4];
+  __shared__ int s_idx[4], s_bad[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int scan = blockIdx.x / N_AZ, row = blockIdx.x - scan * N_AZ;
+  const float4* rp = raw + ((size_t)scan * N_AZ + row) * N_BINS;
+  float4 pt[12];
+#pragma unroll
+  for (int u = 0; u < 12; ++u) {
+    const int b = u * 256 + threadIdx.x;
+    pt[u] = rp[b < N_BINS ? b : N_BINS - 1];
+  }
+  const float4 first = rp[0];
+  const float x0 = first.x, y0 = first.y;
+  float best = 0.f;
+  int best_idx = 0x7fffffff, bad = 0;
+#pragma unroll
+  for (int u = 0; u < 12; ++u) visit(pt[u].x, pt[u].y, pt[u].w, u * 256 + threadIdx.x, x0, y0, lo2, hi2, best, best_idx, bad);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float oi = __shfl_xor(best, off, 64);
+    const int ox = __shfl_xor(best_idx, off, 64);
+    if (oi > best || (oi == best && ox < best_idx)) best = oi, best_idx = ox;
+    bad |= __shfl_xor(bad, off, 64);
+  }
+  if (lane == 0) s_best[wave] = best, s_idx[wave] = best_idx, s_bad[wave] = bad;
+  __syncthreads();
+  if (wave != 0) return;
+  best = s_best[0], best_idx = s_idx[0], bad = s_bad[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    if (s_best[w] > best || (s_best[w] == best && s_idx[w] < best_idx)) best = s_best[w], best_idx = s_idx[w];
+    bad |= s_bad[w];
+  }
+  const int nb = best_idx == 0x7fffffff ? 0 : best_idx;
+  const float4 q = rp[min(max(nb - 32 + lane, 0), N_BINS - 1)];
+  const unsigned long long keepm = __ballot(q.w > 0.5f * best);
+  const unsigned kept = 2;  // (two output points per row, like the other variants)
+  (void)keepm;
+  // word: [63:62] flag (1 aggregate, 2 inclusive prefix) | [61:52] epoch | [51:32] detections | [31:0] kept points
+  const unsigned long long tag = (unsigned long long)(epoch & 1023u) << 52;
+  unsigned long long* fl = flags + (size_t)scan * N_AZ;
+  const unsigned long long mine = (1ull << 32) | kept;
+  if (lane == 0) st64(&fl[row], (row == 0 ? (2ull << 62) : (1ull << 62)) | tag | mine);
+  unsigned long long excl = 0;
+  if (row > 0) {
+    int back = row - 1;  // the nearest predecessor not yet accounted for
+    for (;;) {
+      const int r = back - lane;
+      unsigned long long w = 0;
+      bool valid = r < 0;  // (beyond the scan's first row: nothing to wait for)
+      if (r >= 0) {
+        w = ld64(&fl[r]);
+        valid = (w >> 62) != 0 && ((w >> 52) & 1023u) == (epoch & 1023u);
+      }
+      const unsigned long long is_prefix = __ballot(r >= 0 && valid && (w >> 62) == 2);
+      const unsigned long long ok = __ballot(valid);
+      const int stop = is_prefix ? __ffsll((long long)is_prefix) - 1 : 64;  // the first prefix: lanes 0 .. stop take part
+      const unsigned long long need = stop >= 63 ? ~0ull : ((2ull << stop) - 1ull);
+      if ((ok & need) != need) {
+        __builtin_amdgcn_s_sleep(1);
+        continue;  // somebody in the window has not published yet
+      }
+      unsigned long long v = (r >= 0 && lane <= stop) ? (w & ((1ull << 52) - 1ull)) : 0ull;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      excl += v;
+      if (is_prefix || back - 64 < 0) break;
+      back -= 64;
+    }
+    if (lane == 0) st64(&fl[row], (2ull << 62) | tag | (excl + mine));
+  }
+  const unsigned at = (unsigned)excl;
+  if (lane < 2) out[(size_t)scan * 4096 + at + lane] = make_float4(q.x + x0, q.y, q.z, q.w);
+  if (row == N_AZ - 1 && lane == 0) counts[scan] = (int)(unsigned)(excl + mine);
+}
+
 // the shipped emission's shape: one 512-thread workgroup per scan over the row records
 __global__ __launch_bounds__(512) void k_emit(const Rec* recs, const float4* stage, float4* out) {
   const int scan = blockIdx.x, r = threadIdx.x;
@@ -310,6 +396,24 @@ int main() {
     RUN("wg_rows+agent stores+relaxed ticket+agent-load tail", (k_wg_rows<4>), g_wg);
     RUN("wave_rows+release ticket+acquire tail", (k_wave_rows<3>), g_wave);
     RUN("wave_rows+agent stores+relaxed ticket+agent-load tail", (k_wave_rows<4>), g_wave);
+    {
+      static unsigned epoch = 0;
+      unsigned long long* d_flags;
+      int* d_counts;
+      CHECK(hipMalloc(&d_flags, 16 * N_AZ * 8));
+      CHECK(hipMalloc(&d_counts, 64));
+      CHECK(hipMemset(d_flags, 0, 16 * N_AZ * 8));
+      rep("wg_rows + decoupled look-back (no emission pass)", time_us([&](int r) {
+            ++epoch;
+            hipLaunchKernelGGL(k_wg_rows_lookback, dim3(g_wg), dim3(256), 0, 0, in(r), d_flags, d_out, d_counts, epoch, 1.0, 1e9);
+          }, reps));
+      int h_counts[16];
+      CHECK(hipMemcpy(h_counts, d_counts, 4 * ns, hipMemcpyDeviceToHost));
+      for (int i = 0; i < ns; ++i)
+        if (h_counts[i] != 2 * N_AZ) printf("LOOK-BACK WRONG: scan %d count %d\n", i, h_counts[i]);
+      CHECK(hipFree(d_flags));
+      CHECK(hipFree(d_counts));
+    }
     rep("wave_rows then emit kernel", time_us([&](int r) {
           hipLaunchKernelGGL((k_wave_rows<0>), dim3(g_wave), dim3(256), 0, 0, in(r), d_recs, d_stage, d_ticket, d_out, 1.0, 1e9);
           hipLaunchKernelGGL(k_emit, dim3(ns), dim3(512), 0, 0, d_recs, d_stage, d_out);
