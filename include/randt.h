@@ -485,7 +485,7 @@ int randt_predict_state_batch(const randt_state* last, int n, double stamp, int 
  * blocks pos[2] and rot[1] with plain addition, MotionModelFactor :554-619 / RotationalResidual :307-336 /
  * NDTFrameToMap{,Intensity}FactorResidual :421-451,486-518; pos / rot of the states are the variables, the association still
  * starts from the states' `pose` members like the reference's, ndt_matcher.cpp:364).
- * Limit of the window kernels: mp->n_neighbours <= 8 (RANDT_ERR_UNSUPPORTED beyond; the pair registration takes up to 16). */
+ * Limit: mp->n_neighbours <= 16 (RANDT_ERR_UNSUPPORTED beyond), like the pair registration. */
 int randt_register_window(randt_ctx* ctx, const randt_maps* fixed, const int32_t* h_fixed_idx, int n_fixed,
                           const randt_maps* moving, const int32_t* h_moving_idx, randt_state* h_states, int n_states,
                           const double* h_imu, const randt_matcher_params* mp, const randt_window_params* wp,

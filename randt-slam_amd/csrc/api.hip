@@ -1711,8 +1711,8 @@ static int register_windows(randt_ctx* ctx, int n_windows, const randt_maps* fix
     return randt_set_error(ctx, RANDT_ERR_INVALID, "window solve: parameterization must be RANDT_PARAM_MANIFOLD, _VECTOR or _ANALYTIC", hipSuccess);
   const bool vec = mp->parameterization != RANDT_PARAM_MANIFOLD;
   if (mp->n_neighbours <= 0) return randt_set_error(ctx, RANDT_ERR_INVALID, "n_neighbours must be >= 1", hipSuccess);
-  if (mp->n_neighbours > 8)
-    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window solve: n_neighbours <= 8 (the pair registration takes up to 16; every shipped configuration uses 4)", hipSuccess);
+  if (mp->n_neighbours > 16)
+    return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "window solve: n_neighbours <= 16, like the pair registration (the association keeps at most sixteen candidates per cell; every shipped configuration uses 4)", hipSuccess);
   {
     const int prc = check_matcher_params(ctx, mp);
     if (prc) return prc;

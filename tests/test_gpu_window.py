@@ -172,6 +172,17 @@ def test_window_drive_matches_oracle(drive):
     assert abs(np.hypot(*gs[-1]["lin_vel"]) - 1.0) < 0.15       # the smoother recovered the 1 m/s body speed
 
 
+@pytest.mark.parametrize("k", [9, 12, 16])
+def test_window_with_more_than_eight_neighbours(drive, k):
+    """the window entry refused n_results_kd_lookup > 8 although the association (WIDE instantiation) and the window
+    kernels take any k <= 16: lifted; states, iteration counts and traces equal the oracle's like for the shipped k = 4."""
+    _run_drive(drive, n_fixed=2, mp_over=dict(n_neighbours=k))
+
+
+def test_general_window_kernel_with_twelve_neighbours(drive_general):
+    _run_drive(drive_general, n_fixed=2, use_imu=1, const_vel=0, mp_over=dict(n_neighbours=12))
+
+
 def test_window_overlap_two_fixed_maps(drive):
     _run_drive(drive, n_fixed=2)
 
