@@ -456,7 +456,8 @@ def register_window_batch(ctx, fixed, fixed_idx, moving, moving_idx, states, mp,
     states STATE_DTYPE (W, S + 1), trans4 (W, 4), imu None or (W, S).  Returns (states_out, trans_out, rejected (W,), results (W,))."""
     st = np.array(states, dtype=STATE_DTYPE).copy()
     W, n_states = st.shape
-    fi = np.ascontiguousarray(fixed_idx, dtype=np.int32).reshape(W, -1)
+    fi = np.ascontiguousarray(fixed_idx, dtype=np.int32)
+    fi = fi.reshape(W, fi.shape[-1] if fi.ndim == 2 else max(1, fi.size // max(1, W)))
     mi = np.ascontiguousarray(moving_idx, dtype=np.int32).reshape(W, n_states - 1)
     t = np.array(trans4, dtype=np.float64).reshape(W, 4).copy()
     im = None if imu is None else np.ascontiguousarray(imu, dtype=np.float64).reshape(W, n_states - 1)

@@ -160,3 +160,29 @@ def test_storage_pool_reuses_blocks_and_clones_are_exact(built):
     moved, _ = m.download(0)
     c3, s3_ = np.cos(0.3), np.sin(0.3)
     assert np.allclose(moved["mean"][:, 0], c3 * cells_a["mean"][:, 0] - s3_ * cells_a["mean"][:, 1] + 1.0, atol=1e-5)
+
+
+def test_storage_pool_can_be_switched_off(built):
+    """RANDT_POOL_MAX_BYTES=0 (read at context creation): nothing is parked, every destroy waits for the stream and frees -- the
+    behaviour before round 5, kept as the comparison leg of bench.py's cpp_local_fuser_drive."""
+    import os
+
+    import torch
+
+    old = os.environ.get("RANDT_POOL_MAX_BYTES")
+    os.environ["RANDT_POOL_MAX_BYTES"] = "0"
+    try:
+        ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    finally:
+        if old is None:
+            del os.environ["RANDT_POOL_MAX_BYTES"]
+        else:
+            os.environ["RANDT_POOL_MAX_BYTES"] = old
+    mapp = R.indoor_map_params()
+    s0 = ctx.pool_stats()
+    for _ in range(3):
+        m = R.Maps(ctx, 1, mapp, 256, with_grid=True)
+        m.close()
+    s1 = ctx.pool_stats()
+    assert s1["device_allocs"] == s0["device_allocs"] + 3 and s1["device_frees"] == s0["device_frees"] + 3
+    assert s1["stream_syncs"] == s0["stream_syncs"] + 3 and s1["pool_hits"] == s0["pool_hits"] and s1["pool_blocks"] == 0

@@ -359,6 +359,38 @@ def test_window_batch_entry_is_bit_identical_to_the_single_entry(drive_long, kw)
     assert len({bres[w]["iterations"] for w in range(W)}) > 1     # the windows really are different problems
 
 
+def test_window_batch_entry_edge_cases(drive):
+    """Zero windows is a no-op; a map index outside its batch, a window shape the kernels do not take and a bad parameter set are
+    refused before anything is enqueued, with the states left as they were."""
+    d = drive
+    ctx = d["ctx"]
+    mp, wp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3), R.window_params()
+    st = np.zeros((2, 3), dtype=R.STATE_DTYPE)
+    for w in range(2):
+        s = R.make_state(synth.pose3_to_pose4(d["truth"][w]), lin_vel=(0.8, 0.0), stamp=w * d["dt"])
+        for j in range(3):
+            st[w, j] = s
+            s = R.predict_state(s, (w + j + 1) * d["dt"])
+    fidx, midx, tr = np.zeros((2, 1), np.int32), np.array([[1, 2], [2, 3]], np.int32), np.stack([st[0, 2]["pose"], st[1, 2]["pose"]])
+    out = R.register_window_batch(ctx, d["sub"], fidx[:0], d["smaps"], midx[:0], st[:0], mp, wp, tr[:0])
+    assert out[0].shape == (0, 3) and len(out[3]) == 0
+    before = st.copy()
+    bad_m = midx.copy()
+    bad_m[1, 1] = 10 ** 6
+    with pytest.raises(R.RandtError) as e:
+        R.register_window_batch(ctx, d["sub"], fidx, d["smaps"], bad_m, st, mp, wp, tr)
+    assert e.value.status == R._capi.ERR_INVALID
+    with pytest.raises(R.RandtError) as e:
+        R.register_window_batch(ctx, d["sub"], np.zeros((2, 3), np.int32), d["smaps"], midx, st, mp, wp, tr)     # three fixed maps
+    assert e.value.status == R._capi.ERR_UNSUPPORTED
+    with pytest.raises(R.RandtError) as e:
+        R.register_window_batch(ctx, d["sub"], fidx, d["smaps"], midx, st, R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, n_neighbours=17), wp, tr)
+    assert e.value.status == R._capi.ERR_UNSUPPORTED
+    assert st.tobytes() == before.tobytes()
+    ok = R.register_window_batch(ctx, d["sub"], fidx, d["smaps"], midx, st, mp, wp, tr)                           # and the well-formed call goes through
+    assert ok[3]["n_residuals"].min() > 100 and not ok[2].any()
+
+
 def test_replicas_in_lock_step_equal_independent_odometry_loops(built):
     """ReplicaOdometry: R copies of the processScan call pattern advancing in lock-step (one build / window / merge launch per
     step for all of them) give, replica by replica, the very poses R independent Odometry objects give on the same scans -- over
