@@ -1447,9 +1447,10 @@ def cpp_local_fuser_drive(ctx, n_scans, python_ms_per_scan=None):
     local_fuser.cpp:128-136,173-178 --, the reference-signature Matcher::estimateTransformCeres, transformMap + mergeMapCell), fed
     HOST buffers scan by scan.  Same synthetic drive as config 3.  Reported: wall time per scan after a warm-up, and what the
     context's storage pool / pinned ring leave of the allocator: hipMalloc / hipFree / stream synchronisations per steady-state
-    scan (randt_ctx_pool_stats).  Three legs: packed x y z I points through Map::addScan, pcl::PointXYZI records (32 B, the
-    reference's own host layout) through Map::addScan, and the reference's own insertion -- host clustering + one
-    Map::insertCluster per cluster (HierarchicalMap::addClusters, ndt_hierarchical_map.cpp:28-33)."""
+    scan (randt_ctx_pool_stats).  Four legs: packed x y z I points through Map::addScan, pcl::PointXYZI records (32 B, the
+    reference's own host layout) through Map::addScan, the reference's own insertion -- host clustering (Grid::cluster +
+    labelClouds) + HierarchicalMap::addClusters on the cluster list (ndt_hierarchical_map.cpp:28-33; one launch since round 5) --
+    and that loop spelled out as one Map::insertCluster call per cluster."""
     import subprocess
     import tempfile
 
@@ -1474,7 +1475,8 @@ def cpp_local_fuser_drive(ctx, n_scans, python_ms_per_scan=None):
         warm = 160 if n_scans >= 300 else n_scans // 4
         poses = {}
         for key, flags, n in (("add_scan_packed", [], n_scans), ("add_scan_pointxyzi", ["--xyzi8"], n_scans),
-                              ("add_clusters_pointxyzi", ["--xyzi8", "--clusters"], min(n_scans, 120))):
+                              ("add_clusters_pointxyzi", ["--xyzi8", "--clusters"], n_scans),
+                              ("insert_cluster_loop_pointxyzi", ["--xyzi8", "--cluster-loop"], min(n_scans, 120))):
             if n < n_scans:   # a shorter drive: the same file header with fewer scans
                 sub = os.path.join(tmp, "scans_%d.bin" % n)
                 with open(sub, "wb") as f:
@@ -1496,7 +1498,8 @@ def cpp_local_fuser_drive(ctx, n_scans, python_ms_per_scan=None):
             poses[key] = np.loadtxt(pf)
         out["poses_equal_across_legs"] = {
             "packed_vs_pointxyzi_max_abs": float(np.abs(poses["add_scan_packed"] - poses["add_scan_pointxyzi"]).max()),
-            "add_scan_vs_add_clusters_max_abs": float(np.abs(poses["add_scan_pointxyzi"][:len(poses["add_clusters_pointxyzi"])] - poses["add_clusters_pointxyzi"]).max())}
+            "add_scan_vs_add_clusters_max_abs": float(np.abs(poses["add_scan_pointxyzi"] - poses["add_clusters_pointxyzi"]).max()),
+            "add_scan_vs_insert_cluster_loop_max_abs": float(np.abs(poses["add_scan_pointxyzi"][:len(poses["insert_cluster_loop_pointxyzi"])] - poses["insert_cluster_loop_pointxyzi"]).max())}
     if python_ms_per_scan:
         out["python_resident_loop_ms_per_scan"] = python_ms_per_scan
         out["cpp_over_python_resident"] = out["add_scan_pointxyzi"]["ms_per_scan"] / python_ms_per_scan

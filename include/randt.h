@@ -298,6 +298,13 @@ int randt_maps_reindex(randt_maps* m, int first, int count);
 int randt_maps_insert_cluster(randt_maps* m, int idx, const float* h_points, int n_points, int stride_floats,
                               int intensity_index, int* accepted);
 int randt_maps_insert_cells(randt_maps* m, int idx, const randt_cell* h_cells, int n_cells, int set_grid);
+/* HierarchicalMap::addClusters (ndt_hierarchical_map.cpp:28-33) in ONE call and ONE launch: Map::insertCluster for every cluster
+ * of a list, in order -- cluster c = points [h_offsets[c], h_offsets[c + 1]) of h_points (n_clusters + 1 offsets).  The same
+ * cells, order and index grid as n_clusters randt_maps_insert_cluster calls (a later cluster wins a shared slot).
+ * n_accepted != NULL: synchronous, *n_accepted = clusters that became cells, unplaceable ones reported by the status;
+ * n_accepted == NULL on a library-owned batch: asynchronous, reported by the next synchronising read (see above). */
+int randt_maps_insert_clusters(randt_maps* m, int idx, const float* h_points, const int32_t* h_offsets, int n_clusters,
+                               int stride_floats, int intensity_index, int* n_accepted);
 int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_cell* h_queries, int n_queries,
                         int k, int lookup_mahalanobis, int use_intensity, int32_t* h_out);
 

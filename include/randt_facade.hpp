@@ -380,6 +380,14 @@ class Map {
     if (!writable()) return;
     check(randt_maps_insert_cluster(s_->m, 0, points, n, stride, intensity_index, nullptr), "randt_maps_insert_cluster");
   }
+  // the reference's loop over insertCluster (ndt_hierarchical_map.cpp:28-33) in one call: cluster c = points
+  // [offsets[c], offsets[c + 1]); asynchronous like insertCluster
+  void insertClusters(const float* points, const std::vector<int>& offsets, int stride, int intensity_index) {
+    if (offsets.size() < 2 || !writable()) return;
+    static_assert(sizeof(int) == sizeof(int32_t), "offsets are passed as int32");
+    check(randt_maps_insert_clusters(s_->m, 0, points, reinterpret_cast<const int32_t*>(offsets.data()), static_cast<int>(offsets.size()) - 1, stride,
+                                     intensity_index, nullptr), "randt_maps_insert_clusters");
+  }
   // int insertCell(const Cell& cell): grid_.push_back(cell), index grid untouched (ndt_map.h:137-140)
   int insertCell(const Cell& cell) {
     if (!writable()) return -1;
@@ -567,8 +575,7 @@ class HierarchicalMap {
   // void addClusters(const std::vector<pcl::PointCloud<pcl::PointXYZI>>& clusters, ...): cluster c = points
   // [offsets[c], offsets[c+1]) of one n x stride array, inserted in order like the reference's loop
   void addClusters(const float* points, const std::vector<int>& offsets, int stride, int intensity_index) {
-    for (size_t c = 0; c + 1 < offsets.size(); ++c)
-      ndt_map_.insertCluster(points + static_cast<size_t>(offsets[c]) * stride, offsets[c + 1] - offsets[c], stride, intensity_index);
+    ndt_map_.insertClusters(points, offsets, stride, intensity_index);  // one launch; the same map as one insertCluster per cluster
   }
   // the whole filtered scan at once (clustering on the device): what RadarPreprocessor::processScan + addClusters amount to
   void addScan(const float* points, int n, int stride, int intensity_index, const RadarPreprocessorParameters& rp) {

@@ -136,6 +136,7 @@ SYMBOLS = {
     "randt_maps_reindex": (_I, [_V, _I, _I]),
     "randt_maps_insert_cluster": (_I, [_V, _I, _V, _I, _I, _I, _P(_I)]),
     "randt_maps_insert_cells": (_I, [_V, _I, _V, _I, _I]),
+    "randt_maps_insert_clusters": (_I, [_V, _I, _V, _V, _I, _I, _I, _P(_I)]),
     "randt_closest_cells": (_I, [_V, _V, _I, _V, _I, _I, _I, _I, _V]),
     "randt_cell_add_points": (_I, [_V, _V, _V, _I, _I, _I, _I, _P(_I)]),
     "randt_cells_merge": (_I, [_V, _V, _V, _I]),

@@ -884,6 +884,53 @@ int randt_maps_insert_cluster(randt_maps* m, int idx, const float* h_points, int
   return RANDT_OK;
 }
 
+int randt_maps_insert_clusters(randt_maps* m, int idx, const float* h_points, const int32_t* h_offsets, int n_clusters, int stride_floats,
+                               int intensity_index, int* n_accepted) {
+  DeviceGuard dev_guard__(m ? m->ctx : nullptr);
+  if (!range_ok(m, idx, 1) || n_clusters < 0 || stride_floats < 3 || intensity_index < 0 || intensity_index >= stride_floats) return RANDT_ERR_INVALID;
+  if (n_accepted) *n_accepted = 0;
+  if (n_clusters == 0) return RANDT_OK;
+  if (!h_offsets || h_offsets[0] < 0) return RANDT_ERR_INVALID;
+  for (int c = 0; c < n_clusters; ++c)
+    if (h_offsets[c + 1] < h_offsets[c]) return randt_set_error(m->ctx, RANDT_ERR_INVALID, "cluster offsets must be non-decreasing", hipSuccess);
+  const int n_points = h_offsets[n_clusters];
+  if (n_points > 0 && !h_points) return RANDT_ERR_INVALID;
+  randt_ctx* ctx = m->ctx;
+  // points | offsets | status (2) | accepted (1) in the workspace: through the pinned ring when they fit a segment
+  const size_t pb = (sizeof(float) * (size_t)n_points * stride_floats + 255) & ~(size_t)255, ob = (sizeof(int32_t) * ((size_t)n_clusters + 1) + 255) & ~(size_t)255;
+  int rc = ensure_ws(ctx, pb + ob + 256);
+  if (rc) return rc;
+  char* ws = static_cast<char*>(ctx->ws);
+  bool waited = false;
+  if (char* pin = static_cast<char*>(randt_pin_take(ctx, pb + ob))) {
+    if (n_points) memcpy(pin, h_points, sizeof(float) * (size_t)n_points * stride_floats);
+    memcpy(pin + pb, h_offsets, sizeof(int32_t) * ((size_t)n_clusters + 1));
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws, pin, pb + ob, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    if (n_points) RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws, h_points, sizeof(float) * (size_t)n_points * stride_floats, hipMemcpyHostToDevice, ctx->stream));
+    RANDT_HIP_CHECK(ctx, hipMemcpyAsync(ws + pb, h_offsets, sizeof(int32_t) * ((size_t)n_clusters + 1), hipMemcpyHostToDevice, ctx->stream));
+    RANDT_HIP_CHECK(ctx, randt_sync(ctx));  // pageable sources
+    waited = true;
+  }
+  (void)waited;
+  int32_t* d_tail = reinterpret_cast<int32_t*>(ws + pb + ob);
+  const bool deferred = !n_accepted && m->owns;  // nothing comes back: the unplaceable clusters are reported by the next synchronising read
+  rc = launch_maps_insert_clusters(ctx, m->v, idx, reinterpret_cast<const float*>(ws), reinterpret_cast<const int32_t*>(ws + pb), n_clusters, stride_floats,
+                                   intensity_index, deferred ? m->v.counts + m->v.n_maps : d_tail, deferred ? 1 : 0, d_tail + 2);
+  if (rc) return rc;
+  if (deferred) {
+    m->deferred_pending = true;
+    return RANDT_OK;
+  }
+  int32_t h_tail[3] = {0, 0, 0};
+  RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_tail, d_tail, sizeof(h_tail), hipMemcpyDeviceToHost, ctx->stream));
+  RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+  if (n_accepted) *n_accepted = h_tail[2];
+  if (h_tail[1]) return randt_set_error(ctx, RANDT_ERR_INVALID, "cluster mean outside the map's index grid", hipSuccess);
+  if (h_tail[0]) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "map cell capacity exhausted", hipSuccess);
+  return RANDT_OK;
+}
+
 int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, const randt_cell* h_queries, int n_queries, int k,
                         int lookup_mahalanobis, int use_intensity, int32_t* h_out) {
   DeviceGuard dev_guard__(ctx);

@@ -44,15 +44,10 @@ __global__ __launch_bounds__(64) void k_cells_op(int op, randt_cell* a, const ra
 }
 
 // Cell::addPointCloud (ndt_cell.cpp:25-34) + updateCell (:36-114) for ONE cell that may already hold a distribution.
-// Strictly sequential fp32 sums in point order (one lane): the reference's arithmetic spelled out.
-__global__ __launch_bounds__(64) void k_cell_update(randt_cell* cell, const float* pts, int k, int stride, int ioff, int min_points,
-                                                   int32_t* accepted) {
-  if (threadIdx.x != 0) return;
-  randt_cell c = load_cell(cell);
-  if (!((long long)c.n + (long long)k > (long long)min_points) || k <= 0) {
-    *accepted = 0;
-    return;
-  }
+// Strictly sequential fp32 sums in point order (one lane): the reference's arithmetic spelled out.  Returns false (cell
+// untouched) if the points are not taken (n + k <= min_points).
+__device__ __forceinline__ bool cell_add_points(randt_cell& c, const float* pts, int k, int stride, int ioff, int min_points) {
+  if (!((long long)c.n + (long long)k > (long long)min_points) || k <= 0) return false;
   float m0 = 0.f, m1 = 0.f, m2 = 0.f, maxi = c.max_intensity;
   for (int j = 0; j < k; ++j) {
     const float* p = pts + (size_t)j * stride;
@@ -96,8 +91,101 @@ __global__ __launch_bounds__(64) void k_cell_update(randt_cell* cell, const floa
   }
   c.max_intensity = maxi;
   cell_regularize(c);
+  return true;
+}
+
+__global__ __launch_bounds__(64) void k_cell_update(randt_cell* cell, const float* pts, int k, int stride, int ioff, int min_points,
+                                                   int32_t* accepted) {
+  if (threadIdx.x != 0) return;
+  randt_cell c = load_cell(cell);
+  if (!cell_add_points(c, pts, k, stride, ioff, min_points)) {
+    *accepted = 0;
+    return;
+  }
   store_cell(cell, c);
   *accepted = 1;
+}
+
+// HierarchicalMap::addClusters (ndt_hierarchical_map.cpp:28-33): Map::insertCluster (ndt_map.cpp:238-245) for a whole list of
+// already separated clusters in ONE launch -- cluster c = points [offsets[c], offsets[c + 1]) of one array.  A thread per cluster
+// forms the cell (Cell::addPointCloud + updateCell on an empty cell: cell_add_points), the accepted ones are appended in CLUSTER
+// ORDER (block scan of the accept flags = the reference's grid_.size() at each push_back) and every cell's slot points at it --
+// a later cluster wins a shared slot, like the sequential loop (atomicMax on the compact index).  A cluster whose mean lies
+// outside the index grid is dropped (std::vector::at throws there), one beyond the capacity too: counted in status[0 / 1].
+#define INS_BLOCK 256
+__global__ __launch_bounds__(INS_BLOCK) void k_maps_insert_clusters(MapView dst, int dst_idx, const float* __restrict__ pts, const int32_t* __restrict__ offsets,
+                                                                   int n_clusters, int stride, int ioff, int32_t* __restrict__ status, int accumulate,
+                                                                   int32_t* __restrict__ n_accepted) {
+  __shared__ int s_wave[INS_BLOCK / 64];
+  __shared__ int s_base, s_drop, s_out, s_acc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  randt_cell* dcells = dst.cells + (size_t)dst_idx * dst.cap;
+  int32_t* grid = dst.grid ? dst.grid + (size_t)dst_idx * dst.n_slots : nullptr;
+  if (tid == 0) {
+    s_base = dst.counts[dst_idx];
+    s_drop = s_out = s_acc = 0;
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < n_clusters; c0 += INS_BLOCK) {
+    const int c = c0 + tid;
+    randt_cell cell;
+    cell.n = 0;
+    cell.max_intensity = 0.f;
+    cell.reserved = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cell.mean[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cell.cov[i] = 0.f;
+    bool take = false;
+    uint32_t slot = 0;
+    if (c < n_clusters) {
+      const int first = offsets[c], k = offsets[c + 1] - first;
+      const bool accepted = cell_add_points(cell, pts + (size_t)first * stride, k, stride, ioff, dst.min_points);
+      if (accepted) {
+        atomicAdd(&s_acc, 1);
+        slot = grid ? coord_to_index(dst, cell.mean[0], cell.mean[1]) : 0u;
+        if (grid && slot >= (uint32_t)dst.n_slots) atomicAdd(&s_out, 1);
+        else take = true;
+      }
+    }
+    // exclusive scan of `take` over the block, in cluster order
+    const unsigned long long m = __ballot(take);
+    const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < INS_BLOCK / 64; ++w) {
+      if (w < wave) before += s_wave[w];
+      total += s_wave[w];
+    }
+    const int base = s_base;
+    if (take) {
+      const int at = base + before + in_wave;
+      if (at < dst.cap) {
+        store_cell(dcells + at, cell);
+        if (grid) atomicMax(&grid[slot], at);
+      } else {
+        atomicAdd(&s_drop, 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_base = base + total < dst.cap ? base + total : dst.cap;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    dst.counts[dst_idx] = s_base;
+    if (status) {
+      if (accumulate) {
+        if (s_drop) status[0] += s_drop;
+        if (s_out) status[1] += s_out;
+      } else {
+        status[0] = s_drop;
+        status[1] = s_out;
+      }
+    }
+    if (n_accepted) *n_accepted = s_acc;
+  }
 }
 
 // Cell::transformCellWithPointCloud's second half (ndt_cell.cpp:131-135): pcl::transformPointCloud of the cell's points with
@@ -126,6 +214,15 @@ int launch_points_transform(randt_ctx* ctx, float* d_pts, int n, int stride, con
 int launch_cells_op(randt_ctx* ctx, int op, randt_cell* d_a, const randt_cell* d_b, int n, const double* d_pose4, double* d_out) {
   if (n <= 0) return RANDT_OK;
   hipLaunchKernelGGL(k_cells_op, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, op, d_a, d_b, n, d_pose4, d_out);
+  RANDT_HIP_CHECK(ctx, hipGetLastError());
+  return RANDT_OK;
+}
+
+int launch_maps_insert_clusters(randt_ctx* ctx, const MapView& dst, int dst_idx, const float* d_pts, const int32_t* d_offsets, int n_clusters,
+                                int stride, int ioff, int32_t* d_status, int accumulate, int32_t* d_n_accepted) {
+  if (n_clusters <= 0) return RANDT_OK;
+  hipLaunchKernelGGL(k_maps_insert_clusters, dim3(1), dim3(INS_BLOCK), 0, ctx->stream, dst, dst_idx, d_pts, d_offsets, n_clusters, stride, ioff,
+                     d_status, accumulate, d_n_accepted);
   RANDT_HIP_CHECK(ctx, hipGetLastError());
   return RANDT_OK;
 }

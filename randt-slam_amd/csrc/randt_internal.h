@@ -228,6 +228,8 @@ int launch_sc_detect(randt_ctx* ctx, const randt_sc_params* p, const double* d_d
 
 int launch_points_transform(randt_ctx* ctx, float* d_pts, int n, int stride, const double* d_pose4);
 int launch_cells_op(randt_ctx* ctx, int op, randt_cell* d_a, const randt_cell* d_b, int n, const double* d_pose4, double* d_out);
+int launch_maps_insert_clusters(randt_ctx* ctx, const MapView& dst, int dst_idx, const float* d_pts, const int32_t* d_offsets, int n_clusters,
+                                int stride, int ioff, int32_t* d_status, int accumulate, int32_t* d_n_accepted);
 int launch_cell_update(randt_ctx* ctx, randt_cell* d_cell, const float* d_pts, int k, int stride, int ioff, int min_points,
                        int32_t* d_accepted);
 

@@ -238,6 +238,18 @@ class Maps:
         self.ctx._check(self._lib.randt_maps_merge_batch(self._h, fixed_first, n_fixed, moving._h, moving_first, len(p) // max(1, n_fixed), _dptr(p)),
                         "randt_maps_merge_batch")
 
+    def insert_clusters(self, idx, points, offsets, intensity_index=None, wait=True):
+        """randt_maps_insert_clusters: HierarchicalMap::addClusters, every cluster of a list in one launch.  points (n, stride),
+        offsets (n_clusters + 1).  Returns the number of accepted clusters (wait=False: asynchronous, returns None)."""
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        stride = int(pts.shape[1])
+        ioff = (3 if stride == 4 else 4) if intensity_index is None else intensity_index
+        acc = C.c_int(0)
+        self.ctx._check(self._lib.randt_maps_insert_clusters(self._h, idx, _dptr(pts), _dptr(off), len(off) - 1, stride, ioff, C.byref(acc) if wait else None),
+                        "randt_maps_insert_clusters")
+        return int(acc.value) if wait else None
+
     def insert_cluster(self, idx, points, intensity_index=None):
         """Map::insertCluster: one cell from all `points` (n, stride) float32; returns True if the cell was accepted."""
         pts = np.ascontiguousarray(points, dtype=np.float32)

@@ -11,8 +11,9 @@
 //   --xyzi8     hand the scans over as pcl::PointXYZI records (32 bytes: x y z pad intensity pad pad pad), the reference's own
 //               host layout, instead of packed x y z I
 //   --clusters  the reference's own insertion: Grid::cluster + labelClouds on the host (grid.cpp:7-14,
-//               radar_preprocessor.cpp:151-169), then HierarchicalMap::addClusters = one Map::insertCluster per cluster
-//               (ndt_hierarchical_map.cpp:28-33) -- instead of the whole scan in one call (Map::addScan)
+//               radar_preprocessor.cpp:151-169), then HierarchicalMap::addClusters (ndt_hierarchical_map.cpp:28-33) on the cluster
+//               list -- instead of the whole scan in one call (Map::addScan); --cluster-loop: the same with one
+//               Map::insertCluster call per cluster
 //   --timing W  after W untimed scans: wall time per scan and the context's allocator / synchronisation counters per scan
 //               (randt_ctx_pool_stats) over the rest of the drive, as one JSON line on stdout (bench.py: cpp_local_fuser_drive)
 // tests/test_gpu_local_fuser_cpp.py runs it beside the Python harness (randt-slam_amd/odometry.py) on the same drive.
@@ -81,7 +82,7 @@ class LocalFuser {
   }
 
   // local_fuser.cpp:99-300, data path only.  points: n_points records of `stride` floats, intensity at `intensity_index`
-  void processScan(const float* points, int n_points, int stride, int intensity_index, bool cluster_by_cluster, double stamp) {
+  void processScan(const float* points, int n_points, int stride, int intensity_index, int cluster_by_cluster, double stamp) {
     HierarchicalMap current_scan;  // :103-105
     current_scan.initialize(ctx_, map_parameters_, 0.0, 0.0, 512);
     if (cluster_by_cluster) {
@@ -107,7 +108,12 @@ class LocalFuser {
         const int c = dense[labels[i]];
         std::memcpy(&clustered_[static_cast<size_t>(at[c]++) * stride], points + static_cast<size_t>(i) * stride, sizeof(float) * stride);
       }
-      current_scan.addClusters(clustered_.data(), offsets, stride, intensity_index);  // one Map::insertCluster per cluster
+      if (cluster_by_cluster > 1) {  // the loop spelled out: one Map::insertCluster call per cluster (ndt_hierarchical_map.cpp:29-32)
+        for (size_t c = 0; c + 1 < offsets.size(); ++c)
+          current_scan.getMap().insertCluster(clustered_.data() + static_cast<size_t>(offsets[c]) * stride, offsets[c + 1] - offsets[c], stride, intensity_index);
+      } else {
+        current_scan.addClusters(clustered_.data(), offsets, stride, intensity_index);  // HierarchicalMap::addClusters: the whole list in one call
+      }
     } else {
       current_scan.addScan(points, n_points, stride, intensity_index, preprocessor_parameters_);  // clustering + NDT of the scan in one call
     }
@@ -200,11 +206,13 @@ int main(int argc, char** argv) {
   std::vector<float> scans(static_cast<size_t>(n_scans) * n_points * 4);
   in.read(reinterpret_cast<char*>(scans.data()), static_cast<std::streamsize>(scans.size() * sizeof(float)));
   int size_poses = 135, overlap = 20, n_pos = 0, warm = -1;
-  bool xyzi8 = false, clusters = false;
+  bool xyzi8 = false;
+  int clusters = 0;  // 1: HierarchicalMap::addClusters (the list in one call), 2: one Map::insertCluster call per cluster
   for (int a = 3; a < argc; ++a) {
     const std::string arg = argv[a];
     if (arg == "--xyzi8") xyzi8 = true;
-    else if (arg == "--clusters") clusters = true;
+    else if (arg == "--clusters") clusters = 1;
+    else if (arg == "--cluster-loop") clusters = 2;
     else if (arg == "--timing" && a + 1 < argc) warm = std::atoi(argv[++a]);
     else if (n_pos == 0) { size_poses = std::atoi(argv[a]); ++n_pos; }
     else if (n_pos == 1) { overlap = std::atoi(argv[a]); ++n_pos; }
@@ -254,7 +262,7 @@ int main(int argc, char** argv) {
                 "\"pool_blocks\": %lld, \"insertion\": \"%s\", \"point_layout\": \"%s\", \"submaps_finished\": %d}\n",
                 n_scans - warm, warm, el / n * 1e3, n / el, (s1.device_allocs - s0.device_allocs) / n, (s1.device_frees - s0.device_frees) / n,
                 (s1.stream_syncs - s0.stream_syncs - 1) / n /* the closing synchronisation of this measurement */, (s1.pool_hits - s0.pool_hits) / n,
-                static_cast<long long>(s1.pool_bytes), static_cast<long long>(s1.pool_blocks), clusters ? "addClusters (Map::insertCluster per cluster)" : "addScan",
+                static_cast<long long>(s1.pool_bytes), static_cast<long long>(s1.pool_blocks), clusters == 2 ? "one Map::insertCluster call per cluster" : (clusters ? "HierarchicalMap::addClusters (host clustering, the list in one call)" : "addScan"),
                 xyzi8 ? "pcl::PointXYZI, 32 B" : "packed x y z I, 16 B", fuser.finishedSubmaps());
   }
   std::fclose(out);

@@ -64,8 +64,8 @@ def test_bench_single_gpu_contract():
     sa = d["solve_auto_detection"]                                               # verdict item 6: AUTO = the explicit mode's rate (4-step bursts are noisy: a wide band)
     assert sa["poses_equal_headline"] is True and 0.6 < sa["sustained"]["vs_explicit_throughput_mode"] < 1.6
     cd = d["cpp_local_fuser_drive"]
-    assert cd["add_scan_pointxyzi"]["ms_per_scan"] > 0.05 and cd["add_clusters_pointxyzi"]["ms_per_scan"] > cd["add_scan_pointxyzi"]["ms_per_scan"]
-    assert cd["poses_equal_across_legs"]["packed_vs_pointxyzi_max_abs"] == 0.0 and cd["poses_equal_across_legs"]["add_scan_vs_add_clusters_max_abs"] == 0.0
+    assert cd["add_scan_pointxyzi"]["ms_per_scan"] > 0.05 and cd["insert_cluster_loop_pointxyzi"]["ms_per_scan"] > cd["add_clusters_pointxyzi"]["ms_per_scan"]
+    assert cd["poses_equal_across_legs"]["packed_vs_pointxyzi_max_abs"] == 0.0 and cd["poses_equal_across_legs"]["add_scan_vs_add_clusters_max_abs"] == 0.0 and cd["poses_equal_across_legs"]["add_scan_vs_insert_cluster_loop_max_abs"] == 0.0
     ss1 = pf["roofline"]["single_scan"]
     assert ss1["status_ok"] and ss1["same_count_as_batched"] and 0.0 < ss1["frac"] < 1.0 and ss1["bytes"] == 19200000
     assert d["cpu_baseline"]["single_thread"]["cores"] == 1

@@ -74,12 +74,14 @@ def test_cpp_drive_from_host_buffers_makes_no_allocator_call_in_steady_state(bui
     ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
     py = bench.streaming_odometry(ctx, 300, False)
     out = bench.cpp_local_fuser_drive(ctx, 300, py["ms_per_scan"])
-    for leg in ("add_scan_packed", "add_scan_pointxyzi", "add_clusters_pointxyzi"):
+    for leg in ("add_scan_packed", "add_scan_pointxyzi", "add_clusters_pointxyzi", "insert_cluster_loop_pointxyzi"):
         j = out[leg]
         assert j["device_allocs_per_scan"] == 0 and j["device_frees_per_scan"] == 0, (leg, j)
         assert j["stream_syncs_per_scan"] <= 2.0, (leg, j)
         assert j["pool_hits_per_scan"] >= 1, (leg, j)        # every scan creates maps (and clones the ones it writes to): all from parked blocks
     assert out["add_scan_pointxyzi"]["submaps_finished"] == 2
     assert out["poses_equal_across_legs"]["packed_vs_pointxyzi_max_abs"] == 0.0
-    assert out["poses_equal_across_legs"]["add_scan_vs_add_clusters_max_abs"] == 0.0   # cluster by cluster = the one-launch build, bit for bit
+    assert out["poses_equal_across_legs"]["add_scan_vs_add_clusters_max_abs"] == 0.0   # the cluster list = the one-launch build, bit for bit
+    assert out["poses_equal_across_legs"]["add_scan_vs_insert_cluster_loop_max_abs"] == 0.0
+    assert out["add_clusters_pointxyzi"]["ms_per_scan"] < 0.6 * out["insert_cluster_loop_pointxyzi"]["ms_per_scan"]
     assert out["cpp_over_python_resident"] <= 1.15, out

@@ -186,3 +186,52 @@ def test_storage_pool_can_be_switched_off(built):
     s1 = ctx.pool_stats()
     assert s1["device_allocs"] == s0["device_allocs"] + 3 and s1["device_frees"] == s0["device_frees"] + 3
     assert s1["stream_syncs"] == s0["stream_syncs"] + 3 and s1["pool_hits"] == s0["pool_hits"] and s1["pool_blocks"] == 0
+
+
+def test_cluster_list_in_one_launch_equals_the_batched_build_and_the_loop(env):
+    """randt_maps_insert_clusters = HierarchicalMap::addClusters (ndt_hierarchical_map.cpp:28-33) on a whole cluster list in ONE
+    launch: the very map -- cells, order, index grid, bit for bit -- that one insertCluster call per cluster gives and that the
+    one-launch build of the scan gives; appending to a map that already holds cells; clusters that cannot be placed."""
+    torch, dev, ctx = env
+    pts = _scan(1300)
+    labels = po.grid_labels(pts, IP["n_clusters"], IP["max_range"])
+    order = np.argsort(labels, kind="stable")                       # labelClouds: ascending label, cloud order inside a cluster
+    sorted_pts = pts[order]
+    uniq, first = np.unique(labels[order], return_index=True)
+    offsets = np.concatenate([first, [len(pts)]]).astype(np.int32)
+    whole = R.Maps(ctx, 1, R.indoor_map_params(), 512, with_grid=True)
+    R.ndt_build_batch(ctx, torch.from_numpy(pts[None]).to(dev), R.indoor_cluster_params(), whole)
+    lst = R.Maps(ctx, 1, R.indoor_map_params(), 512, with_grid=True)
+    n_acc = lst.insert_clusters(0, sorted_pts, offsets)
+    a, ga = whole.download(0)
+    b, gb = lst.download(0)
+    assert n_acc == len(a) > 20 and cells_equal(a, b) and np.array_equal(ga, gb)
+    # asynchronous form, in two halves onto a map that is not empty any more: the same map again
+    half = len(uniq) // 2
+    two = R.Maps(ctx, 1, R.indoor_map_params(), 512, with_grid=True)
+    before = ctx.pool_stats()["stream_syncs"]
+    assert two.insert_clusters(0, sorted_pts[:offsets[half]], offsets[:half + 1], wait=False) is None
+    assert two.insert_clusters(0, sorted_pts[offsets[half]:], offsets[half:] - offsets[half], wait=False) is None
+    assert ctx.pool_stats()["stream_syncs"] == before
+    c, gc = two.download(0)
+    assert cells_equal(a, c) and np.array_equal(ga, gc)
+    # a cluster outside the index grid and a capacity that runs out: reported, the rest placed
+    far = sorted_pts.copy()
+    k0 = int(np.argmax(np.diff(offsets) > IP["min_points_per_cell"]))
+    far[offsets[k0]:offsets[k0 + 1], :2] += 500.0                     # (x alone would stay "inside": the reference only checks the flat index)
+    out = R.Maps(ctx, 1, R.indoor_map_params(), 512, with_grid=True)
+    with pytest.raises(R.RandtError) as e:
+        out.insert_clusters(0, far, offsets)
+    assert e.value.status == R._capi.ERR_INVALID and len(out.download(0)[0]) == len(a) - 1
+    tiny = R.Maps(ctx, 1, R.indoor_map_params(), 10, with_grid=True)
+    with pytest.raises(R.RandtError) as e:
+        tiny.insert_clusters(0, sorted_pts, offsets)
+    assert e.value.status == R._capi.ERR_UNSUPPORTED
+    t, _ = tiny.download(0)
+    assert len(t) == 10 and cells_equal(t, a[:10])
+    tiny2 = R.Maps(ctx, 1, R.indoor_map_params(), 10, with_grid=True)
+    tiny2.insert_clusters(0, sorted_pts, offsets, wait=False)          # asynchronous: the status arrives with the next read, once
+    with pytest.raises(R.RandtError) as e:
+        tiny2.counts()
+    assert e.value.status == R._capi.ERR_UNSUPPORTED
+    assert tiny2.counts()[0] == 10
