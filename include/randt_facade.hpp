@@ -329,6 +329,8 @@ class Map {
     randt_maps* m = nullptr;
     std::uint64_t id = 0, version = 0;   // identity of the storage object and a counter of writes to it (Matcher's staging cache)
     bool known_nonempty = false;
+    std::vector<randt_cell> host_cells;  // the cells as last downloaded, valid while host_cells_version == version + 1
+    std::uint64_t host_cells_version = 0;
     ~Storage() {
       if (m) randt_maps_destroy(m);  // the block goes back to the context's pool: no hipFree, no synchronisation
     }
@@ -435,13 +437,27 @@ class Map {
     return !s_->known_nonempty;
   }
 
+  // The cell records on the host: ONE download per content of the map (remembered until the next write through this class), so
+  // that loops over getCellMeanAndCovariance(i) / getPointsInCell(i) -- NDTSlam::createVisualizationMsg, ndt_slam.cpp:370-393 --
+  // cost one device round trip, not one per cell.
+  const std::vector<randt_cell>& hostCells() const {
+    static const std::vector<randt_cell> none;
+    if (!s_ || !s_->m) return none;
+    if (s_->host_cells_version != s_->version + 1) {
+      std::vector<randt_cell> raw(cap_);
+      int n = 0;
+      check(randt_maps_download(s_->m, 0, raw.data(), cap_, &n, nullptr), "randt_maps_download");  // (a deferred insert status: the outputs are valid)
+      raw.resize(static_cast<size_t>(std::min(n, cap_)));
+      s_->host_cells.swap(raw);
+      s_->host_cells_version = s_->version + 1;
+    }
+    return s_->host_cells;
+  }
   std::vector<Cell> getCells() const {
-    std::vector<randt_cell> raw(cap_);
-    int n = 0;
-    check(randt_maps_download(handle(), 0, raw.data(), cap_, &n, nullptr), "randt_maps_download");
+    const std::vector<randt_cell>& raw = hostCells();
     std::vector<Cell> out;
-    out.reserve(n);
-    for (int i = 0; i < n && i < cap_; ++i) out.emplace_back(raw[i], ctx_, params_.min_points_per_cell);
+    out.reserve(raw.size());
+    for (const randt_cell& c : raw) out.emplace_back(c, ctx_, params_.min_points_per_cell);
     return out;
   }
 
@@ -454,10 +470,11 @@ class Map {
 
   // Map::getCellMeanAndCovariance (ndt_map.cpp:33-40)
   bool getCellMeanAndCovariance(unsigned int index, Vector3f& mean, Matrix3f& cov) const {
-    auto cells = getCells();
+    const std::vector<randt_cell>& cells = hostCells();
     if (index < cells.size()) {
-      mean = cells[index].getIntensityMean();
-      cov = cells[index].getIntensityCov();
+      const Cell c(cells[index]);
+      mean = c.getIntensityMean();
+      cov = c.getIntensityCov();
       return true;
     }
     std::cout << "WARNING: requested cell out of range!" << "\n";
@@ -466,17 +483,18 @@ class Map {
 
   // the 2-D overload (ndt_map.cpp:23-31)
   bool getCellMeanAndCovariance(unsigned int index, Vector2f& mean, Matrix2f& cov) const {
-    auto cells = getCells();
+    const std::vector<randt_cell>& cells = hostCells();
     if (index < cells.size()) {
-      mean = cells[index].getMean();
-      cov = cells[index].getCov();
+      const Cell c(cells[index]);
+      mean = c.getMean();
+      cov = c.getCov();
       return true;
     }
     std::cout << "WARNING: requested cell out of range!" << "\n";
     return false;
   }
   // const size_t getPointsInCell(size_t i) const (ndt_map.h:66-68)
-  size_t getPointsInCell(size_t i) const { return getCells().at(i).getNumCells(); }
+  size_t getPointsInCell(size_t i) const { return hostCells().at(i).n; }
 
   // Map::transformMap (ndt_map.cpp:177-182); index grid stays stale like in the reference
   void transformMap(const SE2d& trans) {

@@ -200,6 +200,22 @@ int main() {
                 near_pt.empty() ? (size_t)99 : near_pt[0], pos);
     edit_ok = cells.size() == 2 && grid.at(idx0) == 0 && near_pt.size() == 2 && near_pt[0] == 1 && near_cell.size() == 1 &&
               near_cell[0] == 0 && pos == 2 && m.get_n_cells() == 3;
+    // a loop over the cells like NDTSlam::createVisualizationMsg's (ndt_slam.cpp:370-393): ONE download for the whole loop
+    randt_pool_stats ps0{}, ps1{};
+    randt_ctx_pool_stats(ctx->get(), &ps0);
+    bool loop_ok = true;
+    for (unsigned i = 0; i < 3; ++i) {
+      Vector3f mu;
+      Matrix3f cv;
+      Vector2f mu2;
+      Matrix2f cv2;
+      loop_ok = loop_ok && m.getCellMeanAndCovariance(i, mu, cv) && m.getCellMeanAndCovariance(i, mu2, cv2) && m.getPointsInCell(i) == (i == 2 ? cells[0] : cells[i]).getNumCells() &&
+                mu == (i == 2 ? cells[0] : cells[i]).getIntensityMean() && cv2 == (i == 2 ? cells[0] : cells[i]).getCov();
+    }
+    randt_ctx_pool_stats(ctx->get(), &ps1);
+    std::printf("cell loop: ok %d, %lld stream waits for 9 accessor calls\n", loop_ok, static_cast<long long>(ps1.stream_syncs - ps0.stream_syncs));
+    loop_ok = loop_ok && ps1.stream_syncs - ps0.stream_syncs <= 2;  // one download = the count, then the cells
+    edit_ok = edit_ok && loop_ok;
     // Maps are VALUES (the reference copies them all over, local_fuser.cpp:128-136,173-178): copies share their storage until one
     // is written, and no write to one is ever seen through another
     Map copy = m, third = m;
