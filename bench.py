@@ -1372,7 +1372,7 @@ def streaming_odometry(ctx, n_scans, with_cpu):
     return out
 
 
-def config3_replicas(ctx, n_steps, replica_counts=(64, 256)):
+def config3_replicas(ctx, n_steps, replica_counts=(64, 256, 1024)):
     """BASELINE config 3 does not shard (scan t needs pose t-1: SURVEY 8(e) "replicas only"); its scaling axis is R independent
     odometry loops on one GPU.  randt-slam_amd/odometry.py::ReplicaOdometry advances R of them in lock-step -- per step ONE NDT
     build launch (R scans), ONE randt_register_window_batch (R windows, a workgroup each) and, on keyframe steps, ONE
