@@ -215,17 +215,13 @@ struct Shared {
   int bsize[WIN_SMAX + 1];  // tangent dimensions of state b
   int off_tan[RANDT_WIN_MAX_STATES][5], off_amb[RANDT_WIN_MAX_STATES][5];  // WinDesc's, for the lane-indexed readers (Plus, step norms, assembly)
   int band_ok;
+  // The cell records of every lane's first three NDT trips, staged once per solve (the association is frozen): a lone
+  // workgroup has nothing to hide the L2 latency of the record gathers behind, and they sit on the pass's critical path
+  // three times per pass.  [share][trip][group][lane]: moving record floats 0-3, 4-7, fixed 0-3, 4-7, (moving 8, fixed 8, -, -).
+  // gfx950 lets one workgroup declare all 160 KiB of the CU's LDS.
+  float4 recs[WIN_NDT_WAVES][3][5][64];
   Loss loss;  // robust loss of the running GNC step (uniform; in LDS so that it does not occupy ~20 registers across the solve)
 };
-
-// The cell records of every lane's first three NDT trips, staged once per solve (the association is frozen): a lone
-// workgroup has nothing to hide the L2 latency of the record gathers behind, and they sit on the pass's critical path
-// three times per pass.  [share][trip][group][lane]: moving record floats 0-3, 4-7, fixed 0-3, 4-7, (moving 8, fixed 8, -, -).
-// gfx950 lets one workgroup declare all 160 KiB of the CU's LDS: 92 KB of records + 54 KB of solver state = ONE window per
-// compute unit.  STAGE = false (round 5: batches of more windows than compute units, randt_register_window_batch) leaves the
-// records in L2 and the kernel at 54 KB: two windows per compute unit, each hiding the other's gathers -- same floats, same
-// arithmetic, bit-identical results.
-typedef float4 StagedRecs[3][5][64];
 
 // Unweighted motion / IMU factors at xs[buf], one lane per factor (called by ONE wavefront).
 __device__ void factors_unweighted(const WinDesc& W, Shared& sh, int buf) {
@@ -282,9 +278,9 @@ __device__ __forceinline__ double state_sum(const Shared& sh, const double* r, i
 // MODE 1: ten base sums per wavefront -> rsum[w * 10 ..] (state_sum() combines them per state).
 // In MODE 1 wavefront 6 evaluates the motion / IMU factors of the same point while wavefronts 0-5
 // stream the NDT slots (the factors are a ~2000-instruction serial chain: hidden behind the pass).
-template <int D, int MODE, bool AM2, bool ANALYTIC, bool STAGE>
+template <int D, int MODE, bool AM2, bool ANALYTIC>
 __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinDesc& W, const TermShare& T,
-                         const Shared& sh, const StagedRecs* recs, int buf, const Loss& Lsh, double* out, int& parity, Shared& shw, const double*& rsum,
+                         const Shared& sh, int buf, const Loss& Lsh, double* out, int& parity, Shared& shw, const double*& rsum,
                          int step_from = -1) {
   const Loss L = Lsh;  // LDS -> registers for the duration of the pass
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -336,7 +332,7 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
         for (int t = 0; t < WIN_TRIP_GROUP; ++t) {
           const int slot = s0 + t * T.stride + lane;
           const int tix = grp * WIN_TRIP_GROUP + t;  // trip number of this wavefront
-          ci[t] = tix < 3 ? (tix == 0 ? T.ci0[0] : (tix == 1 ? T.ci0[1] : T.ci0[2])) : (slot < n_slots ? pc[slot] : -1);  // (in registers either way)
+          ci[t] = tix < 3 ? (tix == 0 ? T.ci0[0] : (tix == 1 ? T.ci0[1] : T.ci0[2])) : (slot < n_slots ? pc[slot] : -1);
           val[t] = ci[t] >= 0 && ci[t] < fixed.cap;
         }
         float4 mrec[WIN_TRIP_GROUP][3], frec[WIN_TRIP_GROUP][3];
@@ -345,8 +341,8 @@ __device__ bool ndt_pass(const MapView& fixed, const MapView& moving, const WinD
           const int slot = s0 + t * T.stride + lane;
           const unsigned mi = T.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, kmagic);  // slot / k
           const int tix2 = grp * WIN_TRIP_GROUP + t;
-          if (STAGE && tix2 < 3) {  // staged in LDS at the start of the solve (uniform branch)
-            const float4 (*rc)[64] = recs[T.share][tix2];
+          if (tix2 < 3) {  // staged in LDS at the start of the solve (uniform branch)
+            const float4 (*rc)[64] = sh.recs[T.share][tix2];
             mrec[t][0] = rc[0][lane];
             mrec[t][1] = rc[1][lane];
             frec[t][0] = rc[2][lane];
@@ -672,15 +668,12 @@ __device__ __noinline__ void gj_dense_solve(Shared& sh, int n, double inv_radius
 }
 
 // AM2: Barron shape exactly -2 (the shipped configurations): closed-form loss, no pow() in the kernel
-// (the 54 KB instantiation is held to 128 registers: two 512-thread workgroups per compute unit are four wavefronts per SIMD)
-template <int D, bool AM2, bool ANALYTIC, bool STAGE>
-__global__ __launch_bounds__(WIN_BLOCK) __attribute__((amdgpu_waves_per_eu(STAGE ? 2 : 4, STAGE ? 2 : 4))) void k_solve_window(MapView fixed, MapView moving, const WinDesc* __restrict__ Wp,
+template <int D, bool AM2, bool ANALYTIC>
+__global__ __launch_bounds__(WIN_BLOCK) void k_solve_window(MapView fixed, MapView moving, const WinDesc* __restrict__ Wp,
                                                             const int32_t* __restrict__ corr, SolveParams P,
                                                             double* __restrict__ states, randt_result* __restrict__ result,
                                                             double* trace, int trace_len, int corr_stride, int state_stride) {
   __shared__ Shared sh;
-  __shared__ float4 recs_store[STAGE ? WIN_NDT_WAVES : 1][3][5][STAGE ? 64 : 1];
-  const StagedRecs* recs = reinterpret_cast<const StagedRecs*>(recs_store);
   // one workgroup per window of a batch (randt_register_window_batch): descriptors, correspondence tables, states, results and
   // traces of window w lie w strides behind the first window's (a single window: blockIdx.x = 0)
   Wp += blockIdx.x;
@@ -809,16 +802,16 @@ __global__ __launch_bounds__(WIN_BLOCK) __attribute__((amdgpu_waves_per_eu(STAGE
     for (int q = 0; q < 3; ++q) {
       const int slot = T.first + q * T.stride + lane;
       T.ci0[q] = (T.active && slot < T.n_slots) ? T.pc[slot] : -1;
-      if (STAGE && T.share >= 0 && T.ci0[q] >= 0 && T.ci0[q] < fixed.cap) {
+      if (T.share >= 0 && T.ci0[q] >= 0 && T.ci0[q] < fixed.cap) {
         const unsigned mi = T.k == 1 ? (unsigned)slot : __umulhi((unsigned)slot, T.kmagic);  // slot / k
         const float4* mv = T.mov + (size_t)mi * 3;
         const float4* fv = T.fix + (size_t)T.ci0[q] * 3;
         const float4 m0 = mv[0], m1 = mv[1], m2 = mv[2], f0 = fv[0], f1 = fv[1], f2 = fv[2];
-        recs_store[STAGE ? T.share : 0][q][0][STAGE ? lane : 0] = m0;
-        recs_store[STAGE ? T.share : 0][q][1][STAGE ? lane : 0] = m1;
-        recs_store[STAGE ? T.share : 0][q][2][STAGE ? lane : 0] = f0;
-        recs_store[STAGE ? T.share : 0][q][3][STAGE ? lane : 0] = f1;
-        recs_store[STAGE ? T.share : 0][q][4][STAGE ? lane : 0] = make_float4(m2.x, f2.x, 0.f, 0.f);
+        sh.recs[T.share][q][0][lane] = m0;
+        sh.recs[T.share][q][1][lane] = m1;
+        sh.recs[T.share][q][2][lane] = f0;
+        sh.recs[T.share][q][3][lane] = f1;
+        sh.recs[T.share][q][4][lane] = make_float4(m2.x, f2.x, 0.f, 0.f);
       }
     }
     if (lane == 0 && T.share >= 0) sh.wave_state[T.share] = T.active ? T.state : -1;
@@ -886,7 +879,7 @@ __global__ __launch_bounds__(WIN_BLOCK) __attribute__((amdgpu_waves_per_eu(STAGE
   bool ok = true;
   if (n_res > 0) {
     const double* unused;
-    ok = ndt_pass<D, 0, AM2, ANALYTIC, STAGE>(fixed, moving, W, T, sh, recs, 0, sh.loss, &sh.scal[7], parity, sh, unused);
+    ok = ndt_pass<D, 0, AM2, ANALYTIC>(fixed, moving, W, T, sh, 0, sh.loss, &sh.scal[7], parity, sh, unused);
     raw_max = sh.scal[7];
     res.n_evals++;
     __syncthreads();
@@ -914,7 +907,7 @@ __global__ __launch_bounds__(WIN_BLOCK) __attribute__((amdgpu_waves_per_eu(STAGE
       int num_invalid = 0, iteration = 0;
       double minimum_cost = DBL_MAX;
       const double* rs_cur;  // per-wavefront NDT base sums at the current point
-      bool e_ok = ndt_pass<D, 1, AM2, ANALYTIC, STAGE>(fixed, moving, W, T, sh, recs, p, sh.loss, nullptr, parity, sh, rs_cur);
+      bool e_ok = ndt_pass<D, 1, AM2, ANALYTIC>(fixed, moving, W, T, sh, p, sh.loss, nullptr, parity, sh, rs_cur);
       WT(1);
       double fcost = factors_weight(W, sh, p);
       WT(2);
@@ -1077,7 +1070,7 @@ __global__ __launch_bounds__(WIN_BLOCK) __attribute__((amdgpu_waves_per_eu(STAGE
 
         // ---- candidate: factors + NDT terms with Jacobians (speculative)
         const double* rs_cand;
-        const bool c_ok = ndt_pass<D, 1, AM2, ANALYTIC, STAGE>(fixed, moving, W, T, sh, recs, 1 - p, sh.loss, nullptr, parity, sh, rs_cand, p);
+        const bool c_ok = ndt_pass<D, 1, AM2, ANALYTIC>(fixed, moving, W, T, sh, 1 - p, sh.loss, nullptr, parity, sh, rs_cand, p);
         const double sn2 = sh.scal[1];
         WT(1);
         const double cf = factors_weight(W, sh, 1 - p);
@@ -1166,18 +1159,9 @@ int launch_solve_window(randt_ctx* ctx, const MapView& fixed, const MapView& mov
   // more than three optimised states (no shipped configuration): the general kernel
   if (desc.n_tan > WIN_NMAX || desc.S > WIN_SMAX || desc.n_terms > 6 || ctx->window_general)
     return launch_solve_window_gen(ctx, fixed, moving, desc, d_desc, d_corr, P, d_states, d_result, n_windows, corr_stride, state_stride);
-  // more windows than compute units: the 54 KB instantiation, two windows per compute unit (RANDT_WINDOW_STAGE=0 / 1 forces one)
-  static const int force_stage = getenv("RANDT_WINDOW_STAGE") ? atoi(getenv("RANDT_WINDOW_STAGE")) : -1;
-  const bool stage = force_stage >= 0 ? force_stage != 0 : n_windows <= ctx->n_cus;
 #define RANDT_WIN_LAUNCH(DD, AA, NN)                                                                                       \
-  do {                                                                                                                     \
-    if (stage)                                                                                                             \
-      hipLaunchKernelGGL((k_solve_window<DD, AA, NN, true>), dim3(n_windows), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
-                         d_states, d_result, ctx->d_trace, ctx->trace_len, corr_stride, state_stride);                     \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((k_solve_window<DD, AA, NN, false>), dim3(n_windows), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
-                         d_states, d_result, ctx->d_trace, ctx->trace_len, corr_stride, state_stride);                     \
-  } while (0)
+  hipLaunchKernelGGL((k_solve_window<DD, AA, NN>), dim3(n_windows), dim3(WIN_BLOCK), 0, ctx->stream, fixed, moving, d_desc, d_corr, P, \
+                     d_states, d_result, ctx->d_trace, ctx->trace_len, corr_stride, state_stride)
   const bool am2 = P.alpha == -2.0;
   if (desc.pad_) {  // RANDT_PARAM_ANALYTIC: the reference's hand-written NDT functor (never set by a shipped configuration)
     if (desc.d3) {
