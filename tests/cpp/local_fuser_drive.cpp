@@ -14,6 +14,12 @@
 //               radar_preprocessor.cpp:151-169), then HierarchicalMap::addClusters (ndt_hierarchical_map.cpp:28-33) on the cluster
 //               list -- instead of the whole scan in one call (Map::addScan); --cluster-loop: the same with one
 //               Map::insertCluster call per cluster
+//   --slam F    the whole SLAM loop (row f-4), like randt-slam_amd/slam.py: graph nodes / odometry edges (local_fuser.cpp:192-222,
+//               247-279), SCManager keys per node, LocalFuser::detectLoopClosures after every scan (:318-350: Scan Context
+//               candidate -> Matcher::estimateLoopConstraint against the candidate's finished submap -> Map::transformMap +
+//               calculateCSDivergence gate -> loop edge), GlobalFuser::optimizePoseGraph every 40 scans (ndt_slam.cpp:351-361) and
+//               the current submap's origin following its root node (local_fuser.cpp:78-79).  Writes the graph to file F:
+//               "node x y rot" per node, "loop query candidate cs accepted" per checked candidate.
 //   --timing W  after W untimed scans: wall time per scan and the context's allocator / synchronisation counters per scan
 //               (randt_ctx_pool_stats) over the rest of the drive, as one JSON line on stdout (bench.py: cpp_local_fuser_drive)
 // tests/test_gpu_local_fuser_cpp.py runs it beside the Python harness (randt-slam_amd/odometry.py) on the same drive.
@@ -25,6 +31,7 @@
 #include <deque>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -63,6 +70,62 @@ class LocalFuser {
   }
 
   SE2d getTransform() const { return mul(current_global_transform_, current_transform_); }  // local_fuser.h:113-127
+
+  // ---- the SLAM layer (--slam) --------------------------------------------------------------------------------------------
+  struct LoopLog { int query, candidate; double cs; bool accepted; };
+  void enableSlam() {
+    slam_ = true;
+    ScanContextParameters sp;
+    sp.PC_MAX_RADIUS = 20.0;   // the drive of bench.py's slam_loop / tests/test_gpu_slam.py
+    sp.SC_DIST_THRES = 0.5;
+    sc_manager_.initialize(ctx_, sp);
+    global_fuser_.initialize(ctx_, GlobalFuserParameters());
+  }
+  const std::map<int, Pose>& nodes() const { return nodes_; }
+  const std::vector<LoopLog>& loopLog() const { return loop_log_; }
+  const std::vector<Constraint>& edges() const { return edges_; }
+
+  // LocalFuser::detectLoopClosures, Scan Context branch (local_fuser.cpp:318-350)
+  int detectLoopClosures() {
+    int added = 0;
+    while (!_next_maps_to_search_loop.empty()) {
+      const int q = _next_maps_to_search_loop.front();
+      _next_maps_to_search_loop.pop_front();
+      const std::pair<int, float> det = sc_manager_.detectLoopClosureID(q);   // :323
+      const int lid = det.first;
+      if (lid == -1 || submap_idzs_.at(q) == submap_idzs_.at(lid)) continue;
+      const int sub_i = submap_idzs_.at(lid);
+      if (!submaps_.count(sub_i)) continue;  // submaps_.at() would throw: the candidate's submap is still being built
+      const SE2d root = nodes_.at(root_nodes_.at(sub_i)).pose;
+      SE2d trans = mul(mul(inv(root), nodes_.at(lid).pose), SE2d(-static_cast<double>(det.second), 0.0, 0.0));   // :333
+      Map f_loop_map = submaps_.at(sub_i);   // :329  (copies: values)
+      Map m_loop_map = scans_.at(q);         // :332
+      ndt_matcher_.estimateLoopConstraint(trans, f_loop_map, m_loop_map, 2, true, 1.5);   // :335 (loop_closure_gnc_steps, loop_closure_scale)
+      m_loop_map.transformMap(trans);                                                     // :338
+      const double cs = f_loop_map.calculateCSDivergence(m_loop_map);                     // :339
+      const bool ok = cs < 3.6;                                                           // loop_closure_max_cs_divergence (parameters_indoor.yaml:8)
+      loop_log_.push_back({q, lid, cs, ok});
+      if (ok) {                                                                           // :341-347
+        Constraint c;
+        c.id_begin = root_nodes_.at(sub_i);
+        c.id_end = q;
+        c.trans = trans;
+        c.sqrt_information = {40.0, 0, 0, 0, 40.0, 0, 0, 0, 40.0};                        // loop_closure_weight * I (the drive's 40)
+        edges_.push_back(c);
+        ++added;
+      }
+    }
+    return added;
+  }
+
+  // NDTSlam::optimizePoseGraph (ndt_slam.cpp:351-361) + the pose part of LocalFuser::updateSubmaps (local_fuser.cpp:65-88)
+  void optimizePoseGraph() {
+    if (nodes_.empty() || edges_.empty() || submap_idzs_.back() <= 0) return;
+    const int n_nodes_per_submap = static_cast<int>(std::ceil((submap_size_poses_ - (matcher_parameters_.smoothing_steps - 1)) / static_cast<double>(insertion_step_)));
+    const int max_update_index = static_cast<int>((nodes_.size() - 1) / n_nodes_per_submap) * n_nodes_per_submap;
+    global_fuser_.optimizePoseGraph(nodes_, edges_, nodes_mutex_, max_update_index);
+    current_global_transform_ = nodes_.at(root_nodes_.at(n_finished_submaps_)).pose;
+  }
   bool submapComplete() const { return static_cast<int>(_trajectory.size()) >= submap_size_poses_; }
   int finishedSubmaps() const { return n_finished_submaps_; }
 
@@ -70,9 +133,11 @@ class LocalFuser {
   void initializeNewSubmap(const SE2d& initial_transform) {
     _last_state = _trajectory.back();
     const SE2d old_submap_to_new_submap = mul(inv(current_global_transform_), initial_transform);  // :45, name and all
+    if (slam_) submaps_[n_finished_submaps_] = _current_submap;                                    // :43 submaps_.insert(...)
     _last_submap_transformed = _current_submap;                                                    // :44 (a copy)
     _last_submap_transformed.transformMap(old_submap_to_new_submap);                               // :46 (index grid left stale, like there)
     _next_maps_to_insert.clear();
+    _next_scans_to_insert.clear();
     _map_window.clear();
     current_transform_ = SE2d();
     current_global_transform_ = initial_transform;
@@ -118,6 +183,10 @@ class LocalFuser {
       current_scan.addScan(points, n_points, stride, intensity_index, preprocessor_parameters_);  // clustering + NDT of the scan in one call
     }
     const Map& scan_ndt = current_scan.getMap();
+    cur_points_ = points;
+    cur_n_ = n_points;
+    cur_stride_ = stride;
+    cur_ioff_ = intensity_index;
     process(scan_ndt, stamp);
     if (submapComplete()) {  // ndt_slam.cpp:211-223
       initializeNewSubmap(getTransform());
@@ -142,13 +211,21 @@ class LocalFuser {
       ndt_matcher_.estimateTransformCeres(current_transform_, _trajectory, 0.0, stamp, fixed_ndts, _map_window);  // :139
       const int n = static_cast<int>(_trajectory.size());
       if (static_cast<int>(_map_window.size()) >= matcher_parameters_.smoothing_steps) _map_window.pop_front();  // :152-154
-      if (n % insertion_step_ == 0) _next_maps_to_insert.push_back(scan_ndt);                                     // :155-161
+      if (n % insertion_step_ == 0) {                                                                             // :155-161
+        _next_maps_to_insert.push_back(scan_ndt);
+        if (slam_) _next_scans_to_insert.emplace_back(cur_points_, cur_points_ + static_cast<size_t>(cur_n_) * cur_stride_);
+      }
       const int insertion_delay = matcher_parameters_.smoothing_steps + 1;                                       // ndt_slam.cpp:580
       if (n >= insertion_delay + insertion_step_ && (n - insertion_delay) % insertion_step_ == 0) {              // :164
         const SE2d smoothed = _trajectory.end()[-insertion_delay - 1].pose;                                       // :165-166
         Map smoothed_map = _next_maps_to_insert.front();   // :173 (unused there as well)
         Map global_map = _current_submap;                  // :174 (unused there as well)
         _last_scan_kept = _next_maps_to_insert.front();    // :176 scans_[current_node_id_] = ... "before transforming"
+        if (slam_) {                                        // :192-222 node + odometry edge, :207 Scan Context keys
+          const int nid = addNode(mul(current_global_transform_, smoothed), _next_maps_to_insert.front(), _next_scans_to_insert.front());
+          _next_scans_to_insert.pop_front();
+          _next_maps_to_search_loop.push_back(nid);
+        }
         _next_maps_to_insert.front().transformMap(smoothed);   // :177
         _last_merged_map = _next_maps_to_insert.front();       // :178
         _current_submap.mergeMapCell(_next_maps_to_insert.front());  // :190
@@ -168,13 +245,54 @@ class LocalFuser {
       }
       st.stamp = stamp;
       _trajectory.push_back(st);
+      if (slam_) {                             // :247-279 root node of the submap
+        const int nid = addNode(current_global_transform_, scan_ndt, std::vector<float>(cur_points_, cur_points_ + static_cast<size_t>(cur_n_) * cur_stride_));
+        root_nodes_[n_finished_submaps_] = nid;
+      }
       Map first = scan_ndt;
       first.transformMap(current_transform_);  // :281
       _current_submap.mergeMapCell(first);     // :293
     }
   }
 
+  int addNode(const SE2d& pose, const Map& scan, const std::vector<float>& points) {
+    const int nid = static_cast<int>(nodes_.size());
+    Pose p;
+    p.pose = pose;
+    p.pos = {pose.d[2], pose.d[3]};
+    p.rot = pose.angle();
+    if (nid > 0) {                                       // :199-205, :258-267
+      Constraint c;
+      c.id_begin = nid - 1;
+      c.id_end = nid;
+      c.trans = mul(inv(nodes_.at(nid - 1).pose), pose);
+      c.sqrt_information = {10.0, 0, 0, 0, 10.0, 0, 0, 0, 50.0};   // :203-205
+      edges_.push_back(c);
+      p.traversed_dist = nodes_.at(nid - 1).traversed_dist + std::hypot(c.trans.d[2], c.trans.d[3]);
+    }
+    nodes_[nid] = p;
+    submap_idzs_.push_back(n_finished_submaps_);
+    scans_[nid] = scan;                                  // kept alive for loop registration (a value: shares the storage)
+    sc_manager_.makeAndSaveScancontextAndKeys(points.data(), static_cast<int>(points.size()) / cur_stride_, cur_stride_, cur_ioff_, {pose.d[2], pose.d[3]},
+                                              p.traversed_dist);   // :207, :281
+    return nid;
+  }
+
   std::shared_ptr<Context> ctx_;
+  bool slam_ = false;
+  SCManager sc_manager_;
+  GlobalFuser global_fuser_;
+  std::mutex nodes_mutex_;
+  std::map<int, Pose> nodes_;
+  std::vector<Constraint> edges_;
+  std::vector<int> submap_idzs_;
+  std::map<int, int> root_nodes_;
+  std::map<int, Map> scans_, submaps_;
+  std::deque<int> _next_maps_to_search_loop;
+  std::deque<std::vector<float>> _next_scans_to_insert;
+  std::vector<LoopLog> loop_log_;
+  const float* cur_points_ = nullptr;
+  int cur_n_ = 0, cur_stride_ = 4, cur_ioff_ = 3;
   NDTMapParameters map_parameters_;                    // indoor preset
   RadarPreprocessorParameters preprocessor_parameters_;
   NDTMatcherParameters matcher_parameters_;
@@ -207,6 +325,7 @@ int main(int argc, char** argv) {
   in.read(reinterpret_cast<char*>(scans.data()), static_cast<std::streamsize>(scans.size() * sizeof(float)));
   int size_poses = 135, overlap = 20, n_pos = 0, warm = -1;
   bool xyzi8 = false;
+  std::string slam_file;
   int clusters = 0;  // 1: HierarchicalMap::addClusters (the list in one call), 2: one Map::insertCluster call per cluster
   for (int a = 3; a < argc; ++a) {
     const std::string arg = argv[a];
@@ -214,6 +333,7 @@ int main(int argc, char** argv) {
     else if (arg == "--clusters") clusters = 1;
     else if (arg == "--cluster-loop") clusters = 2;
     else if (arg == "--timing" && a + 1 < argc) warm = std::atoi(argv[++a]);
+    else if (arg == "--slam" && a + 1 < argc) slam_file = argv[++a];
     else if (n_pos == 0) { size_poses = std::atoi(argv[a]); ++n_pos; }
     else if (n_pos == 1) { overlap = std::atoi(argv[a]); ++n_pos; }
   }
@@ -238,6 +358,7 @@ int main(int argc, char** argv) {
     return 3;
   }
   LocalFuser fuser(ctx, size_poses, overlap);
+  if (!slam_file.empty()) fuser.enableSlam();
   std::FILE* out = std::fopen(argv[2], "w");
   if (!out) return 2;
   randt_pool_stats s0{}, s1{};
@@ -249,8 +370,20 @@ int main(int argc, char** argv) {
       t0 = std::chrono::steady_clock::now();
     }
     fuser.processScan(scans.data() + static_cast<size_t>(i) * n_points * stride, n_points, stride, ioff, clusters, 0.25 * i);
+    if (!slam_file.empty()) {
+      fuser.detectLoopClosures();
+      if (i % 40 == 39) fuser.optimizePoseGraph();
+    }
     const SE2d p = fuser.getTransform();
     std::fprintf(out, "%.17g %.17g %.17g %.17g\n", p.d[0], p.d[1], p.d[2], p.d[3]);
+  }
+  if (!slam_file.empty()) {
+    std::FILE* g = std::fopen(slam_file.c_str(), "w");
+    if (!g) return 2;
+    for (const auto& kv : fuser.nodes()) std::fprintf(g, "node %.17g %.17g %.17g\n", kv.second.pos[0], kv.second.pos[1], kv.second.rot);
+    for (const auto& l : fuser.loopLog()) std::fprintf(g, "loop %d %d %.17g %d\n", l.query, l.candidate, l.cs, l.accepted ? 1 : 0);
+    for (const auto& e : fuser.edges()) std::fprintf(g, "edge %d %d %.17g %.17g %.17g\n", e.id_begin, e.id_end, e.trans.d[2], e.trans.d[3], e.trans.angle());
+    std::fclose(g);
   }
   if (warm >= 0 && warm < n_scans) {
     randt_ctx_synchronize(ctx->get());

@@ -85,3 +85,56 @@ def test_cpp_drive_from_host_buffers_makes_no_allocator_call_in_steady_state(bui
     assert out["poses_equal_across_legs"]["add_scan_vs_insert_cluster_loop_max_abs"] == 0.0
     assert out["add_clusters_pointxyzi"]["ms_per_scan"] < 0.6 * out["insert_cluster_loop_pointxyzi"]["ms_per_scan"]
     assert out["cpp_over_python_resident"] <= 1.15, out
+
+
+def test_cpp_whole_slam_loop_matches_the_python_harness(built, tmp_path):
+    """Row f-4 from C++: the facade's SCManager / Matcher::estimateLoopConstraint / Map::calculateCSDivergence / GlobalFuser driven
+    with LocalFuser's graph bookkeeping and detectLoopClosures (tests/cpp/local_fuser_drive.cpp --slam) on a two-lap circle with
+    seven submap roll-overs -- the same nodes, the same loop candidates and decisions, the same optimised poses as
+    randt-slam_amd/slam.py on the same drive (which tests/test_gpu_slam.py holds to the oracle chain)."""
+    import torch
+
+    from randt_slam_amd import slam, synth
+
+    n_scans, per_lap, dt = 300, 160, 0.25
+    world = synth.make_world()
+    th = 2 * np.pi * np.arange(n_scans) / per_lap
+    truth = np.stack([5.0 * np.cos(th), 5.0 * np.sin(th), th + np.pi / 2], 1)
+    scans = np.ascontiguousarray(np.stack([synth.make_scan(world, truth[i], 71000 + i) for i in range(n_scans)]), dtype=np.float32)
+    path = tmp_path / "scans.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([scans.shape[0], scans.shape[1]], dtype=np.int32).tobytes())
+        f.write(scans.tobytes())
+    exe = _build(tmp_path)
+    out, graph = tmp_path / "poses.txt", tmp_path / "graph.txt"
+    r = subprocess.run([exe, str(path), str(out), "40", "10", "--slam", str(graph)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    cpp_poses = np.loadtxt(out)
+    nodes, loops = [], []
+    for line in open(graph):
+        t = line.split()
+        if t[0] == "node":
+            nodes.append([float(v) for v in t[1:]])
+        elif t[0] == "loop":
+            loops.append((int(t[1]), int(t[2]), float(t[3]), int(t[4])))
+    nodes = np.array(nodes)
+
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    s = slam.Slam(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params(), scan_slots=n_scans // 4 + 64, submap_slots=n_scans // 40 + 8),
+                  mp, R.window_params(), R.default_matcher_params(gnc_steps=2), params=dict(submap_size_poses=40, submap_overlap=10),
+                  sc_params=dict(max_radius=20.0, dist_thresh=0.5), loop_closure_weight=40.0)
+    py_poses = []
+    for i in range(n_scans):
+        s.process_scan(scans[i], i * dt)
+        s.detect_loop_closures()
+        if i % 40 == 39:
+            s.optimize_pose_graph()
+        py_poses.append(s.get_transform().copy())        # (after the optimisation moved the current submap's origin, like the drive prints it)
+    py_poses = np.array(py_poses)
+    assert s.n_finished_submaps == 7 and s.n_optimizations == 7
+    assert len(nodes) == len(s.nodes) > 60
+    assert [(q, c, ok) for q, c, _, ok in loops] == [(q, c, int(ok)) for q, c, _, ok in s.loop_log] and sum(ok for _, _, _, ok in loops) >= 10
+    assert np.allclose([cs for _, _, cs, _ in loops], [cs for _, _, cs, _ in s.loop_log], rtol=1e-9, atol=1e-12)
+    assert np.abs(nodes - s.node_positions()).max() <= 1e-8, np.abs(nodes - s.node_positions()).max()
+    assert np.abs(cpp_poses - py_poses).max() <= 1e-8, np.abs(cpp_poses - py_poses).max()
