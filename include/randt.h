@@ -465,6 +465,22 @@ int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans,
                                 int stride_floats, int intensity_index, const randt_filter_params* fp,
                                 float* d_out_points, int pitch_out, int32_t* d_out_counts, float* d_out_polar,
                                 float* d_peaks, int32_t* d_peak_counts, int32_t* d_status);
+/* Host conveniences for ONE raw scan in host memory -- what RadarPreprocessor::processScan is handed (a sensor message,
+ * radar_preprocessor.cpp:30-43).  The raw scan is uploaded (19.2 MB for 400 x 3000 bins: the PCIe copy is most of the call;
+ * it is waited for, the host buffer is free on return), device buffers come from the context's storage pool.
+ *  - randt_filter_scan: filterScan alone, results back on the host (synchronous): up to `capacity` filtered points as packed
+ *    x y z I (*n_out = how many were written; *status = 2 if the filter kept more than `capacity`), optional polar pairs, optional
+ *    per-azimuth peaks (n_azimuths x 3, *n_peaks of them).  *status as d_status above.
+ *  - randt_filter_build: filterScan + clustering + NDT of the kept points into map `map_idx` of `out`, everything on the
+ *    device, nothing read back unless `status` is given (then the call waits and reports the filter's status; NULL: asynchronous
+ *    after the upload).  max_points: capacity of the intermediate point buffer (<= 7168 keeps the one-workgroup build). */
+int randt_filter_scan(randt_ctx* ctx, const float* h_raw, int n_azimuths, int n_bins, int stride_floats, int intensity_index,
+                      const randt_filter_params* fp, float* h_out_points, int capacity, int* n_out, float* h_out_polar,
+                      float* h_peaks, int* n_peaks, int* status);
+int randt_filter_build(randt_ctx* ctx, const float* h_raw, int n_azimuths, int n_bins, int stride_floats, int intensity_index,
+                       const randt_filter_params* fp, const randt_cluster_params* cp, int max_points, randt_maps* out, int map_idx,
+                       int* status);
+
 
 /* ------------------------------------------------------------------ fixed-lag window (a16, a17) */
 /* Matcher::predictTransform, optimize_on_manifold branch (ndt_matcher.cpp:22-59) with predictSE2

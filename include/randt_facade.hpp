@@ -582,6 +582,71 @@ class Map {
   std::shared_ptr<Storage> s_;
 };
 
+// rc::navigation::ndt::RadarPreprocessor (include/radar_preprocessing/radar_preprocessor.h:20-60), the data path: filterScan on a
+// raw polar scan in host memory (a sensor message's cloud: n_azimuths x n_bins points, azimuth after azimuth, range ascending --
+// the layout the reference's filterScan assumes, radar_preprocessor.cpp:61) and processScan = filterScan + clustering + NDT.
+struct RadarFilterParameters {  // the filterScan members of RadarPreprocessorParameters (ndt_slam_parameters.h:30-50)
+  float min_range = 0.6f, max_range = 12.0f, min_intensity = 6.0f, beam_distance_increment_threshold = 0.04f;
+  std::array<float, 12> sensor_to_base{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};  // initial_transform_radar_baselink_, row-major 3 x 4
+};
+class RadarPreprocessor {
+ public:
+  void initialize(std::shared_ptr<Context> ctx, const RadarPreprocessorParameters& clustering, const RadarFilterParameters& filter) {
+    ctx_ = std::move(ctx);
+    clustering_ = clustering;
+    fp_.min_range = filter.min_range;
+    fp_.max_range = filter.max_range;
+    fp_.min_intensity = filter.min_intensity;
+    fp_.beam_distance_increment_threshold = filter.beam_distance_increment_threshold;
+    std::copy(filter.sensor_to_base.begin(), filter.sensor_to_base.end(), fp_.sensor_to_base);
+  }
+  // void filterScan(cloud_in, cloud_out, polar_points, max_detections)                    (radar_preprocessor.cpp:45-125)
+  // cloud_out: packed x y z I in the base frame; polar_points: (angle, range) per kept point; max_detections: (angle, range,
+  // intensity) of every flushed azimuth.  Returns false (outputs untouched) if the cloud is not azimuth-organised or the call failed.
+  bool filterScan(const float* raw, int n_azimuths, int n_bins, int stride, int intensity_index, std::vector<float>& cloud_out,
+                  std::vector<std::pair<double, double>>& polar_points, std::vector<std::array<double, 3>>& max_detections) const {
+    int capacity = 8192;
+    for (;;) {
+      std::vector<float> pts(static_cast<size_t>(capacity) * 4), pol(static_cast<size_t>(capacity) * 2), pk(static_cast<size_t>(n_azimuths) * 3);
+      int n = 0, npk = 0, status = 0;
+      if (!facade_check(randt_filter_scan(ctx_->get(), raw, n_azimuths, n_bins, stride, intensity_index, &fp_, pts.data(), capacity, &n, pol.data(), pk.data(),
+                                          &npk, &status), "randt_filter_scan", ctx_->get()))
+        return false;
+      if (status == 2 && capacity < n_azimuths * n_bins) {  // more kept points than the buffer: once more with a larger one
+        capacity = std::min(capacity * 4, n_azimuths * n_bins);
+        continue;
+      }
+      if (status != 0) {
+        std::cout << "WARNING: filterScan: the cloud is not organised azimuth after azimuth -- previous value kept\n";
+        return false;
+      }
+      cloud_out.assign(pts.begin(), pts.begin() + 4 * static_cast<size_t>(n));
+      polar_points.clear();
+      for (int i = 0; i < n; ++i) polar_points.emplace_back(pol[2 * i], pol[2 * i + 1]);
+      max_detections.clear();
+      for (int i = 0; i < npk; ++i) max_detections.push_back({pk[3 * i], pk[3 * i + 1], pk[3 * i + 2]});
+      return true;
+    }
+  }
+  // RadarPreprocessor::processScan + HierarchicalMap::addClusters (local_fuser.cpp:102-105) without the host round trip of the
+  // filtered points: raw scan up, filter -> clustering -> NDT on the device into scan_ndt.  Returns the filter's status check.
+  bool processScan(const float* raw, int n_azimuths, int n_bins, int stride, int intensity_index, Map& scan_ndt, int max_points = 6144) const {
+    randt_cluster_params cp{clustering_.n_clusters, static_cast<float>(clustering_.max_range)};
+    int status = 0;
+    randt_maps* m = scan_ndt.mutable_handle();
+    if (!m || !facade_check(randt_filter_build(ctx_->get(), raw, n_azimuths, n_bins, stride, intensity_index, &fp_, &cp, max_points, m, 0, &status),
+                            "randt_filter_build", ctx_->get()))
+      return false;
+    if (status != 0) std::cout << "WARNING: processScan: filter status " << status << (status == 2 ? " (more kept points than max_points)" : " (cloud not azimuth-organised)") << "\n";
+    return status == 0;
+  }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  RadarPreprocessorParameters clustering_;
+  randt_filter_params fp_{};
+};
+
 // rc::navigation::ndt::HierarchicalMap, the NDT side only (include/ndt_representation/ndt_hierarchical_map.h): the OGM
 // ray tracing is outside this path, so the class is the pass-through LocalFuser uses to fill a scan's NDT map
 // (ndt_hierarchical_map.cpp:28-33 addClusters -> Map::insertCluster per cluster; :35-37 getMap; clear / transform).

@@ -154,6 +154,8 @@ SYMBOLS = {
     "randt_cs_divergence_batch_dev": (_I, [_V, _V, _I, _I, _V, _V, _I, _I, _V, _V, _V]),
     "randt_cs_divergence": (_I, [_V, _V, _I, _V, _I, _V, _V, _V]),
     "randt_filter_scan_batch_dev": (_I, [_V, _V, _I, _I, _I, _I, _I, _P(FilterParams), _V, _I, _V, _V, _V, _V, _V]),
+    "randt_filter_scan": (_I, [_V, _V, _I, _I, _I, _I, _P(FilterParams), _V, _I, _P(_I), _V, _V, _P(_I), _P(_I)]),
+    "randt_filter_build": (_I, [_V, _V, _I, _I, _I, _I, _P(FilterParams), _P(ClusterParams), _I, _V, _I, _P(_I)]),
     "randt_sc_make_batch_dev": (_I, [_V, _V, _I, _I, _V, _I, _I, _P(ScParams), _V, _V, _V]),
     "randt_sc_detect_batch_dev": (_I, [_V, _P(ScParams), _V, _V, _V, _V, _I, _V, _I, _V, _V, _V]),
     "randt_sc_db_create": (_I, [_V, _P(ScParams), _I, _P(_V)]),

@@ -1487,6 +1487,97 @@ int randt_filter_scan_batch_dev(randt_ctx* ctx, const float* d_raw, int n_scans,
                             d_out_counts, d_out_polar, d_peaks, d_peak_counts, d_status, ctx->ws);
 }
 
+// one raw scan from the host into a pooled device block [raw | points | polar | peaks | counts, peak count, status]
+namespace {
+struct FilterBlock {
+  char* base = nullptr;
+  size_t bytes = 0;
+  float *raw = nullptr, *pts = nullptr, *polar = nullptr, *peaks = nullptr;
+  int32_t* tail = nullptr;  // [0] count, [1] peak count, [2] status
+};
+int filter_upload(randt_ctx* ctx, const float* h_raw, int n_az, int n_bins, int stride, int capacity, bool want_polar, bool want_peaks, FilterBlock* b) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t rb = up(sizeof(float) * (size_t)n_az * n_bins * stride), pb = up(sizeof(float) * 4 * (size_t)capacity),
+               qb = want_polar ? up(sizeof(float) * 2 * (size_t)capacity) : 0, kb = want_peaks ? up(sizeof(float) * 3 * (size_t)n_az) : 0;
+  void* blk = nullptr;
+  hipError_t e = randt_dev_alloc(ctx, &blk, rb + pb + qb + kb + 256, &b->bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return randt_set_error(ctx, e == hipErrorOutOfMemory ? RANDT_ERR_NOMEM : RANDT_ERR_HIP, "hipMalloc (raw scan)", e);
+  }
+  b->base = static_cast<char*>(blk);
+  b->raw = reinterpret_cast<float*>(b->base);
+  b->pts = reinterpret_cast<float*>(b->base + rb);
+  b->polar = want_polar ? reinterpret_cast<float*>(b->base + rb + pb) : nullptr;
+  b->peaks = want_peaks ? reinterpret_cast<float*>(b->base + rb + pb + qb) : nullptr;
+  b->tail = reinterpret_cast<int32_t*>(b->base + rb + pb + qb + kb);
+  e = hipMemcpyAsync(b->raw, h_raw, sizeof(float) * (size_t)n_az * n_bins * stride, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = randt_sync(ctx);  // the caller's buffer (pageable or pinned) is free on return
+  if (e != hipSuccess) {
+    randt_dev_release(ctx, blk, b->bytes);
+    b->base = nullptr;
+    return randt_set_error(ctx, RANDT_ERR_HIP, "raw scan upload", e);
+  }
+  return RANDT_OK;
+}
+}  // namespace
+
+int randt_filter_scan(randt_ctx* ctx, const float* h_raw, int n_azimuths, int n_bins, int stride_floats, int intensity_index,
+                      const randt_filter_params* fp, float* h_out_points, int capacity, int* n_out, float* h_out_polar, float* h_peaks,
+                      int* n_peaks, int* status) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx || !fp || !h_raw || !h_out_points || !n_out || !status || n_azimuths <= 0 || n_bins <= 0 || capacity <= 0 || stride_floats < 3 ||
+      intensity_index < 0 || intensity_index >= stride_floats || (long long)n_azimuths * n_bins > (1ll << 30))
+    return RANDT_ERR_INVALID;
+  FilterBlock b;
+  int rc = filter_upload(ctx, h_raw, n_azimuths, n_bins, stride_floats, capacity, h_out_polar != nullptr, h_peaks != nullptr, &b);
+  if (rc) return rc;
+  rc = randt_filter_scan_batch_dev(ctx, b.raw, 1, n_azimuths, n_bins, stride_floats, intensity_index, fp, b.pts, capacity, b.tail, b.polar, b.peaks,
+                                   h_peaks ? b.tail + 1 : nullptr, b.tail + 2);
+  int32_t h_tail[3] = {0, 0, 0};
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(h_tail, b.tail, sizeof(h_tail), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = randt_sync(ctx);
+    const int n = h_tail[0] < capacity ? h_tail[0] : capacity;
+    if (e == hipSuccess && n > 0) e = hipMemcpyAsync(h_out_points, b.pts, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && n > 0 && h_out_polar) e = hipMemcpyAsync(h_out_polar, b.polar, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && h_peaks && h_tail[1] > 0) e = hipMemcpyAsync(h_peaks, b.peaks, sizeof(float) * 3 * (size_t)h_tail[1], hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = randt_sync(ctx);
+    if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "filter read-back", e);
+  } else {
+    (void)randt_sync(ctx);
+  }
+  randt_dev_release(ctx, b.base, b.bytes);
+  if (rc) return rc;
+  *n_out = h_tail[0];
+  if (n_peaks) *n_peaks = h_tail[1];
+  *status = h_tail[2];
+  return RANDT_OK;
+}
+
+int randt_filter_build(randt_ctx* ctx, const float* h_raw, int n_azimuths, int n_bins, int stride_floats, int intensity_index,
+                       const randt_filter_params* fp, const randt_cluster_params* cp, int max_points, randt_maps* out, int map_idx, int* status) {
+  DeviceGuard dev_guard__(ctx);
+  if (!ctx || !fp || !cp || !h_raw || !range_ok(out, map_idx, 1) || n_azimuths <= 0 || n_bins <= 0 || max_points <= 0 || stride_floats < 3 ||
+      intensity_index < 0 || intensity_index >= stride_floats || (long long)n_azimuths * n_bins > (1ll << 30))
+    return RANDT_ERR_INVALID;
+  FilterBlock b;
+  int rc = filter_upload(ctx, h_raw, n_azimuths, n_bins, stride_floats, max_points, false, false, &b);
+  if (rc) return rc;
+  rc = randt_filter_scan_batch_dev(ctx, b.raw, 1, n_azimuths, n_bins, stride_floats, intensity_index, fp, b.pts, max_points, b.tail, nullptr, nullptr,
+                                   nullptr, b.tail + 2);
+  if (!rc) rc = randt_ndt_build_batch_dev(ctx, b.pts, 1, max_points, b.tail, 4, 3, cp, out, map_idx);
+  int32_t h_status = 0;
+  if (!rc && status) {
+    hipError_t e = hipMemcpyAsync(&h_status, b.tail + 2, sizeof(h_status), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = randt_sync(ctx);
+    if (e != hipSuccess) rc = randt_set_error(ctx, RANDT_ERR_HIP, "filter status read-back", e);
+  }
+  randt_dev_release(ctx, b.base, b.bytes);  // parked: whatever reuses it is enqueued behind the two kernels
+  if (!rc && status) *status = h_status;
+  return rc;
+}
+
 // ------------------------------------------------------------------ correlative search (f-3) ------
 namespace {
 struct BnbNode {

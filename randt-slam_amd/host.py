@@ -503,6 +503,34 @@ def filter_scan_batch(ctx, raw, fp, out_points, out_counts, status, out_polar=No
                                                     _dptr(peaks), _dptr(peak_counts), _dptr(status)), "randt_filter_scan_batch_dev")
 
 
+def filter_scan_host(ctx, raw, fp, capacity=8192, intensity_index=None, want_polar=True, want_peaks=True):
+    """randt_filter_scan: RadarPreprocessor::filterScan for ONE raw scan in host memory, results on the host.
+    raw: (n_azimuths, n_bins, stride) float32 numpy.  Returns (points [n][4], polar [n][2] or None, peaks [m][3] or None, n_kept, status)."""
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    n_az, n_bins, stride = (int(v) for v in raw.shape)
+    ioff = (3 if stride == 4 else 4) if intensity_index is None else intensity_index
+    pts = np.zeros((capacity, 4), dtype=np.float32)
+    pol = np.zeros((capacity, 2), dtype=np.float32) if want_polar else None
+    pk = np.zeros((n_az, 3), dtype=np.float32) if want_peaks else None
+    n, npk, st = C.c_int(0), C.c_int(0), C.c_int(0)
+    ctx._check(ctx._lib.randt_filter_scan(ctx._h, _dptr(raw), n_az, n_bins, stride, ioff, C.byref(fp), _dptr(pts), capacity, C.byref(n), _dptr(pol),
+                                          _dptr(pk), C.byref(npk), C.byref(st)), "randt_filter_scan")
+    m = min(n.value, capacity)
+    return pts[:m], (pol[:m] if want_polar else None), (pk[:npk.value] if want_peaks else None), n.value, st.value
+
+
+def filter_build(ctx, raw, fp, clu, maps, map_idx=0, max_points=6144, intensity_index=None, wait=True):
+    """randt_filter_build: raw polar scan in host memory -> filterScan -> clustering + NDT into maps[map_idx], on the device.
+    Returns the filter's status (wait=False: asynchronous after the upload, returns None)."""
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    n_az, n_bins, stride = (int(v) for v in raw.shape)
+    ioff = (3 if stride == 4 else 4) if intensity_index is None else intensity_index
+    st = C.c_int(0)
+    ctx._check(ctx._lib.randt_filter_build(ctx._h, _dptr(raw), n_az, n_bins, stride, ioff, C.byref(fp), C.byref(clu), int(max_points), maps._h, int(map_idx),
+                                           C.byref(st) if wait else None), "randt_filter_build")
+    return st.value if wait else None
+
+
 # ------------------------------------------------------------------ CS divergence (f-2) -------------
 def cs_divergence_batch(ctx, fixed, fixed_first, fixed_count, fixed_idx, moving, moving_first, n_pairs, pose4, out, terms=None):
     """randt_cs_divergence_batch_dev (Map::calculateCSDivergence after transformMap)."""

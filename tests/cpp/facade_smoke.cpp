@@ -232,6 +232,50 @@ int main() {
     std::printf("map values: shared %d detached %d kept %d grew %d\n", shared, detached, kept, grew);
     edit_ok = edit_ok && shared && detached && kept && grew;
   }
+  // RadarPreprocessor: filterScan / processScan on a raw polar scan in host memory (a small one: 12 azimuths x 80 bins)
+  bool pre_ok = true;
+  {
+    const int n_az = 12, n_bins = 80;
+    std::vector<float> raw(static_cast<size_t>(n_az) * n_bins * 4, 0.f);
+    for (int a = 0; a < n_az; ++a) {
+      const double az = -M_PI + (a + 0.5) * (2 * M_PI / n_az);
+      for (int b = 0; b < n_bins; ++b) {
+        const double r = (b + 0.5) * 0.16;
+        float* p = &raw[(static_cast<size_t>(a) * n_bins + b) * 4];
+        p[0] = static_cast<float>(r * std::cos(az));
+        p[1] = static_cast<float>(r * std::sin(az));
+        p[3] = 1.0f + 0.01f * ((a * 7 + b * 3) % 5);
+      }
+      const int c = 20 + 3 * a;  // a peak of five bins per azimuth
+      const float peak[5] = {30.f, 40.f, 50.f, 40.f, 30.f};
+      for (int k = 0; k < 5; ++k) raw[(static_cast<size_t>(a) * n_bins + c - 2 + k) * 4 + 3] = peak[k];
+    }
+    RadarPreprocessor pre;
+    RadarPreprocessorParameters clu;
+    pre.initialize(ctx, clu, RadarFilterParameters());
+    std::vector<float> cloud;
+    std::vector<std::pair<double, double>> polar;
+    std::vector<std::array<double, 3>> maxd;
+    const bool f_ok = pre.filterScan(raw.data(), n_az, n_bins, 4, 3, cloud, polar, maxd);
+    // the last azimuth is never flushed (radar_preprocessor.cpp:56-75): 11 detections, 5 kept points each
+    bool peak_in = false;
+    for (size_t i = 0; i < cloud.size() / 4 && i < 5; ++i) peak_in = peak_in || cloud[4 * i + 3] == 50.f;   // azimuth 0's run holds its peak
+    pre_ok = f_ok && maxd.size() == 11 && cloud.size() / 4 >= 11 && polar.size() == cloud.size() / 4 && maxd[0][2] == 50.0 && peak_in;
+    Map from_raw, from_pts;
+    from_raw.initialize(ctx, mp, 0.0, 0.0, 64);
+    from_pts.initialize(ctx, mp, 0.0, 0.0, 64);
+    const bool p_ok = pre.processScan(raw.data(), n_az, n_bins, 4, 3, from_raw);
+    RadarPreprocessorParameters rp;
+    from_pts.addScan(cloud.data(), static_cast<int>(cloud.size() / 4), 4, 3, rp);
+    const auto ca = from_raw.getCells(), cb = from_pts.getCells();
+    pre_ok = pre_ok && p_ok && ca.size() == cb.size();
+    for (size_t i = 0; i < ca.size() && pre_ok; ++i) pre_ok = ca[i].getIntensityMean() == cb[i].getIntensityMean() && ca[i].getIntensityCov() == cb[i].getIntensityCov();
+    raw[(3 * n_bins + 40) * 4 + 0] = raw[(9 * n_bins + 40) * 4 + 0];  // a foreign point inside azimuth 3: refused, outputs untouched
+    raw[(3 * n_bins + 40) * 4 + 1] = raw[(9 * n_bins + 40) * 4 + 1];
+    const size_t before = cloud.size();
+    pre_ok = pre_ok && !pre.filterScan(raw.data(), n_az, n_bins, 4, 3, cloud, polar, maxd) && cloud.size() == before;
+    std::printf("radar preprocessor: %zu detections, %zu kept points, %zu cells from the raw scan\n", maxd.size(), cloud.size() / 4, ca.size());
+  }
   // Cell mutators through the facade (ndt_cell.h:24-154) and the never-throw behaviour
   bool cell_ok = true;
   {
@@ -386,6 +430,6 @@ int main() {
     pg_ok = e1 < 0.1 * e0 && nodes.at(0).pos[0] == 0.0 && nodes.at(0).pos[1] == 0.0 &&
             std::fabs(nodes.at(n - 1).pose.d[2] - after[0]) < 1e-12;
   }
-  std::printf("checks: pair %d kept %d window %d sc %d gate %d pg %d edit %d cell %d batch %d\n", ok, kept, win_ok, sc_ok, gate_ok, pg_ok, edit_ok, cell_ok, batch_ok);
-  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok && edit_ok && cell_ok && batch_ok) ? 0 : 2;
+  std::printf("checks: pair %d kept %d window %d sc %d gate %d pg %d edit %d cell %d batch %d pre %d\n", ok, kept, win_ok, sc_ok, gate_ok, pg_ok, edit_ok, cell_ok, batch_ok, pre_ok);
+  return (ok && kept && win_ok && sc_ok && gate_ok && pg_ok && edit_ok && cell_ok && batch_ok && pre_ok) ? 0 : 2;
 }

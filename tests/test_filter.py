@@ -322,3 +322,47 @@ def test_hip_filter_run_shapes_stage_and_fallback(built):
     for s in range(n_scans):
         _, pts, _, _ = po.filter_scan(scans[s].reshape(-1, 4), ofp)
         assert np.array_equal(small[s].cpu().numpy().view(np.uint32), pts[:8].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_host_level_filter_entries_match_the_oracle_and_the_device_chain(built):
+    """randt_filter_scan / randt_filter_build: ONE raw polar scan in HOST memory (what RadarPreprocessor::processScan is handed,
+    radar_preprocessor.cpp:30-43).  filterScan's points / polar pairs / peaks equal the oracle's bit for bit; filter + build gives the
+    very cells the oracle builds from the oracle-filtered points; a too-small buffer and an unorganised cloud are reported."""
+    import torch
+
+    from util import IP, cells_equal, oracle_scan_map
+
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    world = synth.make_world()
+    raw = synth.make_polar_scan(world, synth.make_trajectory(3400, 2)[0], 77)          # (400, 3000, 4): config 5's shape
+    ofp = po.filter_params()
+    cnt, pts, pol, pk = po.filter_scan(raw.reshape(-1, 4), ofp)
+    assert cnt > 500
+    g_pts, g_pol, g_pk, n, status = host.filter_scan_host(ctx, raw, host.filter_params(), capacity=8192)
+    assert status == 0 and n == cnt and len(g_pk) == len(pk)
+    assert np.array_equal(g_pts.view(np.uint32), pts.view(np.uint32)) and np.array_equal(g_pol[:, 1], pol[:, 1])
+    assert np.array_equal(g_pk[:, 1:], pk[:, 1:]) and np.allclose(g_pk[:, 0], pk[:, 0], atol=1e-6)
+    # PCL layout from the host, no polar / peaks wanted
+    pcl = np.zeros(raw.shape[:2] + (8,), dtype=np.float32)
+    pcl[..., :3], pcl[..., 3], pcl[..., 4] = raw[..., :3], 1.0, raw[..., 3]
+    g2, none_pol, none_pk, n2, st2 = host.filter_scan_host(ctx, pcl, host.filter_params(), capacity=8192, intensity_index=4, want_polar=False, want_peaks=False)
+    assert st2 == 0 and n2 == cnt and none_pol is None and none_pk is None and np.array_equal(g2.view(np.uint32), pts.view(np.uint32))
+    # too small a buffer: status 2, the first `capacity` points
+    g3, _, _, n3, st3 = host.filter_scan_host(ctx, raw, host.filter_params(), capacity=100)
+    assert st3 == 2 and n3 == 100 and np.array_equal(g3.view(np.uint32), pts[:100].view(np.uint32))
+    # filter -> clustering -> NDT on the device = the oracle's build of the oracle-filtered points
+    maps = R.Maps(ctx, 2, R.indoor_map_params(), 1024, with_grid=True)
+    assert host.filter_build(ctx, raw, host.filter_params(), R.indoor_cluster_params(), maps, 1) == 0
+    om = oracle_scan_map(pts, cap=1024)
+    cells, grid = maps.download(1)
+    assert len(cells) > 50 and cells_equal(cells, om.cells()) and np.array_equal(grid, om.grid())
+    s0 = ctx.pool_stats()
+    assert host.filter_build(ctx, raw, host.filter_params(), R.indoor_cluster_params(), maps, 0, wait=False) is None   # asynchronous after the upload
+    s1 = ctx.pool_stats()
+    assert s1["stream_syncs"] == s0["stream_syncs"] + 1 and s1["device_allocs"] == s0["device_allocs"]            # (the upload; the block came from the pool)
+    assert cells_equal(maps.download(0)[0], om.cells())
+    bad = raw.copy()
+    bad[5, 100, :2] = bad[200, 100, :2]
+    assert host.filter_build(ctx, bad, host.filter_params(), R.indoor_cluster_params(), maps, 0) == 1
+    assert host.filter_scan_host(ctx, bad, host.filter_params())[4] == 1
