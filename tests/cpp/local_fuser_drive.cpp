@@ -14,6 +14,9 @@
 //               radar_preprocessor.cpp:151-169), then HierarchicalMap::addClusters (ndt_hierarchical_map.cpp:28-33) on the cluster
 //               list -- instead of the whole scan in one call (Map::addScan); --cluster-loop: the same with one
 //               Map::insertCluster call per cluster
+//   --polar A B every "scan" of scans.bin is a RAW POLAR scan of A azimuths x B bins (n_points = A * B, BASELINE config 5):
+//               RadarPreprocessor::processScan -- filterScan (radar_preprocessor.cpp:45-125) + clustering + NDT -- runs on the device
+//               from the host buffer (RadarPreprocessor facade, randt_filter_build)
 //   --slam F    the whole SLAM loop (row f-4), like randt-slam_amd/slam.py: graph nodes / odometry edges (local_fuser.cpp:192-222,
 //               247-279), SCManager keys per node, LocalFuser::detectLoopClosures after every scan (:318-350: Scan Context
 //               candidate -> Matcher::estimateLoopConstraint against the candidate's finished submap -> Map::transformMap +
@@ -147,10 +150,17 @@ class LocalFuser {
   }
 
   // local_fuser.cpp:99-300, data path only.  points: n_points records of `stride` floats, intensity at `intensity_index`
+  void setPolar(int n_azimuths, int n_bins) {
+    polar_az_ = n_azimuths;
+    polar_bins_ = n_bins;
+    _preprocessor.initialize(ctx_, preprocessor_parameters_, RadarFilterParameters());
+  }
   void processScan(const float* points, int n_points, int stride, int intensity_index, int cluster_by_cluster, double stamp) {
     HierarchicalMap current_scan;  // :103-105
     current_scan.initialize(ctx_, map_parameters_, 0.0, 0.0, 512);
-    if (cluster_by_cluster) {
+    if (polar_az_ > 0) {
+      _preprocessor.processScan(points, polar_az_, polar_bins_, stride, intensity_index, current_scan.getMap());  // :102 filterScan + clustering + NDT
+    } else if (cluster_by_cluster) {
       // RadarPreprocessor::processScan's clustering on the host, like the reference: Grid::cluster (grid.cpp:7-14) ...
       const int row_size = static_cast<int>(std::sqrt(static_cast<double>(preprocessor_parameters_.n_clusters)));
       const float resolution = static_cast<float>(preprocessor_parameters_.max_range) * 2 / (row_size);
@@ -297,6 +307,8 @@ class LocalFuser {
   RadarPreprocessorParameters preprocessor_parameters_;
   NDTMatcherParameters matcher_parameters_;
   Matcher ndt_matcher_;
+  RadarPreprocessor _preprocessor;
+  int polar_az_ = 0, polar_bins_ = 0;
   Map _current_submap, _last_submap_transformed, _last_scan_kept, _last_merged_map;
   std::deque<Map> _map_window, _next_maps_to_insert;
   std::vector<float> clustered_;
@@ -326,6 +338,7 @@ int main(int argc, char** argv) {
   int size_poses = 135, overlap = 20, n_pos = 0, warm = -1;
   bool xyzi8 = false;
   std::string slam_file;
+  int polar_az = 0, polar_bins = 0;
   int clusters = 0;  // 1: HierarchicalMap::addClusters (the list in one call), 2: one Map::insertCluster call per cluster
   for (int a = 3; a < argc; ++a) {
     const std::string arg = argv[a];
@@ -334,6 +347,7 @@ int main(int argc, char** argv) {
     else if (arg == "--cluster-loop") clusters = 2;
     else if (arg == "--timing" && a + 1 < argc) warm = std::atoi(argv[++a]);
     else if (arg == "--slam" && a + 1 < argc) slam_file = argv[++a];
+    else if (arg == "--polar" && a + 2 < argc) { polar_az = std::atoi(argv[++a]); polar_bins = std::atoi(argv[++a]); }
     else if (n_pos == 0) { size_poses = std::atoi(argv[a]); ++n_pos; }
     else if (n_pos == 1) { overlap = std::atoi(argv[a]); ++n_pos; }
   }
@@ -359,6 +373,13 @@ int main(int argc, char** argv) {
   }
   LocalFuser fuser(ctx, size_poses, overlap);
   if (!slam_file.empty()) fuser.enableSlam();
+  if (polar_az > 0) {
+    if (polar_az * polar_bins != n_points) {
+      std::fprintf(stderr, "--polar %d %d does not match %d points per scan\n", polar_az, polar_bins, n_points);
+      return 2;
+    }
+    fuser.setPolar(polar_az, polar_bins);
+  }
   std::FILE* out = std::fopen(argv[2], "w");
   if (!out) return 2;
   randt_pool_stats s0{}, s1{};

@@ -138,3 +138,35 @@ def test_cpp_whole_slam_loop_matches_the_python_harness(built, tmp_path):
     assert np.allclose([cs for _, _, cs, _ in loops], [cs for _, _, cs, _ in s.loop_log], rtol=1e-9, atol=1e-12)
     assert np.abs(nodes - s.node_positions()).max() <= 1e-8, np.abs(nodes - s.node_positions()).max()
     assert np.abs(cpp_poses - py_poses).max() <= 1e-8, np.abs(cpp_poses - py_poses).max()
+
+
+def test_cpp_drive_on_raw_polar_scans_matches_the_python_harness(built, tmp_path):
+    """BASELINE config 5 from C++: raw polar scans in host memory -> RadarPreprocessor::processScan (filterScan + clustering + NDT on
+    the device, facade over randt_filter_build) -> the fixed-lag loop; the same poses as the Python harness that filters
+    device-resident scans (randt-slam_amd/odometry.py with polar_filter), which tests/test_gpu_odometry.py holds to the oracle."""
+    import torch
+
+    from randt_slam_amd import host, synth
+
+    n_scans, n_az, n_bins, dt = 24, 400, 700, 0.25
+    world = synth.make_world()
+    traj = synth.make_trajectory(3300, n_scans, step=0.25)
+    raw = np.ascontiguousarray(np.stack([synth.make_polar_scan(world, traj[i], 61000 + i, n_az=n_az, n_bins=n_bins) for i in range(n_scans)]), dtype=np.float32)
+    path = tmp_path / "polar.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([n_scans, n_az * n_bins], dtype=np.int32).tobytes())
+        f.write(raw.tobytes())
+    exe = _build(tmp_path)
+    out = tmp_path / "poses.txt"
+    r = subprocess.run([exe, str(path), str(out), "12", "4", "--polar", str(n_az), str(n_bins)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    cpp = np.loadtxt(out)
+    ctx = R.Context(0, torch.cuda.current_stream().cuda_stream)
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+    odo = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, R.window_params(),
+                            dict(submap_size_poses=12, submap_overlap=4))
+    fp = host.filter_params()
+    py = np.array([odo.process_scan(raw[i], i * dt, polar_filter=fp).copy() for i in range(n_scans)])
+    assert odo.n_finished_submaps >= 1 and odo.n_registrations >= n_scans - 3
+    assert np.abs(cpp - py).max() <= 1e-9, np.abs(cpp - py).max()
+    assert np.hypot(*(py[-1, 2:] - py[0, 2:])) > 1.0           # the drive went somewhere
