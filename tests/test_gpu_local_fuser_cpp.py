@@ -170,3 +170,18 @@ def test_cpp_drive_on_raw_polar_scans_matches_the_python_harness(built, tmp_path
     assert odo.n_finished_submaps >= 1 and odo.n_registrations >= n_scans - 3
     assert np.abs(cpp - py).max() <= 1e-9, np.abs(cpp - py).max()
     assert np.hypot(*(py[-1, 2:] - py[0, 2:])) > 1.0           # the drive went somewhere
+    # ... and with the graph layer on top: the keyframes' Scan Context keys are made of the FILTERED cloud (filterScan's host outputs)
+    from randt_slam_amd import slam
+
+    graph = tmp_path / "graph.txt"
+    r = subprocess.run([exe, str(path), str(out), "12", "4", "--polar", str(n_az), str(n_bins), "--slam", str(graph)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    nodes = np.array([[float(v) for v in ln.split()[1:]] for ln in open(graph) if ln.startswith("node")])
+    s = slam.Slam(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params(), scan_slots=64, submap_slots=8), mp, R.window_params(),
+                  R.default_matcher_params(gnc_steps=2), params=dict(submap_size_poses=12, submap_overlap=4), sc_params=dict(max_radius=20.0, dist_thresh=0.5),
+                  loop_closure_weight=40.0)
+    for i in range(n_scans):
+        s.process_scan(raw[i], i * dt, polar_filter=fp)
+        s.detect_loop_closures()
+    assert len(nodes) == len(s.nodes) >= 4 and np.abs(nodes - s.node_positions()).max() <= 1e-9
+    assert np.abs(np.loadtxt(out) - py).max() <= 1e-9        # the odometry does not care how the scan's NDT was fed
