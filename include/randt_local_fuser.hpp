@@ -160,13 +160,17 @@ class LocalFuser {
   // local_fuser.cpp:99-300, data path only.  points: n_points records of `stride` floats, intensity at `intensity_index`
   // the same on a RAW polar scan (n_azimuths x n_bins points, azimuth after azimuth): RadarPreprocessor::processScan's filterScan
   // runs first (radar_preprocessor.cpp:45-125), on the device
-  void processPolarScan(const float* raw, int n_azimuths, int n_bins, int stride, int intensity_index, double stamp) {
+  void processPolarScan(const float* raw, int n_azimuths, int n_bins, int stride, int intensity_index, double stamp, double imu_yaw_increment = 0.0) {
     polar_az_ = n_azimuths;
     polar_bins_ = n_bins;
-    processScan(raw, n_azimuths * n_bins, stride, intensity_index, stamp, kAddScan);
+    processScan(raw, n_azimuths * n_bins, stride, intensity_index, stamp, kAddScan, imu_yaw_increment);
     polar_az_ = polar_bins_ = 0;
   }
-  void processScan(const float* points, int n_points, int stride, int intensity_index, double stamp, int cluster_by_cluster = kAddScan) {
+  // imu_yaw_increment: the heading change since the last scan from the IMU (what the reference extracts from the two orientation
+  // quaternions, local_fuser.cpp:107-121; used when ndt_matcher_parameters.use_imu is set), 0 otherwise
+  void processScan(const float* points, int n_points, int stride, int intensity_index, double stamp, int cluster_by_cluster = kAddScan,
+                   double imu_yaw_increment = 0.0) {
+    yaw_ = imu_yaw_increment;
     HierarchicalMap current_scan;  // :103-105
     current_scan.initialize(ctx_, map_parameters_, 0.0, 0.0, parameters_.scan_cell_capacity);
     if (polar_az_ > 0 && slam_) {
@@ -230,7 +234,7 @@ class LocalFuser {
  private:
   void process(const Map& scan_ndt, double stamp) {
     if (!_current_submap.isEmpty()) {  // :123
-      ndt_matcher_.predictTransform(0.0, stamp, _trajectory);  // :125
+      ndt_matcher_.predictTransform(yaw_, stamp, _trajectory);  // :125
       // every copy the reference makes is made here (Maps by value, local_fuser.cpp:128-136)
       Map fmap = _current_submap;                              // :128  Map fmap = _current_submap.getMap();
       Map mmap = scan_ndt;                                     // :129  Map mmap = current_scan.getMap();
@@ -241,7 +245,7 @@ class LocalFuser {
         Map old_fmap = _last_submap_transformed;               // :134
         fixed_ndts.push_back(old_fmap);
       }
-      ndt_matcher_.estimateTransformCeres(current_transform_, _trajectory, 0.0, stamp, fixed_ndts, _map_window);  // :139
+      ndt_matcher_.estimateTransformCeres(current_transform_, _trajectory, yaw_, stamp, fixed_ndts, _map_window);  // :139
       const int n = static_cast<int>(_trajectory.size());
       if (static_cast<int>(_map_window.size()) >= matcher_parameters_.smoothing_steps) _map_window.pop_front();  // :152-154
       if (n % insertion_step_ == 0) {                                                                             // :155-161
@@ -326,6 +330,7 @@ class LocalFuser {
   std::deque<int> _next_maps_to_search_loop;
   std::deque<std::vector<float>> _next_scans_to_insert;
   std::vector<LoopLog> loop_log_;
+  double yaw_ = 0.0;
   const float* cur_points_ = nullptr;
   int cur_n_ = 0, cur_stride_ = 4, cur_ioff_ = 3;
   NDTMapParameters map_parameters_;                    // indoor preset
