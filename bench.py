@@ -1345,7 +1345,7 @@ def polar_odometry(ctx, n_scans):
             j = json.loads(line[-1])
             cpp = {"scans": j["scans"], "ms_per_scan": j["ms_per_scan"], "scans_per_sec": j["scans_per_sec"], "raw_GBps_pcie_inclusive": raw_bytes / (j["ms_per_scan"] * 1e-3) / 1e9,
                    "stream_syncs_per_scan": j["stream_syncs_per_scan"], "device_allocs_per_scan": j["device_allocs_per_scan"],
-                   "note": "raw polar scans handed over as pageable host buffers, a FRESH 19.2 MB buffer per scan (the runtime pins its pages for every upload: ~1.5 ms; a "
+                   "note": "raw polar scans handed over as pageable host buffers, a FRESH 19.2 MB buffer per scan (the runtime pins its pages for every upload: 0.7 .. 1.5 ms; a "
                            "buffer that is reused uploads at 50 GB/s, tools/host_polar_probe.py): upload + filter + clustering + NDT + window registration per scan"}
     except Exception as e:  # noqa: BLE001
         cpp = {"error": "%s: %s" % (type(e).__name__, e)}
