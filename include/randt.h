@@ -193,12 +193,21 @@ void randt_matcher_params_default(randt_matcher_params* p);
  *   stream_syncs                  host waits on the context's stream (hipStreamSynchronize / a pinned segment's event)
  *   pool_hits                     allocations served from parked blocks
  *   pool_bytes / pool_blocks      what is parked right now
+ *   foreign_waits                 see below
  * randt_ctx_pool_trim really frees everything parked (synchronises); the pool never parks more than 1 GiB
- * (RANDT_POOL_MAX_BYTES). */
+ * (RANDT_POOL_MAX_BYTES).
+ * BATCHES SHARED BETWEEN CONTEXTS.  A batch may be handed to entry points of OTHER contexts (the fixed / moving side of their
+ * registrations, the source of a copy or a merge, the target of their builds): the batch remembers them, and
+ * randt_maps_destroy makes the owner's stream wait -- on the device, not on the host -- for everything those contexts have
+ * enqueued so far before the block is parked (foreign_waits counts these waits), so the block's next owner cannot overtake
+ * a reader on another stream.  What stays the caller's job: not to destroy a batch from one thread while another thread is
+ * inside a call that uses it, and not to enqueue NEW work on a destroyed batch.  Caller-provided storage (*_external) is
+ * never pooled; its lifetime is the caller's altogether. */
 typedef struct randt_pool_stats {
   int64_t device_allocs, device_frees, stream_syncs, pool_hits;
   int64_t pool_bytes, pool_blocks;
-  int64_t reserved[2];
+  int64_t foreign_waits; /* device-side waits of randt_maps_destroy for OTHER contexts' streams that used the batch (below) */
+  int64_t reserved[1];
 } randt_pool_stats;
 int randt_ctx_pool_stats(const randt_ctx* ctx, randt_pool_stats* out);
 int randt_ctx_pool_trim(randt_ctx* ctx);

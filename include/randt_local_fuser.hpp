@@ -56,6 +56,7 @@ struct LocalFuserParameters {
   int submap_size_poses = 135, submap_overlap = 20, insertion_step = 4;
   bool use_scan_context_as_loop_closure = false;      // the graph / loop-closure layer on top of the odometry
   int loop_closure_gnc_steps = 2;
+  bool use_intensity_in_loop_closure = true;          // ndt_slam.cpp:614-616: defaults to ndt_matcher.use_intensity_as_dimension
   double loop_closure_scale = 1.5, loop_closure_max_cs_divergence = 3.6, loop_closure_weight = 4.0e4;
   std::array<double, 3> odometry_sqrt_information{10.0, 10.0, 50.0};   // local_fuser.cpp:203-205, :264-266 (diagonal)
   int scan_cell_capacity = 512;                        // cells a scan's NDT can hold (a 2000-point scan has <= 333)
@@ -78,6 +79,8 @@ class LocalFuser {
     submap_overlap_ = parameters.submap_overlap;
     insertion_step_ = parameters.insertion_step;
     ndt_matcher_.initialize(matcher_parameters_);
+    last_imu_bias_ = matcher_parameters_.initial_imu_bias;                                        // :36
+    n_finished_submaps_ = 0;                                                                      // :37
     _preprocessor.initialize(ctx_, preprocessor_parameters_, parameters.filter_parameters);
     _current_submap.initialize(ctx_, map_parameters_, 0.0, 0.0);
     if (parameters.use_scan_context_as_loop_closure) {
@@ -110,7 +113,8 @@ class LocalFuser {
       SE2d trans = se2_mul(se2_mul(se2_inv(root), nodes_.at(lid).pose), SE2d(-static_cast<double>(det.second), 0.0, 0.0));   // :333
       Map f_loop_map = submaps_.at(sub_i);   // :329  (copies: values)
       Map m_loop_map = scans_.at(q);         // :332
-      ndt_matcher_.estimateLoopConstraint(trans, f_loop_map, m_loop_map, parameters_.loop_closure_gnc_steps, true, parameters_.loop_closure_scale);   // :335
+      ndt_matcher_.estimateLoopConstraint(trans, f_loop_map, m_loop_map, parameters_.loop_closure_gnc_steps, parameters_.use_intensity_in_loop_closure,
+                                          parameters_.loop_closure_scale);   // :335
       m_loop_map.transformMap(trans);                                                     // :338
       const double cs = f_loop_map.calculateCSDivergence(m_loop_map);                     // :339
       const bool ok = cs < parameters_.loop_closure_max_cs_divergence;                    // :340 (parameters_indoor.yaml:8)
@@ -149,6 +153,7 @@ class LocalFuser {
     _last_submap_transformed.transformMap(old_submap_to_new_submap);                               // :46 (index grid left stale, like there)
     _next_maps_to_insert.clear();
     _next_scans_to_insert.clear();
+    ndt_matcher_.resetMatcher();                                                                   // :51 imu_constraints_ of the old submap must not feed the new one's IMU factors
     _map_window.clear();
     current_transform_ = SE2d();
     current_global_transform_ = initial_transform;
@@ -274,7 +279,9 @@ class LocalFuser {
       st.pose = current_transform_;
       st.pos = {current_transform_.d[2], current_transform_.d[3]};
       st.rot = current_transform_.angle();
-      if (n_finished_submaps_ > 0) {
+      if (n_finished_submaps_ == 0) {          // :231-236 (velocities and acceleration zero: State's defaults)
+        st.imu_bias = last_imu_bias_;          // = ndt_matcher_parameters.initial_imu_bias (:36)
+      } else {                                 // :237-242
         st.lin_vel = _last_state.lin_vel;
         st.rot_vel = _last_state.rot_vel;
         st.lin_acc = _last_state.lin_acc;
@@ -346,6 +353,7 @@ class LocalFuser {
   State _last_state;
   SE2d current_transform_, current_global_transform_;
   int submap_size_poses_ = 135, submap_overlap_ = 20, insertion_step_ = 4, n_finished_submaps_ = 0;
+  double last_imu_bias_ = 0.0;
 };
 
 }  // namespace randt

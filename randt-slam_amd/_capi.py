@@ -36,7 +36,7 @@ class MapParams(C.Structure):
 
 class PoolStats(C.Structure):
     _fields_ = [("device_allocs", C.c_int64), ("device_frees", C.c_int64), ("stream_syncs", C.c_int64), ("pool_hits", C.c_int64),
-                ("pool_bytes", C.c_int64), ("pool_blocks", C.c_int64), ("reserved", C.c_int64 * 2)]
+                ("pool_bytes", C.c_int64), ("pool_blocks", C.c_int64), ("foreign_waits", C.c_int64), ("reserved", C.c_int64 * 1)]
 
 
 class ClusterParams(C.Structure):

@@ -63,6 +63,53 @@ bool randt_device_shared(randt_ctx* ctx) {
   return false;
 }
 
+// ---------------------------------------------------------------- batches used by other contexts' streams ----------
+void randt_note_foreign_user(randt_ctx* user, const randt_maps* m) {
+  for (auto& slot : m->foreign) {
+    randt_ctx* cur = slot.load(std::memory_order_relaxed);
+    if (cur == user) return;
+    if (!cur) {
+      if (slot.compare_exchange_strong(cur, user, std::memory_order_relaxed) || cur == user) return;
+    }
+  }
+  m->foreign_overflow.store(true, std::memory_order_relaxed);
+}
+
+// Before a library-owned batch gives its block back: the owner's stream waits (device side) for a marker recorded NOW on the
+// stream of every other live context that has used the batch -- whatever they enqueued on it so far is ahead of the marker, and
+// the block's next user is enqueued on the owner's stream behind the wait.  A context that no longer exists has synchronised
+// its stream when it was destroyed.  Falls back to a host wait on that stream if an event cannot be had.
+static void wait_for_foreign_users(randt_maps* m) {
+  bool any = m->foreign_overflow.load(std::memory_order_relaxed);
+  for (auto& slot : m->foreign) any = any || slot.load(std::memory_order_relaxed) != nullptr;
+  if (!any) return;
+  const bool all = m->foreign_overflow.load(std::memory_order_relaxed);
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  for (randt_ctx* o : g_ctxs) {
+    if (o == m->ctx) continue;
+    bool used = all;
+    for (auto& slot : m->foreign) used = used || slot.load(std::memory_order_relaxed) == o;
+    if (!used) continue;
+    bool ordered = false;
+    {
+      DeviceGuard on_user(o);
+      if (!o->marker_ev && hipEventCreateWithFlags(&o->marker_ev, hipEventDisableTiming) != hipSuccess) {
+        o->marker_ev = nullptr;
+        (void)hipGetLastError();
+      }
+      if (o->marker_ev && hipEventRecord(o->marker_ev, o->stream) == hipSuccess) {
+        DeviceGuard on_owner(m->ctx);
+        ordered = hipStreamWaitEvent(m->ctx->stream, o->marker_ev, 0) == hipSuccess;
+      }
+      if (!ordered) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(o->stream);
+      }
+    }
+    ++m->ctx->stats.foreign_waits;
+  }
+}
+
 // ---------------------------------------------------------------- storage pool, counters, pinned ring ----------
 hipError_t randt_hip_malloc(randt_ctx* ctx, void** p, size_t bytes) {
   if (ctx) ++ctx->stats.device_allocs;
@@ -438,6 +485,7 @@ int randt_ctx_destroy(randt_ctx* ctx) {
   if (ctx->build_wide_ws) (void)hipFree(ctx->build_wide_ws);
   if (ctx->small) (void)hipFree(ctx->small);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->marker_ev) (void)hipEventDestroy(ctx->marker_ev);
   if (ctx->misrank_word) (void)hipHostFree(ctx->misrank_word);
   if (ctx->d_misrank_count) (void)hipFree(ctx->d_misrank_count);
   delete ctx;
@@ -575,8 +623,12 @@ int randt_maps_create(randt_ctx* ctx, int n_maps, const randt_map_params* p, int
 int randt_maps_destroy(randt_maps* m) {
   DeviceGuard dev_guard__(m ? m->ctx : nullptr);
   if (!m) return RANDT_OK;
-  // no synchronisation: the block's next owner is served by the same stream (randt_internal.h, storage pool)
-  if (m->owns) randt_dev_release(m->ctx, m->block, m->block_bytes);
+  // no synchronisation: the block's next owner is served by the same stream (randt_internal.h, storage pool), behind a
+  // device-side wait for the other contexts that have used the batch
+  if (m->owns) {
+    wait_for_foreign_users(m);
+    randt_dev_release(m->ctx, m->block, m->block_bytes);
+  }
   delete m;
   return RANDT_OK;
 }
@@ -641,11 +693,8 @@ int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cel
   if (m->deferred_pending)
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(deferred, m->v.counts + m->v.n_maps, sizeof(deferred), hipMemcpyDeviceToHost, ctx->stream));
   RANDT_HIP_CHECK(ctx, randt_sync(ctx));
-  if (m->deferred_pending) {
-    m->deferred_pending = false;
-    const int drc = deferred_status(m, deferred);
-    if (drc) return drc;
-  }
+  // the outputs first: randt.h promises the deferred status of earlier asynchronous inserts "with the outputs valid" (what
+  // WAS placed is in the batch and is what the caller gets); the status is reported once, behind the completed download
   if (n_cells) *n_cells = n;
   int c = n < max_cells ? n : max_cells;
   if (h_cells && c > 0)
@@ -655,6 +704,10 @@ int randt_maps_download(randt_maps* m, int idx, randt_cell* h_cells, int max_cel
     RANDT_HIP_CHECK(ctx, hipMemcpyAsync(h_grid, m->v.grid + (size_t)idx * m->v.n_slots, sizeof(int32_t) * m->v.n_slots,
                                         hipMemcpyDeviceToHost, ctx->stream));
   RANDT_HIP_CHECK(ctx, randt_sync(ctx));
+  if (m->deferred_pending) {
+    m->deferred_pending = false;
+    return deferred_status(m, deferred);
+  }
   return RANDT_OK;
 }
 
@@ -714,6 +767,23 @@ int randt_maps_copy(randt_maps* dst, int dst_first, const randt_maps* src, int s
       dst->p.center_x != src->p.center_x || dst->p.center_y != src->p.center_y)
     return randt_set_error(ctx, RANDT_ERR_INVALID, "randt_maps_copy: the two batches differ in map geometry (size, resolution or centre)", hipSuccess);
   if (count == 0) return RANDT_OK;
+  randt_note_user(ctx, src);
+  if (src->ctx->device != ctx->device) {
+    // k_maps_copy dereferences both batches from dst's device: across GPUs that needs peer access, which nobody has promised
+    // here -- the runtime's peer copy does not.  Whole capacity per map, like the kernel.
+    for (int i = 0; i < count; ++i) {
+      RANDT_HIP_CHECK(ctx, hipMemcpyPeerAsync(dst->v.cells + (size_t)(dst_first + i) * dst->v.cap, ctx->device,
+                                              src->v.cells + (size_t)(src_first + i) * src->v.cap, src->ctx->device,
+                                              sizeof(randt_cell) * (size_t)src->v.cap, ctx->stream));
+      if (dst->v.grid && src->v.grid)
+        RANDT_HIP_CHECK(ctx, hipMemcpyPeerAsync(dst->v.grid + (size_t)(dst_first + i) * dst->v.n_slots, ctx->device,
+                                                src->v.grid + (size_t)(src_first + i) * src->v.n_slots, src->ctx->device,
+                                                sizeof(int32_t) * (size_t)src->v.n_slots, ctx->stream));
+    }
+    RANDT_HIP_CHECK(ctx, hipMemcpyPeerAsync(dst->v.counts + dst_first, ctx->device, src->v.counts + src_first, src->ctx->device,
+                                            sizeof(int32_t) * (size_t)count, ctx->stream));
+    return RANDT_OK;
+  }
   return launch_maps_copy(ctx, dst->v, dst_first, src->v, src_first, count);
 }
 
@@ -743,6 +813,7 @@ int randt_ndt_build_batch_dev(randt_ctx* ctx, const float* d_points, int n_scans
   if (n_scans == 0) return RANDT_OK;
   if (!d_points && pitch_points > 0) return RANDT_ERR_INVALID;
   if (pitch_points == 0) return randt_maps_clear(out, first_map, n_scans);
+  randt_note_user(ctx, out);
   return launch_ndt_build(ctx, d_points, n_scans, pitch_points, d_n_points, stride_floats, intensity_index, cp, out->v, first_map);
 }
 
@@ -759,6 +830,7 @@ int randt_ndt_build_pndt_batch_dev(randt_ctx* ctx, const float* d_points, int n_
   if (n_scans == 0) return RANDT_OK;
   if ((!d_points || !d_polar) && pitch_points > 0) return RANDT_ERR_INVALID;
   if (pitch_points == 0) return randt_maps_clear(out, first_map, n_scans);
+  randt_note_user(ctx, out);
   return launch_ndt_build(ctx, d_points, n_scans, pitch_points, d_n_points, stride_floats, intensity_index, cp, out->v, first_map,
                           d_polar, beam_cov9);
 }
@@ -937,6 +1009,7 @@ int randt_closest_cells(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
   if (!ctx || !range_ok(fixed, fixed_idx, 1) || n_queries < 0 || k <= 0) return RANDT_ERR_INVALID;
   if (n_queries == 0) return RANDT_OK;
   if (!h_queries || !h_out) return RANDT_ERR_INVALID;
+  randt_note_user(ctx, fixed);
   randt_maps* tmp = nullptr;
   int rc = maps_alloc(ctx, 1, &fixed->p, n_queries, 0, &tmp);  // pooled, fully overwritten by the upload
   if (rc) return rc;
@@ -1103,6 +1176,9 @@ int randt_maps_merge(randt_maps* fixed, int fixed_idx, const randt_maps* moving,
     return RANDT_ERR_INVALID;
   if (n_moving == 0) return RANDT_OK;
   randt_ctx* ctx = fixed->ctx;
+  if (moving->ctx->device != ctx->device)
+    return randt_set_error(ctx, RANDT_ERR_INVALID, "randt_maps_merge: the two batches live on different devices (copy the moving maps over first)", hipSuccess);
+  randt_note_user(ctx, moving);
   const double* d_pose4 = nullptr;
   bool must_sync = false;
   int rc = stage_poses(ctx, h_pose4, n_moving, &d_pose4, &must_sync);
@@ -1120,6 +1196,9 @@ int randt_maps_merge_batch(randt_maps* fixed, int fixed_first, int n_fixed, cons
     return RANDT_ERR_INVALID;
   if (n_fixed == 0 || n_moving_each == 0) return RANDT_OK;
   randt_ctx* ctx = fixed->ctx;
+  if (moving->ctx->device != ctx->device)
+    return randt_set_error(ctx, RANDT_ERR_INVALID, "randt_maps_merge_batch: the two batches live on different devices", hipSuccess);
+  randt_note_user(ctx, moving);
   const double* d_pose4 = nullptr;
   bool must_sync = false;
   int rc = stage_poses(ctx, h_pose4, n_fixed * n_moving_each, &d_pose4, &must_sync);
@@ -1177,6 +1256,8 @@ int randt_associate_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int
     return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "n_neighbours > 16 not supported by the association kernel (it keeps at most sixteen candidates per cell)", hipSuccess);
   if (n_pairs == 0) return RANDT_OK;
   if (!d_guess4 || !d_corr) return RANDT_ERR_INVALID;
+  randt_note_user(ctx, fixed);
+  randt_note_user(ctx, moving);
   return launch_associate(ctx, fixed->v, d_fixed_idx, moving->v, moving_first, n_pairs, d_guess4, mp->n_neighbours,
                           mp->lookup_mahalanobis, mp->use_intensity, d_corr);
 }
@@ -1189,6 +1270,8 @@ int randt_solve_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int32_t
   if (rc) return rc;
   if (n_pairs == 0) return RANDT_OK;
   if (!d_corr || !d_pose4 || !d_results) return RANDT_ERR_INVALID;
+  randt_note_user(ctx, fixed);
+  randt_note_user(ctx, moving);
   return launch_solve(ctx, fixed->v, d_fixed_idx, moving->v, moving_first, n_pairs, d_corr, mp, d_pose4, d_results);
 }
 
@@ -1200,6 +1283,8 @@ int randt_register_batch_dev(randt_ctx* ctx, const randt_maps* fixed, const int3
   if (rc) return rc;
   if (n_pairs == 0) return RANDT_OK;
   if (!d_pose4 || !d_results) return RANDT_ERR_INVALID;
+  randt_note_user(ctx, fixed);
+  randt_note_user(ctx, moving);
   size_t corr_bytes = sizeof(int32_t) * (size_t)n_pairs * moving->v.cap * mp->n_neighbours;
   rc = ensure_ws(ctx, corr_bytes);
   if (rc) return rc;
@@ -1263,6 +1348,8 @@ int randt_eval_cost_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int fixed
   if (n_poses == 0) return RANDT_OK;
   if (!d_corr || !d_poses4 || !d_cost || mp->n_neighbours <= 0 || !isfinite(mp->loss_alpha) || !(isfinite(scale) && scale > 0.0))
     return RANDT_ERR_INVALID;
+  randt_note_user(ctx, fixed);
+  randt_note_user(ctx, moving);
   return launch_eval_cost(ctx, fixed->v, fixed_idx, moving->v, moving_idx, d_corr, mp->n_neighbours, mp->use_intensity, scale,
                           mp->loss_alpha, d_poses4, n_poses, d_cost, d_n_res);
 }
@@ -1275,6 +1362,8 @@ int randt_cs_divergence_batch_dev(randt_ctx* ctx, const randt_maps* fixed, int f
     return RANDT_ERR_INVALID;
   if (n_pairs == 0) return RANDT_OK;
   if (!d_out) return RANDT_ERR_INVALID;
+  randt_note_user(ctx, fixed);
+  randt_note_user(ctx, moving);
   const int max_tiles = (fixed->v.cap + RANDT_CS_SELF_OUTER - 1) / RANDT_CS_SELF_OUTER;  // partial sums of the fixed maps' self terms (csdiv.hip)
   int rc = ensure_ws(ctx, sizeof(double) * (size_t)fixed_count * max_tiles + 256);
   if (rc) return rc;
@@ -1600,6 +1689,8 @@ int randt_search_global(randt_ctx* ctx, const randt_maps* fixed, int fixed_idx, 
       !isfinite(bp->csm_window_angular) || !isfinite(bp->csm_cost_threshold) || !(isfinite(scale) && scale > 0.0) || !isfinite(mp->loss_alpha) ||
       bp->csm_linear_step >= 2.0 * bp->csm_max_px_accurate_range /* acos argument < -1: angular step NaN */)
     return randt_set_error(ctx, RANDT_ERR_INVALID, "correlative search: steps / ranges must be finite and positive, csm_n_iter in 1..16", hipSuccess);
+  randt_note_user(ctx, fixed);
+  randt_note_user(ctx, moving);
   swl = fmin(swl, bp->csm_window_linear);   // ndt_matcher.cpp:505-506
   swa = fmin(swa, bp->csm_window_angular);
   const int k = 4;                          // addNDTFactor(..., 4), :520
@@ -1863,6 +1954,8 @@ static int register_windows(randt_ctx* ctx, int n_windows, const randt_maps* fix
     for (int j = 0; j < S; ++j)
       if (!range_ok(moving, h_moving_idx[(size_t)w * S + j], 1)) return RANDT_ERR_INVALID;
   }
+  randt_note_user(ctx, fixed);
+  randt_note_user(ctx, moving);
   const int k = mp->n_neighbours;
   const int T = S * n_fixed;  // NDT terms per window
   const size_t NT = (size_t)n_windows * T;

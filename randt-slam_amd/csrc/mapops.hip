@@ -201,11 +201,12 @@ int launch_maps_merge(randt_ctx* ctx, const MapView& fixed, int fixed_idx, const
   if (n_moving <= 0 || n_pairs <= 0) return RANDT_OK;
   size_t lds = (size_t)moving.cap * 4 + 64;
   if (lds > (size_t)ctx->lds_limit) return randt_set_error(ctx, RANDT_ERR_UNSUPPORTED, "moving map capacity too large for merge kernel", hipSuccess);
-  static size_t lds_granted = 0;  // the attribute is per process and device code object; raised, never lowered
-  if (lds > lds_granted) {
+  // the attribute belongs to the kernel's code object on ONE device: remembered per context (a context is one device and one
+  // caller), raised, never lowered -- not in a process-wide static that a second GPU or thread would trust
+  if (lds > ctx->merge_lds_granted) {
     RANDT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_maps_merge),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_granted = lds;
+    ctx->merge_lds_granted = lds;
   }
   hipLaunchKernelGGL(k_maps_merge, dim3(n_pairs), dim3(256), lds, ctx->stream, fixed, fixed_idx, moving, moving_first,
                      n_moving, d_pose4);

@@ -75,8 +75,10 @@ struct randt_ctx {
   // ---- device storage pool (api.hip, randt_dev_alloc / randt_dev_release): the blocks of destroyed map batches and of the
   // host-level entries' temporaries are kept and handed out again.  A block goes back the moment its owner is destroyed,
   // WITHOUT a synchronisation: everything a context does is enqueued on its one stream, so whatever is enqueued on the
-  // block's next owner runs after the previous owner's last kernel.  (A map batch that another context's stream still reads
-  // must not be destroyed -- which was already the rule when destroy only synchronised its own stream.)
+  // block's next owner runs after the previous owner's last kernel.  A batch that OTHER contexts have been handed (as the
+  // fixed / moving side of a registration, the source of a copy or merge, ...) remembers them (randt_maps::foreign), and its
+  // destruction makes the owner's stream wait -- on the device, no host wait -- for a marker event recorded on each of their
+  // streams before the block is parked: the block's next owner also runs behind every foreign reader.
   std::multimap<size_t, void*> pool_free;  // block size -> block
   size_t pool_bytes = 0;                   // bytes parked in pool_free
   size_t pool_cap = (size_t)1 << 30;       // park at most this much (RANDT_POOL_MAX_BYTES); beyond it blocks are really freed
@@ -92,6 +94,9 @@ struct randt_ctx {
   hipEvent_t pin_ev[kPinSegs] = {nullptr, nullptr, nullptr, nullptr};
   bool pin_pending[kPinSegs] = {false, false, false, false};
   randt_maps* tmp_cluster = nullptr;  // one-cell scratch map of randt_maps_insert_cluster (created once per context)
+  size_t merge_lds_granted = 0;       // dynamic LDS k_maps_merge has been granted on this context's device (mapops.hip)
+  hipEvent_t marker_ev = nullptr;     // "everything this context has enqueued so far", recorded when a batch ANOTHER context owns
+                                      // and this one has used is destroyed (randt_maps_destroy waits for it on the owner's stream)
 };
 
 // RANDT_SOLVE_AUTO's question "does this batch have the device to itself?" (api.hip).  Every launcher of the hot path notes its
@@ -125,7 +130,18 @@ struct randt_maps {
   void* block = nullptr;    // owns: ONE pooled block [cells | counts | 2 deferred-status words | grid]
   size_t block_bytes = 0;
   bool deferred_pending = false;  // an asynchronous insert has run since the last synchronising read (api.hip, deferred_status)
+  // contexts other than `ctx` that were handed this (library-owned) batch through an entry point: their streams may still read
+  // or write it when the owner destroys it (randt_note_user / wait_for_foreign_users in api.hip).  Lock-free: several contexts
+  // may use one read-only batch from several threads.
+  static constexpr int kForeignSlots = 32;
+  mutable std::atomic<randt_ctx*> foreign[kForeignSlots] = {};
+  mutable std::atomic<bool> foreign_overflow{false};  // more users than slots: every live context counts as one
 };
+void randt_note_foreign_user(randt_ctx* user, const randt_maps* m);
+// called by every entry point that enqueues work of `user`'s stream on batch `m`
+inline void randt_note_user(randt_ctx* user, const randt_maps* m) {
+  if (m && user && m->ctx != user && m->owns) randt_note_foreign_user(user, m);
+}
 
 // Parameters of the solve kernel (POD copy of randt_matcher_params + derived values).
 struct SolveParams {

@@ -196,6 +196,15 @@ class Maps:
                         "randt_maps_download")
         return cells[: min(n.value, self.capacity)].copy(), grid
 
+    def download_with_status(self, idx):
+        """randt_maps_download without raising: (status, cells, grid).  The status of EARLIER asynchronous inserts is reported
+        here once, with the outputs valid (include/randt.h, "deferred status")."""
+        cells = np.zeros(self.capacity, dtype=CELL_DTYPE)
+        grid = np.empty(self.n_slots, dtype=np.int32) if self.with_grid else None
+        n = C.c_int(-1)
+        rc = self._lib.randt_maps_download(self._h, idx, _dptr(cells), self.capacity, C.byref(n), _dptr(grid))
+        return int(rc), cells[: max(0, min(n.value, self.capacity))].copy(), grid
+
     def counts(self, first=0, count=None):
         count = self.n_maps - first if count is None else count
         out = np.zeros(count, dtype=np.int32)

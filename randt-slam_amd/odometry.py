@@ -144,8 +144,8 @@ class HipBackend:
     def pose_graph_optimize(self, x, ia, ib, meas, sqi, max_update_index, params_kwargs):
         return host.pose_graph_optimize(self.ctx, x, ia, ib, meas, sqi, max_update_index, host.pg_params(**params_kwargs))
 
-    def register_window(self, fixed_idx, moving_idx, states, mp, wp, trans4):
-        st, t, rej, res = host.register_window(self.ctx, self.subs, fixed_idx, self.scans, moving_idx, states, mp, wp, trans4, None)
+    def register_window(self, fixed_idx, moving_idx, states, mp, wp, trans4, imu=None):
+        st, t, rej, res = host.register_window(self.ctx, self.subs, fixed_idx, self.scans, moving_idx, states, mp, wp, trans4, imu)
         return st, t, rej, res
 
 
@@ -180,6 +180,11 @@ class Odometry:
         self.last_result = None
         self.next_scans_to_insert = []                                # keyframe queue: the scans' points (Scan Context input)
         self._cur_points = None
+        # Matcher::imu_constraints_ (ndt_matcher.cpp:18-20,22-59,360): one heading increment per predicted state, dropped at a
+        # submap roll-over (local_fuser.cpp:51 resetMatcher); only read when window_params.use_imu is set
+        self.imu_constraints = []
+        self.initial_imu_bias = float(p.get("initial_imu_bias", 0.0))  # local_fuser.cpp:36,235
+        self._yaw = 0.0
 
     # LocalFuser::getTransform (local_fuser.h:113-127)
     def get_transform(self):
@@ -205,6 +210,7 @@ class Odometry:
         for h in self.next_maps_to_insert + self.map_window:
             self._unref(h)
         self.next_maps_to_insert, self.map_window, self.next_scans_to_insert = [], [], []
+        self.imu_constraints = []                                      # :51 matcher_.resetMatcher()
         self.current_transform = np.array([1.0, 0.0, 0.0, 0.0])
         self.current_global_transform = np.array(initial_transform, dtype=np.float64)
         if not self._on_submap_finished(self.current_submap):          # submaps_.insert(...) (:43) keeps it alive
@@ -241,6 +247,7 @@ class Odometry:
         b = self.b
         if b.submap_cells(self.current_submap) > 0:
             self.trajectory.append(b.predict(self.trajectory[-1], stamp, self.vector))    # :125 (predict / predictSE2 by optimize_on_manifold)
+            self.imu_constraints.append(self._yaw)                                        # ndt_matcher.cpp:58 (inside predictTransform)
             self.map_window.append(scan)                                                  # :130
             self._ref(scan)
             fixed = [self.current_submap]
@@ -248,7 +255,15 @@ class Odometry:
                 fixed.append(self.last_submap_transformed)
             S = min(len(self.trajectory) - 1, self.smoothing_steps)                       # ndt_matcher.cpp:343
             states = np.array(self.trajectory[-S - 1:], dtype=STATE_DTYPE)
-            states, trans, rej, res = b.register_window(fixed, self.map_window[-S:], states, self.mp, self.wp, self.current_transform)
+            imu = None
+            if int(getattr(self.wp, "use_imu", 0)) and len(self.imu_constraints) > S:
+                # imu_constraints_.end()[-i-1], i = S..1 -- sic, one step older than state i (ndt_matcher.cpp:360).  While the
+                # vector is shorter than S + 1 the reference reads in front of its buffer (undefined); the window then runs
+                # without IMU factors here and in the facade (DESIGN, spec decision 12)
+                imu = [self.imu_constraints[-i - 1] for i in range(S, 0, -1)]
+            states, trans, rej, res = (b.register_window(fixed, self.map_window[-S:], states, self.mp, self.wp, self.current_transform, imu)
+                                       if imu is not None else
+                                       b.register_window(fixed, self.map_window[-S:], states, self.mp, self.wp, self.current_transform))
             for j in range(S + 1):
                 self.trajectory[len(self.trajectory) - S - 1 + j] = states[j]
             self.current_transform = trans
@@ -274,7 +289,9 @@ class Odometry:
             st["pose"] = self.current_transform
             st["pos"] = self.current_transform[2:]
             st["rot"] = np.arctan2(self.current_transform[1], self.current_transform[0])
-            if self.n_finished_submaps > 0:
+            if self.n_finished_submaps == 0:
+                st["imu_bias"] = self.initial_imu_bias                                    # :231-236
+            else:
                 st["lin_vel"], st["rot_vel"] = self.last_state["lin_vel"], self.last_state["rot_vel"]
                 st["lin_acc"], st["imu_bias"] = self.last_state["lin_acc"], self.last_state["imu_bias"]
             st["stamp"] = stamp
@@ -282,11 +299,14 @@ class Odometry:
             self._on_first_scan(scan, self._cur_points)                                   # :247-279 root node of the submap
             b.merge(self.current_submap, scan, self.current_transform)                    # :281,293
 
-    def process_scan(self, points, stamp, polar_filter=None):
+    def process_scan(self, points, stamp, polar_filter=None, imu_yaw_increment=0.0):
         """NDTSlam::radarCb (ndt_slam.cpp:211-223): process, roll the submap over when complete.
-        polar_filter: FilterParams -> `points` is a raw polar scan and goes through filterScan first."""
+        polar_filter: FilterParams -> `points` is a raw polar scan and goes through filterScan first.
+        imu_yaw_increment: the heading change since the last scan from the IMU (local_fuser.cpp:107-121), used when
+        window_params.use_imu is set."""
         if self._refs is None:
             self._refs = {}
+        self._yaw = float(imu_yaw_increment)
         self._cur_points = points
         if polar_filter is not None:
             scan = self.b.build_scan_from_polar(points, polar_filter)                     # :102 filterScan + clustering

@@ -332,6 +332,21 @@ int main() {
     const bool tiny_one = tiny.get_n_cells() == 1 && last_status() == RANDT_ERR_UNSUPPORTED;   // the count is valid, the deferred status reported
     const bool tiny_again = tiny.get_n_cells() == 1 && last_status() == RANDT_OK;               // ... once
     cell_ok = cell_ok && keep2.d[2] == 4.0 && keep2.d[3] == 5.0 && tiny_one && tiny_again;
+    // ... and when the first read behind a dropped cluster is the cell DOWNLOAD: the warning is printed, the
+    // one cell that was placed is there -- not an empty vector cached for the map's current content
+    Map tiny_dl;
+    tiny_dl.initialize(ctx, mp, 0.0, 0.0, 1);
+    tiny_dl.insertCluster(a.data(), 24, 4, 3);
+    tiny_dl.insertCluster(b.data(), 12, 4, 3);
+    const auto dl_cells = tiny_dl.getCells();
+    const bool dl_reported = last_status() == RANDT_ERR_UNSUPPORTED;
+    Vector3f dl_mean;
+    Matrix3f dl_cov;
+    const bool dl_ok = dl_cells.size() == 1 && dl_reported && dl_cells[0].getMean() == c1.getMean() && tiny_dl.getPointsInCell(0) == 24 &&
+                       tiny_dl.getCellMeanAndCovariance(0, dl_mean, dl_cov) && dl_mean == c1.getIntensityMean() && tiny_dl.get_n_cells() == 1 &&
+                       last_status() == RANDT_OK;
+    if (!dl_ok) std::printf("download behind a deferred status: %zu cells, status reported %d\n", dl_cells.size(), (int)dl_reported);
+    cell_ok = cell_ok && dl_ok;
     // HierarchicalMap pass-through: cluster by cluster == what insertCluster builds
     HierarchicalMap hm;
     hm.initialize(ctx, mp, 0.0, 0.0, 16);

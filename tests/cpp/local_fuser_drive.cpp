@@ -24,6 +24,10 @@
 //               calculateCSDivergence gate -> loop edge), GlobalFuser::optimizePoseGraph every 40 scans (ndt_slam.cpp:351-361) and
 //               the current submap's origin following its root node (local_fuser.cpp:78-79).  Writes the graph to file F:
 //               "node x y rot" per node, "loop query candidate cs accepted" per checked candidate.
+//   --imu F [B] ndt_matcher.use_imu = true (the indoor preset): file F holds one heading increment per scan (what the reference takes
+//               from two IMU orientations, local_fuser.cpp:107-121), B = ndt_matcher.initial_imu_bias; the increments reach the IMU
+//               factors of the fixed-lag window through Matcher::predictTransform, and a submap roll-over drops them
+//               (Matcher::resetMatcher, local_fuser.cpp:51)
 //   --timing W  after W untimed scans: wall time per scan and the context's allocator / synchronisation counters per scan
 //               (randt_ctx_pool_stats) over the rest of the drive, as one JSON line on stdout (bench.py: cpp_local_fuser_drive)
 // tests/test_gpu_local_fuser_cpp.py runs it beside the Python harness (randt-slam_amd/odometry.py) on the same drive.
@@ -61,7 +65,8 @@ int main(int argc, char** argv) {
   in.read(reinterpret_cast<char*>(scans.data()), static_cast<std::streamsize>(scans.size() * sizeof(float)));
   int size_poses = 135, overlap = 20, n_pos = 0, warm = -1;
   bool xyzi8 = false;
-  std::string slam_file;
+  std::string slam_file, imu_file;
+  double imu_bias0 = 0.0;
   int polar_az = 0, polar_bins = 0;
   int clusters = 0;  // 1: HierarchicalMap::addClusters (the list in one call), 2: one Map::insertCluster call per cluster
   for (int a = 3; a < argc; ++a) {
@@ -71,6 +76,14 @@ int main(int argc, char** argv) {
     else if (arg == "--cluster-loop") clusters = 2;
     else if (arg == "--timing" && a + 1 < argc) warm = std::atoi(argv[++a]);
     else if (arg == "--slam" && a + 1 < argc) slam_file = argv[++a];
+    else if (arg == "--imu" && a + 1 < argc) {
+      imu_file = argv[++a];
+      if (a + 1 < argc && argv[a + 1][0] != '-' ) {
+        char* end = nullptr;
+        const double b = std::strtod(argv[a + 1], &end);
+        if (end && *end == 0 && std::strchr(argv[a + 1], '.')) { imu_bias0 = b; ++a; }  // (a bare integer is submap_size_poses)
+      }
+    }
     else if (arg == "--polar" && a + 2 < argc) { polar_az = std::atoi(argv[++a]); polar_bins = std::atoi(argv[++a]); }
     else if (n_pos == 0) { size_poses = std::atoi(argv[a]); ++n_pos; }
     else if (n_pos == 1) { overlap = std::atoi(argv[a]); ++n_pos; }
@@ -104,6 +117,17 @@ int main(int argc, char** argv) {
     lp.scan_context_parameters.SC_DIST_THRES = 0.5;
     lp.loop_closure_weight = 40.0;
   }
+  std::vector<double> imu_yaw(static_cast<size_t>(n_scans), 0.0);
+  if (!imu_file.empty()) {
+    std::ifstream f(imu_file);
+    for (int i = 0; i < n_scans; ++i)
+      if (!(f >> imu_yaw[static_cast<size_t>(i)])) {
+        std::fprintf(stderr, "%s holds fewer than %d heading increments\n", imu_file.c_str(), n_scans);
+        return 2;
+      }
+    lp.ndt_matcher_parameters.use_imu = true;
+    lp.ndt_matcher_parameters.initial_imu_bias = imu_bias0;
+  }
   LocalFuser fuser;
   fuser.initialize(ctx, lp);
   if (polar_az > 0) {
@@ -123,8 +147,8 @@ int main(int argc, char** argv) {
       t0 = std::chrono::steady_clock::now();
     }
     const float* scan = scans.data() + static_cast<size_t>(i) * n_points * stride;
-    if (polar_az > 0) fuser.processPolarScan(scan, polar_az, polar_bins, stride, ioff, 0.25 * i);
-    else fuser.processScan(scan, n_points, stride, ioff, 0.25 * i, clusters);
+    if (polar_az > 0) fuser.processPolarScan(scan, polar_az, polar_bins, stride, ioff, 0.25 * i, imu_yaw[static_cast<size_t>(i)]);
+    else fuser.processScan(scan, n_points, stride, ioff, 0.25 * i, clusters, imu_yaw[static_cast<size_t>(i)]);
     if (!slam_file.empty()) {
       fuser.detectLoopClosures();
       if (i % 40 == 39) fuser.optimizePoseGraph();

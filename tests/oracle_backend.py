@@ -116,11 +116,11 @@ class OracleBackend:
     def predict(self, state, stamp, vector=False):
         return po.predict_state(np.asarray(state).astype(po.STATE_DTYPE), stamp, vector=vector)
 
-    def register_window(self, fixed_h, moving_h, states, mp, wp, trans4):
+    def register_window(self, fixed_h, moving_h, states, mp, wp, trans4, imu=None):
         from test_gpu_window import to_oracle_wp
         from util import to_oracle_params
 
         rc, st, t, stats = po.register_window([self.subs[h] for h in fixed_h], [self.scans[h] for h in moving_h],
-                                              np.asarray(states).astype(po.STATE_DTYPE), to_oracle_params(mp), to_oracle_wp(wp), trans4)
+                                              np.asarray(states).astype(po.STATE_DTYPE), to_oracle_params(mp), to_oracle_wp(wp), trans4, imu)
         assert rc >= 0
         return st, t, rc == 1, stats

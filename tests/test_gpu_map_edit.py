@@ -235,3 +235,69 @@ def test_cluster_list_in_one_launch_equals_the_batched_build_and_the_loop(env):
         tiny2.counts()
     assert e.value.status == R._capi.ERR_UNSUPPORTED
     assert tiny2.counts()[0] == 10
+    # the same deferred report through the DOWNLOAD: the status comes back once, behind completed outputs -- the
+    # count, the cells that were placed and the index grid -- not instead of them
+    far2 = R.Maps(ctx, 1, R.indoor_map_params(), 512, with_grid=True)
+    far2.insert_clusters(0, far, offsets, wait=False)
+    rc, cells_f, grid_f = far2.download_with_status(0)
+    ref_f, ref_g = out.download(0)                                     # the synchronous insert of the same list, checked above
+    assert rc == R._capi.ERR_INVALID and len(cells_f) == len(a) - 1 and cells_equal(cells_f, ref_f) and np.array_equal(grid_f, ref_g)
+    rc, cells_f2, grid_f2 = far2.download_with_status(0)
+    assert rc == 0 and cells_equal(cells_f2, ref_f) and np.array_equal(grid_f2, ref_g)
+    tiny3 = R.Maps(ctx, 1, R.indoor_map_params(), 10, with_grid=True)
+    tiny3.insert_clusters(0, sorted_pts, offsets, wait=False)
+    rc, cells_t, _ = tiny3.download_with_status(0)
+    assert rc == R._capi.ERR_UNSUPPORTED and len(cells_t) == 10 and cells_equal(cells_t, a[:10])
+
+
+def test_destroying_a_batch_another_contexts_stream_still_reads(built):
+    """ADVICE r5 #3.  randt_maps_destroy parks the block without a host synchronisation, and the block's next owner is
+    served by the OWNER's stream -- so a reader on another context's stream used to race with it silently.  The batch now
+    remembers the contexts it was handed to, and its destruction makes the owner's stream wait (on the device) for a marker
+    on each of their streams: context B keeps six registration batches in flight against a batch context A owns, A destroys
+    it and immediately takes the same block for a new, cleared batch -- B's results are those of the undisturbed run, A made
+    no host wait, and `foreign_waits` counted the one device-side wait."""
+    import torch
+    from util import GpuRig
+
+    rig = GpuRig(problem(n_submaps=2, scans_per_submap=32, n_keyframes=12))
+    rig.build_submaps()
+    rig.build_scans()
+    a = rig.ctx
+    side = torch.cuda.Stream()
+    b = R.Context(0, side.cuda_stream)
+    mp = R.default_matcher_params()
+    g4 = synth.pose3_to_pose4(rig.prob["guess"])
+    n = rig.B
+
+    def run(fixed, reps):
+        poses = [torch.from_numpy(g4.copy()).to(rig.dev) for _ in range(reps)]
+        res = [torch.zeros((n, 64), dtype=torch.uint8, device=rig.dev) for _ in range(reps)]
+        torch.cuda.synchronize()
+        for r in range(reps):
+            R.register_batch(b, fixed, rig.fixed_idx, rig.scan_maps, 0, n, mp, poses[r], res[r])
+        return poses, res
+
+    ref, _ = run(rig.submaps, 1)
+    b.synchronize()
+    ref = ref[0].cpu().numpy()
+    assert np.abs(ref - g4).max() > 1e-3                      # the registrations do move their poses
+
+    shared = rig.submaps.clone()                              # owned by A
+    a.synchronize()
+    s0 = a.pool_stats()
+    poses, _ = run(shared, 6)                                 # B: ~1 ms of kernels in flight on its own stream
+    shared.close()                                            # A: parks the block ...
+    fresh = R.Maps(a, rig.n_sub, rig.mapp, rig.mapp.size_x * rig.mapp.size_y, with_grid=True)   # ... and clears it for its next owner
+    s1 = a.pool_stats()
+    assert s1["pool_hits"] == s0["pool_hits"] + 1             # the very block
+    assert s1["foreign_waits"] == s0["foreign_waits"] + 1 and s1["stream_syncs"] == s0["stream_syncs"]
+    b.synchronize()
+    a.synchronize()
+    for p in poses:
+        assert np.array_equal(p.cpu().numpy(), ref)
+    assert fresh.counts().sum() == 0
+    # a batch nobody else has used costs no wait
+    own = rig.submaps.clone()
+    own.close()
+    assert a.pool_stats()["foreign_waits"] == s1["foreign_waits"]
