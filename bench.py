@@ -326,9 +326,13 @@ def main():
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     n_dev = torch.cuda.device_count()
     backend = os.environ.get("RANDT_BENCH_BACKEND", "nccl")
-    if local_rank >= n_dev and backend != "gloo":
+    # RANDT_RANKS_SHARE_GPU=1 (set by randt_slam_amd.shard.shared_gpu_rank_env, tests only): every rank sits on GPU 0 and RCCL is
+    # told they are one-GPU nodes (NCCL_HOSTID), so the multi-rank RCCL path runs on a one-GPU box.  Never a scaling number:
+    # the line carries `ranks_share_one_gpu`.
+    share_gpu = os.environ.get("RANDT_RANKS_SHARE_GPU") == "1" and world > 1
+    if local_rank >= n_dev and backend != "gloo" and not share_gpu:
         raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, n_dev))
-    local_rank = local_rank % max(1, n_dev)   # only differs in the single-GPU gloo logic test
+    local_rank = local_rank % max(1, n_dev)   # only differs in the single-GPU gloo logic test and under RANDT_RANKS_SHARE_GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_group_path:
@@ -610,6 +614,8 @@ def main():
             out["group_transport"] = "randt_group over RCCL (C ABI)" if grp is not None else ("gloo control-flow test" if via_cpu else "torch.distributed FALLBACK")
             if group_error:
                 out["group_error"] = group_error
+            if share_gpu:
+                out["ranks_share_one_gpu"] = True   # a test of the RCCL path (socket transport between fake nodes), NOT a scaling figure
         if strong is not None:
             out["strong_scaling"] = strong
         # Everything below is a side measurement on rank 0: a failure there must never cost the headline line.

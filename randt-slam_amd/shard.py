@@ -8,8 +8,27 @@ by the library itself, or peer copies inside one process; host.Group binds it). 
 remain for launch-time plumbing (shipping the RCCL unique id) and for the gloo control-flow tests on boxes with fewer
 GPUs than ranks.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def shared_gpu_rank_env(rank, world, port, base=None):
+    """TEST / PROBE PLUMBING: the environment of rank `rank` of a `world`-rank job whose ranks ALL sit on GPU 0.
+
+    RCCL refuses two ranks on one device ("Duplicate GPU detected": equal host hash and bus id).  The host hash is taken from
+    NCCL_HOSTID when it is set, so ranks that set DIFFERENT ids look like one-GPU nodes of their own: RCCL connects them with
+    its built-in socket transport (loopback) instead of xGMI / shared memory.  The bytes take another road; everything else
+    is the real thing -- ncclGetUniqueId, ncclCommInitRank with world > 1, the bootstrap, ncclBroadcast / ncclAllGather
+    between ranks, stream ordering against the kernels.  This is how the multi-rank RCCL path of csrc/group.hip and of
+    bench.py --gpus N is exercised on the builder's one-GPU leases (tools/rccl_two_ranks_probe.py, tests/test_gpu_group.py,
+    tests/test_gpu_bench.py); never used for a reported scaling number (bench.py marks such a line `ranks_share_one_gpu`)."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               NCCL_HOSTID="randt-fake-node-%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket",
+               NCCL_DEBUG=env.get("NCCL_DEBUG", "WARN"), HSA_ENABLE_IPC_MODE_LEGACY="0", RANDT_RANKS_SHARE_GPU="1")
+    return env
 
 
 def shard_range(n_items, world_size, rank):

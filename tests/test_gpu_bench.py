@@ -105,6 +105,36 @@ def test_bench_group_path_on_one_rank():
     assert "expected_ceiling" in ss
 
 
+def test_bench_two_ranks_over_rccl_sharing_the_one_gpu():
+    """bench.py --gpus 2 AS THE DRIVER LAUNCHES IT on an 8-GPU node -- one process per rank, torch.distributed "nccl" (= RCCL) for the
+    launch plumbing, randt_group_create_rank + ncclBroadcast of the submap tables + the strong region's ncclAllGather per step --
+    with both ranks on the one GPU of this box (shard.shared_gpu_rank_env: an NCCL_HOSTID per rank, socket transport).  The
+    line must come from the RCCL group path (no fallback), the strong split must equal the unsharded batch bit for bit, and the
+    line says that its ranks shared a GPU."""
+    from randt_slam_amd import shard
+
+    port = 29540
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "2", "--repeats", "3", "--min-seconds", "0.05",
+           "--no-cpu-baseline", "--no-config2", "--no-roofline-sections", "--odometry-scans", "0", "--polar-scans", "0", "--slam-scans", "0",
+           "--polar-odometry-scans", "0", "--streams", "4"]
+    procs = [subprocess.Popen(cmd, cwd=ROOT, env=shard.shared_gpu_rank_env(r, 2, port), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate())
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[0][-1500:] + o[1][-1500:] for o in outs)
+    d = _last_json(outs[0][0])
+    assert d["n_gpus"] == 2 and d["ranks_share_one_gpu"] is True and d["scaling"] == "weak"
+    assert d["group_fallback"] is False and "RCCL" in d["group_transport"] and "group_error" not in d
+    ss = d["strong_scaling"]
+    assert ss["poses_bit_identical_to_unsharded"] is True and "ncclAllGather" in ss["entry"]
+    assert ss["pipelined"]["value"] > 1e4 and d["value"] > 1e5
+
+
 def test_bench_two_ranks_rccl():
     """The same over RCCL (backend "nccl") when the box has two GPUs (the driver's multi-GPU node; skipped on a 1-GPU box)."""
     import torch

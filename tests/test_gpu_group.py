@@ -154,3 +154,33 @@ def test_group_argument_checks(base):
     with pytest.raises(R.RandtError):
         grp.broadcast_maps([foreign, foreign])
     grp.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_several_ranks_sharing_the_one_gpu(built, world):
+    """RCCL with MORE THAN ONE RANK on a one-GPU box (round 6).  One process per rank, every rank on GPU 0, each with an
+    NCCL_HOSTID of its own (randt_slam_amd.shard.shared_gpu_rank_env) so that RCCL sees one-GPU nodes instead of a duplicate
+    device and connects them over its socket transport: ncclCommInitRank with world > 1, randt_group_broadcast_maps from
+    rank 0 (the other ranks start with EMPTY tables), randt_group_scan_register_batch_dev with the ncclAllGather of packed
+    rows -- every rank ends with the whole batch's poses and records, bit-identical to one context running it alone; without
+    the gather a rank holds exactly its shard (uneven at 4 and 8 ranks: 34 registrations).  tools/rccl_two_ranks_probe.py is
+    the per-rank program."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_two_ranks_probe.py"), str(world)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, RCCL_PROBE_TIMEOUT="300"))
+    text = r.stdout + r.stderr
+    ranks = [json.loads(ln[len("RCCL_PROBE "):]) for ln in r.stdout.splitlines() if ln.startswith("RCCL_PROBE ")]
+    assert r.returncode == 0 and len(ranks) == world, text[-3000:]
+    assert sorted(d["rank"] for d in ranks) == list(range(world))
+    covered = []
+    for d in ranks:
+        assert d["group"] == dict(world=world, n_local=1, first_rank=d["rank"], transport=_capi.TRANSPORT_RCCL), d
+        assert d["torch_all_reduce_ok"] and d["broadcast_tables_equal"], d
+        assert d["gathered_poses_bit_identical"] and d["gathered_records_bit_identical"] and d["ungathered_rows_ok"], d
+        covered += list(range(*d["shard"]))
+    assert sorted(covered) == list(range(34))
