@@ -116,6 +116,48 @@ def test_oracle_reproduces_odometry_golden():
         assert np.abs(p - z["poses4"][i]).max() < 1e-8, i
 
 
+def test_harness_imu_bookkeeping_on_the_oracle_backend():
+    """Matcher::imu_constraints_ in the processScan harness (round 6, ADVICE r5 #2), on the CPU oracle: one increment per
+    predicted state (ndt_matcher.cpp:58), IMU factors only once the vector is longer than the window (the reference reads in
+    front of it until then: DESIGN spec decision 12), dropped at a submap roll-over (local_fuser.cpp:51 resetMatcher), first
+    state of submap 0 = initial_imu_bias (:36,235), later submaps inherit the last state's bias (:241)."""
+    import randt_slam_amd as R
+    from randt_slam_amd import odometry
+    from oracle_backend import OracleBackend
+
+    mg, _ = _odometry_golden()
+    traj, scans = mg.drive_inputs()
+    small = dict(submap_size_poses=6, submap_overlap=3, initial_imu_bias=0.02)
+    heading = np.unwrap(np.asarray(traj)[:, 2])
+    yaw = np.concatenate([[0.0], np.diff(heading)]) + 0.005
+    mp = R.default_matcher_params(parameterization=R.PARAM_MANIFOLD, gnc_steps=3)
+
+    class Spy(OracleBackend):
+        calls = []
+
+        def register_window(self, fixed_h, moving_h, states, mp, wp, trans4, imu=None):
+            Spy.calls.append(None if imu is None else list(imu))
+            return super().register_window(fixed_h, moving_h, states, mp, wp, trans4, imu)
+
+    Spy.calls = []
+    odo = odometry.Odometry(Spy(), mp, R.window_params(use_imu=1), small)
+    odo.process_scan(scans[0], 0.0, imu_yaw_increment=yaw[0])
+    assert odo.trajectory[0]["imu_bias"] == 0.02 and odo.imu_constraints == []
+    for i in range(1, 9):
+        odo.process_scan(scans[i], i * mg.DT, imu_yaw_increment=yaw[i])
+    # scans 1..5 fill submap 0 (windows of 1, 2, 3, 3, 3 states), scan 5 rolls over, scans 6..8 are the new submap's first windows
+    assert odo.n_finished_submaps == 1 and len(odo.trajectory) == 4 and len(odo.imu_constraints) == 3
+    assert [c is None for c in Spy.calls] == [True, True, True, False, False, True, True, True]
+    assert Spy.calls[3] == [yaw[1], yaw[2], yaw[3]] and Spy.calls[4] == [yaw[2], yaw[3], yaw[4]]   # sic: one step older than the states
+    assert odo.trajectory[0]["imu_bias"] == odo.last_state["imu_bias"] != 0.02                      # estimated, then inherited
+    # without use_imu nothing is passed down, whatever the caller feeds
+    Spy.calls = []
+    off = odometry.Odometry(Spy(), mp, R.window_params(use_imu=0), small)
+    for i in range(6):
+        off.process_scan(scans[i], i * mg.DT, imu_yaw_increment=yaw[i])
+    assert all(c is None for c in Spy.calls)
+
+
 @pytest.mark.gpu
 def test_hip_path_reproduces_odometry_golden(built):
     """the HIP fixed-lag path against the committed drive (window solve, keyframe merges, one submap roll-over) --

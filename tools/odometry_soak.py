@@ -1,5 +1,5 @@
 """Longer GPU-vs-oracle drives through the LocalFuser::processScan call pattern (outside the test suite).
-Usage: odometry_soak.py [n_drives] [n_scans]"""
+Usage: odometry_soak.py [n_drives] [n_scans]   (SOAK_LAGS / SOAK_LONG_LAGS / SOAK_PARAMS / SOAK_IMU = 1 widen the draw)"""
 import os
 import sys
 
@@ -24,9 +24,15 @@ for d in (range(n_drives) if os.environ.get('SOAK_DRIVE') is None else [int(os.e
     if os.environ.get("SOAK_LAGS") == "1":   # lags beyond the shipped 3: the general window kernel (window_gen.hip)
         small["smoothing_steps"] = int(rng.choice([3, 4, 5, 6, 7] if os.environ.get("SOAK_LONG_LAGS") != "1" else [8, 9, 10, 11, 12]))   # (8..12: window_gen_big.hip, round 4)
     param = R.PARAM_MANIFOLD if os.environ.get("SOAK_PARAMS") != "1" else int(rng.choice([R.PARAM_MANIFOLD, R.PARAM_VECTOR, R.PARAM_ANALYTIC]))
-    # (the harness feeds no gyro increments, so the IMU factor stays off: with use_imu = 1 and all-zero measurements the
-    #  problem contradicts itself, costs are ~1e5 and last-bit differences amplify by 1e4 per scan -- chaos, not parity)
-    use_imu, const_vel = 0, int(rng.random() < 0.6)
+    # SOAK_IMU=1 (round 6: the harness feeds heading increments): gyro increments = the truth's heading steps + noise + a bias,
+    # IMU factors on, a non-zero initial bias; without increments the factor stays off (all-zero measurements contradict the
+    # drive, costs are ~1e5 and last-bit differences amplify by 1e4 per scan -- chaos, not parity)
+    soak_imu = os.environ.get("SOAK_IMU") == "1"
+    use_imu, const_vel = (1 if soak_imu else 0), int(rng.random() < 0.6)
+    heading = np.unwrap(np.asarray(traj)[:, 2])
+    yaw = (np.concatenate([[0.0], np.diff(heading)]) + rng.normal(0.0, 2e-3, n_scans) + 0.003) if soak_imu else np.zeros(n_scans)
+    if soak_imu:
+        small["initial_imu_bias"] = float(rng.choice([0.0, 0.01]))
     mp = R.default_matcher_params(parameterization=param, gnc_steps=3)
     wp = R.window_params(use_imu=use_imu, const_vel=const_vel)
     gpu = odometry.Odometry(odometry.HipBackend(ctx, R.indoor_map_params(), R.indoor_cluster_params()), mp, wp, small)
@@ -37,9 +43,9 @@ for d in (range(n_drives) if os.environ.get('SOAK_DRIVE') is None else [int(os.e
     cpu1 = odometry.Odometry(OracleBackend(), mp, wp1, small)
     worst_t = worst_r = worst_self = 0.0
     for i in range(n_scans):
-        pg = gpu.process_scan(scans[i], i * 0.25)
-        pc = cpu.process_scan(scans[i], i * 0.25)
-        p1 = cpu1.process_scan(scans[i], i * 0.25)
+        pg = gpu.process_scan(scans[i], i * 0.25, imu_yaw_increment=yaw[i])
+        pc = cpu.process_scan(scans[i], i * 0.25, imu_yaw_increment=yaw[i])
+        p1 = cpu1.process_scan(scans[i], i * 0.25, imu_yaw_increment=yaw[i])
         worst_self = max(worst_self, np.abs(p1[2:] - pc[2:]).max())
         dt_ = np.abs(pg[2:] - pc[2:]).max()
         if os.environ.get("SOAK_VERBOSE") == "1" and dt_ > 10 * max(worst_t, 1e-9):
