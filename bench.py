@@ -1119,6 +1119,30 @@ def polar_filter(ctx, n_scans):
         e[1].record(st)
         torch.cuda.synchronize()
         t_bb = e[0].elapsed_time(e[1]) / 20 * 1e-3
+        # the same 20 launches dealt to TWO contexts / streams in turn (a caller replaying a bag keeps two batches in flight): the
+        # emission of one launch -- a 5.6 us dependent tail on 16 workgroups -- and its fill / drain overlap the next launch's rows
+        t_2s = None
+        try:
+            side = torch.cuda.Stream(device=dev)
+            ctx2 = R.Context(ctx.device, side.cuda_stream)
+            out2, counts2, status2 = torch.zeros_like(out), torch.zeros_like(counts), torch.zeros_like(status)
+            host.filter_scan_batch(ctx2, raws[1], fp, out2, counts2, status2)
+            torch.cuda.synchronize()
+            e[0].record(st)
+            side.wait_event(e[0])
+            for i in range(20):
+                if i % 2 == 0:
+                    host.filter_scan_batch(ctx, raws[i % 4], fp, out, counts, status)
+                else:
+                    host.filter_scan_batch(ctx2, raws[i % 4], fp, out2, counts2, status2)
+            st.wait_stream(side)
+            e[1].record(st)
+            torch.cuda.synchronize()
+            t_2s = e[0].elapsed_time(e[1]) / 20 * 1e-3
+            two_ok = bool((status2 == 0).all().item()) and bool((counts2 == counts).all().item())   # raws[3] last on both: same scans, same counts
+            del out2, ctx2
+        except Exception as ex:  # noqa: BLE001 -- a side measurement
+            t_2s, two_ok = None, "%s" % ex
         del raws
     # the same stage with 64 scans per launch (1.23 GB of input: nothing of it is still in the Infinity Cache when it is read):
     # the fill and drain of a launch and the emission are paid once per 64 scans instead of once per 16
@@ -1183,6 +1207,10 @@ def polar_filter(ctx, n_scans):
         roof["long_launch"] = long_launch
     if t_bb:
         roof["back_to_back"] = {"ms": t_bb * 1e3, "achieved": nbytes / t_bb / 1e9, "frac": nbytes / t_bb / 1e9 / HBM_PEAK_GBS, "launches": 20, "distinct_inputs": 4}
+        if t_2s:
+            roof["two_streams"] = {"ms": t_2s * 1e3, "achieved": nbytes / t_2s / 1e9, "frac": nbytes / t_2s / 1e9 / HBM_PEAK_GBS, "launches": 20, "distinct_inputs": 4,
+                                   "streams": 2, "same_counts": two_ok,
+                                   "note": "the back_to_back launches dealt to two contexts in turn: one launch's emission and drain run beside the next one's rows"}
     # counter rows of the two kernels at THIS launch size (a workgroup of 256 threads per row; 512 threads per scan)
     fr, fe = find_row("k_filter_rows<true,true>", n_scans * 400 * 256), find_row("k_filter_emit<true>", n_scans * 512)
     fr1, fe1 = find_row("k_filter_rows<true,true>", 400 * 256), find_row("k_filter_emit<true>", 512)

@@ -541,7 +541,11 @@ class Map {
   // read access for the C ABI (registration, copies); writes through it are invisible to the maps that share the storage
   randt_maps* handle() const { return s_ ? s_->m : nullptr; }
   // write access: detaches from the copies first
-  randt_maps* mutable_handle() { return writable() ? s_->m : nullptr; }
+  randt_maps* mutable_handle() {
+    if (!writable()) return nullptr;
+    s_->known_nonempty = false;  // whatever is written through the handle may replace the content: isEmpty() asks again
+    return s_->m;
+  }
   // identity and write counter of the storage behind this map: equal pairs = equal device content (Matcher's staging cache)
   std::uint64_t storage_id() const { return s_ ? s_->id : 0; }
   std::uint64_t storage_version() const { return s_ ? s_->version : 0; }

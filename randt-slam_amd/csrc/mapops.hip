@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void k_maps_transform(MapView m, int first, in
   const int map = first + blockIdx.y;
   float aff[4];
   pose_to_affine_f(pose4 + 4 * blockIdx.y, aff);
-  const int n = m.counts[map];
+  const int n = min(m.counts[map], m.cap);  // (caller-provided storage may hold anything: never walk past the capacity)
   randt_cell* cells = m.cells + (size_t)map * m.cap;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     randt_cell c = load_cell(cells + i);
@@ -40,11 +40,11 @@ __global__ __launch_bounds__(256) void k_maps_merge(MapView fixed, int fixed_idx
   pose4 += 4 * (size_t)blockIdx.x * n_moving;
   randt_cell* fcells = fixed.cells + (size_t)fixed_idx * fixed.cap;
   int32_t* fgrid = fixed.grid + (size_t)fixed_idx * fixed.n_slots;
-  int n_cells = fixed.counts[fixed_idx];
+  int n_cells = min(max(fixed.counts[fixed_idx], 0), fixed.cap);
   for (int t = 0; t < n_moving; ++t) {
     const int mmap = moving_first + t;
     const randt_cell* mcells = moving.cells + (size_t)mmap * moving.cap;
-    const int M = moving.counts[mmap];
+    const int M = min(moving.counts[mmap], moving.cap);  // slots[] holds moving.cap entries
     float aff[4];
     pose_to_affine_f(pose4 + 4 * t, aff);
     for (int i = tid; i < M; i += 256) {
