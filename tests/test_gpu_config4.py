@@ -213,8 +213,9 @@ def test_auto_solve_mode_sees_other_contexts_in_flight(cfg4):
         with torch.cuda.stream(sb):
             R.scan_register_batch(cb, pts_b, rig.clu, sub_b, fidx_b, ws_b, mp, pose, res_b)
         placement = lib.randt_debug_last_solve_placement(cb._h)
+        a_busy = not sa.query()              # still busy NOW => it was busy when the library decided (the test's premise, below)
         cb.synchronize()
-        return placement, pose.cpu().numpy().copy(), res_b.cpu().numpy().copy()
+        return placement, pose.cpu().numpy().copy(), res_b.cpu().numpy().copy(), a_busy
 
     def occupy_a(n=6):
         poses = [pose_a0.clone() for _ in range(n)]
@@ -227,8 +228,19 @@ def test_auto_solve_mode_sees_other_contexts_in_flight(cfg4):
     torch.cuda.synchronize()
     alone = run_b()
     assert alone[0] == 8                                                  # nothing else in flight: the split geometry
-    keep = occupy_a()
-    busy = run_b()                                                        # ca's launches are still running (6 x ~0.4 ms)
+    def run_b_beside_a():
+        # ca's launches must still be running when cb enqueues (6 x ~0.4 ms normally does; on a loaded host the few host calls
+        # in between can outlast them, then the premise -- not the library -- failed: more work, once more)
+        for n in (6, 24, 96):
+            keep = occupy_a(n)
+            out = run_b()
+            ca.synchronize()
+            del keep
+            if out[3]:
+                return out
+        pytest.skip("the host could not keep context A busy while context B enqueued")
+
+    busy = run_b_beside_a()
     assert busy[0] == 0, busy[0]
     assert np.array_equal(alone[1], busy[1]) and np.array_equal(alone[2], busy[2])   # a placement, not a different answer
     ca.synchronize()                                                      # the library's own synchronisation resets ca's stamp
