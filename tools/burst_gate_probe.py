@@ -59,9 +59,15 @@ def main():
         for st in streams:
             st.wait_event(e0)
         t0 = time.perf_counter()
+        tail = int(os.environ.get("PROBE_TAIL_LATENCY", "0"))   # the last `tail` steps of the burst declare the latency placement
         for s in range(K):
+            if tail and s >= K - tail:
+                ctxs[s % n_streams].set_solve_mode(R._capi.SOLVE_LATENCY)
             batch.step(s % n_streams, streams[s % n_streams], poses[s])
         t_enq = time.perf_counter() - t0
+        if tail:
+            for c in ctxs:
+                c.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
         for st in streams[1:]:
             streams[0].wait_stream(st)
         e1.record(streams[0])
