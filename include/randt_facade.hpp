@@ -671,10 +671,19 @@ class HierarchicalMap {
   const Map& getMap() const { return ndt_map_; }
   Map& getMap() { return ndt_map_; }
   void clear() { ndt_map_.clear(); }
-  void transformMap(const SE2d& trans) { ndt_map_.transformMapWithPointCloud(trans); }
+  void transformMap(const SE2d& trans) { ndt_map_.transformMap(trans); }                            // ndt_hierarchical_map.cpp:74-76
+  void transformMapWithPointCloud(const SE2d& trans) { ndt_map_.transformMapWithPointCloud(trans); }  // :78-80
+  // void mergeMapCell(const HierarchicalMap& m_map) (:68-72): the NDT layer's Map::mergeMapCell
+  void mergeMapCell(const HierarchicalMap& m_map) { ndt_map_.mergeMapCell(m_map.ndt_map_); }
+  bool isEmpty() const { return ndt_map_.isEmpty(); }                                               // ndt_hierarchical_map.h:85-87
+  // void transformMapToOrigin(const Sophus::SE2d& new_origin) (:82-85) / getOrigin (h:91-93): the submap's origin in the global
+  // frame -- bookkeeping for the OGM layer (LocalFuser::updateSubmaps, local_fuser.cpp:72,78); the cells do not move
+  void transformMapToOrigin(const SE2d& new_origin) { origin_in_global_frame_ = new_origin; }
+  const SE2d& getOrigin() const { return origin_in_global_frame_; }
 
  private:
   Map ndt_map_;
+  SE2d origin_in_global_frame_;
 };
 
 // Several GPUs behind one caller: the C ABI's multi-GPU group (randt_group_*, csrc/group.hip) for the batched loop
