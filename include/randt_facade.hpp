@@ -658,24 +658,33 @@ class HierarchicalMap {
  public:
   void initialize(std::shared_ptr<Context> ctx, const NDTMapParameters& p, double center_x, double center_y, int cell_capacity = 0) {
     ndt_map_.initialize(std::move(ctx), p, center_x, center_y, cell_capacity);
+    is_empty = true;  // ndt_hierarchical_map.cpp:15
   }
   // void addClusters(const std::vector<pcl::PointCloud<pcl::PointXYZI>>& clusters, ...): cluster c = points
   // [offsets[c], offsets[c+1]) of one n x stride array, inserted in order like the reference's loop
   void addClusters(const float* points, const std::vector<int>& offsets, int stride, int intensity_index) {
     ndt_map_.insertClusters(points, offsets, stride, intensity_index);  // one launch; the same map as one insertCluster per cluster
+    is_empty = false;  // :32 -- whatever the clusters amounted to
   }
   // the whole filtered scan at once (clustering on the device): what RadarPreprocessor::processScan + addClusters amount to
   void addScan(const float* points, int n, int stride, int intensity_index, const RadarPreprocessorParameters& rp) {
     ndt_map_.addScan(points, n, stride, intensity_index, rp);
+    is_empty = false;
   }
   const Map& getMap() const { return ndt_map_; }
   Map& getMap() { return ndt_map_; }
-  void clear() { ndt_map_.clear(); }
+  void clear() { ndt_map_.clear(); }  // (:7-10: the flag is NOT touched; LocalFuser::initializeNewSubmap re-initialises right behind it)
   void transformMap(const SE2d& trans) { ndt_map_.transformMap(trans); }                            // ndt_hierarchical_map.cpp:74-76
   void transformMapWithPointCloud(const SE2d& trans) { ndt_map_.transformMapWithPointCloud(trans); }  // :78-80
   // void mergeMapCell(const HierarchicalMap& m_map) (:68-72): the NDT layer's Map::mergeMapCell
-  void mergeMapCell(const HierarchicalMap& m_map) { ndt_map_.mergeMapCell(m_map.ndt_map_); }
-  bool isEmpty() const { return ndt_map_.isEmpty(); }                                               // ndt_hierarchical_map.h:85-87
+  void mergeMapCell(const HierarchicalMap& m_map) {
+    ndt_map_.mergeMapCell(m_map.ndt_map_);
+    is_empty = false;  // :71 -- also when the merged map held no cell
+  }
+  // inline bool isEmpty() const { return is_empty; } (ndt_hierarchical_map.h:85-87): a FLAG -- true from initialize() until the
+  // first addClusters / mergeMapCell, whatever those put into the map -- not Map::isEmpty()'s cell count (ndt_map.h:144-146).
+  // LocalFuser::processScan's "first scan of the submap" test reads this one (local_fuser.cpp:108).
+  bool isEmpty() const { return is_empty; }
   // void transformMapToOrigin(const Sophus::SE2d& new_origin) (:82-85) / getOrigin (h:91-93): the submap's origin in the global
   // frame -- bookkeeping for the OGM layer (LocalFuser::updateSubmaps, local_fuser.cpp:72,78); the cells do not move
   void transformMapToOrigin(const SE2d& new_origin) { origin_in_global_frame_ = new_origin; }
@@ -684,6 +693,7 @@ class HierarchicalMap {
  private:
   Map ndt_map_;
   SE2d origin_in_global_frame_;
+  bool is_empty = true;
 };
 
 // Several GPUs behind one caller: the C ABI's multi-GPU group (randt_group_*, csrc/group.hip) for the batched loop

@@ -83,6 +83,7 @@ class LocalFuser {
     n_finished_submaps_ = 0;                                                                      // :37
     _preprocessor.initialize(ctx_, preprocessor_parameters_, parameters.filter_parameters);
     _current_submap.initialize(ctx_, map_parameters_, 0.0, 0.0);
+    current_submap_is_empty_ = true;   // HierarchicalMap::initialize (ndt_hierarchical_map.cpp:15)
     if (parameters.use_scan_context_as_loop_closure) {
       slam_ = true;
       sc_manager_.initialize(ctx_, parameters.scan_context_parameters);
@@ -158,6 +159,7 @@ class LocalFuser {
     current_transform_ = SE2d();
     current_global_transform_ = initial_transform;
     _current_submap.clear();
+    current_submap_is_empty_ = true;   // :55 _current_submap.initialize(...) sets HierarchicalMap::is_empty
     _trajectory.clear();
     ++n_finished_submaps_;
   }
@@ -238,7 +240,9 @@ class LocalFuser {
 
  private:
   void process(const Map& scan_ndt, double stamp) {
-    if (!_current_submap.isEmpty()) {  // :123
+    // :108 `!_current_submap.isEmpty()` is HierarchicalMap's FLAG (ndt_hierarchical_map.h:85-87): false from the first mergeMapCell
+    // on, whatever was merged -- a submap whose first scan produced no cell still counts as started
+    if (!current_submap_is_empty_) {
       ndt_matcher_.predictTransform(yaw_, stamp, _trajectory);  // :125
       // every copy the reference makes is made here (Maps by value, local_fuser.cpp:128-136)
       Map fmap = _current_submap;                              // :128  Map fmap = _current_submap.getMap();
@@ -271,6 +275,7 @@ class LocalFuser {
         _next_maps_to_insert.front().transformMap(smoothed);   // :177
         _last_merged_map = _next_maps_to_insert.front();       // :178
         _current_submap.mergeMapCell(_next_maps_to_insert.front());  // :190
+        current_submap_is_empty_ = false;
         _next_maps_to_insert.pop_front();                      // :223
       }
     } else {
@@ -296,6 +301,7 @@ class LocalFuser {
       Map first = scan_ndt;
       first.transformMap(current_transform_);  // :281
       _current_submap.mergeMapCell(first);     // :293
+      current_submap_is_empty_ = false;        // ndt_hierarchical_map.cpp:71
     }
   }
 
@@ -352,6 +358,7 @@ class LocalFuser {
   std::vector<State> _trajectory;
   State _last_state;
   SE2d current_transform_, current_global_transform_;
+  bool current_submap_is_empty_ = true;                // HierarchicalMap::is_empty of _current_submap
   int submap_size_poses_ = 135, submap_overlap_ = 20, insertion_step_ = 4, n_finished_submaps_ = 0;
   double last_imu_bias_ = 0.0;
 };

@@ -166,6 +166,7 @@ class Odometry:
         self.fix_submap_handover = bool(p.get("fix_submap_handover", False))   # False = the reference's behaviour
         self.vector = int(getattr(matcher_params, "parameterization", 0)) in (2, 3)   # VECTOR / ANALYTIC: (pos, rot) blocks (optimize_on_manifold: false or the analytic flag)
         self.current_submap = backend.new_submap()
+        self.current_submap_is_empty = True                           # HierarchicalMap::is_empty (ndt_hierarchical_map.h:85-87): a flag, not a cell count
         self.last_submap_transformed = None
         self.trajectory = []                                          # list of STATE_DTYPE scalars
         self.map_window = []                                          # scan handles of the newest states
@@ -216,6 +217,7 @@ class Odometry:
         if not self._on_submap_finished(self.current_submap):          # submaps_.insert(...) (:43) keeps it alive
             b.release_submap(self.current_submap)
         self.current_submap = b.new_submap()
+        self.current_submap_is_empty = True                            # :55 initialize()
         self.trajectory = []
         self.n_finished_submaps += 1
 
@@ -245,7 +247,9 @@ class Odometry:
     # LocalFuser::processScan (local_fuser.cpp:99-300), data path only
     def _process(self, scan, stamp):
         b = self.b
-        if b.submap_cells(self.current_submap) > 0:
+        # :108 `!_current_submap.isEmpty()`: HierarchicalMap's flag -- false from the first mergeMapCell on, even if that scan
+        # produced no cell (ndt_hierarchical_map.cpp:68-72) -- not Map::isEmpty()'s cell count
+        if not self.current_submap_is_empty:
             self.trajectory.append(b.predict(self.trajectory[-1], stamp, self.vector))    # :125 (predict / predictSE2 by optimize_on_manifold)
             self.imu_constraints.append(self._yaw)                                        # ndt_matcher.cpp:58 (inside predictTransform)
             self.map_window.append(scan)                                                  # :130
@@ -298,6 +302,7 @@ class Odometry:
             self.trajectory.append(st)
             self._on_first_scan(scan, self._cur_points)                                   # :247-279 root node of the submap
             b.merge(self.current_submap, scan, self.current_transform)                    # :281,293
+            self.current_submap_is_empty = False
 
     def process_scan(self, points, stamp, polar_filter=None, imu_yaw_increment=0.0):
         """NDTSlam::radarCb (ndt_slam.cpp:211-223): process, roll the submap over when complete.
@@ -403,11 +408,8 @@ class ReplicaOdometry:
         return len(self.trajectory) >= self.submap_size_poses
 
     def _submap_nonempty(self):
-        if not self.submap_known_nonempty:
-            n = self.subs.counts(self.current_submap * self.R, self.R)
-            if (n > 0).any() and not (n > 0).all():
-                raise host.RandtError(3, "ReplicaOdometry", "replicas left lock-step: some submaps are empty, some are not")
-            self.submap_known_nonempty = bool((n > 0).all())
+        # HierarchicalMap::isEmpty() is a flag that the first mergeMapCell clears whatever it merged (ndt_hierarchical_map.cpp:68-72,
+        # local_fuser.cpp:108): a function of the scan COUNT, so the replicas cannot leave lock-step over it and nothing is read back
         return self.submap_known_nonempty
 
     def initialize_new_submap(self, initial_transform):
@@ -475,6 +477,7 @@ class ReplicaOdometry:
             st["stamp"] = stamp
             self.trajectory.append(st)
             self.subs.merge_batch(self.current_submap * R, R, self.scans, scan * R, self.current_transform)
+            self.submap_known_nonempty = True
 
     def process_scans(self, points, stamp):
         """points: (R, n_points, stride) float32 device tensor, scan r for replica r.  Returns the (R, 4) global poses."""
