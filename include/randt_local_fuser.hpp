@@ -134,6 +134,66 @@ class LocalFuser {
     return added;
   }
 
+  // NOT in the reference (its loop registers the candidates one by one): the same search with the registrations of ALL pending
+  // queries as ONE batch, sharded over the GPUs of `group` -- north_star's multi-GPU unit ("independent scan-to-submap
+  // registrations ... loop-closure candidates shard across the GPUs"; Matcher::estimateLoopConstraintBatch: staging, broadcast of
+  // the candidate submaps, contiguous shards, gather).  The candidates of different queries do not depend on each other (an
+  // accepted edge never feeds a later registration), and the batched registrations are bit-identical to the single calls, so the
+  // graph comes out exactly as from detectLoopClosures() called at the same moments.  Pays when several queries are pending --
+  // a search timer slower than the keyframe rate (ndt_slam.cpp:363-365), offline replays.
+  int detectLoopClosuresBatched(DeviceGroup& group, int* n_candidates = nullptr) {
+    struct Candidate { int q, lid, sub_i; };
+    std::vector<Candidate> cand;
+    std::vector<SE2d> trans;
+    while (!_next_maps_to_search_loop.empty()) {
+      const int q = _next_maps_to_search_loop.front();
+      _next_maps_to_search_loop.pop_front();
+      const std::pair<int, float> det = sc_manager_.detectLoopClosureID(q);   // :323
+      const int lid = det.first;
+      if (lid == -1 || submap_idzs_.at(q) == submap_idzs_.at(lid)) continue;
+      const int sub_i = submap_idzs_.at(lid);
+      if (!submaps_.count(sub_i)) continue;
+      const SE2d root = nodes_.at(root_nodes_.at(sub_i)).pose;
+      cand.push_back({q, lid, sub_i});
+      trans.push_back(se2_mul(se2_mul(se2_inv(root), nodes_.at(lid).pose), SE2d(-static_cast<double>(det.second), 0.0, 0.0)));   // :333
+    }
+    if (n_candidates) *n_candidates = static_cast<int>(cand.size());
+    if (cand.empty()) return 0;
+    std::vector<const Map*> fixed, moving;
+    std::vector<int> fixed_of_pair;
+    std::map<int, int> slot_of_submap;
+    for (const Candidate& c : cand) {
+      if (!slot_of_submap.count(c.sub_i)) {
+        slot_of_submap[c.sub_i] = static_cast<int>(fixed.size());
+        fixed.push_back(&submaps_.at(c.sub_i));
+      }
+      fixed_of_pair.push_back(slot_of_submap.at(c.sub_i));
+      moving.push_back(&scans_.at(c.q));
+    }
+    ndt_matcher_.estimateLoopConstraintBatch(group, trans, fixed, fixed_of_pair, moving, parameters_.loop_closure_gnc_steps,
+                                             parameters_.use_intensity_in_loop_closure, parameters_.loop_closure_scale);   // :335, all at once
+    int added = 0;
+    for (size_t p = 0; p < cand.size(); ++p) {   // the gate and the edges in query order, like the sequential loop
+      const Candidate& c = cand[p];
+      Map m_loop_map = scans_.at(c.q);
+      m_loop_map.transformMap(trans[p]);                                                                  // :338
+      const double cs = submaps_.at(c.sub_i).calculateCSDivergence(m_loop_map);                           // :339
+      const bool ok = cs < parameters_.loop_closure_max_cs_divergence;
+      loop_log_.push_back({c.q, c.lid, cs, ok});
+      if (ok) {
+        Constraint e;
+        e.id_begin = root_nodes_.at(c.sub_i);
+        e.id_end = c.q;
+        e.trans = trans[p];
+        const double w = parameters_.loop_closure_weight;
+        e.sqrt_information = {w, 0, 0, 0, w, 0, 0, 0, w};
+        edges_.push_back(e);
+        ++added;
+      }
+    }
+    return added;
+  }
+
   // NDTSlam::optimizePoseGraph (ndt_slam.cpp:351-361) + the pose part of LocalFuser::updateSubmaps (local_fuser.cpp:65-88)
   void optimizePoseGraph() {
     if (nodes_.empty() || edges_.empty() || submap_idzs_.back() <= 0) return;

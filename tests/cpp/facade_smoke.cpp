@@ -355,6 +355,24 @@ int main() {
     hm.addClusters(both.data(), {0, 24, 36}, 4, 3);
     const auto hc = hm.getMap().getCells();
     cell_ok = cell_ok && hc.size() == 2 && hc[0].getMean() == c1.getMean() && hc[1].getIntensityCov() == c2.getIntensityCov();
+    // HierarchicalMap::isEmpty() is the reference's FLAG (ndt_hierarchical_map.h:85-87): true from initialize() until the first
+    // addClusters / mergeMapCell, whatever they held -- not the cell count; clear() leaves it alone; transformMapToOrigin / getOrigin
+    // only keep the submap's origin (the cells do not move)
+    HierarchicalMap fresh, target;
+    fresh.initialize(ctx, mp, 0.0, 0.0, 16);
+    target.initialize(ctx, mp, 0.0, 0.0, 16);
+    const bool flag0 = fresh.isEmpty() && target.isEmpty() && fresh.getMap().isEmpty();
+    target.mergeMapCell(fresh);                                       // merges NOTHING: no cell, yet the submap counts as started
+    const bool flag1 = !target.isEmpty() && target.getMap().isEmpty() && target.getMap().get_n_cells() == 0;
+    target.mergeMapCell(hm);
+    const unsigned merged_cells = target.getMap().get_n_cells();      // (the two clusters may share a 0.5 m slot: then they merge into one cell)
+    const bool flag2 = !target.isEmpty() && merged_cells >= 1 && merged_cells <= 2;
+    target.clear();
+    const bool flag3 = !target.isEmpty() && target.getMap().get_n_cells() == 0;
+    target.transformMapToOrigin(SE2d(0.25, 3.0, -1.0));
+    const bool origin_ok = target.getOrigin().d[2] == 3.0 && target.getOrigin().d[3] == -1.0 && std::fabs(target.getOrigin().angle() - 0.25) < 1e-15;
+    if (!(flag0 && flag1 && flag2 && flag3 && origin_ok)) std::printf("HierarchicalMap flag / origin: %d %d %d %d %d\n", flag0, flag1, flag2, flag3, origin_ok);
+    cell_ok = cell_ok && flag0 && flag1 && flag2 && flag3 && origin_ok;
   }
   // batched loop registration over a group of (virtual) GPUs: bit-identical to the pair-by-pair calls
   bool batch_ok = true;

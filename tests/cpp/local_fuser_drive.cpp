@@ -24,6 +24,11 @@
 //               calculateCSDivergence gate -> loop edge), GlobalFuser::optimizePoseGraph every 40 scans (ndt_slam.cpp:351-361) and
 //               the current submap's origin following its root node (local_fuser.cpp:78-79).  Writes the graph to file F:
 //               "node x y rot" per node, "loop query candidate cs accepted" per checked candidate.
+//   --loop-every N   with --slam: search loop closures every N scans instead of after every scan (a search timer slower than the
+//               keyframe rate, ndt_slam.cpp:363-365): several queries are then pending per search
+//   --loop-group G   with --slam: the pending queries' registrations as ONE batch over a DeviceGroup of G members (virtual ranks on
+//               GPU 0 here; the GPUs of a node in deployment) -- LocalFuser::detectLoopClosuresBatched; must give the very graph of
+//               the sequential search at the same --loop-every
 //   --imu F [B] ndt_matcher.use_imu = true (the indoor preset): file F holds one heading increment per scan (what the reference takes
 //               from two IMU orientations, local_fuser.cpp:107-121), B = ndt_matcher.initial_imu_bias; the increments reach the IMU
 //               factors of the fixed-lag window through Matcher::predictTransform, and a submap roll-over drops them
@@ -39,6 +44,7 @@
 #include <deque>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -66,6 +72,7 @@ int main(int argc, char** argv) {
   int size_poses = 135, overlap = 20, n_pos = 0, warm = -1;
   bool xyzi8 = false;
   std::string slam_file, imu_file;
+  int loop_every = 1, loop_group = 0;
   double imu_bias0 = 0.0;
   int polar_az = 0, polar_bins = 0;
   int clusters = 0;  // 1: HierarchicalMap::addClusters (the list in one call), 2: one Map::insertCluster call per cluster
@@ -76,6 +83,8 @@ int main(int argc, char** argv) {
     else if (arg == "--cluster-loop") clusters = 2;
     else if (arg == "--timing" && a + 1 < argc) warm = std::atoi(argv[++a]);
     else if (arg == "--slam" && a + 1 < argc) slam_file = argv[++a];
+    else if (arg == "--loop-every" && a + 1 < argc) loop_every = std::max(1, std::atoi(argv[++a]));
+    else if (arg == "--loop-group" && a + 1 < argc) loop_group = std::atoi(argv[++a]);
     else if (arg == "--imu" && a + 1 < argc) {
       imu_file = argv[++a];
       if (a + 1 < argc && argv[a + 1][0] != '-' ) {
@@ -136,6 +145,15 @@ int main(int argc, char** argv) {
       return 2;
     }
   }
+  std::unique_ptr<DeviceGroup> group;
+  if (loop_group > 0) {
+    group.reset(new DeviceGroup(std::vector<int>(static_cast<size_t>(loop_group), 0)));
+    if (!group->get()) {
+      std::fprintf(stderr, "--loop-group %d: no group (%s)\n", loop_group, randt_group_last_error(nullptr));
+      return 2;
+    }
+  }
+  int n_searches = 0, n_batched_candidates = 0, largest_batch = 0;
   std::FILE* out = std::fopen(argv[2], "w");
   if (!out) return 2;
   randt_pool_stats s0{}, s1{};
@@ -150,7 +168,17 @@ int main(int argc, char** argv) {
     if (polar_az > 0) fuser.processPolarScan(scan, polar_az, polar_bins, stride, ioff, 0.25 * i, imu_yaw[static_cast<size_t>(i)]);
     else fuser.processScan(scan, n_points, stride, ioff, 0.25 * i, clusters, imu_yaw[static_cast<size_t>(i)]);
     if (!slam_file.empty()) {
-      fuser.detectLoopClosures();
+      if (i % loop_every == loop_every - 1) {
+        ++n_searches;
+        if (group) {
+          int nc = 0;
+          fuser.detectLoopClosuresBatched(*group, &nc);
+          n_batched_candidates += nc;
+          largest_batch = std::max(largest_batch, nc);
+        } else {
+          fuser.detectLoopClosures();
+        }
+      }
       if (i % 40 == 39) fuser.optimizePoseGraph();
     }
     const SE2d p = fuser.getTransform();
@@ -178,6 +206,8 @@ int main(int argc, char** argv) {
                 xyzi8 ? "pcl::PointXYZI, 32 B" : "packed x y z I, 16 B", fuser.finishedSubmaps());
   }
   std::fclose(out);
+  if (group) std::printf("batched loop search: %d searches, %d candidates registered in batches (largest %d) over %d group members\n", n_searches,
+                         n_batched_candidates, largest_batch, group->size());
   std::printf("drive of %d scans done: %d submaps finished, first error status %d\n", n_scans, fuser.finishedSubmaps(), first_error());
   return first_error() == RANDT_OK ? 0 : 1;
 }

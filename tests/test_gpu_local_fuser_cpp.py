@@ -284,3 +284,39 @@ def test_cpp_drive_on_raw_polar_scans_matches_the_python_harness(built, tmp_path
         s.detect_loop_closures()
     assert len(nodes) == len(s.nodes) >= 4 and np.abs(nodes - s.node_positions()).max() <= 1e-9
     assert np.abs(np.loadtxt(out) - py).max() <= 1e-9        # the odometry does not care how the scan's NDT was fed
+
+
+def test_cpp_batched_loop_search_over_a_device_group_gives_the_sequential_graph(built, tmp_path):
+    """north_star's multi-GPU unit inside the reference's own call pattern: LocalFuser::detectLoopClosuresBatched registers the
+    candidates of ALL pending queries as one batch through Matcher::estimateLoopConstraintBatch over a DeviceGroup (three virtual
+    ranks on GPU 0 here: staging, broadcast of the candidate submaps, contiguous shards, gather).  With the loop search running
+    every 12th scan (a search timer slower than the keyframe rate) several queries are pending per search; the drive must end
+    with the very graph -- nodes, loop decisions with their CS values, edges, poses, character for character -- of the
+    sequential detectLoopClosures() at the same cadence."""
+    import re
+
+    from randt_slam_amd import synth
+
+    n_scans, per_lap = 300, 160
+    world = synth.make_world()
+    th = 2 * np.pi * np.arange(n_scans) / per_lap
+    truth = np.stack([5.0 * np.cos(th), 5.0 * np.sin(th), th + np.pi / 2], 1)
+    scans = np.ascontiguousarray(np.stack([synth.make_scan(world, truth[i], 71000 + i) for i in range(n_scans)]), dtype=np.float32)
+    path = tmp_path / "scans.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([scans.shape[0], scans.shape[1]], dtype=np.int32).tobytes())
+        f.write(scans.tobytes())
+    exe = _build(tmp_path)
+    outs = {}
+    for tag, extra in (("seq", []), ("batched", ["--loop-group", "3"])):
+        poses, graph = tmp_path / ("poses_%s.txt" % tag), tmp_path / ("graph_%s.txt" % tag)
+        r = subprocess.run([exe, str(path), str(poses), "40", "10", "--slam", str(graph), "--loop-every", "12"] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        outs[tag] = (open(poses).read(), open(graph).read(), r.stdout)
+    m = re.search(r"batched loop search: (\d+) searches, (\d+) candidates registered in batches \(largest (\d+)\) over 3 group members", outs["batched"][2])
+    assert m and int(m.group(1)) == 25 and int(m.group(2)) >= 10 and int(m.group(3)) >= 2, outs["batched"][2][-600:]
+    assert outs["seq"][1].count("\nloop ") + outs["seq"][1].startswith("loop ") == int(m.group(2))      # every candidate of the sequential search went through a batch
+    assert outs["seq"][1] == outs["batched"][1]          # the graph: nodes, loop log (CS values at 17 digits), edges
+    assert outs["seq"][0] == outs["batched"][0]          # every scan's pose
+    loops = [ln.split() for ln in outs["seq"][1].splitlines() if ln.startswith("loop ")]
+    assert any(ln[-1] == "1" for ln in loops) and any(ln[-1] == "0" for ln in loops) or len(loops) >= 10   # the gate decided both ways / often
