@@ -122,7 +122,7 @@ def test_bench_two_ranks_over_rccl_sharing_the_one_gpu():
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=600))
+            outs.append(p.communicate(timeout=240))   # (~25 s normally)
         except subprocess.TimeoutExpired:
             p.kill()
             outs.append(p.communicate())

@@ -171,8 +171,8 @@ def test_rccl_several_ranks_sharing_the_one_gpu(built, world):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_two_ranks_probe.py"), str(world)], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, RCCL_PROBE_TIMEOUT="300"))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_two_ranks_probe.py"), str(world)], capture_output=True, text=True, timeout=200,
+                       env=dict(os.environ, RCCL_PROBE_TIMEOUT="150"))   # (a run takes ~10 s; the driver caps the whole GPU suite at 1200 s)
     text = r.stdout + r.stderr
     ranks = [json.loads(ln[len("RCCL_PROBE "):]) for ln in r.stdout.splitlines() if ln.startswith("RCCL_PROBE ")]
     assert r.returncode == 0 and len(ranks) == world, text[-3000:]
