@@ -154,6 +154,7 @@ int main(int argc, char** argv) {
     }
   }
   int n_searches = 0, n_batched_candidates = 0, largest_batch = 0;
+  double loop_search_s = 0.0;
   std::FILE* out = std::fopen(argv[2], "w");
   if (!out) return 2;
   randt_pool_stats s0{}, s1{};
@@ -170,6 +171,7 @@ int main(int argc, char** argv) {
     if (!slam_file.empty()) {
       if (i % loop_every == loop_every - 1) {
         ++n_searches;
+        const auto ts = std::chrono::steady_clock::now();
         if (group) {
           int nc = 0;
           fuser.detectLoopClosuresBatched(*group, &nc);
@@ -178,6 +180,7 @@ int main(int argc, char** argv) {
         } else {
           fuser.detectLoopClosures();
         }
+        loop_search_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
       }
       if (i % 40 == 39) fuser.optimizePoseGraph();
     }
@@ -206,6 +209,7 @@ int main(int argc, char** argv) {
                 xyzi8 ? "pcl::PointXYZI, 32 B" : "packed x y z I, 16 B", fuser.finishedSubmaps());
   }
   std::fclose(out);
+  if (!slam_file.empty()) std::printf("loop search: %d calls, %.3f ms in total (%s)\n", n_searches, loop_search_s * 1e3, group ? "batched over the group" : "sequential");
   if (group) std::printf("batched loop search: %d searches, %d candidates registered in batches (largest %d) over %d group members\n", n_searches,
                          n_batched_candidates, largest_batch, group->size());
   std::printf("drive of %d scans done: %d submaps finished, first error status %d\n", n_scans, fuser.finishedSubmaps(), first_error());
