@@ -25,7 +25,22 @@ def main():
     Ks = [int(a) for a in sys.argv[1:]] or [20]
     dev = torch.device("cuda", 0)
     n_streams = int(os.environ.get("PROBE_STREAMS", "16"))
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
+    # PROBE_PRIO=first4 / last4 / alt: HIP stream priorities (-1 = high) for some of the streams -- does the queue scheduler's
+    # preference shorten the burst's drain?
+    prio = os.environ.get("PROBE_PRIO", "")
+    def pr(j):
+        if prio == "first4":
+            return -1 if j < 4 else 0
+        if prio == "last4":
+            return -1 if j >= n_streams - 4 else 0
+        if prio == "alt":
+            return -1 if j % 2 == 0 else 0
+        return 0
+    if prio:
+        streams = [torch.cuda.Stream(device=dev, priority=pr(j)) for j in range(n_streams)]
+        torch.cuda.set_stream(streams[0])
+    else:   # bench.py's own set-up
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     ctxs = [R.Context(0, st.cuda_stream) for st in streams]
     for c in ctxs:
         c.set_solve_mode(R._capi.SOLVE_THROUGHPUT)
