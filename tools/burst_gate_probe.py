@@ -10,7 +10,9 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# bench.py's set-up is the default stream + 15 created ones on 16 hardware queues.  PROBE_PRIO creates all sixteen (priorities are a
+# creation-time property) and the default stream keeps a queue of its own: 17 queues, or two streams share one (-27 % at K = 256)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "17" if os.environ.get("PROBE_PRIO") else "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import numpy as np  # noqa: E402
